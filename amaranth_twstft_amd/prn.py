@@ -1,0 +1,108 @@
+"""PRN replica definition (host side).
+
+Mirrors the reference's LFSR semantics so code files written by either side are
+interchangeable:
+
+* Fibonacci LFSR, right shift, feedback bit = parity(state & taps) shifted into the MSB,
+  seed 1, output = state LSB *before* the shift, one byte (0/1) per chip
+  (reference: amaranth_twstft/common.py:15-30 ``unary_xor``/``nextstate``,
+  common.py:59-73 ``write_prn_seq``; C twin tools/mseq_calculator.c:9-18 ``lfsr_next``).
+* Code files are raw bytes 0/1, named ``noiselen<N>_bitlen<B>_taps<T>.bin``
+  (reference: experiments/221207_twoway_codes/codes/).
+
+The device-side generator (``twx_lfsr_chips`` in csrc/) produces the same bytes; this module is
+the host mirror used to write/read code files and by the tests.
+"""
+from __future__ import annotations
+
+import gzip
+import os
+
+import numpy as np
+
+
+def nextstate(current: int, taps: int, bit_len: int) -> int:
+    """One LFSR step (same name and argument meaning as reference common.py:23)."""
+    bit = bin(current & taps).count("1") & 1
+    return (current >> 1) | (bit << (bit_len - 1))
+
+
+def lfsr_chips(bit_len: int, taps: int, noiselen: int, seed: int = 1) -> np.ndarray:
+    """``noiselen`` chips (uint8 0/1) of the LFSR(bit_len, taps) sequence started at ``seed``."""
+    if not (1 <= bit_len <= 32):
+        raise ValueError("bit_len must be in 1..32")
+    if taps <= 0 or taps >> bit_len:
+        raise ValueError("taps must be a non-zero bit_len-bit mask")
+    out = np.empty(noiselen, dtype=np.uint8)
+    # The output stream obeys s[i+B] = XOR_{t in taps} s[i+t]; over GF(2) the same relation holds
+    # with every offset multiplied by 2^m (Frobenius), which lets numpy extend the stream in
+    # blocks of 2^m*(B - t_max) chips once the first 2^m*B chips exist.
+    tap_pos = [t for t in range(bit_len) if (taps >> t) & 1]
+    m = 10
+    head = min(noiselen, (bit_len << m))
+    state = seed
+    msb = bit_len - 1
+    for i in range(head):
+        out[i] = state & 1
+        bit = bin(state & taps).count("1") & 1
+        state = (state >> 1) | (bit << msb)
+    if noiselen > head:
+        step = 1 << m
+        blk = step * (bit_len - tap_pos[-1])
+        big = bit_len * step
+        pos = head
+        while pos < noiselen:
+            n = min(blk, noiselen - pos)
+            base = pos - big
+            acc = out[base + tap_pos[0] * step: base + tap_pos[0] * step + n].copy()
+            for t in tap_pos[1:]:
+                acc ^= out[base + t * step: base + t * step + n]
+            out[pos:pos + n] = acc
+            pos += n
+    return out
+
+
+def lfsr_chips_slow(bit_len: int, taps: int, noiselen: int, seed: int = 1) -> np.ndarray:
+    """Bit-serial form of :func:`lfsr_chips` (kept as the plain statement of the recurrence)."""
+    out = np.empty(noiselen, dtype=np.uint8)
+    state = seed
+    for i in range(noiselen):
+        out[i] = state & 1
+        state = nextstate(state, taps, bit_len)
+    return out
+
+
+def lfsr_period(bit_len: int, taps: int, seed: int = 1) -> int:
+    """Cycle length from ``seed`` (reference: tools/mseq_calculator.c:29-38)."""
+    state = seed
+    n = 0
+    while True:
+        state = nextstate(state, taps, bit_len)
+        n += 1
+        if state == seed or state == 0:
+            return n
+
+
+def write_prn_seq(bitlen: int, noiselen: int, taps_a: int, path: str | None = None) -> str:
+    """Write a BPSK code file (reference: common.py:59-73, BPSK branch)."""
+    if path is None:
+        path = f"prn{taps_a}bpsk{bitlen}bits.bin"
+    lfsr_chips(bitlen, taps_a, noiselen).tofile(path)
+    return path
+
+
+def read_code_file(path: str) -> np.ndarray:
+    """Read a chip file (bytes 0/1; ``.gz`` transparently) → uint8 array.
+
+    Reference readers: ``fread(f,inf,'int8')`` godual_ranging.m:63; ``list(fd.read())``
+    experiments/221219_twoway/processing/godual_ranging.py:71-74.
+    """
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rb") as f:
+        data = f.read()
+    chips = np.frombuffer(data, dtype=np.uint8).copy()
+    if chips.size == 0:
+        raise ValueError(f"empty code file {path}")
+    if chips.max() > 1:
+        raise ValueError(f"{os.path.basename(path)}: chips must be bytes 0/1")
+    return chips

@@ -1,0 +1,371 @@
+"""CPU ORACLE for the TWSTFT correlation hot path — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  The product path (``amaranth_twstft_amd``) never does, and fails loudly when the
+HIP library is missing.
+
+This is a plain numpy (fp64, ``np.fft`` = pocketfft, the same library the reference's numpy
+path uses) restatement of the reference algorithm.  Every function cites the reference lines it
+follows (paths relative to the reference repository root).
+
+Parity pinning (see tests/golden/README.md, tools/make_golden.py):
+  * PRN generation is pinned by the reference's own code files (SHA-256 / prefix fixtures made
+    from experiments/221207_twoway_codes/codes/*.bin.gz, 231001_DLL_PLL/{0,1}.bin,
+    220706_TWSTFT/*.bin) and by ``amaranth_twstft/common.py:nextstate`` imported at
+    fixture-generation time.
+  * ``processing()`` is pinned by outputs of the reference's own numpy code run in the build
+    container on seeded synthetic captures: ``experiments/221219_twoway/processing/
+    godual_ranging.py:processing`` (full-precision return values, fine-frequency step on) and
+    ``experiments/221207_twoway_codes/processing/godual_ranging.py:ranging`` (printed rows).
+  * The reference holds NO test vectors of its own for the correlator, and the
+    Octave-only variants (``processing_claudio``, ``search_df``), the C++-only Hamming window
+    and the 231001_DLL_PLL acquisition/tracking restatements have no runnable twin here:
+    for those functions parity is UNPINNED (hand restatement, cross-checked by identities).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------------
+# PRN replica
+# --------------------------------------------------------------------------------------------
+
+def lfsr_next(lfsr: int, taps: int, bits: int) -> int:
+    """tools/mseq_calculator.c:9-18 ``lfsr_next`` ≡ amaranth_twstft/common.py:23-30 ``nextstate``."""
+    masked = lfsr & taps
+    bit = 0
+    for i in range(bits):
+        bit ^= (masked >> i) & 1
+    return (lfsr >> 1) | (bit << (bits - 1))
+
+
+def lfsr_chips(bitlen: int, taps: int, noiselen: int) -> np.ndarray:
+    """amaranth_twstft/common.py:59-73 ``write_prn_seq`` (BPSK branch): seed 1, byte = state%2."""
+    out = np.empty(noiselen, dtype=np.uint8)
+    a = 1
+    for i in range(noiselen):
+        out[i] = a % 2
+        a = lfsr_next(a, taps, bitlen)
+    return out
+
+
+def make_code(chips: np.ndarray, sps: int = 2) -> np.ndarray:
+    """processing/Octave/godual_ranging.m:63-65: repelems ×2, ``2*code-1`` → ±1 (float64)."""
+    return np.repeat(np.asarray(chips, dtype=np.float64), sps) * 2.0 - 1.0
+
+
+def make_fcode(code: np.ndarray, convention: str = "godual") -> np.ndarray:
+    """Code spectrum.
+
+    ``godual``:  ``fcode=conj(fft(code'))``  processing/Octave/godual_ranging.m:66,
+                 experiments/221219_twoway/processing/godual_ranging.py:78.
+    ``claudio``: ``fcode=fft(code')``  acquisition/claudio_aligned_code_ranging_separate.m:124.
+    ``hamming``: godual × Hamming window over the spectrum index, processing/CPP/main.cpp:717-719
+                 (sigpack ``hamming(N)`` = 0.54-0.46*cos(2*pi*i/(N-1))).  UNPINNED.
+    """
+    f = np.fft.fft(code)
+    if convention == "godual":
+        return np.conj(f)
+    if convention == "claudio":
+        return f
+    if convention == "hamming":
+        n = len(code)
+        w = 0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(n) / (n - 1))
+        return np.conj(f) * w
+    raise ValueError(convention)
+
+
+def freq_axis(fs: float, n: int) -> np.ndarray:
+    """``freq=linspace(-fs/2,fs/2,length(code))`` godual_ranging.m:73 (spacing fs/(n-1), sic)."""
+    return np.linspace(-fs / 2, fs / 2, num=n, dtype=float)
+
+
+def band_godual(freq: np.ndarray, remote: int = 0, OP: int = 0) -> np.ndarray:
+    """Search band ``k`` of godual_ranging.m:83-89 (0-based indices into the fftshifted axis)."""
+    if remote != 1:
+        return np.nonzero((freq < 20000) & (freq > -20000))[0]
+    if OP == 1:
+        return np.nonzero((freq > -120000) & (freq < -80000))[0]
+    return np.nonzero((freq < 120000) & (freq > 80000))[0]
+
+
+def band_numpy(freq: np.ndarray, foffset: float = 0.0, frange: float = 8000.0) -> np.ndarray:
+    """``k`` of experiments/221219_twoway/processing/godual_ranging.py:80-81."""
+    return np.nonzero((freq < 2 * (foffset + frange)) & (freq > 2 * (foffset - frange)))[0]
+
+
+# --------------------------------------------------------------------------------------------
+# capture reader
+# --------------------------------------------------------------------------------------------
+
+def deinterleave(raw: np.ndarray, n_channels: int, channel: int) -> np.ndarray:
+    """int16 ``[I1 Q1 I2 Q2 …]`` → complex128 of one channel.
+
+    godual_ranging.m:76-79 (2 channels), godual_ranging.py:100-102,112-113;
+    single-channel files acquisition/claudio_aligned_code_ranging_separate.m:148-151.
+    """
+    raw = np.asarray(raw).reshape(-1, 2 * n_channels)
+    return raw[:, 2 * channel].astype(np.float64) + 1j * raw[:, 2 * channel + 1].astype(np.float64)
+
+
+# --------------------------------------------------------------------------------------------
+# the per-window kernel
+# --------------------------------------------------------------------------------------------
+
+def coarse_df(d: np.ndarray, k: np.ndarray, freq: np.ndarray):
+    """godual_ranging.m:14-15 / godual_ranging.py:21-23. Returns (0-based shifted index, df)."""
+    d2_fft = np.fft.fftshift(np.abs(np.fft.fft(d * d)))
+    tmp = int(d2_fft[k].argmax() + k[0])
+    return tmp, freq[tmp] / 2
+
+
+def fine_df(y: np.ndarray, fs: float) -> float:
+    """Fine frequency from the phase drift, experiments/221219_twoway/processing/
+    godual_ranging.py:26-27 (Octave twin 221219…/godual_ranging.m:19-21; commented out in
+    processing/Octave/godual_ranging.m:19-24).  Needs len(y) >= fs/3."""
+    a = np.polyfit(np.arange(1, fs // 3, 10) / fs,
+                   np.convolve(np.angle(y[0:int(fs // 3):10]), np.ones(100) / 100)[49:-50], 1)
+    return a[0] / 2 / np.pi
+
+
+def xcorr_interp(ffty: np.ndarray, fcode: np.ndarray, Nint: int) -> np.ndarray:
+    """godual_ranging.m:25-28 in the direct-scatter form of godual_ranging.py:31-37:
+    spectrum product, zero-pad to (2*Nint+1)*N around Nyquist, inverse FFT."""
+    n = len(ffty)
+    multmp = ffty * fcode
+    if Nint == 0:
+        return np.fft.ifft(multmp)
+    interpolation = np.zeros((2 * Nint + 1) * n, dtype=complex)
+    interpolation[:n // 2] = multmp[:n // 2]
+    interpolation[-(n // 2):] = multmp[-(n // 2):]
+    return np.fft.ifft(interpolation)
+
+
+def peak_refine(prnmap: np.ndarray, wrap: bool = True):
+    """godual_ranging.m:29-33. ``indice`` is 0-based here (Octave's is this +1).
+
+    The reference indexes ``indice-1`` / ``indice+1`` without bounds handling (numpy wraps -1,
+    raises at the end; Octave raises at both ends); ``wrap=True`` treats the map as circular,
+    which is what acquisition/claudio_aligned_code_ranging_separate.m:71-80 does explicitly.
+    """
+    m = len(prnmap)
+    indice = int(np.abs(prnmap).argmax())
+    xval = prnmap[indice]
+    xvalm1 = prnmap[(indice - 1) % m] if wrap else prnmap[indice - 1]
+    xvalp1 = prnmap[(indice + 1) % m] if wrap else prnmap[indice + 1]
+    correction = (abs(xvalm1) - abs(xvalp1)) / (abs(xvalm1) + abs(xvalp1) - 2 * abs(xval)) / 2
+    return indice, correction, xval, xvalm1, xvalp1
+
+
+def snr_wipeoff(ffty: np.ndarray, code: np.ndarray, indice: int, Nint: int,
+                rot: int = -1, ddof: int = 0):
+    """godual_ranging.m:38-48 / godual_ranging.py:55-64.
+
+    ``rot`` is the rotate offset relative to the 0-based peak index: -1 in godual_ranging.m:43
+    (1-based ``indice-1``), godual_ranging.py(221219):59 and processing/CPP/main.cpp:332; the
+    221207 numpy file uses -2 (ch1, :104) and 0 (ch2, :122).
+    ``ddof``: numpy ``np.var`` is population (0); Octave ``var`` is N-1 (1).
+    Returns (SNRr, SNRi, puissancecode, puissancenoise).
+    """
+    n = len(ffty)
+    r = 2 * Nint + 1
+    yint = np.zeros(r * n, dtype=complex)
+    yint[:n // 2] = ffty[:n // 2]
+    yint[-(n // 2):] = ffty[-(n // 2):]
+    yinti = np.fft.ifft(yint)
+    codetmp = np.repeat(code, r)
+    s = (indice + rot) % (r * n)
+    yincode = np.concatenate((yinti[s:], yinti[:s])) * codetmp
+    var = np.var(yincode, ddof=ddof)
+    mr = np.mean(np.real(yincode))
+    mi = np.mean(np.imag(yincode))
+    return mr ** 2 / var, mi ** 2 / var, mr ** 2 + mi ** 2, var
+
+
+def processing(d, k, freq, temps, fcode, code, Nint=1, fs=5e6, fine_freq=False,
+               snr_rot=-1, ddof=0, df=None):
+    """``processing(d,k)`` of processing/Octave/godual_ranging.m:12-49
+    (≡ experiments/221219_twoway/processing/godual_ranging.py:18-65 when ``fine_freq=True``).
+
+    ``d`` is the mean-removed complex window.  If ``df`` is given the coarse estimate is skipped
+    (code-phase-only variant, cf. ``processing(d,df)`` of claudio_aligned_code_ranging_separate.m:49).
+    Returns a dict with 0-based ``indice``.
+    """
+    if df is None:
+        _, dftmp = coarse_df(d, k, freq)
+    else:
+        dftmp = float(df)
+    lo = np.exp(-1j * 2 * np.pi * dftmp * temps)
+    y = d * lo
+    if fine_freq:
+        dfleftover = fine_df(y, fs)
+        lo = np.exp(-1j * 2 * np.pi * dfleftover * temps)
+        y = y * lo
+        dftmp += dfleftover
+    ffttmp = np.fft.fft(y)
+    prnmap = xcorr_interp(ffttmp, fcode, Nint)
+    indice, correction, xval, xvalm1, xvalp1 = peak_refine(prnmap)
+    SNRr, SNRi, pcode, pnoise = snr_wipeoff(ffttmp, code, indice, Nint, rot=snr_rot, ddof=ddof)
+    return dict(indice=indice, correction=correction, xval=xval, xvalm1=xvalm1, xvalp1=xvalp1,
+                df=dftmp, SNRr=SNRr, SNRi=SNRi, puissance=np.var(y, ddof=ddof),
+                puissancecode=pcode, puissancenoise=pnoise)
+
+
+def ranging(raw, chips, fs=5e6, sps=2, Nint=1, n_channels=2, channels=(0, 1), band="godual",
+            remote=0, OP=0, foffset=0.0, frange=8000.0, **kw):
+    """Window loop of godual_ranging.m:59-102 over an in-memory int16 capture.
+
+    ``raw``: int16 array of interleaved samples.  A short final window is dropped
+    (godual_ranging.m:81,102).  Returns {channel: [result dict per window]}.
+    """
+    code = make_code(chips, sps)
+    fcode = make_fcode(code, "godual")
+    n = len(code)
+    freq = freq_axis(fs, n)
+    k = band_godual(freq, remote, OP) if band == "godual" else band_numpy(freq, foffset, frange)
+    temps = np.arange(n) / fs
+    raw = np.asarray(raw).reshape(-1, 2 * n_channels)
+    nwin = raw.shape[0] // n
+    out = {c: [] for c in channels}
+    for p in range(nwin):
+        blk = raw[p * n:(p + 1) * n]
+        for c in channels:
+            d = deinterleave(blk, n_channels, c)
+            d = d - np.mean(d)
+            out[c].append(processing(d, k, freq, temps, fcode, code, Nint=Nint, fs=fs, **kw))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# "claudio" production variant (reversed-conjugate convention) — UNPINNED (Octave only)
+# --------------------------------------------------------------------------------------------
+
+def processing_claudio(d, df, temps, fcode_claudio, code, Nint=1, ddof=1):
+    """acquisition/claudio_aligned_code_ranging_separate.m:49-102 for one code per call
+    (len(d) == len(code)); ``fcode_claudio = fft(code)`` (:124).  0-based ``indice``.
+    """
+    n = len(d)
+    r = 2 * Nint + 1
+    lo = np.exp(-1j * 2 * np.pi * df * temps)
+    y = d * lo
+    ffty = np.fft.fft(y)
+    multmp = fcode_claudio * np.conj(ffty)                       # :59
+    pad = np.zeros(r * n, dtype=complex)
+    pad[:n // 2] = multmp[:n // 2]
+    pad[-(n // 2):] = multmp[-(n // 2):]
+    prnmap = np.fft.ifft(pad)                                     # :60-61
+    yint = np.zeros(r * n, dtype=complex)
+    yint[:n // 2] = ffty[:n // 2]
+    yint[-(n // 2):] = ffty[-(n // 2):]
+    yint = np.fft.ifft(yint)                                      # :62-65
+    codetmp = np.repeat(code, r)
+    indice = int(np.abs(prnmap).argmax())                         # :69
+    xval = prnmap[indice]
+    xvalm1 = prnmap[indice - 1] if indice >= 1 else prnmap[-1]    # :71-75
+    xvalp1 = prnmap[indice + 1] if indice + 2 < r * n else prnmap[0]  # :76-80 (1-based '<')
+    correction = (abs(xvalm1) - abs(xvalp1)) / (abs(xvalm1) + abs(xvalp1) - 2 * abs(xval)) / 2
+    ind1 = indice + 1                                             # Octave 1-based
+    if ind1 > 2:                                                  # :90-94
+        rot = np.concatenate((codetmp[ind1 - 2:], codetmp[:ind1 - 2]))
+    else:
+        rot = codetmp
+    yincode = rot * yint
+    var = np.var(yincode, ddof=ddof)
+    mr, mi = np.mean(yincode.real), np.mean(yincode.imag)
+    return dict(indice=indice, correction=correction, xval=xval, xvalm1=xvalm1, xvalp1=xvalp1,
+                df=df, SNRr=mr ** 2 / var, SNRi=mi ** 2 / var, puissance=np.var(y, ddof=ddof),
+                puissancecode=mr ** 2 + mi ** 2, puissancenoise=var)
+
+
+def search_df(d, k, df_threshold, freq, temps, fcode_claudio):
+    """acquisition/claudio_aligned_code_ranging_separate.m:27-47. ``k``/result 0-based; 0 → -1."""
+    n = len(fcode_claudio)
+    kbon = -1
+    d2 = np.fft.fftshift(np.abs(np.fft.fft(d ** 2)))
+    ktmp = np.nonzero(d2[k] > np.median(d2[k]) * df_threshold)[0] + k[0]
+    if 0 < len(ktmp) < 100:
+        for kk in ktmp:
+            dftmp = freq[kk] / 2
+            lo = np.exp(-1j * 2 * np.pi * dftmp * temps)
+            y = d[:n] * lo
+            prnmap = np.abs(np.fft.ifft(fcode_claudio * np.conj(np.fft.fft(y))))
+            b = int(prnmap.argmax())
+            prnsig = prnmap[b]
+            prnmap[max(b - 5, 0):b + 6] = 0
+            prnvar = np.var(prnmap, ddof=1)
+            if prnsig ** 2 / prnvar > 100:
+                kbon = int(kk)
+    return kbon
+
+
+# --------------------------------------------------------------------------------------------
+# delay × Doppler cross-ambiguity (experiments/231001_DLL_PLL/rxcomplex.cpp) — UNPINNED
+# --------------------------------------------------------------------------------------------
+
+def caf_bins(y0, fcode, fs, f_lo, f_hi, f_step):
+    """Per-Doppler-bin circular xcorr peak, the loop of rxcomplex.cpp:534-563 restated on the
+    godual replica (Nint=0): for each trial offset mix → FFT → × fcode → IFFT → arg-max.
+    ``y0`` is the mean-removed window.  Returns (freqs, peak |.|, peak lag)."""
+    n = len(y0)
+    t = np.arange(n) / fs
+    nb = int(np.floor((f_hi - f_lo) / f_step + 1e-9)) + 1
+    freqs = f_lo + f_step * np.arange(nb)
+    pk = np.empty(nb)
+    lag = np.empty(nb, dtype=np.int64)
+    for i, f in enumerate(freqs):
+        y = y0 * np.exp(-1j * 2 * np.pi * f * t)
+        m = np.abs(np.fft.ifft(np.fft.fft(y) * fcode))
+        lag[i] = int(m.argmax())
+        pk[i] = m[lag[i]]
+    return freqs, pk, lag
+
+
+def caf_bins_shift(y0, fcode, k_lo, k_hi):
+    """Same surface on the integer-bin Doppler grid f = k*fs/N: a frequency shift by k bins is a
+    circular shift of FFT(y) by k, so one forward FFT serves all bins."""
+    Y = np.fft.fft(y0)
+    ks = np.arange(k_lo, k_hi + 1)
+    pk = np.empty(len(ks))
+    lag = np.empty(len(ks), dtype=np.int64)
+    for i, kk in enumerate(ks):
+        m = np.abs(np.fft.ifft(np.roll(Y, -kk) * fcode))
+        lag[i] = int(m.argmax())
+        pk[i] = m[lag[i]]
+    return ks, pk, lag
+
+
+def sliding_dot(y, code, nlag):
+    """Direct sliding dot products for ±nlag lags (the ``cblas_dgemm`` of rxcomplex.cpp:605 with
+    ``PRN_mapping`` :989-999 replicas): out[l] = (1/n) * sum_i y[i] * code[(i - (l-nlag)) mod n]."""
+    n = len(y)
+    out = np.empty(2 * nlag + 1, dtype=complex)
+    for li in range(2 * nlag + 1):
+        out[li] = np.dot(y, np.roll(code, li - nlag)) / n
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# FIR front end (no reference twin: parameters from experiments/2403/zmq_rx.py:208-215) — UNPINNED
+# --------------------------------------------------------------------------------------------
+
+def fir_lowpass_hamming(fs, cutoff, transition):
+    """GNU Radio ``firdes.low_pass(1, fs, cutoff, transition, WIN_HAMMING)`` design rule:
+    ntaps = int(53 * fs / (22 * transition)) made odd; windowed sinc, unit DC gain."""
+    ntaps = int(53.0 * fs / (22.0 * transition))
+    if ntaps % 2 == 0:
+        ntaps += 1
+    m = (ntaps - 1) // 2
+    n = np.arange(-m, m + 1)
+    w = 0.54 - 0.46 * np.cos(2 * np.pi * (n + m) / (ntaps - 1))
+    fw = 2 * np.pi * cutoff / fs
+    with np.errstate(divide="ignore", invalid="ignore"):
+        h = np.where(n == 0, fw / np.pi, np.sin(n * fw) / (n * np.pi)) * w
+    return h / h.sum()
+
+
+def fir_decimate(x, taps, dec):
+    """y[m] = sum_j taps[j] * x[m*dec + j]  ('valid' part, direct form)."""
+    nout = (len(x) - len(taps)) // dec + 1
+    idx = np.arange(nout)[:, None] * dec + np.arange(len(taps))[None, :]
+    return (x[idx] * taps[None, ::1]).sum(axis=1)

@@ -1,0 +1,138 @@
+"""CPU: pin the oracle against outputs of the reference's own code (tests/golden/*.json)."""
+import hashlib
+import math
+import re
+
+import numpy as np
+import pytest
+
+from oracle import twstft_oracle as orc
+from amaranth_twstft_amd import prn
+from tests.helpers import load_golden, capture_from_desc, chips_for
+
+
+def test_lfsr_matches_reference_nextstate():
+    g = load_golden("prn_codes.json")
+    for e in g["lfsr"]:
+        chips = orc.lfsr_chips(e["bitlen"], e["taps"], e["n"])
+        assert hashlib.sha256(bytes(chips)).hexdigest() == e["chips_sha256"]
+        assert list(chips[:64]) == e["chips_head"]
+        # host mirror (fast block form) and its final state
+        assert np.array_equal(prn.lfsr_chips(e["bitlen"], e["taps"], e["n"]), chips)
+        a = 1
+        for _ in range(e["n"]):
+            a = prn.nextstate(a, e["taps"], e["bitlen"])
+        assert a == e["final_state"]
+
+
+def test_code_files_regenerate_bit_exact():
+    g = load_golden("prn_codes.json")
+    assert len(g["files"]) == 18
+    for e in g["files"]:
+        assert e["regenerated_matches"]
+        chips = chips_for(e["bitlen"], e["taps"], e["len"])
+        assert hashlib.sha256(bytes(chips)).hexdigest() == e["sha256"], e["name"]
+        assert list(chips[:48]) == e["head"] and list(chips[-16:]) == e["tail"]
+
+
+def _rows_221207(raw, chips, fs, Nint):
+    """Oracle restatement of the printed row of 221207 godual_ranging.py:135."""
+    code = orc.make_code(chips, 2)
+    fcode = orc.make_fcode(code)
+    n = len(code)
+    freq = orc.freq_axis(fs, n)
+    k = orc.band_numpy(freq, 0.0, 8000.0)
+    temps = np.arange(n) / fs
+    raw = raw.reshape(-1, 4)
+    rows = []
+    for p in range(raw.shape[0] // n):
+        blk = raw[p * n:(p + 1) * n]
+        d1 = orc.deinterleave(blk, 2, 0); d1 = d1 - d1.mean()
+        d2 = orc.deinterleave(blk, 2, 1); d2 = d2 - d2.mean()
+        r1 = orc.processing(d1, k, freq, temps, fcode, code, Nint=Nint, fs=fs, snr_rot=-2)
+        # channel 2 is NOT mixed in that file (fft2tmp=np.fft.fft(d2), :66) and rotates by 0 (:122)
+        r2 = orc.processing(d2, k, freq, temps, fcode, code, Nint=Nint, fs=fs, snr_rot=0, df=0.0)
+        rows.append(((r1["indice"] - r2["indice"] + r1["correction"] - r2["correction"]) / fs / 3,
+                     r1["df"], 10 * np.log10(r1["puissance"]), 10 * np.log10(r1["SNRi"] + r1["SNRr"]),
+                     10 * np.log10(r2["SNRi"] + r2["SNRr"])))
+    return rows
+
+
+@pytest.mark.parametrize("case", ["c5k", "c10k", "c25k", "c100k"])
+def test_oracle_vs_221207_ranging_rows(case):
+    g = load_golden("ref221207_ranging.json")
+    c = next(x for x in g["cases"] if x["name"] == case)
+    chips, raw = capture_from_desc(c["synth"], c["input_sha256"])
+    rows = _rows_221207(raw, chips, c["fs"], c["Nint"])
+    assert len(rows) == c["nwin"]
+    for mine, line in zip(rows, c["rows"]):
+        f = line.split("\t")
+        ref = [float(v) for v in f[1:]]
+        assert abs(mine[0] - ref[0]) <= 1.0e-12, (mine, ref)      # printed to 1e-12 s
+        assert abs(mine[1] - ref[1]) <= 0.05 + 1e-9
+        for a, b in zip(mine[2:], ref[2:]):
+            assert abs(a - b) <= 0.05 + 1e-9
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("case", ["n2M", "n2M_loopback"])
+def test_oracle_vs_221219_processing(case):
+    g = load_golden("ref221219_processing.json")
+    c = next(x for x in g["cases"] if x["name"] == case)
+    chips, raw = capture_from_desc(c["synth"], c["input_sha256"])
+    fs = c["fs"]
+    code = orc.make_code(chips, 2)
+    fcode = orc.make_fcode(code)
+    n = len(code)
+    freq = orc.freq_axis(fs, n)
+    k = orc.band_numpy(freq, 0.0, 8000.0)
+    temps = np.arange(n) / fs
+    d = orc.deinterleave(raw, 1, 0)
+    d = d - d.mean()
+    r = orc.processing(d, k, freq, temps, fcode, code, Nint=c["Nint"], fs=fs, fine_freq=True)
+    ref = c["ref"]
+    assert r["indice"] == ref["indice"]
+    assert abs(r["correction"] - ref["correction"]) < 1e-9
+    assert abs(r["df"] - ref["df"]) < 1e-9
+    for key in ("SNRr", "SNRi", "puissance", "puissancecode", "puissancenoise"):
+        assert abs(r[key] - ref[key]) <= 1e-9 * abs(ref[key]), key
+
+
+def test_snr_identity_used_by_device_path():
+    """mean(yincode) = (z[i-1]+z[i]+z[i+1])/M and mean|yint|^2 = mean|y|^2/R^2."""
+    rng = np.random.default_rng(3)
+    chips = chips_for(13, 27, 2500)
+    code = orc.make_code(chips, 2)
+    n = len(code)
+    y = np.roll(code, 777) * 3 + rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    fcode = orc.make_fcode(code)
+    ffty = np.fft.fft(y)
+    z = orc.xcorr_interp(ffty, fcode, 1)
+    ind, *_ = orc.peak_refine(z)
+    SNRr, SNRi, pcode, pnoise = orc.snr_wipeoff(ffty, code, ind, 1, rot=-1, ddof=0)
+    M = 3 * n
+    mean = (z[ind - 1] + z[ind] + z[(ind + 1) % M]) / M
+    p2 = np.mean(np.abs(y) ** 2) / 9
+    var = p2 - abs(mean) ** 2
+    assert abs(mean.real ** 2 / var - SNRr) < 1e-10 * SNRr
+    assert abs(mean.imag ** 2 / var - SNRi) < 1e-10 * max(SNRi, 1e-30) + 1e-18
+    assert abs(var - pnoise) < 1e-10 * pnoise
+
+
+def test_claudio_convention_is_mirrored_godual():
+    """ifft(F·conj(Y)) = conj(reverse(ifft(conj(F)·Y))) — the cross-check SURVEY.md §8c names."""
+    rng = np.random.default_rng(4)
+    chips = chips_for(13, 27, 2500)
+    code = orc.make_code(chips, 2)
+    n = len(code)
+    fs = 5e6
+    temps = np.arange(n) / fs
+    d = np.roll(code, 1500) * 5 * np.exp(2j * np.pi * 300.0 * temps) + rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    d = d - d.mean()
+    freq = orc.freq_axis(fs, n)
+    g = orc.processing(d, None, freq, temps, orc.make_fcode(code), code, Nint=1, fs=fs, df=300.0)
+    c = orc.processing_claudio(d, 300.0, temps, orc.make_fcode(code, "claudio"), code, Nint=1)
+    M = 3 * n
+    assert c["indice"] == (M - g["indice"]) % M
+    assert abs(c["xval"] - np.conj(g["xval"])) < 1e-9 * abs(g["xval"])
+    assert abs(c["correction"] + g["correction"]) < 1e-9
