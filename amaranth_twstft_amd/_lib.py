@@ -1,0 +1,113 @@
+"""ctypes binding of libtwstft_hip.so (C ABI: include/twstft_hip.h).
+
+There is no CPU fallback: if the shared library is missing or cannot be loaded this module
+raises, and every product entry point that needs it fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtwstft_hip.so")
+
+TWX_OK = 0
+TWX_CONV_GODUAL, TWX_CONV_CLAUDIO = 0, 1
+TWX_WIN_NONE, TWX_WIN_HAMMING = 0, 1
+TWX_F32, TWX_F64 = 0, 1
+TWX_FLAG_PROFILE = 1
+TWX_PROF_MAX = 16
+
+
+class TwxError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"twstft_hip error {status}: {msg}")
+        self.status = status
+
+
+class twx_config(C.Structure):
+    _fields_ = [("fs", C.c_double), ("sps", C.c_int32), ("nint", C.c_int32),
+                ("chips", C.POINTER(C.c_uint8)), ("n_chips", C.c_int64),
+                ("lfsr_bitlen", C.c_int32), ("lfsr_taps", C.c_int32),
+                ("convention", C.c_int32), ("window", C.c_int32), ("precision", C.c_int32),
+                ("var_ddof", C.c_int32), ("snr_rot", C.c_int32), ("device", C.c_int32),
+                ("max_batch", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class twx_band(C.Structure):
+    _fields_ = [("k_lo", C.c_int64), ("k_hi", C.c_int64)]
+
+
+class twx_result(C.Structure):
+    _fields_ = [("indice0", C.c_int64), ("correction", C.c_double),
+                ("xval", C.c_double * 2), ("xvalm1", C.c_double * 2), ("xvalp1", C.c_double * 2),
+                ("zwin", (C.c_double * 2) * 7),
+                ("df", C.c_double), ("df_index", C.c_int64),
+                ("SNRr", C.c_double), ("SNRi", C.c_double), ("puissance", C.c_double),
+                ("puissancecode", C.c_double), ("puissancenoise", C.c_double),
+                ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+class twx_info(C.Structure):
+    _fields_ = [("n", C.c_int64), ("n1", C.c_int32), ("n2", C.c_int32), ("nphase", C.c_int32),
+                ("batch", C.c_int32), ("precision", C.c_int32), ("col_w", C.c_int32),
+                ("device_bytes", C.c_int64)]
+
+
+class twx_prof_entry(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("ms_total", C.c_double), ("launches", C.c_int64), ("units", C.c_int64)]
+
+
+# every symbol include/twstft_hip.h declares: (restype, argtypes)
+_VP = C.c_void_p
+SYMBOLS = {
+    "twx_abi_version": (C.c_int, []),
+    "twx_strerror": (C.c_char_p, [C.c_int]),
+    "twx_last_error": (C.c_char_p, [_VP]),
+    "twx_create": (C.c_int, [C.POINTER(twx_config), C.POINTER(_VP)]),
+    "twx_destroy": (None, [_VP]),
+    "twx_get_info": (C.c_int, [_VP, C.POINTER(twx_info)]),
+    "twx_process_windows": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
+    "twx_process_windows_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
+    "twx_synchronize": (C.c_int, [_VP]),
+    "twx_stream": (_VP, [_VP]),
+    "twx_fft_forward": (C.c_int, [_VP, _VP, _VP]),
+    "twx_get_code_spectrum": (C.c_int, [_VP, _VP]),
+    "twx_xcorr_map": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, _VP]),
+    "twx_profile_reset": (C.c_int, [_VP]),
+    "twx_profile_get": (C.c_int, [_VP, C.POINTER(twx_prof_entry), C.c_int32, C.POINTER(C.c_int32)]),
+    "twx_lfsr_chips": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _VP]),
+    "twx_synth_capture_dev": (C.c_int, [_VP, C.c_int64, C.c_int64, _VP, C.c_int64, C.c_int32, C.c_int32, _VP, _VP]),
+    "twx_dev_alloc": (_VP, [C.c_size_t]),
+    "twx_dev_free": (None, [_VP]),
+    "twx_memcpy_h2d": (C.c_int, [_VP, _VP, C.c_size_t]),
+    "twx_memcpy_d2h": (C.c_int, [_VP, _VP, C.c_size_t]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and bind every declared symbol; raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)            # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.twx_abi_version() != 1:
+        raise ImportError("libtwstft_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status, ctx=None):
+    if status != TWX_OK:
+        lib = load()
+        msg = lib.twx_last_error(ctx)
+        raise TwxError(status, (msg or lib.twx_strerror(status) or b"?").decode())

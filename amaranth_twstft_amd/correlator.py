@@ -1,0 +1,215 @@
+"""Host-side mirror of the reference's correlation interface, running on the HIP library.
+
+Names and argument meaning follow the reference scripts so the parity tests read like the
+reference's own usage:
+
+* ``Correlator.processing(raw, k)``  ↔  ``processing(d,k)``  processing/Octave/godual_ranging.m:12
+  (the window is handed over as raw int16 IQ; mean removal of :80 happens on the device)
+* ``Correlator.processing_df(raw, df)``  ↔  ``processing(d,df)``
+  acquisition/claudio_aligned_code_ranging_separate.m:49
+* ``Correlator.ranging(raw, ...)``  ↔  the window loop ``ranging(filename, prn_code, …)`` of
+  experiments/221219_twoway/processing/godual_ranging.py:67-139 / godual_ranging.m:59-102
+* ``freq_axis`` / ``band_godual`` / ``band_numpy``  ↔  godual_ranging.m:73,83-89, godual_ranging.py:79-81
+
+All arithmetic on samples happens in libtwstft_hip.so (no numpy/torch fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+
+def freq_axis(fs: float, n: int) -> np.ndarray:
+    """``freq=linspace(-fs/2,fs/2,length(code))`` (godual_ranging.m:73)."""
+    return np.linspace(-fs / 2, fs / 2, num=n, dtype=float)
+
+
+def _band_range(mask_idx: np.ndarray) -> tuple[int, int]:
+    if mask_idx.size == 0:
+        raise ValueError("empty search band")
+    lo, hi = int(mask_idx[0]), int(mask_idx[-1])
+    if hi - lo + 1 != mask_idx.size:
+        raise ValueError("search band must be contiguous")
+    return lo, hi
+
+
+def band_godual(fs: float, n: int, remote: int = 0, OP: int = 0) -> tuple[int, int]:
+    """Search band of godual_ranging.m:83-89 as an inclusive 0-based index range."""
+    f = freq_axis(fs, n)
+    if remote != 1:
+        k = np.nonzero((f < 20000) & (f > -20000))[0]
+    elif OP == 1:
+        k = np.nonzero((f > -120000) & (f < -80000))[0]
+    else:
+        k = np.nonzero((f < 120000) & (f > 80000))[0]
+    return _band_range(k)
+
+
+def band_numpy(fs: float, n: int, foffset: float = 0.0, frange: float = 8000.0) -> tuple[int, int]:
+    """Search band of experiments/221219_twoway/processing/godual_ranging.py:80-81."""
+    f = freq_axis(fs, n)
+    return _band_range(np.nonzero((f < 2 * (foffset + frange)) & (f > 2 * (foffset - frange)))[0])
+
+
+@dataclass
+class WindowResult:
+    """Outputs of ``processing`` for one channel-window (0-based ``indice``; Octave's is +1)."""
+    indice: int
+    correction: float
+    xval: complex
+    xvalm1: complex
+    xvalp1: complex
+    zwin: np.ndarray
+    df: float
+    df_index: int
+    SNRr: float
+    SNRi: float
+    puissance: float
+    puissancecode: float
+    puissancenoise: float
+
+    def delay(self, fs: float, nint: int, sign: int = +1) -> float:
+        """``(indice-1±correction)/fs/(2*Nint+1)`` as printed by godual_ranging.m:96."""
+        return (self.indice + sign * self.correction) / fs / (2 * nint + 1)
+
+
+def _to_result(r: L.twx_result) -> WindowResult:
+    z = np.array([[p[0], p[1]] for p in r.zwin])
+    return WindowResult(int(r.indice0), r.correction, complex(*r.xval), complex(*r.xvalm1), complex(*r.xvalp1),
+                        z[:, 0] + 1j * z[:, 1], r.df, int(r.df_index), r.SNRr, r.SNRi, r.puissance,
+                        r.puissancecode, r.puissancenoise)
+
+
+class Correlator:
+    """One code + one GPU. Mirrors the globals ``fs Nint code fcode`` of godual_ranging.m:3-5,62-66."""
+
+    def __init__(self, chips=None, fs: float = 5e6, sps: int = 2, Nint: int = 1, *, lfsr: tuple[int, int, int] | None = None,
+                 precision: str = "f32", var_ddof: int = 0, snr_rot: int = -1, window: str = "none",
+                 device: int = -1, max_batch: int = 0, profile: bool = False):
+        self._lib = L.load()
+        cfg = L.twx_config()
+        cfg.fs, cfg.sps, cfg.nint = fs, sps, Nint
+        if chips is not None:
+            self._chips = np.ascontiguousarray(chips, dtype=np.uint8)
+            cfg.chips = self._chips.ctypes.data_as(C.POINTER(C.c_uint8))
+            cfg.n_chips = self._chips.size
+        elif lfsr is not None:
+            cfg.chips = None
+            cfg.lfsr_bitlen, cfg.lfsr_taps, cfg.n_chips = lfsr
+        else:
+            raise ValueError("give chips or lfsr=(bitlen, taps, noiselen)")
+        cfg.convention = L.TWX_CONV_GODUAL
+        cfg.window = {"none": L.TWX_WIN_NONE, "hamming": L.TWX_WIN_HAMMING}[window]
+        cfg.precision = {"f32": L.TWX_F32, "f64": L.TWX_F64}[precision]
+        cfg.var_ddof, cfg.snr_rot, cfg.device, cfg.max_batch = var_ddof, snr_rot, device, max_batch
+        cfg.flags = L.TWX_FLAG_PROFILE if profile else 0
+        h = C.c_void_p()
+        L.check(self._lib.twx_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        info = L.twx_info()
+        L.check(self._lib.twx_get_info(self._h, C.byref(info)), self._h)
+        self.info = info
+        self.fs, self.sps, self.Nint = fs, sps, Nint
+        self.n = int(info.n)
+
+    # -- lifetime ------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.twx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- the kernel ----------------------------------------------------------------------
+    def _windows(self, raw, n_channels):
+        raw = np.ascontiguousarray(raw, dtype=np.int16).reshape(-1)
+        per = self.n * 2 * n_channels
+        nwin = raw.size // per          # short final window is dropped (godual_ranging.m:81,102)
+        return raw, nwin
+
+    def process(self, raw, n_channels=1, channel=0, band=None, df=None) -> list[WindowResult]:
+        """Run ``processing`` over every full window of an interleaved int16 capture (host memory)."""
+        raw, nwin = self._windows(raw, n_channels)
+        out = (L.twx_result * max(nwin, 1))()
+        bptr = None
+        dptr = None
+        if band is not None:
+            b = L.twx_band(int(band[0]), int(band[1]))
+            bptr = C.byref(b)
+        else:
+            if df is None:
+                raise ValueError("give band (estimate df) or df (per window)")
+            dfa = np.ascontiguousarray(np.broadcast_to(np.asarray(df, dtype=np.float64), (nwin,)))
+            dptr = dfa.ctypes.data_as(C.c_void_p)
+        L.check(self._lib.twx_process_windows(self._h, raw.ctypes.data_as(C.c_void_p), nwin, n_channels, channel,
+                                              bptr, dptr, C.cast(out, C.c_void_p)), self._h)
+        return [_to_result(out[i]) for i in range(nwin)]
+
+    def processing(self, raw_window, k, n_channels=1, channel=0) -> WindowResult:
+        """``processing(d,k)`` (godual_ranging.m:12): ``k`` = (k_lo, k_hi) or an index array."""
+        if not (isinstance(k, tuple) and len(k) == 2):
+            k = _band_range(np.asarray(k))
+        return self.process(raw_window, n_channels, channel, band=k)[0]
+
+    def processing_df(self, raw_window, df, n_channels=1, channel=0) -> WindowResult:
+        """``processing(d,df)`` (claudio_aligned_code_ranging_separate.m:49), godual peak convention."""
+        return self.process(raw_window, n_channels, channel, df=df)[0]
+
+    def ranging(self, raw, n_channels=2, channels=(0, 1), band=None, remote=0, OP=0):
+        """Window loop of godual_ranging.m:75-102: {channel: [WindowResult …]}."""
+        if band is None:
+            band = band_godual(self.fs, self.n, remote, OP)
+        return {c: self.process(raw, n_channels, c, band=band) for c in channels}
+
+    # -- inspection ----------------------------------------------------------------------
+    def fft(self, x) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.complex128)
+        assert x.size == self.n
+        out = np.empty(self.n, dtype=np.complex128)
+        L.check(self._lib.twx_fft_forward(self._h, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), self._h)
+        return out
+
+    def code_spectrum(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.complex128)
+        L.check(self._lib.twx_get_code_spectrum(self._h, out.ctypes.data_as(C.c_void_p)), self._h)
+        return out
+
+    def xcorr_map(self, raw_window, df, n_channels=1, channel=0) -> np.ndarray:
+        raw = np.ascontiguousarray(raw_window, dtype=np.int16).reshape(-1)
+        assert raw.size >= self.n * 2 * n_channels
+        out = np.empty(self.n * (2 * self.Nint + 1), dtype=np.complex128)
+        L.check(self._lib.twx_xcorr_map(self._h, raw.ctypes.data_as(C.c_void_p), n_channels, channel, float(df),
+                                        out.ctypes.data_as(C.c_void_p)), self._h)
+        return out
+
+    def profile(self, reset=False) -> dict:
+        ents = (L.twx_prof_entry * L.TWX_PROF_MAX)()
+        n = C.c_int32()
+        L.check(self._lib.twx_profile_get(self._h, ents, L.TWX_PROF_MAX, C.byref(n)), self._h)
+        out = {ents[i].name.decode(): dict(ms_total=ents[i].ms_total, launches=ents[i].launches, units=ents[i].units)
+               for i in range(n.value)}
+        if reset:
+            L.check(self._lib.twx_profile_reset(self._h), self._h)
+        return out
+
+
+def lfsr_chips_device(bitlen: int, taps: int, n: int) -> np.ndarray:
+    """LFSR chips generated by the device kernel (same bytes as prn.lfsr_chips)."""
+    lib = L.load()
+    out = np.empty(n, dtype=np.uint8)
+    L.check(lib.twx_lfsr_chips(bitlen, taps, n, out.ctypes.data_as(C.c_void_p)))
+    return out

@@ -1,0 +1,723 @@
+// twx_api.hip — C ABI (include/twstft_hip.h) of the TWSTFT correlator: context, plan choice,
+// twiddle tables, the per-batch kernel sequence and the inspection entry points.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "twx_kernels.h"
+#include "twx_plans.h"
+
+namespace twx {
+
+// ------------------------------------------------------------------------------------------
+// registry
+// ------------------------------------------------------------------------------------------
+static std::vector<ColOps>& col_reg() { static std::vector<ColOps> v; return v; }
+static std::vector<RowOps>& row_reg() { static std::vector<RowOps> v; return v; }
+void register_col(const ColOps& o) { col_reg().push_back(o); }
+void register_row(const RowOps& o) { row_reg().push_back(o); }
+const ColOps* find_col(int L, int f64) {
+    for (auto& o : col_reg()) if (o.L == L && o.f64 == f64) return &o;
+    return nullptr;
+}
+const RowOps* find_row(int L, int f64) {
+    for (auto& o : row_reg()) if (o.L == L && o.f64 == f64) return &o;
+    return nullptr;
+}
+bool choose_split(long long n, int f64, const ColOps** col, const RowOps** row) {
+    // prefer the longest row plan (fewest, longest contiguous rows; column tiles stay ≤ 80 KB)
+    const ColOps* bc = nullptr; const RowOps* br = nullptr;
+    for (auto& r : row_reg()) {
+        if (r.f64 != f64 || n % r.L || (r.L & 1)) continue;
+        const long long n1 = n / r.L;
+        if (n1 > 100000) continue;
+        const ColOps* c = find_col((int)n1, f64);
+        if (!c || r.L % c->W) continue;
+        if (!br || r.L > br->L) { br = &r; bc = c; }
+    }
+    if (!br) return false;
+    *col = bc; *row = br;
+    return true;
+}
+
+static thread_local std::string g_create_err;
+
+#define HIPCHK(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            char buf_[256];                                                                 \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return fail(TWX_E_HIP, buf_);                                                   \
+        }                                                                                   \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+template <typename S, typename D>
+__global__ void k_convert(const cpx<S>* __restrict__ in, cpx<D>* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = mk<D>((D)in[i].x, (D)in[i].y);
+}
+
+// chips of LFSR(bitlen,taps), seed 1, one byte per chip (amaranth_twstft/common.py:23-30,59-73).
+// Every thread jumps to its segment by applying the 2^j-step transition matrices
+// (precomputed on the host), then runs the bit-serial recurrence.
+__global__ void k_lfsr(int bitlen, unsigned taps, long long n, long long seg, const unsigned* __restrict__ jump /*[40][32]*/,
+                       unsigned char* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long start = t * seg;
+    if (start >= n) return;
+    unsigned state = 1u;
+    for (int j = 0; j < 40; ++j) {
+        if ((start >> j) & 1) {
+            const unsigned* m = jump + j * 32;       // column i = image of basis state bit i
+            unsigned ns = 0;
+            for (int i = 0; i < bitlen; ++i) if ((state >> i) & 1u) ns ^= m[i];
+            state = ns;
+        }
+    }
+    const long long end = min(n, start + seg);
+    for (long long i = start; i < end; ++i) {
+        out[i] = (unsigned char)(state & 1u);
+        const unsigned bit = __popc(state & taps) & 1u;
+        state = (state >> 1) | (bit << (bitlen - 1));
+    }
+}
+
+// integer synthetic capture generator — must stay bit-identical to amaranth_twstft_amd/synth.py
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+__device__ __forceinline__ void icossin_q30(unsigned ph, long long& cs, long long& sn) {
+    const long long quad = ph >> 30;
+    const long long x = ph & ((1u << 30) - 1);
+    const long long y = (x * 1686629713ll) >> 30;
+    const long long y2 = (y * y) >> 30;
+    const long long one = 1ll << 30;
+    long long t = one - y2 / 110;
+    t = one - (((y2 / 72) * t) >> 30);
+    t = one - (((y2 / 42) * t) >> 30);
+    t = one - (((y2 / 20) * t) >> 30);
+    t = one - (((y2 / 6) * t) >> 30);
+    const long long s0 = (y * t) >> 30;
+    long long u = one - y2 / 132;
+    u = one - (((y2 / 90) * u) >> 30);
+    u = one - (((y2 / 56) * u) >> 30);
+    u = one - (((y2 / 30) * u) >> 30);
+    u = one - (((y2 / 12) * u) >> 30);
+    const long long c0 = one - (((y2 / 2) * u) >> 30);
+    cs = quad == 0 ? c0 : quad == 1 ? -s0 : quad == 2 ? -c0 : s0;
+    sn = quad == 0 ? s0 : quad == 1 ? c0 : quad == 2 ? -s0 : -c0;
+}
+struct SynthChan { long long delay_q8, fstep, phi0, amp, noise_gain, seed, stream, pad; };
+struct SynthArgs { SynthChan ch[4]; };
+__global__ void k_synth(short2* __restrict__ out, long long n, long long n0, const unsigned char* __restrict__ chips,
+                        long long n_chips, int sps, int nch, SynthArgs a) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n * nch; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nch);
+        const long long idx = n0 + i / nch;
+        const SynthChan p = a.ch[c];
+        const long long period = n_chips * sps * 256;
+        long long q = (idx * 256 - p.delay_q8) % period; if (q < 0) q += period;
+        const long long code = 2 * (long long)chips[q / (sps * 256)] - 1;
+        const unsigned ph = (unsigned)(((unsigned long long)idx * (unsigned long long)(p.fstep & 0xffffffffll) +
+                                        (unsigned long long)(p.phi0 & 0xffffffffll)) & 0xffffffffull);
+        long long cs, sn;
+        icossin_q30(ph, cs, sn);
+        long long si = (p.amp * code * cs) >> 30;
+        long long sq = (p.amp * code * sn) >> 30;
+        if (p.noise_gain) {
+            const unsigned long long key = (unsigned long long)p.seed * 0xD6E8FEB86659FD93ull + (unsigned long long)p.stream * 0xA0761D6478BD642Full;
+            const unsigned long long ctr = (unsigned long long)idx * 0x9E3779B97F4A7C15ull + key;
+            const unsigned long long h[4] = {mix64(ctr), mix64(ctr ^ 0x5851F42D4C957F2Dull), mix64(ctr ^ 0x2545F4914F6CDD1Dull),
+                                             mix64(ctr ^ 0x9FB21C651E98DF25ull)};
+            long long ni = -4 * 65535, nq = -4 * 65535;
+            for (int k = 0; k < 4; ++k) {
+                ni += (long long)(h[k] & 0xffff) + (long long)((h[k] >> 16) & 0xffff);
+                nq += (long long)((h[k] >> 32) & 0xffff) + (long long)(h[k] >> 48);
+            }
+            si += (ni * p.noise_gain) >> 20;
+            sq += (nq * p.noise_gain) >> 20;
+        }
+        si = si < -32768 ? -32768 : si > 32767 ? 32767 : si;
+        sq = sq < -32768 ? -32768 : sq > 32767 ? 32767 : sq;
+        out[i] = make_short2((short)si, (short)sq);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+struct ProfRec { hipEvent_t a, b; int cls; long long units; };
+static const char* kProfNames[] = {"k_sums", "k_col_fwd_square", "k_row_band", "k_df_tables", "k_col_fwd_mix",
+                                   "k_row_mid", "k_col_inv", "k_peak"};
+enum { PC_SUMS = 0, PC_COL_SQ, PC_ROW_BAND, PC_DFT, PC_COL_MIX, PC_ROW_MID, PC_COL_INV, PC_PEAK, PC_COUNT };
+
+struct CtxBase {
+    twx_config cfg{};
+    std::string err;
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    long long N = 0; int N1 = 0, N2 = 0, R = 1, B = 1;
+    const ColOps* col = nullptr; const RowOps* row = nullptr;
+    std::vector<void*> allocs;
+    long long dev_bytes = 0;
+    // profiling
+    bool profile = false;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[PC_COUNT] = {0}; long long prof_n[PC_COUNT] = {0}; long long prof_units[PC_COUNT] = {0};
+
+    virtual ~CtxBase() {
+        for (void* p : allocs) (void)hipFree(p);
+        for (auto& r : prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    int fail(int code, const std::string& msg) { err = msg; return code; }
+    template <typename U> int dalloc(U** p, size_t count) {
+        void* q = nullptr;
+        size_t bytes = std::max<size_t>(count * sizeof(U), 16);
+        hipError_t e = hipMalloc(&q, bytes);
+        if (e != hipSuccess) { char b[160]; snprintf(b, sizeof b, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); return fail(TWX_E_NOMEM, b); }
+        allocs.push_back(q); dev_bytes += (long long)bytes;
+        *p = reinterpret_cast<U*>(q);
+        return TWX_OK;
+    }
+    void dfree(void* p) {
+        auto it = std::find(allocs.begin(), allocs.end(), p);
+        if (it != allocs.end()) allocs.erase(it);
+        (void)hipFree(p);
+    }
+    hipEvent_t get_event() {
+        if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    struct ProfScope {
+        CtxBase* c; ProfRec r; bool on;
+        ProfScope(CtxBase* c_, int cls, long long units) : c(c_), on(c_->profile) {
+            if (on) { r.cls = cls; r.units = units; r.a = c->get_event(); r.b = c->get_event(); (void)hipEventRecord(r.a, c->stream); }
+        }
+        ~ProfScope() { if (on) { (void)hipEventRecord(r.b, c->stream); c->prof_pending.push_back(r); } }
+    };
+    void prof_collect() {
+        for (auto& r : prof_pending) {
+            float ms = 0;
+            (void)hipEventSynchronize(r.b);
+            (void)hipEventElapsedTime(&ms, r.a, r.b);
+            prof_ms[r.cls] += ms; prof_n[r.cls] += 1; prof_units[r.cls] += r.units;
+            ev_pool.push_back(r.a); ev_pool.push_back(r.b);
+        }
+        prof_pending.clear();
+    }
+    virtual int init() = 0;
+    virtual int process(const void* iq_dev, long long nwin, int nch, int ch, const twx_band* band, const double* df,
+                        twx_result* out_dev) = 0;
+    virtual int fft_forward(const double* in, double* out) = 0;
+    virtual int code_spectrum(double* out) = 0;
+    virtual int xcorr_map(const int16_t* iq, int nch, int ch, double df, double* out) = 0;
+};
+
+template <typename T> static void host_twiddle(std::vector<cpx<T>>& v, long long count, long long num_mul, long long den, int sign) {
+    v.resize(count);
+    for (long long m = 0; m < count; ++m) {
+        // angle = sign * 2*pi * (m*num_mul mod den)/den, evaluated in long double
+        const long long r = (long long)(((__int128)m * num_mul) % den);
+        const long double a = 2.0L * 3.14159265358979323846264338327950288L * (long double)r / (long double)den;
+        v[m] = mk<T>((T)cosl(a), (T)(sign * sinl(a)));
+    }
+}
+
+template <typename T> struct Ctx : CtxBase {
+    using C = cpx<T>;
+    int tshift = 11;
+    double scale_pow2 = 1.0;
+    // tables
+    C *tw1 = nullptr, *tw2 = nullptr, *ta = nullptr, *tb = nullptr, *ramp1 = nullptr, *ramp2 = nullptr;
+    cpx<double>* tw1d = nullptr;
+    C* cspec = nullptr;
+    unsigned char* chips_dev = nullptr;
+    // batch buffers
+    WinSums* sums = nullptr; double* dfv = nullptr; long long* dfidx = nullptr;
+    C *e1 = nullptr, *e2 = nullptr, *A = nullptr, *Bz = nullptr, *dc = nullptr;
+    ArgPart<T>*part_band = nullptr, *part_peak = nullptr;
+    twx_result* res_dev = nullptr;
+    int ntiles = 0;
+
+    template <typename U> int upload(U** dst, const std::vector<U>& src) {
+        int rc = dalloc(dst, src.size());
+        if (rc) return rc;
+        HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(U), hipMemcpyHostToDevice));
+        return TWX_OK;
+    }
+
+    int make_tables() {
+        std::vector<C> h;
+        host_twiddle<T>(h, N1, 1, N1, -1); if (int rc = upload(&tw1, h)) return rc;
+        host_twiddle<T>(h, N2, 1, N2, -1); if (int rc = upload(&tw2, h)) return rc;
+        tshift = 1; while ((2ll << (2 * tshift)) <= N) ++tshift;     // 2^tshift ≈ sqrt(N)
+        host_twiddle<T>(h, (N >> tshift) + 1, 1ll << tshift, N, -1); if (int rc = upload(&ta, h)) return rc;
+        host_twiddle<T>(h, 1ll << tshift, 1, N, -1); if (int rc = upload(&tb, h)) return rc;
+        std::vector<cpx<double>> hd;
+        host_twiddle<double>(hd, N1, 1, N1, -1); if (int rc = upload(&tw1d, hd)) return rc;
+        // interpolation phase ramps exp(+2 pi i rho k/(R N)), k signed, split k = k1 + N1*k2:
+        //   ramp1[rho][k1] = exp(+2 pi i rho k1/(R N)),  ramp2[rho][k2] = exp(+2 pi i rho k2s/(R N2))
+        std::vector<C> r1((size_t)R * N1), r2((size_t)R * N2);
+        const long double tp = 2.0L * 3.14159265358979323846264338327950288L;
+        for (int rho = 0; rho < R; ++rho) {
+            for (int k1 = 0; k1 < N1; ++k1) {
+                long double a = tp * (long double)(((__int128)rho * k1) % ((__int128)R * N)) / ((long double)R * (long double)N);
+                r1[(size_t)rho * N1 + k1] = mk<T>((T)cosl(a), (T)sinl(a));
+            }
+            for (int k2 = 0; k2 < N2; ++k2) {
+                long long k2s = (k2 >= N2 / 2 + (N2 & 1)) ? k2 - N2 : k2;   // N even ⇒ k >= N/2 ⇔ k2 >= N2/2 (N2 even)
+                long long num = ((long long)rho * k2s) % ((long long)R * N2);
+                long double a = tp * (long double)num / ((long double)R * (long double)N2);
+                r2[(size_t)rho * N2 + k2] = mk<T>((T)cosl(a), (T)sinl(a));
+            }
+        }
+        if (int rc = upload(&ramp1, r1)) return rc;
+        if (int rc = upload(&ramp2, r2)) return rc;
+        return TWX_OK;
+    }
+
+    // conj(fft(code)) in [k1][k2] layout, computed in fp64 when the fp64 plans exist
+    int make_code_spectrum() {
+        if (int rc = dalloc(&cspec, (size_t)N)) return rc;
+        const ColOps* c64 = find_col(N1, 1); const RowOps* r64 = find_row(N2, 1);
+        const bool use64 = !std::is_same<T, double>::value && c64 && r64 && c64->W == col->W;
+        if (std::is_same<T, double>::value || !use64) return code_spectrum_T<T>(cspec, col, row, tw1, tw2, ta, tb);
+        // temporary fp64 tables and buffers
+        cpx<double>*t1 = nullptr, *t2 = nullptr, *tad = nullptr, *tbd = nullptr, *spec = nullptr;
+        std::vector<cpx<double>> h;
+        host_twiddle<double>(h, N1, 1, N1, -1); if (int rc = upload(&t1, h)) return rc;
+        host_twiddle<double>(h, N2, 1, N2, -1); if (int rc = upload(&t2, h)) return rc;
+        host_twiddle<double>(h, (N >> tshift) + 1, 1ll << tshift, N, -1); if (int rc = upload(&tad, h)) return rc;
+        host_twiddle<double>(h, 1ll << tshift, 1, N, -1); if (int rc = upload(&tbd, h)) return rc;
+        if (int rc = dalloc(&spec, (size_t)N)) return rc;
+        if (int rc = code_spectrum_T<double>(spec, c64, r64, t1, t2, tad, tbd)) return rc;
+        hipLaunchKernelGGL((k_convert<double, T>), dim3(1024), dim3(256), 0, stream, spec, cspec, N);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        long long before = dev_bytes;
+        dfree(t1); dfree(t2); dfree(tad); dfree(tbd); dfree(spec);
+        dev_bytes = before - (long long)((N1 + N2 + (N >> tshift) + 1 + (1ll << tshift) + N) * sizeof(cpx<double>));
+        return TWX_OK;
+    }
+    template <typename U>
+    int code_spectrum_T(cpx<U>* out, const ColOps* c, const RowOps* r, const cpx<U>* t1, const cpx<U>* t2,
+                        const cpx<U>* tad, const cpx<U>* tbd) {
+        cpx<U>* tmp = nullptr;
+        if (int rc = dalloc(&tmp, (size_t)N)) return rc;
+        ColFwdArgs<U> ca{};
+        ca.in_win_stride = 0; ca.sums = nullptr; ca.remove_mean = 0; ca.n = N; ca.n2 = N2; ca.ntiles = N2 / c->W; ca.nwin = 1;
+        ca.e1 = nullptr; ca.e2 = nullptr; ca.tw1 = t1; ca.ta = tad; ca.tb = tbd; ca.tshift = tshift; ca.out = tmp;
+        if (c->fwd(COL_PLAIN, IN_CHIPS, chips_dev, cfg.sps, &ca, (unsigned)ca.ntiles, stream)) return fail(TWX_E_HIP, "code col pass launch failed");
+        RowArgs<U> ra{};
+        ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = tmp; ra.tw2 = t2; ra.spec_out = out;
+        ra.conj_out = 1; ra.hamming = (cfg.window == TWX_WIN_HAMMING);
+        if (r->run(ROW_STORE, &ra, (unsigned)N1, stream)) return fail(TWX_E_HIP, "code row pass launch failed");
+        HIPCHK(hipStreamSynchronize(stream));
+        long long before = dev_bytes;
+        dfree(tmp);
+        dev_bytes = before - (long long)(N * sizeof(cpx<U>));
+        return TWX_OK;
+    }
+
+    int init() override {
+        profile = (cfg.flags & TWX_FLAG_PROFILE) != 0;
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        R = 2 * cfg.nint + 1;
+        ntiles = N2 / col->W;
+        B = cfg.max_batch > 0 ? cfg.max_batch : (int)std::max<long long>(1, std::min<long long>(16, (1536ll << 20) / (N * (long long)sizeof(C) * (1 + R))));
+        // range safety: the unnormalised correlation peak reaches ~N^2*32768 — keep |z|^2 inside fp32
+        int e = 0; while ((1ll << e) < N) ++e;
+        scale_pow2 = std::is_same<T, float>::value ? ldexp(1.0, -e) : 1.0;
+        // code
+        if (int rc = dalloc(&chips_dev, (size_t)cfg.n_chips)) return rc;
+        if (cfg.chips) {
+            for (long long i = 0; i < cfg.n_chips; ++i)
+                if (cfg.chips[i] > 1) return fail(TWX_E_ARG, "chips must be bytes 0/1");
+            HIPCHK(hipMemcpy(chips_dev, cfg.chips, (size_t)cfg.n_chips, hipMemcpyHostToDevice));
+        } else {
+            if (int rc = lfsr_to_device(cfg.lfsr_bitlen, (unsigned)cfg.lfsr_taps, cfg.n_chips, chips_dev)) return rc;
+        }
+        if (int rc = make_tables()) return rc;
+        if (int rc = make_code_spectrum()) return rc;
+        // batch buffers
+        if (int rc = dalloc(&sums, (size_t)B)) return rc;
+        if (int rc = dalloc(&dfv, (size_t)B)) return rc;
+        if (int rc = dalloc(&dfidx, (size_t)B)) return rc;
+        if (int rc = dalloc(&e1, (size_t)B * N1)) return rc;
+        if (int rc = dalloc(&e2, (size_t)B * N2)) return rc;
+        if (int rc = dalloc(&A, (size_t)B * N)) return rc;
+        if (int rc = dalloc(&Bz, (size_t)B * R * N)) return rc;
+        if (int rc = dalloc(&dc, (size_t)B)) return rc;
+        if (int rc = dalloc(&part_band, (size_t)B * N1)) return rc;
+        if (int rc = dalloc(&part_peak, (size_t)B * R * ntiles)) return rc;
+        if (int rc = dalloc(&res_dev, (size_t)B)) return rc;
+        HIPCHK(hipStreamSynchronize(stream));
+        return TWX_OK;
+    }
+
+    int lfsr_to_device(int bitlen, unsigned taps, long long n, unsigned char* out) {
+        if (bitlen < 2 || bitlen > 32 || taps == 0 || (bitlen < 32 && (taps >> bitlen))) return fail(TWX_E_ARG, "bad LFSR parameters");
+        // transition matrices M^(2^j) as columns (image of each basis state)
+        std::vector<unsigned> jump(40 * 32, 0);
+        unsigned m[32];
+        for (int i = 0; i < bitlen; ++i) {
+            unsigned s = 1u << i;
+            unsigned bit = __builtin_popcount(s & taps) & 1u;
+            m[i] = (s >> 1) | (bit << (bitlen - 1));
+        }
+        for (int j = 0; j < 40; ++j) {
+            for (int i = 0; i < bitlen; ++i) jump[j * 32 + i] = m[i];
+            unsigned sq[32];
+            for (int i = 0; i < bitlen; ++i) {   // sq = m∘m
+                unsigned s = m[i], ns = 0;
+                for (int b = 0; b < bitlen; ++b) if ((s >> b) & 1u) ns ^= m[b];
+                sq[i] = ns;
+            }
+            memcpy(m, sq, sizeof m);
+        }
+        unsigned* jd = nullptr;
+        if (int rc = dalloc(&jd, jump.size())) return rc;
+        HIPCHK(hipMemcpy(jd, jump.data(), jump.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        const long long seg = 256;
+        const long long nthreads = (n + seg - 1) / seg;
+        hipLaunchKernelGGL(k_lfsr, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, bitlen, taps, n, seg, jd, out);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        long long before = dev_bytes;
+        dfree(jd);
+        dev_bytes = before - (long long)(jump.size() * sizeof(unsigned));
+        return TWX_OK;
+    }
+
+    // one batch of nb windows starting at `in` (short2 units: window stride N*nch, channel offset applied)
+    int run_batch(const short2* in, int nb, int nch, const twx_band* band, const double* df_host, twx_result* out_dev,
+                  C* zout /*optional full map, nb must be 1*/) {
+        HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums) * nb, stream));
+        {
+            ProfScope ps(this, PC_SUMS, (long long)nb * N);
+            const int chunks = (int)std::min<long long>(256, std::max<long long>(1, N / 4096));
+            hipLaunchKernelGGL((k_sums<0>), dim3(chunks, nb), dim3(256), 0, stream, in, (long long)N * nch, nch, N, sums);
+            HIPCHK(hipGetLastError());
+        }
+        ColFwdArgs<T> ca{};
+        ca.in_win_stride = (long long)N * nch; ca.sums = sums; ca.remove_mean = 1; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = nb;
+        ca.e1 = e1; ca.e2 = e2; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.out = A;
+        RowArgs<T> ra{};
+        ra.n = N; ra.n1 = N1; ra.nwin = nb; ra.A = A; ra.tw2 = tw2;
+        ra.part = part_band; ra.cspec = cspec; ra.ramp1 = ramp1; ra.ramp2 = ramp2; ra.nphase = R; ra.scale = (T)scale_pow2;
+        ra.ta = ta; ra.tb = tb; ra.tshift = tshift; ra.Bz = Bz; ra.dc = dc;
+        if (band) {
+            if (band->k_lo < 0 || band->k_hi >= N || band->k_lo > band->k_hi) return fail(TWX_E_ARG, "band outside 0..N-1");
+            ra.band_lo = band->k_lo; ra.band_hi = band->k_hi;
+            {
+                ProfScope ps(this, PC_COL_SQ, (long long)nb * N);
+                if (col->fwd(COL_SQUARE, IN_I16, in, nch, &ca, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_fwd(square) launch failed");
+            }
+            {
+                ProfScope ps(this, PC_ROW_BAND, (long long)nb * N);
+                if (row->run(ROW_BAND, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(band) launch failed");
+            }
+        } else {
+            HIPCHK(hipMemcpyAsync(dfv, df_host, sizeof(double) * nb, hipMemcpyHostToDevice, stream));
+        }
+        {
+            ProfScope ps(this, PC_DFT, nb);
+            hipLaunchKernelGGL((k_df_tables<T>), dim3(nb), dim3(256), 0, stream, band ? 1 : 0, part_band, N1, dfv, dfidx, cfg.fs,
+                               (long long)N, N1, N2, e1, e2);
+            HIPCHK(hipGetLastError());
+        }
+        {
+            ProfScope ps(this, PC_COL_MIX, (long long)nb * N);
+            if (col->fwd(COL_MIX, IN_I16, in, nch, &ca, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_fwd(mix) launch failed");
+        }
+        {
+            ProfScope ps(this, PC_ROW_MID, (long long)nb * N);
+            if (row->run(ROW_MID, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(mid) launch failed");
+        }
+        ColInvArgs<T> ia{};
+        ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = R; ia.nwin = nb; ia.Bz = Bz; ia.tw1 = tw1; ia.part = part_peak; ia.zout = zout;
+        {
+            ProfScope ps(this, PC_COL_INV, (long long)nb * N);
+            if (col->inv(&ia, (unsigned)(ntiles * R * nb), stream)) return fail(TWX_E_HIP, "k_col_inv launch failed");
+        }
+        PeakArgs<T> pa{};
+        pa.n = N; pa.n1 = N1; pa.n2 = N2; pa.nphase = R; pa.nparts = R * ntiles; pa.part = part_peak; pa.Bz = Bz; pa.tw1d = tw1d;
+        pa.sums = sums; pa.remove_mean = 1; pa.dc = dc; pa.dfv = dfv; pa.dfidx = dfidx; pa.inv_scale = 1.0 / scale_pow2;
+        pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.res = out_dev;
+        {
+            ProfScope ps(this, PC_PEAK, nb);
+            hipLaunchKernelGGL((k_peak<T>), dim3(nb), dim3(1024), 0, stream, pa);
+            HIPCHK(hipGetLastError());
+        }
+        return TWX_OK;
+    }
+
+    int process(const void* iq_dev, long long nwin, int nch, int ch, const twx_band* band, const double* df,
+                twx_result* out_dev) override {
+        if (!band && !df) return fail(TWX_E_ARG, "either band or df must be given");
+        const short2* base = reinterpret_cast<const short2*>(iq_dev) + ch;
+        for (long long w0 = 0; w0 < nwin; w0 += B) {
+            const int nb = (int)std::min<long long>(B, nwin - w0);
+            if (int rc = run_batch(base + w0 * N * nch, nb, nch, band, df ? df + w0 : nullptr, out_dev + w0, nullptr)) return rc;
+        }
+        return TWX_OK;
+    }
+
+    int fft_forward(const double* in, double* out) override {
+        cpx<double>* din = nullptr; C* tmp = nullptr; C* spec = nullptr;
+        if (int rc = dalloc(&din, (size_t)N)) return rc;
+        if (int rc = dalloc(&tmp, (size_t)N)) return rc;
+        if (int rc = dalloc(&spec, (size_t)N)) return rc;
+        HIPCHK(hipMemcpy(din, in, (size_t)N * 16, hipMemcpyHostToDevice));
+        ColFwdArgs<T> ca{};
+        ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = 1; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.out = tmp;
+        if (col->fwd(COL_PLAIN, IN_C64, din, 0, &ca, (unsigned)ntiles, stream)) return fail(TWX_E_HIP, "col pass launch failed");
+        RowArgs<T> ra{};
+        ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = tmp; ra.tw2 = tw2; ra.spec_out = spec;
+        if (row->run(ROW_STORE, &ra, (unsigned)N1, stream)) return fail(TWX_E_HIP, "row pass launch failed");
+        HIPCHK(hipStreamSynchronize(stream));
+        std::vector<C> h((size_t)N);
+        HIPCHK(hipMemcpy(h.data(), spec, (size_t)N * sizeof(C), hipMemcpyDeviceToHost));
+        for (int k1 = 0; k1 < N1; ++k1)
+            for (int k2 = 0; k2 < N2; ++k2) {
+                const long long k = k1 + (long long)N1 * k2;
+                out[2 * k] = (double)h[(size_t)k1 * N2 + k2].x; out[2 * k + 1] = (double)h[(size_t)k1 * N2 + k2].y;
+            }
+        long long before = dev_bytes;
+        dfree(din); dfree(tmp); dfree(spec);
+        dev_bytes = before - (long long)(N * (16 + 2 * sizeof(C)));
+        return TWX_OK;
+    }
+    int code_spectrum(double* out) override {
+        std::vector<C> h((size_t)N);
+        HIPCHK(hipMemcpy(h.data(), cspec, (size_t)N * sizeof(C), hipMemcpyDeviceToHost));
+        for (int k1 = 0; k1 < N1; ++k1)
+            for (int k2 = 0; k2 < N2; ++k2) {
+                const long long k = k1 + (long long)N1 * k2;
+                out[2 * k] = (double)h[(size_t)k1 * N2 + k2].x; out[2 * k + 1] = (double)h[(size_t)k1 * N2 + k2].y;
+            }
+        return TWX_OK;
+    }
+    int xcorr_map(const int16_t* iq, int nch, int ch, double df, double* out) override {
+        short2* din = nullptr; C* z = nullptr;
+        if (int rc = dalloc(&din, (size_t)N * nch)) return rc;
+        if (int rc = dalloc(&z, (size_t)N * R)) return rc;
+        HIPCHK(hipMemcpy(din, iq, (size_t)N * nch * 4, hipMemcpyHostToDevice));
+        int rc = run_batch(din + ch, 1, nch, nullptr, &df, res_dev, z);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(stream));
+        std::vector<C> h((size_t)N * R);
+        HIPCHK(hipMemcpy(h.data(), z, h.size() * sizeof(C), hipMemcpyDeviceToHost));
+        const double sc = 1.0 / scale_pow2 / ((double)N * R);
+        for (size_t i = 0; i < h.size(); ++i) { out[2 * i] = (double)h[i].x * sc; out[2 * i + 1] = (double)h[i].y * sc; }
+        long long before = dev_bytes;
+        dfree(din); dfree(z);
+        dev_bytes = before - (long long)((size_t)N * nch * 4 + (size_t)N * R * sizeof(C));
+        return TWX_OK;
+    }
+};
+
+}  // namespace twx
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+using namespace twx;
+struct twx_ctx { CtxBase* impl; };
+
+extern "C" {
+
+int twx_abi_version(void) { return TWX_ABI_VERSION; }
+
+const char* twx_strerror(int status) {
+    switch (status) {
+        case TWX_OK: return "ok";
+        case TWX_E_ARG: return "invalid argument";
+        case TWX_E_SIZE: return "unsupported window length";
+        case TWX_E_HIP: return "HIP runtime error";
+        case TWX_E_NOMEM: return "out of device memory";
+        case TWX_E_STATE: return "invalid state";
+        default: return "unknown status";
+    }
+}
+const char* twx_last_error(const twx_ctx* ctx) { return ctx ? ctx->impl->err.c_str() : g_create_err.c_str(); }
+
+int twx_create(const twx_config* cfg, twx_ctx** out) {
+    if (!cfg || !out) { g_create_err = "null argument"; return TWX_E_ARG; }
+    *out = nullptr;
+    if (!(cfg->fs > 0) || cfg->sps < 1 || cfg->nint < 0 || cfg->nint > 2 || cfg->n_chips < 1) { g_create_err = "bad fs/sps/nint/n_chips"; return TWX_E_ARG; }
+    if (cfg->precision != TWX_F32 && cfg->precision != TWX_F64) { g_create_err = "bad precision"; return TWX_E_ARG; }
+    if (cfg->convention != TWX_CONV_GODUAL) { g_create_err = "only TWX_CONV_GODUAL is implemented on the device (claudio = mirrored godual, see INTEGRATION.md)"; return TWX_E_ARG; }
+    if (cfg->var_ddof < 0 || cfg->var_ddof > 1) { g_create_err = "var_ddof must be 0 or 1"; return TWX_E_ARG; }
+    const long long N = cfg->n_chips * cfg->sps;
+    if (N % 2) { g_create_err = "window length must be even"; return TWX_E_SIZE; }
+    if ((long long)N * (2 * cfg->nint + 1) >= 0xffffffffll) { g_create_err = "window too long for 32-bit lag indices"; return TWX_E_SIZE; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "no HIP device available (the HIP path has no CPU fallback)"; return TWX_E_HIP; }
+    if (cfg->device >= 0) { if (hipSetDevice(cfg->device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return TWX_E_HIP; } }
+    const ColOps* col; const RowOps* row;
+    const int f64 = cfg->precision == TWX_F64;
+    if (!choose_split(N, f64, &col, &row)) {
+        char b[200]; snprintf(b, sizeof b, "no compiled plan pair N1*N2 = %lld (see DESIGN.md §plans)", N);
+        g_create_err = b; return TWX_E_SIZE;
+    }
+    CtxBase* c = f64 ? static_cast<CtxBase*>(new Ctx<double>()) : static_cast<CtxBase*>(new Ctx<float>());
+    c->cfg = *cfg; c->N = N; c->N1 = col->L; c->N2 = row->L; c->col = col; c->row = row;
+    (void)hipGetDevice(&c->dev);
+    int rc = c->init();
+    if (rc) { g_create_err = c->err; delete c; return rc; }
+    c->cfg.chips = nullptr;
+    *out = new twx_ctx{c};
+    return TWX_OK;
+}
+
+void twx_destroy(twx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->impl->dev);
+    (void)hipStreamSynchronize(ctx->impl->stream);
+    delete ctx->impl;
+    delete ctx;
+}
+
+int twx_get_info(const twx_ctx* ctx, twx_info* info) {
+    if (!ctx || !info) return TWX_E_ARG;
+    const CtxBase* c = ctx->impl;
+    info->n = c->N; info->n1 = c->N1; info->n2 = c->N2; info->nphase = c->R; info->batch = c->B;
+    info->precision = c->cfg.precision; info->col_w = c->col->W; info->device_bytes = c->dev_bytes;
+    return TWX_OK;
+}
+
+int twx_process_windows_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_windows, int32_t n_channels, int32_t channel,
+                            const twx_band* band, const double* df, twx_result* out_dev) {
+    if (!ctx) return TWX_E_ARG;
+    CtxBase* c = ctx->impl;
+    if (!iq_dev || !out_dev || n_windows < 0 || n_channels < 1 || channel < 0 || channel >= n_channels) return c->fail(TWX_E_ARG, "bad argument");
+    (void)hipSetDevice(c->dev);
+    return c->process(iq_dev, n_windows, n_channels, channel, band, df, out_dev);
+}
+
+int twx_synchronize(twx_ctx* ctx) {
+    if (!ctx) return TWX_E_ARG;
+    hipError_t e = hipStreamSynchronize(ctx->impl->stream);
+    if (e != hipSuccess) return ctx->impl->fail(TWX_E_HIP, hipGetErrorString(e));
+    return TWX_OK;
+}
+void* twx_stream(twx_ctx* ctx) { return ctx ? (void*)ctx->impl->stream : nullptr; }
+
+int twx_process_windows(twx_ctx* ctx, const int16_t* iq, int64_t n_windows, int32_t n_channels, int32_t channel,
+                        const twx_band* band, const double* df, twx_result* out) {
+    if (!ctx) return TWX_E_ARG;
+    CtxBase* c = ctx->impl;
+    if (!iq || !out || n_windows < 0 || n_channels < 1 || channel < 0 || channel >= n_channels) return c->fail(TWX_E_ARG, "bad argument");
+    if (n_windows == 0) return TWX_OK;
+    (void)hipSetDevice(c->dev);
+    // stage the capture in chunks of the batch size so host captures of any length fit
+    const long long chunk = c->B;
+    const size_t win_bytes = (size_t)c->N * n_channels * 4;
+    void* d_in = nullptr; twx_result* d_res = nullptr;
+    if (hipMalloc(&d_in, win_bytes * chunk) != hipSuccess) return c->fail(TWX_E_NOMEM, "staging buffer allocation failed");
+    if (hipMalloc((void**)&d_res, sizeof(twx_result) * chunk) != hipSuccess) { (void)hipFree(d_in); return c->fail(TWX_E_NOMEM, "result buffer allocation failed"); }
+    int rc = TWX_OK;
+    for (long long w0 = 0; w0 < n_windows && rc == TWX_OK; w0 += chunk) {
+        const long long nb = std::min<long long>(chunk, n_windows - w0);
+        if (hipMemcpyAsync(d_in, (const char*)iq + (size_t)w0 * win_bytes, win_bytes * nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = c->fail(TWX_E_HIP, "H2D copy failed"); break; }
+        rc = c->process(d_in, nb, n_channels, channel, band, df ? df + w0 : nullptr, d_res);
+        if (rc) break;
+        if (hipMemcpyAsync(out + w0, d_res, sizeof(twx_result) * nb, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = c->fail(TWX_E_HIP, "D2H copy failed"); break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = c->fail(TWX_E_HIP, "stream synchronize failed (kernel fault?)"); break; }
+    }
+    (void)hipFree(d_in); (void)hipFree(d_res);
+    return rc;
+}
+
+int twx_fft_forward(twx_ctx* ctx, const double* in, double* out) {
+    if (!ctx || !in || !out) return TWX_E_ARG;
+    (void)hipSetDevice(ctx->impl->dev);
+    return ctx->impl->fft_forward(in, out);
+}
+int twx_get_code_spectrum(twx_ctx* ctx, double* out) {
+    if (!ctx || !out) return TWX_E_ARG;
+    (void)hipSetDevice(ctx->impl->dev);
+    return ctx->impl->code_spectrum(out);
+}
+int twx_xcorr_map(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, double df, double* out) {
+    if (!ctx || !iq || !out || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
+    (void)hipSetDevice(ctx->impl->dev);
+    return ctx->impl->xcorr_map(iq, n_channels, channel, df, out);
+}
+
+int twx_profile_reset(twx_ctx* ctx) {
+    if (!ctx) return TWX_E_ARG;
+    CtxBase* c = ctx->impl;
+    (void)hipStreamSynchronize(c->stream);
+    c->prof_collect();
+    for (int i = 0; i < PC_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; c->prof_units[i] = 0; }
+    return TWX_OK;
+}
+int twx_profile_get(twx_ctx* ctx, twx_prof_entry* entries, int32_t max_entries, int32_t* n_entries) {
+    if (!ctx || !entries || !n_entries) return TWX_E_ARG;
+    CtxBase* c = ctx->impl;
+    (void)hipStreamSynchronize(c->stream);
+    c->prof_collect();
+    int n = 0;
+    for (int i = 0; i < PC_COUNT && n < max_entries; ++i) {
+        if (!c->prof_n[i]) continue;
+        memset(&entries[n], 0, sizeof(twx_prof_entry));
+        snprintf(entries[n].name, sizeof entries[n].name, "%s", kProfNames[i]);
+        entries[n].ms_total = c->prof_ms[i]; entries[n].launches = c->prof_n[i]; entries[n].units = c->prof_units[i];
+        ++n;
+    }
+    *n_entries = n;
+    return TWX_OK;
+}
+
+int twx_lfsr_chips(int32_t bitlen, int32_t taps, int64_t n, uint8_t* out_host) {
+    if (!out_host || n < 1) return TWX_E_ARG;
+    Ctx<float> tmp;   // borrows the allocator / error plumbing only
+    if (hipStreamCreateWithFlags(&tmp.stream, hipStreamNonBlocking) != hipSuccess) { g_create_err = "no HIP device"; return TWX_E_HIP; }
+    unsigned char* d = nullptr;
+    int rc = tmp.dalloc(&d, (size_t)n);
+    if (!rc) rc = tmp.lfsr_to_device(bitlen, (unsigned)taps, n, d);
+    if (!rc && hipMemcpy(out_host, d, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = TWX_E_HIP;
+    if (rc) g_create_err = tmp.err;
+    return rc;
+}
+
+int twx_synth_capture_dev(void* out_dev, int64_t n, int64_t n0, const uint8_t* chips_dev, int64_t n_chips, int32_t sps,
+                          int32_t n_channels, const int64_t* params_host, void* stream) {
+    if (!out_dev || !chips_dev || !params_host || n_channels < 1 || n_channels > 4 || n < 0) return TWX_E_ARG;
+    SynthArgs a{};
+    for (int c = 0; c < n_channels; ++c) {
+        const int64_t* p = params_host + 8 * c;
+        a.ch[c] = SynthChan{p[0], p[1], p[2], p[3], p[4], p[5], p[6], 0};
+    }
+    const long long total = n * n_channels;
+    const unsigned blocks = (unsigned)std::min<long long>(8192, (total + 255) / 256);
+    if (!blocks) return TWX_OK;
+    hipLaunchKernelGGL(k_synth, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (short2*)out_dev, (long long)n, (long long)n0,
+                       chips_dev, (long long)n_chips, sps, n_channels, a);
+    return hipGetLastError() == hipSuccess ? TWX_OK : TWX_E_HIP;
+}
+
+void* twx_dev_alloc(size_t bytes) { void* p = nullptr; return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr; }
+void twx_dev_free(void* p) { (void)hipFree(p); }
+int twx_memcpy_h2d(void* d, const void* s, size_t b) { return hipMemcpy(d, s, b, hipMemcpyHostToDevice) == hipSuccess ? TWX_OK : TWX_E_HIP; }
+int twx_memcpy_d2h(void* d, const void* s, size_t b) { return hipMemcpy(d, s, b, hipMemcpyDeviceToHost) == hipSuccess ? TWX_OK : TWX_E_HIP; }
+
+}  // extern "C"

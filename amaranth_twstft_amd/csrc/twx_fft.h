@@ -1,0 +1,251 @@
+// twx_fft.h — mixed-radix (2/3/4/5 and their products) in-register butterflies and the
+// LDS-staged Stockham stages used by every FFT pass of the TWSTFT correlator.
+//
+// Design: a transform of length N = N1*N2 (5 000 000 = 625*8000 for the 1-s
+// window of processing/Octave/godual_ranging.m:25-28) is done as a column pass (length N1,
+// W adjacent columns per workgroup) and a row pass (length N2), each an in-LDS Stockham autosort
+// FFT whose first stage loads straight from global memory and whose last stage stores straight
+// to global memory.  All code here is plain C++ (TWX_HD = __host__ __device__) so the same
+// templates are exercised on the CPU by tests/cpu/fft_emul.cpp (thread loop emulation).
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TWX_HD __host__ __device__ __forceinline__
+#define TWX_UNROLL _Pragma("unroll")
+#else
+#define TWX_HD inline
+#define TWX_UNROLL
+#endif
+
+namespace twx {
+
+// ------------------------------------------------------------------------------------------
+// complex helpers
+// ------------------------------------------------------------------------------------------
+template <typename T> struct cpx { T x, y; };
+
+template <typename T> TWX_HD cpx<T> mk(T x, T y) { cpx<T> r; r.x = x; r.y = y; return r; }
+template <typename T> TWX_HD cpx<T> operator+(cpx<T> a, cpx<T> b) { return mk<T>(a.x + b.x, a.y + b.y); }
+template <typename T> TWX_HD cpx<T> operator-(cpx<T> a, cpx<T> b) { return mk<T>(a.x - b.x, a.y - b.y); }
+template <typename T> TWX_HD cpx<T> cmul(cpx<T> a, cpx<T> b) {
+    return mk<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+template <typename T> TWX_HD cpx<T> cmulc(cpx<T> a, cpx<T> b) {  // a * conj(b)
+    return mk<T>(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+template <typename T> TWX_HD cpx<T> cconj(cpx<T> a) { return mk<T>(a.x, -a.y); }
+template <typename T> TWX_HD cpx<T> cscale(cpx<T> a, T s) { return mk<T>(a.x * s, a.y * s); }
+template <typename T> TWX_HD T cnorm(cpx<T> a) { return a.x * a.x + a.y * a.y; }
+// multiply by -i (forward quarter turn e^{-i pi/2}) or +i
+template <typename T> TWX_HD cpx<T> mul_mi(cpx<T> a) { return mk<T>(a.y, -a.x); }
+template <typename T> TWX_HD cpx<T> mul_pi(cpx<T> a) { return mk<T>(-a.y, a.x); }
+
+// ------------------------------------------------------------------------------------------
+// compile-time trigonometry: cos/sin of 2*pi*num/den, exact octant reduction + Taylor series
+// ------------------------------------------------------------------------------------------
+constexpr double kPi = 3.14159265358979323846264338327950288;
+
+constexpr double cx_sin_small(double x) {  // |x| <= pi/4
+    double x2 = x * x, term = x, sum = x;
+    for (int k = 1; k <= 12; ++k) { term *= -x2 / double((2 * k) * (2 * k + 1)); sum += term; }
+    return sum;
+}
+constexpr double cx_cos_small(double x) {
+    double x2 = x * x, term = 1.0, sum = 1.0;
+    for (int k = 1; k <= 12; ++k) { term *= -x2 / double((2 * k - 1) * (2 * k)); sum += term; }
+    return sum;
+}
+struct cx_cs { double c, s; };
+constexpr cx_cs cx_cossin_turn(long long num, long long den) {  // angle = 2*pi*num/den
+    long long a = num % den; if (a < 0) a += den;
+    long long p = 2 * a, q = den;  // theta = pi * p / q in [0, 2pi)
+    double sc = 1.0, ss = 1.0;
+    if (p > q) { p = 2 * q - p; ss = -ss; }            // theta -> 2pi - theta
+    if (2 * p > q) { p = q - p; sc = -sc; }            // theta -> pi - theta
+    bool swap = false;
+    if (4 * p > q) { p = q - 2 * p; q = 2 * q; swap = true; }  // theta -> pi/2 - theta
+    double x = kPi * double(p) / double(q);
+    double c = cx_cos_small(x), s = cx_sin_small(x);
+    if (swap) { double t = c; c = s; s = t; }
+    return cx_cs{sc * c, ss * s};
+}
+
+// multiply by the constant W_R^E = exp(-+ 2*pi*i*E/R)  (forward: minus; INV: plus)
+template <typename T, int R, int E, bool INV> TWX_HD cpx<T> cmul_const(cpx<T> a) {
+    constexpr int e = ((E % R) + R) % R;
+    if constexpr (e == 0) {
+        return a;
+    } else if constexpr ((4 * e) % R == 0) {
+        constexpr int quarter = (4 * e) / R;  // 1,2,3
+        if constexpr (quarter == 2) return mk<T>(-a.x, -a.y);
+        else if constexpr ((quarter == 1) != INV) return mul_mi(a);
+        else return mul_pi(a);
+    } else {
+        constexpr cx_cs w = cx_cossin_turn(e, R);
+        constexpr T c = T(w.c);
+        constexpr T s = INV ? T(w.s) : T(-w.s);
+        return mk<T>(a.x * c - a.y * s, a.x * s + a.y * c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// in-register DFT of size R (natural order in, natural order out)
+// ------------------------------------------------------------------------------------------
+template <int R> struct FirstFactor {
+    static constexpr int value = (R % 4 == 0 && R > 4) ? 4 : (R % 5 == 0 && R > 5) ? 5
+                               : (R % 2 == 0 && R > 2) ? 2 : (R % 3 == 0 && R > 3) ? 3 : R;
+};
+
+template <typename T, int R, bool INV, int A = FirstFactor<R>::value> struct Bfly {
+    // composite: R = A*B, input r = A*b + a, output q = qb + B*qa
+    static constexpr int B = R / A;
+    static TWX_HD void run(cpx<T>* v) {
+        cpx<T> y[A][B];
+        TWX_UNROLL
+        for (int a = 0; a < A; ++a) {
+            cpx<T> t[B];
+            TWX_UNROLL
+            for (int b = 0; b < B; ++b) t[b] = v[A * b + a];
+            Bfly<T, B, INV>::run(t);
+            TWX_UNROLL
+            for (int qb = 0; qb < B; ++qb) y[a][qb] = t[qb];
+        }
+        twiddle_rows(y, Idx<0>{});
+        TWX_UNROLL
+        for (int qb = 0; qb < B; ++qb) {
+            cpx<T> t[A];
+            TWX_UNROLL
+            for (int a = 0; a < A; ++a) t[a] = y[a][qb];
+            Bfly<T, A, INV>::run(t);
+            TWX_UNROLL
+            for (int qa = 0; qa < A; ++qa) v[qb + B * qa] = t[qa];
+        }
+    }
+    template <int I> struct Idx {};
+    // y[a][qb] *= W_R^{a*qb}, with compile-time exponents (I enumerates a*B+qb)
+    template <int I> static TWX_HD void twiddle_rows(cpx<T> (&y)[A][B], Idx<I>) {
+        constexpr int a = I / B, qb = I % B;
+        y[a][qb] = cmul_const<T, R, a * qb, INV>(y[a][qb]);
+        twiddle_rows(y, Idx<I + 1>{});
+    }
+    static TWX_HD void twiddle_rows(cpx<T> (&)[A][B], Idx<R>) {}
+};
+
+template <typename T, bool INV> struct Bfly<T, 1, INV, 1> {
+    static TWX_HD void run(cpx<T>*) {}
+};
+template <typename T, bool INV> struct Bfly<T, 2, INV, 2> {
+    static TWX_HD void run(cpx<T>* v) {
+        cpx<T> a = v[0], b = v[1];
+        v[0] = a + b; v[1] = a - b;
+    }
+};
+template <typename T, bool INV> struct Bfly<T, 3, INV, 3> {
+    static TWX_HD void run(cpx<T>* v) {
+        constexpr T s = T(0.86602540378443864676372317075294);  // sin(2pi/3)
+        cpx<T> t1 = v[1] + v[2], t2 = v[1] - v[2];
+        cpx<T> m = mk<T>(v[0].x - T(0.5) * t1.x, v[0].y - T(0.5) * t1.y);
+        cpx<T> js = INV ? mk<T>(-s * t2.y, s * t2.x) : mk<T>(s * t2.y, -s * t2.x);  // -+ i*s*t2
+        v[0] = v[0] + t1; v[1] = m + js; v[2] = m - js;
+    }
+};
+template <typename T, bool INV> struct Bfly<T, 4, INV, 4> {
+    static TWX_HD void run(cpx<T>* v) {
+        cpx<T> a = v[0] + v[2], b = v[0] - v[2], c = v[1] + v[3], d = v[1] - v[3];
+        cpx<T> jd = INV ? mul_pi(d) : mul_mi(d);
+        v[0] = a + c; v[2] = a - c; v[1] = b + jd; v[3] = b - jd;
+    }
+};
+template <typename T, bool INV> struct Bfly<T, 5, INV, 5> {
+    static TWX_HD void run(cpx<T>* v) {
+        constexpr T c1 = T(0.30901699437494742410229341718282);   // cos(2pi/5)
+        constexpr T c2 = T(-0.80901699437494742410229341718282);  // cos(4pi/5)
+        constexpr T s1 = T(0.95105651629515357211643933337938);   // sin(2pi/5)
+        constexpr T s2 = T(0.58778525229247312916870595463907);   // sin(4pi/5)
+        cpx<T> t1 = v[1] + v[4], t2 = v[2] + v[3], t3 = v[1] - v[4], t4 = v[2] - v[3];
+        cpx<T> a1 = mk<T>(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+        cpx<T> a2 = mk<T>(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+        cpx<T> b1 = mk<T>(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+        cpx<T> b2 = mk<T>(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+        // forward: y1 = a1 - i*b1, y4 = a1 + i*b1, y2 = a2 - i*b2, y3 = a2 + i*b2
+        cpx<T> ib1 = INV ? mul_pi(b1) : mul_mi(b1);
+        cpx<T> ib2 = INV ? mul_pi(b2) : mul_mi(b2);
+        v[0] = v[0] + t1 + t2;
+        v[1] = a1 + ib1; v[4] = a1 - ib1;
+        v[2] = a2 + ib2; v[3] = a2 - ib2;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// plan: length L as a product of up to four radices (Stockham stage order)
+// ------------------------------------------------------------------------------------------
+template <int L_, int R0_, int R1_ = 1, int R2_ = 1, int R3_ = 1> struct Plan {
+    static constexpr int L = L_;
+    static constexpr int S = (R1_ == 1) ? 1 : (R2_ == 1) ? 2 : (R3_ == 1) ? 3 : 4;
+    static constexpr int radix(int s) { return s == 0 ? R0_ : s == 1 ? R1_ : s == 2 ? R2_ : R3_; }
+    static constexpr int ns(int s) {  // product of the radices before stage s
+        int p = 1;
+        for (int i = 0; i < s; ++i) p *= radix(i);
+        return p;
+    }
+    static constexpr int rmax() {
+        int m = 1;
+        for (int i = 0; i < S; ++i) m = radix(i) > m ? radix(i) : m;
+        return m;
+    }
+    static constexpr int rmin() {
+        int m = radix(0);
+        for (int i = 1; i < S; ++i) m = radix(i) < m ? radix(i) : m;
+        return m;
+    }
+    static constexpr int max_tasks = L / rmin();   // per column
+    static_assert(R0_ * R1_ * R2_ * R3_ == L_, "radices must multiply to L");
+};
+
+// ------------------------------------------------------------------------------------------
+// one tile = W columns of length-L data in LDS, element (p, c) at index pad(p)*W + c
+// ------------------------------------------------------------------------------------------
+template <class P, typename T, bool INV, int W, int PADQ> struct Tile {
+    using C = cpx<T>;
+    static constexpr int L = P::L;
+    static TWX_HD int pad(int p) { return PADQ > 0 ? p + p / (PADQ > 0 ? PADQ : 1) : p; }
+    static constexpr int lds_elems = (PADQ > 0 ? (L + (L - 1) / (PADQ > 0 ? PADQ : 1)) : L) * W;
+
+    template <int s> static constexpr int R() { return P::radix(s); }
+    template <int s> static constexpr int tasks() { return (L / P::radix(s)) * W; }  // per tile
+
+    // Stockham indexing for stage s, per-column task j in [0, L/R)
+    template <int s> static TWX_HD int in_pos(int j, int r) { return j + r * (L / P::radix(s)); }
+    template <int s> static TWX_HD int out_pos(int j, int q) {
+        constexpr int Ns = P::ns(s), Rr = P::radix(s);
+        if constexpr (Ns == 1) return j * Rr + q;
+        else if constexpr (Ns * Rr == L) return j + q * Ns;   // last stage: j < Ns
+        else return (j / Ns) * (Ns * Rr) + (j % Ns) + q * Ns;
+    }
+
+    // stage-s butterfly on v[0..R) (inputs already in natural r order, twiddled)
+    template <int s> static TWX_HD void bfly(C* v) { Bfly<T, P::radix(s), INV>::run(v); }
+
+    // read the R inputs of task (j, c) of stage s (s >= 1) from LDS and apply the stage twiddles
+    // tw = table of exp(-2*pi*i*m/L), m in [0, L)
+    template <int s> static TWX_HD void load_lds(const C* lds, const C* tw, int j, int c, C* v) {
+        constexpr int Ns = P::ns(s), Rr = P::radix(s);
+        constexpr int step = L / (Ns * Rr);
+        const int jm = (Ns * Rr == L) ? j : (j % Ns);
+        TWX_UNROLL
+        for (int r = 0; r < Rr; ++r) v[r] = lds[pad(in_pos<s>(j, r)) * W + c];
+        TWX_UNROLL
+        for (int r = 1; r < Rr; ++r) {
+            C w = tw[jm * r * step];
+            v[r] = INV ? cmulc(v[r], w) : cmul(v[r], w);
+        }
+    }
+    template <int s> static TWX_HD void store_lds(C* lds, int j, int c, const C* v) {
+        constexpr int Rr = P::radix(s);
+        TWX_UNROLL
+        for (int q = 0; q < Rr; ++q) lds[pad(out_pos<s>(j, q)) * W + c] = v[q];
+    }
+};
+
+}  // namespace twx

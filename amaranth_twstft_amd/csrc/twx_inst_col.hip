@@ -1,0 +1,51 @@
+// Instantiates the column-pass kernels of ONE plan: compile with
+//   -DTWX_PLAN='Plan<625,25,25>' -DTWX_W=16 -DTWX_NT=448
+#include <type_traits>
+#include "twx_kernels.h"
+#include "twx_plans.h"
+
+namespace twx {
+namespace {
+using P = TWX_PLAN;
+using PR = typename Rev<P>::type;
+constexpr int W = TWX_W;
+constexpr int NT = TWX_NT;
+static_assert(P::max_tasks * W <= NT, "one task per thread per stage");
+
+template <typename T, int MODE, class In>
+int launch_fwd(In in, const ColFwdArgs<T>& a, unsigned nblk, hipStream_t s) {
+    hipLaunchKernelGGL((k_col_fwd<P, T, W, MODE, In, NT>), dim3(nblk), dim3(NT), 0, s, in, a);
+    return (int)hipGetLastError();
+}
+
+template <typename T> int fwd(int mode, int intype, const void* inptr, int aux, const void* args, unsigned nblk, hipStream_t s) {
+    const ColFwdArgs<T>& a = *reinterpret_cast<const ColFwdArgs<T>*>(args);
+    if (intype == IN_I16) {
+        InI16 in{reinterpret_cast<const short2*>(inptr), aux};
+        if (mode == COL_MIX) return launch_fwd<T, COL_MIX>(in, a, nblk, s);
+        if (mode == COL_SQUARE) return launch_fwd<T, COL_SQUARE>(in, a, nblk, s);
+    } else if (intype == IN_CHIPS && mode == COL_PLAIN) {
+        InChips in{reinterpret_cast<const unsigned char*>(inptr), aux};
+        return launch_fwd<T, COL_PLAIN>(in, a, nblk, s);
+    } else if (intype == IN_C64) {
+        InCplx<double> in{reinterpret_cast<const cpx<double>*>(inptr)};
+        if (mode == COL_PLAIN) return launch_fwd<T, COL_PLAIN>(in, a, nblk, s);
+    }
+    return -1;
+}
+template <typename T> int inv(const void* args, unsigned nblk, hipStream_t s) {
+    const ColInvArgs<T>& a = *reinterpret_cast<const ColInvArgs<T>*>(args);
+    hipLaunchKernelGGL((k_col_inv<PR, T, W, NT>), dim3(nblk), dim3(NT), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+struct Reg {
+    Reg() {
+        register_col(ColOps{P::L, W, NT, 0, &fwd<float>, &inv<float>});
+#ifndef TWX_NO_F64
+        register_col(ColOps{P::L, W, NT, 1, &fwd<double>, &inv<double>});
+#endif
+    }
+} reg_instance;
+}  // namespace
+}  // namespace twx

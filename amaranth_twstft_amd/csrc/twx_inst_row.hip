@@ -1,0 +1,32 @@
+// Instantiates the row-pass kernels of ONE plan: compile with
+//   -DTWX_PLAN='Plan<8000,20,20,20>' -DTWX_NT=448 -DTWX_PADQ=20
+#include <type_traits>
+#include "twx_kernels.h"
+#include "twx_plans.h"
+
+namespace twx {
+namespace {
+using P = TWX_PLAN;
+constexpr int NT = TWX_NT;
+constexpr int PADQ = TWX_PADQ;
+static_assert(P::max_tasks <= NT, "one task per thread per stage");
+
+template <typename T> int run(int mode, const void* args, unsigned nblk, hipStream_t s) {
+    const RowArgs<T>& a = *reinterpret_cast<const RowArgs<T>*>(args);
+    if (mode == ROW_STORE) hipLaunchKernelGGL((k_row<P, T, ROW_STORE, PADQ, NT>), dim3(nblk), dim3(NT), 0, s, a);
+    else if (mode == ROW_BAND) hipLaunchKernelGGL((k_row<P, T, ROW_BAND, PADQ, NT>), dim3(nblk), dim3(NT), 0, s, a);
+    else if (mode == ROW_MID) hipLaunchKernelGGL((k_row<P, T, ROW_MID, PADQ, NT>), dim3(nblk), dim3(NT), 0, s, a);
+    else return -1;
+    return (int)hipGetLastError();
+}
+
+struct Reg {
+    Reg() {
+        register_row(RowOps{P::L, NT, 0, &run<float>});
+#ifndef TWX_NO_F64
+        register_row(RowOps{P::L, NT, 1, &run<double>});
+#endif
+    }
+} reg_instance;
+}  // namespace
+}  // namespace twx

@@ -1,0 +1,605 @@
+// twx_kernels.h — gfx950 kernels of the per-window correlator.
+//
+// One channel-window of processing/Octave/godual_ranging.m:12-49 (≡ experiments/221219_twoway/
+// processing/godual_ranging.py:18-65) is three HBM round trips over N = N1*N2 samples:
+//
+//   k_col_fwd   int16 IQ → (x-mean)·NCO (or squared) → length-N1 column FFTs → ·W_N^{k1 n2} → A[k1][n2]
+//   k_row       A[k1][:] → length-N2 FFT  (spectrum index k = k1 + N1*k2, stored [k1][k2])
+//                 BAND : |.|^2 arg-max over the carrier search band           (godual_ranging.m:14-15)
+//                 MID  : · conj(FFT(code)) → R=(2*Nint+1) phase-ramped inverse FFTs → ·W_N^{-k1 q2} → Bz[rho][k1][q2]
+//                 STORE: spectrum out (code spectrum at context creation, FFT test entry point)
+//   k_col_inv   Bz[rho][:][q2] → length-N1 inverse FFTs → |z|^2 arg-max with index R*(q1*N2+q2)+rho
+//
+// The zero-padded 3N-point inverse FFT of godual_ranging.m:27-28 is evaluated as R interleaved
+// N-point inverse FFTs of the spectrum times exp(2*pi*i*k*rho/(R*N)) (polyphase form, exact),
+// so no 3N transform and no radix-3 pass exist; k_peak re-evaluates the samples around the peak
+// in fp64 from Bz and derives the code-wipe-off SNR (godual_ranging.m:38-48) from them
+// (identity in DESIGN.md §SNR; tests/test_oracle_golden.py::test_snr_identity_used_by_device_path).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "twx_fft.h"
+#include "../../include/twstft_hip.h"
+
+namespace twx {
+
+// ------------------------------------------------------------------------------------------
+// device-side per-window records
+// ------------------------------------------------------------------------------------------
+struct WinSums {            // exact integer sums over the raw int16 window
+    long long sI, sQ;
+    unsigned long long sP;  // sum(I^2+Q^2)
+};
+template <typename T> struct ArgPart { T val; unsigned int idx; };
+template <> struct ArgPart<double> { double val; unsigned int idx; unsigned int pad; };
+
+// XCD-aware block remap: consecutive logical ids land on the same XCD (blocks b and b+8 share
+// one under round-robin dispatch; MI355X_MICROARCH.md §Workgroup dispatch). Bijective for any n.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk >> 3, rem = nblk & 7u, xcd = bid & 7u, pos = bid >> 3;
+    return xcd < rem ? xcd * (q + 1) + pos : rem * (q + 1) + (xcd - rem) * q + pos;
+}
+
+template <typename T> __device__ __forceinline__ T shfl_down_t(T v, int d) { return __shfl_down(v, d, 64); }
+__device__ __forceinline__ long long shfl_down_ll(long long v, int d) {
+    int lo = __shfl_down((int)(v & 0xffffffffll), d, 64);
+    int hi = __shfl_down((int)(v >> 32), d, 64);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// (value, index) max with "first index wins" ties — Octave max / np.argmax semantics
+// (godual_ranging.m:15,29).
+template <typename T> struct Best {
+    T val; unsigned int idx;
+    __device__ __forceinline__ void take(T v, unsigned int i) {
+        if (v > val || (v == val && i < idx)) { val = v; idx = i; }
+    }
+};
+template <typename T> __device__ __forceinline__ Best<T> wave_best(Best<T> b) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        T ov = __shfl_down(b.val, d, 64);
+        unsigned int oi = __shfl_down(b.idx, d, 64);
+        b.take(ov, oi);
+    }
+    return b;
+}
+// block-wide arg-max; result valid in thread 0. scratch: >= 2*nwaves words of T/uint
+template <typename T, int NT> __device__ __forceinline__ Best<T> block_best(Best<T> b, void* scratch) {
+    constexpr int NW = NT / 64;
+    T* sv = reinterpret_cast<T*>(scratch);
+    unsigned int* si = reinterpret_cast<unsigned int*>(sv + NW);
+    b = wave_best(b);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sv[wv] = b.val; si[wv] = b.idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < NW; ++w) b.take(sv[w], si[w]);
+    }
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------
+// input loaders (sample n of the current window → complex T)
+// ------------------------------------------------------------------------------------------
+struct InI16 {   // interleaved int16 IQ, nch channels per sample (godual_ranging.m:76-79)
+    const short2* p; int nch;
+    template <typename T> __device__ __forceinline__ cpx<T> load(long long n) const {
+        short2 s = p[n * nch];
+        return mk<T>((T)s.x, (T)s.y);
+    }
+};
+struct InChips {  // code replica: chips {0,1} held sps samples, value 2c-1 (godual_ranging.m:63-65)
+    const unsigned char* p; int sps;
+    template <typename T> __device__ __forceinline__ cpx<T> load(long long n) const {
+        return mk<T>((T)(2 * (int)p[n / sps] - 1), (T)0);
+    }
+};
+template <typename S> struct InCplx {  // complex float/double samples (processing(d,k) entry)
+    const cpx<S>* p;
+    template <typename T> __device__ __forceinline__ cpx<T> load(long long n) const {
+        cpx<S> s = p[n];
+        return mk<T>((T)s.x, (T)s.y);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// k_sums: exact integer statistics of a raw int16 window (mean removal godual_ranging.m:80,
+// power terms of :46).  grid = (chunks, windows)
+// ------------------------------------------------------------------------------------------
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_sums(const short2* __restrict__ in, long long win_stride /*short2 units*/,
+                                              int nch, long long n, WinSums* __restrict__ sums) {
+    const int b = blockIdx.y;
+    const short2* p = in + (long long)b * win_stride;
+    long long sI = 0, sQ = 0;
+    unsigned long long sP = 0;
+    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per, hi = min(n, lo + per);
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        short2 s = p[i * nch];
+        sI += s.x; sQ += s.y;
+        sP += (unsigned long long)((int)s.x * (int)s.x + (int)s.y * (int)s.y);
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        sI += shfl_down_ll(sI, d);
+        sQ += shfl_down_ll(sQ, d);
+        sP += (unsigned long long)shfl_down_ll((long long)sP, d);
+    }
+    __shared__ long long sh[3][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][wv] = sI; sh[1][wv] = sQ; sh[2][wv] = (long long)sP; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sI = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        sQ = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        sP = (unsigned long long)(sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3]);
+        atomicAdd((unsigned long long*)&sums[b].sI, (unsigned long long)sI);
+        atomicAdd((unsigned long long*)&sums[b].sQ, (unsigned long long)sQ);
+        atomicAdd(&sums[b].sP, sP);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_df_tables: (optionally) finish the coarse carrier estimate, then build the per-window NCO
+// tables  E1[n1] = exp(-2*pi*i*df*n1*N2/fs),  E2[n2] = exp(-2*pi*i*df*n2/fs)
+// (lo=exp(-j*2*pi*df*temps), godual_ranging.m:17 with temps=[0:N-1]/fs :72).  grid = windows
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_df_tables(int estimate, const ArgPart<T>* __restrict__ part, int nparts,
+                                                   double* __restrict__ dfv, long long* __restrict__ dfidx,
+                                                   double fs, long long n, int n1, int n2,
+                                                   cpx<T>* __restrict__ e1, cpx<T>* __restrict__ e2) {
+    const int b = blockIdx.x;
+    __shared__ double s_df;
+    __shared__ char scratch[64];
+    if (estimate) {
+        Best<T> best; best.val = T(-1); best.idx = 0xffffffffu;
+        for (int i = threadIdx.x; i < nparts; i += 256) best.take(part[(long long)b * nparts + i].val, part[(long long)b * nparts + i].idx);
+        best = block_best<T, 256>(best, scratch);
+        if (threadIdx.x == 0) {
+            // freq=linspace(-fs/2,fs/2,N); df=freq(idx)/2  (godual_ranging.m:15,73; numpy linspace
+            // arithmetic: start + i*step, endpoint exact) — separate mul/add, no FMA contraction
+            const long long i = best.idx;
+            const double step = fs / (double)(n - 1);
+            double f = (i == n - 1) ? fs / 2 : __dadd_rn(__dmul_rn((double)i, step), -fs / 2);
+            s_df = f / 2;
+            dfv[b] = s_df;
+            dfidx[b] = i;
+        }
+    } else if (threadIdx.x == 0) {
+        s_df = dfv[b];
+        dfidx[b] = -1;
+    }
+    __syncthreads();
+    const double fn = s_df / fs;   // cycles per sample
+    for (int i = threadIdx.x; i < n1 + n2; i += 256) {
+        double ph;
+        if (i < n1) ph = fn * ((double)i * (double)n2); else ph = fn * (double)(i - n1);
+        ph -= rint(ph);
+        double s, c;
+        sincospi(-2.0 * ph, &s, &c);
+        if (i < n1) e1[(long long)b * n1 + i] = mk<T>((T)c, (T)s);
+        else e2[(long long)b * n2 + (i - n1)] = mk<T>((T)c, (T)s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_col_fwd: first pass of the forward transform
+// ------------------------------------------------------------------------------------------
+enum { COL_MIX = 0, COL_SQUARE = 1, COL_PLAIN = 2 };
+
+template <typename T> struct ColFwdArgs {
+    long long in_win_stride;        // elements of the input type between windows
+    const WinSums* sums;            // per window (MIX/SQUARE with mean removal) or nullptr
+    int remove_mean;
+    long long n;                    // N = n1*n2
+    int n2, ntiles, nwin;
+    const cpx<T>* e1; const cpx<T>* e2;   // per-window NCO tables (MIX)
+    const cpx<T>* tw1;              // exp(-2 pi i m/N1)
+    const cpx<T>* ta; const cpx<T>* tb; int tshift;  // exp(-2 pi i m/N) two-level: m = a<<tshift | b
+    cpx<T>* out;                    // A[b][k1][n2]
+};
+
+template <class P1, typename T, int W, int MODE, class In, int NT>
+__global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
+    using TL = Tile<P1, T, false, W, 0>;
+    using C = cpx<T>;
+    constexpr int S = P1::S;
+    __shared__ C lds[TL::lds_elems];
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = logical / a.ntiles, tile = logical % a.ntiles;
+    const int c0 = tile * W;
+    const int tid = threadIdx.x;
+    In win = in; win.p += (long long)b * a.in_win_stride;
+    T mx = 0, my = 0;
+    if (MODE != COL_PLAIN && a.remove_mean) {
+        WinSums s = a.sums[b];
+        mx = (T)((double)s.sI / (double)a.n);
+        my = (T)((double)s.sQ / (double)a.n);
+    }
+    C v[P1::rmax()];
+    // ---- stage 0: global → registers
+    {
+        constexpr int R = P1::radix(0);
+        if (tid < TL::template tasks<0>()) {
+            const int j = tid / W, c = tid % W;
+            C e2c = mk<T>(1, 0);
+            if (MODE == COL_MIX) e2c = a.e2[(long long)b * a.n2 + c0 + c];
+            TWX_UNROLL
+            for (int r = 0; r < R; ++r) {
+                const int n1 = TL::template in_pos<0>(j, r);
+                C x = win.template load<T>((long long)n1 * a.n2 + c0 + c);
+                x.x -= mx; x.y -= my;
+                if (MODE == COL_MIX) {
+                    C e = cmul(a.e1[(long long)b * P1::L + n1], e2c);
+                    x = cmul(x, e);
+                } else if (MODE == COL_SQUARE) {
+                    x = mk<T>(x.x * x.x - x.y * x.y, T(2) * x.x * x.y);
+                }
+                v[r] = x;
+            }
+            TL::template bfly<0>(v);
+            if (S > 1) TL::template store_lds<0>(lds, j, c, v);
+        }
+    }
+    if (S > 1) __syncthreads();
+    if constexpr (S > 2) {
+        if (tid < TL::template tasks<1>()) { TL::template load_lds<1>(lds, a.tw1, tid / W, tid % W, v); TL::template bfly<1>(v); }
+        __syncthreads();
+        if (tid < TL::template tasks<1>()) TL::template store_lds<1>(lds, tid / W, tid % W, v);
+        __syncthreads();
+    }
+    if constexpr (S > 3) {
+        if (tid < TL::template tasks<2>()) { TL::template load_lds<2>(lds, a.tw1, tid / W, tid % W, v); TL::template bfly<2>(v); }
+        __syncthreads();
+        if (tid < TL::template tasks<2>()) TL::template store_lds<2>(lds, tid / W, tid % W, v);
+        __syncthreads();
+    }
+    // ---- last stage: registers → ·W_N^{k1 n2} → global
+    {
+        constexpr int s = S - 1;
+        constexpr int R = P1::radix(s);
+        if (tid < TL::template tasks<s>()) {
+            const int j = tid / W, c = tid % W;
+            if (S > 1) { TL::template load_lds<s>(lds, a.tw1, j, c, v); TL::template bfly<s>(v); }
+            const unsigned n2i = c0 + c;
+            const unsigned mask = (1u << a.tshift) - 1u;
+            C* out = a.out + (long long)b * a.n;
+            TWX_UNROLL
+            for (int q = 0; q < R; ++q) {
+                const unsigned k1 = TL::template out_pos<s>(j, q);
+                const unsigned m = k1 * n2i;
+                C w = cmul(a.ta[m >> a.tshift], a.tb[m & mask]);
+                out[(long long)k1 * a.n2 + n2i] = cmul(v[q], w);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_row: second pass of the forward transform with a fused epilogue
+// ------------------------------------------------------------------------------------------
+enum { ROW_STORE = 0, ROW_BAND = 1, ROW_MID = 2 };
+
+template <typename T> struct RowArgs {
+    long long n; int n1, nwin;
+    const cpx<T>* A;                 // [b][k1][n2]
+    const cpx<T>* tw2;               // exp(-2 pi i m/N2)
+    // STORE
+    cpx<T>* spec_out;                // [b][k1][k2]
+    int conj_out; int hamming;       // code-spectrum options (main.cpp:717-719 window)
+    // BAND
+    long long band_lo, band_hi;      // inclusive, indices of the fftshifted spectrum
+    ArgPart<T>* part;                // [b][n1]
+    // MID
+    const cpx<T>* cspec;             // conj(FFT(code)) in [k1][k2] layout
+    const cpx<T>* ramp2;             // [R][N2]: exp(+2 pi i rho k2s/(R N2)), k2s signed
+    const cpx<T>* ramp1;             // [R][N1]: exp(+2 pi i rho k1/(R N))
+    int nphase;                      // R = 2*Nint+1
+    T scale;                         // power of two applied to the product (range safety)
+    const cpx<T>* ta; const cpx<T>* tb; int tshift;
+    cpx<T>* Bz;                      // [b][rho][k1][q2]
+    cpx<T>* dc;                      // [b]  X[0] of the window (mean(y) for puissance, :46)
+};
+
+// reverse of a plan (inverse transform consumes the forward's last-stage register layout)
+template <class P> struct Rev;
+template <int L, int R0, int R1, int R2, int R3> struct Rev<Plan<L, R0, R1, R2, R3>> {
+    using type = typename std::conditional<R1 == 1, Plan<L, R0>,
+                 typename std::conditional<R2 == 1, Plan<L, R1, R0>,
+                 typename std::conditional<R3 == 1, Plan<L, R2, R1, R0>, Plan<L, R3, R2, R1, R0>>::type>::type>::type;
+};
+
+// middle stages (1 .. S-2) of an in-LDS transform, registers v, in place
+template <class TL, class P, typename T, int s, int NT> struct MidStages {
+    static __device__ __forceinline__ void run(cpx<T>* lds, const cpx<T>* tw, cpx<T>* v, int tid) {
+        if constexpr (s < P::S - 1) {
+            if (tid < TL::template tasks<s>()) { TL::template load_lds<s>(lds, tw, tid, 0, v); TL::template bfly<s>(v); }
+            __syncthreads();
+            if (tid < TL::template tasks<s>()) TL::template store_lds<s>(lds, tid, 0, v);
+            __syncthreads();
+            MidStages<TL, P, T, s + 1, NT>::run(lds, tw, v, tid);
+        }
+    }
+};
+
+template <class P2, typename T, int MODE, int PADQ, int NT>
+__global__ __launch_bounds__(NT) void k_row(RowArgs<T> a) {
+    using C = cpx<T>;
+    using TF = Tile<P2, T, false, 1, PADQ>;
+    using PR = typename Rev<P2>::type;
+    using TI = Tile<PR, T, true, 1, PADQ>;
+    constexpr int S = P2::S;
+    constexpr int N2 = P2::L;
+    constexpr int RL = P2::radix(S - 1);          // forward last radix == inverse first radix
+    static_assert(S >= 2, "row plans need >= 2 stages");
+    __shared__ C lds[TF::lds_elems];
+    __shared__ char red[128];
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int k1 = logical / a.nwin, b = logical % a.nwin;   // same k1 of all windows adjacent → shared code-spectrum row
+    const int tid = threadIdx.x;
+    const C* row = a.A + (long long)b * a.n + (long long)k1 * N2;
+    C v[P2::rmax()];
+    // ---- forward stage 0 (global → regs → LDS)
+    {
+        constexpr int R = P2::radix(0);
+        if (tid < TF::template tasks<0>()) {
+            TWX_UNROLL
+            for (int r = 0; r < R; ++r) v[r] = row[TF::template in_pos<0>(tid, r)];
+            TF::template bfly<0>(v);
+            TF::template store_lds<0>(lds, tid, 0, v);
+        }
+    }
+    __syncthreads();
+    MidStages<TF, P2, T, 1, NT>::run(lds, a.tw2, v, tid);
+    // ---- forward last stage: v[q] = X[k1 + N1*k2], k2 = tid + q*(N2/RL)
+    const bool act = tid < TF::template tasks<S - 1>();
+    if (act) { TF::template load_lds<S - 1>(lds, a.tw2, tid, 0, v); TF::template bfly<S - 1>(v); }
+
+    if constexpr (MODE == ROW_STORE) {
+        if (act) {
+            C* out = a.spec_out + (long long)b * a.n + (long long)k1 * N2;
+            TWX_UNROLL
+            for (int q = 0; q < RL; ++q) {
+                const int k2 = TF::template out_pos<S - 1>(tid, q);
+                C x = v[q];
+                if (a.conj_out) x = cconj(x);
+                if (a.hamming) {
+                    const double k = (double)k1 + (double)a.n1 * (double)k2;
+                    x = cscale(x, (T)(0.54 - 0.46 * cospi(2.0 * k / (double)(a.n - 1))));
+                }
+                out[k2] = x;
+            }
+        }
+    } else if constexpr (MODE == ROW_BAND) {
+        // d2=fftshift(abs(fft(d.^2))); [~,df]=max(d2(k))   (godual_ranging.m:14-15)
+        Best<T> best; best.val = T(-1); best.idx = 0xffffffffu;
+        if (act) {
+            const long long half = a.n / 2;   // fftshift: shifted[i] = F[(i + ceil(N/2)) mod N]; N even on this path
+            TWX_UNROLL
+            for (int q = 0; q < RL; ++q) {
+                const int k2 = TF::template out_pos<S - 1>(tid, q);
+                long long k = (long long)k1 + (long long)a.n1 * k2;
+                long long i = k - (a.n - half); if (i < 0) i += a.n;   // inverse of k = (i + N - half) mod N
+                if (i >= a.band_lo && i <= a.band_hi) best.take(cnorm(v[q]), (unsigned int)i);
+            }
+        }
+        best = block_best<T, NT>(best, red);
+        if (tid == 0) { ArgPart<T> p; p.val = best.val; p.idx = best.idx; a.part[(long long)b * a.n1 + k1] = p; }
+    } else {
+        // ---- MID: product with the code spectrum, R phase-ramped inverse transforms
+        C pr[RL];
+        if (act) {
+            const C* cs = a.cspec + (long long)k1 * N2;
+            if (k1 == 0 && tid == 0) a.dc[b] = v[0];
+            TWX_UNROLL
+            for (int q = 0; q < RL; ++q) {
+                const int k2 = TF::template out_pos<S - 1>(tid, q);
+                pr[q] = cscale(cmul(v[q], cs[k2]), a.scale);      // ffty.*fcode  (godual_ranging.m:26)
+            }
+        }
+        const unsigned mask = (1u << a.tshift) - 1u;
+        for (int rho = 0; rho < a.nphase; ++rho) {
+            __syncthreads();   // previous transform's LDS reads are done
+            if (tid < TI::template tasks<0>()) {
+                if (rho == 0) {
+                    TWX_UNROLL
+                    for (int r = 0; r < RL; ++r) v[r] = pr[r];
+                } else {
+                    const C r1 = a.ramp1[(long long)rho * a.n1 + k1];
+                    const C* r2 = a.ramp2 + (long long)rho * N2;
+                    TWX_UNROLL
+                    for (int r = 0; r < RL; ++r) v[r] = cmul(pr[r], cmul(r2[TI::template in_pos<0>(tid, r)], r1));
+                }
+                TI::template bfly<0>(v);
+                TI::template store_lds<0>(lds, tid, 0, v);
+            }
+            __syncthreads();
+            MidStages<TI, PR, T, 1, NT>::run(lds, a.tw2, v, tid);
+            if (tid < TI::template tasks<S - 1>()) {
+                constexpr int RI = PR::radix(S - 1);
+                TI::template load_lds<S - 1>(lds, a.tw2, tid, 0, v);
+                TI::template bfly<S - 1>(v);
+                C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
+                TWX_UNROLL
+                for (int q = 0; q < RI; ++q) {
+                    const unsigned q2 = TI::template out_pos<S - 1>(tid, q);
+                    const unsigned m = (unsigned)k1 * q2;
+                    C w = cmul(a.ta[m >> a.tshift], a.tb[m & mask]);
+                    out[q2] = cmulc(v[q], w);                      // · W_N^{-k1 q2}
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_col_inv: last pass of the inverse transform fused with [~,indice]=max(abs(prnmap))
+// (godual_ranging.m:29).  grid = ntiles * R * windows
+// ------------------------------------------------------------------------------------------
+template <typename T> struct ColInvArgs {
+    long long n; int n2, ntiles, nphase, nwin;
+    const cpx<T>* Bz;        // [b][rho][k1][q2]
+    const cpx<T>* tw1;
+    ArgPart<T>* part;        // [b][rho*ntiles + tile]
+    cpx<T>* zout;            // optional full output [b][R*N] (natural interleaved order), or nullptr
+};
+
+template <class P1R, typename T, int W, int NT>
+__global__ __launch_bounds__(NT) void k_col_inv(ColInvArgs<T> a) {
+    using TL = Tile<P1R, T, true, W, 0>;
+    using C = cpx<T>;
+    constexpr int S = P1R::S;
+    __shared__ C lds[TL::lds_elems];
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = logical % a.ntiles;
+    const int rho = (logical / a.ntiles) % a.nphase;
+    const int b = logical / (a.ntiles * a.nphase);
+    const int c0 = tile * W, tid = threadIdx.x;
+    const C* src = a.Bz + ((long long)b * a.nphase + rho) * a.n;
+    C v[P1R::rmax()];
+    {
+        constexpr int R = P1R::radix(0);
+        if (tid < TL::template tasks<0>()) {
+            const int j = tid / W, c = tid % W;
+            TWX_UNROLL
+            for (int r = 0; r < R; ++r) v[r] = src[(long long)TL::template in_pos<0>(j, r) * a.n2 + c0 + c];
+            TL::template bfly<0>(v);
+            if (S > 1) TL::template store_lds<0>(lds, j, c, v);
+        }
+    }
+    if (S > 1) __syncthreads();
+    if constexpr (S > 2) {
+        if (tid < TL::template tasks<1>()) { TL::template load_lds<1>(lds, a.tw1, tid / W, tid % W, v); TL::template bfly<1>(v); }
+        __syncthreads();
+        if (tid < TL::template tasks<1>()) TL::template store_lds<1>(lds, tid / W, tid % W, v);
+        __syncthreads();
+    }
+    if constexpr (S > 3) {
+        if (tid < TL::template tasks<2>()) { TL::template load_lds<2>(lds, a.tw1, tid / W, tid % W, v); TL::template bfly<2>(v); }
+        __syncthreads();
+        if (tid < TL::template tasks<2>()) TL::template store_lds<2>(lds, tid / W, tid % W, v);
+        __syncthreads();
+    }
+    Best<T> best; best.val = T(-1); best.idx = 0xffffffffu;
+    {
+        constexpr int s = S - 1;
+        constexpr int R = P1R::radix(s);
+        if (tid < TL::template tasks<s>()) {
+            const int j = tid / W, c = tid % W;
+            if (S > 1) { TL::template load_lds<s>(lds, a.tw1, j, c, v); TL::template bfly<s>(v); }
+            TWX_UNROLL
+            for (int q = 0; q < R; ++q) {
+                const long long q1 = TL::template out_pos<s>(j, q);
+                const long long m = (q1 * a.n2 + c0 + c) * a.nphase + rho;
+                best.take(cnorm(v[q]), (unsigned int)m);
+                if (a.zout) a.zout[(long long)b * a.n * a.nphase + m] = v[q];
+            }
+        }
+    }
+    __syncthreads();   // LDS reads finished before it is reused as reduction scratch
+    best = block_best<T, NT>(best, lds);
+    if (tid == 0) {
+        ArgPart<T> p; p.val = best.val; p.idx = best.idx;
+        a.part[(long long)b * (a.ntiles * a.nphase) + rho * a.ntiles + tile] = p;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_peak: finish the arg-max, re-evaluate prnmap around the peak in fp64 from Bz, parabolic
+// correction (godual_ranging.m:29-33) and the wipe-off statistics (:38-48).  grid = windows
+// ------------------------------------------------------------------------------------------
+#define TWX_PEAK_LO (-4)
+#define TWX_PEAK_HI (7)
+#define TWX_PEAK_NP (TWX_PEAK_HI - TWX_PEAK_LO + 1)
+
+template <typename T> struct PeakArgs {
+    long long n; int n1, n2, nphase, nparts;
+    const ArgPart<T>* part;
+    const cpx<T>* Bz;
+    const cpx<double>* tw1d;     // exp(-2 pi i m/N1) in fp64
+    const WinSums* sums; int remove_mean;
+    const cpx<T>* dc;
+    const double* dfv; const long long* dfidx;
+    double inv_scale;            // undoes RowArgs::scale
+    int var_ddof, snr_rot;
+    twx_result* res;             // [b]
+};
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_peak(PeakArgs<T> a) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ char scratch[256];
+    __shared__ unsigned int s_idx;
+    __shared__ double s_z[TWX_PEAK_NP][2];
+    Best<T> best; best.val = T(-1); best.idx = 0xffffffffu;
+    for (int i = tid; i < a.nparts; i += 1024) {
+        ArgPart<T> p = a.part[(long long)b * a.nparts + i];
+        best.take(p.val, p.idx);
+    }
+    best = block_best<T, 1024>(best, scratch);
+    if (tid == 0) s_idx = best.idx;
+    __syncthreads();
+    const long long M = a.n * a.nphase;
+    const long long mstar = s_idx;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int pt = wv; pt < TWX_PEAK_NP; pt += 16) {
+        long long m = (mstar + TWX_PEAK_LO + pt) % M; if (m < 0) m += M;
+        const int rho = (int)(m % a.nphase);
+        const long long q = m / a.nphase;
+        const int q1 = (int)(q / a.n2), q2 = (int)(q % a.n2);
+        const cpx<T>* src = a.Bz + ((long long)b * a.nphase + rho) * a.n + q2;
+        double sx = 0, sy = 0;
+        for (int k1 = lane; k1 < a.n1; k1 += 64) {
+            cpx<T> v = src[(long long)k1 * a.n2];
+            cpx<double> w = a.tw1d[(int)(((long long)k1 * q1) % a.n1)];   // conj → inverse
+            sx += (double)v.x * w.x + (double)v.y * w.y;
+            sy += (double)v.y * w.x - (double)v.x * w.y;
+        }
+        for (int d = 32; d >= 1; d >>= 1) { sx += __shfl_down(sx, d, 64); sy += __shfl_down(sy, d, 64); }
+        if (lane == 0) { s_z[pt][0] = sx * a.inv_scale / (double)M; s_z[pt][1] = sy * a.inv_scale / (double)M; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        twx_result r;
+        r.indice0 = mstar;
+        const int c = -TWX_PEAK_LO;
+        for (int i = 0; i < 7; ++i) { r.zwin[i][0] = s_z[c - 3 + i][0]; r.zwin[i][1] = s_z[c - 3 + i][1]; }
+        r.xval[0] = s_z[c][0]; r.xval[1] = s_z[c][1];
+        r.xvalm1[0] = s_z[c - 1][0]; r.xvalm1[1] = s_z[c - 1][1];
+        r.xvalp1[0] = s_z[c + 1][0]; r.xvalp1[1] = s_z[c + 1][1];
+        const double am = hypot(r.xvalm1[0], r.xvalm1[1]), a0 = hypot(r.xval[0], r.xval[1]), ap = hypot(r.xvalp1[0], r.xvalp1[1]);
+        r.correction = (am - ap) / (am + ap - 2 * a0) / 2;                 // godual_ranging.m:33
+        r.df = a.dfv[b];
+        r.df_index = a.dfidx[b];
+        // wipe-off mean = sum_{i<R} prnmap[indice+rot+i] / M   
+        double mr = 0, mi = 0;
+        int ok = 1;
+        for (int i = 0; i < a.nphase; ++i) {
+            const int o = a.snr_rot + i;
+            if (o < TWX_PEAK_LO || o > TWX_PEAK_HI) { ok = 0; break; }
+            mr += s_z[c + o][0]; mi += s_z[c + o][1];
+        }
+        mr /= (double)M; mi /= (double)M;
+        const double N = (double)a.n;
+        WinSums s = a.sums[b];
+        double mI = 0, mQ = 0;
+        if (a.remove_mean) { mI = (double)s.sI / N; mQ = (double)s.sQ / N; }
+        // sum|y|^2 = sum|d-mean|^2 (|lo|=1);   mean(y) = X[0]/N
+        const double sumsq = (double)s.sP - 2.0 * (mI * (double)s.sI + mQ * (double)s.sQ) + N * (mI * mI + mQ * mQ);
+        const double ybx = (double)a.dc[b].x / N, yby = (double)a.dc[b].y / N;
+        r.puissance = (sumsq - N * (ybx * ybx + yby * yby)) / (N - a.var_ddof);          // var(y), :46
+        const double R2 = (double)a.nphase * (double)a.nphase;
+        const double sum_yint = (double)M * (sumsq / N) / R2;                             // sum|yint|^2
+        const double var = (sum_yint - (double)M * (mr * mr + mi * mi)) / ((double)M - a.var_ddof);
+        r.SNRr = ok ? mr * mr / var : nan("");
+        r.SNRi = ok ? mi * mi / var : nan("");
+        r.puissancecode = ok ? mr * mr + mi * mi : nan("");
+        r.puissancenoise = ok ? var : nan("");
+        r.status = 0; r.reserved = 0;
+        a.res[b] = r;
+    }
+}
+
+}  // namespace twx

@@ -1,0 +1,29 @@
+// twx_plans.h — registry of the compiled FFT pass kernels (one entry per plan length, per
+// precision).  Each twx_inst_*.hip translation unit instantiates the kernels of one plan and
+// registers type-erased launchers here; twx_api.hip picks N = N1*N2 from what is registered.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace twx {
+
+enum { IN_I16 = 0, IN_CHIPS = 1, IN_C32 = 2, IN_C64 = 3 };
+
+struct ColOps {
+    int L, W, NT, f64;
+    // mode: COL_*, intype: IN_*, aux: nch (IN_I16) / sps (IN_CHIPS); args: ColFwdArgs<T>*
+    int (*fwd)(int mode, int intype, const void* inptr, int aux, const void* args, unsigned nblk, hipStream_t s);
+    int (*inv)(const void* args /*ColInvArgs<T>*/, unsigned nblk, hipStream_t s);
+};
+struct RowOps {
+    int L, NT, f64;
+    int (*run)(int mode, const void* args /*RowArgs<T>*/, unsigned nblk, hipStream_t s);
+};
+
+void register_col(const ColOps& o);
+void register_row(const RowOps& o);
+const ColOps* find_col(int L, int f64);
+const RowOps* find_row(int L, int f64);
+// pick N1 (column plan) × N2 (row plan) for n at the given precision
+bool choose_split(long long n, int f64, const ColOps** col, const RowOps** row);
+
+}  // namespace twx

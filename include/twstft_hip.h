@@ -1,0 +1,152 @@
+/* twstft_hip.h — C ABI of libtwstft_hip.so, the MI355X (gfx950) implementation of the TWSTFT
+ * correlation post-processing hot path of oscimp/amaranth_twstft.
+ *
+ * The reference has no FFI seam for this path: the kernel is an inline Octave function using
+ * globals (processing/Octave/godual_ranging.m:3,12-49), restated in numpy
+ * (experiments/221219_twoway/processing/godual_ranging.py:18-65) and C++
+ * (processing/CPP/main.cpp:224-361 GoRanging::_process_method).  Each entry point below names
+ * the reference interface it replaces.  Plain pointers and sizes only; the library never throws
+ * across this boundary: every function returns 0 (TWX_OK) or a negative twx_status, and
+ * twx_last_error() gives the text.  A context is NOT thread-safe: one context per
+ * (host thread, GPU).  Host-side bindings: INTEGRATION.md (MEX / Octave / ctypes).
+ */
+#ifndef TWSTFT_HIP_H
+#define TWSTFT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TWX_ABI_VERSION 1
+
+typedef struct twx_ctx twx_ctx;
+
+typedef enum twx_status {
+    TWX_OK = 0,
+    TWX_E_ARG = -1,        /* bad argument */
+    TWX_E_SIZE = -2,       /* window length not factorable by the built plans */
+    TWX_E_HIP = -3,        /* HIP runtime error (no GPU, launch failure, …) */
+    TWX_E_NOMEM = -4,
+    TWX_E_STATE = -5
+} twx_status;
+
+/* xcorr conventions (SURVEY.md §7 "convention zoo") */
+enum { TWX_CONV_GODUAL = 0,   /* fft(y).*conj(fft(code))   godual_ranging.m:26,66            */
+       TWX_CONV_CLAUDIO = 1 };/* fft(code).*conj(fft(y))   claudio_aligned_code_ranging_separate.m:59,124 */
+enum { TWX_WIN_NONE = 0, TWX_WIN_HAMMING = 1 };   /* Hamming on fcode: processing/CPP/main.cpp:717-719 */
+enum { TWX_F32 = 0, TWX_F64 = 1 };
+enum { TWX_FLAG_PROFILE = 1 };                    /* time every kernel launch with HIP events */
+
+/* Replaces the script constants / globals `fs Nint code fcode` (godual_ranging.m:3-5,62-66),
+ * GoRanging's constructor arguments (processing/CPP/main.cpp:93-189). */
+typedef struct twx_config {
+    double fs;               /* sample rate, Hz (5e6) */
+    int32_t sps;             /* samples per chip (2: `repelems` ×2, godual_ranging.m:64) */
+    int32_t nint;            /* Nint; interpolation factor is 2*nint+1 (godual_ranging.m:5,27) */
+    const uint8_t* chips;    /* host pointer, n_chips bytes 0/1 (code file contents), or NULL … */
+    int64_t n_chips;
+    int32_t lfsr_bitlen;     /* … to generate LFSR(bitlen,taps) from seed 1 on the device      */
+    int32_t lfsr_taps;       /*   (amaranth_twstft/common.py:23-30,59-73)                       */
+    int32_t convention;      /* TWX_CONV_* */
+    int32_t window;          /* TWX_WIN_*  */
+    int32_t precision;       /* TWX_F32 / TWX_F64 */
+    int32_t var_ddof;        /* 0: numpy np.var; 1: Octave var (godual_ranging.m:44-48) */
+    int32_t snr_rot;         /* rotate offset of the wipe-off relative to the 0-based peak: -1
+                                (godual_ranging.m:43, godual_ranging.py(221219):59, main.cpp:332) */
+    int32_t device;          /* HIP device ordinal, -1 = current */
+    int32_t max_batch;       /* channel-windows per launch (0 = default) */
+    int32_t flags;           /* TWX_FLAG_* */
+    int32_t reserved[4];
+} twx_config;
+
+/* Carrier search band `k` of processing(d,k) (godual_ranging.m:83-89): inclusive range of
+ * 0-based indices into the fftshifted spectrum of d.^2 (Octave's k(1)-1 .. k(end)-1). */
+typedef struct twx_band { int64_t k_lo, k_hi; } twx_band;
+
+/* One channel-window result = the outputs of processing(d,k) (godual_ranging.m:12) plus the
+ * complex peak samples the later scripts save (`xval*`, claudio…separate.m:207). */
+typedef struct twx_result {
+    int64_t indice0;         /* 0-based arg-max in the (2*nint+1)*N grid (Octave indice = +1) */
+    double correction;       /* parabolic vertex offset, godual_ranging.m:33 */
+    double xval[2], xvalm1[2], xvalp1[2];   /* prnmap(indice), (indice-1), (indice+1): re, im */
+    double zwin[7][2];       /* prnmap(indice-3 … indice+3), circular */
+    double df;               /* carrier offset used (Hz) */
+    int64_t df_index;        /* 0-based fftshifted arg-max index of |fft(d.^2)|, -1 if df was supplied */
+    double SNRr, SNRi, puissance, puissancecode, puissancenoise;   /* godual_ranging.m:44-48 */
+    int32_t status, reserved;
+} twx_result;
+
+typedef struct twx_info {
+    int64_t n;               /* complex samples per channel-window = n_chips*sps */
+    int32_t n1, n2;          /* N = n1*n2 (column pass × row pass) */
+    int32_t nphase;          /* 2*nint+1 */
+    int32_t batch;           /* channel-windows per launch */
+    int32_t precision;
+    int32_t col_w;           /* adjacent columns per column-pass workgroup */
+    int64_t device_bytes;    /* device memory held by the context */
+} twx_info;
+
+const char* twx_strerror(int status);
+const char* twx_last_error(const twx_ctx* ctx);      /* ctx may be NULL: last create() error */
+int twx_abi_version(void);
+
+/* Build plans/twiddles, upload or generate the code and compute conj(fft(code)) once
+ * (godual_ranging.m:62-66; GoRanging::fill_fcode main.cpp:658-732). */
+int twx_create(const twx_config* cfg, twx_ctx** out);
+void twx_destroy(twx_ctx* ctx);
+int twx_get_info(const twx_ctx* ctx, twx_info* info);
+
+/* processing(d,k) over n_windows consecutive windows of a raw capture held in HOST memory.
+ * iq: little-endian int16, n_channels interleaved IQ pairs per sample ([I Q] or [I1 Q1 I2 Q2],
+ * godual_ranging.m:76-79), window w occupying samples [w*N, (w+1)*N).  `channel` selects the
+ * pair.  band != NULL: estimate df per window in that band (godual_ranging.m:14-15);
+ * band == NULL: df[w] is used (processing(d,df), claudio…separate.m:49).  The window mean is
+ * removed (godual_ranging.m:80).  out: n_windows results (host). */
+int twx_process_windows(twx_ctx* ctx, const int16_t* iq, int64_t n_windows, int32_t n_channels,
+                        int32_t channel, const twx_band* band, const double* df, twx_result* out);
+
+/* Same with the capture already resident in DEVICE memory (iq_dev) and results written to
+ * DEVICE memory (out_dev, n_windows records).  Asynchronous on the context's stream:
+ * call twx_synchronize() before reading.  df (host pointer) is copied at enqueue time. */
+int twx_process_windows_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_windows, int32_t n_channels,
+                            int32_t channel, const twx_band* band, const double* df, twx_result* out_dev);
+int twx_synchronize(twx_ctx* ctx);
+void* twx_stream(twx_ctx* ctx);                      /* hipStream_t of the context */
+
+/* Test / inspection entry points -------------------------------------------------------- */
+/* Forward FFT of n complex doubles (host, interleaved re/im) through the context's two-pass
+ * transform; out in natural order.  (Parity check of the transform vs np.fft.fft.) */
+int twx_fft_forward(twx_ctx* ctx, const double* in, double* out);
+/* conj(fft(code)) (× window) as held by the context, natural order, interleaved re/im doubles. */
+int twx_get_code_spectrum(twx_ctx* ctx, double* out);
+/* Full interpolated correlation map prnmap (godual_ranging.m:28) of ONE window: (2*nint+1)*N
+ * complex doubles (host).  Slow path for tests. */
+int twx_xcorr_map(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, double df,
+                  double* out);
+
+/* Profiling (TWX_FLAG_PROFILE): per kernel class, HIP-event time on the context's stream. */
+#define TWX_PROF_MAX 16
+typedef struct twx_prof_entry { char name[32]; double ms_total; int64_t launches; int64_t units; } twx_prof_entry;
+int twx_profile_reset(twx_ctx* ctx);
+int twx_profile_get(twx_ctx* ctx, twx_prof_entry* entries, int32_t max_entries, int32_t* n_entries);
+
+/* Device-side helpers (replica generation, synthetic captures) ---------------------------- */
+/* LFSR chips into host memory, generated on the device (common.py:59-73 semantics). */
+int twx_lfsr_chips(int32_t bitlen, int32_t taps, int64_t n, uint8_t* out_host);
+/* Integer synthetic capture generator (amaranth_twstft_amd/synth.py) writing int16 into DEVICE
+ * memory: n samples × n_channels, channel c described by params[c*8 .. c*8+7] =
+ * {delay_q8, fstep, phi0, amp, noise_gain, seed, stream, 0}; sample indices start at n0. */
+int twx_synth_capture_dev(void* out_dev, int64_t n, int64_t n0, const uint8_t* chips_dev, int64_t n_chips,
+                          int32_t sps, int32_t n_channels, const int64_t* params_host, void* stream);
+void* twx_dev_alloc(size_t bytes);
+void twx_dev_free(void* p);
+int twx_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int twx_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TWSTFT_HIP_H */
