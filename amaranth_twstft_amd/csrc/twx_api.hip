@@ -171,7 +171,7 @@ struct CtxBase {
     hipStream_t stream = nullptr;
     long long N = 0; int N1 = 0, N2 = 0, R = 1, B = 1;
     const ColOps* col = nullptr; const RowOps* row = nullptr;
-    std::vector<void*> allocs;
+    std::vector<std::pair<void*, size_t>> allocs;
     long long dev_bytes = 0;
     // profiling
     bool profile = false;
@@ -180,7 +180,7 @@ struct CtxBase {
     double prof_ms[PC_COUNT] = {0}; long long prof_n[PC_COUNT] = {0}; long long prof_units[PC_COUNT] = {0};
 
     virtual ~CtxBase() {
-        for (void* p : allocs) (void)hipFree(p);
+        for (auto& p : allocs) (void)hipFree(p.first);
         for (auto& r : prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -191,13 +191,13 @@ struct CtxBase {
         size_t bytes = std::max<size_t>(count * sizeof(U), 16);
         hipError_t e = hipMalloc(&q, bytes);
         if (e != hipSuccess) { char b[160]; snprintf(b, sizeof b, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); return fail(TWX_E_NOMEM, b); }
-        allocs.push_back(q); dev_bytes += (long long)bytes;
+        allocs.push_back({q, bytes}); dev_bytes += (long long)bytes;
         *p = reinterpret_cast<U*>(q);
         return TWX_OK;
     }
     void dfree(void* p) {
-        auto it = std::find(allocs.begin(), allocs.end(), p);
-        if (it != allocs.end()) allocs.erase(it);
+        for (auto it = allocs.begin(); it != allocs.end(); ++it)
+            if (it->first == p) { dev_bytes -= (long long)it->second; allocs.erase(it); break; }
         (void)hipFree(p);
     }
     hipEvent_t get_event() {
@@ -239,12 +239,29 @@ template <typename T> static void host_twiddle(std::vector<cpx<T>>& v, long long
     }
 }
 
+
+// StageTabs<P> entries for radices rad[0..S) (see twx_fft.h): tab[s][d][r][x] = exp(-2 pi i x r/den(s,d))
+template <typename T> static void host_stage_tabs(std::vector<cpx<T>>& v, int S, const int* rad) {
+    v.clear();
+    const long double tp = 2.0L * 3.14159265358979323846264338327950288L;
+    for (int s = 1; s < S; ++s)
+        for (int d = 0; d < s; ++d) {
+            long long den = rad[s];
+            for (int i = d; i < s; ++i) den *= rad[i];
+            for (int r = 0; r < rad[s]; ++r)
+                for (int x = 0; x < rad[d]; ++x) {
+                    const long double a = tp * (long double)(((long long)x * r) % den) / (long double)den;
+                    v.push_back(mk<T>((T)cosl(a), (T)(-sinl(a))));
+                }
+        }
+}
+
 template <typename T> struct Ctx : CtxBase {
     using C = cpx<T>;
     int tshift = 11;
     double scale_pow2 = 1.0;
     // tables
-    C *tw1 = nullptr, *tw2 = nullptr, *ta = nullptr, *tb = nullptr, *ramp1 = nullptr, *ramp2 = nullptr;
+    C *tw1 = nullptr, *stab_f = nullptr, *stab_i = nullptr, *ea = nullptr, *eb = nullptr, *ta = nullptr, *tb = nullptr, *ramp1 = nullptr;
     cpx<double>* tw1d = nullptr;
     C* cspec = nullptr;
     unsigned char* chips_dev = nullptr;
@@ -265,7 +282,13 @@ template <typename T> struct Ctx : CtxBase {
     int make_tables() {
         std::vector<C> h;
         host_twiddle<T>(h, N1, 1, N1, -1); if (int rc = upload(&tw1, h)) return rc;
-        host_twiddle<T>(h, N2, 1, N2, -1); if (int rc = upload(&tw2, h)) return rc;
+        {
+            int rr[4] = {row->R[0], row->R[1], row->R[2], row->R[3]};
+            host_stage_tabs<T>(h, row->S, rr); if (int rc = upload(&stab_f, h)) return rc;
+            int ri[4] = {1, 1, 1, 1};
+            for (int i = 0; i < row->S; ++i) ri[i] = row->R[row->S - 1 - i];
+            host_stage_tabs<T>(h, row->S, ri); if (int rc = upload(&stab_i, h)) return rc;
+        }
         tshift = 1; while ((2ll << (2 * tshift)) <= N) ++tshift;     // 2^tshift ≈ sqrt(N)
         host_twiddle<T>(h, (N >> tshift) + 1, 1ll << tshift, N, -1); if (int rc = upload(&ta, h)) return rc;
         host_twiddle<T>(h, 1ll << tshift, 1, N, -1); if (int rc = upload(&tb, h)) return rc;
@@ -273,22 +296,29 @@ template <typename T> struct Ctx : CtxBase {
         host_twiddle<double>(hd, N1, 1, N1, -1); if (int rc = upload(&tw1d, hd)) return rc;
         // interpolation phase ramps exp(+2 pi i rho k/(R N)), k signed, split k = k1 + N1*k2:
         //   ramp1[rho][k1] = exp(+2 pi i rho k1/(R N)),  ramp2[rho][k2] = exp(+2 pi i rho k2s/(R N2))
-        std::vector<C> r1((size_t)R * N1), r2((size_t)R * N2);
+        const int RL = row->R[row->S - 1], NSL = N2 / RL;
+        std::vector<C> r1((size_t)R * N1), hea((size_t)R * NSL), heb((size_t)R * 2 * RL);
         const long double tp = 2.0L * 3.14159265358979323846264338327950288L;
         for (int rho = 0; rho < R; ++rho) {
             for (int k1 = 0; k1 < N1; ++k1) {
                 long double a = tp * (long double)(((__int128)rho * k1) % ((__int128)R * N)) / ((long double)R * (long double)N);
                 r1[(size_t)rho * N1 + k1] = mk<T>((T)cosl(a), (T)sinl(a));
             }
-            for (int k2 = 0; k2 < N2; ++k2) {
-                long long k2s = (k2 >= N2 / 2 + (N2 & 1)) ? k2 - N2 : k2;   // N even ⇒ k >= N/2 ⇔ k2 >= N2/2 (N2 even)
-                long long num = ((long long)rho * k2s) % ((long long)R * N2);
-                long double a = tp * (long double)num / ((long double)R * (long double)N2);
-                r2[(size_t)rho * N2 + k2] = mk<T>((T)cosl(a), (T)sinl(a));
+            // exp(+2 pi i rho k2s/(R N2)), k2 = j + NSL*r, k2s = k2 - N2*[2*k2 >= N2]
+            for (int j = 0; j < NSL; ++j) {
+                long double a = tp * (long double)((long long)rho * j) / ((long double)R * (long double)N2);
+                hea[(size_t)rho * NSL + j] = mk<T>((T)cosl(a), (T)sinl(a));
             }
+            for (int w = 0; w < 2; ++w)
+                for (int r = 0; r < RL; ++r) {
+                    long long num = ((long long)rho * ((long long)NSL * r - (long long)w * N2)) % ((long long)R * N2);
+                    long double a = tp * (long double)num / ((long double)R * (long double)N2);
+                    heb[((size_t)rho * 2 + w) * RL + r] = mk<T>((T)cosl(a), (T)sinl(a));
+                }
         }
+        if (int rc = upload(&ea, hea)) return rc;
+        if (int rc = upload(&eb, heb)) return rc;
         if (int rc = upload(&ramp1, r1)) return rc;
-        if (int rc = upload(&ramp2, r2)) return rc;
         return TWX_OK;
     }
 
@@ -297,12 +327,13 @@ template <typename T> struct Ctx : CtxBase {
         if (int rc = dalloc(&cspec, (size_t)N)) return rc;
         const ColOps* c64 = find_col(N1, 1); const RowOps* r64 = find_row(N2, 1);
         const bool use64 = !std::is_same<T, double>::value && c64 && r64 && c64->W == col->W;
-        if (std::is_same<T, double>::value || !use64) return code_spectrum_T<T>(cspec, col, row, tw1, tw2, ta, tb);
+        if (std::is_same<T, double>::value || !use64) return code_spectrum_T<T>(cspec, col, row, tw1, stab_f, ta, tb);
         // temporary fp64 tables and buffers
         cpx<double>*t1 = nullptr, *t2 = nullptr, *tad = nullptr, *tbd = nullptr, *spec = nullptr;
+        int rr[4] = {r64->R[0], r64->R[1], r64->R[2], r64->R[3]};
         std::vector<cpx<double>> h;
         host_twiddle<double>(h, N1, 1, N1, -1); if (int rc = upload(&t1, h)) return rc;
-        host_twiddle<double>(h, N2, 1, N2, -1); if (int rc = upload(&t2, h)) return rc;
+        host_stage_tabs<double>(h, r64->S, rr); if (int rc = upload(&t2, h)) return rc;
         host_twiddle<double>(h, (N >> tshift) + 1, 1ll << tshift, N, -1); if (int rc = upload(&tad, h)) return rc;
         host_twiddle<double>(h, 1ll << tshift, 1, N, -1); if (int rc = upload(&tbd, h)) return rc;
         if (int rc = dalloc(&spec, (size_t)N)) return rc;
@@ -310,9 +341,7 @@ template <typename T> struct Ctx : CtxBase {
         hipLaunchKernelGGL((k_convert<double, T>), dim3(1024), dim3(256), 0, stream, spec, cspec, N);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
-        long long before = dev_bytes;
         dfree(t1); dfree(t2); dfree(tad); dfree(tbd); dfree(spec);
-        dev_bytes = before - (long long)((N1 + N2 + (N >> tshift) + 1 + (1ll << tshift) + N) * sizeof(cpx<double>));
         return TWX_OK;
     }
     template <typename U>
@@ -325,13 +354,11 @@ template <typename T> struct Ctx : CtxBase {
         ca.e1 = nullptr; ca.e2 = nullptr; ca.tw1 = t1; ca.ta = tad; ca.tb = tbd; ca.tshift = tshift; ca.out = tmp;
         if (c->fwd(COL_PLAIN, IN_CHIPS, chips_dev, cfg.sps, &ca, (unsigned)ca.ntiles, stream)) return fail(TWX_E_HIP, "code col pass launch failed");
         RowArgs<U> ra{};
-        ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = tmp; ra.tw2 = t2; ra.spec_out = out;
+        ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = tmp; ra.stab_f = t2; ra.stab_i = t2; ra.spec_out = out;
         ra.conj_out = 1; ra.hamming = (cfg.window == TWX_WIN_HAMMING);
         if (r->run(ROW_STORE, &ra, (unsigned)N1, stream)) return fail(TWX_E_HIP, "code row pass launch failed");
         HIPCHK(hipStreamSynchronize(stream));
-        long long before = dev_bytes;
         dfree(tmp);
-        dev_bytes = before - (long long)(N * sizeof(cpx<U>));
         return TWX_OK;
     }
 
@@ -399,9 +426,7 @@ template <typename T> struct Ctx : CtxBase {
         hipLaunchKernelGGL(k_lfsr, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, bitlen, taps, n, seg, jd, out);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
-        long long before = dev_bytes;
         dfree(jd);
-        dev_bytes = before - (long long)(jump.size() * sizeof(unsigned));
         return TWX_OK;
     }
 
@@ -419,8 +444,8 @@ template <typename T> struct Ctx : CtxBase {
         ca.in_win_stride = (long long)N * nch; ca.sums = sums; ca.remove_mean = 1; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = nb;
         ca.e1 = e1; ca.e2 = e2; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.out = A;
         RowArgs<T> ra{};
-        ra.n = N; ra.n1 = N1; ra.nwin = nb; ra.A = A; ra.tw2 = tw2;
-        ra.part = part_band; ra.cspec = cspec; ra.ramp1 = ramp1; ra.ramp2 = ramp2; ra.nphase = R; ra.scale = (T)scale_pow2;
+        ra.n = N; ra.n1 = N1; ra.nwin = nb; ra.A = A; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.ea = ea; ra.eb = eb;
+        ra.part = part_band; ra.cspec = cspec; ra.ramp1 = ramp1; ra.nphase = R; ra.scale = (T)scale_pow2;
         ra.ta = ta; ra.tb = tb; ra.tshift = tshift; ra.Bz = Bz; ra.dc = dc;
         if (band) {
             if (band->k_lo < 0 || band->k_hi >= N || band->k_lo > band->k_hi) return fail(TWX_E_ARG, "band outside 0..N-1");
@@ -489,7 +514,7 @@ template <typename T> struct Ctx : CtxBase {
         ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = 1; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.out = tmp;
         if (col->fwd(COL_PLAIN, IN_C64, din, 0, &ca, (unsigned)ntiles, stream)) return fail(TWX_E_HIP, "col pass launch failed");
         RowArgs<T> ra{};
-        ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = tmp; ra.tw2 = tw2; ra.spec_out = spec;
+        ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = tmp; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.spec_out = spec;
         if (row->run(ROW_STORE, &ra, (unsigned)N1, stream)) return fail(TWX_E_HIP, "row pass launch failed");
         HIPCHK(hipStreamSynchronize(stream));
         std::vector<C> h((size_t)N);
@@ -499,9 +524,7 @@ template <typename T> struct Ctx : CtxBase {
                 const long long k = k1 + (long long)N1 * k2;
                 out[2 * k] = (double)h[(size_t)k1 * N2 + k2].x; out[2 * k + 1] = (double)h[(size_t)k1 * N2 + k2].y;
             }
-        long long before = dev_bytes;
         dfree(din); dfree(tmp); dfree(spec);
-        dev_bytes = before - (long long)(N * (16 + 2 * sizeof(C)));
         return TWX_OK;
     }
     int code_spectrum(double* out) override {
@@ -526,9 +549,7 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipMemcpy(h.data(), z, h.size() * sizeof(C), hipMemcpyDeviceToHost));
         const double sc = 1.0 / scale_pow2 / ((double)N * R);
         for (size_t i = 0; i < h.size(); ++i) { out[2 * i] = (double)h[i].x * sc; out[2 * i + 1] = (double)h[i].y * sc; }
-        long long before = dev_bytes;
         dfree(din); dfree(z);
-        dev_bytes = before - (long long)((size_t)N * nch * 4 + (size_t)N * R * sizeof(C));
         return TWX_OK;
     }
 };

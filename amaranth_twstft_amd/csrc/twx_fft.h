@@ -248,4 +248,56 @@ template <class P, typename T, bool INV, int W, int PADQ> struct Tile {
     }
 };
 
+// ------------------------------------------------------------------------------------------
+// compact per-stage twiddle tables (kept in LDS by the row kernels)
+//
+// Stage s (radix R_s, Ns = R_0*...*R_{s-1}) needs W_{Ns*R_s}^{jm*r}, jm = j mod Ns.  With the
+// mixed-radix digits of jm (x_0 = jm mod R_0, x_1 = (jm / R_0) mod R_1, ...) it factors into
+//   prod_d  W_{den_d}^{x_d * r},   den_d = R_s * R_d * R_{d+1} * ... * R_{s-1}
+// so every factor comes from a tiny 2-D table tab[s][d][r][x_d] (R_s x R_d entries), stored
+// r-major so that consecutive lanes (consecutive x_0) read consecutive entries.
+// ------------------------------------------------------------------------------------------
+template <class P> struct StageTabs {
+    static constexpr int off(int s, int d) {        // entries before table (s, d)
+        int o = 0;
+        for (int ss = 1; ss < P::S; ++ss)
+            for (int dd = 0; dd < ss; ++dd) {
+                if (ss == s && dd == d) return o;
+                o += P::radix(ss) * P::radix(dd);
+            }
+        return o;
+    }
+    static constexpr int total = off(P::S, 0);
+    static constexpr int den(int s, int d) {
+        int v = P::radix(s);
+        for (int i = d; i < s; ++i) v *= P::radix(i);
+        return v;
+    }
+};
+
+template <class P, typename T, bool INV, int PADQ> struct RowTile : Tile<P, T, INV, 1, PADQ> {
+    using Base = Tile<P, T, INV, 1, PADQ>;
+    using C = cpx<T>;
+    // read the inputs of task j of stage s (s >= 1) from LDS and apply twiddles from LDS tables
+    template <int s> static TWX_HD void load_lds_tab(const C* lds, const C* tabs, int j, C* v) {
+        constexpr int Ns = P::ns(s), Rr = P::radix(s);
+        const int jm = (Ns * Rr == P::L) ? j : (j % Ns);
+        int x[4]; int rem = jm;
+        TWX_UNROLL
+        for (int d = 0; d < s; ++d) { x[d] = rem % P::radix(d); rem /= P::radix(d); }
+        v[0] = lds[Base::pad(Base::template in_pos<s>(j, 0))];
+        TWX_UNROLL
+        for (int r = 1; r < Rr; ++r) {
+            C w = tabs[StageTabs<P>::off(s, 0) + r * P::radix(0) + x[0]];
+            TWX_UNROLL
+            for (int d = 1; d < s; ++d) w = cmul(w, tabs[StageTabs<P>::off(s, d) + r * P::radix(d) + x[d]]);
+            const C u = lds[Base::pad(Base::template in_pos<s>(j, r))];
+            v[r] = INV ? cmulc(u, w) : cmul(u, w);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TWX_SCHED_GROUP)
+            if (r % TWX_SCHED_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    }
+};
+
 }  // namespace twx

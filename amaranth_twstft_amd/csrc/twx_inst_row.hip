@@ -22,9 +22,9 @@ template <typename T> int run(int mode, const void* args, unsigned nblk, hipStre
 
 struct Reg {
     Reg() {
-        register_row(RowOps{P::L, NT, 0, &run<float>});
+        register_row(RowOps{P::L, NT, 0, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<float>});
 #ifndef TWX_NO_F64
-        register_row(RowOps{P::L, NT, 1, &run<double>});
+        register_row(RowOps{P::L, NT, 1, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<double>});
 #endif
     }
 } reg_instance;

@@ -281,11 +281,16 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
 // k_row: second pass of the forward transform with a fused epilogue
 // ------------------------------------------------------------------------------------------
 enum { ROW_STORE = 0, ROW_BAND = 1, ROW_MID = 2 };
+#define TWX_MAX_PHASE 5
+#ifndef TWX_ROW_WAVES
+#define TWX_ROW_WAVES 1
+#endif
 
 template <typename T> struct RowArgs {
     long long n; int n1, nwin;
     const cpx<T>* A;                 // [b][k1][n2]
-    const cpx<T>* tw2;               // exp(-2 pi i m/N2)
+    const cpx<T>* stab_f;            // StageTabs<P2> entries (forward sign)
+    const cpx<T>* stab_i;            // StageTabs<Rev<P2>> entries (forward sign; used conjugated)
     // STORE
     cpx<T>* spec_out;                // [b][k1][k2]
     int conj_out; int hamming;       // code-spectrum options (main.cpp:717-719 window)
@@ -294,11 +299,13 @@ template <typename T> struct RowArgs {
     ArgPart<T>* part;                // [b][n1]
     // MID
     const cpx<T>* cspec;             // conj(FFT(code)) in [k1][k2] layout
-    const cpx<T>* ramp2;             // [R][N2]: exp(+2 pi i rho k2s/(R N2)), k2s signed
+    // interpolation ramp exp(+2 pi i rho k2s/(R N2)), k2 = j + Ns*r, split as ea[rho][j]*eb[rho][wrap][r]
+    const cpx<T>* ea;                // [R][Ns], Ns = N2 / (last forward radix)
+    const cpx<T>* eb;                // [R][2][RL]
     const cpx<T>* ramp1;             // [R][N1]: exp(+2 pi i rho k1/(R N))
     int nphase;                      // R = 2*Nint+1
     T scale;                         // power of two applied to the product (range safety)
-    const cpx<T>* ta; const cpx<T>* tb; int tshift;
+    const cpx<T>* ta; const cpx<T>* tb; int tshift;   // exp(-2 pi i m/N), m = a<<tshift | b
     cpx<T>* Bz;                      // [b][rho][k1][q2]
     cpx<T>* dc;                      // [b]  X[0] of the window (mean(y) for puissance, :46)
 };
@@ -311,58 +318,81 @@ template <int L, int R0, int R1, int R2, int R3> struct Rev<Plan<L, R0, R1, R2, 
                  typename std::conditional<R3 == 1, Plan<L, R2, R1, R0>, Plan<L, R3, R2, R1, R0>>::type>::type>::type;
 };
 
-// middle stages (1 .. S-2) of an in-LDS transform, registers v, in place
-template <class TL, class P, typename T, int s, int NT> struct MidStages {
-    static __device__ __forceinline__ void run(cpx<T>* lds, const cpx<T>* tw, cpx<T>* v, int tid) {
+// middle stages (1 .. S-2) of an in-LDS row transform, registers v, in place
+template <class TL, class P, typename T, int s> struct MidStages {
+    static __device__ __forceinline__ void run(cpx<T>* lds, const cpx<T>* tabs, cpx<T>* v, int tid) {
         if constexpr (s < P::S - 1) {
-            if (tid < TL::template tasks<s>()) { TL::template load_lds<s>(lds, tw, tid, 0, v); TL::template bfly<s>(v); }
+            if (tid < TL::template tasks<s>()) { TL::template load_lds_tab<s>(lds, tabs, tid, v); TL::template bfly<s>(v); }
             __syncthreads();
             if (tid < TL::template tasks<s>()) TL::template store_lds<s>(lds, tid, 0, v);
             __syncthreads();
-            MidStages<TL, P, T, s + 1, NT>::run(lds, tw, v, tid);
+            MidStages<TL, P, T, s + 1>::run(lds, tabs, v, tid);
         }
     }
 };
 
 template <class P2, typename T, int MODE, int PADQ, int NT>
-__global__ __launch_bounds__(NT) void k_row(RowArgs<T> a) {
+__global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
     using C = cpx<T>;
-    using TF = Tile<P2, T, false, 1, PADQ>;
+    using TF = RowTile<P2, T, false, PADQ>;
     using PR = typename Rev<P2>::type;
-    using TI = Tile<PR, T, true, 1, PADQ>;
+    using TI = RowTile<PR, T, true, PADQ>;
     constexpr int S = P2::S;
     constexpr int N2 = P2::L;
     constexpr int RL = P2::radix(S - 1);          // forward last radix == inverse first radix
+    constexpr int NSL = N2 / RL;                  // tasks of those stages
+    constexpr bool PAL = std::is_same<P2, PR>::value;
+    constexpr int NTF = StageTabs<P2>::total, NTI = (MODE == ROW_MID && !PAL) ? StageTabs<PR>::total : 0;
+    constexpr int NEB = MODE == ROW_MID ? TWX_MAX_PHASE * 2 * RL : 0;
+    constexpr int NVC = MODE == ROW_MID ? PR::radix(S - 1) : 0;
     static_assert(S >= 2, "row plans need >= 2 stages");
-    __shared__ C lds[TF::lds_elems];
-    __shared__ char red[128];
+    __shared__ C lds[TF::lds_elems + NTF + NTI + NEB + NVC + 16];
+    C* tab_f = lds + TF::lds_elems;
+    C* tab_i = PAL ? tab_f : tab_f + NTF;
+    C* s_eb = tab_f + NTF + NTI;
+    C* s_vc = s_eb + NEB;
+    void* red = (void*)(s_vc + NVC);
     const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
     const int k1 = logical / a.nwin, b = logical % a.nwin;   // same k1 of all windows adjacent → shared code-spectrum row
     const int tid = threadIdx.x;
     const C* row = a.A + (long long)b * a.n + (long long)k1 * N2;
     C v[P2::rmax()];
-    // ---- forward stage 0 (global → regs → LDS)
+    // ---- forward stage 0 (global → regs → LDS); small tables global → LDS
     {
         constexpr int R = P2::radix(0);
         if (tid < TF::template tasks<0>()) {
             TWX_UNROLL
             for (int r = 0; r < R; ++r) v[r] = row[TF::template in_pos<0>(tid, r)];
+        }
+        for (int i = tid; i < NTF; i += NT) tab_f[i] = a.stab_f[i];
+        if constexpr (MODE == ROW_MID) {
+            if constexpr (!PAL) for (int i = tid; i < NTI; i += NT) tab_i[i] = a.stab_i[i];
+            for (int i = tid; i < a.nphase * 2 * RL; i += NT) s_eb[i] = a.eb[i];
+            // Vc[q] = conj(W_N^{k1 * q * NSLi}), NSLi = N2 / (last inverse radix)
+            constexpr int RIL = PR::radix(S - 1);
+            if (tid < RIL) {
+                const unsigned m = (unsigned)k1 * (unsigned)tid * (unsigned)(N2 / RIL);
+                s_vc[tid] = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & ((1u << a.tshift) - 1u)]));
+            }
+        }
+        if (tid < TF::template tasks<0>()) {
             TF::template bfly<0>(v);
             TF::template store_lds<0>(lds, tid, 0, v);
         }
     }
     __syncthreads();
-    MidStages<TF, P2, T, 1, NT>::run(lds, a.tw2, v, tid);
-    // ---- forward last stage: v[q] = X[k1 + N1*k2], k2 = tid + q*(N2/RL)
-    const bool act = tid < TF::template tasks<S - 1>();
-    if (act) { TF::template load_lds<S - 1>(lds, a.tw2, tid, 0, v); TF::template bfly<S - 1>(v); }
+    MidStages<TF, P2, T, 1>::run(lds, tab_f, v, tid);
+    // ---- forward last stage: v[q] = X[k1 + N1*k2], k2 = tid + q*NSL
+    const bool act = tid < NSL;
+    if (act) { TF::template load_lds_tab<S - 1>(lds, tab_f, tid, v); TF::template bfly<S - 1>(v); }
+    __builtin_amdgcn_sched_barrier(0);   // keep the epilogue's global loads below the butterfly (register pressure)
 
     if constexpr (MODE == ROW_STORE) {
         if (act) {
             C* out = a.spec_out + (long long)b * a.n + (long long)k1 * N2;
             TWX_UNROLL
             for (int q = 0; q < RL; ++q) {
-                const int k2 = TF::template out_pos<S - 1>(tid, q);
+                const int k2 = tid + q * NSL;
                 C x = v[q];
                 if (a.conj_out) x = cconj(x);
                 if (a.hamming) {
@@ -376,12 +406,12 @@ __global__ __launch_bounds__(NT) void k_row(RowArgs<T> a) {
         // d2=fftshift(abs(fft(d.^2))); [~,df]=max(d2(k))   (godual_ranging.m:14-15)
         Best<T> best; best.val = T(-1); best.idx = 0xffffffffu;
         if (act) {
-            const long long half = a.n / 2;   // fftshift: shifted[i] = F[(i + ceil(N/2)) mod N]; N even on this path
+            const long long half = a.n / 2;   // shifted index i ↔ bin k = (i - floor(N/2)) mod N
             TWX_UNROLL
             for (int q = 0; q < RL; ++q) {
-                const int k2 = TF::template out_pos<S - 1>(tid, q);
+                const int k2 = tid + q * NSL;
                 long long k = (long long)k1 + (long long)a.n1 * k2;
-                long long i = k - (a.n - half); if (i < 0) i += a.n;   // inverse of k = (i + N - half) mod N
+                long long i = k - (a.n - half); if (i < 0) i += a.n;
                 if (i >= a.band_lo && i <= a.band_hi) best.take(cnorm(v[q]), (unsigned int)i);
             }
         }
@@ -389,46 +419,56 @@ __global__ __launch_bounds__(NT) void k_row(RowArgs<T> a) {
         if (tid == 0) { ArgPart<T> p; p.val = best.val; p.idx = best.idx; a.part[(long long)b * a.n1 + k1] = p; }
     } else {
         // ---- MID: product with the code spectrum, R phase-ramped inverse transforms
+        constexpr int RIL = PR::radix(S - 1);
+        constexpr int NSI = N2 / RIL;
         C pr[RL];
         if (act) {
             const C* cs = a.cspec + (long long)k1 * N2;
             if (k1 == 0 && tid == 0) a.dc[b] = v[0];
             TWX_UNROLL
-            for (int q = 0; q < RL; ++q) {
-                const int k2 = TF::template out_pos<S - 1>(tid, q);
-                pr[q] = cscale(cmul(v[q], cs[k2]), a.scale);      // ffty.*fcode  (godual_ranging.m:26)
-            }
+            for (int q = 0; q < RL; ++q)
+                pr[q] = cscale(cmul(v[q], cs[tid + q * NSL]), a.scale);      // ffty.*fcode  (godual_ranging.m:26)
         }
-        const unsigned mask = (1u << a.tshift) - 1u;
+        // per-thread output twiddle base conj(W_N^{k1*j}), j = output task index of the inverse's last stage
+        C ub = mk<T>(1, 0);
+        if (tid < NSI) {
+            const unsigned m = (unsigned)k1 * (unsigned)tid;
+            ub = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & ((1u << a.tshift) - 1u)]));
+        }
         for (int rho = 0; rho < a.nphase; ++rho) {
             __syncthreads();   // previous transform's LDS reads are done
-            if (tid < TI::template tasks<0>()) {
+            // launder the thread index: stops LICM from hoisting ~100 loop-invariant LDS/table
+            // addresses out of the rho loop (they were being spilled to scratch)
+            int lt = tid;
+            asm volatile("" : "+v"(lt));
+            if (lt < NSL) {
                 if (rho == 0) {
                     TWX_UNROLL
                     for (int r = 0; r < RL; ++r) v[r] = pr[r];
                 } else {
-                    const C r1 = a.ramp1[(long long)rho * a.n1 + k1];
-                    const C* r2 = a.ramp2 + (long long)rho * N2;
+                    const C eaj = a.ea[rho * NSL + lt];
+                    const C* ebr = s_eb + rho * 2 * RL;
                     TWX_UNROLL
-                    for (int r = 0; r < RL; ++r) v[r] = cmul(pr[r], cmul(r2[TI::template in_pos<0>(tid, r)], r1));
+                    for (int r = 0; r < RL; ++r) {
+                        const int wrap = (2 * (lt + r * NSL) >= N2) ? RL : 0;
+                        v[r] = cmul(cmul(pr[r], eaj), ebr[wrap + r]);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 TI::template bfly<0>(v);
-                TI::template store_lds<0>(lds, tid, 0, v);
+                TI::template store_lds<0>(lds, lt, 0, v);
             }
             __syncthreads();
-            MidStages<TI, PR, T, 1, NT>::run(lds, a.tw2, v, tid);
-            if (tid < TI::template tasks<S - 1>()) {
-                constexpr int RI = PR::radix(S - 1);
-                TI::template load_lds<S - 1>(lds, a.tw2, tid, 0, v);
+            MidStages<TI, PR, T, 1>::run(lds, tab_i, v, lt);
+            if (lt < NSI) {
+                TI::template load_lds_tab<S - 1>(lds, tab_i, lt, v);
                 TI::template bfly<S - 1>(v);
+                __builtin_amdgcn_sched_barrier(0);
+                const C u = cmul(ub, a.ramp1[(long long)rho * a.n1 + k1]);
                 C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
                 TWX_UNROLL
-                for (int q = 0; q < RI; ++q) {
-                    const unsigned q2 = TI::template out_pos<S - 1>(tid, q);
-                    const unsigned m = (unsigned)k1 * q2;
-                    C w = cmul(a.ta[m >> a.tshift], a.tb[m & mask]);
-                    out[q2] = cmulc(v[q], w);                      // · W_N^{-k1 q2}
-                }
+                for (int q = 0; q < RIL; ++q)
+                    out[lt + q * NSI] = cmul(cmul(v[q], u), s_vc[q]);       // · W_N^{-k1 q2} · ramp1
             }
         }
     }

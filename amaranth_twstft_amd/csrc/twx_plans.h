@@ -16,6 +16,7 @@ struct ColOps {
 };
 struct RowOps {
     int L, NT, f64;
+    int S, R[4];       // radices in forward stage order
     int (*run)(int mode, const void* args /*RowArgs<T>*/, unsigned nblk, hipStream_t s);
 };
 

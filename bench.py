@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the TWSTFT correlation hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* = one pass of ``processing(d,k)`` (processing/Octave/godual_ranging.m:12-49: coarse
+carrier estimate, NCO mix, FFT circular xcorr with ×3 interpolation, peak pick, parabolic
+refinement, wipe-off SNR) over ``--windows`` 1-second windows (5 Msps int16 IQ, 2.5 Mchip
+LFSR(22, taps 3) code = BASELINE.json configs[1]) that are already resident in HBM.  Windows are
+independent, so with N GPUs every rank processes its own shard (weak scaling) and the per-window
+results are gathered with one RCCL all_gather per step.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FS = 5e6
+BITLEN, TAPS, NCHIPS = 22, 3, 2_500_000
+N = 2 * NCHIPS
+HBM_PEAK_GBS = 8000.0
+
+# compulsory HBM bytes per input complex sample of each kernel, fp32
+ALGO_BYTES = {"k_sums": 4, "k_col_fwd_square": 12, "k_row_band": 8, "k_df_tables": 0, "k_col_fwd_mix": 12,
+              "k_row_mid": 40, "k_col_inv": 24, "k_peak": 0}
+
+
+def window_params(p: int, rank: int):
+    """Per-window synthetic parameters (channel 1)."""
+    from amaranth_twstft_amd import synth
+    g = rank * 100000 + p
+    delay = 1311765 - int(round(0.025 * g))
+    df = 1780.75 + 0.05 * math.sin(2 * math.pi * g / 600)
+    return synth.SynthParams(delay_q8=delay * 256, fstep=synth.fstep_for_df(df, FS), phi0=(g * 2654435761) & 0xFFFFFFFF,
+                             amp=200, noise_gain=synth.noise_gain_for_sigma(400.0), seed=1000 + g, stream=0), delay
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--windows", type=int, default=64, help="1-s windows per GPU per step (resident in HBM)")
+    ap.add_argument("--batch", type=int, default=0, help="channel-windows per launch (0 = library default)")
+    ap.add_argument("--workload", choices=["processing", "xcorr"], default="processing",
+                    help="processing = full processing(d,k); xcorr = df supplied (code-phase-only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from amaranth_twstft_amd import _lib as L, prn
+    from amaranth_twstft_amd.correlator import Correlator, band_godual
+    lib = L.load()
+
+    chips = prn.lfsr_chips(BITLEN, TAPS, NCHIPS)
+    cor = Correlator(chips, fs=FS, Nint=1, device=local_rank, max_batch=a.batch)
+    nwin = a.windows
+    # --- synthetic capture, generated on the device, resident in HBM
+    chips_dev = torch.from_numpy(chips).to(dev)
+    iq = torch.empty((nwin, N, 2), dtype=torch.int16, device=dev)
+    delays = []
+    for p in range(nwin):
+        sp, delay = window_params(p, rank)
+        delays.append(delay)
+        params = np.array([sp.delay_q8, sp.fstep, sp.phi0, sp.amp, sp.noise_gain, sp.seed, sp.stream, 0], dtype=np.int64)
+        L.check(lib.twx_synth_capture_dev(iq[p].data_ptr(), N, 0, chips_dev.data_ptr(), NCHIPS, 2, 1,
+                                          params.ctypes.data_as(C.c_void_p), None))
+    torch.cuda.synchronize()
+    res = torch.zeros((nwin, C.sizeof(L.twx_result)), dtype=torch.uint8, device=dev)
+    gathered = torch.zeros((world * nwin, C.sizeof(L.twx_result)), dtype=torch.uint8, device=dev) if world > 1 else None
+    band = L.twx_band(*band_godual(FS, N))
+    df_true = np.array([1780.75] * nwin, dtype=np.float64)
+
+    def step(c):
+        if a.workload == "processing":
+            L.check(lib.twx_process_windows_dev(c._h, iq.data_ptr(), nwin, 1, 0, C.byref(band), None, res.data_ptr()), c._h)
+        else:
+            L.check(lib.twx_process_windows_dev(c._h, iq.data_ptr(), nwin, 1, 0, None, df_true.ctypes.data_as(C.c_void_p),
+                                                res.data_ptr()), c._h)
+        if world > 1:
+            L.check(lib.twx_synchronize(c._h), c._h)        # results complete before RCCL reads them
+            dist.all_gather_into_tensor(gathered, res)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(cor)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(cor)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # --- correctness of what was timed: integer lags must equal the generator's delays
+    host = res.cpu().numpy().tobytes()
+    arr = (L.twx_result * nwin).from_buffer_copy(host)
+    lag_ok = all(int(arr[p].indice0) == 3 * delays[p] for p in range(nwin))
+
+    samples = world * nwin * N * a.steps
+    value = samples / dt / 1e6
+    out = {"metric": "Msamples/s correlated (1 s integrations, 2.5 Mchip PRN)", "value": round(value, 2), "unit": "Msamples/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": ("processing(d,k) full chain" if a.workload == "processing" else "xcorr, df supplied")
+                      + ": 1 s windows, 5 Msps int16 IQ, 2.5 Mchip LFSR(22,3) code, Nint=1 (configs[1])",
+                      "windows_per_gpu_per_step": nwin, "samples_per_window": N, "batch": int(cor.info.batch),
+                      "n1": int(cor.info.n1), "n2": int(cor.info.n2), "sharding": f"windows/{world}"},
+           "integer_lag_exact": bool(lag_ok)}
+
+    # --- roofline of the dominant kernel: HIP events around every launch on the library's stream
+    if rank == 0 and not a.no_roofline:
+        pc = Correlator(chips, fs=FS, Nint=1, device=local_rank, max_batch=a.batch, profile=True)
+        step_w = min(nwin, 32)
+        def prof_pass():
+            L.check(lib.twx_process_windows_dev(pc._h, iq.data_ptr(), step_w, 1, 0,
+                                                C.byref(band) if a.workload == "processing" else None,
+                                                None if a.workload == "processing" else df_true.ctypes.data_as(C.c_void_p),
+                                                res.data_ptr()), pc._h)
+        prof_pass()
+        pc.profile(reset=True)          # discard the warm-up pass
+        prof_pass()
+        prof = pc.profile()
+        kern = {k: dict(ms_avg=v["ms_total"] / v["launches"], launches=v["launches"],
+                        samples_per_launch=v["units"] / v["launches"]) for k, v in prof.items()}
+        dom = max(kern, key=lambda k: prof[k]["ms_total"])
+        byts = ALGO_BYTES[dom] * kern[dom]["samples_per_launch"]
+        ach = byts / (kern[dom]["ms_avg"] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "algorithmic_bytes_per_launch": int(byts), "avg_ms": round(kern[dom]["ms_avg"], 4)}
+        out["kernels"] = {k: {"avg_ms": round(v["ms_avg"], 4), "GB/s": round(ALGO_BYTES[k] * v["samples_per_launch"] / (v["ms_avg"] * 1e-3) / 1e9, 1)}
+                          for k, v in kern.items()}
+        tot = sum(ALGO_BYTES[k] for k in kern)
+        out["chain_GBs_algorithmic"] = round(tot * value * 1e6 / 1e9 / world, 1)
+        pc.close()
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                t = json.load(open(pmc))
+                if t.get("kernel") == dom:
+                    out["roofline"]["traffic"] = t.get("bytes_per_launch")
+            except Exception:
+                pass
+
+    # --- CPU baseline: the oracle (numpy fp64 restatement = the reference's numpy path) on one window
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import twstft_oracle as orc
+        raw = iq[0].cpu().numpy()
+        t1 = time.perf_counter()
+        code = orc.make_code(chips, 2)
+        fcode = orc.make_fcode(code)
+        freq = orc.freq_axis(FS, N)
+        k = orc.band_godual(freq)
+        temps = np.arange(N) / FS
+        t2 = time.perf_counter()
+        d = orc.deinterleave(raw, 1, 0)
+        d = d - d.mean()
+        r = orc.processing(d, k, freq, temps, fcode, code, Nint=1, fs=FS, df=None if a.workload == "processing" else 1780.75)
+        t3 = time.perf_counter()
+        out["cpu_baseline"] = {"value": round(N / (t3 - t2) / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                               "sample": f"1 window of the same workload ({N} samples, {t3 - t2:.1f} s; code spectrum setup {t2 - t1:.1f} s excluded)",
+                               "indice_matches_gpu": bool(r["indice"] == int(arr[0].indice0))}
+    if rank == 0:
+        print(json.dumps(out))
+    cor.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
