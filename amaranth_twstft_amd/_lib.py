@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtwstft_hip.so")
+LIB_PATH = os.environ.get("TWX_LIB") or os.path.join(_HERE, "libtwstft_hip.so")   # TWX_LIB: kernel-variant experiments
 
 TWX_OK = 0
 TWX_CONV_GODUAL, TWX_CONV_CLAUDIO = 0, 1

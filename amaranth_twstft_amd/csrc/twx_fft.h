@@ -23,6 +23,26 @@ namespace twx {
 // ------------------------------------------------------------------------------------------
 // complex helpers
 // ------------------------------------------------------------------------------------------
+#if defined(__clang__)
+// native 2-vectors: complex add/sub/scale map 1:1 onto v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32
+// (no register shuffles), and the swizzles of a complex multiply fold into op_sel / neg modifiers
+template <typename T> struct cpx_sel;
+template <> struct cpx_sel<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct cpx_sel<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <typename T> using cpx = typename cpx_sel<T>::type;
+template <typename T> TWX_HD cpx<T> mk(T x, T y) { cpx<T> r; r.x = x; r.y = y; return r; }
+#define TWX_CPX_OPS(T)                                                                             \
+    TWX_HD cpx<T> cmul(cpx<T> a, cpx<T> b) { cpx<T> bs; bs.x = -b.y; bs.y = b.x; return a.xx * b + a.yy * bs; }   \
+    TWX_HD cpx<T> cmulc(cpx<T> a, cpx<T> b) { cpx<T> bs; bs.x = b.y; bs.y = -b.y; return a * b.xx + a.yx * bs; }   \
+    TWX_HD cpx<T> cconj(cpx<T> a) { cpx<T> r; r.x = a.x; r.y = -a.y; return r; }                  \
+    TWX_HD cpx<T> cscale(cpx<T> a, T s) { return a * s; }                                          \
+    TWX_HD T cnorm(cpx<T> a) { return a.x * a.x + a.y * a.y; }                                     \
+    TWX_HD cpx<T> mul_mi(cpx<T> a) { cpx<T> r; r.x = a.y; r.y = -a.x; return r; }                  \
+    TWX_HD cpx<T> mul_pi(cpx<T> a) { cpx<T> r; r.x = -a.y; r.y = a.x; return r; }
+TWX_CPX_OPS(float)
+TWX_CPX_OPS(double)
+#undef TWX_CPX_OPS
+#else
 template <typename T> struct cpx { T x, y; };
 
 template <typename T> TWX_HD cpx<T> mk(T x, T y) { cpx<T> r; r.x = x; r.y = y; return r; }
@@ -40,6 +60,7 @@ template <typename T> TWX_HD T cnorm(cpx<T> a) { return a.x * a.x + a.y * a.y; }
 // multiply by -i (forward quarter turn e^{-i pi/2}) or +i
 template <typename T> TWX_HD cpx<T> mul_mi(cpx<T> a) { return mk<T>(a.y, -a.x); }
 template <typename T> TWX_HD cpx<T> mul_pi(cpx<T> a) { return mk<T>(-a.y, a.x); }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // compile-time trigonometry: cos/sin of 2*pi*num/den, exact octant reduction + Taylor series
@@ -85,7 +106,7 @@ template <typename T, int R, int E, bool INV> TWX_HD cpx<T> cmul_const(cpx<T> a)
         constexpr cx_cs w = cx_cossin_turn(e, R);
         constexpr T c = T(w.c);
         constexpr T s = INV ? T(w.s) : T(-w.s);
-        return mk<T>(a.x * c - a.y * s, a.x * s + a.y * c);
+        return cscale(a, c) + cscale(mul_pi(a), s);
     }
 }
 
@@ -145,8 +166,8 @@ template <typename T, bool INV> struct Bfly<T, 3, INV, 3> {
     static TWX_HD void run(cpx<T>* v) {
         constexpr T s = T(0.86602540378443864676372317075294);  // sin(2pi/3)
         cpx<T> t1 = v[1] + v[2], t2 = v[1] - v[2];
-        cpx<T> m = mk<T>(v[0].x - T(0.5) * t1.x, v[0].y - T(0.5) * t1.y);
-        cpx<T> js = INV ? mk<T>(-s * t2.y, s * t2.x) : mk<T>(s * t2.y, -s * t2.x);  // -+ i*s*t2
+        cpx<T> m = v[0] - cscale(t1, T(0.5));
+        cpx<T> js = INV ? cscale(mul_pi(t2), s) : cscale(mul_mi(t2), s);  // -+ i*s*t2
         v[0] = v[0] + t1; v[1] = m + js; v[2] = m - js;
     }
 };
@@ -164,10 +185,10 @@ template <typename T, bool INV> struct Bfly<T, 5, INV, 5> {
         constexpr T s1 = T(0.95105651629515357211643933337938);   // sin(2pi/5)
         constexpr T s2 = T(0.58778525229247312916870595463907);   // sin(4pi/5)
         cpx<T> t1 = v[1] + v[4], t2 = v[2] + v[3], t3 = v[1] - v[4], t4 = v[2] - v[3];
-        cpx<T> a1 = mk<T>(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
-        cpx<T> a2 = mk<T>(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
-        cpx<T> b1 = mk<T>(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
-        cpx<T> b2 = mk<T>(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+        cpx<T> a1 = v[0] + cscale(t1, c1) + cscale(t2, c2);
+        cpx<T> a2 = v[0] + cscale(t1, c2) + cscale(t2, c1);
+        cpx<T> b1 = cscale(t3, s1) + cscale(t4, s2);
+        cpx<T> b2 = cscale(t3, s2) - cscale(t4, s1);
         // forward: y1 = a1 - i*b1, y4 = a1 + i*b1, y2 = a2 - i*b2, y3 = a2 + i*b2
         cpx<T> ib1 = INV ? mul_pi(b1) : mul_mi(b1);
         cpx<T> ib2 = INV ? mul_pi(b2) : mul_mi(b2);
@@ -224,6 +245,33 @@ template <class P, typename T, bool INV, int W, int PADQ> struct Tile {
         else return (j / Ns) * (Ns * Rr) + (j % Ns) + q * Ns;
     }
 
+    // physical (padded) LDS element index of logical position p; strength-reduced forms: the
+    // r/q-dependent part is a compile-time multiple whenever the stride is a multiple of PADQ
+    template <int s> static TWX_HD int in_base(int j) { return pad(j); }
+    template <int s> static TWX_HD int in_idx(int base, int j, int r) {
+        constexpr int Tt = L / P::radix(s);
+        if constexpr (PADQ == 0) return base + r * Tt;
+        else if constexpr (Tt % (PADQ > 0 ? PADQ : 1) == 0) return base + r * (Tt + Tt / (PADQ > 0 ? PADQ : 1));
+        else return pad(j + r * Tt);
+    }
+    template <int s> static TWX_HD int out_base(int j) {
+        constexpr int Ns = P::ns(s), Rr = P::radix(s);
+        if constexpr (PADQ == 0) return out_pos<s>(j, 0);
+        else if constexpr (Ns == 1 && Rr == PADQ) return j * (Rr + 1);
+        else if constexpr (Ns * Rr == L) return pad(j);
+        else if constexpr (Ns % (PADQ > 0 ? PADQ : 1) == 0) {
+            constexpr int NR = Ns * Rr;
+            return (j / Ns) * (NR + NR / PADQ) + pad(j % Ns);
+        } else return 0;
+    }
+    template <int s> static TWX_HD int out_idx(int base, int j, int q) {
+        constexpr int Ns = P::ns(s), Rr = P::radix(s);
+        if constexpr (PADQ == 0) return base + q * Ns;
+        else if constexpr (Ns == 1 && Rr == PADQ) return base + q;
+        else if constexpr (Ns % (PADQ > 0 ? PADQ : 1) == 0) return base + q * (Ns + Ns / (PADQ > 0 ? PADQ : 1));
+        else return pad(out_pos<s>(j, q));
+    }
+
     // stage-s butterfly on v[0..R) (inputs already in natural r order, twiddled)
     template <int s> static TWX_HD void bfly(C* v) { Bfly<T, P::radix(s), INV>::run(v); }
 
@@ -233,8 +281,9 @@ template <class P, typename T, bool INV, int W, int PADQ> struct Tile {
         constexpr int Ns = P::ns(s), Rr = P::radix(s);
         constexpr int step = L / (Ns * Rr);
         const int jm = (Ns * Rr == L) ? j : (j % Ns);
+        const int ib = in_base<s>(j);
         TWX_UNROLL
-        for (int r = 0; r < Rr; ++r) v[r] = lds[pad(in_pos<s>(j, r)) * W + c];
+        for (int r = 0; r < Rr; ++r) v[r] = lds[in_idx<s>(ib, j, r) * W + c];
         TWX_UNROLL
         for (int r = 1; r < Rr; ++r) {
             C w = tw[jm * r * step];
@@ -243,8 +292,9 @@ template <class P, typename T, bool INV, int W, int PADQ> struct Tile {
     }
     template <int s> static TWX_HD void store_lds(C* lds, int j, int c, const C* v) {
         constexpr int Rr = P::radix(s);
+        const int ob = out_base<s>(j);
         TWX_UNROLL
-        for (int q = 0; q < Rr; ++q) lds[pad(out_pos<s>(j, q)) * W + c] = v[q];
+        for (int q = 0; q < Rr; ++q) lds[out_idx<s>(ob, j, q) * W + c] = v[q];
     }
 };
 
@@ -285,13 +335,14 @@ template <class P, typename T, bool INV, int PADQ> struct RowTile : Tile<P, T, I
         int x[4]; int rem = jm;
         TWX_UNROLL
         for (int d = 0; d < s; ++d) { x[d] = rem % P::radix(d); rem /= P::radix(d); }
-        v[0] = lds[Base::pad(Base::template in_pos<s>(j, 0))];
+        const int ib = Base::template in_base<s>(j);
+        v[0] = lds[Base::template in_idx<s>(ib, j, 0)];
         TWX_UNROLL
         for (int r = 1; r < Rr; ++r) {
             C w = tabs[StageTabs<P>::off(s, 0) + r * P::radix(0) + x[0]];
             TWX_UNROLL
             for (int d = 1; d < s; ++d) w = cmul(w, tabs[StageTabs<P>::off(s, d) + r * P::radix(d) + x[d]]);
-            const C u = lds[Base::pad(Base::template in_pos<s>(j, r))];
+            const C u = lds[Base::template in_idx<s>(ib, j, r)];
             v[r] = INV ? cmulc(u, w) : cmul(u, w);
 #if defined(__HIP_DEVICE_COMPILE__) && defined(TWX_SCHED_GROUP)
             if (r % TWX_SCHED_GROUP == 0) __builtin_amdgcn_sched_barrier(0);

@@ -425,9 +425,16 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
         if (act) {
             const C* cs = a.cspec + (long long)k1 * N2;
             if (k1 == 0 && tid == 0) a.dc[b] = v[0];
+            // ffty.*fcode (godual_ranging.m:26); in chunks so that the code-spectrum loads in flight
+            // do not push the kernel over the 128-VGPR budget of two workgroups per CU
+            constexpr int CH = 5;
             TWX_UNROLL
-            for (int q = 0; q < RL; ++q)
-                pr[q] = cscale(cmul(v[q], cs[tid + q * NSL]), a.scale);      // ffty.*fcode  (godual_ranging.m:26)
+            for (int q0 = 0; q0 < RL; q0 += CH) {
+                TWX_UNROLL
+                for (int q = q0; q < (q0 + CH < RL ? q0 + CH : RL); ++q)
+                    pr[q] = cscale(cmul(v[q], cs[tid + q * NSL]), a.scale);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // per-thread output twiddle base conj(W_N^{k1*j}), j = output task index of the inverse's last stage
         C ub = mk<T>(1, 0);
