@@ -92,6 +92,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 /
+    # libhsa-runtime64.so.1.  If this library pulled in /opt/rocm's copies first, a later
+    # `import torch` would find "No HIP GPUs".  Loading torch's copies first (when torch is
+    # installed) makes both users share them; hosts without torch (MATLAB/Octave MEX) are unaffected.
+    if os.environ.get("TWX_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")

@@ -1,0 +1,92 @@
+"""CPU: the C-ABI library loads and exports every symbol the header declares; host-side logic."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from amaranth_twstft_amd import _lib as L
+from amaranth_twstft_amd import correlator as cor
+from amaranth_twstft_amd import dist as D
+from oracle import twstft_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "twstft_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(twx_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    names = _header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/twstft_hip.h but not exported"
+    assert set(names) == set(L.SYMBOLS), (set(names) ^ set(L.SYMBOLS))
+    assert lib.twx_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(L.twx_result) == 240
+    assert C.sizeof(L.twx_config) == 88
+    assert C.sizeof(L.twx_band) == 16
+    assert C.sizeof(L.twx_info) == 40
+    assert L.twx_result.df.offset == 176 and L.twx_result.zwin.offset == 64
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(L.TwxError) as e:
+        cor.Correlator(lfsr=(14, 43, 10000))
+    assert e.value.status == -3 and "no CPU fallback" in str(e.value)
+
+
+def test_bad_arguments_are_errors_not_crashes():
+    lib = L.load()
+    h = C.c_void_p()
+    assert lib.twx_create(None, C.byref(h)) == -1
+    cfg = L.twx_config()
+    cfg.fs, cfg.sps, cfg.nint, cfg.n_chips = 5e6, 2, 7, 1000
+    assert lib.twx_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"nint" in lib.twx_last_error(None)
+    assert lib.twx_strerror(-2) == b"unsupported window length"
+    assert lib.twx_get_info(None, None) == -1
+
+
+def test_band_helpers_match_reference_band_definitions():
+    fs = 5e6
+    for n in (20000, 200000):
+        f = orc.freq_axis(fs, n)
+        assert np.array_equal(cor.freq_axis(fs, n), f)
+        k = orc.band_godual(f, 0, 0)
+        assert cor.band_godual(fs, n) == (k[0], k[-1])
+        k = orc.band_godual(f, 1, 0)
+        assert cor.band_godual(fs, n, remote=1, OP=0) == (k[0], k[-1])
+        k = orc.band_godual(f, 1, 1)
+        assert cor.band_godual(fs, n, remote=1, OP=1) == (k[0], k[-1])
+        k = orc.band_numpy(f, 0.0, 8000.0)
+        assert cor.band_numpy(fs, n) == (k[0], k[-1])
+
+
+def test_delay_formula():
+    r = cor.WindowResult(3935295, -0.25, 1j, 1j, 1j, np.zeros(7, complex), 0.0, -1, 0, 0, 0, 0, 0)
+    # (indice-1+correction)/fs/(2*Nint+1) with Octave's 1-based indice (godual_ranging.m:96)
+    assert abs(r.delay(5e6, 1) - (3935295 - 0.25) / 5e6 / 3) < 1e-18
+
+
+def test_shard_windows_partition():
+    for n in (0, 1, 7, 600, 601):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard_windows(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1 and max(sizes) == D.max_shard(n, world) or n == 0
+    assert D.shard_windows(600, 3, 8) == (225, 300)

@@ -1,0 +1,235 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle and the golden fixtures.
+
+Gates (BASELINE.json north_star): integer-sample peak lag bit-exact; peak magnitude within 1e-6
+relative (fp32 device path vs fp64 oracle); correction / df / SNR compared at tolerances stated
+per assertion.
+"""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+from amaranth_twstft_amd import prn, synth
+from amaranth_twstft_amd import _lib as L
+from amaranth_twstft_amd.correlator import Correlator, band_numpy, band_godual, lfsr_chips_device
+from oracle import twstft_oracle as orc
+from tests.helpers import load_golden, capture_from_desc, chips_for
+
+pytestmark = pytest.mark.gpu
+FS = 5e6
+MAG_TOL = 1e-6          # north_star: peak magnitude within 1e-6 relative (fp32)
+
+
+def _check(g, o, corr_tol=2e-4, snr_tol=2e-4):
+    assert g.indice == o["indice"]                                            # bit-exact integer lag
+    assert abs(abs(g.xval) - abs(o["xval"])) <= MAG_TOL * abs(o["xval"])
+    assert abs(g.xval - o["xval"]) <= 2 * MAG_TOL * abs(o["xval"])
+    assert abs(abs(g.xvalm1) - abs(o["xvalm1"])) <= 2 * MAG_TOL * abs(o["xval"])
+    assert abs(abs(g.xvalp1) - abs(o["xvalp1"])) <= 2 * MAG_TOL * abs(o["xval"])
+    assert abs(g.correction - o["correction"]) <= corr_tol                    # samples of the 3x grid (<= 13 ps)
+    assert abs(g.df - o["df"]) <= 1e-9
+    for k in ("SNRr", "SNRi", "puissancecode"):
+        assert abs(getattr(g, k) - o[k]) <= snr_tol * max(abs(o["SNRr"]), abs(o["SNRi"]), abs(o[k])) + 1e-30, k
+    for k in ("puissance", "puissancenoise"):
+        assert abs(getattr(g, k) - o[k]) <= 1e-6 * abs(o[k]), k
+
+
+def _capture(bitlen, taps, nchips, nwin, seed, df=(1780.75, 0.0), amp=(300, 3000), sigma=(500.0, 100.0)):
+    chips = chips_for(bitlen, taps, nchips)
+    n = 2 * nchips
+    chans = [synth.SynthParams(delay_q8=(n // 3 + 1157) * 256, fstep=synth.fstep_for_df(df[0], FS), phi0=1 << 29, amp=amp[0],
+                               noise_gain=synth.noise_gain_for_sigma(sigma[0]), seed=seed, stream=0),
+             synth.SynthParams(delay_q8=(n // 5) * 256, fstep=synth.fstep_for_df(df[1], FS), phi0=0, amp=amp[1],
+                               noise_gain=synth.noise_gain_for_sigma(sigma[1]), seed=seed, stream=1)]
+    return chips, synth.synth_capture(n * nwin, chips, 2, chans)
+
+
+@pytest.mark.parametrize("bitlen,taps,nchips", [(13, 27, 5000), (14, 43, 10000), (15, 3, 25000), (17, 9, 100000),
+                                                 (18, 39, 250000), (19, 39, 500000)])
+def test_fft_and_code_spectrum(bitlen, taps, nchips):
+    chips = chips_for(bitlen, taps, nchips)
+    n = 2 * nchips
+    with Correlator(chips, fs=FS) as cor:
+        rng = np.random.default_rng(n)
+        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        ref = np.fft.fft(x)
+        assert np.abs(cor.fft(x) - ref).max() <= 1e-6 * np.abs(ref).max()
+        cref = orc.make_fcode(orc.make_code(chips, 2))
+        assert np.abs(cor.code_spectrum() - cref).max() <= 2e-7 * np.abs(cref).max()
+
+
+@pytest.mark.parametrize("bitlen,taps,nchips,nwin", [(13, 27, 5000, 5), (14, 57, 10000, 4), (15, 17, 25000, 3),
+                                                      (17, 15, 100000, 3), (19, 63, 500000, 1)])
+def test_processing_vs_oracle_two_channels(bitlen, taps, nchips, nwin):
+    chips, raw = _capture(bitlen, taps, nchips, nwin, seed=nchips)
+    n = 2 * nchips
+    band = band_numpy(FS, n)
+    with Correlator(chips, fs=FS, Nint=1) as cor:
+        got = cor.ranging(raw, n_channels=2, channels=(0, 1), band=band)
+    ref = orc.ranging(raw, chips, fs=FS, Nint=1, n_channels=2, band="numpy")
+    for c in (0, 1):
+        assert len(got[c]) == len(ref[c]) == nwin
+        for g, o in zip(got[c], ref[c]):
+            _check(g, o)
+            assert g.df_index >= 0
+
+
+def test_df_supplied_and_full_map():
+    chips, raw = _capture(14, 43, 10000, 2, seed=3)
+    n = 20000
+    with Correlator(chips, fs=FS, Nint=1) as cor:
+        got = cor.process(raw, n_channels=2, channel=0, df=[1781.0, 1779.5])
+        z = cor.xcorr_map(raw[:n], 1781.0, n_channels=2, channel=0)
+    code = orc.make_code(chips, 2)
+    fcode = orc.make_fcode(code)
+    temps = np.arange(n) / FS
+    for w, df in enumerate((1781.0, 1779.5)):
+        d = orc.deinterleave(raw[w * n:(w + 1) * n], 2, 0)
+        d = d - d.mean()
+        o = orc.processing(d, None, None, temps, fcode, code, Nint=1, fs=FS, df=df)
+        _check(got[w], o)
+        assert got[w].df_index == -1
+        if w == 0:
+            zr = orc.xcorr_interp(np.fft.fft(d * np.exp(-2j * np.pi * df * temps)), fcode, 1)
+            assert np.abs(z - zr).max() <= 1e-6 * np.abs(zr).max()
+            assert int(np.abs(z).argmax()) == o["indice"]
+
+
+@pytest.mark.parametrize("Nint", [0, 2])
+def test_other_interpolation_factors(Nint):
+    chips, raw = _capture(14, 43, 10000, 2, seed=9)
+    n = 20000
+    with Correlator(chips, fs=FS, Nint=Nint) as cor:
+        got = cor.process(raw, n_channels=2, channel=0, band=band_numpy(FS, n))
+    ref = orc.ranging(raw, chips, fs=FS, Nint=Nint, n_channels=2, channels=(0,), band="numpy")[0]
+    for g, o in zip(got, ref):
+        _check(g, o)
+
+
+def test_octave_variance_convention_and_remote_band():
+    chips, raw = _capture(14, 43, 10000, 1, seed=21, df=(50000.0, 0.0), amp=(800, 3000))
+    n = 20000
+    with Correlator(chips, fs=FS, Nint=1, var_ddof=1) as cor:
+        g = cor.processing(raw, band_godual(FS, n, remote=1, OP=0), n_channels=2, channel=0)
+    o = orc.ranging(raw, chips, fs=FS, Nint=1, n_channels=2, channels=(0,), band="godual", remote=1, OP=0, ddof=1)[0][0]
+    _check(g, o)
+    assert abs(g.df - 50000.0) < 300.0
+
+
+def test_single_channel_layout_and_short_final_window():
+    chips = chips_for(14, 43, 10000)
+    n = 20000
+    p = synth.SynthParams(delay_q8=4321 * 256, fstep=synth.fstep_for_df(-700.0, FS), phi0=5, amp=250,
+                          noise_gain=synth.noise_gain_for_sigma(400.0), seed=77)
+    raw = synth.synth_channel(2 * n + 1234, chips, 2, p)           # 2 full windows + a short one
+    with Correlator(chips, fs=FS) as cor:
+        got = cor.process(raw, n_channels=1, channel=0, band=band_numpy(FS, n))
+        assert cor.process(raw[:100], n_channels=1, channel=0, band=band_numpy(FS, n)) == []   # empty: no full window
+    assert len(got) == 2                                             # godual_ranging.m:81,102
+    ref = orc.ranging(raw[:2 * n], chips, fs=FS, Nint=1, n_channels=1, channels=(0,), band="numpy")[0]
+    for g, o in zip(got, ref):
+        _check(g, o)
+        assert g.indice == 3 * 4321
+
+
+@pytest.mark.parametrize("case", ["c5k", "c10k", "c25k", "c100k"])
+def test_golden_221207_rows(case):
+    """Device path reproduces the reference's own printed rows (tests/golden/ref221207_ranging.json)."""
+    g = load_golden("ref221207_ranging.json")
+    c = next(x for x in g["cases"] if x["name"] == case)
+    chips, raw = capture_from_desc(c["synth"], c["input_sha256"])
+    n = 2 * len(chips)
+    fs = c["fs"]
+    with Correlator(chips, fs=fs, Nint=c["Nint"], snr_rot=-2) as cor1, Correlator(chips, fs=fs, Nint=c["Nint"], snr_rot=0) as cor2:
+        r1 = cor1.process(raw, n_channels=2, channel=0, band=band_numpy(fs, n))
+        r2 = cor2.process(raw, n_channels=2, channel=1, df=0.0)     # ch2 is not mixed in that script (:66)
+    for a, b, line in zip(r1, r2, c["rows"]):
+        ref = [float(v) for v in line.split("\t")[1:]]
+        mine = ((a.indice - b.indice + a.correction - b.correction) / fs / 3, a.df, 10 * np.log10(a.puissance),
+                10 * np.log10(a.SNRi + a.SNRr), 10 * np.log10(b.SNRi + b.SNRr))
+        assert abs(mine[0] - ref[0]) <= 1.0e-12 + 2e-4 / fs / 3      # printed to 1e-12 s; fp32 correction tolerance
+        assert abs(mine[1] - ref[1]) <= 0.05 + 1e-9
+        for x, y in zip(mine[2:], ref[2:]):
+            assert abs(x - y) <= 0.051
+
+
+def test_full_size_window_vs_golden_and_oracle():
+    """N = 5 000 000 (BASELINE.json configs[1]): lag equals the reference's (221219 golden, C2) and
+    everything else matches the oracle run on the same input."""
+    g = load_golden("ref221219_processing.json")
+    c = next(x for x in g["cases"] if x["name"] == "n5M_C2")
+    chips, raw = capture_from_desc(c["synth"], c["input_sha256"])
+    n = 2 * len(chips)
+    band = band_numpy(FS, n)
+    with Correlator(chips, fs=FS, Nint=1) as cor:
+        assert (cor.info.n1, cor.info.n2) == (625, 8000)
+        got = cor.process(raw, n_channels=1, channel=0, band=band)[0]
+    assert got.indice == c["ref"]["indice"] == 3 * 1311765           # reference's own result
+    code = orc.make_code(chips, 2)
+    d = orc.deinterleave(raw, 1, 0)
+    d = d - d.mean()
+    freq = orc.freq_axis(FS, n)
+    o = orc.processing(d, np.arange(band[0], band[1] + 1), freq, np.arange(n) / FS, orc.make_fcode(code), code, Nint=1, fs=FS)
+    _check(got, o)
+
+
+def test_batched_device_api_linearity_and_determinism():
+    """Size-independent properties at full size on device-resident data: every window of a batch
+    peaks at 3*delay, results are independent of batch size, and repeated runs are bit-identical."""
+    import torch
+    lib = L.load()
+    nchips, n = 2500000, 5000000
+    chips = chips_for(22, 3, nchips)
+    dev = torch.device("cuda", 0)
+    chips_dev = torch.from_numpy(chips).to(dev)
+    nwin = 6
+    iq = torch.empty((nwin, n, 2), dtype=torch.int16, device=dev)
+    delays = [1311765 - 7 * p for p in range(nwin)]
+    for p in range(nwin):
+        params = np.array([delays[p] * 256, synth.fstep_for_df(1780.75, FS), 12345 * p, 200, synth.noise_gain_for_sigma(400.0),
+                           1000 + p, 0, 0], dtype=np.int64)
+        L.check(lib.twx_synth_capture_dev(iq[p].data_ptr(), n, 0, chips_dev.data_ptr(), nchips, 2, 1,
+                                          params.ctypes.data_as(C.c_void_p), None))
+    torch.cuda.synchronize()
+    # device generator == numpy generator (bit-exact) on a slice
+    ref = synth.synth_channel(4096, chips, 2, synth.SynthParams(delay_q8=delays[1] * 256, fstep=synth.fstep_for_df(1780.75, FS),
+                                                              phi0=12345, amp=200, noise_gain=synth.noise_gain_for_sigma(400.0),
+                                                              seed=1001, stream=0), n0=0)
+    assert np.array_equal(iq[1, :4096].cpu().numpy(), ref)
+    band = L.twx_band(*band_godual(FS, n))
+    outs = []
+    for batch in (1, 4, 0):
+        with Correlator(chips, fs=FS, Nint=1, max_batch=batch) as cor:
+            res = torch.zeros((nwin, C.sizeof(L.twx_result)), dtype=torch.uint8, device=dev)
+            for _ in range(2):
+                L.check(lib.twx_process_windows_dev(cor._h, iq.data_ptr(), nwin, 1, 0, C.byref(band), None, res.data_ptr()), cor._h)
+                L.check(lib.twx_synchronize(cor._h), cor._h)
+                outs.append(res.cpu().numpy().tobytes())
+    assert all(o == outs[0] for o in outs)                           # batch-size independent, run-to-run identical
+    arr = (L.twx_result * nwin).from_buffer_copy(outs[0])
+    for p in range(nwin):
+        assert arr[p].indice0 == 3 * delays[p]
+        assert abs(arr[p].df - 1780.75) < 0.51                        # 0.5 Hz bins (godual_ranging.m:14)
+
+
+def test_lfsr_device_generator():
+    for bitlen, taps, n in [(13, 27, 5000), (17, 9, 100000), (22, 57, 300001)]:
+        assert np.array_equal(lfsr_chips_device(bitlen, taps, n), prn.lfsr_chips(bitlen, taps, n))
+    g = load_golden("prn_codes.json")
+    e = next(x for x in g["files"] if x["name"] == "noiselen2500000_bitlen22_taps03.bin.gz")
+    assert hashlib.sha256(lfsr_chips_device(22, 3, e["len"]).tobytes()).hexdigest() == e["sha256"]
+
+
+def test_context_from_lfsr_parameters_equals_context_from_chips():
+    chips, raw = _capture(14, 43, 10000, 1, seed=5)
+    with Correlator(chips, fs=FS) as a, Correlator(lfsr=(14, 43, 10000), fs=FS) as b:
+        ra = a.process(raw, n_channels=2, channel=0, band=band_numpy(FS, 20000))[0]
+        rb = b.process(raw, n_channels=2, channel=0, band=band_numpy(FS, 20000))[0]
+    assert ra.indice == rb.indice and ra.xval == rb.xval and ra.SNRr == rb.SNRr and np.array_equal(ra.zwin, rb.zwin)
+
+
+def test_unsupported_length_is_a_clean_error():
+    with pytest.raises(L.TwxError) as e:
+        Correlator(chips_for(13, 27, 5000)[:4999], fs=FS)
+    assert e.value.status in (-2,)
