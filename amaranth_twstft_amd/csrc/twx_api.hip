@@ -367,7 +367,11 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         R = 2 * cfg.nint + 1;
         ntiles = N2 / col->W;
-        B = cfg.max_batch > 0 ? cfg.max_batch : (int)std::max<long long>(1, std::min<long long>(16, (1536ll << 20) / (N * (long long)sizeof(C) * (1 + R))));
+        if (cfg.max_batch > 0) B = cfg.max_batch;
+        else {   // largest power of two whose A+Bz buffers stay under ~1.5 GiB, at most 16 windows per launch
+            const long long fit = std::max<long long>(1, (1536ll << 20) / (N * (long long)sizeof(C) * (1 + R)));
+            B = 1; while (B * 2 <= fit && B * 2 <= 16) B *= 2;
+        }
         // range safety: the unnormalised correlation peak reaches ~N^2*32768 — keep |z|^2 inside fp32
         int e = 0; while ((1ll << e) < N) ++e;
         scale_pow2 = std::is_same<T, float>::value ? ldexp(1.0, -e) : 1.0;

@@ -32,9 +32,12 @@ BITLEN, TAPS, NCHIPS = 22, 3, 2_500_000
 N = 2 * NCHIPS
 HBM_PEAK_GBS = 8000.0
 
-# compulsory HBM bytes per input complex sample of each kernel, fp32
-ALGO_BYTES = {"k_sums": 4, "k_col_fwd_square": 12, "k_row_band": 8, "k_df_tables": 0, "k_col_fwd_mix": 12,
-              "k_row_mid": 40, "k_col_inv": 24, "k_peak": 0}
+# compulsory (algorithmic) HBM bytes of one launch over S samples of N-sample windows, fp32
+# (DESIGN.md §4): int16 IQ in = 4 B, complex fp32 = 8 B; k_row_mid reads A (8), writes 3 phases (24)
+# and reads the code spectrum once per launch (8*N, shared by all windows of the launch).
+ALGO_BYTES = {"k_sums": lambda S: 4 * S, "k_col_fwd_square": lambda S: 12 * S, "k_row_band": lambda S: 8 * S,
+              "k_df_tables": lambda S: 0, "k_col_fwd_mix": lambda S: 12 * S, "k_row_mid": lambda S: 32 * S + 8 * N,
+              "k_col_inv": lambda S: 24 * S, "k_peak": lambda S: 0}
 
 
 def window_params(p: int, rank: int):
@@ -156,15 +159,16 @@ def main():
         kern = {k: dict(ms_avg=v["ms_total"] / v["launches"], launches=v["launches"],
                         samples_per_launch=v["units"] / v["launches"]) for k, v in prof.items()}
         dom = max(kern, key=lambda k: prof[k]["ms_total"])
-        byts = ALGO_BYTES[dom] * kern[dom]["samples_per_launch"]
+        byts = ALGO_BYTES[dom](kern[dom]["samples_per_launch"])
         ach = byts / (kern[dom]["ms_avg"] * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                            "algorithmic_bytes_per_launch": int(byts), "avg_ms": round(kern[dom]["ms_avg"], 4)}
-        out["kernels"] = {k: {"avg_ms": round(v["ms_avg"], 4), "GB/s": round(ALGO_BYTES[k] * v["samples_per_launch"] / (v["ms_avg"] * 1e-3) / 1e9, 1)}
+        out["kernels"] = {k: {"avg_ms": round(v["ms_avg"], 4), "GB/s": round(ALGO_BYTES[k](v["samples_per_launch"]) / (v["ms_avg"] * 1e-3) / 1e9, 1)}
                           for k, v in kern.items()}
-        tot = sum(ALGO_BYTES[k] for k in kern)
-        out["chain_GBs_algorithmic"] = round(tot * value * 1e6 / 1e9 / world, 1)
+        tot = sum(ALGO_BYTES[k](kern[k]["samples_per_launch"]) for k in kern)
+        spl = kern[dom]["samples_per_launch"]
+        out["chain_GBs_algorithmic"] = round(tot / spl * value * 1e6 / 1e9 / world, 1)
         pc.close()
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
