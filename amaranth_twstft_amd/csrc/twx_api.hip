@@ -270,6 +270,7 @@ template <typename T> struct Ctx : CtxBase {
     C *e1 = nullptr, *e2 = nullptr, *A = nullptr, *Bz = nullptr, *dc = nullptr;
     ArgPart<T>*part_band = nullptr, *part_peak = nullptr;
     twx_result* res_dev = nullptr;
+    unsigned long long* stamps_dev = nullptr;   // TWX_STAMPS diagnostic builds
     int ntiles = 0;
 
     template <typename U> int upload(U** dst, const std::vector<U>& src) {
@@ -398,6 +399,10 @@ template <typename T> struct Ctx : CtxBase {
         if (int rc = dalloc(&part_band, (size_t)B * N1)) return rc;
         if (int rc = dalloc(&part_peak, (size_t)B * R * ntiles)) return rc;
         if (int rc = dalloc(&res_dev, (size_t)B)) return rc;
+#ifdef TWX_STAMPS
+        if (int rc = dalloc(&stamps_dev, (size_t)B * N1 * 8 * 32)) return rc;
+        HIPCHK(hipMemset(stamps_dev, 0, (size_t)B * N1 * 8 * 32 * 8));
+#endif
         HIPCHK(hipStreamSynchronize(stream));
         return TWX_OK;
     }
@@ -451,6 +456,7 @@ template <typename T> struct Ctx : CtxBase {
         ra.n = N; ra.n1 = N1; ra.nwin = nb; ra.A = A; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.ea = ea; ra.eb = eb;
         ra.part = part_band; ra.cspec = cspec; ra.ramp1 = ramp1; ra.nphase = R; ra.scale = (T)scale_pow2;
         ra.ta = ta; ra.tb = tb; ra.tshift = tshift; ra.Bz = Bz; ra.dc = dc;
+        ra.stamps = stamps_dev;
         if (band) {
             if (band->k_lo < 0 || band->k_hi >= N || band->k_lo > band->k_hi) return fail(TWX_E_ARG, "band outside 0..N-1");
             ra.band_lo = band->k_lo; ra.band_hi = band->k_hi;
@@ -685,6 +691,14 @@ int twx_xcorr_map(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t c
     if (!ctx || !iq || !out || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
     (void)hipSetDevice(ctx->impl->dev);
     return ctx->impl->xcorr_map(iq, n_channels, channel, df, out);
+}
+
+int twx_debug_stamps(twx_ctx* ctx, unsigned long long* out, long long count) {
+    if (!ctx || !out) return TWX_E_ARG;
+    Ctx<float>* c = dynamic_cast<Ctx<float>*>(ctx->impl);
+    if (!c || !c->stamps_dev) return TWX_E_STATE;
+    (void)hipStreamSynchronize(c->stream);
+    return hipMemcpy(out, c->stamps_dev, (size_t)count * 8, hipMemcpyDeviceToHost) == hipSuccess ? TWX_OK : TWX_E_HIP;
 }
 
 int twx_profile_reset(twx_ctx* ctx) {

@@ -116,10 +116,26 @@ __global__ __launch_bounds__(256) void k_sums(const short2* __restrict__ in, lon
     unsigned long long sP = 0;
     const long long per = (n + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * per, hi = min(n, lo + per);
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-        short2 s = p[i * nch];
+    auto acc = [&](short2 s) {
         sI += s.x; sQ += s.y;
         sP += (unsigned long long)((int)s.x * (int)s.x + (int)s.y * (int)s.y);
+    };
+    if (nch == 1 && ((reinterpret_cast<unsigned long long>(p) & 15) == 0)) {
+        // 16 B per lane: four [I Q] samples per load (coalesced 1 KiB per wave-instruction)
+        long long i = lo;
+        for (; i < hi && (i & 3); ++i) if (threadIdx.x == 0) acc(p[i]);
+        const long long nv = (hi - i) >> 2;
+        const int4* pv = reinterpret_cast<const int4*>(p + i);
+        for (long long k = threadIdx.x; k < nv; k += 256) {
+            int4 q = pv[k];
+            short2 s0, s1, s2, s3;
+            s0.x = (short)(q.x & 0xffff); s0.y = (short)(q.x >> 16); s1.x = (short)(q.y & 0xffff); s1.y = (short)(q.y >> 16);
+            s2.x = (short)(q.z & 0xffff); s2.y = (short)(q.z >> 16); s3.x = (short)(q.w & 0xffff); s3.y = (short)(q.w >> 16);
+            acc(s0); acc(s1); acc(s2); acc(s3);
+        }
+        for (long long t = i + (nv << 2) + threadIdx.x; t < hi; t += 256) acc(p[t]);
+    } else {
+        for (long long i = lo + threadIdx.x; i < hi; i += 256) acc(p[i * nch]);
     }
     for (int d = 32; d >= 1; d >>= 1) {
         sI += shfl_down_ll(sI, d);
@@ -282,6 +298,9 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
 // ------------------------------------------------------------------------------------------
 enum { ROW_STORE = 0, ROW_BAND = 1, ROW_MID = 2 };
 #define TWX_MAX_PHASE 5
+#ifndef TWX_ABL
+#define TWX_ABL 0   // 1: no Bz stores, 2: no cspec load, 3: nphase forced to 1, 4: no A load, 5: no inverse transforms
+#endif
 #ifndef TWX_ROW_WAVES
 #define TWX_ROW_WAVES 1
 #endif
@@ -308,6 +327,7 @@ template <typename T> struct RowArgs {
     const cpx<T>* ta; const cpx<T>* tb; int tshift;   // exp(-2 pi i m/N), m = a<<tshift | b
     cpx<T>* Bz;                      // [b][rho][k1][q2]
     cpx<T>* dc;                      // [b]  X[0] of the window (mean(y) for puissance, :46)
+    unsigned long long* stamps;      // diagnostic builds (TWX_STAMPS) only
 };
 
 // reverse of a plan (inverse transform consumes the forward's last-stage register layout)
@@ -330,6 +350,14 @@ template <class TL, class P, typename T, int s> struct MidStages {
         }
     }
 };
+
+#ifdef TWX_STAMPS   // diagnostic build only: s_memtime at segment boundaries of one wave per workgroup
+#define TWX_STAMP(i) do { if (MODE == ROW_MID && a.stamps && (threadIdx.x & 63) == 0) { \
+        unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+        a.stamps[((long long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * 32 + (i)] = t_; } } while (0)
+#else
+#define TWX_STAMP(i) do { } while (0)
+#endif
 
 template <class P2, typename T, int MODE, int PADQ, int NT>
 __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
@@ -357,12 +385,21 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
     const int tid = threadIdx.x;
     const C* row = a.A + (long long)b * a.n + (long long)k1 * N2;
     C v[P2::rmax()];
+    C csr[MODE == ROW_MID ? RL : 1];     // code-spectrum row, requested at kernel start (latency hidden by the forward FFT)
+    if constexpr (MODE == ROW_MID) {
+        if (tid < NSL) {
+            const C* cs = a.cspec + (long long)k1 * N2;
+            TWX_UNROLL
+            for (int q = 0; q < RL; ++q) csr[q] = cs[tid + q * NSL];
+        }
+    }
+    TWX_STAMP(0);
     // ---- forward stage 0 (global → regs → LDS); small tables global → LDS
     {
         constexpr int R = P2::radix(0);
         if (tid < TF::template tasks<0>()) {
             TWX_UNROLL
-            for (int r = 0; r < R; ++r) v[r] = row[TF::template in_pos<0>(tid, r)];
+            for (int r = 0; r < R; ++r) v[r] = (TWX_ABL == 4 && MODE == ROW_MID) ? mk<T>((T)(tid + r), (T)r) : row[TF::template in_pos<0>(tid, r)];
         }
         for (int i = tid; i < NTF; i += NT) tab_f[i] = a.stab_f[i];
         if constexpr (MODE == ROW_MID) {
@@ -380,12 +417,14 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
             TF::template store_lds<0>(lds, tid, 0, v);
         }
     }
+    TWX_STAMP(1);
     __syncthreads();
+    TWX_STAMP(2);
     MidStages<TF, P2, T, 1>::run(lds, tab_f, v, tid);
+    TWX_STAMP(3);
     // ---- forward last stage: v[q] = X[k1 + N1*k2], k2 = tid + q*NSL
     const bool act = tid < NSL;
     if (act) { TF::template load_lds_tab<S - 1>(lds, tab_f, tid, v); TF::template bfly<S - 1>(v); }
-    __builtin_amdgcn_sched_barrier(0);   // keep the epilogue's global loads below the butterfly (register pressure)
 
     if constexpr (MODE == ROW_STORE) {
         if (act) {
@@ -423,18 +462,10 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
         constexpr int NSI = N2 / RIL;
         C pr[RL];
         if (act) {
-            const C* cs = a.cspec + (long long)k1 * N2;
             if (k1 == 0 && tid == 0) a.dc[b] = v[0];
-            // ffty.*fcode (godual_ranging.m:26); in chunks so that the code-spectrum loads in flight
-            // do not push the kernel over the 128-VGPR budget of two workgroups per CU
-            constexpr int CH = 5;
             TWX_UNROLL
-            for (int q0 = 0; q0 < RL; q0 += CH) {
-                TWX_UNROLL
-                for (int q = q0; q < (q0 + CH < RL ? q0 + CH : RL); ++q)
-                    pr[q] = cscale(cmul(v[q], cs[tid + q * NSL]), a.scale);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int q = 0; q < RL; ++q)
+                pr[q] = cscale(cmul(v[q], TWX_ABL == 2 ? v[(q + 1) % RL] : csr[q]), a.scale);   // ffty.*fcode  (godual_ranging.m:26)
         }
         // per-thread output twiddle base conj(W_N^{k1*j}), j = output task index of the inverse's last stage
         C ub = mk<T>(1, 0);
@@ -442,41 +473,61 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
             const unsigned m = (unsigned)k1 * (unsigned)tid;
             ub = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & ((1u << a.tshift) - 1u)]));
         }
-        for (int rho = 0; rho < a.nphase; ++rho) {
+        TWX_STAMP(4);
+        const int nph = TWX_ABL == 3 ? 1 : TWX_ABL == 5 ? 0 : a.nphase;
+        // software-pipelined per-phase scalars: the ramp factor of the NEXT phase is requested one
+        // phase ahead so its global-load latency never sits on the critical path
+        C ea_cur = mk<T>(1, 0), ea_n = mk<T>(1, 0);
+        if (nph > 1 && tid < NSL) ea_n = a.ea[NSL + tid];
+        C r1_cur = a.ramp1[k1];
+        for (int rho = 0; rho < nph; ++rho) {
             __syncthreads();   // previous transform's LDS reads are done
             // launder the thread index: stops LICM from hoisting ~100 loop-invariant LDS/table
             // addresses out of the rho loop (they were being spilled to scratch)
             int lt = tid;
             asm volatile("" : "+v"(lt));
+            TWX_STAMP(5 + rho * 6);
+            const C eaj = ea_cur;          // exp(+2 pi i rho j/(R N2)) of THIS phase (unused for rho = 0)
+            const C r1 = r1_cur;
+            ea_cur = ea_n;
+            if (rho + 2 < nph && lt < NSL) ea_n = a.ea[(rho + 2) * NSL + lt];
+            if (rho + 1 < nph) r1_cur = a.ramp1[(long long)(rho + 1) * a.n1 + k1];
             if (lt < NSL) {
                 if (rho == 0) {
                     TWX_UNROLL
                     for (int r = 0; r < RL; ++r) v[r] = pr[r];
                 } else {
-                    const C eaj = a.ea[rho * NSL + lt];
-                    const C* ebr = s_eb + rho * 2 * RL;
                     TWX_UNROLL
                     for (int r = 0; r < RL; ++r) {
-                        const int wrap = (2 * (lt + r * NSL) >= N2) ? RL : 0;
-                        v[r] = cmul(cmul(pr[r], eaj), ebr[wrap + r]);
+                        C e;
+                        if constexpr (RL % 2 == 0) e = a.eb[(rho * 2 + (r >= RL / 2 ? 1 : 0)) * RL + r];   // wave-uniform → scalar load
+                        else e = s_eb[(rho * 2 + ((2 * (lt + r * NSL) >= N2) ? 1 : 0)) * RL + r];
+                        v[r] = cmul(cmul(pr[r], eaj), e);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 TI::template bfly<0>(v);
                 TI::template store_lds<0>(lds, lt, 0, v);
             }
+            TWX_STAMP(6 + rho * 6);
             __syncthreads();
+            TWX_STAMP(7 + rho * 6);
             MidStages<TI, PR, T, 1>::run(lds, tab_i, v, lt);
+            TWX_STAMP(8 + rho * 6);
             if (lt < NSI) {
                 TI::template load_lds_tab<S - 1>(lds, tab_i, lt, v);
                 TI::template bfly<S - 1>(v);
                 __builtin_amdgcn_sched_barrier(0);
-                const C u = cmul(ub, a.ramp1[(long long)rho * a.n1 + k1]);
+                TWX_STAMP(9 + rho * 6);
+                const C u = cmul(ub, r1);
                 C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
                 TWX_UNROLL
-                for (int q = 0; q < RIL; ++q)
-                    out[lt + q * NSI] = cmul(cmul(v[q], u), s_vc[q]);       // · W_N^{-k1 q2} · ramp1
+                for (int q = 0; q < RIL; ++q) {
+                    C o = cmul(cmul(v[q], u), s_vc[q]);                     // · W_N^{-k1 q2} · ramp1
+                    if (TWX_ABL == 1) { asm volatile("" ::"v"(o)); } else out[lt + q * NSI] = o;
+                }
             }
+            TWX_STAMP(10 + rho * 6);
         }
     }
 }
