@@ -88,7 +88,7 @@ class Correlator:
     """One code + one GPU. Mirrors the globals ``fs Nint code fcode`` of godual_ranging.m:3-5,62-66."""
 
     def __init__(self, chips=None, fs: float = 5e6, sps: int = 2, Nint: int = 1, *, lfsr: tuple[int, int, int] | None = None,
-                 precision: str = "f32", var_ddof: int = 0, snr_rot: int = -1, window: str = "none",
+                 precision: str = "f32", var_ddof: int = 0, snr_rot: int = -1, window: str = "none", convention: str = "godual",
                  device: int = -1, max_batch: int = 0, profile: bool = False):
         self._lib = L.load()
         cfg = L.twx_config()
@@ -102,7 +102,7 @@ class Correlator:
             cfg.lfsr_bitlen, cfg.lfsr_taps, cfg.n_chips = lfsr
         else:
             raise ValueError("give chips or lfsr=(bitlen, taps, noiselen)")
-        cfg.convention = L.TWX_CONV_GODUAL
+        cfg.convention = {"godual": L.TWX_CONV_GODUAL, "claudio": L.TWX_CONV_CLAUDIO}[convention]
         cfg.window = {"none": L.TWX_WIN_NONE, "hamming": L.TWX_WIN_HAMMING}[window]
         cfg.precision = {"f32": L.TWX_F32, "f64": L.TWX_F64}[precision]
         cfg.var_ddof, cfg.snr_rot, cfg.device, cfg.max_batch = var_ddof, snr_rot, device, max_batch

@@ -494,7 +494,7 @@ template <typename T> struct Ctx : CtxBase {
         PeakArgs<T> pa{};
         pa.n = N; pa.n1 = N1; pa.n2 = N2; pa.nphase = R; pa.nparts = R * ntiles; pa.part = part_peak; pa.Bz = Bz; pa.tw1d = tw1d;
         pa.sums = sums; pa.remove_mean = 1; pa.dc = dc; pa.dfv = dfv; pa.dfidx = dfidx; pa.inv_scale = 1.0 / scale_pow2;
-        pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.res = out_dev;
+        pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.convention = cfg.convention; pa.res = out_dev;
         {
             ProfScope ps(this, PC_PEAK, nb);
             hipLaunchKernelGGL((k_peak<T>), dim3(nb), dim3(1024), 0, stream, pa);
@@ -594,7 +594,7 @@ int twx_create(const twx_config* cfg, twx_ctx** out) {
     *out = nullptr;
     if (!(cfg->fs > 0) || cfg->sps < 1 || cfg->nint < 0 || cfg->nint > 2 || cfg->n_chips < 1) { g_create_err = "bad fs/sps/nint/n_chips"; return TWX_E_ARG; }
     if (cfg->precision != TWX_F32 && cfg->precision != TWX_F64) { g_create_err = "bad precision"; return TWX_E_ARG; }
-    if (cfg->convention != TWX_CONV_GODUAL) { g_create_err = "only TWX_CONV_GODUAL is implemented on the device (claudio = mirrored godual, see INTEGRATION.md)"; return TWX_E_ARG; }
+    if (cfg->convention != TWX_CONV_GODUAL && cfg->convention != TWX_CONV_CLAUDIO) { g_create_err = "bad convention"; return TWX_E_ARG; }
     if (cfg->var_ddof < 0 || cfg->var_ddof > 1) { g_create_err = "var_ddof must be 0 or 1"; return TWX_E_ARG; }
     const long long N = cfg->n_chips * cfg->sps;
     if (N % 2) { g_create_err = "window length must be even"; return TWX_E_SIZE; }

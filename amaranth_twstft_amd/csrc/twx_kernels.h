@@ -622,6 +622,7 @@ template <typename T> struct PeakArgs {
     const double* dfv; const long long* dfidx;
     double inv_scale;            // undoes RowArgs::scale
     int var_ddof, snr_rot;
+    int convention;              // TWX_CONV_*
     twx_result* res;             // [b]
 };
 
@@ -661,12 +662,23 @@ __global__ __launch_bounds__(1024) void k_peak(PeakArgs<T> a) {
     __syncthreads();
     if (tid == 0) {
         twx_result r;
-        r.indice0 = mstar;
         const int c = -TWX_PEAK_LO;
-        for (int i = 0; i < 7; ++i) { r.zwin[i][0] = s_z[c - 3 + i][0]; r.zwin[i][1] = s_z[c - 3 + i][1]; }
-        r.xval[0] = s_z[c][0]; r.xval[1] = s_z[c][1];
-        r.xvalm1[0] = s_z[c - 1][0]; r.xvalm1[1] = s_z[c - 1][1];
-        r.xvalp1[0] = s_z[c + 1][0]; r.xvalp1[1] = s_z[c + 1][1];
+        int rot = a.snr_rot;
+        if (a.convention == TWX_CONV_CLAUDIO) {
+            // prnmap_c[m] = conj(prnmap_g[(M - m) mod M])  (fcode.*conj(ffty), claudio…separate.m:59):
+            // mirrored index, conjugated samples, m1/p1 swapped; the code-rotating wipe-off of :90-94
+            // sums prnmap_g[m*+1 .. m*+R] (absolute 0..R-1 when the 1-based peak index is <= 2)
+            const long long ic = (M - mstar) % M;
+            r.indice0 = ic;
+            for (int i = 0; i < 7; ++i) { r.zwin[i][0] = s_z[c + 3 - i][0]; r.zwin[i][1] = -s_z[c + 3 - i][1]; }
+            rot = (ic + 1 > 2) ? 1 : (int)((M - mstar) % M);   // ic in {0,1}: absolute indices 0.. ⇒ offset ic from m*
+        } else {
+            r.indice0 = mstar;
+            for (int i = 0; i < 7; ++i) { r.zwin[i][0] = s_z[c - 3 + i][0]; r.zwin[i][1] = s_z[c - 3 + i][1]; }
+        }
+        r.xval[0] = r.zwin[3][0]; r.xval[1] = r.zwin[3][1];
+        r.xvalm1[0] = r.zwin[2][0]; r.xvalm1[1] = r.zwin[2][1];
+        r.xvalp1[0] = r.zwin[4][0]; r.xvalp1[1] = r.zwin[4][1];
         const double am = hypot(r.xvalm1[0], r.xvalm1[1]), a0 = hypot(r.xval[0], r.xval[1]), ap = hypot(r.xvalp1[0], r.xvalp1[1]);
         r.correction = (am - ap) / (am + ap - 2 * a0) / 2;                 // godual_ranging.m:33
         r.df = a.dfv[b];
@@ -675,7 +687,7 @@ __global__ __launch_bounds__(1024) void k_peak(PeakArgs<T> a) {
         double mr = 0, mi = 0;
         int ok = 1;
         for (int i = 0; i < a.nphase; ++i) {
-            const int o = a.snr_rot + i;
+            const int o = rot + i;
             if (o < TWX_PEAK_LO || o > TWX_PEAK_HI) { ok = 0; break; }
             mr += s_z[c + o][0]; mi += s_z[c + o][1];
         }

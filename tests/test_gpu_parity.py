@@ -233,3 +233,52 @@ def test_unsupported_length_is_a_clean_error():
     with pytest.raises(L.TwxError) as e:
         Correlator(chips_for(13, 27, 5000)[:4999], fs=FS)
     assert e.value.status in (-2,)
+
+
+def test_fp64_context_tighter_than_fp32():
+    """TWX_F64 instantiation of the same kernels (BASELINE.json configs[4]: fp64 vs fp32 tolerance)."""
+    chips, raw = _capture(17, 9, 100000, 1, seed=31)
+    n = 200000
+    band = band_numpy(FS, n)
+    with Correlator(chips, fs=FS, Nint=1, precision="f64") as c64, Correlator(chips, fs=FS, Nint=1) as c32:
+        g64 = c64.process(raw, n_channels=2, channel=0, band=band)[0]
+        g32 = c32.process(raw, n_channels=2, channel=0, band=band)[0]
+    o = orc.ranging(raw, chips, fs=FS, Nint=1, n_channels=2, channels=(0,), band="numpy")[0][0]
+    assert g64.indice == g32.indice == o["indice"]
+    assert abs(g64.xval - o["xval"]) <= 1e-10 * abs(o["xval"])       # both sides are fp64 FFTs of 2e5 points
+    assert abs(g64.correction - o["correction"]) <= 1e-9
+    assert abs(g64.SNRr - o["SNRr"]) <= 1e-9 * o["SNRr"]
+    assert abs(abs(g32.xval) - abs(g64.xval)) <= MAG_TOL * abs(g64.xval)       # fp32 vs fp64 peak magnitude
+
+
+def test_hamming_windowed_code_spectrum():
+    """fcode × Hamming (processing/CPP/main.cpp:717-719); oracle restatement is unpinned."""
+    chips, raw = _capture(14, 43, 10000, 1, seed=41)
+    n = 20000
+    with Correlator(chips, fs=FS, Nint=1, window="hamming") as cor:
+        cs = cor.code_spectrum()
+        g = cor.process(raw, n_channels=2, channel=1, df=0.0)[0]
+    code = orc.make_code(chips, 2)
+    fh = orc.make_fcode(code, "hamming")
+    assert np.abs(cs - fh).max() <= 3e-7 * np.abs(fh).max()
+    d = orc.deinterleave(raw, 2, 1)
+    d = d - d.mean()
+    z = orc.xcorr_interp(np.fft.fft(d), fh, 1)
+    ind, corr, xval, _, _ = orc.peak_refine(z)
+    assert g.indice == ind and abs(abs(g.xval) - abs(xval)) <= MAG_TOL * abs(xval) and abs(g.correction - corr) < 2e-4
+
+
+def test_claudio_convention():
+    """Reversed-conjugate convention of acquisition/claudio_aligned_code_ranging_separate.m:49-102."""
+    chips, raw = _capture(17, 9, 100000, 2, seed=51, df=(300.0, 0.0))
+    n = 200000
+    with Correlator(chips, fs=FS, Nint=1, convention="claudio", var_ddof=1) as cor:
+        got = cor.process(raw, n_channels=2, channel=0, df=300.0)
+    code = orc.make_code(chips, 2)
+    temps = np.arange(n) / FS
+    fc = orc.make_fcode(code, "claudio")
+    for w, g in enumerate(got):
+        d = orc.deinterleave(raw[w * n:(w + 1) * n], 2, 0)
+        d = d - d.mean()
+        o = orc.processing_claudio(d, 300.0, temps, fc, code, Nint=1, ddof=1)
+        _check(g, o)
