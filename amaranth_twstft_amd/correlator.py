@@ -175,6 +175,47 @@ class Correlator:
             band = band_godual(self.fs, self.n, remote, OP)
         return {c: self.process(raw, n_channels, c, band=band) for c in channels}
 
+    # -- delay x Doppler search (experiments/231001_DLL_PLL/rxcomplex.cpp:521-572) -----------------
+    def caf_bins(self, raw_window, k_lo: int, k_hi: int, n_channels=1, channel=0):
+        """Per-bin (peak |xcorr|, lag) on the integer-bin Doppler grid f = k*fs/N, k = k_lo..k_hi."""
+        raw = np.ascontiguousarray(raw_window, dtype=np.int16).reshape(-1)
+        assert raw.size >= self.n * 2 * n_channels
+        nb = int(k_hi) - int(k_lo) + 1
+        pk = np.empty(nb, dtype=np.float64)
+        lag = np.empty(nb, dtype=np.int64)
+        L.check(self._lib.twx_caf_bins(self._h, raw.ctypes.data_as(C.c_void_p), n_channels, channel, int(k_lo), int(k_hi),
+                                       pk.ctypes.data_as(C.c_void_p), lag.ctypes.data_as(C.c_void_p)), self._h)
+        return pk, lag
+
+    def caf_freqs(self, raw_window, freqs, n_channels=1, channel=0) -> list[WindowResult]:
+        """processing(d,df) of the same window for every trial offset in ``freqs`` (Hz)."""
+        raw = np.ascontiguousarray(raw_window, dtype=np.int16).reshape(-1)
+        assert raw.size >= self.n * 2 * n_channels
+        f = np.ascontiguousarray(freqs, dtype=np.float64)
+        out = (L.twx_result * max(f.size, 1))()
+        L.check(self._lib.twx_caf_freqs(self._h, raw.ctypes.data_as(C.c_void_p), n_channels, channel,
+                                        f.ctypes.data_as(C.c_void_p), f.size, C.cast(out, C.c_void_p)), self._h)
+        return [_to_result(out[i]) for i in range(f.size)]
+
+    def acquire(self, raw_window, fc_init: float, frange: float, fstep: float, n_channels=1, channel=0):
+        """Coarse-to-fine carrier/code-phase acquisition, the loop of rxcomplex.cpp:534-567: sweep
+        fc±frange in fstep, keep the highest peak, then halve the step (range = step) until < 1 Hz.
+        Returns (fc, peak magnitude, lag in samples of the interpolated grid)."""
+        fc, best_pk, best_lag = float(fc_init), 0.0, 0
+        while True:
+            flow, fhigh = fc - frange, fc + frange
+            trial = np.arange(flow, fhigh + 1e-9 * max(1.0, abs(fhigh)), fstep)
+            res = self.caf_freqs(raw_window, trial, n_channels, channel)
+            for f, r in zip(trial, res):
+                pk = abs(r.xval)
+                if pk > best_pk:
+                    fc, best_pk, best_lag = float(f), pk, r.indice
+            fstep = fstep / 2.0
+            frange = fstep
+            if fstep < 1.0:
+                break
+        return fc, best_pk, best_lag
+
     # -- inspection ----------------------------------------------------------------------
     def fft(self, x) -> np.ndarray:
         x = np.ascontiguousarray(x, dtype=np.complex128)

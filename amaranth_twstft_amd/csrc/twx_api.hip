@@ -227,6 +227,8 @@ struct CtxBase {
     virtual int fft_forward(const double* in, double* out) = 0;
     virtual int code_spectrum(double* out) = 0;
     virtual int xcorr_map(const int16_t* iq, int nch, int ch, double df, double* out) = 0;
+    virtual int caf_bins(const int16_t* iq, int nch, int ch, long long k_lo, long long k_hi, double* pk, long long* lag) = 0;
+    virtual int caf_freqs(const int16_t* iq, int nch, int ch, const double* freqs, long long nf, twx_result* out) = 0;
 };
 
 template <typename T> static void host_twiddle(std::vector<cpx<T>>& v, long long count, long long num_mul, long long den, int sign) {
@@ -441,16 +443,17 @@ template <typename T> struct Ctx : CtxBase {
 
     // one batch of nb windows starting at `in` (short2 units: window stride N*nch, channel offset applied)
     int run_batch(const short2* in, int nb, int nch, const twx_band* band, const double* df_host, twx_result* out_dev,
-                  C* zout /*optional full map, nb must be 1*/) {
+                  C* zout /*optional full map, nb must be 1*/, bool same_window = false) {
+        const long long wstride = same_window ? 0 : (long long)N * nch;
         HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums) * nb, stream));
         {
             ProfScope ps(this, PC_SUMS, (long long)nb * N);
             const int chunks = (int)std::min<long long>(256, std::max<long long>(1, N / 4096));
-            hipLaunchKernelGGL((k_sums<0>), dim3(chunks, nb), dim3(256), 0, stream, in, (long long)N * nch, nch, N, sums);
+            hipLaunchKernelGGL((k_sums<0>), dim3(chunks, nb), dim3(256), 0, stream, in, wstride, nch, N, sums);
             HIPCHK(hipGetLastError());
         }
         ColFwdArgs<T> ca{};
-        ca.in_win_stride = (long long)N * nch; ca.sums = sums; ca.remove_mean = 1; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = nb;
+        ca.in_win_stride = wstride; ca.sums = sums; ca.remove_mean = 1; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = nb;
         ca.e1 = e1; ca.e2 = e2; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.out = A;
         RowArgs<T> ra{};
         ra.n = N; ra.n1 = N1; ra.nwin = nb; ra.A = A; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.ea = ea; ra.eb = eb;
@@ -560,6 +563,59 @@ template <typename T> struct Ctx : CtxBase {
         const double sc = 1.0 / scale_pow2 / ((double)N * R);
         for (size_t i = 0; i < h.size(); ++i) { out[2 * i] = (double)h[i].x * sc; out[2 * i + 1] = (double)h[i].y * sc; }
         dfree(din); dfree(z);
+        return TWX_OK;
+    }
+
+    int caf_freqs(const int16_t* iq, int nch, int ch, const double* freqs, long long nf, twx_result* out) override {
+        short2* din = nullptr;
+        if (int rc = dalloc(&din, (size_t)N * nch)) return rc;
+        HIPCHK(hipMemcpy(din, iq, (size_t)N * nch * 4, hipMemcpyHostToDevice));
+        for (long long f0 = 0; f0 < nf; f0 += B) {
+            const int nb = (int)std::min<long long>(B, nf - f0);
+            if (int rc = run_batch(din + ch, nb, nch, nullptr, freqs + f0, res_dev, nullptr, true)) return rc;
+            HIPCHK(hipMemcpyAsync(out + f0, res_dev, sizeof(twx_result) * nb, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        }
+        dfree(din);
+        return TWX_OK;
+    }
+
+    int caf_bins(const int16_t* iq, int nch, int ch, long long k_lo, long long k_hi, double* pk, long long* lag) override {
+        if (k_hi < k_lo) return fail(TWX_E_ARG, "k_hi < k_lo");
+        short2* din = nullptr; C* Ysp = nullptr; double* pk_d = nullptr; long long* lag_d = nullptr;
+        const int nbmax = B * R;
+        if (int rc = dalloc(&din, (size_t)N * nch)) return rc;
+        if (int rc = dalloc(&Ysp, (size_t)N)) return rc;
+        if (int rc = dalloc(&pk_d, (size_t)nbmax)) return rc;
+        if (int rc = dalloc(&lag_d, (size_t)nbmax)) return rc;
+        HIPCHK(hipMemcpy(din, iq, (size_t)N * nch * 4, hipMemcpyHostToDevice));
+        const short2* in = din + ch;
+        HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums), stream));
+        hipLaunchKernelGGL((k_sums<0>), dim3((unsigned)std::min<long long>(256, std::max<long long>(1, N / 4096)), 1), dim3(256), 0, stream, in, 0ll, nch, N, sums);
+        HIPCHK(hipGetLastError());
+        ColFwdArgs<T> ca{};
+        ca.in_win_stride = 0; ca.sums = sums; ca.remove_mean = 1; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = 1;
+        ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.out = A;
+        if (col->fwd(COL_PLAIN, IN_I16, in, nch, &ca, (unsigned)ntiles, stream)) return fail(TWX_E_HIP, "k_col_fwd(plain) launch failed");
+        RowArgs<T> ra{};
+        ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = A; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.spec_out = Ysp;
+        if (row->run(ROW_STORE, &ra, (unsigned)N1, stream)) return fail(TWX_E_HIP, "k_row(store) launch failed");
+        for (long long k0 = k_lo; k0 <= k_hi; k0 += nbmax) {
+            const int nb = (int)std::min<long long>(nbmax, k_hi - k0 + 1);
+            CafArgs<T> fa{};
+            fa.n = N; fa.n1 = N1; fa.nbins = nb; fa.kappa0 = k0; fa.Y = Ysp; fa.cspec = cspec; fa.stab_i = stab_i;
+            fa.ta = ta; fa.tb = tb; fa.tshift = tshift; fa.scale = (T)scale_pow2; fa.Bz = Bz;
+            if (row->caf(&fa, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row_caf launch failed");
+            ColInvArgs<T> ia{};
+            ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = 1; ia.nwin = nb; ia.Bz = Bz; ia.tw1 = tw1; ia.part = part_peak; ia.zout = nullptr;
+            if (col->inv(&ia, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_inv launch failed");
+            hipLaunchKernelGGL((k_caf_reduce<T>), dim3(nb), dim3(256), 0, stream, part_peak, ntiles, 1.0 / scale_pow2 / (double)N, pk_d, lag_d);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(pk + (k0 - k_lo), pk_d, sizeof(double) * nb, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(lag + (k0 - k_lo), lag_d, sizeof(long long) * nb, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        }
+        dfree(din); dfree(Ysp); dfree(pk_d); dfree(lag_d);
         return TWX_OK;
     }
 };
@@ -699,6 +755,17 @@ int twx_debug_stamps(twx_ctx* ctx, unsigned long long* out, long long count) {
     if (!c || !c->stamps_dev) return TWX_E_STATE;
     (void)hipStreamSynchronize(c->stream);
     return hipMemcpy(out, c->stamps_dev, (size_t)count * 8, hipMemcpyDeviceToHost) == hipSuccess ? TWX_OK : TWX_E_HIP;
+}
+
+int twx_caf_bins(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, int64_t k_lo, int64_t k_hi, double* pk, int64_t* lag) {
+    if (!ctx || !iq || !pk || !lag || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
+    (void)hipSetDevice(ctx->impl->dev);
+    return ctx->impl->caf_bins(iq, n_channels, channel, k_lo, k_hi, pk, (long long*)lag);
+}
+int twx_caf_freqs(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, const double* freqs, int64_t n_freqs, twx_result* out) {
+    if (!ctx || !iq || !freqs || !out || n_freqs < 0 || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
+    (void)hipSetDevice(ctx->impl->dev);
+    return ctx->impl->caf_freqs(iq, n_channels, channel, freqs, n_freqs, out);
 }
 
 int twx_profile_reset(twx_ctx* ctx) {

@@ -24,6 +24,7 @@ template <typename T> int fwd(int mode, int intype, const void* inptr, int aux, 
         InI16 in{reinterpret_cast<const short2*>(inptr), aux};
         if (mode == COL_MIX) return launch_fwd<T, COL_MIX>(in, a, nblk, s);
         if (mode == COL_SQUARE) return launch_fwd<T, COL_SQUARE>(in, a, nblk, s);
+        if (mode == COL_PLAIN) return launch_fwd<T, COL_PLAIN>(in, a, nblk, s);
     } else if (intype == IN_CHIPS && mode == COL_PLAIN) {
         InChips in{reinterpret_cast<const unsigned char*>(inptr), aux};
         return launch_fwd<T, COL_PLAIN>(in, a, nblk, s);

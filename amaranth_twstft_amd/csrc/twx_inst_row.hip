@@ -20,11 +20,17 @@ template <typename T> int run(int mode, const void* args, unsigned nblk, hipStre
     return (int)hipGetLastError();
 }
 
+template <typename T> int caf(const void* args, unsigned nblk, hipStream_t s) {
+    const CafArgs<T>& a = *reinterpret_cast<const CafArgs<T>*>(args);
+    hipLaunchKernelGGL((k_row_caf<P, T, PADQ, NT>), dim3(nblk), dim3(NT), 0, s, a);
+    return (int)hipGetLastError();
+}
+
 struct Reg {
     Reg() {
-        register_row(RowOps{P::L, NT, 0, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<float>});
+        register_row(RowOps{P::L, NT, 0, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<float>, &caf<float>});
 #ifndef TWX_NO_F64
-        register_row(RowOps{P::L, NT, 1, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<double>});
+        register_row(RowOps{P::L, NT, 1, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<double>, &caf<double>});
 #endif
     }
 } reg_instance;

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
     const int tid = threadIdx.x;
     In win = in; win.p += (long long)b * a.in_win_stride;
     T mx = 0, my = 0;
-    if (MODE != COL_PLAIN && a.remove_mean) {
+    if (a.remove_mean) {
         WinSums s = a.sums[b];
         mx = (T)((double)s.sI / (double)a.n);
         my = (T)((double)s.sQ / (double)a.n);
@@ -530,6 +530,84 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
             TWX_STAMP(10 + rho * 6);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_row_caf: delay x Doppler cross-ambiguity on the integer-bin Doppler grid f = kappa*fs/N.
+// Mixing by exp(-2 pi i kappa n/N) is a circular shift of FFT(y) by kappa bins,
+// so one forward transform Y serves every bin: row k1 of the shifted spectrum is row
+// (k1+kappa) mod N1 of Y rotated by floor((k1+kappa)/N1) along k2.  Per bin this kernel does
+// Y_shift .* conj(FFT(code)) → inverse row FFT → ·W_N^{-k1 q2}  (the loop body of
+// experiments/231001_DLL_PLL/rxcomplex.cpp:543-551 without the per-bin forward FFT).
+// grid = N1 * nbins (bins of equal k1 adjacent → the code-spectrum row is shared in L2)
+// ------------------------------------------------------------------------------------------
+template <typename T> struct CafArgs {
+    long long n; int n1, nbins; long long kappa0;
+    const cpx<T>* Y;        // FFT of the mean-removed window, [k1][k2]
+    const cpx<T>* cspec;    // conj(FFT(code)), [k1][k2]
+    const cpx<T>* stab_i;
+    const cpx<T>* ta; const cpx<T>* tb; int tshift;
+    T scale;
+    cpx<T>* Bz;             // [bin][k1][q2]
+};
+
+template <class P2, typename T, int PADQ, int NT>
+__global__ __launch_bounds__(NT) void k_row_caf(CafArgs<T> a) {
+    using C = cpx<T>;
+    using PR = typename Rev<P2>::type;
+    using TI = RowTile<PR, T, true, PADQ>;
+    constexpr int S = P2::S, N2 = P2::L;
+    constexpr int R0 = PR::radix(0), NS0 = N2 / R0, RIL = PR::radix(S - 1), NSI = N2 / RIL;
+    constexpr int NTI = StageTabs<PR>::total;
+    __shared__ C lds[TI::lds_elems + NTI + RIL];
+    C* tab_i = lds + TI::lds_elems;
+    C* s_vc = tab_i + NTI;
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int k1 = logical / a.nbins, bin = logical % a.nbins;
+    const int tid = threadIdx.x;
+    const long long sft = (long long)k1 + a.kappa0 + bin;
+    long long k1s = sft % a.n1; if (k1s < 0) k1s += a.n1;
+    long long cr = ((sft - k1s) / a.n1) % N2; if (cr < 0) cr += N2;
+    const C* yrow = a.Y + k1s * N2;
+    const C* cs = a.cspec + (long long)k1 * N2;
+    C v[PR::rmax()];
+    if (tid < NS0) {
+        TWX_UNROLL
+        for (int r = 0; r < R0; ++r) {
+            int k2 = tid + r * NS0;
+            int ks = k2 + (int)cr; if (ks >= N2) ks -= N2;
+            v[r] = cscale(cmul(yrow[ks], cs[k2]), a.scale);
+        }
+    }
+    for (int i = tid; i < NTI; i += NT) tab_i[i] = a.stab_i[i];
+    if (tid < RIL) {
+        const unsigned m = (unsigned)k1 * (unsigned)tid * (unsigned)NSI;
+        s_vc[tid] = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & ((1u << a.tshift) - 1u)]));
+    }
+    if (tid < NS0) { TI::template bfly<0>(v); TI::template store_lds<0>(lds, tid, 0, v); }
+    __syncthreads();
+    MidStages<TI, PR, T, 1>::run(lds, tab_i, v, tid);
+    if (tid < NSI) {
+        TI::template load_lds_tab<S - 1>(lds, tab_i, tid, v);
+        TI::template bfly<S - 1>(v);
+        const unsigned m = (unsigned)k1 * (unsigned)tid;
+        const C ub = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & ((1u << a.tshift) - 1u)]));
+        C* out = a.Bz + (long long)bin * a.n + (long long)k1 * N2;
+        TWX_UNROLL
+        for (int q = 0; q < RIL; ++q) out[tid + q * NSI] = cmul(cmul(v[q], ub), s_vc[q]);
+    }
+}
+
+// per-bin (peak magnitude, lag) from the column-pass partial records.  grid = nbins
+template <typename T>
+__global__ __launch_bounds__(256) void k_caf_reduce(const ArgPart<T>* __restrict__ part, int nparts, double mag_scale,
+                                                    double* __restrict__ pk, long long* __restrict__ lag) {
+    const int b = blockIdx.x;
+    __shared__ char scratch[64];
+    Best<T> best; best.val = T(-1); best.idx = 0xffffffffu;
+    for (int i = threadIdx.x; i < nparts; i += 256) best.take(part[(long long)b * nparts + i].val, part[(long long)b * nparts + i].idx);
+    best = block_best<T, 256>(best, scratch);
+    if (threadIdx.x == 0) { pk[b] = sqrt((double)best.val) * mag_scale; lag[b] = best.idx; }
 }
 
 // ------------------------------------------------------------------------------------------

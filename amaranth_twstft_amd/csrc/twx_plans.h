@@ -18,6 +18,7 @@ struct RowOps {
     int L, NT, f64;
     int S, R[4];       // radices in forward stage order
     int (*run)(int mode, const void* args /*RowArgs<T>*/, unsigned nblk, hipStream_t s);
+    int (*caf)(const void* args /*CafArgs<T>*/, unsigned nblk, hipStream_t s);
 };
 
 void register_col(const ColOps& o);

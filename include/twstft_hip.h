@@ -127,6 +127,20 @@ int twx_get_code_spectrum(twx_ctx* ctx, double* out);
 int twx_xcorr_map(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, double df,
                   double* out);
 
+/* Delay x Doppler cross-ambiguity of ONE window (host int16 capture, as twx_process_windows) ------
+ * Replaces the acquisition sweep of experiments/231001_DLL_PLL/rxcomplex.cpp:534-563 (per trial
+ * offset: down-convert → FFT → cross_spectrum → IFFT → izamax).
+ * twx_caf_bins: integer-bin Doppler grid f = kappa*fs/N, kappa = k_lo..k_hi inclusive (fs/N = 1 Hz
+ *   for the 1-s window); one forward FFT, then per bin a circular spectrum shift, the code-spectrum
+ *   product and an inverse FFT (no interpolation).  pk[i] = max |xcorr| (same normalisation as
+ *   prnmap, 1/N), lag[i] = its 0-based lag, i = kappa-k_lo.
+ * twx_caf_freqs: arbitrary trial offsets (Hz): full processing(d,df) of the same window per offset
+ *   (context's nint applies); out = n_freqs results. */
+int twx_caf_bins(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, int64_t k_lo, int64_t k_hi,
+                 double* pk, int64_t* lag);
+int twx_caf_freqs(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, const double* freqs,
+                  int64_t n_freqs, twx_result* out);
+
 /* Profiling (TWX_FLAG_PROFILE): per kernel class, HIP-event time on the context's stream. */
 #define TWX_PROF_MAX 16
 typedef struct twx_prof_entry { char name[32]; double ms_total; int64_t launches; int64_t units; } twx_prof_entry;

@@ -282,3 +282,68 @@ def test_claudio_convention():
         d = d - d.mean()
         o = orc.processing_claudio(d, 300.0, temps, fc, code, Nint=1, ddof=1)
         _check(g, o)
+
+
+def test_caf_integer_bins_vs_oracle():
+    """Delay x Doppler surface on the integer-bin grid vs the oracle's
+    shift-and-correlate restatement of rxcomplex.cpp:534-563 (unpinned)."""
+    nchips, n = 10000, 20000
+    chips = chips_for(14, 43, nchips)
+    df_bins = 7                                               # true offset = 7 bins = 7*fs/N = 1750 Hz
+    p = synth.SynthParams(delay_q8=6543 * 256, fstep=synth.fstep_for_df(df_bins * FS / n, FS), phi0=77, amp=400,
+                          noise_gain=synth.noise_gain_for_sigma(300.0), seed=8)
+    raw = synth.synth_channel(n, chips, 2, p)
+    with Correlator(chips, fs=FS, Nint=0) as cor:
+        pk, lag = cor.caf_bins(raw, -40, 40)
+    d = orc.deinterleave(raw, 1, 0)
+    d = d - d.mean()
+    ks, pk_o, lag_o = orc.caf_bins_shift(d, orc.make_fcode(orc.make_code(chips, 2)), -40, 40)
+    assert np.array_equal(lag, lag_o)                          # every bin's arg-max, bit-exact
+    assert np.abs(pk - pk_o).max() <= MAG_TOL * pk_o.max()
+    best = int(np.argmax(pk))
+    assert ks[best] == df_bins and lag[best] == 6543
+
+
+def test_caf_arbitrary_frequencies_and_acquire():
+    nchips, n = 10000, 20000
+    chips = chips_for(14, 57, nchips)
+    p = synth.SynthParams(delay_q8=1500 * 256, fstep=synth.fstep_for_df(1337.0, FS), phi0=5, amp=500,
+                          noise_gain=synth.noise_gain_for_sigma(300.0), seed=18)
+    raw = synth.synth_channel(n, chips, 2, p)
+    freqs = np.array([1000.0, 1250.0, 1337.0, 1500.0])
+    d = orc.deinterleave(raw, 1, 0)
+    d = d - d.mean()
+    fcode = orc.make_fcode(orc.make_code(chips, 2))
+    f_o, pk_o, lag_o = orc.caf_bins(d, fcode, FS, 1000.0, 1500.0, 1e9)   # single evaluation helper below
+    with Correlator(chips, fs=FS, Nint=0) as cor:
+        res = cor.caf_freqs(raw, freqs)
+        for f, r in zip(freqs, res):
+            y = d * np.exp(-2j * np.pi * f * np.arange(n) / FS)
+            m = np.abs(np.fft.ifft(np.fft.fft(y) * fcode))
+            assert r.indice == int(m.argmax())
+            assert abs(abs(r.xval) - m.max()) <= MAG_TOL * m.max()
+        fc, pk, lag = cor.acquire(raw, fc_init=1200.0, frange=512.0, fstep=128.0)
+    assert lag == 1500 and abs(fc - 1337.0) <= 1.0
+
+
+def test_caf_full_size_peak_location():
+    """Full-size window (5e6 samples): the CAF peak over +-30 bins sits at the generator's offset and delay."""
+    nchips, n = 2500000, 5000000
+    chips = chips_for(22, 3, nchips)
+    p = synth.SynthParams(delay_q8=1311765 * 256, fstep=synth.fstep_for_df(12.0, FS), phi0=0, amp=200,
+                          noise_gain=synth.noise_gain_for_sigma(400.0), seed=7)
+    import ctypes as C2
+    lib = L.load()
+    import torch
+    dev = torch.device("cuda", 0)
+    iq = torch.empty((n, 2), dtype=torch.int16, device=dev)
+    params = np.array([p.delay_q8, p.fstep, p.phi0, p.amp, p.noise_gain, p.seed, p.stream, 0], dtype=np.int64)
+    cd = torch.from_numpy(chips).to(dev)
+    L.check(lib.twx_synth_capture_dev(iq.data_ptr(), n, 0, cd.data_ptr(), nchips, 2, 1, params.ctypes.data_as(C2.c_void_p), None))
+    torch.cuda.synchronize()
+    raw = iq.cpu().numpy()
+    with Correlator(chips, fs=FS, Nint=0) as cor:
+        pk, lag = cor.caf_bins(raw, -30, 30)
+    best = int(np.argmax(pk))
+    assert best - 30 == 12 and lag[best] == 1311765
+    assert pk[best] > 3 * np.median(pk)
