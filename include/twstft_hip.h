@@ -141,6 +141,22 @@ int twx_caf_bins(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t ch
 int twx_caf_freqs(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, const double* freqs,
                   int64_t n_freqs, twx_result* out);
 
+/* Direct sliding dot-product correlator for short codes (tracking stage) -----------------------
+ * Replaces downconv_trk + cblas_dgemm(W^T X)/nobs + the PRN_mapping replica matrix of
+ * experiments/231001_DLL_PLL/rxcomplex.cpp:593-605,989-999,1051-1061.  For code period p < ncodes
+ * and lag index li (lag = li - nlag, nlag <= 31):
+ *   out[p][li] = (scale/nobs) * sum_i x[pt+p*nobs+i] * exp(-2 pi j (ff*(p*nobs+i)+phi)) * replica[(i-lag) mod nobs]
+ * iq: host int16 capture of n_samples samples; ff in cycles/sample, phi in cycles; out: ncodes*(2*nlag+1)
+ * complex doubles (re, im).  cor = re^2+im^2 and phi = atan2(im,re)/2pi (get_cor_and_phi, :1063) are host one-liners. */
+int twx_sliding_dot(const int16_t* iq, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t pt, int64_t nobs,
+                    int32_t ncodes, int32_t nlag, const float* replica, double ff, double phi, double scale, double* out);
+
+/* FIR low-pass + decimation front end (BASELINE.json configs[4], 70 Msps → 5 Msps): y[m] = sum_j taps[j]*x[m*dec+j],
+ * "valid" part only: *n_out = (n_in-ntaps)/dec+1.  ntaps <= 1024, dec <= 16.  out_i16 (interleaved IQ, rounded
+ * half-to-even, saturated) and/or out_f32 (interleaved re,im) may be NULL.  No twin in the reference. */
+int twx_fir_decimate(const int16_t* iq, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps, int32_t ntaps,
+                     int32_t dec, int16_t* out_i16, float* out_f32, int64_t* n_out);
+
 /* Profiling (TWX_FLAG_PROFILE): per kernel class, HIP-event time on the context's stream. */
 #define TWX_PROF_MAX 16
 typedef struct twx_prof_entry { char name[32]; double ms_total; int64_t launches; int64_t units; } twx_prof_entry;

@@ -314,7 +314,6 @@ def test_caf_arbitrary_frequencies_and_acquire():
     d = orc.deinterleave(raw, 1, 0)
     d = d - d.mean()
     fcode = orc.make_fcode(orc.make_code(chips, 2))
-    f_o, pk_o, lag_o = orc.caf_bins(d, fcode, FS, 1000.0, 1500.0, 1e9)   # single evaluation helper below
     with Correlator(chips, fs=FS, Nint=0) as cor:
         res = cor.caf_freqs(raw, freqs)
         for f, r in zip(freqs, res):
@@ -347,3 +346,77 @@ def test_caf_full_size_peak_location():
     best = int(np.argmax(pk))
     assert best - 30 == 12 and lag[best] == 1311765
     assert pk[best] > 3 * np.median(pk)
+
+
+def test_sliding_dot_short_code():
+    """Direct path (a12): ±nlag sliding dot products per 40-ms code period vs the oracle restatement
+    of rxcomplex.cpp:605,989-999 (unpinned) and vs the FFT path on the same data."""
+    from amaranth_twstft_amd import tracking
+    nchips, sps = 10000, 2
+    nobs, ncodes, nlag = nchips * sps, 5, 28
+    chips = chips_for(14, 43, nchips)
+    delay = 11
+    p = synth.SynthParams(delay_q8=delay * 256, fstep=synth.fstep_for_df(250.0, FS), phi0=1 << 28, amp=600,
+                          noise_gain=synth.noise_gain_for_sigma(200.0), seed=61)
+    raw = synth.synth_channel(nobs * ncodes + 100, chips, sps, p)
+    code = orc.make_code(chips, sps)
+    ff = synth.df_of_fstep(p.fstep, FS) / FS
+    got = tracking.sliding_dot(raw, code, nobs, ncodes, nlag, pt=0, ff=ff, phi=0.0, scale=np.sqrt(2.0) / 32768.0)
+    x = orc.deinterleave(raw, 1, 0)
+    for pp in range(ncodes):
+        i = np.arange(pp * nobs, (pp + 1) * nobs)
+        y = np.sqrt(2.0) / 32768.0 * x[i] * np.exp(-2j * np.pi * ff * i)
+        ref = orc.sliding_dot(y, code, nlag)
+        assert np.abs(got[pp] - ref).max() <= 2e-6 * np.abs(ref).max()
+        assert int(np.abs(got[pp]).argmax()) - nlag == delay
+    cor, phi = tracking.get_cor_and_phi(got)
+    lag, hrc = tracking.hrc_delay(cor, nlag)
+    assert (lag == delay).all() and np.all(np.abs(hrc - delay) < 0.5)
+
+
+def test_fir_decimating_front_end():
+    """70 Msps → 5 Msps front end (configs[4]); oracle = fp64 direct convolution (unpinned)."""
+    from amaranth_twstft_amd import frontend
+    fs_in, dec = 70e6, 14
+    taps = frontend.lowpass_taps(fs_in, 2.1e6, 0.4e6)
+    assert taps.size % 2 == 1 and 400 < taps.size < 1024
+    assert np.allclose(taps, orc.fir_lowpass_hamming(fs_in, 2.1e6, 0.4e6), atol=1e-7)
+    rng = np.random.default_rng(5)
+    n_in = 200000
+    raw = np.clip(rng.normal(0, 3000, (n_in, 2)), -32768, 32767).astype(np.int16)
+    y = frontend.fir_decimate(raw, taps, dec, out="f32")
+    x = raw[:, 0].astype(np.float64) + 1j * raw[:, 1]
+    ref = orc.fir_decimate(x, taps.astype(np.float64), dec)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-3
+    y16 = frontend.fir_decimate(raw, taps, dec, out="int16")
+    assert np.abs(y16[:, 0] - np.rint(ref.real)).max() <= 1 and np.abs(y16[:, 1] - np.rint(ref.imag)).max() <= 1
+
+
+def test_wideband_chain_70msps():
+    """configs[4] in miniature: chips held 28 samples at 70 Msps → FIR ↓14 → standard chain at 5 Msps;
+    the lag found equals the lag the oracle finds on the same decimated int16 samples, fp32 vs fp64
+    peak magnitude within 1e-6."""
+    from amaranth_twstft_amd import frontend
+    nchips = 10000
+    chips = chips_for(14, 43, nchips)
+    sps_in, dec = 28, 14
+    n_in = nchips * sps_in
+    taps = frontend.lowpass_taps(70e6, 2.1e6, 0.4e6)
+    p = synth.SynthParams(delay_q8=(3000 * 14 + 5) * 256, fstep=synth.fstep_for_df(500.0, 70e6), phi0=3, amp=2000,
+                          noise_gain=synth.noise_gain_for_sigma(3000.0), seed=71)
+    wide = synth.synth_channel(n_in + taps.size + dec, chips, sps_in, p)
+    narrow = frontend.fir_decimate(wide, taps, dec, out="int16")[: 2 * nchips]
+    assert narrow.shape == (2 * nchips, 2)
+    with Correlator(chips, fs=FS, Nint=1) as c32, Correlator(chips, fs=FS, Nint=1, precision="f64") as c64:
+        g32 = c32.process(narrow, n_channels=1, channel=0, df=500.0)[0]
+        g64 = c64.process(narrow, n_channels=1, channel=0, df=500.0)[0]
+    d = orc.deinterleave(narrow, 1, 0)
+    d = d - d.mean()
+    code = orc.make_code(chips, 2)
+    o = orc.processing(d, None, None, np.arange(2 * nchips) / FS, orc.make_fcode(code), code, Nint=1, fs=FS, df=500.0)
+    assert g32.indice == g64.indice == o["indice"]
+    assert abs(abs(g32.xval) - abs(g64.xval)) <= MAG_TOL * abs(g64.xval)
+    # y[m] is centred on input sample m*dec + (ntaps-1)/2, so the lag moves EARLIER by the half length
+    expect = (3000 * 14 + 5 - (taps.size - 1) / 2) / 14.0
+    assert abs(g32.indice / 3.0 - expect) < 1.0
