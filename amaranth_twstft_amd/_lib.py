@@ -16,6 +16,7 @@ TWX_CONV_GODUAL, TWX_CONV_CLAUDIO = 0, 1
 TWX_WIN_NONE, TWX_WIN_HAMMING = 0, 1
 TWX_F32, TWX_F64 = 0, 1
 TWX_FLAG_PROFILE = 1
+TWX_FLAG_FINE_FREQ = 2
 TWX_PROF_MAX = 16
 
 

@@ -89,7 +89,7 @@ class Correlator:
 
     def __init__(self, chips=None, fs: float = 5e6, sps: int = 2, Nint: int = 1, *, lfsr: tuple[int, int, int] | None = None,
                  precision: str = "f32", var_ddof: int = 0, snr_rot: int = -1, window: str = "none", convention: str = "godual",
-                 device: int = -1, max_batch: int = 0, profile: bool = False):
+                 device: int = -1, max_batch: int = 0, profile: bool = False, fine_freq: bool = False):
         self._lib = L.load()
         cfg = L.twx_config()
         cfg.fs, cfg.sps, cfg.nint = fs, sps, Nint
@@ -106,7 +106,7 @@ class Correlator:
         cfg.window = {"none": L.TWX_WIN_NONE, "hamming": L.TWX_WIN_HAMMING}[window]
         cfg.precision = {"f32": L.TWX_F32, "f64": L.TWX_F64}[precision]
         cfg.var_ddof, cfg.snr_rot, cfg.device, cfg.max_batch = var_ddof, snr_rot, device, max_batch
-        cfg.flags = L.TWX_FLAG_PROFILE if profile else 0
+        cfg.flags = (L.TWX_FLAG_PROFILE if profile else 0) | (L.TWX_FLAG_FINE_FREQ if fine_freq else 0)
         h = C.c_void_p()
         L.check(self._lib.twx_create(C.byref(cfg), C.byref(h)))
         self._h = h

@@ -273,6 +273,7 @@ template <typename T> struct Ctx : CtxBase {
     ArgPart<T>*part_band = nullptr, *part_peak = nullptr;
     twx_result* res_dev = nullptr;
     unsigned long long* stamps_dev = nullptr;   // TWX_STAMPS diagnostic builds
+    double* fine_u = nullptr; int fine_M = 0;   // TWX_FLAG_FINE_FREQ
     int ntiles = 0;
 
     template <typename U> int upload(U** dst, const std::vector<U>& src) {
@@ -405,6 +406,12 @@ template <typename T> struct Ctx : CtxBase {
         if (int rc = dalloc(&stamps_dev, (size_t)B * N1 * 8 * 32)) return rc;
         HIPCHK(hipMemset(stamps_dev, 0, (size_t)B * N1 * 8 * 32 * 8));
 #endif
+        if (cfg.flags & TWX_FLAG_FINE_FREQ) {
+            const long long third = (long long)floor(cfg.fs / 3.0);        // int(fs//3)
+            if (N < third) return fail(TWX_E_ARG, "TWX_FLAG_FINE_FREQ needs a window of at least fs/3 samples (godual_ranging.py:26)");
+            fine_M = (int)((third + 9) / 10);
+            if (int rc = dalloc(&fine_u, (size_t)B * fine_M)) return rc;
+        }
         HIPCHK(hipStreamSynchronize(stream));
         return TWX_OK;
     }
@@ -478,6 +485,15 @@ template <typename T> struct Ctx : CtxBase {
             ProfScope ps(this, PC_DFT, nb);
             hipLaunchKernelGGL((k_df_tables<T>), dim3(nb), dim3(256), 0, stream, band ? 1 : 0, part_band, N1, dfv, dfidx, cfg.fs,
                                (long long)N, N1, N2, e1, e2);
+            HIPCHK(hipGetLastError());
+        }
+        if (cfg.flags & TWX_FLAG_FINE_FREQ) {
+            hipLaunchKernelGGL((k_fine_angle<0>), dim3(64, nb), dim3(256), 0, stream, in, wstride, nch, (long long)N, sums, dfv, cfg.fs, fine_M, fine_u);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL((k_fine_fit<0>), dim3(nb), dim3(1024), 0, stream, fine_u, fine_M, cfg.fs, dfv);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL((k_df_tables<T>), dim3(nb), dim3(256), 0, stream, 2, part_band, N1, dfv, dfidx, cfg.fs,
+                               (long long)N, N1, N2, e1, e2);       // rebuild the NCO tables for df + dfleftover
             HIPCHK(hipGetLastError());
         }
         {

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_df_tables(int estimate, const ArgPart<T
     const int b = blockIdx.x;
     __shared__ double s_df;
     __shared__ char scratch[64];
-    if (estimate) {
+    if (estimate == 1) {
         Best<T> best; best.val = T(-1); best.idx = 0xffffffffu;
         for (int i = threadIdx.x; i < nparts; i += 256) best.take(part[(long long)b * nparts + i].val, part[(long long)b * nparts + i].idx);
         best = block_best<T, 256>(best, scratch);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_df_tables(int estimate, const ArgPart<T
         }
     } else if (threadIdx.x == 0) {
         s_df = dfv[b];
-        dfidx[b] = -1;
+        if (estimate == 0) dfidx[b] = -1;     // 2: tables only (after the fine-frequency step)
     }
     __syncthreads();
     const double fn = s_df / fs;   // cycles per sample
@@ -198,6 +198,75 @@ __global__ __launch_bounds__(256) void k_df_tables(int estimate, const ArgPart<T
         if (i < n1) e1[(long long)b * n1 + i] = mk<T>((T)c, (T)s);
         else e2[(long long)b * n2 + (i - n1)] = mk<T>((T)c, (T)s);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fine carrier offset from the phase drift (optional; experiments/221219_twoway/processing/
+// godual_ranging.py:26-30, Octave twin 221219…/godual_ranging.m:19-24, commented out in
+// processing/Octave/godual_ranging.m:19-24):
+//   a = polyfit([1:10:fs/3]/fs, conv(angle(y(1:10:fs/3)), ones(100,1)/100)(50:end-50), 1); df += a(1)/2/pi
+// k_fine_angle: u[m] = angle((d[10m]-mean) * exp(-2 pi j df 10m/fs)), m < M  (fp64).  grid = (chunks, windows)
+// k_fine_fit:   100-tap moving average with the reference's edge handling, straight-line LSQ slope,
+//               df += slope/2pi.  grid = windows
+// ------------------------------------------------------------------------------------------
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_fine_angle(const short2* __restrict__ in, long long win_stride, int nch, long long n,
+                                                    const WinSums* __restrict__ sums, const double* __restrict__ dfv, double fs,
+                                                    int M, double* __restrict__ u) {
+    const int b = blockIdx.y;
+    const short2* p = in + (long long)b * win_stride;
+    const WinSums s = sums[b];
+    const double mI = (double)s.sI / (double)n, mQ = (double)s.sQ / (double)n;
+    const double fn = dfv[b] / fs;
+    for (int m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256) {
+        const long long i = 10ll * m;
+        const short2 x = p[i * nch];
+        double ph = fn * (double)i; ph -= rint(ph);
+        double sn, cs;
+        sincospi(-2.0 * ph, &sn, &cs);
+        const double re = (double)x.x - mI, im = (double)x.y - mQ;
+        u[(long long)b * M + m] = atan2(re * sn + im * cs, re * cs - im * sn);
+    }
+}
+
+__device__ __forceinline__ double block_sum_1024(double v, double* sh) {
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    return t;
+}
+
+template <int UNUSED = 0>
+__global__ __launch_bounds__(1024) void k_fine_fit(const double* __restrict__ u, int M, double fs, double* __restrict__ dfv) {
+    const int b = blockIdx.x;
+    const double* ub = u + (long long)b * M;
+    __shared__ double sh[16];
+    // pass 1: means of t and v
+    double sv = 0, st = 0;
+    for (int i = threadIdx.x; i < M; i += 1024) {
+        const int lo = max(0, i - 50), hi = min(i + 49, M - 1);
+        double a = 0;
+        for (int j = lo; j <= hi; ++j) a += ub[j];
+        sv += a * 0.01;
+        st += (1.0 + 10.0 * (double)i) / fs;
+    }
+    const double vbar = block_sum_1024(sv, sh) / (double)M;
+    const double tbar = block_sum_1024(st, sh) / (double)M;
+    double sxy = 0, sxx = 0;
+    for (int i = threadIdx.x; i < M; i += 1024) {
+        const int lo = max(0, i - 50), hi = min(i + 49, M - 1);
+        double a = 0;
+        for (int j = lo; j <= hi; ++j) a += ub[j];
+        const double dt = (1.0 + 10.0 * (double)i) / fs - tbar;
+        sxy += dt * (a * 0.01 - vbar);
+        sxx += dt * dt;
+    }
+    const double txy = block_sum_1024(sxy, sh);
+    const double txx = block_sum_1024(sxx, sh);
+    if (threadIdx.x == 0) dfv[b] += txy / txx / (2.0 * 3.14159265358979323846);
 }
 
 // ------------------------------------------------------------------------------------------

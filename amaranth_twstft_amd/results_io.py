@@ -1,0 +1,57 @@
+"""Result containers in the reference's formats, so the later analysis scripts consume them unchanged.
+
+* ``save_mat``: the variable set of ``save -mat … corr* df1 df2 indic* SNR* code puissan*``
+  (processing/Octave/godual_ranging.m:126-131) plus ``xval*`` (acquisition/
+  claudio_aligned_code_ranging_separate.m:207); 1×nwin row vectors, ``indice`` 1-based as Octave
+  stores it, MAT v5 via scipy.io (schema seen in experiments/220616_Besancon/1655300700.mat.gz).
+* ``tsv_rows``: the per-window line printed by godual_ranging.m:96,98.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _vec(results, attr):
+    return np.array([[getattr(r, attr) for r in results]])
+
+
+def mat_dict(res1, res2=None, code=None, remote: int = 0) -> dict:
+    """Variables of godual_ranging.m:126-131 for channel 1 (measurement) and optionally 2 (reference)."""
+    d = {}
+    for suffix, res in (("1", res1), ("2", res2)):
+        if res is None:
+            continue
+        d["indice" + suffix] = _vec(res, "indice").astype(np.float64) + 1.0        # Octave 1-based
+        d["correction" + suffix] = _vec(res, "correction")
+        d["df" + suffix] = _vec(res, "df")
+        d[f"SNR{suffix}r"] = _vec(res, "SNRr")
+        d[f"SNR{suffix}i"] = _vec(res, "SNRi")
+        d["puissance" + suffix] = _vec(res, "puissance")
+        d[f"puissance{suffix}code"] = _vec(res, "puissancecode")
+        d[f"puissance{suffix}noise"] = _vec(res, "puissancenoise")
+        d["xval" + suffix] = _vec(res, "xval")
+        d[f"xval{suffix}m1"] = _vec(res, "xvalm1")
+        d[f"xval{suffix}p1"] = _vec(res, "xvalp1")
+    if code is not None:
+        d["code"] = np.asarray(code, dtype=np.float64).reshape(1, -1)
+    return d
+
+
+def save_mat(path: str, res1, res2=None, code=None, remote: int = 0) -> None:
+    import scipy.io
+    scipy.io.savemat(path, mat_dict(res1, res2, code, remote), format="5", do_compression=False)
+
+
+def tsv_rows(res1, res2, fs: float, Nint: int):
+    """Lines of godual_ranging.m:96 (two channels) or :98 (remote, one channel); header of :74."""
+    yield "n\tdt1\tdf1\tP1\tSNR1\tdt2\tdf2\tP2\tSNR2\r\n"
+    r = 2 * Nint + 1
+    for p, a in enumerate(res1, start=1):
+        # Octave: (indice1(p)-1+correction1(p))/fs/(2*Nint+1) with 1-based indice == 0-based indice here
+        row = "%d\t%.12f\t%.3f\t%.1f\t%.1f" % (p, (a.indice + a.correction) / fs / r, a.df, 10 * np.log10(a.puissance),
+                                                 10 * np.log10(a.SNRi + a.SNRr))
+        if res2 is not None:
+            b = res2[p - 1]
+            row += "\t%.12f\t%.3f\t%.1f\t%.1f" % ((b.indice - b.correction) / fs / r, b.df, 10 * np.log10(b.puissance),
+                                                  10 * np.log10(b.SNRi + b.SNRr))
+        yield row + "\r\n"

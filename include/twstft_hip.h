@@ -38,7 +38,10 @@ enum { TWX_CONV_GODUAL = 0,   /* fft(y).*conj(fft(code))   godual_ranging.m:26,6
        TWX_CONV_CLAUDIO = 1 };/* fft(code).*conj(fft(y))   claudio_aligned_code_ranging_separate.m:59,124 */
 enum { TWX_WIN_NONE = 0, TWX_WIN_HAMMING = 1 };   /* Hamming on fcode: processing/CPP/main.cpp:717-719 */
 enum { TWX_F32 = 0, TWX_F64 = 1 };
-enum { TWX_FLAG_PROFILE = 1 };                    /* time every kernel launch with HIP events */
+enum { TWX_FLAG_PROFILE = 1,                      /* time every kernel launch with HIP events */
+       TWX_FLAG_FINE_FREQ = 2 };                  /* add the phase-drift fine carrier step of
+                                                     experiments/221219_twoway/processing/godual_ranging.py:26-30
+                                                     (needs N >= fs/3; off = processing/Octave/godual_ranging.m) */
 
 /* Replaces the script constants / globals `fs Nint code fcode` (godual_ranging.m:3-5,62-66),
  * GoRanging's constructor arguments (processing/CPP/main.cpp:93-189). */

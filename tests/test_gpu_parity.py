@@ -420,3 +420,26 @@ def test_wideband_chain_70msps():
     # y[m] is centred on input sample m*dec + (ntaps-1)/2, so the lag moves EARLIER by the half length
     expect = (3000 * 14 + 5 - (taps.size - 1) / 2) / 14.0
     assert abs(g32.indice / 3.0 - expect) < 1.0
+
+
+@pytest.mark.parametrize("case", ["n2M", "n2M_loopback", "n5M_C2"])
+def test_device_vs_reference_221219_processing_values(case):
+    """The device path with the fine-frequency step on, against the RETURN VALUES of the reference's
+    own processing() (experiments/221219_twoway/processing/godual_ranging.py:18-65) stored in
+    tests/golden/ref221219_processing.json — no oracle in between."""
+    g = load_golden("ref221219_processing.json")
+    c = next(x for x in g["cases"] if x["name"] == case)
+    chips, raw = capture_from_desc(c["synth"], c["input_sha256"])
+    n = 2 * len(chips)
+    with Correlator(chips, fs=c["fs"], Nint=c["Nint"], fine_freq=True) as cor:
+        got = cor.process(raw, n_channels=1, channel=0, band=band_numpy(c["fs"], n))[0]
+    ref = c["ref"]
+    assert got.indice == ref["indice"]                                   # integer lag: bit-exact
+    assert abs(got.correction - ref["correction"]) <= 2e-4
+    assert abs(got.df - ref["df"]) <= 1e-5                               # Hz (README parity level: 1e-3 Hz)
+    delay_err = abs((got.indice + got.correction) - (ref["indice"] + ref["correction"])) / c["fs"] / 3
+    assert delay_err <= 2e-11                                            # 20 ps
+    for k in ("SNRr", "SNRi", "puissancecode"):
+        assert abs(getattr(got, k) - ref[k]) <= 3e-4 * max(ref["SNRr"], ref["SNRi"], ref[k]) + 1e-30, k
+    for k in ("puissance", "puissancenoise"):
+        assert abs(getattr(got, k) - ref[k]) <= 1e-6 * ref[k], k
