@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <mutex>
 #include <string>
@@ -274,6 +275,8 @@ template <typename T> struct Ctx : CtxBase {
     twx_result* res_dev = nullptr;
     unsigned long long* stamps_dev = nullptr;   // TWX_STAMPS diagnostic builds
     double* fine_u = nullptr; int fine_M = 0;   // TWX_FLAG_FINE_FREQ
+    unsigned int* queue = nullptr;              // row queue of the persistent middle pass
+    int persistent = 0; int ncu = 256;   // TWX_ROW_PERSISTENT: 0 = one WG per row (default), k>0 = persistent row queue with k WGs per CU, -1 = one WG per (row, phase)
     int ntiles = 0;
 
     template <typename U> int upload(U** dst, const std::vector<U>& src) {
@@ -402,6 +405,13 @@ template <typename T> struct Ctx : CtxBase {
         if (int rc = dalloc(&part_band, (size_t)B * N1)) return rc;
         if (int rc = dalloc(&part_peak, (size_t)B * R * ntiles)) return rc;
         if (int rc = dalloc(&res_dev, (size_t)B)) return rc;
+        if (int rc = dalloc(&queue, 4)) return rc;
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+            const char* e = getenv("TWX_ROW_PERSISTENT");
+            if (e) persistent = atoi(e);
+        }
 #ifdef TWX_STAMPS
         if (int rc = dalloc(&stamps_dev, (size_t)B * N1 * 8 * 32)) return rc;
         HIPCHK(hipMemset(stamps_dev, 0, (size_t)B * N1 * 8 * 32 * 8));
@@ -502,7 +512,14 @@ template <typename T> struct Ctx : CtxBase {
         }
         {
             ProfScope ps(this, PC_ROW_MID, (long long)nb * N);
-            if (row->run(ROW_MID, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(mid) launch failed");
+            if (persistent < 0) {
+                if (row->mid_s(&ra, (unsigned)(N1 * nb * R), stream)) return fail(TWX_E_HIP, "k_row_mid_s launch failed");
+            } else if (persistent) {
+                HIPCHK(hipMemsetAsync(queue, 0, 4, stream));
+                const unsigned total = (unsigned)(N1 * nb);
+                const unsigned grid = std::min<unsigned>(total, (unsigned)(ncu * persistent));
+                if (row->mid_p(&ra, queue, total, grid, stream)) return fail(TWX_E_HIP, "k_row_mid_p launch failed");
+            } else if (row->run(ROW_MID, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(mid) launch failed");
         }
         ColInvArgs<T> ia{};
         ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = R; ia.nwin = nb; ia.Bz = Bz; ia.tw1 = tw1; ia.part = part_peak; ia.zout = zout;

@@ -26,11 +26,23 @@ template <typename T> int caf(const void* args, unsigned nblk, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+template <typename T> int mid_p(const void* args, unsigned int* queue, unsigned total_rows, unsigned nblk, hipStream_t s) {
+    const RowArgs<T>& a = *reinterpret_cast<const RowArgs<T>*>(args);
+    hipLaunchKernelGGL((k_row_mid_p<P, T, PADQ, NT>), dim3(nblk), dim3(NT), 0, s, a, queue, total_rows);
+    return (int)hipGetLastError();
+}
+
+template <typename T> int mid_s(const void* args, unsigned nblk, hipStream_t s) {
+    const RowArgs<T>& a = *reinterpret_cast<const RowArgs<T>*>(args);
+    hipLaunchKernelGGL((k_row_mid_s<P, T, PADQ, NT>), dim3(nblk), dim3(NT), 0, s, a);
+    return (int)hipGetLastError();
+}
+
 struct Reg {
     Reg() {
-        register_row(RowOps{P::L, NT, 0, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<float>, &caf<float>});
+        register_row(RowOps{P::L, NT, 0, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<float>, &caf<float>, &mid_s<float>, &mid_p<float>});
 #ifndef TWX_NO_F64
-        register_row(RowOps{P::L, NT, 1, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<double>, &caf<double>});
+        register_row(RowOps{P::L, NT, 1, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<double>, &caf<double>, &mid_s<double>, &mid_p<double>});
 #endif
     }
 } reg_instance;

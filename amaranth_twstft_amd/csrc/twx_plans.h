@@ -19,6 +19,8 @@ struct RowOps {
     int S, R[4];       // radices in forward stage order
     int (*run)(int mode, const void* args /*RowArgs<T>*/, unsigned nblk, hipStream_t s);
     int (*caf)(const void* args /*CafArgs<T>*/, unsigned nblk, hipStream_t s);
+    int (*mid_s)(const void* args /*RowArgs<T>*/, unsigned nblk, hipStream_t s);
+    int (*mid_p)(const void* args /*RowArgs<T>*/, unsigned int* queue, unsigned total_rows, unsigned nblk, hipStream_t s);
 };
 
 void register_col(const ColOps& o);
