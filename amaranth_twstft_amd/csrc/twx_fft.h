@@ -349,6 +349,31 @@ template <class P, typename T, bool INV, int PADQ> struct RowTile : Tile<P, T, I
 #endif
         }
     }
+    // the same twiddles kept by the caller: tw[r-1] = W_{Ns*R}^{jm*r} (forward sign), r = 1..R-1
+    template <int s> static TWX_HD void stage_twiddles(const C* tabs, int j, C* tw) {
+        constexpr int Ns = P::ns(s), Rr = P::radix(s);
+        const int jm = (Ns * Rr == P::L) ? j : (j % Ns);
+        int x[4]; int rem = jm;
+        TWX_UNROLL
+        for (int d = 0; d < s; ++d) { x[d] = rem % P::radix(d); rem /= P::radix(d); }
+        TWX_UNROLL
+        for (int r = 1; r < Rr; ++r) {
+            C w = tabs[StageTabs<P>::off(s, 0) + r * P::radix(0) + x[0]];
+            TWX_UNROLL
+            for (int d = 1; d < s; ++d) w = cmul(w, tabs[StageTabs<P>::off(s, d) + r * P::radix(d) + x[d]]);
+            tw[r - 1] = w;
+        }
+    }
+    template <int s> static TWX_HD void load_lds_pre(const C* lds, const C* tw, int j, C* v) {
+        constexpr int Rr = P::radix(s);
+        const int ib = Base::template in_base<s>(j);
+        v[0] = lds[Base::template in_idx<s>(ib, j, 0)];
+        TWX_UNROLL
+        for (int r = 1; r < Rr; ++r) {
+            const C u = lds[Base::template in_idx<s>(ib, j, r)];
+            v[r] = INV ? cmulc(u, tw[r - 1]) : cmul(u, tw[r - 1]);
+        }
+    }
 };
 
 }  // namespace twx

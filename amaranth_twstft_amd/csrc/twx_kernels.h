@@ -367,6 +367,9 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
 // ------------------------------------------------------------------------------------------
 enum { ROW_STORE = 0, ROW_BAND = 1, ROW_MID = 2 };
 #define TWX_MAX_PHASE 5
+#ifndef TWX_KEEP_TW
+#define TWX_KEEP_TW 0
+#endif
 #ifndef TWX_ABL
 #define TWX_ABL 0   // 1: no Bz stores, 2: no cspec load, 3: nphase forced to 1, 4: no A load, 5: no inverse transforms
 #endif
@@ -493,7 +496,15 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
     TWX_STAMP(3);
     // ---- forward last stage: v[q] = X[k1 + N1*k2], k2 = tid + q*NSL
     const bool act = tid < NSL;
-    if (act) { TF::template load_lds_tab<S - 1>(lds, tab_f, tid, v); TF::template bfly<S - 1>(v); }
+    // last-stage twiddles W_N2^{j r} are the same for the forward and (conjugated) the R inverse
+    // transforms of a palindromic plan: combine them once per row and keep them in registers
+    constexpr bool KEEP_TW = (MODE == ROW_MID) && PAL && (TWX_KEEP_TW != 0);
+    C twl[KEEP_TW ? RL - 1 : 1];
+    if constexpr (KEEP_TW) {
+        if (act) { TF::template stage_twiddles<S - 1>(tab_f, tid, twl); TF::template load_lds_pre<S - 1>(lds, twl, tid, v); TF::template bfly<S - 1>(v); }
+    } else {
+        if (act) { TF::template load_lds_tab<S - 1>(lds, tab_f, tid, v); TF::template bfly<S - 1>(v); }
+    }
 
     if constexpr (MODE == ROW_STORE) {
         if (act) {
@@ -584,7 +595,8 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
             MidStages<TI, PR, T, 1>::run(lds, tab_i, v, lt);
             TWX_STAMP(8 + rho * 6);
             if (lt < NSI) {
-                TI::template load_lds_tab<S - 1>(lds, tab_i, lt, v);
+                if constexpr (KEEP_TW) TI::template load_lds_pre<S - 1>(lds, twl, lt, v);
+                else TI::template load_lds_tab<S - 1>(lds, tab_i, lt, v);
                 TI::template bfly<S - 1>(v);
                 __builtin_amdgcn_sched_barrier(0);
                 TWX_STAMP(9 + rho * 6);
