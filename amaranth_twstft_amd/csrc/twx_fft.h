@@ -32,16 +32,48 @@ template <> struct cpx_sel<double> { typedef double type __attribute__((ext_vect
 template <typename T> using cpx = typename cpx_sel<T>::type;
 template <typename T> TWX_HD cpx<T> mk(T x, T y) { cpx<T> r; r.x = x; r.y = y; return r; }
 #define TWX_CPX_OPS(T)                                                                             \
-    TWX_HD cpx<T> cmul(cpx<T> a, cpx<T> b) { cpx<T> bs; bs.x = -b.y; bs.y = b.x; return a.xx * b + a.yy * bs; }   \
-    TWX_HD cpx<T> cmulc(cpx<T> a, cpx<T> b) { cpx<T> bs; bs.x = b.y; bs.y = -b.y; return a * b.xx + a.yx * bs; }   \
+    TWX_HD cpx<T> cmul_g(cpx<T> a, cpx<T> b) { cpx<T> bs; bs.x = -b.y; bs.y = b.x; return a.xx * b + a.yy * bs; }   \
+    TWX_HD cpx<T> cmulc_g(cpx<T> a, cpx<T> b) { cpx<T> bs; bs.x = b.y; bs.y = -b.y; return a * b.xx + a.yx * bs; }   \
     TWX_HD cpx<T> cconj(cpx<T> a) { cpx<T> r; r.x = a.x; r.y = -a.y; return r; }                  \
     TWX_HD cpx<T> cscale(cpx<T> a, T s) { return a * s; }                                          \
     TWX_HD T cnorm(cpx<T> a) { return a.x * a.x + a.y * a.y; }                                     \
-    TWX_HD cpx<T> mul_mi(cpx<T> a) { cpx<T> r; r.x = a.y; r.y = -a.x; return r; }                  \
-    TWX_HD cpx<T> mul_pi(cpx<T> a) { cpx<T> r; r.x = -a.y; r.y = a.x; return r; }
+    TWX_HD cpx<T> mul_mi(cpx<T> a) { return a.yx * cpx<T>{T(1), T(-1)}; }                          \
+    TWX_HD cpx<T> mul_pi(cpx<T> a) { return a.yx * cpx<T>{T(-1), T(1)}; }                          \
+    /* b + (-i)*d and b + (+i)*d as ONE packed fma on the swizzled operand (exact: the factors are +-1) */ \
+    TWX_HD cpx<T> cadd_mi(cpx<T> b, cpx<T> d) { return __builtin_elementwise_fma(d.yx, cpx<T>{T(1), T(-1)}, b); }  \
+    TWX_HD cpx<T> cadd_pi(cpx<T> b, cpx<T> d) { return __builtin_elementwise_fma(d.yx, cpx<T>{T(-1), T(1)}, b); }  \
+    /* a*(c + i*s): packed mul + packed fma, the rotation folded into the constant pair */       \
+    TWX_HD cpx<T> cmul_cs(cpx<T> a, T c, T s) { return __builtin_elementwise_fma(a.yx, cpx<T>{-s, s}, a * c); }
 TWX_CPX_OPS(float)
 TWX_CPX_OPS(double)
 #undef TWX_CPX_OPS
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TWX_NO_ASM_CMUL)
+// fp32 complex multiply as exactly two packed instructions: the operand swizzles and the sign live in
+// op_sel / neg modifiers (hipcc builds the rotated operand with v_xor + v_mov otherwise: 4 instructions).
+// Plain VGPR-to-VGPR VALU ops: no wait states needed around the asm (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ cpx<float> cmul_f32_asm(cpx<float> a, cpx<float> b) {
+    cpx<float> t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                  // (a.x b.x, a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(t));   // (-a.y b.y + t.x, a.y b.x + t.y)
+    return d;
+}
+__device__ __forceinline__ cpx<float> cmulc_f32_asm(cpx<float> a, cpx<float> b) {   // a * conj(b)
+    cpx<float> t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));                  // (a.x b.x, a.y b.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(t));   // (a.y b.y + t.x, -a.x b.y + t.y)
+    return d;
+}
+#define TWX_ASM_CMUL 1
+#endif
+TWX_HD cpx<double> cmul(cpx<double> a, cpx<double> b) { return cmul_g(a, b); }
+TWX_HD cpx<double> cmulc(cpx<double> a, cpx<double> b) { return cmulc_g(a, b); }
+#if defined(TWX_ASM_CMUL)
+__device__ __forceinline__ cpx<float> cmul(cpx<float> a, cpx<float> b) { return cmul_f32_asm(a, b); }
+__device__ __forceinline__ cpx<float> cmulc(cpx<float> a, cpx<float> b) { return cmulc_f32_asm(a, b); }
+#else
+TWX_HD cpx<float> cmul(cpx<float> a, cpx<float> b) { return cmul_g(a, b); }
+TWX_HD cpx<float> cmulc(cpx<float> a, cpx<float> b) { return cmulc_g(a, b); }
+#endif
 #else
 template <typename T> struct cpx { T x, y; };
 
@@ -60,6 +92,9 @@ template <typename T> TWX_HD T cnorm(cpx<T> a) { return a.x * a.x + a.y * a.y; }
 // multiply by -i (forward quarter turn e^{-i pi/2}) or +i
 template <typename T> TWX_HD cpx<T> mul_mi(cpx<T> a) { return mk<T>(a.y, -a.x); }
 template <typename T> TWX_HD cpx<T> mul_pi(cpx<T> a) { return mk<T>(-a.y, a.x); }
+template <typename T> TWX_HD cpx<T> cadd_mi(cpx<T> b, cpx<T> d) { return mk<T>(b.x + d.y, b.y - d.x); }
+template <typename T> TWX_HD cpx<T> cadd_pi(cpx<T> b, cpx<T> d) { return mk<T>(b.x - d.y, b.y + d.x); }
+template <typename T> TWX_HD cpx<T> cmul_cs(cpx<T> a, T c, T s) { return mk<T>(a.x * c - a.y * s, a.x * s + a.y * c); }
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -106,7 +141,7 @@ template <typename T, int R, int E, bool INV> TWX_HD cpx<T> cmul_const(cpx<T> a)
         constexpr cx_cs w = cx_cossin_turn(e, R);
         constexpr T c = T(w.c);
         constexpr T s = INV ? T(w.s) : T(-w.s);
-        return cscale(a, c) + cscale(mul_pi(a), s);
+        return cmul_cs(a, c, s);
     }
 }
 
@@ -167,15 +202,18 @@ template <typename T, bool INV> struct Bfly<T, 3, INV, 3> {
         constexpr T s = T(0.86602540378443864676372317075294);  // sin(2pi/3)
         cpx<T> t1 = v[1] + v[2], t2 = v[1] - v[2];
         cpx<T> m = v[0] - cscale(t1, T(0.5));
-        cpx<T> js = INV ? cscale(mul_pi(t2), s) : cscale(mul_mi(t2), s);  // -+ i*s*t2
-        v[0] = v[0] + t1; v[1] = m + js; v[2] = m - js;
+        cpx<T> st2 = cscale(t2, s);
+        v[0] = v[0] + t1;
+        v[1] = INV ? cadd_pi(m, st2) : cadd_mi(m, st2);   // m -+ i*s*t2
+        v[2] = INV ? cadd_mi(m, st2) : cadd_pi(m, st2);
     }
 };
 template <typename T, bool INV> struct Bfly<T, 4, INV, 4> {
     static TWX_HD void run(cpx<T>* v) {
         cpx<T> a = v[0] + v[2], b = v[0] - v[2], c = v[1] + v[3], d = v[1] - v[3];
-        cpx<T> jd = INV ? mul_pi(d) : mul_mi(d);
-        v[0] = a + c; v[2] = a - c; v[1] = b + jd; v[3] = b - jd;
+        v[0] = a + c; v[2] = a - c;
+        v[1] = INV ? cadd_pi(b, d) : cadd_mi(b, d);
+        v[3] = INV ? cadd_mi(b, d) : cadd_pi(b, d);
     }
 };
 template <typename T, bool INV> struct Bfly<T, 5, INV, 5> {
@@ -190,11 +228,9 @@ template <typename T, bool INV> struct Bfly<T, 5, INV, 5> {
         cpx<T> b1 = cscale(t3, s1) + cscale(t4, s2);
         cpx<T> b2 = cscale(t3, s2) - cscale(t4, s1);
         // forward: y1 = a1 - i*b1, y4 = a1 + i*b1, y2 = a2 - i*b2, y3 = a2 + i*b2
-        cpx<T> ib1 = INV ? mul_pi(b1) : mul_mi(b1);
-        cpx<T> ib2 = INV ? mul_pi(b2) : mul_mi(b2);
         v[0] = v[0] + t1 + t2;
-        v[1] = a1 + ib1; v[4] = a1 - ib1;
-        v[2] = a2 + ib2; v[3] = a2 - ib2;
+        v[1] = INV ? cadd_pi(a1, b1) : cadd_mi(a1, b1); v[4] = INV ? cadd_mi(a1, b1) : cadd_pi(a1, b1);
+        v[2] = INV ? cadd_pi(a2, b2) : cadd_mi(a2, b2); v[3] = INV ? cadd_mi(a2, b2) : cadd_pi(a2, b2);
     }
 };
 

@@ -53,7 +53,9 @@ __device__ __forceinline__ long long shfl_down_ll(long long v, int d) {
 template <typename T> struct Best {
     T val; unsigned int idx;
     __device__ __forceinline__ void take(T v, unsigned int i) {
-        if (v > val || (v == val && i < idx)) { val = v; idx = i; }
+        const bool better = (v > val) | ((v == val) & (i < idx));   // branch-free: v_cmp + v_cndmask, no exec-mask juggling
+        val = better ? v : val;
+        idx = better ? i : idx;
     }
 };
 template <typename T> __device__ __forceinline__ Best<T> wave_best(Best<T> b) {
@@ -88,17 +90,29 @@ struct InI16 {   // interleaved int16 IQ, nch channels per sample (godual_rangin
         short2 s = p[n * nch];
         return mk<T>((T)s.x, (T)s.y);
     }
+    // sample (ubase + lane): wave-uniform part and 32-bit lane part kept apart (saddr-form loads)
+    template <typename T> __device__ __forceinline__ cpx<T> load2(long long ubase, unsigned lane) const {
+        const short2* q = p + ubase * nch;
+        short2 s = q[lane * (unsigned)nch];
+        return mk<T>((T)s.x, (T)s.y);
+    }
 };
 struct InChips {  // code replica: chips {0,1} held sps samples, value 2c-1 (godual_ranging.m:63-65)
     const unsigned char* p; int sps;
     template <typename T> __device__ __forceinline__ cpx<T> load(long long n) const {
         return mk<T>((T)(2 * (int)p[n / sps] - 1), (T)0);
     }
+    template <typename T> __device__ __forceinline__ cpx<T> load2(long long ubase, unsigned lane) const { return load<T>(ubase + lane); }
 };
 template <typename S> struct InCplx {  // complex float/double samples (processing(d,k) entry)
     const cpx<S>* p;
     template <typename T> __device__ __forceinline__ cpx<T> load(long long n) const {
         cpx<S> s = p[n];
+        return mk<T>((T)s.x, (T)s.y);
+    }
+    template <typename T> __device__ __forceinline__ cpx<T> load2(long long ubase, unsigned lane) const {
+        const cpx<S>* q = p + ubase;
+        cpx<S> s = q[lane];
         return mk<T>((T)s.x, (T)s.y);
     }
 };
@@ -311,10 +325,11 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
             const int j = tid / W, c = tid % W;
             C e2c = mk<T>(1, 0);
             if (MODE == COL_MIX) e2c = a.e2[(long long)b * a.n2 + c0 + c];
+            const unsigned lane_in = (unsigned)j * (unsigned)a.n2 + (unsigned)(c0 + c);
             TWX_UNROLL
             for (int r = 0; r < R; ++r) {
                 const int n1 = TL::template in_pos<0>(j, r);
-                C x = win.template load<T>((long long)n1 * a.n2 + c0 + c);
+                C x = win.template load2<T>((long long)(r * (P1::L / R)) * a.n2, lane_in);
                 x.x -= mx; x.y -= my;
                 if (MODE == COL_MIX) {
                     C e = cmul(a.e1[(long long)b * P1::L + n1], e2c);
@@ -351,12 +366,15 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
             const unsigned n2i = c0 + c;
             const unsigned mask = (1u << a.tshift) - 1u;
             C* out = a.out + (long long)b * a.n;
+            const unsigned lane_out = (unsigned)TL::template out_pos<s>(j, 0) * (unsigned)a.n2 + n2i;
+            constexpr int QS = (S == 1) ? 1 : P1::L / R;     // row step between a thread's outputs
             TWX_UNROLL
             for (int q = 0; q < R; ++q) {
                 const unsigned k1 = TL::template out_pos<s>(j, q);
                 const unsigned m = k1 * n2i;
                 C w = cmul(a.ta[m >> a.tshift], a.tb[m & mask]);
-                out[(long long)k1 * a.n2 + n2i] = cmul(v[q], w);
+                C* orow = out + (long long)(q * QS) * a.n2;   // wave-uniform
+                orow[lane_out] = cmul(v[q], w);
             }
         }
     }
@@ -367,6 +385,9 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
 // ------------------------------------------------------------------------------------------
 enum { ROW_STORE = 0, ROW_BAND = 1, ROW_MID = 2 };
 #define TWX_MAX_PHASE 5
+#ifndef TWX_ABLC
+#define TWX_ABLC 0   // column-pass ablations (timing-only): 1 = no transforms, 2 = no global loads
+#endif
 #ifndef TWX_KEEP_TW
 #define TWX_KEEP_TW 0
 #endif
@@ -462,7 +483,7 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
         if (tid < NSL) {
             const C* cs = a.cspec + (long long)k1 * N2;
             TWX_UNROLL
-            for (int q = 0; q < RL; ++q) csr[q] = cs[tid + q * NSL];
+            for (int q = 0; q < RL; ++q) csr[q] = (cs + q * NSL)[(unsigned)tid];
         }
     }
     TWX_STAMP(0);
@@ -471,7 +492,7 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
         constexpr int R = P2::radix(0);
         if (tid < TF::template tasks<0>()) {
             TWX_UNROLL
-            for (int r = 0; r < R; ++r) v[r] = (TWX_ABL == 4 && MODE == ROW_MID) ? mk<T>((T)(tid + r), (T)r) : row[TF::template in_pos<0>(tid, r)];
+            for (int r = 0; r < R; ++r) v[r] = (TWX_ABL == 4 && MODE == ROW_MID) ? mk<T>((T)(tid + r), (T)r) : (row + r * (N2 / R))[(unsigned)tid];
         }
         for (int i = tid; i < NTF; i += NT) tab_f[i] = a.stab_f[i];
         if constexpr (MODE == ROW_MID) {
@@ -605,7 +626,7 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
                 TWX_UNROLL
                 for (int q = 0; q < RIL; ++q) {
                     C o = cmul(cmul(v[q], u), s_vc[q]);                     // · W_N^{-k1 q2} · ramp1
-                    if (TWX_ABL == 1) { asm volatile("" ::"v"(o)); } else out[lt + q * NSI] = o;
+                    if (TWX_ABL == 1) { asm volatile("" ::"v"(o)); } else (out + q * NSI)[(unsigned)lt] = o;
                 }
             }
             TWX_STAMP(10 + rho * 6);
@@ -648,7 +669,7 @@ __global__ __launch_bounds__(NT, 4) void k_row_mid_s(RowArgs<T> a) {
     C v[P2::rmax()];
     if (tid < NS0) {
         TWX_UNROLL
-        for (int r = 0; r < R0; ++r) v[r] = row[tid + r * NS0];
+        for (int r = 0; r < R0; ++r) v[r] = (row + r * NS0)[(unsigned)tid];
     }
     for (int i = tid; i < NTF; i += NT) tab_f[i] = a.stab_f[i];
     if constexpr (!PAL) for (int i = tid; i < NTI; i += NT) tab_i[i] = a.stab_i[i];
@@ -669,7 +690,7 @@ __global__ __launch_bounds__(NT, 4) void k_row_mid_s(RowArgs<T> a) {
         const C eaj = a.ea[rho * NSL + tid];
         TWX_UNROLL
         for (int r = 0; r < RL; ++r) {
-            C p = cscale(cmul(v[r], cs[tid + r * NSL]), a.scale);      // ffty.*fcode (godual_ranging.m:26)
+            C p = cscale(cmul(v[r], (cs + r * NSL)[(unsigned)tid]), a.scale);      // ffty.*fcode (godual_ranging.m:26)
             if (rho != 0) {
                 C e;
                 if constexpr (RL % 2 == 0) e = a.eb[(rho * 2 + (r >= RL / 2 ? 1 : 0)) * RL + r];
@@ -691,7 +712,7 @@ __global__ __launch_bounds__(NT, 4) void k_row_mid_s(RowArgs<T> a) {
         const C u = cmul(cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask])), a.ramp1[(long long)rho * a.n1 + k1]);
         C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
         TWX_UNROLL
-        for (int q = 0; q < RIL; ++q) out[tid + q * NSI] = cmul(cmul(v[q], u), s_vc[q]);
+        for (int q = 0; q < RIL; ++q) (out + q * NSI)[(unsigned)tid] = cmul(cmul(v[q], u), s_vc[q]);
     }
 }
 
@@ -734,7 +755,7 @@ __global__ __launch_bounds__(NT) void k_row_mid_p(RowArgs<T> a, unsigned int* __
     if (cur < total_rows && tid0 < NS0) {
         const C* row = a.A + (long long)(cur % a.nwin) * a.n + (long long)(cur / a.nwin) * N2;
         TWX_UNROLL
-        for (int r = 0; r < R0; ++r) nxt[r] = row[tid0 + r * NS0];
+        for (int r = 0; r < R0; ++r) nxt[r] = (row + r * NS0)[(unsigned)tid0];
     }
     __syncthreads();    // every thread has read s_next before it is overwritten below
     while (cur < total_rows) {
@@ -746,7 +767,7 @@ __global__ __launch_bounds__(NT) void k_row_mid_p(RowArgs<T> a, unsigned int* __
         if (tid < NSL) {
             const C* cs = a.cspec + (long long)k1 * N2;
             TWX_UNROLL
-            for (int q = 0; q < RL; ++q) csr[q] = cs[tid + q * NSL];
+            for (int q = 0; q < RL; ++q) csr[q] = (cs + q * NSL)[(unsigned)tid];
         }
         if (tid < RIL) {
             const unsigned m = (unsigned)k1 * (unsigned)tid * (unsigned)NSI;
@@ -764,7 +785,7 @@ __global__ __launch_bounds__(NT) void k_row_mid_p(RowArgs<T> a, unsigned int* __
         if (nx < total_rows && tid < NS0) {      // prefetch the next row: stays in flight during this row's transforms
             const C* row = a.A + (long long)(nx % a.nwin) * a.n + (long long)(nx / a.nwin) * N2;
             TWX_UNROLL
-            for (int r = 0; r < R0; ++r) nxt[r] = row[tid + r * NS0];
+            for (int r = 0; r < R0; ++r) nxt[r] = (row + r * NS0)[(unsigned)tid];
         }
         MidStages<TF, P2, T, 1>::run(lds, tab_f, v, tid);
         C pr[RL];
@@ -818,7 +839,7 @@ __global__ __launch_bounds__(NT) void k_row_mid_p(RowArgs<T> a, unsigned int* __
                 const C u = cmul(ub, r1);
                 C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
                 TWX_UNROLL
-                for (int q = 0; q < RIL; ++q) out[lt + q * NSI] = cmul(cmul(v[q], u), s_vc[q]);   // · W_N^{-k1 q2} · ramp1
+                for (int q = 0; q < RIL; ++q) (out + q * NSI)[(unsigned)lt] = cmul(cmul(v[q], u), s_vc[q]);   // · W_N^{-k1 q2} · ramp1
             }
         }
         __syncthreads();   // LDS workspace, s_vc and s_next are free for the next row
@@ -888,7 +909,7 @@ __global__ __launch_bounds__(NT) void k_row_caf(CafArgs<T> a) {
         const C ub = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & ((1u << a.tshift) - 1u)]));
         C* out = a.Bz + (long long)bin * a.n + (long long)k1 * N2;
         TWX_UNROLL
-        for (int q = 0; q < RIL; ++q) out[tid + q * NSI] = cmul(cmul(v[q], ub), s_vc[q]);
+        for (int q = 0; q < RIL; ++q) (out + q * NSI)[(unsigned)tid] = cmul(cmul(v[q], ub), s_vc[q]);
     }
 }
 
@@ -933,10 +954,16 @@ __global__ __launch_bounds__(NT) void k_col_inv(ColInvArgs<T> a) {
         constexpr int R = P1R::radix(0);
         if (tid < TL::template tasks<0>()) {
             const int j = tid / W, c = tid % W;
+            // address = wave-uniform row base (SGPR pair) + 32-bit lane offset → saddr-form global loads,
+            // no per-element 64-bit VALU address arithmetic
+            const unsigned int loff = ((unsigned int)j * (unsigned int)a.n2 + (unsigned int)(c0 + c)) * (unsigned int)sizeof(C);
+            const char* cbase = reinterpret_cast<const char*>(src);
+            const unsigned long long rstride = (unsigned long long)(P1R::L / R) * (unsigned long long)a.n2 * sizeof(C);
             TWX_UNROLL
-            for (int r = 0; r < R; ++r) v[r] = src[(long long)TL::template in_pos<0>(j, r) * a.n2 + c0 + c];
-            TL::template bfly<0>(v);
-            if (S > 1) TL::template store_lds<0>(lds, j, c, v);
+            for (int r = 0; r < R; ++r)
+                v[r] = (TWX_ABLC == 2) ? mk<T>((T)(tid + r), (T)(r - tid)) : *reinterpret_cast<const C*>(cbase + r * rstride + loff);
+            if (TWX_ABLC != 1) TL::template bfly<0>(v);
+            if (S > 1 && TWX_ABLC != 1) TL::template store_lds<0>(lds, j, c, v);
         }
     }
     if (S > 1) __syncthreads();
@@ -958,13 +985,26 @@ __global__ __launch_bounds__(NT) void k_col_inv(ColInvArgs<T> a) {
         constexpr int R = P1R::radix(s);
         if (tid < TL::template tasks<s>()) {
             const int j = tid / W, c = tid % W;
-            if (S > 1) { TL::template load_lds<s>(lds, a.tw1, j, c, v); TL::template bfly<s>(v); }
+            if (S > 1 && TWX_ABLC != 1) { TL::template load_lds<s>(lds, a.tw1, j, c, v); TL::template bfly<s>(v); }
+            const unsigned int mbase = (unsigned int)(c0 + c) * (unsigned int)a.nphase + (unsigned int)rho;
+            const unsigned int mstep = (unsigned int)a.n2 * (unsigned int)a.nphase;
+            // per-thread arg-max in two cheap sweeps: max value (1 op per sample), then the first q that
+            // attains it (the lag index grows with q, so the lowest q is the lowest index)
+            T nv[R];
+            T bv = T(-1);
             TWX_UNROLL
-            for (int q = 0; q < R; ++q) {
-                const long long q1 = TL::template out_pos<s>(j, q);
-                const long long m = (q1 * a.n2 + c0 + c) * a.nphase + rho;
-                best.take(cnorm(v[q]), (unsigned int)m);
-                if (a.zout) a.zout[(long long)b * a.n * a.nphase + m] = v[q];
+            for (int q = 0; q < R; ++q) { nv[q] = cnorm(v[q]); bv = nv[q] > bv ? nv[q] : bv; }
+            int bq = 0;
+            TWX_UNROLL
+            for (int q = R - 1; q >= 0; --q) bq = (nv[q] == bv) ? q : bq;
+            best.val = bv;
+            best.idx = (unsigned int)(j + bq * (P1R::L / R)) * mstep + mbase;                         // R*(q1*N2+q2)+rho < 2^32
+            if (a.zout) {       // test/inspection path only (twx_xcorr_map)
+                TWX_UNROLL
+                for (int q = 0; q < R; ++q) {
+                    const unsigned int m = (unsigned int)TL::template out_pos<s>(j, q) * mstep + mbase;
+                    a.zout[(long long)b * a.n * a.nphase + m] = v[q];
+                }
             }
         }
     }
