@@ -63,9 +63,9 @@ static thread_local std::string g_create_err;
 // small device helpers
 // ------------------------------------------------------------------------------------------
 template <typename S, typename D>
-__global__ void k_convert(const cpx<S>* __restrict__ in, cpx<D>* __restrict__ out, long long n) {
+__global__ void k_convert(const cpx<S>* __restrict__ in, cpx<D>* __restrict__ out, long long n, double scale) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        out[i] = mk<D>((D)in[i].x, (D)in[i].y);
+        out[i] = mk<D>((D)(in[i].x * scale), (D)(in[i].y * scale));
 }
 
 // chips of LFSR(bitlen,taps), seed 1, one byte per chip (amaranth_twstft/common.py:23-30,59-73).
@@ -264,7 +264,7 @@ template <typename T> struct Ctx : CtxBase {
     int tshift = 11;
     double scale_pow2 = 1.0;
     // tables
-    C *tw1 = nullptr, *stab_f = nullptr, *stab_i = nullptr, *ea = nullptr, *eb = nullptr, *ta = nullptr, *tb = nullptr, *ramp1 = nullptr;
+    C *tw1 = nullptr, *tcw = nullptr, *stab_f = nullptr, *stab_i = nullptr, *ea = nullptr, *eb = nullptr, *ta = nullptr, *tb = nullptr, *ramp1 = nullptr;
     cpx<double>* tw1d = nullptr;
     C* cspec = nullptr;
     unsigned char* chips_dev = nullptr;
@@ -289,6 +289,17 @@ template <typename T> struct Ctx : CtxBase {
     int make_tables() {
         std::vector<C> h;
         host_twiddle<T>(h, N1, 1, N1, -1); if (int rc = upload(&tw1, h)) return rc;
+        {   // tc[k1][c] = exp(-2 pi i k1 c/N)
+            const int W = col->W;
+            h.resize((size_t)N1 * W);
+            const long double tp2 = 2.0L * 3.14159265358979323846264338327950288L;
+            for (int k1 = 0; k1 < N1; ++k1)
+                for (int c = 0; c < W; ++c) {
+                    const long double a = tp2 * (long double)((long long)k1 * c) / (long double)N;
+                    h[(size_t)k1 * W + c] = mk<T>((T)cosl(a), (T)(-sinl(a)));
+                }
+            if (int rc = upload(&tcw, h)) return rc;
+        }
         {
             int rr[4] = {row->R[0], row->R[1], row->R[2], row->R[3]};
             host_stage_tabs<T>(h, row->S, rr); if (int rc = upload(&stab_f, h)) return rc;
@@ -334,7 +345,7 @@ template <typename T> struct Ctx : CtxBase {
         if (int rc = dalloc(&cspec, (size_t)N)) return rc;
         const ColOps* c64 = find_col(N1, 1); const RowOps* r64 = find_row(N2, 1);
         const bool use64 = !std::is_same<T, double>::value && c64 && r64 && c64->W == col->W;
-        if (std::is_same<T, double>::value || !use64) return code_spectrum_T<T>(cspec, col, row, tw1, stab_f, ta, tb);
+        if (std::is_same<T, double>::value || !use64) return code_spectrum_T<T>(cspec, col, row, tw1, stab_f, ta, tb, tcw, scale_pow2 == 1.0 ? 0.0 : scale_pow2);
         // temporary fp64 tables and buffers
         cpx<double>*t1 = nullptr, *t2 = nullptr, *tad = nullptr, *tbd = nullptr, *spec = nullptr;
         int rr[4] = {r64->R[0], r64->R[1], r64->R[2], r64->R[3]};
@@ -344,25 +355,37 @@ template <typename T> struct Ctx : CtxBase {
         host_twiddle<double>(h, (N >> tshift) + 1, 1ll << tshift, N, -1); if (int rc = upload(&tad, h)) return rc;
         host_twiddle<double>(h, 1ll << tshift, 1, N, -1); if (int rc = upload(&tbd, h)) return rc;
         if (int rc = dalloc(&spec, (size_t)N)) return rc;
-        if (int rc = code_spectrum_T<double>(spec, c64, r64, t1, t2, tad, tbd)) return rc;
-        hipLaunchKernelGGL((k_convert<double, T>), dim3(1024), dim3(256), 0, stream, spec, cspec, N);
+        cpx<double>* tcd = nullptr;
+        {
+            const int W = c64->W;
+            h.resize((size_t)N1 * W);
+            const long double tp2 = 2.0L * 3.14159265358979323846264338327950288L;
+            for (int k1 = 0; k1 < N1; ++k1)
+                for (int c = 0; c < W; ++c) {
+                    const long double a = tp2 * (long double)((long long)k1 * c) / (long double)N;
+                    h[(size_t)k1 * W + c] = mk<double>((double)cosl(a), (double)(-sinl(a)));
+                }
+            if (int rc = upload(&tcd, h)) return rc;
+        }
+        if (int rc = code_spectrum_T<double>(spec, c64, r64, t1, t2, tad, tbd, tcd)) return rc;
+        hipLaunchKernelGGL((k_convert<double, T>), dim3(1024), dim3(256), 0, stream, spec, cspec, N, scale_pow2);   // range scale folded in
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
-        dfree(t1); dfree(t2); dfree(tad); dfree(tbd); dfree(spec);
+        dfree(t1); dfree(t2); dfree(tad); dfree(tbd); dfree(tcd); dfree(spec);
         return TWX_OK;
     }
     template <typename U>
     int code_spectrum_T(cpx<U>* out, const ColOps* c, const RowOps* r, const cpx<U>* t1, const cpx<U>* t2,
-                        const cpx<U>* tad, const cpx<U>* tbd) {
+                        const cpx<U>* tad, const cpx<U>* tbd, const cpx<U>* tcu, double store_scale = 0.0) {
         cpx<U>* tmp = nullptr;
         if (int rc = dalloc(&tmp, (size_t)N)) return rc;
         ColFwdArgs<U> ca{};
         ca.in_win_stride = 0; ca.sums = nullptr; ca.remove_mean = 0; ca.n = N; ca.n2 = N2; ca.ntiles = N2 / c->W; ca.nwin = 1;
-        ca.e1 = nullptr; ca.e2 = nullptr; ca.tw1 = t1; ca.ta = tad; ca.tb = tbd; ca.tshift = tshift; ca.out = tmp;
+        ca.e1 = nullptr; ca.e2 = nullptr; ca.tw1 = t1; ca.ta = tad; ca.tb = tbd; ca.tshift = tshift; ca.tc = tcu; ca.out = tmp;
         if (c->fwd(COL_PLAIN, IN_CHIPS, chips_dev, cfg.sps, &ca, (unsigned)ca.ntiles, stream)) return fail(TWX_E_HIP, "code col pass launch failed");
         RowArgs<U> ra{};
         ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = tmp; ra.stab_f = t2; ra.stab_i = t2; ra.spec_out = out;
-        ra.conj_out = 1; ra.hamming = (cfg.window == TWX_WIN_HAMMING);
+        ra.conj_out = 1; ra.hamming = (cfg.window == TWX_WIN_HAMMING); ra.scale = (U)store_scale;
         if (r->run(ROW_STORE, &ra, (unsigned)N1, stream)) return fail(TWX_E_HIP, "code row pass launch failed");
         HIPCHK(hipStreamSynchronize(stream));
         dfree(tmp);
@@ -465,13 +488,14 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums) * nb, stream));
         {
             ProfScope ps(this, PC_SUMS, (long long)nb * N);
-            const int chunks = (int)std::min<long long>(256, std::max<long long>(1, N / 4096));
+            // few, fat chunks: the three 64-bit atomics per workgroup land on the same words of a window
+            const int chunks = (int)std::min<long long>(64, std::max<long long>(1, N / 16384));
             hipLaunchKernelGGL((k_sums<0>), dim3(chunks, nb), dim3(256), 0, stream, in, wstride, nch, N, sums);
             HIPCHK(hipGetLastError());
         }
         ColFwdArgs<T> ca{};
         ca.in_win_stride = wstride; ca.sums = sums; ca.remove_mean = 1; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = nb;
-        ca.e1 = e1; ca.e2 = e2; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.out = A;
+        ca.e1 = e1; ca.e2 = e2; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.tc = tcw; ca.out = A;
         RowArgs<T> ra{};
         ra.n = N; ra.n1 = N1; ra.nwin = nb; ra.A = A; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.ea = ea; ra.eb = eb;
         ra.part = part_band; ra.cspec = cspec; ra.ramp1 = ramp1; ra.nphase = R; ra.scale = (T)scale_pow2;
@@ -557,7 +581,7 @@ template <typename T> struct Ctx : CtxBase {
         if (int rc = dalloc(&spec, (size_t)N)) return rc;
         HIPCHK(hipMemcpy(din, in, (size_t)N * 16, hipMemcpyHostToDevice));
         ColFwdArgs<T> ca{};
-        ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = 1; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.out = tmp;
+        ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = 1; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.tc = tcw; ca.out = tmp;
         if (col->fwd(COL_PLAIN, IN_C64, din, 0, &ca, (unsigned)ntiles, stream)) return fail(TWX_E_HIP, "col pass launch failed");
         RowArgs<T> ra{};
         ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = tmp; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.spec_out = spec;
@@ -579,7 +603,7 @@ template <typename T> struct Ctx : CtxBase {
         for (int k1 = 0; k1 < N1; ++k1)
             for (int k2 = 0; k2 < N2; ++k2) {
                 const long long k = k1 + (long long)N1 * k2;
-                out[2 * k] = (double)h[(size_t)k1 * N2 + k2].x; out[2 * k + 1] = (double)h[(size_t)k1 * N2 + k2].y;
+                out[2 * k] = (double)h[(size_t)k1 * N2 + k2].x / scale_pow2; out[2 * k + 1] = (double)h[(size_t)k1 * N2 + k2].y / scale_pow2;
             }
         return TWX_OK;
     }
@@ -624,11 +648,11 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipMemcpy(din, iq, (size_t)N * nch * 4, hipMemcpyHostToDevice));
         const short2* in = din + ch;
         HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums), stream));
-        hipLaunchKernelGGL((k_sums<0>), dim3((unsigned)std::min<long long>(256, std::max<long long>(1, N / 4096)), 1), dim3(256), 0, stream, in, 0ll, nch, N, sums);
+        hipLaunchKernelGGL((k_sums<0>), dim3((unsigned)std::min<long long>(64, std::max<long long>(1, N / 16384)), 1), dim3(256), 0, stream, in, 0ll, nch, N, sums);
         HIPCHK(hipGetLastError());
         ColFwdArgs<T> ca{};
         ca.in_win_stride = 0; ca.sums = sums; ca.remove_mean = 1; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = 1;
-        ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.out = A;
+        ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.tc = tcw; ca.out = A;
         if (col->fwd(COL_PLAIN, IN_I16, in, nch, &ca, (unsigned)ntiles, stream)) return fail(TWX_E_HIP, "k_col_fwd(plain) launch failed");
         RowArgs<T> ra{};
         ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = A; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.spec_out = Ysp;

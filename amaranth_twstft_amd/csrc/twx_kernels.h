@@ -140,12 +140,31 @@ __global__ __launch_bounds__(256) void k_sums(const short2* __restrict__ in, lon
         for (; i < hi && (i & 3); ++i) if (threadIdx.x == 0) acc(p[i]);
         const long long nv = (hi - i) >> 2;
         const int4* pv = reinterpret_cast<const int4*>(p + i);
-        for (long long k = threadIdx.x; k < nv; k += 256) {
-            int4 q = pv[k];
-            short2 s0, s1, s2, s3;
-            s0.x = (short)(q.x & 0xffff); s0.y = (short)(q.x >> 16); s1.x = (short)(q.y & 0xffff); s1.y = (short)(q.y >> 16);
-            s2.x = (short)(q.z & 0xffff); s2.y = (short)(q.z >> 16); s3.x = (short)(q.w & 0xffff); s3.y = (short)(q.w >> 16);
-            acc(s0); acc(s1); acc(s2); acc(s3);
+        // four independent 16-B loads in flight per thread; 32-bit partial sums per group (|I|,|Q| <= 2^15:
+        // 16 samples fit), widened once per group
+        auto acc4 = [&](int4 q, int& aI, int& aQ, unsigned long long& aP) {
+            const int w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int xi = (short)(w[t] & 0xffff), xq = w[t] >> 16;
+                aI += xi; aQ += xq;
+                aP += (unsigned long long)(unsigned int)(xi * xi + xq * xq);
+            }
+        };
+        long long k = threadIdx.x;
+        for (; k + 7 * 256 < nv; k += 8 * 256) {
+            int4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = pv[k + u * 256];
+            int aI = 0, aQ = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc4(q[u], aI, aQ, sP);
+            sI += aI; sQ += aQ;
+        }
+        for (; k < nv; k += 256) {
+            int aI = 0, aQ = 0;
+            acc4(pv[k], aI, aQ, sP);
+            sI += aI; sQ += aQ;
         }
         for (long long t = i + (nv << 2) + threadIdx.x; t < hi; t += 256) acc(p[t]);
     } else {
@@ -297,6 +316,7 @@ template <typename T> struct ColFwdArgs {
     const cpx<T>* e1; const cpx<T>* e2;   // per-window NCO tables (MIX)
     const cpx<T>* tw1;              // exp(-2 pi i m/N1)
     const cpx<T>* ta; const cpx<T>* tb; int tshift;  // exp(-2 pi i m/N) two-level: m = a<<tshift | b
+    const cpx<T>* tc;               // [N1][W]: exp(-2 pi i k1 c/N), c < W  (coalesced part of the output twiddle)
     cpx<T>* out;                    // A[b][k1][n2]
 };
 
@@ -323,16 +343,16 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
         constexpr int R = P1::radix(0);
         if (tid < TL::template tasks<0>()) {
             const int j = tid / W, c = tid % W;
-            C e2c = mk<T>(1, 0);
-            if (MODE == COL_MIX) e2c = a.e2[(long long)b * a.n2 + c0 + c];
+            // NCO factor exp(-j 2 pi df n/fs), n = (j + r*T)*N2 + n2:  E1[j]·E2[n2] per thread, E1[r*T] wave-uniform
+            C ejc = mk<T>(1, 0);
+            if (MODE == COL_MIX) ejc = cmul(a.e1[(long long)b * P1::L + j], a.e2[(long long)b * a.n2 + c0 + c]);
             const unsigned lane_in = (unsigned)j * (unsigned)a.n2 + (unsigned)(c0 + c);
             TWX_UNROLL
             for (int r = 0; r < R; ++r) {
-                const int n1 = TL::template in_pos<0>(j, r);
                 C x = win.template load2<T>((long long)(r * (P1::L / R)) * a.n2, lane_in);
                 x.x -= mx; x.y -= my;
                 if (MODE == COL_MIX) {
-                    C e = cmul(a.e1[(long long)b * P1::L + n1], e2c);
+                    C e = (r == 0) ? ejc : cmul(a.e1[(long long)b * P1::L + r * (P1::L / R)], ejc);   // scalar load × per-thread constant
                     x = cmul(x, e);
                 } else if (MODE == COL_SQUARE) {
                     x = mk<T>(x.x * x.x - x.y * x.y, T(2) * x.x * x.y);
@@ -368,12 +388,17 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
             C* out = a.out + (long long)b * a.n;
             const unsigned lane_out = (unsigned)TL::template out_pos<s>(j, 0) * (unsigned)a.n2 + n2i;
             constexpr int QS = (S == 1) ? 1 : P1::L / R;     // row step between a thread's outputs
+            // W_N^{k1 n2}, k1 = j + q*QS, n2 = c0 + c  =  W_N^{j c0} (per thread) · W_N^{q QS c0} (wave-uniform)
+            //                                            · W_N^{k1 c} (one coalesced 8-B load from tc[k1][c])
+            const unsigned mj = (S == 1) ? 0u : (unsigned)j * (unsigned)c0;
+            const C wj = cmul(a.ta[mj >> a.tshift], a.tb[mj & mask]);
+            const C* tcl = a.tc + (unsigned)TL::template out_pos<s>(j, 0) * W + c;
             TWX_UNROLL
             for (int q = 0; q < R; ++q) {
-                const unsigned k1 = TL::template out_pos<s>(j, q);
-                const unsigned m = k1 * n2i;
-                C w = cmul(a.ta[m >> a.tshift], a.tb[m & mask]);
-                C* orow = out + (long long)(q * QS) * a.n2;   // wave-uniform
+                const unsigned mq = (unsigned)(q * QS) * (unsigned)c0;                  // wave-uniform: scalar loads
+                const C wq = cmul(a.ta[mq >> a.tshift], a.tb[mq & mask]);
+                const C w = cmul(cmul(wq, wj), tcl[q * QS * W]);
+                C* orow = out + (long long)(q * QS) * a.n2;                             // wave-uniform
                 orow[lane_out] = cmul(v[q], w);
             }
         }
@@ -535,6 +560,7 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
                 const int k2 = tid + q * NSL;
                 C x = v[q];
                 if (a.conj_out) x = cconj(x);
+                if (a.scale != T(0)) x = cscale(x, a.scale);   // code spectrum is stored pre-scaled (0 = leave as is)
                 if (a.hamming) {
                     const double k = (double)k1 + (double)a.n1 * (double)k2;
                     x = cscale(x, (T)(0.54 - 0.46 * cospi(2.0 * k / (double)(a.n - 1))));
@@ -566,7 +592,7 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
             if (k1 == 0 && tid == 0) a.dc[b] = v[0];
             TWX_UNROLL
             for (int q = 0; q < RL; ++q)
-                pr[q] = cscale(cmul(v[q], TWX_ABL == 2 ? v[(q + 1) % RL] : csr[q]), a.scale);   // ffty.*fcode  (godual_ranging.m:26)
+                pr[q] = cmul(v[q], TWX_ABL == 2 ? v[(q + 1) % RL] : csr[q]);   // ffty.*fcode (godual_ranging.m:26); fcode carries the range scale
         }
         // per-thread output twiddle base conj(W_N^{k1*j}), j = output task index of the inverse's last stage
         C ub = mk<T>(1, 0);
@@ -690,7 +716,7 @@ __global__ __launch_bounds__(NT, 4) void k_row_mid_s(RowArgs<T> a) {
         const C eaj = a.ea[rho * NSL + tid];
         TWX_UNROLL
         for (int r = 0; r < RL; ++r) {
-            C p = cscale(cmul(v[r], (cs + r * NSL)[(unsigned)tid]), a.scale);      // ffty.*fcode (godual_ranging.m:26)
+            C p = cmul(v[r], (cs + r * NSL)[(unsigned)tid]);      // ffty.*fcode (godual_ranging.m:26)
             if (rho != 0) {
                 C e;
                 if constexpr (RL % 2 == 0) e = a.eb[(rho * 2 + (r >= RL / 2 ? 1 : 0)) * RL + r];
@@ -794,7 +820,7 @@ __global__ __launch_bounds__(NT) void k_row_mid_p(RowArgs<T> a, unsigned int* __
             TF::template bfly<S - 1>(v);
             if (k1 == 0 && tid == 0) a.dc[b] = v[0];
             TWX_UNROLL
-            for (int q = 0; q < RL; ++q) pr[q] = cscale(cmul(v[q], csr[q]), a.scale);   // ffty.*fcode (godual_ranging.m:26)
+            for (int q = 0; q < RL; ++q) pr[q] = cmul(v[q], csr[q]);   // ffty.*fcode (godual_ranging.m:26)
         }
         C ub = mk<T>(1, 0);
         if (tid < NSI) {
@@ -891,7 +917,7 @@ __global__ __launch_bounds__(NT) void k_row_caf(CafArgs<T> a) {
         for (int r = 0; r < R0; ++r) {
             int k2 = tid + r * NS0;
             int ks = k2 + (int)cr; if (ks >= N2) ks -= N2;
-            v[r] = cscale(cmul(yrow[ks], cs[k2]), a.scale);
+            v[r] = cmul(yrow[ks], cs[k2]);
         }
     }
     for (int i = tid; i < NTI; i += NT) tab_i[i] = a.stab_i[i];
