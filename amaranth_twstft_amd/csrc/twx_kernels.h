@@ -349,7 +349,7 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
             const unsigned lane_in = (unsigned)j * (unsigned)a.n2 + (unsigned)(c0 + c);
             TWX_UNROLL
             for (int r = 0; r < R; ++r) {
-                C x = win.template load2<T>((long long)(r * (P1::L / R)) * a.n2, lane_in);
+                C x = (TWX_ABLF == 2) ? mk<T>((T)(tid + r), (T)(r - tid)) : win.template load2<T>((long long)(r * (P1::L / R)) * a.n2, lane_in);
                 x.x -= mx; x.y -= my;
                 if (MODE == COL_MIX) {
                     C e = (r == 0) ? ejc : cmul(a.e1[(long long)b * P1::L + r * (P1::L / R)], ejc);   // scalar load × per-thread constant
@@ -359,8 +359,8 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
                 }
                 v[r] = x;
             }
-            TL::template bfly<0>(v);
-            if (S > 1) TL::template store_lds<0>(lds, j, c, v);
+            if (TWX_ABLF != 1) TL::template bfly<0>(v);
+            if (S > 1 && TWX_ABLF != 1) TL::template store_lds<0>(lds, j, c, v);
         }
     }
     if (S > 1) __syncthreads();
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
         constexpr int R = P1::radix(s);
         if (tid < TL::template tasks<s>()) {
             const int j = tid / W, c = tid % W;
-            if (S > 1) { TL::template load_lds<s>(lds, a.tw1, j, c, v); TL::template bfly<s>(v); }
+            if (S > 1 && TWX_ABLF != 1) { TL::template load_lds<s>(lds, a.tw1, j, c, v); TL::template bfly<s>(v); }
             const unsigned n2i = c0 + c;
             const unsigned mask = (1u << a.tshift) - 1u;
             C* out = a.out + (long long)b * a.n;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
                 const C wq = cmul(a.ta[mq >> a.tshift], a.tb[mq & mask]);
                 const C w = cmul(cmul(wq, wj), tcl[q * QS * W]);
                 C* orow = out + (long long)(q * QS) * a.n2;                             // wave-uniform
-                orow[lane_out] = cmul(v[q], w);
+                if (TWX_ABLF == 3) { C o = cmul(v[q], w); asm volatile("" ::"v"(o)); } else orow[lane_out] = cmul(v[q], w);
             }
         }
     }
@@ -410,6 +410,9 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
 // ------------------------------------------------------------------------------------------
 enum { ROW_STORE = 0, ROW_BAND = 1, ROW_MID = 2 };
 #define TWX_MAX_PHASE 5
+#ifndef TWX_ABLF
+#define TWX_ABLF 0   // k_col_fwd ablations (timing-only): 1 = no transform, 2 = no loads, 3 = no stores
+#endif
 #ifndef TWX_ABLC
 #define TWX_ABLC 0   // column-pass ablations (timing-only): 1 = no transforms, 2 = no global loads
 #endif
