@@ -223,6 +223,8 @@ struct CtxBase {
         prof_pending.clear();
     }
     virtual int init() = 0;
+    virtual int sync_all() = 0;
+    virtual int pipeline_depth() const = 0;
     virtual int process(const void* iq_dev, long long nwin, int nch, int ch, const twx_band* band, const double* df,
                         twx_result* out_dev) = 0;
     virtual int fft_forward(const double* in, double* out) = 0;
@@ -273,6 +275,23 @@ template <typename T> struct Ctx : CtxBase {
     C *e1 = nullptr, *e2 = nullptr, *A = nullptr, *Bz = nullptr, *dc = nullptr;
     ArgPart<T>*part_band = nullptr, *part_peak = nullptr;
     twx_result* res_dev = nullptr;
+    // Two pipeline slots (own stream + own batch buffers): consecutive batches alternate slots so that the
+    // compute-heavy middle pass of one batch can share CUs with the memory-heavy column passes of the other.
+    struct Slot {
+        hipStream_t stream; WinSums* sums; double* dfv; long long* dfidx; C *e1, *e2, *A, *Bz, *dc;
+        ArgPart<T>*part_band, *part_peak; twx_result* res_dev; unsigned int* queue; double* fine_u;
+    };
+    Slot slots[4] = {}; int nslots = 1;
+    void use_slot(int k) {
+        const Slot& q = slots[k];
+        stream = q.stream; sums = q.sums; dfv = q.dfv; dfidx = q.dfidx; e1 = q.e1; e2 = q.e2; A = q.A; Bz = q.Bz; dc = q.dc;
+        part_band = q.part_band; part_peak = q.part_peak; res_dev = q.res_dev; queue = q.queue; fine_u = q.fine_u;
+    }
+    int pipeline_depth() const override { return nslots; }
+    int sync_all() override {
+        for (int k = 0; k < nslots; ++k) HIPCHK(hipStreamSynchronize(slots[k].stream));
+        return TWX_OK;
+    }
     unsigned long long* stamps_dev = nullptr;   // TWX_STAMPS diagnostic builds
     double* fine_u = nullptr; int fine_M = 0;   // TWX_FLAG_FINE_FREQ
     unsigned int* queue = nullptr;              // row queue of the persistent middle pass
@@ -392,7 +411,12 @@ template <typename T> struct Ctx : CtxBase {
         return TWX_OK;
     }
 
+    ~Ctx() override {
+        for (int k = 1; k < nslots; ++k) if (slots[k].stream) (void)hipStreamDestroy(slots[k].stream);
+        stream = slots[0].stream ? slots[0].stream : stream;   // base class destroys slot 0's stream
+    }
     int init() override {
+        memset(slots, 0, sizeof slots);
         profile = (cfg.flags & TWX_FLAG_PROFILE) != 0;
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         R = 2 * cfg.nint + 1;
@@ -416,19 +440,36 @@ template <typename T> struct Ctx : CtxBase {
         }
         if (int rc = make_tables()) return rc;
         if (int rc = make_code_spectrum()) return rc;
-        // batch buffers
-        if (int rc = dalloc(&sums, (size_t)B)) return rc;
-        if (int rc = dalloc(&dfv, (size_t)B)) return rc;
-        if (int rc = dalloc(&dfidx, (size_t)B)) return rc;
-        if (int rc = dalloc(&e1, (size_t)B * N1)) return rc;
-        if (int rc = dalloc(&e2, (size_t)B * N2)) return rc;
-        if (int rc = dalloc(&A, (size_t)B * N)) return rc;
-        if (int rc = dalloc(&Bz, (size_t)B * R * N)) return rc;
-        if (int rc = dalloc(&dc, (size_t)B)) return rc;
-        if (int rc = dalloc(&part_band, (size_t)B * N1)) return rc;
-        if (int rc = dalloc(&part_peak, (size_t)B * R * ntiles)) return rc;
-        if (int rc = dalloc(&res_dev, (size_t)B)) return rc;
-        if (int rc = dalloc(&queue, 4)) return rc;
+        // batch buffers, one set per pipeline slot
+        {
+            const char* e = getenv("TWX_STREAMS");
+            nslots = e ? std::max(1, std::min(4, atoi(e))) : 3;
+        }
+        if (cfg.flags & TWX_FLAG_FINE_FREQ) {
+            const long long third = (long long)floor(cfg.fs / 3.0);        // int(fs//3)
+            if (N < third) return fail(TWX_E_ARG, "TWX_FLAG_FINE_FREQ needs a window of at least fs/3 samples (godual_ranging.py:26)");
+            fine_M = (int)((third + 9) / 10);
+        }
+        for (int k = 0; k < nslots; ++k) {
+            Slot& q = slots[k];
+            memset(&q, 0, sizeof q);
+            if (k == 0) q.stream = stream;
+            else HIPCHK(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
+            if (int rc = dalloc(&q.sums, (size_t)B)) return rc;
+            if (int rc = dalloc(&q.dfv, (size_t)B)) return rc;
+            if (int rc = dalloc(&q.dfidx, (size_t)B)) return rc;
+            if (int rc = dalloc(&q.e1, (size_t)B * N1)) return rc;
+            if (int rc = dalloc(&q.e2, (size_t)B * N2)) return rc;
+            if (int rc = dalloc(&q.A, (size_t)B * N)) return rc;
+            if (int rc = dalloc(&q.Bz, (size_t)B * R * N)) return rc;
+            if (int rc = dalloc(&q.dc, (size_t)B)) return rc;
+            if (int rc = dalloc(&q.part_band, (size_t)B * N1)) return rc;
+            if (int rc = dalloc(&q.part_peak, (size_t)B * R * ntiles)) return rc;
+            if (int rc = dalloc(&q.res_dev, (size_t)B)) return rc;
+            if (int rc = dalloc(&q.queue, 4)) return rc;
+            if (fine_M) { if (int rc = dalloc(&q.fine_u, (size_t)B * fine_M)) return rc; }
+        }
+        use_slot(0);
         {
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
@@ -439,12 +480,6 @@ template <typename T> struct Ctx : CtxBase {
         if (int rc = dalloc(&stamps_dev, (size_t)B * N1 * 8 * 32)) return rc;
         HIPCHK(hipMemset(stamps_dev, 0, (size_t)B * N1 * 8 * 32 * 8));
 #endif
-        if (cfg.flags & TWX_FLAG_FINE_FREQ) {
-            const long long third = (long long)floor(cfg.fs / 3.0);        // int(fs//3)
-            if (N < third) return fail(TWX_E_ARG, "TWX_FLAG_FINE_FREQ needs a window of at least fs/3 samples (godual_ranging.py:26)");
-            fine_M = (int)((third + 9) / 10);
-            if (int rc = dalloc(&fine_u, (size_t)B * fine_M)) return rc;
-        }
         HIPCHK(hipStreamSynchronize(stream));
         return TWX_OK;
     }
@@ -567,10 +602,13 @@ template <typename T> struct Ctx : CtxBase {
                 twx_result* out_dev) override {
         if (!band && !df) return fail(TWX_E_ARG, "either band or df must be given");
         const short2* base = reinterpret_cast<const short2*>(iq_dev) + ch;
-        for (long long w0 = 0; w0 < nwin; w0 += B) {
+        int k = 0;
+        for (long long w0 = 0; w0 < nwin; w0 += B, k = (k + 1) % nslots) {
             const int nb = (int)std::min<long long>(B, nwin - w0);
-            if (int rc = run_batch(base + w0 * N * nch, nb, nch, band, df ? df + w0 : nullptr, out_dev + w0, nullptr)) return rc;
+            use_slot(k);
+            if (int rc = run_batch(base + w0 * N * nch, nb, nch, band, df ? df + w0 : nullptr, out_dev + w0, nullptr)) { use_slot(0); return rc; }
         }
+        use_slot(0);
         return TWX_OK;
     }
 
@@ -734,7 +772,7 @@ int twx_create(const twx_config* cfg, twx_ctx** out) {
 void twx_destroy(twx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->impl->dev);
-    (void)hipStreamSynchronize(ctx->impl->stream);
+    (void)ctx->impl->sync_all();
     delete ctx->impl;
     delete ctx;
 }
@@ -758,9 +796,7 @@ int twx_process_windows_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_windows,
 
 int twx_synchronize(twx_ctx* ctx) {
     if (!ctx) return TWX_E_ARG;
-    hipError_t e = hipStreamSynchronize(ctx->impl->stream);
-    if (e != hipSuccess) return ctx->impl->fail(TWX_E_HIP, hipGetErrorString(e));
-    return TWX_OK;
+    return ctx->impl->sync_all();
 }
 void* twx_stream(twx_ctx* ctx) { return ctx ? (void*)ctx->impl->stream : nullptr; }
 
@@ -772,7 +808,7 @@ int twx_process_windows(twx_ctx* ctx, const int16_t* iq, int64_t n_windows, int3
     if (n_windows == 0) return TWX_OK;
     (void)hipSetDevice(c->dev);
     // stage the capture in chunks of the batch size so host captures of any length fit
-    const long long chunk = c->B;
+    const long long chunk = (long long)c->B * c->pipeline_depth();   // one batch per pipeline slot in flight
     const size_t win_bytes = (size_t)c->N * n_channels * 4;
     void* d_in = nullptr; twx_result* d_res = nullptr;
     if (hipMalloc(&d_in, win_bytes * chunk) != hipSuccess) return c->fail(TWX_E_NOMEM, "staging buffer allocation failed");
@@ -781,10 +817,12 @@ int twx_process_windows(twx_ctx* ctx, const int16_t* iq, int64_t n_windows, int3
     for (long long w0 = 0; w0 < n_windows && rc == TWX_OK; w0 += chunk) {
         const long long nb = std::min<long long>(chunk, n_windows - w0);
         if (hipMemcpyAsync(d_in, (const char*)iq + (size_t)w0 * win_bytes, win_bytes * nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = c->fail(TWX_E_HIP, "H2D copy failed"); break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = c->fail(TWX_E_HIP, "H2D copy failed"); break; }
         rc = c->process(d_in, nb, n_channels, channel, band, df ? df + w0 : nullptr, d_res);
         if (rc) break;
-        if (hipMemcpyAsync(out + w0, d_res, sizeof(twx_result) * nb, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = c->fail(TWX_E_HIP, "D2H copy failed"); break; }
-        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = c->fail(TWX_E_HIP, "stream synchronize failed (kernel fault?)"); break; }
+        rc = c->sync_all();
+        if (rc) { c->err = "stream synchronize failed (kernel fault?): " + c->err; break; }
+        if (hipMemcpy(out + w0, d_res, sizeof(twx_result) * nb, hipMemcpyDeviceToHost) != hipSuccess) { rc = c->fail(TWX_E_HIP, "D2H copy failed"); break; }
     }
     (void)hipFree(d_in); (void)hipFree(d_res);
     return rc;
@@ -828,7 +866,7 @@ int twx_caf_freqs(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t c
 int twx_profile_reset(twx_ctx* ctx) {
     if (!ctx) return TWX_E_ARG;
     CtxBase* c = ctx->impl;
-    (void)hipStreamSynchronize(c->stream);
+    (void)c->sync_all();
     c->prof_collect();
     for (int i = 0; i < PC_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; c->prof_units[i] = 0; }
     return TWX_OK;
@@ -836,7 +874,7 @@ int twx_profile_reset(twx_ctx* ctx) {
 int twx_profile_get(twx_ctx* ctx, twx_prof_entry* entries, int32_t max_entries, int32_t* n_entries) {
     if (!ctx || !entries || !n_entries) return TWX_E_ARG;
     CtxBase* c = ctx->impl;
-    (void)hipStreamSynchronize(c->stream);
+    (void)c->sync_all();
     c->prof_collect();
     int n = 0;
     for (int i = 0; i < PC_COUNT && n < max_entries; ++i) {

@@ -22,6 +22,21 @@
 #include "twx_fft.h"
 #include "../../include/twstft_hip.h"
 
+// build-time switches (defaults = product build; the non-zero ablation values are timing-only
+// diagnostic builds whose results are wrong)
+#ifndef TWX_ABL
+#define TWX_ABL 0       // k_row<MID>: 1 no Bz stores, 2 no code-spectrum load, 3 one phase only, 4 no A load, 5 no inverse transforms
+#endif
+#ifndef TWX_ABLC
+#define TWX_ABLC 0      // k_col_inv: 1 no transforms, 2 no global loads
+#endif
+#ifndef TWX_ABLF
+#define TWX_ABLF 0      // k_col_fwd: 1 no transform, 2 no loads, 3 no stores
+#endif
+#ifndef TWX_KEEP_TW
+#define TWX_KEEP_TW 0   // keep the last-stage row twiddles in registers across the transforms of a row
+#endif
+
 namespace twx {
 
 // ------------------------------------------------------------------------------------------
@@ -410,18 +425,6 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
 // ------------------------------------------------------------------------------------------
 enum { ROW_STORE = 0, ROW_BAND = 1, ROW_MID = 2 };
 #define TWX_MAX_PHASE 5
-#ifndef TWX_ABLF
-#define TWX_ABLF 0   // k_col_fwd ablations (timing-only): 1 = no transform, 2 = no loads, 3 = no stores
-#endif
-#ifndef TWX_ABLC
-#define TWX_ABLC 0   // column-pass ablations (timing-only): 1 = no transforms, 2 = no global loads
-#endif
-#ifndef TWX_KEEP_TW
-#define TWX_KEEP_TW 0
-#endif
-#ifndef TWX_ABL
-#define TWX_ABL 0   // 1: no Bz stores, 2: no cspec load, 3: nphase forced to 1, 4: no A load, 5: no inverse transforms
-#endif
 #ifndef TWX_ROW_WAVES
 #define TWX_ROW_WAVES 1
 #endif
