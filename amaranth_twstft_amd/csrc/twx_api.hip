@@ -444,6 +444,7 @@ template <typename T> struct Ctx : CtxBase {
         {
             const char* e = getenv("TWX_STREAMS");
             nslots = e ? std::max(1, std::min(4, atoi(e))) : 3;
+            if (profile) nslots = 1;   // per-kernel HIP-event timing is only meaningful when kernels do not overlap
         }
         if (cfg.flags & TWX_FLAG_FINE_FREQ) {
             const long long third = (long long)floor(cfg.fs / 3.0);        // int(fs//3)

@@ -161,6 +161,8 @@ def main():
         dom = max(kern, key=lambda k: prof[k]["ms_total"])
         byts = ALGO_BYTES[dom](kern[dom]["samples_per_launch"])
         ach = byts / (kern[dom]["ms_avg"] * 1e-3) / 1e9
+        out["roofline_note"] = ("per-kernel durations are HIP-event timed in a context with ONE pipeline slot (kernels of "
+                                "different batches do not overlap); the timed region above runs %d slots" % int(os.environ.get("TWX_STREAMS", "3")))
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                            "algorithmic_bytes_per_launch": int(byts), "avg_ms": round(kern[dom]["ms_avg"], 4)}
