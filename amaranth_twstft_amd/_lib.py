@@ -75,6 +75,7 @@ SYMBOLS = {
     "twx_fft_forward": (C.c_int, [_VP, _VP, _VP]),
     "twx_get_code_spectrum": (C.c_int, [_VP, _VP]),
     "twx_xcorr_map": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, _VP]),
+    "twx_process_file": (C.c_int, [_VP, C.c_char_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(twx_band), C.c_double, _VP, C.c_int64, C.POINTER(C.c_int64)]),
     "twx_caf_bins": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _VP, _VP]),
     "twx_caf_freqs": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP, C.c_int64, _VP]),
     "twx_sliding_dot": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_double, C.c_double, C.c_double, _VP]),

@@ -159,6 +159,25 @@ class Correlator:
                                               bptr, dptr, C.cast(out, C.c_void_p)), self._h)
         return [_to_result(out[i]) for i in range(nwin)]
 
+    def process_file(self, path: str, n_channels=1, channel=0, band=None, df=None, skip_samples: int = 0,
+                     max_windows: int | None = None) -> list[WindowResult]:
+        """Window loop over a capture file (godual_ranging.m:70-103), pinned double-buffered ingest."""
+        import os
+        per = self.n * 4 * n_channels
+        avail = max(0, (os.path.getsize(path) - skip_samples * 4 * n_channels)) // per
+        nmax = avail if max_windows is None else min(avail, max_windows)
+        out = (L.twx_result * max(nmax, 1))()
+        bptr = None
+        if band is not None:
+            b = L.twx_band(int(band[0]), int(band[1]))
+            bptr = C.byref(b)
+        elif df is None:
+            raise ValueError("give band (estimate df) or df")
+        ndone = C.c_int64()
+        L.check(self._lib.twx_process_file(self._h, os.fsencode(path), n_channels, channel, skip_samples, bptr,
+                                           float(df) if df is not None else 0.0, C.cast(out, C.c_void_p), nmax, C.byref(ndone)), self._h)
+        return [_to_result(out[i]) for i in range(ndone.value)]
+
     def processing(self, raw_window, k, n_channels=1, channel=0) -> WindowResult:
         """``processing(d,k)`` (godual_ranging.m:12): ``k`` = (k_lo, k_hi) or an index array."""
         if not (isinstance(k, tuple) and len(k) == 2):

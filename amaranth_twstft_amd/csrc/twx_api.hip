@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <sys/types.h>
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -232,6 +233,8 @@ struct CtxBase {
     virtual int xcorr_map(const int16_t* iq, int nch, int ch, double df, double* out) = 0;
     virtual int caf_bins(const int16_t* iq, int nch, int ch, long long k_lo, long long k_hi, double* pk, long long* lag) = 0;
     virtual int caf_freqs(const int16_t* iq, int nch, int ch, const double* freqs, long long nf, twx_result* out) = 0;
+    virtual int process_file(const char* path, int nch, int ch, long long skip, const twx_band* band, double df_const,
+                             twx_result* out, long long max_windows, long long* n_done) = 0;
 };
 
 template <typename T> static void host_twiddle(std::vector<cpx<T>>& v, long long count, long long num_mul, long long den, int sign) {
@@ -676,6 +679,52 @@ template <typename T> struct Ctx : CtxBase {
         return TWX_OK;
     }
 
+    int process_file(const char* path, int nch, int ch, long long skip, const twx_band* band, double df_const,
+                     twx_result* out, long long max_windows, long long* n_done) override {
+        *n_done = 0;
+        FILE* f = fopen(path, "rb");
+        if (!f) return fail(TWX_E_ARG, std::string("cannot open ") + path);
+        if (skip > 0 && fseeko(f, (off_t)skip * nch * 4, SEEK_SET) != 0) { fclose(f); return fail(TWX_E_ARG, "seek failed"); }
+        const size_t win_bytes = (size_t)N * nch * 4;
+        struct Stage { void* host; short2* dev; long long w0; int nb; };
+        Stage st[4] = {};
+        int rc = TWX_OK;
+        std::vector<double> dfs((size_t)B, df_const);
+        for (int k = 0; k < nslots && rc == TWX_OK; ++k) {
+            if (hipHostMalloc(&st[k].host, win_bytes * B, hipHostMallocDefault) != hipSuccess) rc = fail(TWX_E_NOMEM, "pinned staging allocation failed");
+            else if (hipMalloc((void**)&st[k].dev, win_bytes * B) != hipSuccess) rc = fail(TWX_E_NOMEM, "device staging allocation failed");
+        }
+        auto drain = [&](int k) -> int {       // wait for slot k's batch and fetch its results
+            if (st[k].nb == 0) return TWX_OK;
+            if (hipStreamSynchronize(slots[k].stream) != hipSuccess) return fail(TWX_E_HIP, "stream synchronize failed");
+            if (hipMemcpy(out + st[k].w0, slots[k].res_dev, sizeof(twx_result) * st[k].nb, hipMemcpyDeviceToHost) != hipSuccess) return fail(TWX_E_HIP, "D2H copy failed");
+            *n_done += st[k].nb;
+            st[k].nb = 0;
+            return TWX_OK;
+        };
+        long long w0 = 0;
+        bool eof = false;
+        for (int k = 0; rc == TWX_OK && !eof && w0 < max_windows; k = (k + 1) % nslots) {
+            rc = drain(k);
+            if (rc) break;
+            const long long want = std::min<long long>(B, max_windows - w0);
+            const size_t got = fread(st[k].host, 1, win_bytes * want, f);
+            const int nb = (int)(got / win_bytes);                    // whole windows only
+            if ((long long)nb < want) eof = true;
+            if (nb == 0) break;
+            use_slot(k);
+            if (hipMemcpyAsync(st[k].dev, st[k].host, win_bytes * nb, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = fail(TWX_E_HIP, "H2D copy failed"); break; }
+            rc = run_batch(st[k].dev + ch, nb, nch, band, band ? nullptr : dfs.data(), slots[k].res_dev, nullptr);
+            st[k].w0 = w0; st[k].nb = nb;
+            w0 += nb;
+        }
+        for (int k = 0; k < nslots; ++k) { int r2 = drain(k); if (rc == TWX_OK) rc = r2; }
+        use_slot(0);
+        for (int k = 0; k < nslots; ++k) { if (st[k].host) (void)hipHostFree(st[k].host); if (st[k].dev) (void)hipFree(st[k].dev); }
+        fclose(f);
+        return rc;
+    }
+
     int caf_bins(const int16_t* iq, int nch, int ch, long long k_lo, long long k_hi, double* pk, long long* lag) override {
         if (k_hi < k_lo) return fail(TWX_E_ARG, "k_hi < k_lo");
         short2* din = nullptr; C* Ysp = nullptr; double* pk_d = nullptr; long long* lag_d = nullptr;
@@ -851,6 +900,18 @@ int twx_debug_stamps(twx_ctx* ctx, unsigned long long* out, long long count) {
     if (!c || !c->stamps_dev) return TWX_E_STATE;
     (void)hipStreamSynchronize(c->stream);
     return hipMemcpy(out, c->stamps_dev, (size_t)count * 8, hipMemcpyDeviceToHost) == hipSuccess ? TWX_OK : TWX_E_HIP;
+}
+
+int twx_process_file(twx_ctx* ctx, const char* path, int32_t n_channels, int32_t channel, int64_t skip_samples, const twx_band* band,
+                     double df_const, twx_result* out, int64_t max_windows, int64_t* n_done) {
+    if (!ctx) return TWX_E_ARG;
+    CtxBase* c = ctx->impl;
+    if (!path || !out || !n_done || max_windows < 0 || n_channels < 1 || channel < 0 || channel >= n_channels || skip_samples < 0) return c->fail(TWX_E_ARG, "bad argument");
+    (void)hipSetDevice(c->dev);
+    long long nd = 0;
+    int rc = c->process_file(path, n_channels, channel, skip_samples, band, df_const, out, max_windows, &nd);
+    *n_done = nd;
+    return rc;
 }
 
 int twx_caf_bins(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, int64_t k_lo, int64_t k_hi, double* pk, int64_t* lag) {

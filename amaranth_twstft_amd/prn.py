@@ -106,3 +106,8 @@ def read_code_file(path: str) -> np.ndarray:
     if chips.max() > 1:
         raise ValueError(f"{os.path.basename(path)}: chips must be bytes 0/1")
     return chips
+
+
+def chips_to_code(chips: np.ndarray, sps: int = 2) -> np.ndarray:
+    """``repelems`` ×sps and ``2*code-1`` (godual_ranging.m:64-65) — the ``code`` vector saved in the .mat."""
+    return np.repeat(np.asarray(chips, dtype=np.float64), sps) * 2.0 - 1.0

@@ -119,6 +119,16 @@ int twx_process_windows_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_windows,
 int twx_synchronize(twx_ctx* ctx);
 void* twx_stream(twx_ctx* ctx);                      /* hipStream_t of the context */
 
+/* File-in / results-out: the window loop of godual_ranging.m:70-103 over a capture FILE (raw int16,
+ * n_channels interleaved IQ pairs per sample; skip_samples complex samples are skipped first, cf. the
+ * 30-s fseek of claudio_aligned_code_ranging_separate.m:128).  Reads through pinned host buffers, one per
+ * pipeline slot, so file I/O, PCIe copies and kernels overlap (the reader/worker overlap of
+ * processing/CPP/main.cpp:488-497).  band != NULL: per-window coarse df; else df_const is used for every
+ * window (GoRanging's per-file foffset).  A short final window ends the loop (godual_ranging.m:81,102).
+ * out: capacity max_windows; *n_done = windows processed. */
+int twx_process_file(twx_ctx* ctx, const char* path, int32_t n_channels, int32_t channel, int64_t skip_samples,
+                     const twx_band* band, double df_const, twx_result* out, int64_t max_windows, int64_t* n_done);
+
 /* Test / inspection entry points -------------------------------------------------------- */
 /* Forward FFT of n complex doubles (host, interleaved re/im) through the context's two-pass
  * transform; out in natural order.  (Parity check of the transform vs np.fft.fft.) */

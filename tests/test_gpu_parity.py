@@ -443,3 +443,49 @@ def test_device_vs_reference_221219_processing_values(case):
         assert abs(getattr(got, k) - ref[k]) <= 3e-4 * max(ref["SNRr"], ref["SNRi"], ref[k]) + 1e-30, k
     for k in ("puissance", "puissancenoise"):
         assert abs(getattr(got, k) - ref[k]) <= 1e-6 * ref[k], k
+
+
+def test_process_file_matches_in_memory_path(tmp_path):
+    """File-in / results-out (godual_ranging.m:70-103): pinned, slot-pipelined ingest == in-memory call,
+    including the 2-channel layout, a byte offset skip and a short final window."""
+    chips, raw = _capture(15, 3, 25000, 21, seed=91)          # 21 windows of 50000 samples, 2 channels
+    n = 50000
+    path = tmp_path / "1670074501.bin"
+    tail = raw[:1234]
+    np.concatenate([raw, tail]).tofile(path)                    # + a short final window
+    band = band_numpy(FS, n)
+    with Correlator(chips, fs=FS, Nint=1, max_batch=4) as cor:
+        mem = cor.process(raw, n_channels=2, channel=1, band=band)
+        fil = cor.process_file(str(path), n_channels=2, channel=1, band=band)
+        skp = cor.process_file(str(path), n_channels=2, channel=0, df=1780.75, skip_samples=3 * n, max_windows=5)
+        ref = cor.process(raw[3 * n:8 * n], n_channels=2, channel=0, df=1780.75)
+    assert len(fil) == len(mem) == 21
+    for a, b in zip(fil, mem):
+        assert a.indice == b.indice and a.xval == b.xval and a.df == b.df and a.SNRr == b.SNRr
+    assert len(skp) == 5
+    for a, b in zip(skp, ref):
+        assert a.indice == b.indice and a.xval == b.xval
+
+
+def test_script_level_drop_in(tmp_path):
+    """godual_ranging.m as a whole: directory of captures + directory of codes in → TSV rows + .mat out."""
+    import io
+    import scipy.io
+    from amaranth_twstft_amd import godual_ranging
+    chips, raw = _capture(14, 43, 10000, 3, seed=101)
+    (tmp_path / "codes").mkdir()
+    prn.lfsr_chips(14, 43, 10000).tofile(tmp_path / "codes" / "noiselen10000_bitlen14_taps43.bin")
+    prn.lfsr_chips(14, 57, 10000).tofile(tmp_path / "codes" / "noiselen10000_bitlen14_taps57.bin")
+    raw.tofile(tmp_path / "1670074501.bin")
+    buf = io.StringIO()
+    done = godual_ranging.run(str(tmp_path), str(tmp_path / "codes"), remote=0, OP=0, out=buf)
+    assert len(done) == 1 and done[0].endswith("1670074501.mat")
+    lines = buf.getvalue().split("\n")
+    assert lines[1].startswith("n\tdt1\tdf1") and len([l for l in lines if l[:1].isdigit() and "\t" in l]) == 3
+    m = scipy.io.loadmat(done[0])
+    ref = orc.ranging(raw, chips, fs=FS, Nint=1, n_channels=2, band="godual", ddof=1)
+    assert [int(v) for v in m["indice1"][0]] == [o["indice"] + 1 for o in ref[0]]       # Octave 1-based
+    assert [int(v) for v in m["indice2"][0]] == [o["indice"] + 1 for o in ref[1]]
+    assert np.allclose(m["SNR1r"][0], [o["SNRr"] for o in ref[0]], rtol=3e-4)
+    buf2 = io.StringIO()
+    assert godual_ranging.run(str(tmp_path), str(tmp_path / "codes"), out=buf2) == [] and "already done" in buf2.getvalue()
