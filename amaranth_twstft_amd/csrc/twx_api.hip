@@ -7,6 +7,8 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <future>
+#include <unistd.h>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -285,6 +287,8 @@ template <typename T> struct Ctx : CtxBase {
         ArgPart<T>*part_band, *part_peak; twx_result* res_dev; unsigned int* queue; double* fine_u;
     };
     Slot slots[4] = {}; int nslots = 1;
+    struct Stage { void* host; short2* dev; size_t bytes; long long w0; int nb; };
+    Stage stage[4] = {};     // pinned host + device staging of twx_process_file, kept across calls
     void use_slot(int k) {
         const Slot& q = slots[k];
         stream = q.stream; sums = q.sums; dfv = q.dfv; dfidx = q.dfidx; e1 = q.e1; e2 = q.e2; A = q.A; Bz = q.Bz; dc = q.dc;
@@ -415,6 +419,7 @@ template <typename T> struct Ctx : CtxBase {
     }
 
     ~Ctx() override {
+        for (int k = 0; k < 4; ++k) { if (stage[k].host) (void)hipHostFree(stage[k].host); if (stage[k].dev) (void)hipFree(stage[k].dev); }
         for (int k = 1; k < nslots; ++k) if (slots[k].stream) (void)hipStreamDestroy(slots[k].stream);
         stream = slots[0].stream ? slots[0].stream : stream;   // base class destroys slot 0's stream
     }
@@ -686,13 +691,18 @@ template <typename T> struct Ctx : CtxBase {
         if (!f) return fail(TWX_E_ARG, std::string("cannot open ") + path);
         if (skip > 0 && fseeko(f, (off_t)skip * nch * 4, SEEK_SET) != 0) { fclose(f); return fail(TWX_E_ARG, "seek failed"); }
         const size_t win_bytes = (size_t)N * nch * 4;
-        struct Stage { void* host; short2* dev; long long w0; int nb; };
-        Stage st[4] = {};
+        Stage* st = stage;
         int rc = TWX_OK;
         std::vector<double> dfs((size_t)B, df_const);
         for (int k = 0; k < nslots && rc == TWX_OK; ++k) {
+            st[k].nb = 0;
+            if (st[k].bytes >= win_bytes * B) continue;
+            if (st[k].host) (void)hipHostFree(st[k].host);
+            if (st[k].dev) (void)hipFree(st[k].dev);
+            st[k].host = nullptr; st[k].dev = nullptr; st[k].bytes = 0;
             if (hipHostMalloc(&st[k].host, win_bytes * B, hipHostMallocDefault) != hipSuccess) rc = fail(TWX_E_NOMEM, "pinned staging allocation failed");
             else if (hipMalloc((void**)&st[k].dev, win_bytes * B) != hipSuccess) rc = fail(TWX_E_NOMEM, "device staging allocation failed");
+            else st[k].bytes = win_bytes * B;
         }
         auto drain = [&](int k) -> int {       // wait for slot k's batch and fetch its results
             if (st[k].nb == 0) return TWX_OK;
@@ -702,25 +712,53 @@ template <typename T> struct Ctx : CtxBase {
             st[k].nb = 0;
             return TWX_OK;
         };
+        // chunk c lives at file offset base + c*B windows; up to nslots reads are in flight on helper
+        // threads (pread into the pinned buffers) while earlier chunks copy and compute
+        const int fd = fileno(f);
+        const off_t base_off = (off_t)skip * nch * 4;
+        auto start_read = [&](int k, long long chunk) {
+            const long long first = chunk * B;
+            const long long want = std::max<long long>(0, std::min<long long>(B, max_windows - first));
+            return std::async(std::launch::async, [=]() -> long long {
+                size_t total = 0; const size_t need = win_bytes * (size_t)want;
+                while (total < need) {
+                    const ssize_t r = pread(fd, (char*)st[k].host + total, need - total, base_off + (off_t)first * (off_t)win_bytes + (off_t)total);
+                    if (r <= 0) break;
+                    total += (size_t)r;
+                }
+                return (long long)(total / win_bytes);              // whole windows only
+            });
+        };
+        std::future<long long> rd[4];
+        hipEvent_t h2d_done[4] = {};
+        for (int k = 0; k < nslots; ++k) (void)hipEventCreateWithFlags(&h2d_done[k], hipEventDisableTiming);
+        long long next_chunk = 0;
+        for (int k = 0; k < nslots; ++k) rd[k] = start_read(k, next_chunk++);
         long long w0 = 0;
         bool eof = false;
-        for (int k = 0; rc == TWX_OK && !eof && w0 < max_windows; k = (k + 1) % nslots) {
-            rc = drain(k);
+        int kprev = -1;
+        for (int k = 0; rc == TWX_OK && !eof; k = (k + 1) % nslots) {
+            const long long want = std::max<long long>(0, std::min<long long>(B, max_windows - w0));
+            const int nb = (int)rd[k].get();
+            if ((long long)nb < want || want == 0) eof = true;
+            rc = drain(k);                       // results of the batch that used this slot nslots chunks ago
             if (rc) break;
-            const long long want = std::min<long long>(B, max_windows - w0);
-            const size_t got = fread(st[k].host, 1, win_bytes * want, f);
-            const int nb = (int)(got / win_bytes);                    // whole windows only
-            if ((long long)nb < want) eof = true;
-            if (nb == 0) break;
-            use_slot(k);
-            if (hipMemcpyAsync(st[k].dev, st[k].host, win_bytes * nb, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = fail(TWX_E_HIP, "H2D copy failed"); break; }
-            rc = run_batch(st[k].dev + ch, nb, nch, band, band ? nullptr : dfs.data(), slots[k].res_dev, nullptr);
-            st[k].w0 = w0; st[k].nb = nb;
-            w0 += nb;
+            if (nb > 0) {
+                use_slot(k);
+                if (hipMemcpyAsync(st[k].dev, st[k].host, win_bytes * nb, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = fail(TWX_E_HIP, "H2D copy failed"); break; }
+                (void)hipEventRecord(h2d_done[k], stream);
+                rc = run_batch(st[k].dev + ch, nb, nch, band, band ? nullptr : dfs.data(), slots[k].res_dev, nullptr);
+                st[k].w0 = w0; st[k].nb = nb;
+                w0 += nb;
+            }
+            // refill the pinned buffer of the PREVIOUS slot: its H2D copy had a whole iteration to finish
+            if (kprev >= 0 && !eof) { (void)hipEventSynchronize(h2d_done[kprev]); rd[kprev] = start_read(kprev, next_chunk++); }
+            kprev = k;
         }
+        for (int k = 0; k < nslots; ++k) if (rd[k].valid()) (void)rd[k].get();
+        for (int k = 0; k < nslots; ++k) if (h2d_done[k]) { (void)hipEventSynchronize(h2d_done[k]); (void)hipEventDestroy(h2d_done[k]); }
         for (int k = 0; k < nslots; ++k) { int r2 = drain(k); if (rc == TWX_OK) rc = r2; }
         use_slot(0);
-        for (int k = 0; k < nslots; ++k) { if (st[k].host) (void)hipHostFree(st[k].host); if (st[k].dev) (void)hipFree(st[k].dev); }
         fclose(f);
         return rc;
     }
