@@ -274,6 +274,8 @@ template <typename T> struct Ctx : CtxBase {
     C *tw1 = nullptr, *tcw = nullptr, *stab_f = nullptr, *stab_i = nullptr, *ea = nullptr, *eb = nullptr, *ta = nullptr, *tb = nullptr, *ramp1 = nullptr;
     cpx<double>* tw1d = nullptr;
     C* cspec = nullptr;
+    C *cspec_perm = nullptr, *dtabs = nullptr, *ea_d = nullptr, *eb_d = nullptr;   // DIF/DIT row pass (k_rowd)
+    int use_rowd = 0;
     unsigned char* chips_dev = nullptr;
     // batch buffers
     WinSums* sums = nullptr; double* dfv = nullptr; long long* dfidx = nullptr;
@@ -362,6 +364,38 @@ template <typename T> struct Ctx : CtxBase {
         }
         if (int rc = upload(&ea, hea)) return rc;
         if (int rc = upload(&eb, heb)) return rc;
+        {   // DIF/DIT row pass tables (RowD, twx_fft.h)
+            const char* e = getenv("TWX_ROWD");
+            use_rowd = (row->rowd != nullptr) && (!e || atoi(e) != 0);
+        }
+        if (use_rowd) {
+            const int Rr = row->R[row->S - 1], R0 = row->S == 3 ? row->R[0] : 1, NU = R0 * Rr;
+            std::vector<C> t((size_t)Rr * Rr + 2 * (size_t)R0 * Rr);
+            auto Wf = [&](long long num, long long den) {
+                const long double a = tp * (long double)(num % den) / (long double)den;
+                return mk<T>((T)cosl(a), (T)(-sinl(a)));
+            };
+            for (int q = 0; q < Rr; ++q) for (int x = 0; x < Rr; ++x) t[(size_t)q * Rr + x] = Wf((long long)x * q, (long long)Rr * Rr);
+            for (int q = 0; q < R0; ++q) for (int x = 0; x < Rr; ++x) {
+                t[(size_t)Rr * Rr + (size_t)q * Rr + x] = Wf((long long)x * q, N2);
+                t[(size_t)Rr * Rr + (size_t)R0 * Rr + (size_t)q * Rr + x] = Wf((long long)x * q, N2 / Rr);
+            }
+            if (int rc = upload(&dtabs, t)) return rc;
+            std::vector<C> a1((size_t)R * NU), b1((size_t)R * 2 * Rr);
+            for (int rho = 0; rho < R; ++rho) {
+                for (int q0 = 0; q0 < R0; ++q0) for (int q1 = 0; q1 < Rr; ++q1) {
+                    const long double a = tp * (long double)((long long)rho * (q0 + R0 * q1)) / ((long double)R * (long double)N2);
+                    a1[(size_t)rho * NU + q0 * Rr + q1] = mk<T>((T)cosl(a), (T)sinl(a));
+                }
+                for (int w = 0; w < 2; ++w) for (int q2 = 0; q2 < Rr; ++q2) {
+                    long long num = ((long long)rho * ((long long)NU * q2 - (long long)w * N2)) % ((long long)R * N2);
+                    const long double a = tp * (long double)num / ((long double)R * (long double)N2);
+                    b1[((size_t)rho * 2 + w) * Rr + q2] = mk<T>((T)cosl(a), (T)sinl(a));
+                }
+            }
+            if (int rc = upload(&ea_d, a1)) return rc;
+            if (int rc = upload(&eb_d, b1)) return rc;
+        }
         if (int rc = upload(&ramp1, r1)) return rc;
         return TWX_OK;
     }
@@ -448,6 +482,12 @@ template <typename T> struct Ctx : CtxBase {
         }
         if (int rc = make_tables()) return rc;
         if (int rc = make_code_spectrum()) return rc;
+        if (use_rowd) {
+            if (int rc = dalloc(&cspec_perm, (size_t)N)) return rc;
+            const int Rr = row->R[row->S - 1], R0 = row->S == 3 ? row->R[0] : 1;
+            hipLaunchKernelGGL((k_cspec_perm<T>), dim3(N1), dim3(256), 0, stream, cspec, cspec_perm, N1, N2, R0, Rr);
+            HIPCHK(hipGetLastError());
+        }
         // batch buffers, one set per pipeline slot
         {
             const char* e = getenv("TWX_STREAMS");
@@ -554,7 +594,10 @@ template <typename T> struct Ctx : CtxBase {
             }
             {
                 ProfScope ps(this, PC_ROW_BAND, (long long)nb * N);
-                if (row->run(ROW_BAND, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(band) launch failed");
+                if (use_rowd) {
+                    RowDArgs<T> rd{}; rd.r = ra; rd.dtabs = dtabs; rd.cspec_perm = cspec_perm; rd.ea_d = ea_d; rd.eb_d = eb_d;
+                    if (row->rowd(ROW_BAND, &rd, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_rowd(band) launch failed");
+                } else if (row->run(ROW_BAND, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(band) launch failed");
             }
         } else {
             HIPCHK(hipMemcpyAsync(dfv, df_host, sizeof(double) * nb, hipMemcpyHostToDevice, stream));
@@ -580,7 +623,10 @@ template <typename T> struct Ctx : CtxBase {
         }
         {
             ProfScope ps(this, PC_ROW_MID, (long long)nb * N);
-            if (persistent < 0) {
+            if (use_rowd && persistent == 0) {
+                RowDArgs<T> rd{}; rd.r = ra; rd.dtabs = dtabs; rd.cspec_perm = cspec_perm; rd.ea_d = ea_d; rd.eb_d = eb_d;
+                if (row->rowd(ROW_MID, &rd, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_rowd(mid) launch failed");
+            } else if (persistent < 0) {
                 if (row->mid_s(&ra, (unsigned)(N1 * nb * R), stream)) return fail(TWX_E_HIP, "k_row_mid_s launch failed");
             } else if (persistent) {
                 HIPCHK(hipMemsetAsync(queue, 0, 4, stream));

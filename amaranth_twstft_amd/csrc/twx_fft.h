@@ -412,4 +412,95 @@ template <class P, typename T, bool INV, int PADQ> struct RowTile : Tile<P, T, I
     }
 };
 
+// ------------------------------------------------------------------------------------------
+// RowD: row transform in decimation-in-frequency (forward) / decimation-in-time (inverse) form,
+// L = R0 * R * R.  Only the stride-(L/R0) stage exchanges data between all threads of the
+// workgroup; the two inner stages work on R0 independent blocks of R*R elements, and each block
+// is owned by R lanes of ONE wave (64/R blocks per wave), so the inner exchange needs no
+// workgroup barrier.  One workgroup barrier per forward transform, two per inverse transform
+// (the Stockham form above needs four).
+//
+//   forward:  stage 0  thread t=(i1,i2)  x[t + (L/R0) r] → DFT_R0 → ·W_L^{t q0}         → lds(q0,i1,i2)   | barrier
+//             stage 1  thread (q0,i2)    lds(q0,r,i2)     → DFT_R  → ·W_{R^2}^{i2 q1}    → lds(q0,q1,i2)   | wave
+//             stage 2  thread (q0,q1)    lds(q0,q1,r)     → DFT_R  → X[q0 + R0 q1 + R0 R q2] in v[q2]
+//   inverse:  stage A  thread (q0,q1)    v[q2]            → IDFT_R → ·W_{R^2}^{-q1 a}    → lds(q0,q1,a)    | wave
+//             stage B  thread (q0,a)     lds(q0,r,a)      → IDFT_R → ·W_L^{-q0(a + R b)} → lds(q0,b,a)     | barrier
+//             stage C  thread t=a+R b    lds(r,b,a)       → IDFT_R0 → z[t + (L/R0) c] in v[c]
+// lds(q0,i1,i2) = q0*R*(R+1) + i1*(R+1) + i2  (rows padded by one element: stride-(R+1) accesses
+// of stages 2/A are bank-conflict free).  Tables (forward sign): ta[q][x] = W_{R^2}^{x q} (R x R),
+// tb[q0][x] = W_L^{x q0}, tc[q0][x] = W_{L/R}^{x q0} (R0 x R each).
+// ------------------------------------------------------------------------------------------
+template <class P, typename T> struct RowD {
+    using C = cpx<T>;
+    static constexpr int L = P::L;
+    static constexpr int R0 = (P::S == 3) ? P::radix(0) : 1;
+    static constexpr int R = P::radix(P::S - 1);
+    static_assert(P::S == 2 || P::S == 3, "RowD needs L = [R0 *] R * R");
+    static_assert(P::radix(P::S - 2) == R && R0 * R * R == L, "RowD needs equal inner radices");
+    static constexpr int M = R * R;               // block length = L / R0 = stage-0 / stage-C tasks
+    static constexpr int BK = R * (R + 1);        // padded block
+    static constexpr int lds_elems = R0 * BK;
+    static constexpr int BPW = 64 / R;            // blocks per wave
+    static constexpr int NT_BLK = ((R0 + BPW - 1) / BPW) * 64;   // threads needed by the block stages
+    static constexpr int NT_MIN = (M > NT_BLK ? ((M + 63) / 64) * 64 : NT_BLK);
+    static constexpr int tab_a = 0, tab_b = R * R, tab_c = R * R + R0 * R, tab_total = R * R + 2 * R0 * R;
+
+    static TWX_HD int phys(int q0, int i1, int i2) { return q0 * BK + i1 * (R + 1) + i2; }
+    static TWX_HD bool blk_map(int tid, int& q0, int& i) {
+        const int w = tid >> 6, l = tid & 63;
+        q0 = w * BPW + l / R; i = l % R;
+        return l < BPW * R && q0 < R0;
+    }
+    // ---- forward
+    static TWX_HD void f0_twiddle_store(C* lds, const C* tabs, int t, C* v) {     // after DFT_R0 of the loaded inputs
+        const int i1 = t / R, i2 = t % R;
+        lds[phys(0, i1, i2)] = v[0];
+        TWX_UNROLL
+        for (int q0 = 1; q0 < R0; ++q0) {
+            const C w = cmul(tabs[tab_b + q0 * R + i2], tabs[tab_c + q0 * R + i1]);
+            lds[phys(q0, i1, i2)] = cmul(v[q0], w);
+        }
+    }
+    static TWX_HD void f1(C* lds, const C* tabs, int q0, int i2, C* v) {
+        TWX_UNROLL
+        for (int r = 0; r < R; ++r) v[r] = lds[phys(q0, r, i2)];
+        Bfly<T, R, false>::run(v);
+        lds[phys(q0, 0, i2)] = v[0];
+        TWX_UNROLL
+        for (int q1 = 1; q1 < R; ++q1) lds[phys(q0, q1, i2)] = cmul(v[q1], tabs[tab_a + q1 * R + i2]);
+    }
+    static TWX_HD void f2(const C* lds, int q0, int q1, C* v) {
+        TWX_UNROLL
+        for (int r = 0; r < R; ++r) v[r] = lds[phys(q0, q1, r)];
+        Bfly<T, R, false>::run(v);
+    }
+    static TWX_HD int k_of(int q0, int q1, int q2) { return q0 + R0 * q1 + R0 * R * q2; }   // bin held in v[q2] after f2
+    // ---- inverse
+    static TWX_HD void iA(C* lds, const C* tabs, int q0, int q1, C* v) {
+        Bfly<T, R, true>::run(v);
+        lds[phys(q0, q1, 0)] = v[0];
+        TWX_UNROLL
+        for (int a = 1; a < R; ++a) lds[phys(q0, q1, a)] = cmulc(v[a], tabs[tab_a + a * R + q1]);
+    }
+    static TWX_HD void iB(C* lds, const C* tabs, int q0, int a, C* v) {
+        TWX_UNROLL
+        for (int r = 0; r < R; ++r) v[r] = lds[phys(q0, r, a)];
+        Bfly<T, R, true>::run(v);
+        if (R0 == 1) {
+            TWX_UNROLL
+            for (int b = 0; b < R; ++b) lds[phys(q0, b, a)] = v[b];
+        } else {
+            const C wa = tabs[tab_b + q0 * R + a];
+            TWX_UNROLL
+            for (int b = 0; b < R; ++b) lds[phys(q0, b, a)] = cmulc(v[b], cmul(wa, tabs[tab_c + q0 * R + b]));
+        }
+    }
+    static TWX_HD void iC(const C* lds, int t, C* v) {                            // → v[c] = z[t + M c]
+        const int b = t / R, a = t % R;
+        TWX_UNROLL
+        for (int r = 0; r < R0; ++r) v[r] = lds[phys(r, b, a)];
+        Bfly<T, R0, true>::run(v);
+    }
+};
+
 }  // namespace twx

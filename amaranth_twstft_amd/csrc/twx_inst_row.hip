@@ -38,11 +38,28 @@ template <typename T> int mid_s(const void* args, unsigned nblk, hipStream_t s) 
     return (int)hipGetLastError();
 }
 
+template <class PP> struct HasRowD {
+    static constexpr bool value = (PP::S == 2 && PP::radix(0) == PP::radix(1) && 64 / PP::radix(1) >= 1) ||
+                                  (PP::S == 3 && PP::radix(1) == PP::radix(2));
+};
+template <typename T> int rowd(int mode, const void* args, unsigned nblk, hipStream_t s) {
+    if constexpr (HasRowD<P>::value) {
+        constexpr int NTD = RowD<P, T>::NT_MIN;
+        const RowDArgs<T>& a = *reinterpret_cast<const RowDArgs<T>*>(args);
+        if (mode == ROW_BAND) hipLaunchKernelGGL((k_rowd<P, T, ROW_BAND, NTD>), dim3(nblk), dim3(NTD), 0, s, a);
+        else if (mode == ROW_MID) hipLaunchKernelGGL((k_rowd<P, T, ROW_MID, NTD>), dim3(nblk), dim3(NTD), 0, s, a);
+        else return -1;
+        return (int)hipGetLastError();
+    } else {
+        return -1;
+    }
+}
+
 struct Reg {
     Reg() {
-        register_row(RowOps{P::L, NT, 0, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<float>, &caf<float>, &mid_s<float>, &mid_p<float>});
+        register_row(RowOps{P::L, NT, 0, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<float>, &caf<float>, HasRowD<P>::value ? &rowd<float> : nullptr, &mid_s<float>, &mid_p<float>});
 #ifndef TWX_NO_F64
-        register_row(RowOps{P::L, NT, 1, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<double>, &caf<double>, &mid_s<double>, &mid_p<double>});
+        register_row(RowOps{P::L, NT, 1, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<double>, &caf<double>, HasRowD<P>::value ? &rowd<double> : nullptr, &mid_s<double>, &mid_p<double>});
 #endif
     }
 } reg_instance;

@@ -667,6 +667,159 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_rowd: the row pass on the DIF/DIT transform (RowD, twx_fft.h): same epilogues as k_row<BAND> and
+// k_row<MID>, but only the stride-(N2/R0) stages synchronise the workgroup — 7 workgroup barriers
+// per row for the full middle pass instead of 21.  The code spectrum is read in "block-thread"
+// order (cspec_perm[k1][q2][q0*R+q1] = conj(FFT(code))[k1 + N1*(q0 + R0 q1 + R0 R q2)]).
+// ------------------------------------------------------------------------------------------
+template <typename T> struct RowDArgs {
+    RowArgs<T> r;                    // shared fields (A, band, part, ramp1, ta/tb, Bz, dc, nphase, ...)
+    const cpx<T>* dtabs;             // RowD tables: ta | tb | tc
+    const cpx<T>* cspec_perm;        // [k1][q2][u]
+    const cpx<T>* ea_d;              // [rho][u]      exp(+2 pi i rho (q0 + R0 q1)/(Rint N2)), u = q0*R + q1
+    const cpx<T>* eb_d;              // [rho][2][q2]  exp(+2 pi i rho (R0 R q2 - wrap N2)/(Rint N2))
+};
+
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <class P2, typename T, int MODE, int NT>
+__global__ __launch_bounds__(NT, (MODE == ROW_MID ? 4 : 1)) void k_rowd(RowDArgs<T> ad) {
+    using C = cpx<T>;
+    using D = RowD<P2, T>;
+    const RowArgs<T>& a = ad.r;
+    constexpr int N2 = D::L, R = D::R, R0 = D::R0, M = D::M, NU = R0 * R;
+    constexpr int RMAX = R > R0 ? R : R0;
+    constexpr int NEB = MODE == ROW_MID ? TWX_MAX_PHASE * 2 * R : 0;
+    constexpr int NVC = MODE == ROW_MID ? R0 : 0;
+    static_assert(NT >= D::NT_MIN, "not enough threads for RowD");
+    __shared__ C lds[D::lds_elems + D::tab_total + NEB + NVC + 16];
+    C* tabs = lds + D::lds_elems;
+    C* s_eb = tabs + D::tab_total;
+    C* s_vc = s_eb + NEB;
+    void* red = (void*)(s_vc + NVC);
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int k1 = logical / a.nwin, b = logical % a.nwin;
+    const int tid = threadIdx.x;
+    int q0, qi;
+    const bool act = D::blk_map(tid, q0, qi);
+    const int u = q0 * R + qi;
+    const unsigned mask = (1u << a.tshift) - 1u;
+    const C* row = a.A + (long long)b * a.n + (long long)k1 * N2;
+    C v[RMAX];
+    C csr[MODE == ROW_MID ? R : 1];
+    if constexpr (MODE == ROW_MID) {
+        if (act) {
+            const C* cs = ad.cspec_perm + (long long)k1 * N2;
+            TWX_UNROLL
+            for (int q2 = 0; q2 < R; ++q2) csr[q2] = (cs + q2 * NU)[(unsigned)u];
+        }
+    }
+    if (tid < M) {
+        TWX_UNROLL
+        for (int r = 0; r < R0; ++r) v[r] = (row + r * M)[(unsigned)tid];
+    }
+    for (int i = tid; i < D::tab_total; i += NT) tabs[i] = ad.dtabs[i];
+    if constexpr (MODE == ROW_MID) {
+        for (int i = tid; i < a.nphase * 2 * R; i += NT) s_eb[i] = ad.eb_d[i];
+        if (tid < R0) {
+            const unsigned m = (unsigned)k1 * (unsigned)tid * (unsigned)M;      // conj(W_N^{k1 * c * M})
+            s_vc[tid] = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
+        }
+    }
+    __syncthreads();                                   // tables visible (the row loads are in flight meanwhile)
+    if (tid < M) {
+        Bfly<T, R0, false>::run(v);
+        D::f0_twiddle_store(lds, tabs, tid, v);
+    }
+    __syncthreads();                                   // all-to-all exchange of the stride-M stage
+    if (act) D::f1(lds, tabs, q0, qi, v);
+    wave_sync_lds();
+    if (act) D::f2(lds, q0, qi, v);                    // v[q2] = X[k1 + N1*(q0 + R0 qi + R0 R q2)]
+
+    if constexpr (MODE == ROW_BAND) {
+        Best<T> best; best.val = T(-1); best.idx = 0xffffffffu;
+        if (act) {
+            const long long half = a.n / 2;
+            TWX_UNROLL
+            for (int q2 = 0; q2 < R; ++q2) {
+                const long long k = (long long)k1 + (long long)a.n1 * D::k_of(q0, qi, q2);
+                long long i = k - (a.n - half); if (i < 0) i += a.n;
+                if (i >= a.band_lo && i <= a.band_hi) best.take(cnorm(v[q2]), (unsigned int)i);
+            }
+        }
+        best = block_best<T, NT>(best, red);
+        if (tid == 0) { ArgPart<T> p; p.val = best.val; p.idx = best.idx; a.part[(long long)b * a.n1 + k1] = p; }
+    } else {
+        C pr[R];
+        C ub = mk<T>(1, 0);
+        if (tid < M) {
+            const unsigned m = (unsigned)k1 * (unsigned)tid;
+            ub = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
+        }
+        if (act) {
+            if (k1 == 0 && u == 0) a.dc[b] = v[0];
+            TWX_UNROLL
+            for (int q2 = 0; q2 < R; ++q2) pr[q2] = cmul(v[q2], csr[q2]);      // ffty.*fcode (godual_ranging.m:26)
+        }
+        C ea_cur = mk<T>(1, 0), ea_n = mk<T>(1, 0);
+        if (a.nphase > 1 && act) ea_n = ad.ea_d[NU + u];
+        C r1_cur = a.ramp1[k1];
+        for (int rho = 0; rho < a.nphase; ++rho) {
+            if (rho > 0) __syncthreads();              // previous phase's stage C has read every block
+            int lt = tid;
+            asm volatile("" : "+v"(lt));               // keep address arithmetic inside the loop (see k_row)
+            int lq0, lqi;
+            const bool lact = D::blk_map(lt, lq0, lqi);
+            const C eaj = ea_cur;
+            const C r1 = r1_cur;
+            ea_cur = ea_n;
+            if (rho + 2 < a.nphase && lact) ea_n = ad.ea_d[(rho + 2) * NU + lq0 * R + lqi];
+            if (rho + 1 < a.nphase) r1_cur = a.ramp1[(long long)(rho + 1) * a.n1 + k1];
+            if (lact) {
+                if (rho == 0) {
+                    TWX_UNROLL
+                    for (int q2 = 0; q2 < R; ++q2) v[q2] = pr[q2];
+                } else {
+                    TWX_UNROLL
+                    for (int q2 = 0; q2 < R; ++q2) {
+                        C e;
+                        if constexpr (R % 2 == 0) e = ad.eb_d[(rho * 2 + (q2 >= R / 2 ? 1 : 0)) * R + q2];   // wave-uniform → scalar load
+                        else e = s_eb[(rho * 2 + ((2 * D::k_of(lq0, lqi, q2) >= N2) ? 1 : 0)) * R + q2];
+                        v[q2] = cmul(cmul(pr[q2], eaj), e);
+                    }
+                }
+                D::iA(lds, tabs, lq0, lqi, v);
+            }
+            wave_sync_lds();
+            if (lact) D::iB(lds, tabs, lq0, lqi, v);
+            __syncthreads();
+            if (lt < M) {
+                D::iC(lds, lt, v);
+                const C uu = cmul(ub, r1);
+                C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
+                TWX_UNROLL
+                for (int c = 0; c < R0; ++c) (out + c * M)[(unsigned)lt] = cmul(cmul(v[c], uu), s_vc[c]);   // · W_N^{-k1 q2} · ramp1
+            }
+        }
+    }
+}
+
+// code spectrum in block-thread order for k_rowd<MID>
+template <typename T>
+__global__ void k_cspec_perm(const cpx<T>* __restrict__ nat, cpx<T>* __restrict__ perm, int n1, int n2, int r0, int r) {
+    const int k1 = blockIdx.x;
+    const int nu = r0 * r;
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+        const int q2 = i / nu, uu = i % nu, q0 = uu / r, q1 = uu % r;
+        perm[(long long)k1 * n2 + i] = nat[(long long)k1 * n2 + q0 + r0 * q1 + r0 * r * q2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_row_mid_s: "split" form of k_row<MID>: one workgroup per (row, phase rho).  The forward row
 // transform is recomputed by each of the R workgroups of a row (they are adjacent in dispatch order,
 // so the A row and the code-spectrum row come from L2 for all but the first), in exchange the

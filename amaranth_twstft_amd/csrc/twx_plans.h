@@ -19,6 +19,7 @@ struct RowOps {
     int S, R[4];       // radices in forward stage order
     int (*run)(int mode, const void* args /*RowArgs<T>*/, unsigned nblk, hipStream_t s);
     int (*caf)(const void* args /*CafArgs<T>*/, unsigned nblk, hipStream_t s);
+    int (*rowd)(int mode, const void* args /*RowDArgs<T>*/, unsigned nblk, hipStream_t s);   // nullptr if the plan has no DIF form
     int (*mid_s)(const void* args /*RowArgs<T>*/, unsigned nblk, hipStream_t s);
     int (*mid_p)(const void* args /*RowArgs<T>*/, unsigned int* queue, unsigned total_rows, unsigned nblk, hipStream_t s);
 };

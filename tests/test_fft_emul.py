@@ -15,3 +15,14 @@ def test_fft_templates_on_cpu(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-2000:]
     assert "ALL OK" in out.stdout and "FAIL" not in out.stdout
+
+
+@pytest.mark.slow
+def test_rowd_transform_on_cpu(tmp_path):
+    """The DIF/DIT row transform (RowD: one all-to-all stage, two wave-local stages) against a direct DFT."""
+    exe = tmp_path / "rowd_emul"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", str(exe), os.path.join(ROOT, "tests", "cpu", "rowd_emul.cpp")],
+                   check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert "ALL OK" in out.stdout and "FAIL" not in out.stdout

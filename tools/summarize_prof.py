@@ -21,6 +21,10 @@ def short(name):
         mm = re.search(r">, (float|double), (\d),", targs)
         if mm:
             mode = {"0": "_store", "1": "_band", "2": "_mid"}[mm.group(2)] + ("_f64" if mm.group(1) == "double" else "")
+    elif k == "k_rowd":
+        mm = re.search(r">, (float|double), (\d),", targs)
+        if mm:
+            return "k_row" + {"1": "_band", "2": "_mid"}.get(mm.group(2), "") + ("_f64" if mm.group(1) == "double" else "") + "(dif)"
     elif k == "k_col_fwd":
         mm = re.search(r">, (float|double), \d+, (\d),", targs)
         if mm:
