@@ -15,6 +15,7 @@ TWX_OK = 0
 TWX_CONV_GODUAL, TWX_CONV_CLAUDIO = 0, 1
 TWX_WIN_NONE, TWX_WIN_HAMMING = 0, 1
 TWX_F32, TWX_F64 = 0, 1
+TWX_OPT_REMOVE_MEAN = 1
 TWX_FLAG_PROFILE = 1
 TWX_FLAG_FINE_FREQ = 2
 TWX_PROF_MAX = 16
@@ -71,6 +72,7 @@ SYMBOLS = {
     "twx_process_windows": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
     "twx_process_windows_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
     "twx_synchronize": (C.c_int, [_VP]),
+    "twx_set_option": (C.c_int, [_VP, C.c_int32, C.c_int64]),
     "twx_stream": (_VP, [_VP]),
     "twx_fft_forward": (C.c_int, [_VP, _VP, _VP]),
     "twx_get_code_spectrum": (C.c_int, [_VP, _VP]),
@@ -78,6 +80,8 @@ SYMBOLS = {
     "twx_process_file": (C.c_int, [_VP, C.c_char_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(twx_band), C.c_double, _VP, C.c_int64, C.POINTER(C.c_int64)]),
     "twx_caf_bins": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _VP, _VP]),
     "twx_caf_freqs": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP, C.c_int64, _VP]),
+    "twx_sqspec_bins_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_int32, _VP]),
+    "twx_sqspec_band_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _VP]),
     "twx_sliding_dot": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_double, C.c_double, C.c_double, _VP]),
     "twx_fir_decimate": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_int32, C.c_int32, _VP, _VP, C.POINTER(C.c_int64)]),
     "twx_profile_reset": (C.c_int, [_VP]),

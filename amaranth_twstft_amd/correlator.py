@@ -248,12 +248,61 @@ class Correlator:
         L.check(self._lib.twx_get_code_spectrum(self._h, out.ctypes.data_as(C.c_void_p)), self._h)
         return out
 
-    def xcorr_map(self, raw_window, df, n_channels=1, channel=0) -> np.ndarray:
+    def set_remove_mean(self, on: bool):
+        """``d=d-mean(d)`` before the NCO (default on; the reference's callers do it, godual_ranging.m:80,94)."""
+        L.check(self._lib.twx_set_option(self._h, L.TWX_OPT_REMOVE_MEAN, 1 if on else 0), self._h)
+
+    def xcorr_map(self, raw_window, df, n_channels=1, channel=0, raw_mean: bool = False) -> np.ndarray:
+        """The whole interpolated ``prnmap`` of one window (``raw_mean``: skip the mean removal)."""
         raw = np.ascontiguousarray(raw_window, dtype=np.int16).reshape(-1)
         assert raw.size >= self.n * 2 * n_channels
         out = np.empty(self.n * (2 * self.Nint + 1), dtype=np.complex128)
-        L.check(self._lib.twx_xcorr_map(self._h, raw.ctypes.data_as(C.c_void_p), n_channels, channel, float(df),
-                                        out.ctypes.data_as(C.c_void_p)), self._h)
+        if raw_mean:
+            self.set_remove_mean(False)
+        try:
+            L.check(self._lib.twx_xcorr_map(self._h, raw.ctypes.data_as(C.c_void_p), n_channels, channel, float(df),
+                                            out.ctypes.data_as(C.c_void_p)), self._h)
+        finally:
+            if raw_mean:
+                self.set_remove_mean(True)
+        return out
+
+    # -- device-resident input (pointers from twx_dev_alloc or any HIP allocation) -------------
+    def process_dev(self, iq_dev: int, nwin: int, n_channels=1, channel=0, band=None, df=None) -> list[WindowResult]:
+        """``process`` on ``nwin`` consecutive windows that already sit in device memory at ``iq_dev``."""
+        nbytes = C.sizeof(L.twx_result) * max(nwin, 1)
+        res = self._lib.twx_dev_alloc(nbytes)
+        if not res:
+            raise MemoryError("twx_dev_alloc failed")
+        try:
+            bptr = dptr = None
+            if band is not None:
+                b = L.twx_band(int(band[0]), int(band[1]))
+                bptr = C.byref(b)
+            else:
+                dfa = np.ascontiguousarray(np.broadcast_to(np.asarray(df, dtype=np.float64), (nwin,)))
+                dptr = dfa.ctypes.data_as(C.c_void_p)
+            L.check(self._lib.twx_process_windows_dev(self._h, iq_dev, nwin, n_channels, channel, bptr, dptr, res), self._h)
+            L.check(self._lib.twx_synchronize(self._h), self._h)
+            out = (L.twx_result * max(nwin, 1))()
+            L.check(self._lib.twx_memcpy_d2h(C.cast(out, C.c_void_p), res, nbytes))
+        finally:
+            self._lib.twx_dev_free(res)
+        return [_to_result(out[i]) for i in range(nwin)]
+
+    def sqspec_bins_dev(self, iq_dev: int, n_samples: int, bins, n_channels=1, channel=0) -> np.ndarray:
+        """``fft(d.^2)`` of an ``n_samples`` chunk at the given signed DFT bins (complex128)."""
+        b = np.ascontiguousarray(bins, dtype=np.int64)
+        out = np.empty(2 * b.size, dtype=np.float64)
+        L.check(self._lib.twx_sqspec_bins_dev(self._h, iq_dev, int(n_samples), n_channels, channel,
+                                              b.ctypes.data_as(C.c_void_p), b.size, out.ctypes.data_as(C.c_void_p)), self._h)
+        return out[0::2] + 1j * out[1::2]
+
+    def sqspec_band_dev(self, iq_dev: int, n_samples: int, k_lo: int, n_bins: int, n_channels=1, channel=0) -> np.ndarray:
+        """``abs(fft(d.^2))`` over ``n_bins`` consecutive signed bins from ``k_lo``; ``n_samples`` a multiple of N."""
+        out = np.empty(int(n_bins), dtype=np.float64)
+        L.check(self._lib.twx_sqspec_band_dev(self._h, iq_dev, int(n_samples), n_channels, channel, int(k_lo), int(n_bins),
+                                              out.ctypes.data_as(C.c_void_p)), self._h)
         return out
 
     def profile(self, reset=False) -> dict:

@@ -225,6 +225,7 @@ struct CtxBase {
         }
         prof_pending.clear();
     }
+    int remove_mean = 1;          // TWX_OPT_REMOVE_MEAN
     virtual int init() = 0;
     virtual int sync_all() = 0;
     virtual int pipeline_depth() const = 0;
@@ -235,6 +236,8 @@ struct CtxBase {
     virtual int xcorr_map(const int16_t* iq, int nch, int ch, double df, double* out) = 0;
     virtual int caf_bins(const int16_t* iq, int nch, int ch, long long k_lo, long long k_hi, double* pk, long long* lag) = 0;
     virtual int caf_freqs(const int16_t* iq, int nch, int ch, const double* freqs, long long nf, twx_result* out) = 0;
+    virtual int sqspec_bins(const void* iq_dev, long long L, int nch, int ch, const long long* bins, int nb, double* out) = 0;
+    virtual int sqspec_band(const void* iq_dev, long long L, int nch, int ch, long long k_lo, long long nk, double* out) = 0;
     virtual int process_file(const char* path, int nch, int ch, long long skip, const twx_band* band, double df_const,
                              twx_result* out, long long max_windows, long long* n_done) = 0;
 };
@@ -578,7 +581,7 @@ template <typename T> struct Ctx : CtxBase {
             HIPCHK(hipGetLastError());
         }
         ColFwdArgs<T> ca{};
-        ca.in_win_stride = wstride; ca.sums = sums; ca.remove_mean = 1; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = nb;
+        ca.in_win_stride = wstride; ca.sums = sums; ca.remove_mean = remove_mean; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = nb;
         ca.e1 = e1; ca.e2 = e2; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.tc = tcw; ca.out = A;
         RowArgs<T> ra{};
         ra.n = N; ra.n1 = N1; ra.nwin = nb; ra.A = A; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.ea = ea; ra.eb = eb;
@@ -643,7 +646,7 @@ template <typename T> struct Ctx : CtxBase {
         }
         PeakArgs<T> pa{};
         pa.n = N; pa.n1 = N1; pa.n2 = N2; pa.nphase = R; pa.nparts = R * ntiles; pa.part = part_peak; pa.Bz = Bz; pa.tw1d = tw1d;
-        pa.sums = sums; pa.remove_mean = 1; pa.dc = dc; pa.dfv = dfv; pa.dfidx = dfidx; pa.inv_scale = 1.0 / scale_pow2;
+        pa.sums = sums; pa.remove_mean = remove_mean; pa.dc = dc; pa.dfv = dfv; pa.dfidx = dfidx; pa.inv_scale = 1.0 / scale_pow2;
         pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.convention = cfg.convention; pa.res = out_dev;
         {
             ProfScope ps(this, PC_PEAK, nb);
@@ -727,6 +730,55 @@ template <typename T> struct Ctx : CtxBase {
             HIPCHK(hipStreamSynchronize(stream));
         }
         dfree(din);
+        return TWX_OK;
+    }
+
+    // d2 = fft(d.^2) of an L-sample chunk at a few bins (direct sums; L arbitrary)
+    int sqspec_bins(const void* iq_dev, long long L, int nch, int ch, const long long* bins, int nb, double* out) override {
+        if (L < 1 || nb < 1 || nb > 64) return fail(TWX_E_ARG, "sqspec_bins: need L >= 1 and 1..64 bins");
+        long long hb[64];
+        for (int i = 0; i < nb; ++i) { hb[i] = bins[i] % L; if (hb[i] < 0) hb[i] += L; }
+        long long* bd = nullptr; double* acc = nullptr;
+        if (int rc = dalloc(&bd, (size_t)nb)) return rc;
+        if (int rc = dalloc(&acc, (size_t)2 * nb)) return rc;
+        HIPCHK(hipMemcpyAsync(bd, hb, sizeof(long long) * nb, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemsetAsync(acc, 0, sizeof(double) * 2 * nb, stream));
+        const unsigned grid = (unsigned)std::min<long long>(2048, (L + 255) / 256);
+        hipLaunchKernelGGL((k_sq_dft_bins<0>), dim3(grid), dim3(256), 0, stream, reinterpret_cast<const short2*>(iq_dev) + ch, nch, L, bd, nb, acc);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out, acc, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        dfree(bd); dfree(acc);
+        return TWX_OK;
+    }
+    // |fft(d.^2)| of an L = M*N sample chunk over nk consecutive (signed) bins from k_lo: M decimated
+    // N-point transforms with this context's plan, then the radix-M recombination of the band only
+    int sqspec_band(const void* iq_dev, long long L, int nch, int ch, long long k_lo, long long nk, double* out) override {
+        if (L < N || L % N) return fail(TWX_E_ARG, "sqspec_band: L must be a multiple of the context's window length");
+        if (nk < 1 || nk > L) return fail(TWX_E_ARG, "sqspec_band: bad bin count");
+        const long long M = L / N;
+        if (M > 4096 || nch * M > 0x7fffffffll) return fail(TWX_E_ARG, "sqspec_band: chunk too long for this window length");
+        C* spec = nullptr; double* mag = nullptr;
+        if (int rc = dalloc(&spec, (size_t)(M * N))) return rc;
+        if (int rc = dalloc(&mag, (size_t)nk)) return rc;
+        if (int rc = sync_all()) return rc;
+        use_slot(0);
+        const short2* base = reinterpret_cast<const short2*>(iq_dev) + ch;
+        for (long long r0 = 0; r0 < M; r0 += B) {
+            const int nb = (int)std::min<long long>(B, M - r0);
+            ColFwdArgs<T> ca{};
+            ca.in_win_stride = nch; ca.sums = nullptr; ca.remove_mean = 0; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = nb;
+            ca.e1 = e1; ca.e2 = e2; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.tc = tcw; ca.out = A;
+            if (col->fwd(COL_SQUARE, IN_I16, base + r0 * nch, (int)(nch * M), &ca, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_fwd(square) launch failed");
+            RowArgs<T> ra{};
+            ra.n = N; ra.n1 = N1; ra.nwin = nb; ra.A = A; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.spec_out = spec + r0 * N;
+            if (row->run(ROW_STORE, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(store) launch failed");
+        }
+        hipLaunchKernelGGL((k_sqspec_combine<T>), dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, stream, spec, (int)M, (long long)N, N1, N2, k_lo, nk, mag);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out, mag, sizeof(double) * nk, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        dfree(spec); dfree(mag);
         return TWX_OK;
     }
 
@@ -932,6 +984,11 @@ int twx_synchronize(twx_ctx* ctx) {
     if (!ctx) return TWX_E_ARG;
     return ctx->impl->sync_all();
 }
+int twx_set_option(twx_ctx* ctx, int32_t option, int64_t value) {
+    if (!ctx) return TWX_E_ARG;
+    if (option == TWX_OPT_REMOVE_MEAN) { (void)ctx->impl->sync_all(); ctx->impl->remove_mean = value ? 1 : 0; return TWX_OK; }
+    return ctx->impl->fail(TWX_E_ARG, "unknown option");
+}
 void* twx_stream(twx_ctx* ctx) { return ctx ? (void*)ctx->impl->stream : nullptr; }
 
 int twx_process_windows(twx_ctx* ctx, const int16_t* iq, int64_t n_windows, int32_t n_channels, int32_t channel,
@@ -1007,6 +1064,19 @@ int twx_caf_freqs(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t c
     if (!ctx || !iq || !freqs || !out || n_freqs < 0 || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
     (void)hipSetDevice(ctx->impl->dev);
     return ctx->impl->caf_freqs(iq, n_channels, channel, freqs, n_freqs, out);
+}
+
+int twx_sqspec_bins_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel,
+                        const int64_t* bins, int32_t n_bins, double* out_re_im) {
+    if (!ctx || !iq_dev || !bins || !out_re_im || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
+    (void)hipSetDevice(ctx->impl->dev);
+    return ctx->impl->sqspec_bins(iq_dev, n_samples, n_channels, channel, (const long long*)bins, n_bins, out_re_im);
+}
+int twx_sqspec_band_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel,
+                        int64_t k_lo, int64_t n_bins, double* out_mag) {
+    if (!ctx || !iq_dev || !out_mag || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
+    (void)hipSetDevice(ctx->impl->dev);
+    return ctx->impl->sqspec_band(iq_dev, n_samples, n_channels, channel, k_lo, n_bins, out_mag);
 }
 
 int twx_profile_reset(twx_ctx* ctx) {

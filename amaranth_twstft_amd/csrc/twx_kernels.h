@@ -1111,6 +1111,64 @@ __global__ __launch_bounds__(256) void k_caf_reduce(const ArgPart<T>* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// Long squared spectra for the acquisition stage (search_df and the per-chunk carrier update of
+// acquisition/claudio_aligned_code_ranging_separate.m:27-31,162-163): d2 = abs(fft(d.^2)) over a
+// chunk of L samples, L not tied to the code length.
+//   k_sq_dft_bins:    a handful of bins by direct summation (exact integer phase reduction).
+//   k_sqspec_combine: a band of bins of an L = M*N point transform from the M decimated N-point
+//                     spectra F_r (r = n mod M): X[k] = sum_r W_L^{r k} F_r[k mod N].
+// ------------------------------------------------------------------------------------------
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_sq_dft_bins(const short2* __restrict__ in, int nch, long long L,
+                                                     const long long* __restrict__ bins, int nb, double* __restrict__ acc /*[nb][2]*/) {
+    __shared__ double red[4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int bi = 0; bi < nb; ++bi) {
+        const long long kk = bins[bi];            // already reduced to 0..L-1
+        double sx = 0, sy = 0;
+        for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < L; n += (long long)gridDim.x * 256) {
+            const short2 s = in[n * nch];
+            const double I = (double)s.x, Q = (double)s.y;
+            const double re = I * I - Q * Q, im = 2.0 * I * Q;          // d^2, exact
+            const unsigned long long t = ((unsigned long long)n * (unsigned long long)kk) % (unsigned long long)L;
+            double sn, cs;
+            sincospi(2.0 * (double)t / (double)L, &sn, &cs);
+            sx += re * cs + im * sn;                                     // d^2 * exp(-i phi)
+            sy += im * cs - re * sn;
+        }
+        for (int d = 32; d >= 1; d >>= 1) { sx += __shfl_down(sx, d, 64); sy += __shfl_down(sy, d, 64); }
+        if (lane == 0) { red[wave][0] = sx; red[wave][1] = sy; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&acc[2 * bi], red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+            atomicAdd(&acc[2 * bi + 1], red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_sqspec_combine(const cpx<T>* __restrict__ spec /*[M][k1][k2]*/, int M, long long N, int N1, int N2,
+                                                        long long k_lo, long long nk, double* __restrict__ mag) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nk) return;
+    const long long L = (long long)M * N;
+    long long kk = (k_lo + i) % L; if (kk < 0) kk += L;
+    const long long j = kk % N;
+    const int k1 = (int)(j % N1), k2 = (int)(j / N1);
+    double sx = 0, sy = 0;
+    for (int r = 0; r < M; ++r) {
+        const cpx<T> f = spec[(long long)r * N + (long long)k1 * N2 + k2];
+        const unsigned long long t = ((unsigned long long)r * (unsigned long long)kk) % (unsigned long long)L;
+        double sn, cs;
+        sincospi(2.0 * (double)t / (double)L, &sn, &cs);
+        sx += (double)f.x * cs + (double)f.y * sn;
+        sy += (double)f.y * cs - (double)f.x * sn;
+    }
+    mag[i] = sqrt(sx * sx + sy * sy);
+}
+
+// ------------------------------------------------------------------------------------------
 // k_col_inv: last pass of the inverse transform fused with [~,indice]=max(abs(prnmap))
 // (godual_ranging.m:29).  grid = ntiles * R * windows
 // ------------------------------------------------------------------------------------------

@@ -117,6 +117,13 @@ int twx_process_windows(twx_ctx* ctx, const int16_t* iq, int64_t n_windows, int3
 int twx_process_windows_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_windows, int32_t n_channels,
                             int32_t channel, const twx_band* band, const double* df, twx_result* out_dev);
 int twx_synchronize(twx_ctx* ctx);
+
+/* Run-time options.  TWX_OPT_REMOVE_MEAN (default 1): subtract the window's complex mean before the
+ * NCO (d=d-mean(d), godual_ranging.m:80,94, done by the caller of processing() in the reference);
+ * 0 leaves the samples as they are (search_df mixes the raw chunk,
+ * acquisition/claudio_aligned_code_ranging_separate.m:34). */
+enum { TWX_OPT_REMOVE_MEAN = 1 };
+int twx_set_option(twx_ctx* ctx, int32_t option, int64_t value);
 void* twx_stream(twx_ctx* ctx);                      /* hipStream_t of the context */
 
 /* File-in / results-out: the window loop of godual_ranging.m:70-103 over a capture FILE (raw int16,
@@ -153,6 +160,20 @@ int twx_caf_bins(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t ch
                  double* pk, int64_t* lag);
 int twx_caf_freqs(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, const double* freqs,
                   int64_t n_freqs, twx_result* out);
+
+/* Long squared spectra for carrier acquisition ----------------------------------------------------
+ * Replaces d2=fftshift(abs(fft(d.^2))) over a whole ls-second chunk in
+ * acquisition/claudio_aligned_code_ranging_separate.m:30 (search_df) and :162-163 (per-chunk carrier
+ * update on kbon-3..kbon+3).  iq_dev is a DEVICE pointer to n_samples interleaved int16 IQ samples
+ * (no mean removal, as in the script); bins are signed DFT bin numbers of the n_samples-point
+ * transform (shifted index i of the script = bin + floor(n_samples/2)); outputs are HOST arrays.
+ * twx_sqspec_bins_dev: complex fft(d.^2)[bin] for up to 64 bins by direct summation (any n_samples).
+ * twx_sqspec_band_dev: abs(fft(d.^2)) for n_bins consecutive bins starting at k_lo; n_samples must
+ *   be a multiple M of the context's window length N (M decimated N-point transforms + recombination). */
+int twx_sqspec_bins_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel,
+                        const int64_t* bins, int32_t n_bins, double* out_re_im);
+int twx_sqspec_band_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel,
+                        int64_t k_lo, int64_t n_bins, double* out_mag);
 
 /* Direct sliding dot-product correlator for short codes (tracking stage) -----------------------
  * Replaces downconv_trk + cblas_dgemm(W^T X)/nobs + the PRN_mapping replica matrix of

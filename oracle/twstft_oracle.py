@@ -299,6 +299,99 @@ def search_df(d, k, df_threshold, freq, temps, fcode_claudio):
     return kbon
 
 
+def _oround(x: float) -> int:
+    """Octave ``round`` (half away from zero)."""
+    return int(np.floor(abs(x) + 0.5)) * (1 if x >= 0 else -1)
+
+
+def ranging_tracked(raw, chips, fs=5e6, sps=2, Nint=1, ls_samples=None, band_hz=8000.0, df_threshold=20.0,
+                    skip_samples=0, kbon=None):
+    """Tracked multi-code loop of acquisition/claudio_aligned_code_ranging_separate.m:143-205 — UNPINNED
+    (Octave only).  ``raw`` = single-channel interleaved int16 ``[I Q]…`` file contents; ``ls_samples``
+    = samples per chunk (``fs*ls`` :157).  1-based bookkeeping is kept as in the script, including
+    its quirks: ``indice1`` is the 1-based peak index divided by (2Nint+1) (:168) except after a
+    re-alignment, where the raw 1-based index of the second measurement is stored (:179); after the
+    carrier search the file is re-read from its START (:153-155), so ``skip_samples`` only moves the
+    chunk that ``search_df`` sees.  Deviation: where the script would index past the chunk after a
+    re-alignment (Octave aborts), the first measurement is kept and the chunk ends.
+    Returns a dict of per-code lists plus ``df`` per chunk, ``kbon`` (0-based), ``moved``/``movedval``.
+    """
+    raw = np.asarray(raw).reshape(-1)
+    code = make_code(chips, sps)
+    n = len(code)
+    fc = make_fcode(code, "claudio")
+    temps = np.arange(n) / fs
+    L = int(ls_samples if ls_samples is not None else fs * 2)
+    freq = np.linspace(-fs / 2, fs / 2 - 1.0, L)                    # :131 (fs/fs = 1)
+    k = np.nonzero((freq < band_hz) & (freq > -band_hz))[0]          # :134
+    r = 2 * Nint + 1
+    out = dict(xval=[], indice1=[], correction1=[], SNR1r=[], SNR1i=[], puissance1=[], df=[], moved=[], movedval=[], kbon=-1)
+    pos = skip_samples * 2
+    dold = np.zeros(0, dtype=complex)
+    df_found = kbon is not None
+    if df_found:
+        out["kbon"] = int(kbon)
+    p = 1
+    guard = 0
+    while True:
+        chunk = raw[pos:pos + 2 * L]
+        pos += 2 * L
+        if len(chunk) != 2 * L:
+            break
+        d = chunk[0::2].astype(np.float64) + 1j * chunk[1::2].astype(np.float64)
+        if not df_found:
+            kb = search_df(d, k, df_threshold, freq, temps, fc)
+            if kb >= 0:
+                df_found = True
+                out["kbon"] = kb
+            chunk = raw[0:2 * L]                                       # fclose/fopen/fread :153-155
+            pos = 2 * L
+            d = chunk[0::2].astype(np.float64) + 1j * chunk[1::2].astype(np.float64)
+            guard += 1
+            if not df_found and guard > 2:                             # the script would loop forever here
+                break
+        if df_found:
+            kb = out["kbon"]
+            d = np.concatenate((dold, d))
+            d2 = np.fft.fftshift(np.abs(np.fft.fft(d ** 2)))
+            j = int(np.argmax(d2[kb - 3:kb + 4]))
+            df = freq[j + kb - 3] / 2
+            out["df"].append(df)
+            dindex = 1.0
+            while True:
+                s0 = _oround(dindex)
+                dpart = d[s0 - 1:s0 - 1 + n]
+                dpart = dpart - dpart.mean()
+                o = processing_claudio(dpart, df, temps, fc, code, Nint=Nint, ddof=1)
+                ind = (o["indice"] + 1) / r
+                stop = False
+                if 10 * np.log10(o["SNRi"] + o["SNRr"]) > -30:
+                    if (43 < ind < n / 2) or (n / 2 < ind < n - 2):
+                        out["moved"].append(p)
+                        out["movedval"].append(ind + 1)
+                        dnew = dindex
+                        if dnew - ind + 1 < 0:
+                            dnew += n
+                        dnew = dnew - ind + 21
+                        s1 = _oround(dnew)
+                        if s1 >= 1 and s1 - 1 + n <= len(d):
+                            dindex = dnew
+                            dpart = d[s1 - 1:s1 - 1 + n]
+                            dpart = dpart - dpart.mean()
+                            o = processing_claudio(dpart, df, temps, fc, code, Nint=Nint, ddof=1)
+                            ind = float(o["indice"] + 1)
+                        else:
+                            stop = True
+                out["xval"].append(o["xval"]); out["indice1"].append(ind); out["correction1"].append(o["correction"])
+                out["SNR1r"].append(o["SNRr"]); out["SNR1i"].append(o["SNRi"]); out["puissance1"].append(o["puissance"])
+                p += 1
+                dindex += n
+                if stop or dindex + n - 1 > len(d):
+                    break
+            dold = d[_oround(dindex) - 1:] if dindex < len(d) else np.zeros(0, dtype=complex)
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # delay × Doppler cross-ambiguity (experiments/231001_DLL_PLL/rxcomplex.cpp) — UNPINNED
 # --------------------------------------------------------------------------------------------

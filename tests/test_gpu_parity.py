@@ -524,3 +524,97 @@ def test_edge_cases_zero_input_wraparound_and_full_scale():
         o = orc.processing(d, None, None, temps, fcode, code, Nint=1, fs=FS, df=0.0)
         _check(g, o)
         assert g.indice == 3 * 4242
+
+
+# ---------------------------------------------------------------------------------------------
+# acquisition stage + tracked multi-code loop (acquisition/claudio_aligned_code_ranging_separate.m)
+# ---------------------------------------------------------------------------------------------
+
+def _tracked_capture(ncodes=170, df=30.0, delay=1500, seed=3, sigma=300.0, amp=500):
+    nchips, n = 10000, 20000
+    chips = chips_for(14, 43, nchips)
+    p = synth.SynthParams(delay_q8=delay * 256, fstep=synth.fstep_for_df(df, FS), phi0=5, amp=amp,
+                          noise_gain=synth.noise_gain_for_sigma(sigma), seed=seed)
+    return chips, n, synth.synth_channel(n * ncodes, chips, 2, p)
+
+
+def test_squared_spectrum_bins_and_band():
+    """abs(fft(d.^2)) over a chunk longer than the code (search_df :30, carrier update :162-163)."""
+    from amaranth_twstft_amd.tracked import _DevBuf
+    chips, n, raw = _tracked_capture(ncodes=52)
+    with Correlator(chips, fs=FS, Nint=1, convention="claudio", var_ddof=1) as cor:
+        buf = _DevBuf(cor._lib, raw.nbytes)
+        try:
+            buf.upload(0, raw)
+            d = orc.deinterleave(raw, 1, 0)
+            for Ld in (50 * n, 50 * n + 1234, 51 * n + 7):          # the carry makes the chunk length arbitrary
+                ref = np.fft.fft(d[:Ld] ** 2)
+                bins = np.array([-3, -1, 0, 1, 2, 12, 13, Ld // 2, -(Ld // 2)])
+                got = cor.sqspec_bins_dev(buf.ptr, Ld, bins)
+                want = ref[bins % Ld]
+                assert np.abs(got - want).max() <= 1e-9 * np.abs(ref).max()
+            Lc = 50 * n
+            ref = np.abs(np.fft.fft(d[:Lc] ** 2))
+            k_lo, nk = -3200, 6400
+            got = cor.sqspec_band_dev(buf.ptr, Lc, k_lo, nk)
+            want = ref[np.arange(k_lo, k_lo + nk) % Lc]
+            assert np.abs(got - want).max() <= 2e-6 * want.max()
+            assert int(np.argmax(got)) == int(np.argmax(want))
+        finally:
+            buf.close()
+
+
+def test_tracked_multicode_loop_vs_oracle():
+    """search_df + per-chunk carrier + 40-ms code loop with re-alignment, against the oracle's
+    restatement of claudio_aligned_code_ranging_separate.m:143-205 (unpinned: Octave only)."""
+    from amaranth_twstft_amd.tracked import TrackedRanging
+    chips, n, raw = _tracked_capture()
+    Lc = 50 * n
+    want = orc.ranging_tracked(raw, chips, fs=FS, ls_samples=Lc)
+    with TrackedRanging(chips, fs=FS, Nint=1, ls_samples=Lc) as tr:
+        got = tr.run(raw)
+    assert got["kbon"] == want["kbon"] and want["kbon"] > 0
+    assert got["df"] == want["df"]
+    assert got["moved"] == want["moved"] == [1] and np.allclose(got["movedval"], want["movedval"])
+    assert len(got["indice1"]) == len(want["indice1"]) > 100
+    assert got["indice1"] == want["indice1"]                     # integer lags (and the /3 bookkeeping) bit-exact
+    gx, wx = np.abs(np.array(got["xval"])), np.abs(np.array(want["xval"]))
+    assert np.abs(gx - wx).max() <= MAG_TOL * wx.max()
+    assert np.abs(np.array(got["correction1"]) - np.array(want["correction1"])).max() < 2e-4
+    for key in ("SNR1r", "SNR1i", "puissance1"):
+        a, b = np.array(got[key]), np.array(want[key])
+        assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max() + 1e-12, key
+    assert got["batches"] <= 2 + len(want["df"])                 # one batch per chunk once aligned
+
+
+def test_tracked_loop_realigns_after_a_jump():
+    """A mid-capture delay jump (sample loss) moves the window once more; codes before and after agree with the oracle."""
+    from amaranth_twstft_amd.tracked import TrackedRanging
+    chips, n, a = _tracked_capture(ncodes=60, delay=1500, seed=4)
+    _, _, b = _tracked_capture(ncodes=60, delay=1500 + 777, seed=5)
+    raw = np.concatenate((a, b))
+    Lc = 50 * n
+    want = orc.ranging_tracked(raw, chips, fs=FS, ls_samples=Lc)
+    with TrackedRanging(chips, fs=FS, Nint=1, ls_samples=Lc) as tr:
+        got = tr.run(raw)
+    assert len(want["moved"]) >= 2
+    assert got["moved"] == want["moved"] and got["indice1"] == want["indice1"]
+    gx, wx = np.abs(np.array(got["xval"])), np.abs(np.array(want["xval"]))
+    assert np.abs(gx - wx).max() <= MAG_TOL * wx.max()
+
+
+def test_tracked_loop_reference_sizes():
+    """The script's own sizes: 100 kchip code (N = 200 000, 40 ms), 2-s chunks of 10^7 samples (:15,125-131)."""
+    from amaranth_twstft_amd.tracked import TrackedRanging
+    nchips, n = 100000, 200000
+    chips = chips_for(17, 9, nchips)
+    p = synth.SynthParams(delay_q8=123456 * 256, fstep=synth.fstep_for_df(12.0, FS), phi0=9, amp=300,
+                          noise_gain=synth.noise_gain_for_sigma(500.0), seed=21)
+    raw = synth.synth_channel(n * 101, chips, 2, p)
+    want = orc.ranging_tracked(raw, chips, fs=FS)
+    with TrackedRanging(chips, fs=FS, Nint=1) as tr:
+        got = tr.run(raw)
+    assert got["kbon"] == want["kbon"] and want["kbon"] > 0 and got["df"] == want["df"]
+    assert got["moved"] == want["moved"] and got["indice1"] == want["indice1"] and len(want["indice1"]) >= 98
+    gx, wx = np.abs(np.array(got["xval"])), np.abs(np.array(want["xval"]))
+    assert np.abs(gx - wx).max() <= MAG_TOL * wx.max()
