@@ -55,3 +55,22 @@ def tsv_rows(res1, res2, fs: float, Nint: int):
             row += "\t%.12f\t%.3f\t%.1f\t%.1f" % ((b.indice - b.correction) / fs / r, b.df, 10 * np.log10(b.puissance),
                                                   10 * np.log10(b.SNRi + b.SNRr))
         yield row + "\r\n"
+
+
+def tracked_mat_dict(out: dict, code=None) -> dict:
+    """Variables the tracked script leaves in its workspace for ``save -mat … corr* df indic* SNR* code puissan*
+    xval* moved*`` (acquisition/claudio_aligned_code_ranging_separate.m:207): per-code row vectors ``xval1
+    indice1 correction1 SNR1r SNR1i puissance1``, per-chunk ``df``, ``moved``/``movedval``.  ``out`` is the dict
+    returned by ``tracked.TrackedRanging.run`` (``indice1`` already carries the script's own bookkeeping)."""
+    row = lambda v, dt=np.float64: np.asarray(v, dtype=dt).reshape(1, -1)
+    d = {"xval1": row(out["xval"], np.complex128), "indice1": row(out["indice1"]), "correction1": row(out["correction1"]),
+         "SNR1r": row(out["SNR1r"]), "SNR1i": row(out["SNR1i"]), "puissance1": row(out["puissance1"]),
+         "df": row(out["df"]), "moved": row(out["moved"]), "movedval": row(out["movedval"])}
+    if code is not None:
+        d["code"] = np.asarray(code, dtype=np.float64).reshape(1, -1)
+    return d
+
+
+def save_tracked_mat(path: str, out: dict, code=None) -> None:
+    from scipy.io import savemat
+    savemat(path, tracked_mat_dict(out, code), do_compression=False)

@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=10, help="windows of the workload timed on the host CPU (oracle)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
+                    "multi-rank path on a box with fewer GPUs than ranks)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -70,12 +72,22 @@ def main():
     if world != a.gpus:
         if rank == 0:
             print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if a.backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPUs visible")
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     from amaranth_twstft_amd import _lib as L, prn
     from amaranth_twstft_amd.correlator import Correlator, band_godual
@@ -108,7 +120,12 @@ def main():
                                                 res.data_ptr()), c._h)
         if world > 1:
             L.check(lib.twx_synchronize(c._h), c._h)        # results complete before RCCL reads them
-            dist.all_gather_into_tensor(gathered, res)
+            if a.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, res)        # RCCL over xGMI, 240 B per window
+            else:
+                host = gathered.cpu()
+                dist.all_gather_into_tensor(host, res.cpu())
+                gathered.copy_(host)
 
     def barrier():
         if world > 1:
@@ -124,7 +141,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -209,6 +226,7 @@ def main():
         print(json.dumps(out))
     cor.close()
     if world > 1:
+        dist.barrier()                   # rank 0 may still have been profiling; leave together
         dist.destroy_process_group()
 
 

@@ -30,3 +30,21 @@ def test_tsv_row_format():
     assert rows[0].startswith("n\tdt1\tdf1")
     f = rows[1].rstrip("\r\n").split("\t")
     assert f[0] == "1" and f[1] == "%.12f" % (3935295 / 5e6 / 3) and f[2] == "1780.750" and len(f) == 9
+
+
+def test_tracked_mat_roundtrip_feeds_twoway(tmp_path):
+    """tracked .mat variable set (claudio_aligned_code_ranging_separate.m:207) → loadmat → twoway (go_1s.m:83-95)."""
+    from scipy.io import loadmat
+    from amaranth_twstft_amd import results_io, twoway
+    n = 60
+    out = dict(xval=[(1000 + i) * np.exp(0.2j) for i in range(n)], indice1=[21.0 + (i % 2) for i in range(n)],
+               correction1=[0.1] * n, SNR1r=[1e-3] * n, SNR1i=[2e-3] * n, puissance1=[5.0] * n, df=[12.5, 12.0],
+               moved=[1], movedval=[777.0])
+    p = tmp_path / "rangingclaudio_x.mat"
+    results_io.save_tracked_mat(str(p), out, code=[1, -1, 1])
+    m = loadmat(str(p))
+    assert m["xval1"].shape == (1, n) and np.iscomplexobj(m["xval1"]) and m["df"].shape == (1, 2)
+    assert m["moved"].ravel().tolist() == [1] and m["code"].ravel().tolist() == [1, -1, 1]
+    k, trunc = twoway.valid_codes(m["xval1"].ravel())
+    d = twoway.delays_ns(m["indice1"].ravel(), m["correction1"].ravel(), k)
+    assert not trunc and len(d) == n - 11 and abs(d[0] - (21.0 + 0.1 / 3) / 5e6 * 1e9) < 1e-9
