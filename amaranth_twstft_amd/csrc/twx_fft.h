@@ -482,6 +482,17 @@ template <class P, typename T> struct RowD {
         TWX_UNROLL
         for (int a = 1; a < R; ++a) lds[phys(q0, q1, a)] = cmulc(v[a], tabs[tab_a + a * R + q1]);
     }
+    // iA in two halves: the register part touches only the (read-only) tables, so it may run before the
+    // workgroup barrier that frees the data region; the store part must follow it
+    static TWX_HD void iA_pre(const C* tabs, int q1, C* v) {
+        Bfly<T, R, true>::run(v);
+        TWX_UNROLL
+        for (int a = 1; a < R; ++a) v[a] = cmulc(v[a], tabs[tab_a + a * R + q1]);
+    }
+    static TWX_HD void iA_store(C* lds, int q0, int q1, const C* v) {
+        TWX_UNROLL
+        for (int a = 0; a < R; ++a) lds[phys(q0, q1, a)] = v[a];
+    }
     static TWX_HD void iB(C* lds, const C* tabs, int q0, int a, C* v) {
         TWX_UNROLL
         for (int r = 0; r < R; ++r) v[r] = lds[phys(q0, r, a)];

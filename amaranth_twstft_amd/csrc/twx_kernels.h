@@ -24,6 +24,11 @@
 
 // build-time switches (defaults = product build; the non-zero ablation values are timing-only
 // diagnostic builds whose results are wrong)
+#ifndef TWX_PRIO
+#define TWX_PRIO 0      // experiment: 1 = raise wave priority in the memory-issue sections of k_rowd<MID>, 2 = in the arithmetic sections
+#endif
+#define TWX_PRIO_MEM() do { if (TWX_PRIO == 1) __builtin_amdgcn_s_setprio(3); else if (TWX_PRIO == 2) __builtin_amdgcn_s_setprio(0); } while (0)
+#define TWX_PRIO_ALU() do { if (TWX_PRIO == 1) __builtin_amdgcn_s_setprio(0); else if (TWX_PRIO == 2) __builtin_amdgcn_s_setprio(3); } while (0)
 #ifndef TWX_ABL
 #define TWX_ABL 0       // k_row<MID>: 1 no Bz stores, 2 no code-spectrum load, 3 one phase only, 4 no A load, 5 no inverse transforms
 #endif
@@ -711,6 +716,7 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID ? 4 : 1)) void k_rowd(RowDArgs
     const C* row = a.A + (long long)b * a.n + (long long)k1 * N2;
     C v[RMAX];
     C csr[MODE == ROW_MID ? R : 1];
+    if constexpr (MODE == ROW_MID) TWX_PRIO_MEM();
     if constexpr (MODE == ROW_MID) {
         if (act) {
             const C* cs = ad.cspec_perm + (long long)k1 * N2;
@@ -731,6 +737,7 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID ? 4 : 1)) void k_rowd(RowDArgs
         }
     }
     __syncthreads();                                   // tables visible (the row loads are in flight meanwhile)
+    if constexpr (MODE == ROW_MID) TWX_PRIO_ALU();
     if (tid < M) {
         Bfly<T, R0, false>::run(v);
         D::f0_twiddle_store(lds, tabs, tid, v);
@@ -765,44 +772,49 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID ? 4 : 1)) void k_rowd(RowDArgs
             TWX_UNROLL
             for (int q2 = 0; q2 < R; ++q2) pr[q2] = cmul(v[q2], csr[q2]);      // ffty.*fcode (godual_ranging.m:26)
         }
-        C ea_cur = mk<T>(1, 0), ea_n = mk<T>(1, 0);
-        if (a.nphase > 1 && act) ea_n = ad.ea_d[NU + u];
+        // Phase rho's register work (ramp, first inverse butterfly, its twiddles) is done BEFORE the barrier
+        // that ends phase rho-1, so waves that finish stage C early spend the wait on arithmetic.
         C r1_cur = a.ramp1[k1];
+        if (act) {
+            TWX_UNROLL
+            for (int q2 = 0; q2 < R; ++q2) v[q2] = pr[q2];
+            D::iA_pre(tabs, qi, v);
+        }
         for (int rho = 0; rho < a.nphase; ++rho) {
-            if (rho > 0) __syncthreads();              // previous phase's stage C has read every block
             int lt = tid;
             asm volatile("" : "+v"(lt));               // keep address arithmetic inside the loop (see k_row)
             int lq0, lqi;
             const bool lact = D::blk_map(lt, lq0, lqi);
-            const C eaj = ea_cur;
             const C r1 = r1_cur;
-            ea_cur = ea_n;
-            if (rho + 2 < a.nphase && lact) ea_n = ad.ea_d[(rho + 2) * NU + lq0 * R + lqi];
-            if (rho + 1 < a.nphase) r1_cur = a.ramp1[(long long)(rho + 1) * a.n1 + k1];
-            if (lact) {
-                if (rho == 0) {
-                    TWX_UNROLL
-                    for (int q2 = 0; q2 < R; ++q2) v[q2] = pr[q2];
-                } else {
-                    TWX_UNROLL
-                    for (int q2 = 0; q2 < R; ++q2) {
-                        C e;
-                        if constexpr (R % 2 == 0) e = ad.eb_d[(rho * 2 + (q2 >= R / 2 ? 1 : 0)) * R + q2];   // wave-uniform → scalar load
-                        else e = s_eb[(rho * 2 + ((2 * D::k_of(lq0, lqi, q2) >= N2) ? 1 : 0)) * R + q2];
-                        v[q2] = cmul(cmul(pr[q2], eaj), e);
-                    }
-                }
-                D::iA(lds, tabs, lq0, lqi, v);
+            C eaj = mk<T>(1, 0);
+            if (rho + 1 < a.nphase) {                  // next phase's ramp factors: in flight during this phase
+                r1_cur = a.ramp1[(long long)(rho + 1) * a.n1 + k1];
+                if (lact) eaj = ad.ea_d[(rho + 1) * NU + lq0 * R + lqi];
             }
+            if (rho > 0) __syncthreads();              // previous phase's stage C has read every block
+            if (lact) D::iA_store(lds, lq0, lqi, v);
             wave_sync_lds();
             if (lact) D::iB(lds, tabs, lq0, lqi, v);
             __syncthreads();
             if (lt < M) {
+                TWX_PRIO_MEM();
                 D::iC(lds, lt, v);
                 const C uu = cmul(ub, r1);
                 C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
                 TWX_UNROLL
                 for (int c = 0; c < R0; ++c) (out + c * M)[(unsigned)lt] = cmul(cmul(v[c], uu), s_vc[c]);   // · W_N^{-k1 q2} · ramp1
+                TWX_PRIO_ALU();
+            }
+            if (rho + 1 < a.nphase && lact) {
+                const int rn = rho + 1;
+                TWX_UNROLL
+                for (int q2 = 0; q2 < R; ++q2) {
+                    C e;
+                    if constexpr (R % 2 == 0) e = ad.eb_d[(rn * 2 + (q2 >= R / 2 ? 1 : 0)) * R + q2];   // wave-uniform → scalar load
+                    else e = s_eb[(rn * 2 + ((2 * D::k_of(lq0, lqi, q2) >= N2) ? 1 : 0)) * R + q2];
+                    v[q2] = cmul(cmul(pr[q2], eaj), e);
+                }
+                D::iA_pre(tabs, lqi, v);
             }
         }
     }
