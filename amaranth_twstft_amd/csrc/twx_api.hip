@@ -22,6 +22,7 @@ namespace twx {
 // ------------------------------------------------------------------------------------------
 // registry
 // ------------------------------------------------------------------------------------------
+LaunchEvents& launch_events() { static thread_local LaunchEvents le; return le; }
 static std::vector<ColOps>& col_reg() { static std::vector<ColOps> v; return v; }
 static std::vector<RowOps>& row_reg() { static std::vector<RowOps> v; return v; }
 void register_col(const ColOps& o) { col_reg().push_back(o); }
@@ -211,9 +212,14 @@ struct CtxBase {
     struct ProfScope {
         CtxBase* c; ProfRec r; bool on;
         ProfScope(CtxBase* c_, int cls, long long units) : c(c_), on(c_->profile) {
-            if (on) { r.cls = cls; r.units = units; r.a = c->get_event(); r.b = c->get_event(); (void)hipEventRecord(r.a, c->stream); }
+            if (on) { r.cls = cls; r.units = units; r.a = c->get_event(); r.b = c->get_event(); launch_events() = LaunchEvents{r.a, r.b}; }
         }
-        ~ProfScope() { if (on) { (void)hipEventRecord(r.b, c->stream); c->prof_pending.push_back(r); } }
+        ~ProfScope() {
+            if (!on) return;
+            LaunchEvents& le = launch_events();
+            if (le.start) { le = LaunchEvents{}; c->ev_pool.push_back(r.a); c->ev_pool.push_back(r.b); }   // nothing was launched
+            else c->prof_pending.push_back(r);
+        }
     };
     void prof_collect() {
         for (auto& r : prof_pending) {
@@ -431,7 +437,7 @@ template <typename T> struct Ctx : CtxBase {
             if (int rc = upload(&tcd, h)) return rc;
         }
         if (int rc = code_spectrum_T<double>(spec, c64, r64, t1, t2, tad, tbd, tcd)) return rc;
-        hipLaunchKernelGGL((k_convert<double, T>), dim3(1024), dim3(256), 0, stream, spec, cspec, N, scale_pow2);   // range scale folded in
+        TWX_LAUNCH((k_convert<double, T>), dim3(1024), dim3(256), stream, spec, cspec, N, scale_pow2);   // range scale folded in
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
         dfree(t1); dfree(t2); dfree(tad); dfree(tbd); dfree(tcd); dfree(spec);
@@ -488,7 +494,7 @@ template <typename T> struct Ctx : CtxBase {
         if (use_rowd) {
             if (int rc = dalloc(&cspec_perm, (size_t)N)) return rc;
             const int Rr = row->R[row->S - 1], R0 = row->S == 3 ? row->R[0] : 1;
-            hipLaunchKernelGGL((k_cspec_perm<T>), dim3(N1), dim3(256), 0, stream, cspec, cspec_perm, N1, N2, R0, Rr);
+            TWX_LAUNCH((k_cspec_perm<T>), dim3(N1), dim3(256), stream, cspec, cspec_perm, N1, N2, R0, Rr);
             HIPCHK(hipGetLastError());
         }
         // batch buffers, one set per pipeline slot
@@ -561,7 +567,7 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipMemcpy(jd, jump.data(), jump.size() * sizeof(unsigned), hipMemcpyHostToDevice));
         const long long seg = 256;
         const long long nthreads = (n + seg - 1) / seg;
-        hipLaunchKernelGGL(k_lfsr, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, bitlen, taps, n, seg, jd, out);
+        TWX_LAUNCH(k_lfsr, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), stream, bitlen, taps, n, seg, jd, out);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
         dfree(jd);
@@ -577,7 +583,7 @@ template <typename T> struct Ctx : CtxBase {
             ProfScope ps(this, PC_SUMS, (long long)nb * N);
             // few, fat chunks: the three 64-bit atomics per workgroup land on the same words of a window
             const int chunks = (int)std::min<long long>(64, std::max<long long>(1, N / 16384));
-            hipLaunchKernelGGL((k_sums<0>), dim3(chunks, nb), dim3(256), 0, stream, in, wstride, nch, N, sums);
+            TWX_LAUNCH((k_sums<0>), dim3(chunks, nb), dim3(256), stream, in, wstride, nch, N, sums);
             HIPCHK(hipGetLastError());
         }
         ColFwdArgs<T> ca{};
@@ -607,16 +613,16 @@ template <typename T> struct Ctx : CtxBase {
         }
         {
             ProfScope ps(this, PC_DFT, nb);
-            hipLaunchKernelGGL((k_df_tables<T>), dim3(nb), dim3(256), 0, stream, band ? 1 : 0, part_band, N1, dfv, dfidx, cfg.fs,
+            TWX_LAUNCH((k_df_tables<T>), dim3(nb), dim3(256), stream, band ? 1 : 0, part_band, N1, dfv, dfidx, cfg.fs,
                                (long long)N, N1, N2, e1, e2);
             HIPCHK(hipGetLastError());
         }
         if (cfg.flags & TWX_FLAG_FINE_FREQ) {
-            hipLaunchKernelGGL((k_fine_angle<0>), dim3(64, nb), dim3(256), 0, stream, in, wstride, nch, (long long)N, sums, dfv, cfg.fs, fine_M, fine_u);
+            TWX_LAUNCH((k_fine_angle<0>), dim3(64, nb), dim3(256), stream, in, wstride, nch, (long long)N, sums, dfv, cfg.fs, fine_M, fine_u);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL((k_fine_fit<0>), dim3(nb), dim3(1024), 0, stream, fine_u, fine_M, cfg.fs, dfv);
+            TWX_LAUNCH((k_fine_fit<0>), dim3(nb), dim3(1024), stream, fine_u, fine_M, cfg.fs, dfv);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL((k_df_tables<T>), dim3(nb), dim3(256), 0, stream, 2, part_band, N1, dfv, dfidx, cfg.fs,
+            TWX_LAUNCH((k_df_tables<T>), dim3(nb), dim3(256), stream, 2, part_band, N1, dfv, dfidx, cfg.fs,
                                (long long)N, N1, N2, e1, e2);       // rebuild the NCO tables for df + dfleftover
             HIPCHK(hipGetLastError());
         }
@@ -650,7 +656,7 @@ template <typename T> struct Ctx : CtxBase {
         pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.convention = cfg.convention; pa.res = out_dev;
         {
             ProfScope ps(this, PC_PEAK, nb);
-            hipLaunchKernelGGL((k_peak<T>), dim3(nb), dim3(1024), 0, stream, pa);
+            TWX_LAUNCH((k_peak<T>), dim3(nb), dim3(1024), stream, pa);
             HIPCHK(hipGetLastError());
         }
         return TWX_OK;
@@ -744,7 +750,7 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipMemcpyAsync(bd, hb, sizeof(long long) * nb, hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemsetAsync(acc, 0, sizeof(double) * 2 * nb, stream));
         const unsigned grid = (unsigned)std::min<long long>(2048, (L + 255) / 256);
-        hipLaunchKernelGGL((k_sq_dft_bins<0>), dim3(grid), dim3(256), 0, stream, reinterpret_cast<const short2*>(iq_dev) + ch, nch, L, bd, nb, acc);
+        TWX_LAUNCH((k_sq_dft_bins<0>), dim3(grid), dim3(256), stream, reinterpret_cast<const short2*>(iq_dev) + ch, nch, L, bd, nb, acc);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(out, acc, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -774,7 +780,7 @@ template <typename T> struct Ctx : CtxBase {
             ra.n = N; ra.n1 = N1; ra.nwin = nb; ra.A = A; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.spec_out = spec + r0 * N;
             if (row->run(ROW_STORE, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(store) launch failed");
         }
-        hipLaunchKernelGGL((k_sqspec_combine<T>), dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, stream, spec, (int)M, (long long)N, N1, N2, k_lo, nk, mag);
+        TWX_LAUNCH((k_sqspec_combine<T>), dim3((unsigned)((nk + 255) / 256)), dim3(256), stream, spec, (int)M, (long long)N, N1, N2, k_lo, nk, mag);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(out, mag, sizeof(double) * nk, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -872,7 +878,7 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipMemcpy(din, iq, (size_t)N * nch * 4, hipMemcpyHostToDevice));
         const short2* in = din + ch;
         HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums), stream));
-        hipLaunchKernelGGL((k_sums<0>), dim3((unsigned)std::min<long long>(64, std::max<long long>(1, N / 16384)), 1), dim3(256), 0, stream, in, 0ll, nch, N, sums);
+        TWX_LAUNCH((k_sums<0>), dim3((unsigned)std::min<long long>(64, std::max<long long>(1, N / 16384)), 1), dim3(256), stream, in, 0ll, nch, N, sums);
         HIPCHK(hipGetLastError());
         ColFwdArgs<T> ca{};
         ca.in_win_stride = 0; ca.sums = sums; ca.remove_mean = 1; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = 1;
@@ -890,7 +896,7 @@ template <typename T> struct Ctx : CtxBase {
             ColInvArgs<T> ia{};
             ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = 1; ia.nwin = nb; ia.Bz = Bz; ia.tw1 = tw1; ia.part = part_peak; ia.zout = nullptr;
             if (col->inv(&ia, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_inv launch failed");
-            hipLaunchKernelGGL((k_caf_reduce<T>), dim3(nb), dim3(256), 0, stream, part_peak, ntiles, 1.0 / scale_pow2 / (double)N, pk_d, lag_d);
+            TWX_LAUNCH((k_caf_reduce<T>), dim3(nb), dim3(256), stream, part_peak, ntiles, 1.0 / scale_pow2 / (double)N, pk_d, lag_d);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(pk + (k0 - k_lo), pk_d, sizeof(double) * nb, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipMemcpyAsync(lag + (k0 - k_lo), lag_d, sizeof(long long) * nb, hipMemcpyDeviceToHost, stream));

@@ -14,7 +14,7 @@ static_assert(P::max_tasks * W <= NT, "one task per thread per stage");
 
 template <typename T, int MODE, class In>
 int launch_fwd(In in, const ColFwdArgs<T>& a, unsigned nblk, hipStream_t s) {
-    hipLaunchKernelGGL((k_col_fwd<P, T, W, MODE, In, NT>), dim3(nblk), dim3(NT), 0, s, in, a);
+    TWX_LAUNCH((k_col_fwd<P, T, W, MODE, In, NT>), dim3(nblk), dim3(NT), s, in, a);
     return (int)hipGetLastError();
 }
 
@@ -36,7 +36,7 @@ template <typename T> int fwd(int mode, int intype, const void* inptr, int aux, 
 }
 template <typename T> int inv(const void* args, unsigned nblk, hipStream_t s) {
     const ColInvArgs<T>& a = *reinterpret_cast<const ColInvArgs<T>*>(args);
-    hipLaunchKernelGGL((k_col_inv<PR, T, W, NT>), dim3(nblk), dim3(NT), 0, s, a);
+    TWX_LAUNCH((k_col_inv<PR, T, W, NT>), dim3(nblk), dim3(NT), s, a);
     return (int)hipGetLastError();
 }
 

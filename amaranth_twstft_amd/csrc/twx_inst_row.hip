@@ -13,28 +13,28 @@ static_assert(P::max_tasks <= NT, "one task per thread per stage");
 
 template <typename T> int run(int mode, const void* args, unsigned nblk, hipStream_t s) {
     const RowArgs<T>& a = *reinterpret_cast<const RowArgs<T>*>(args);
-    if (mode == ROW_STORE) hipLaunchKernelGGL((k_row<P, T, ROW_STORE, PADQ, NT>), dim3(nblk), dim3(NT), 0, s, a);
-    else if (mode == ROW_BAND) hipLaunchKernelGGL((k_row<P, T, ROW_BAND, PADQ, NT>), dim3(nblk), dim3(NT), 0, s, a);
-    else if (mode == ROW_MID) hipLaunchKernelGGL((k_row<P, T, ROW_MID, PADQ, NT>), dim3(nblk), dim3(NT), 0, s, a);
+    if (mode == ROW_STORE) TWX_LAUNCH((k_row<P, T, ROW_STORE, PADQ, NT>), dim3(nblk), dim3(NT), s, a);
+    else if (mode == ROW_BAND) TWX_LAUNCH((k_row<P, T, ROW_BAND, PADQ, NT>), dim3(nblk), dim3(NT), s, a);
+    else if (mode == ROW_MID) TWX_LAUNCH((k_row<P, T, ROW_MID, PADQ, NT>), dim3(nblk), dim3(NT), s, a);
     else return -1;
     return (int)hipGetLastError();
 }
 
 template <typename T> int caf(const void* args, unsigned nblk, hipStream_t s) {
     const CafArgs<T>& a = *reinterpret_cast<const CafArgs<T>*>(args);
-    hipLaunchKernelGGL((k_row_caf<P, T, PADQ, NT>), dim3(nblk), dim3(NT), 0, s, a);
+    TWX_LAUNCH((k_row_caf<P, T, PADQ, NT>), dim3(nblk), dim3(NT), s, a);
     return (int)hipGetLastError();
 }
 
 template <typename T> int mid_p(const void* args, unsigned int* queue, unsigned total_rows, unsigned nblk, hipStream_t s) {
     const RowArgs<T>& a = *reinterpret_cast<const RowArgs<T>*>(args);
-    hipLaunchKernelGGL((k_row_mid_p<P, T, PADQ, NT>), dim3(nblk), dim3(NT), 0, s, a, queue, total_rows);
+    TWX_LAUNCH((k_row_mid_p<P, T, PADQ, NT>), dim3(nblk), dim3(NT), s, a, queue, total_rows);
     return (int)hipGetLastError();
 }
 
 template <typename T> int mid_s(const void* args, unsigned nblk, hipStream_t s) {
     const RowArgs<T>& a = *reinterpret_cast<const RowArgs<T>*>(args);
-    hipLaunchKernelGGL((k_row_mid_s<P, T, PADQ, NT>), dim3(nblk), dim3(NT), 0, s, a);
+    TWX_LAUNCH((k_row_mid_s<P, T, PADQ, NT>), dim3(nblk), dim3(NT), s, a);
     return (int)hipGetLastError();
 }
 
@@ -46,8 +46,8 @@ template <typename T> int rowd(int mode, const void* args, unsigned nblk, hipStr
     if constexpr (HasRowD<P>::value) {
         constexpr int NTD = RowD<P, T>::NT_MIN;
         const RowDArgs<T>& a = *reinterpret_cast<const RowDArgs<T>*>(args);
-        if (mode == ROW_BAND) hipLaunchKernelGGL((k_rowd<P, T, ROW_BAND, NTD>), dim3(nblk), dim3(NTD), 0, s, a);
-        else if (mode == ROW_MID) hipLaunchKernelGGL((k_rowd<P, T, ROW_MID, NTD>), dim3(nblk), dim3(NTD), 0, s, a);
+        if (mode == ROW_BAND) TWX_LAUNCH((k_rowd<P, T, ROW_BAND, NTD>), dim3(nblk), dim3(NTD), s, a);
+        else if (mode == ROW_MID) TWX_LAUNCH((k_rowd<P, T, ROW_MID, NTD>), dim3(nblk), dim3(NTD), s, a);
         else return -1;
         return (int)hipGetLastError();
     } else {

@@ -3,8 +3,23 @@
 // registers type-erased launchers here; twx_api.hip picks N = N1*N2 from what is registered.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 namespace twx {
+
+// Per-kernel timing: while a profiling scope is open on this thread the next launch carries the scope's two
+// events, which then hold the dispatch's own begin/end timestamps (the durations rocprofv3 reports), instead
+// of bracketing the launch with two extra barrier packets.
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
+LaunchEvents& launch_events();          // thread-local, defined in twx_api.hip
+#define TWX_LAUNCH(kernel, grid, block, stream, ...)                                                              \
+    do {                                                                                                          \
+        ::twx::LaunchEvents& le_ = ::twx::launch_events();                                                        \
+        if (le_.start) {                                                                                          \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, le_.start, le_.stop, 0, __VA_ARGS__);           \
+            le_.start = le_.stop = nullptr;                                                                       \
+        } else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                   \
+    } while (0)
 
 enum { IN_I16 = 0, IN_CHIPS = 1, IN_C32 = 2, IN_C64 = 3 };
 
