@@ -90,3 +90,23 @@ def test_shard_windows_partition():
             sizes = [e - s for s, e in spans]
             assert max(sizes) - min(sizes) <= 1 and max(sizes) == D.max_shard(n, world) or n == 0
     assert D.shard_windows(600, 3, 8) == (225, 300)
+
+
+def test_header_is_plain_c_and_client_links(tmp_path):
+    """include/twstft_hip.h compiles as C99 and a C client links against the shared library (no C++/torch types)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "amaranth_twstft_amd")
+    exe = tmp_path / "abi_smoke"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cpu", "abi_smoke.c"), "-L" + libdir, "-ltwstft_hip",
+                    "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
+    assert exe.exists()
+
+
+def test_mex_gateway_type_checks():
+    """mex/twstft_processing_mex.cpp against a declarations-only mex.h (no MATLAB/Octave in the image)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(root, "tests", "cpu", "mex_stub"),
+                    "-I" + os.path.join(root, "include"), os.path.join(root, "mex", "twstft_processing_mex.cpp")], check=True)

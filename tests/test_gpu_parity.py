@@ -6,6 +6,7 @@ per assertion.
 """
 import ctypes as C
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -618,3 +619,16 @@ def test_tracked_loop_reference_sizes():
     assert got["moved"] == want["moved"] and got["indice1"] == want["indice1"] and len(want["indice1"]) >= 98
     gx, wx = np.abs(np.array(got["xval"])), np.abs(np.array(want["xval"]))
     assert np.abs(gx - wx).max() <= MAG_TOL * wx.max()
+
+
+def test_plain_c_client_of_the_abi(tmp_path):
+    """A C99 program (no Python, no torch) drives the library end to end: tests/cpu/abi_smoke.c."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "amaranth_twstft_amd")
+    exe = tmp_path / "abi_smoke"
+    subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpu", "abi_smoke.c"),
+                    "-L" + libdir, "-ltwstft_hip", "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe), "10000", "14", "43", "4321"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "indice0=12963" in out.stdout
