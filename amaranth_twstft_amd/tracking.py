@@ -46,3 +46,76 @@ def hrc_delay(cor: np.ndarray, nlag: int):
             wide = (c[k - 2] - c[k + 2]) / (c[k - 2] - 2.0 * c[k] + c[k + 2])
             out[p] = narrow - wide + (k - nlag)
     return pk - nlag, out
+
+
+def _wlinear(x, w, y):
+    """``gsl_fit_wlinear``: weighted least squares y = c0 + c1·x; returns (c0, c1, chisq)."""
+    x, w, y = (np.asarray(v, dtype=float) for v in (x, w, y))
+    W = w.sum()
+    xm, ym = (w * x).sum() / W, (w * y).sum() / W
+    dx, dy = x - xm, y - ym
+    c1 = (w * dx * dy).sum() / (w * dx * dx).sum()
+    c0 = ym - c1 * xm
+    return c0, c1, float((w * (y - c0 - c1 * x) ** 2).sum())
+
+
+def tracking_update(cor: np.ndarray, phi: np.ndarray, nlag: int, state: dict) -> dict | None:
+    """One tracking epoch of experiments/231001_DLL_PLL/rxcomplex.cpp:620-745 on the ``bps-1`` code periods
+    whose power/phase matrices ``cor``/``phi`` ([bps-1, 2·nlag+1]) came from :func:`sliding_dot` +
+    :func:`get_cor_and_phi`: per-code peak and high-resolution-correlator delay (:630-661), 3-sigma filter on
+    median/IQR (:689-716), BPSK half-cycle phase unwrap against ``last_phi`` (:710-715), weighted linear fits of
+    phase → carrier update and of delay → code-phase update (:728-745).
+
+    ``state`` holds ``fc pt last_phi fs duration psbb`` (the ``ci[i]`` fields) and is updated in place; the
+    returned dict has the printed quantities (``freq phi cnt gd dg sdgd pk``).  ``None`` when fewer than half of
+    the periods produced a usable peak (:667), in which case ``state`` is left alone.  UNPINNED (GSL/CBLAS
+    program, cannot be built here).
+    """
+    bps = cor.shape[0] + 1
+    fs, duration, pt = state["fs"], state["duration"], state["pt"]
+    psbb = state.get("psbb", 1.0)
+    res_gd, res_phi, ps, w = (np.zeros(bps) for _ in range(4))
+    ttag_phi = np.zeros(bps)
+    nl = 2 * nlag + 1
+    for p in range(bps - 1):
+        k = int(np.argmax(cor[p]))                                    # cblas_idamax on non-negative powers (:630)
+        ttag_phi[p] = p * duration + pt / fs
+        ps[p] = cor[p, k] / psbb
+        if k - 2 >= 0 and k + 2 < nl:
+            c = cor[p]
+            res_phi[p] = phi[p, k]
+            res_gd[p] = ((c[k - 1] - c[k + 1]) / (c[k - 1] - 2.0 * c[k] + c[k + 1])
+                         - (c[k - 2] - c[k + 2]) / (c[k - 2] - 2.0 * c[k] + c[k + 2])
+                         + float(pt + k - nlag)) * 1.0e9 / fs
+            w[p] = 1.0
+    cnt = int(w.sum())
+    if cnt * 2 <= bps:
+        return None
+    sel = np.sort(res_gd[w > 0])                                      # kth_smallest ≡ order statistics
+    ii = sel.size
+    c0 = sel[ii // 2]
+    stddev = (sel[ii * 3 // 4] - sel[ii // 4]) / 1.349
+    last_phi = state["last_phi"]
+    cnt = 0
+    for p in range(bps - 1):
+        if w[p] != 0.0:
+            if abs(res_gd[p] - c0) < 3.0 * stddev:
+                cnt += 1
+                while abs(res_phi[p] - last_phi) > 0.25:
+                    res_phi[p] += -0.5 if res_phi[p] > last_phi else 0.5
+                last_phi = res_phi[p]
+            else:
+                w[p] = 0.0
+    state["last_phi"] = last_phi
+    c0, c1, _ = _wlinear(ttag_phi, w, res_phi)
+    state["fc_prev"] = state["fc"]
+    state["fc"] += round(c1)
+    state["df"] = c1 - round(c1)
+    state["phi"] = float(np.fmod(c0 + 1000.0, 1.0))
+    ttag_gd = np.arange(bps) * duration
+    g0, g1, chi = _wlinear(ttag_gd, w, res_gd)
+    out = dict(freq=state["fc"] + state["df"], phi=state["phi"], cnt=cnt, gd=g0 + 0.5 * g1, dg=g1,
+               sdgd=float(np.sqrt(chi / cnt)), pk=float(ps[w > 0].mean()) if cnt else 0.0)
+    state["pt_prev"] = pt
+    state["pt"] = int(round((g0 + g1) * fs / 1.0e9))
+    return out

@@ -1,0 +1,51 @@
+"""CPU: host arithmetic of the tracking epoch (experiments/231001_DLL_PLL/rxcomplex.cpp:620-745), known answers."""
+import numpy as np
+
+from amaranth_twstft_amd import tracking
+
+
+def _matrices(bps, nlag, true_lag, f_res, phi0, duration, pt, fs, outlier=None):
+    """Triangular correlation peak at fractional lag `true_lag`; phase ramps with the residual carrier f_res."""
+    lags = np.arange(-nlag, nlag + 1)
+    cor = np.zeros((bps - 1, 2 * nlag + 1))
+    phi = np.zeros_like(cor)
+    for p in range(bps - 1):
+        tl = true_lag + 0.01 * np.sin(1.7 * p) + (outlier[1] if outlier and p == outlier[0] else 0.0)   # jitter: IQR > 0
+        amp = np.clip(1.0 - np.abs(lags - tl) / 2.0, 0.0, None)          # 2-sample-wide triangle (1 chip at 2 sps)
+        cor[p] = amp ** 2
+        ph = phi0 + f_res * (p * duration + pt / fs)
+        ph += 0.5 * (p % 2)                                              # BPSK data flips: half-cycle jumps
+        phi[p] = (ph + 0.5) % 1.0 - 0.5
+    return cor, phi
+
+
+def test_weighted_linear_fit_matches_polyfit():
+    rng = np.random.default_rng(0)
+    x = np.arange(20.0); y = 3.0 - 0.25 * x + rng.normal(0, 0.01, 20); w = np.ones(20); w[5] = 0
+    c0, c1, chi = tracking._wlinear(x, w, y)
+    ref = np.polyfit(np.delete(x, 5), np.delete(y, 5), 1)
+    assert abs(c1 - ref[0]) < 1e-12 and abs(c0 - ref[1]) < 1e-12 and chi > 0
+
+
+def test_tracking_epoch_recovers_carrier_and_code_phase():
+    fs, nobs, bps, nlag = 5e6, 20000, 25, 28
+    duration = nobs / fs
+    pt = 1000
+    st = dict(fc=1000.0, pt=pt, last_phi=0.1, fs=fs, duration=duration, psbb=1.0)
+    cor, phi = _matrices(bps, nlag, true_lag=3.3, f_res=7.4, phi0=0.12, duration=duration, pt=pt, fs=fs, outlier=(9, 6.0))
+    out = tracking.tracking_update(cor, phi, nlag, st)
+    assert out is not None and out["cnt"] == bps - 2                     # the 6-sample outlier is rejected
+    assert abs(out["freq"] - 1007.4) < 1e-6                              # fc + round(c1) + fractional part
+    assert st["fc"] == 1007.0 and abs(st["df"] - 0.4) < 1e-6
+    assert abs(out["dg"]) < 20.0 and out["sdgd"] < 5.0                    # constant delay up to the 2-ns jitter
+    hrc = out["gd"] * fs / 1e9 - pt                                      # HRC estimate in samples relative to pt
+    assert abs(hrc - 3.3) < 0.5                                          # the HRC discriminator is biased on a triangle; sign and size right
+    assert st["pt"] == int(round((out["gd"]) * fs / 1e9))
+
+
+def test_tracking_epoch_needs_half_of_the_periods():
+    fs, nobs, bps, nlag = 5e6, 20000, 25, 28
+    cor = np.zeros((bps - 1, 2 * nlag + 1)); phi = np.zeros_like(cor)
+    cor[:, 0] = 1.0                                                      # peak at the window edge everywhere → unusable
+    st = dict(fc=0.0, pt=0, last_phi=0.0, fs=fs, duration=nobs / fs)
+    assert tracking.tracking_update(cor, phi, nlag, st) is None and st["fc"] == 0.0
