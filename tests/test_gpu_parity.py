@@ -62,7 +62,7 @@ def test_fft_and_code_spectrum(bitlen, taps, nchips):
 
 
 @pytest.mark.parametrize("bitlen,taps,nchips,nwin", [(13, 27, 5000, 5), (14, 57, 10000, 4), (15, 17, 25000, 3),
-                                                      (17, 15, 100000, 3), (19, 63, 500000, 1)])
+                                                      (17, 15, 100000, 3), (18, 63, 250000, 2), (19, 63, 500000, 1)])
 def test_processing_vs_oracle_two_channels(bitlen, taps, nchips, nwin):
     chips, raw = _capture(bitlen, taps, nchips, nwin, seed=nchips)
     n = 2 * nchips
