@@ -313,6 +313,7 @@ template <typename T> struct Ctx : CtxBase {
     unsigned long long* stamps_dev = nullptr;   // TWX_STAMPS diagnostic builds
     double* fine_u = nullptr; int fine_M = 0;   // TWX_FLAG_FINE_FREQ
     unsigned int* queue = nullptr;              // row queue of the persistent middle pass
+    int io_threads = 4;                         // TWX_IO_THREADS: concurrent preads per chunk in twx_process_file
     int persistent = 0; int ncu = 256;   // TWX_ROW_PERSISTENT: 0 = one WG per row (default), k>0 = persistent row queue with k WGs per CU, -1 = one WG per (row, phase)
     int ntiles = 0;
 
@@ -536,6 +537,8 @@ template <typename T> struct Ctx : CtxBase {
             if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
             const char* e = getenv("TWX_ROW_PERSISTENT");
             if (e) persistent = atoi(e);
+            const char* io = getenv("TWX_IO_THREADS");
+            if (io) io_threads = std::max(1, std::min(32, atoi(io)));
         }
 #ifdef TWX_STAMPS
         if (int rc = dalloc(&stamps_dev, (size_t)B * N1 * 8 * 32)) return rc;
@@ -827,11 +830,33 @@ template <typename T> struct Ctx : CtxBase {
             const long long first = chunk * B;
             const long long want = std::max<long long>(0, std::min<long long>(B, max_windows - first));
             return std::async(std::launch::async, [=]() -> long long {
-                size_t total = 0; const size_t need = win_bytes * (size_t)want;
-                while (total < need) {
-                    const ssize_t r = pread(fd, (char*)st[k].host + total, need - total, base_off + (off_t)first * (off_t)win_bytes + (off_t)total);
-                    if (r <= 0) break;
-                    total += (size_t)r;
+                // one chunk = io_threads contiguous pieces read concurrently (a single pread out of the page cache is a
+                // ~5 GB/s memcpy; PCIe takes ten times that)
+                const size_t need = win_bytes * (size_t)want;
+                const off_t off0 = base_off + (off_t)first * (off_t)win_bytes;
+                char* dst = (char*)st[k].host;
+                auto read_piece = [=](size_t lo, size_t hi) -> size_t {
+                    size_t done = lo;
+                    while (done < hi) {
+                        const ssize_t r = pread(fd, dst + done, hi - done, off0 + (off_t)done);
+                        if (r <= 0) break;
+                        done += (size_t)r;
+                    }
+                    return done - lo;
+                };
+                const int P = (int)std::max<size_t>(1, std::min<size_t>((size_t)io_threads, need >> 22));
+                const size_t piece = ((need + P - 1) / P + 4095) & ~(size_t)4095;
+                std::vector<std::future<size_t>> parts;
+                for (int i = 1; i < P; ++i) {
+                    const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));
+                    parts.push_back(std::async(std::launch::async, read_piece, lo, hi));
+                }
+                size_t total = read_piece(0, std::min(need, piece));
+                bool contiguous = total == std::min(need, piece);
+                for (int i = 1; i < P; ++i) {
+                    const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));
+                    const size_t got = parts[i - 1].get();
+                    if (contiguous) { total += got; contiguous = got == hi - lo; }
                 }
                 return (long long)(total / win_bytes);              // whole windows only
             });
