@@ -295,7 +295,7 @@ template <typename T> struct Ctx : CtxBase {
     // compute-heavy middle pass of one batch can share CUs with the memory-heavy column passes of the other.
     struct Slot {
         hipStream_t stream; WinSums* sums; double* dfv; long long* dfidx; C *e1, *e2, *A, *Bz, *dc;
-        ArgPart<T>*part_band, *part_peak; twx_result* res_dev; unsigned int* queue; double* fine_u;
+        ArgPart<T>*part_band, *part_peak; twx_result* res_dev; double* fine_u;
     };
     Slot slots[4] = {}; int nslots = 1;
     struct Stage { void* host; short2* dev; size_t bytes; long long w0; int nb; };
@@ -303,7 +303,7 @@ template <typename T> struct Ctx : CtxBase {
     void use_slot(int k) {
         const Slot& q = slots[k];
         stream = q.stream; sums = q.sums; dfv = q.dfv; dfidx = q.dfidx; e1 = q.e1; e2 = q.e2; A = q.A; Bz = q.Bz; dc = q.dc;
-        part_band = q.part_band; part_peak = q.part_peak; res_dev = q.res_dev; queue = q.queue; fine_u = q.fine_u;
+        part_band = q.part_band; part_peak = q.part_peak; res_dev = q.res_dev; fine_u = q.fine_u;
     }
     int pipeline_depth() const override { return nslots; }
     int sync_all() override {
@@ -312,9 +312,8 @@ template <typename T> struct Ctx : CtxBase {
     }
     unsigned long long* stamps_dev = nullptr;   // TWX_STAMPS diagnostic builds
     double* fine_u = nullptr; int fine_M = 0;   // TWX_FLAG_FINE_FREQ
-    unsigned int* queue = nullptr;              // row queue of the persistent middle pass
     int io_threads = 4;                         // TWX_IO_THREADS: concurrent preads per chunk in twx_process_file
-    int persistent = 0; int ncu = 256;   // TWX_ROW_PERSISTENT: 0 = one WG per row (default), k>0 = persistent row queue with k WGs per CU, -1 = one WG per (row, phase)
+    int ncu = 256;
     int ntiles = 0;
 
     template <typename U> int upload(U** dst, const std::vector<U>& src) {
@@ -528,15 +527,12 @@ template <typename T> struct Ctx : CtxBase {
             if (int rc = dalloc(&q.part_band, (size_t)B * N1)) return rc;
             if (int rc = dalloc(&q.part_peak, (size_t)B * R * ntiles)) return rc;
             if (int rc = dalloc(&q.res_dev, (size_t)B)) return rc;
-            if (int rc = dalloc(&q.queue, 4)) return rc;
             if (fine_M) { if (int rc = dalloc(&q.fine_u, (size_t)B * fine_M)) return rc; }
         }
         use_slot(0);
         {
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-            const char* e = getenv("TWX_ROW_PERSISTENT");
-            if (e) persistent = atoi(e);
             const char* io = getenv("TWX_IO_THREADS");
             if (io) io_threads = std::max(1, std::min(32, atoi(io)));
         }
@@ -638,16 +634,9 @@ template <typename T> struct Ctx : CtxBase {
         }
         {
             ProfScope ps(this, PC_ROW_MID, (long long)nb * N);
-            if (use_rowd && persistent == 0) {
+            if (use_rowd) {
                 RowDArgs<T> rd{}; rd.r = ra; rd.dtabs = dtabs; rd.cspec_perm = cspec_perm; rd.ea_d = ea_d; rd.eb_d = eb_d;
                 if (row->rowd(ROW_MID, &rd, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_rowd(mid) launch failed");
-            } else if (persistent < 0) {
-                if (row->mid_s(&ra, (unsigned)(N1 * nb * R), stream)) return fail(TWX_E_HIP, "k_row_mid_s launch failed");
-            } else if (persistent) {
-                HIPCHK(hipMemsetAsync(queue, 0, 4, stream));
-                const unsigned total = (unsigned)(N1 * nb);
-                const unsigned grid = std::min<unsigned>(total, (unsigned)(ncu * persistent));
-                if (row->mid_p(&ra, queue, total, grid, stream)) return fail(TWX_E_HIP, "k_row_mid_p launch failed");
             } else if (row->run(ROW_MID, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(mid) launch failed");
         }
         ColInvArgs<T> ia{};

@@ -400,16 +400,6 @@ template <class P, typename T, bool INV, int PADQ> struct RowTile : Tile<P, T, I
             tw[r - 1] = w;
         }
     }
-    template <int s> static TWX_HD void load_lds_pre(const C* lds, const C* tw, int j, C* v) {
-        constexpr int Rr = P::radix(s);
-        const int ib = Base::template in_base<s>(j);
-        v[0] = lds[Base::template in_idx<s>(ib, j, 0)];
-        TWX_UNROLL
-        for (int r = 1; r < Rr; ++r) {
-            const C u = lds[Base::template in_idx<s>(ib, j, r)];
-            v[r] = INV ? cmulc(u, tw[r - 1]) : cmul(u, tw[r - 1]);
-        }
-    }
 };
 
 // ------------------------------------------------------------------------------------------

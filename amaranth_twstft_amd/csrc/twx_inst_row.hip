@@ -26,17 +26,6 @@ template <typename T> int caf(const void* args, unsigned nblk, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <typename T> int mid_p(const void* args, unsigned int* queue, unsigned total_rows, unsigned nblk, hipStream_t s) {
-    const RowArgs<T>& a = *reinterpret_cast<const RowArgs<T>*>(args);
-    TWX_LAUNCH((k_row_mid_p<P, T, PADQ, NT>), dim3(nblk), dim3(NT), s, a, queue, total_rows);
-    return (int)hipGetLastError();
-}
-
-template <typename T> int mid_s(const void* args, unsigned nblk, hipStream_t s) {
-    const RowArgs<T>& a = *reinterpret_cast<const RowArgs<T>*>(args);
-    TWX_LAUNCH((k_row_mid_s<P, T, PADQ, NT>), dim3(nblk), dim3(NT), s, a);
-    return (int)hipGetLastError();
-}
 
 template <class PP> struct HasRowD {
     static constexpr bool value = (PP::S == 2 && PP::radix(0) == PP::radix(1) && 64 / PP::radix(1) >= 1) ||
@@ -57,9 +46,9 @@ template <typename T> int rowd(int mode, const void* args, unsigned nblk, hipStr
 
 struct Reg {
     Reg() {
-        register_row(RowOps{P::L, NT, 0, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<float>, &caf<float>, HasRowD<P>::value ? &rowd<float> : nullptr, &mid_s<float>, &mid_p<float>});
+        register_row(RowOps{P::L, NT, 0, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<float>, &caf<float>, HasRowD<P>::value ? &rowd<float> : nullptr});
 #ifndef TWX_NO_F64
-        register_row(RowOps{P::L, NT, 1, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<double>, &caf<double>, HasRowD<P>::value ? &rowd<double> : nullptr, &mid_s<double>, &mid_p<double>});
+        register_row(RowOps{P::L, NT, 1, P::S, {P::radix(0), P::radix(1), P::radix(2), P::radix(3)}, &run<double>, &caf<double>, HasRowD<P>::value ? &rowd<double> : nullptr});
 #endif
     }
 } reg_instance;

@@ -24,11 +24,6 @@
 
 // build-time switches (defaults = product build; the non-zero ablation values are timing-only
 // diagnostic builds whose results are wrong)
-#ifndef TWX_PRIO
-#define TWX_PRIO 0      // experiment: 1 = raise wave priority in the memory-issue sections of k_rowd<MID>, 2 = in the arithmetic sections
-#endif
-#define TWX_PRIO_MEM() do { if (TWX_PRIO == 1) __builtin_amdgcn_s_setprio(3); else if (TWX_PRIO == 2) __builtin_amdgcn_s_setprio(0); } while (0)
-#define TWX_PRIO_ALU() do { if (TWX_PRIO == 1) __builtin_amdgcn_s_setprio(0); else if (TWX_PRIO == 2) __builtin_amdgcn_s_setprio(3); } while (0)
 #ifndef TWX_ABL
 #define TWX_ABL 0       // k_row<MID>: 1 no Bz stores, 2 no code-spectrum load, 3 one phase only, 4 no A load, 5 no inverse transforms
 #endif
@@ -37,9 +32,6 @@
 #endif
 #ifndef TWX_ABLF
 #define TWX_ABLF 0      // k_col_fwd: 1 no transform, 2 no loads, 3 no stores
-#endif
-#ifndef TWX_KEEP_TW
-#define TWX_KEEP_TW 0   // keep the last-stage row twiddles in registers across the transforms of a row
 #endif
 
 namespace twx {
@@ -553,15 +545,7 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
     TWX_STAMP(3);
     // ---- forward last stage: v[q] = X[k1 + N1*k2], k2 = tid + q*NSL
     const bool act = tid < NSL;
-    // last-stage twiddles W_N2^{j r} are the same for the forward and (conjugated) the R inverse
-    // transforms of a palindromic plan: combine them once per row and keep them in registers
-    constexpr bool KEEP_TW = (MODE == ROW_MID) && PAL && (TWX_KEEP_TW != 0);
-    C twl[KEEP_TW ? RL - 1 : 1];
-    if constexpr (KEEP_TW) {
-        if (act) { TF::template stage_twiddles<S - 1>(tab_f, tid, twl); TF::template load_lds_pre<S - 1>(lds, twl, tid, v); TF::template bfly<S - 1>(v); }
-    } else {
-        if (act) { TF::template load_lds_tab<S - 1>(lds, tab_f, tid, v); TF::template bfly<S - 1>(v); }
-    }
+    if (act) { TF::template load_lds_tab<S - 1>(lds, tab_f, tid, v); TF::template bfly<S - 1>(v); }
 
     if constexpr (MODE == ROW_STORE) {
         if (act) {
@@ -653,8 +637,7 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
             MidStages<TI, PR, T, 1>::run(lds, tab_i, v, lt);
             TWX_STAMP(8 + rho * 6);
             if (lt < NSI) {
-                if constexpr (KEEP_TW) TI::template load_lds_pre<S - 1>(lds, twl, lt, v);
-                else TI::template load_lds_tab<S - 1>(lds, tab_i, lt, v);
+                TI::template load_lds_tab<S - 1>(lds, tab_i, lt, v);
                 TI::template bfly<S - 1>(v);
                 __builtin_amdgcn_sched_barrier(0);
                 TWX_STAMP(9 + rho * 6);
@@ -692,7 +675,7 @@ __device__ __forceinline__ void wave_sync_lds() {
 }
 
 template <class P2, typename T, int MODE, int NT>
-__global__ __launch_bounds__(NT, (MODE == ROW_MID ? 4 : 1)) void k_rowd(RowDArgs<T> ad) {
+__global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) void k_rowd(RowDArgs<T> ad) {
     using C = cpx<T>;
     using D = RowD<P2, T>;
     const RowArgs<T>& a = ad.r;
@@ -716,7 +699,6 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID ? 4 : 1)) void k_rowd(RowDArgs
     const C* row = a.A + (long long)b * a.n + (long long)k1 * N2;
     C v[RMAX];
     C csr[MODE == ROW_MID ? R : 1];
-    if constexpr (MODE == ROW_MID) TWX_PRIO_MEM();
     if constexpr (MODE == ROW_MID) {
         if (act) {
             const C* cs = ad.cspec_perm + (long long)k1 * N2;
@@ -737,7 +719,6 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID ? 4 : 1)) void k_rowd(RowDArgs
         }
     }
     __syncthreads();                                   // tables visible (the row loads are in flight meanwhile)
-    if constexpr (MODE == ROW_MID) TWX_PRIO_ALU();
     if (tid < M) {
         Bfly<T, R0, false>::run(v);
         D::f0_twiddle_store(lds, tabs, tid, v);
@@ -797,13 +778,11 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID ? 4 : 1)) void k_rowd(RowDArgs
             if (lact) D::iB(lds, tabs, lq0, lqi, v);
             __syncthreads();
             if (lt < M) {
-                TWX_PRIO_MEM();
                 D::iC(lds, lt, v);
                 const C uu = cmul(ub, r1);
                 C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
                 TWX_UNROLL
                 for (int c = 0; c < R0; ++c) (out + c * M)[(unsigned)lt] = cmul(cmul(v[c], uu), s_vc[c]);   // · W_N^{-k1 q2} · ramp1
-                TWX_PRIO_ALU();
             }
             if (rho + 1 < a.nphase && lact) {
                 const int rn = rho + 1;
@@ -828,219 +807,6 @@ __global__ void k_cspec_perm(const cpx<T>* __restrict__ nat, cpx<T>* __restrict_
     for (int i = threadIdx.x; i < n2; i += blockDim.x) {
         const int q2 = i / nu, uu = i % nu, q0 = uu / r, q1 = uu % r;
         perm[(long long)k1 * n2 + i] = nat[(long long)k1 * n2 + q0 + r0 * q1 + r0 * r * q2];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_row_mid_s: "split" form of k_row<MID>: one workgroup per (row, phase rho).  The forward row
-// transform is recomputed by each of the R workgroups of a row (they are adjacent in dispatch order,
-// so the A row and the code-spectrum row come from L2 for all but the first), in exchange the
-// product never has to persist in registers across R inverse transforms: ~half the VGPRs, two
-// workgroups per CU.  grid = N1 * nwin * R
-// ------------------------------------------------------------------------------------------
-template <class P2, typename T, int PADQ, int NT>
-__global__ __launch_bounds__(NT, 4) void k_row_mid_s(RowArgs<T> a) {
-    using C = cpx<T>;
-    using TF = RowTile<P2, T, false, PADQ>;
-    using PR = typename Rev<P2>::type;
-    using TI = RowTile<PR, T, true, PADQ>;
-    constexpr int S = P2::S, N2 = P2::L;
-    constexpr int R0 = P2::radix(0), NS0 = N2 / R0;
-    constexpr int RL = P2::radix(S - 1), NSL = N2 / RL;
-    constexpr int RIL = PR::radix(S - 1), NSI = N2 / RIL;
-    constexpr bool PAL = std::is_same<P2, PR>::value;
-    constexpr int NTF = StageTabs<P2>::total, NTI = PAL ? 0 : StageTabs<PR>::total;
-    constexpr int NEB = TWX_MAX_PHASE * 2 * RL;
-    __shared__ C lds[TF::lds_elems + NTF + NTI + NEB + RIL];
-    C* tab_f = lds + TF::lds_elems;
-    C* tab_i = PAL ? tab_f : tab_f + NTF;
-    C* s_eb = tab_f + NTF + NTI;
-    C* s_vc = s_eb + NEB;
-    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int rho = logical % a.nphase;
-    const int b = (logical / a.nphase) % a.nwin;
-    const int k1 = logical / (a.nphase * a.nwin);
-    const int tid = threadIdx.x;
-    const unsigned mask = (1u << a.tshift) - 1u;
-    const C* row = a.A + (long long)b * a.n + (long long)k1 * N2;
-    C v[P2::rmax()];
-    if (tid < NS0) {
-        TWX_UNROLL
-        for (int r = 0; r < R0; ++r) v[r] = (row + r * NS0)[(unsigned)tid];
-    }
-    for (int i = tid; i < NTF; i += NT) tab_f[i] = a.stab_f[i];
-    if constexpr (!PAL) for (int i = tid; i < NTI; i += NT) tab_i[i] = a.stab_i[i];
-    for (int i = tid; i < a.nphase * 2 * RL; i += NT) s_eb[i] = a.eb[i];
-    if (tid < RIL) {
-        const unsigned m = (unsigned)k1 * (unsigned)tid * (unsigned)NSI;
-        s_vc[tid] = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
-    }
-    if (tid < NS0) { TF::template bfly<0>(v); TF::template store_lds<0>(lds, tid, 0, v); }
-    __syncthreads();
-    MidStages<TF, P2, T, 1>::run(lds, tab_f, v, tid);
-    if (tid < NSL) {
-        TF::template load_lds_tab<S - 1>(lds, tab_f, tid, v);
-        TF::template bfly<S - 1>(v);
-        if (k1 == 0 && tid == 0 && rho == 0) a.dc[b] = v[0];
-        __builtin_amdgcn_sched_barrier(0);
-        const C* cs = a.cspec + (long long)k1 * N2;
-        const C eaj = a.ea[rho * NSL + tid];
-        TWX_UNROLL
-        for (int r = 0; r < RL; ++r) {
-            C p = cmul(v[r], (cs + r * NSL)[(unsigned)tid]);      // ffty.*fcode (godual_ranging.m:26)
-            if (rho != 0) {
-                C e;
-                if constexpr (RL % 2 == 0) e = a.eb[(rho * 2 + (r >= RL / 2 ? 1 : 0)) * RL + r];
-                else e = s_eb[(rho * 2 + ((2 * (tid + r * NSL) >= N2) ? 1 : 0)) * RL + r];
-                p = cmul(cmul(p, eaj), e);
-            }
-            v[r] = p;
-        }
-    }
-    __syncthreads();     // forward transform's LDS reads done
-    if (tid < NSL) { TI::template bfly<0>(v); TI::template store_lds<0>(lds, tid, 0, v); }
-    __syncthreads();
-    MidStages<TI, PR, T, 1>::run(lds, tab_i, v, tid);
-    if (tid < NSI) {
-        TI::template load_lds_tab<S - 1>(lds, tab_i, tid, v);
-        TI::template bfly<S - 1>(v);
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned m = (unsigned)k1 * (unsigned)tid;
-        const C u = cmul(cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask])), a.ramp1[(long long)rho * a.n1 + k1]);
-        C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
-        TWX_UNROLL
-        for (int q = 0; q < RIL; ++q) (out + q * NSI)[(unsigned)tid] = cmul(cmul(v[q], u), s_vc[q]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_row_mid_p: persistent form of k_row<MID>.  Workgroups pull rows (k1, window) from a device
-// counter; while row i is being transformed the A-row of row i+1 is already in flight into
-// registers, so the global-load phase (≈ 20 % of a row's time when serialised, measured with the
-// TWX_STAMPS build) overlaps the four row transforms.  Stage tables are loaded once per workgroup.
-// grid = any (≥ number of CUs); queue must be zero at launch.
-// ------------------------------------------------------------------------------------------
-template <class P2, typename T, int PADQ, int NT>
-__global__ __launch_bounds__(NT) void k_row_mid_p(RowArgs<T> a, unsigned int* __restrict__ queue, unsigned int total_rows) {
-    using C = cpx<T>;
-    using TF = RowTile<P2, T, false, PADQ>;
-    using PR = typename Rev<P2>::type;
-    using TI = RowTile<PR, T, true, PADQ>;
-    constexpr int S = P2::S, N2 = P2::L;
-    constexpr int R0 = P2::radix(0), NS0 = N2 / R0;
-    constexpr int RL = P2::radix(S - 1), NSL = N2 / RL;
-    constexpr int RIL = PR::radix(S - 1), NSI = N2 / RIL;
-    constexpr bool PAL = std::is_same<P2, PR>::value;
-    constexpr int NTF = StageTabs<P2>::total, NTI = PAL ? 0 : StageTabs<PR>::total;
-    constexpr int NEB = TWX_MAX_PHASE * 2 * RL;
-    static_assert(S >= 2, "row plans need >= 2 stages");
-    __shared__ C lds[TF::lds_elems + NTF + NTI + NEB + RIL];
-    __shared__ unsigned int s_next;
-    C* tab_f = lds + TF::lds_elems;
-    C* tab_i = PAL ? tab_f : tab_f + NTF;
-    C* s_eb = tab_f + NTF + NTI;
-    C* s_vc = s_eb + NEB;
-    const int tid0 = threadIdx.x;
-    for (int i = tid0; i < NTF; i += NT) tab_f[i] = a.stab_f[i];
-    if constexpr (!PAL) for (int i = tid0; i < NTI; i += NT) tab_i[i] = a.stab_i[i];
-    for (int i = tid0; i < a.nphase * 2 * RL; i += NT) s_eb[i] = a.eb[i];
-    if (tid0 == 0) s_next = atomicAdd(queue, 1u);
-    __syncthreads();
-    unsigned int cur = s_next;
-    const unsigned mask = (1u << a.tshift) - 1u;
-    C nxt[R0];
-    if (cur < total_rows && tid0 < NS0) {
-        const C* row = a.A + (long long)(cur % a.nwin) * a.n + (long long)(cur / a.nwin) * N2;
-        TWX_UNROLL
-        for (int r = 0; r < R0; ++r) nxt[r] = (row + r * NS0)[(unsigned)tid0];
-    }
-    __syncthreads();    // every thread has read s_next before it is overwritten below
-    while (cur < total_rows) {
-        int tid = tid0;
-        asm volatile("" : "+v"(tid));        // keep per-row address arithmetic inside the loop (register pressure)
-        const int k1 = cur / a.nwin, b = cur % a.nwin;
-        C v[P2::rmax()];
-        C csr[RL];
-        if (tid < NSL) {
-            const C* cs = a.cspec + (long long)k1 * N2;
-            TWX_UNROLL
-            for (int q = 0; q < RL; ++q) csr[q] = (cs + q * NSL)[(unsigned)tid];
-        }
-        if (tid < RIL) {
-            const unsigned m = (unsigned)k1 * (unsigned)tid * (unsigned)NSI;
-            s_vc[tid] = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
-        }
-        if (tid == 0) s_next = atomicAdd(queue, 1u);
-        if (tid < NS0) {
-            TWX_UNROLL
-            for (int r = 0; r < R0; ++r) v[r] = nxt[r];
-            TF::template bfly<0>(v);
-            TF::template store_lds<0>(lds, tid, 0, v);
-        }
-        __syncthreads();
-        const unsigned int nx = s_next;
-        if (nx < total_rows && tid < NS0) {      // prefetch the next row: stays in flight during this row's transforms
-            const C* row = a.A + (long long)(nx % a.nwin) * a.n + (long long)(nx / a.nwin) * N2;
-            TWX_UNROLL
-            for (int r = 0; r < R0; ++r) nxt[r] = (row + r * NS0)[(unsigned)tid];
-        }
-        MidStages<TF, P2, T, 1>::run(lds, tab_f, v, tid);
-        C pr[RL];
-        if (tid < NSL) {
-            TF::template load_lds_tab<S - 1>(lds, tab_f, tid, v);
-            TF::template bfly<S - 1>(v);
-            if (k1 == 0 && tid == 0) a.dc[b] = v[0];
-            TWX_UNROLL
-            for (int q = 0; q < RL; ++q) pr[q] = cmul(v[q], csr[q]);   // ffty.*fcode (godual_ranging.m:26)
-        }
-        C ub = mk<T>(1, 0);
-        if (tid < NSI) {
-            const unsigned m = (unsigned)k1 * (unsigned)tid;
-            ub = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
-        }
-        C ea_cur = mk<T>(1, 0), ea_n = mk<T>(1, 0);
-        if (a.nphase > 1 && tid < NSL) ea_n = a.ea[NSL + tid];
-        C r1_cur = a.ramp1[k1];
-        for (int rho = 0; rho < a.nphase; ++rho) {
-            __syncthreads();   // previous transform's LDS reads are done
-            int lt = tid;
-            asm volatile("" : "+v"(lt));
-            const C eaj = ea_cur;
-            const C r1 = r1_cur;
-            ea_cur = ea_n;
-            if (rho + 2 < a.nphase && lt < NSL) ea_n = a.ea[(rho + 2) * NSL + lt];
-            if (rho + 1 < a.nphase) r1_cur = a.ramp1[(long long)(rho + 1) * a.n1 + k1];
-            if (lt < NSL) {
-                if (rho == 0) {
-                    TWX_UNROLL
-                    for (int r = 0; r < RL; ++r) v[r] = pr[r];
-                } else {
-                    TWX_UNROLL
-                    for (int r = 0; r < RL; ++r) {
-                        C e;
-                        if constexpr (RL % 2 == 0) e = a.eb[(rho * 2 + (r >= RL / 2 ? 1 : 0)) * RL + r];   // wave-uniform → scalar load
-                        else e = s_eb[(rho * 2 + ((2 * (lt + r * NSL) >= N2) ? 1 : 0)) * RL + r];
-                        v[r] = cmul(cmul(pr[r], eaj), e);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                TI::template bfly<0>(v);
-                TI::template store_lds<0>(lds, lt, 0, v);
-            }
-            __syncthreads();
-            MidStages<TI, PR, T, 1>::run(lds, tab_i, v, lt);
-            if (lt < NSI) {
-                TI::template load_lds_tab<S - 1>(lds, tab_i, lt, v);
-                TI::template bfly<S - 1>(v);
-                __builtin_amdgcn_sched_barrier(0);
-                const C u = cmul(ub, r1);
-                C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
-                TWX_UNROLL
-                for (int q = 0; q < RIL; ++q) (out + q * NSI)[(unsigned)lt] = cmul(cmul(v[q], u), s_vc[q]);   // · W_N^{-k1 q2} · ramp1
-            }
-        }
-        __syncthreads();   // LDS workspace, s_vc and s_next are free for the next row
-        cur = nx;
     }
 }
 

@@ -35,8 +35,6 @@ struct RowOps {
     int (*run)(int mode, const void* args /*RowArgs<T>*/, unsigned nblk, hipStream_t s);
     int (*caf)(const void* args /*CafArgs<T>*/, unsigned nblk, hipStream_t s);
     int (*rowd)(int mode, const void* args /*RowDArgs<T>*/, unsigned nblk, hipStream_t s);   // nullptr if the plan has no DIF form
-    int (*mid_s)(const void* args /*RowArgs<T>*/, unsigned nblk, hipStream_t s);
-    int (*mid_p)(const void* args /*RowArgs<T>*/, unsigned int* queue, unsigned total_rows, unsigned nblk, hipStream_t s);
 };
 
 void register_col(const ColOps& o);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build a named variant of the library with extra compiler flags into amaranth_twstft_amd/variants/
-# (git-ignored; travels with gpurun):   tools/variants.sh prio1 "-DTWX_PRIO=1"
-# Run on the GPU box:                   TWX_LIB=amaranth_twstft_amd/variants/lib_prio1.so python bench.py ...
+# (git-ignored; travels with gpurun):   tools/variants.sh noload "-DTWX_ABL=4"
+# Run on the GPU box:                   TWX_LIB=amaranth_twstft_amd/variants/lib_noload.so python bench.py ...
 set -e
 name=$1; shift
 cd "$(dirname "$0")/../amaranth_twstft_amd/csrc"
