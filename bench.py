@@ -112,8 +112,8 @@ def main():
     band = L.twx_band(*band_godual(FS, N))
     df_true = np.array([1780.75] * nwin, dtype=np.float64)
 
-    def step(c):
-        if a.workload == "processing":
+    def step(c, workload=None):
+        if (workload or a.workload) == "processing":
             L.check(lib.twx_process_windows_dev(c._h, iq.data_ptr(), nwin, 1, 0, C.byref(band), None, res.data_ptr()), c._h)
         else:
             L.check(lib.twx_process_windows_dev(c._h, iq.data_ptr(), nwin, 1, 0, None, df_true.ctypes.data_as(C.c_void_p),
@@ -145,6 +145,22 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # --- the other workload, timed the same way (reported beside `value`, never instead of it)
+    other = "xcorr" if a.workload == "processing" else "processing"
+    step(cor, other)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(cor, other)
+    barrier()
+    dt_other = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt_other], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt_other = float(tmax.item())
+    step(cor)                            # leave the results of the headline workload in `res` for the checks below
+    barrier()
+
     # --- correctness of what was timed: integer lags must equal the generator's delays
     host = res.cpu().numpy().tobytes()
     arr = (L.twx_result * nwin).from_buffer_copy(host)
@@ -159,7 +175,10 @@ def main():
                       + ": 1 s windows, 5 Msps int16 IQ, 2.5 Mchip LFSR(22,3) code, Nint=1 (configs[1])",
                       "windows_per_gpu_per_step": nwin, "samples_per_window": N, "batch": int(cor.info.batch),
                       "n1": int(cor.info.n1), "n2": int(cor.info.n2), "sharding": f"windows/{world}"},
-           "integer_lag_exact": bool(lag_ok)}
+           "integer_lag_exact": bool(lag_ok),
+           "other_workload": {"workload": "xcorr, df supplied (code-phase only)" if other == "xcorr" else "processing(d,k) full chain",
+                              "value": round(world * nwin * N * a.steps / dt_other / 1e6, 2), "unit": "Msamples/s",
+                              "ms_per_step": round(dt_other / a.steps * 1e3, 3)}}
 
     # --- roofline of the dominant kernel: HIP events around every launch on the library's stream
     if rank == 0 and not a.no_roofline:
