@@ -22,6 +22,7 @@ namespace twx {
 // ------------------------------------------------------------------------------------------
 // registry
 // ------------------------------------------------------------------------------------------
+static int wshift_of(int w) { int sft = 0; while ((1 << sft) < w) ++sft; return sft; }
 LaunchEvents& launch_events() { static thread_local LaunchEvents le; return le; }
 static std::vector<ColOps>& col_reg() { static std::vector<ColOps> v; return v; }
 static std::vector<RowOps>& row_reg() { static std::vector<RowOps> v; return v; }
@@ -453,7 +454,7 @@ template <typename T> struct Ctx : CtxBase {
         ca.e1 = nullptr; ca.e2 = nullptr; ca.tw1 = t1; ca.ta = tad; ca.tb = tbd; ca.tshift = tshift; ca.tc = tcu; ca.out = tmp;
         if (c->fwd(COL_PLAIN, IN_CHIPS, chips_dev, cfg.sps, &ca, (unsigned)ca.ntiles, stream)) return fail(TWX_E_HIP, "code col pass launch failed");
         RowArgs<U> ra{};
-        ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = tmp; ra.stab_f = t2; ra.stab_i = t2; ra.spec_out = out;
+        ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = tmp; ra.wshift = wshift_of(c->W); ra.stab_f = t2; ra.stab_i = t2; ra.spec_out = out;
         ra.conj_out = 1; ra.hamming = (cfg.window == TWX_WIN_HAMMING); ra.scale = (U)store_scale;
         if (r->run(ROW_STORE, &ra, (unsigned)N1, stream)) return fail(TWX_E_HIP, "code row pass launch failed");
         HIPCHK(hipStreamSynchronize(stream));
@@ -592,7 +593,7 @@ template <typename T> struct Ctx : CtxBase {
         ca.in_win_stride = wstride; ca.sums = sums; ca.remove_mean = remove_mean; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = nb;
         ca.e1 = e1; ca.e2 = e2; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.tc = tcw; ca.out = A;
         RowArgs<T> ra{};
-        ra.n = N; ra.n1 = N1; ra.nwin = nb; ra.A = A; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.ea = ea; ra.eb = eb;
+        ra.n = N; ra.n1 = N1; ra.nwin = nb; ra.A = A; ra.wshift = wshift_of(col->W); ra.stab_f = stab_f; ra.stab_i = stab_i; ra.ea = ea; ra.eb = eb;
         ra.part = part_band; ra.cspec = cspec; ra.ramp1 = ramp1; ra.nphase = R; ra.scale = (T)scale_pow2;
         ra.ta = ta; ra.tb = tb; ra.tshift = tshift; ra.Bz = Bz; ra.dc = dc;
         ra.stamps = stamps_dev;
@@ -681,7 +682,7 @@ template <typename T> struct Ctx : CtxBase {
         ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = 1; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.tc = tcw; ca.out = tmp;
         if (col->fwd(COL_PLAIN, IN_C64, din, 0, &ca, (unsigned)ntiles, stream)) return fail(TWX_E_HIP, "col pass launch failed");
         RowArgs<T> ra{};
-        ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = tmp; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.spec_out = spec;
+        ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = tmp; ra.wshift = wshift_of(col->W); ra.stab_f = stab_f; ra.stab_i = stab_i; ra.spec_out = spec;
         if (row->run(ROW_STORE, &ra, (unsigned)N1, stream)) return fail(TWX_E_HIP, "row pass launch failed");
         HIPCHK(hipStreamSynchronize(stream));
         std::vector<C> h((size_t)N);
@@ -772,7 +773,7 @@ template <typename T> struct Ctx : CtxBase {
             ca.e1 = e1; ca.e2 = e2; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.tc = tcw; ca.out = A;
             if (col->fwd(COL_SQUARE, IN_I16, base + r0 * nch, (int)(nch * M), &ca, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_fwd(square) launch failed");
             RowArgs<T> ra{};
-            ra.n = N; ra.n1 = N1; ra.nwin = nb; ra.A = A; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.spec_out = spec + r0 * N;
+            ra.n = N; ra.n1 = N1; ra.nwin = nb; ra.A = A; ra.wshift = wshift_of(col->W); ra.stab_f = stab_f; ra.stab_i = stab_i; ra.spec_out = spec + r0 * N;
             if (row->run(ROW_STORE, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(store) launch failed");
         }
         TWX_LAUNCH((k_sqspec_combine<T>), dim3((unsigned)((nk + 255) / 256)), dim3(256), stream, spec, (int)M, (long long)N, N1, N2, k_lo, nk, mag);
@@ -902,7 +903,7 @@ template <typename T> struct Ctx : CtxBase {
         ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.tc = tcw; ca.out = A;
         if (col->fwd(COL_PLAIN, IN_I16, in, nch, &ca, (unsigned)ntiles, stream)) return fail(TWX_E_HIP, "k_col_fwd(plain) launch failed");
         RowArgs<T> ra{};
-        ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = A; ra.stab_f = stab_f; ra.stab_i = stab_i; ra.spec_out = Ysp;
+        ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = A; ra.wshift = wshift_of(col->W); ra.stab_f = stab_f; ra.stab_i = stab_i; ra.spec_out = Ysp;
         if (row->run(ROW_STORE, &ra, (unsigned)N1, stream)) return fail(TWX_E_HIP, "k_row(store) launch failed");
         for (long long k0 = k_lo; k0 <= k_hi; k0 += nbmax) {
             const int nb = (int)std::min<long long>(nbmax, k_hi - k0 + 1);

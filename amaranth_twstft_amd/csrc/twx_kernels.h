@@ -31,7 +31,7 @@
 #define TWX_ABLC 0      // k_col_inv: 1 no transforms, 2 no global loads
 #endif
 #ifndef TWX_ABLF
-#define TWX_ABLF 0      // k_col_fwd: 1 no transform, 2 no loads, 3 no stores
+#define TWX_ABLF 0      // k_col_fwd: 1 no transform, 2 no loads, 3 no stores, 4 stores only, 5 loads only
 #endif
 
 namespace twx {
@@ -93,6 +93,24 @@ template <typename T, int NT> __device__ __forceinline__ Best<T> block_best(Best
     return b;
 }
 
+// Global access at (wave-uniform base, 32-bit lane byte offset).  The base is pinned into an SGPR pair with
+// readfirstlane (which also stops the optimiser from folding base and lane parts into one 64-bit VALU address per
+// access) and re-typed as a GLOBAL pointer, so the access compiles to the saddr form
+// `global_load/store v, v_off, s[base:base+1]`.
+#define TWX_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ unsigned long long sgpr_u64(unsigned long long u) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <typename V> __device__ __forceinline__ V ld_su(const void* ubase, unsigned lane_bytes) {
+    const TWX_GLOBAL char* g = (const TWX_GLOBAL char*)sgpr_u64(reinterpret_cast<unsigned long long>(ubase));
+    return *(const TWX_GLOBAL V*)(g + lane_bytes);
+}
+template <typename V> __device__ __forceinline__ void st_su(void* ubase, unsigned lane_bytes, V val) {
+    TWX_GLOBAL char* g = (TWX_GLOBAL char*)sgpr_u64(reinterpret_cast<unsigned long long>(ubase));
+    *(TWX_GLOBAL V*)(g + lane_bytes) = val;
+}
+
 // ------------------------------------------------------------------------------------------
 // input loaders (sample n of the current window → complex T)
 // ------------------------------------------------------------------------------------------
@@ -108,6 +126,16 @@ struct InI16 {   // interleaved int16 IQ, nch channels per sample (godual_rangin
         short2 s = q[lane * (unsigned)nch];
         return mk<T>((T)s.x, (T)s.y);
     }
+    // the same sample as one raw 32-bit word: wave-uniform byte base (SGPR pair) + 32-bit lane BYTE offset, which the
+    // compiler turns into `global_load_dword v, v_off, s[base]` — no per-load 64-bit VALU address arithmetic, so all
+    // the loads of a butterfly can be in flight at once
+    static constexpr bool has_raw = true;
+    __device__ __forceinline__ unsigned load_raw(long long ubase, unsigned lane) const {
+        return ld_su<unsigned>(reinterpret_cast<const char*>(p) + (unsigned long long)ubase * (unsigned long long)nch * 4ull, lane * (unsigned)nch * 4u);
+    }
+    template <typename T> static __device__ __forceinline__ cpx<T> unpack(unsigned w) {
+        return mk<T>((T)(short)(w & 0xffffu), (T)(short)(w >> 16));
+    }
 };
 struct InChips {  // code replica: chips {0,1} held sps samples, value 2c-1 (godual_ranging.m:63-65)
     const unsigned char* p; int sps;
@@ -115,6 +143,7 @@ struct InChips {  // code replica: chips {0,1} held sps samples, value 2c-1 (god
         return mk<T>((T)(2 * (int)p[n / sps] - 1), (T)0);
     }
     template <typename T> __device__ __forceinline__ cpx<T> load2(long long ubase, unsigned lane) const { return load<T>(ubase + lane); }
+    static constexpr bool has_raw = false;
 };
 template <typename S> struct InCplx {  // complex float/double samples (processing(d,k) entry)
     const cpx<S>* p;
@@ -127,6 +156,7 @@ template <typename S> struct InCplx {  // complex float/double samples (processi
         cpx<S> s = q[lane];
         return mk<T>((T)s.x, (T)s.y);
     }
+    static constexpr bool has_raw = false;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -355,13 +385,20 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
         constexpr int R = P1::radix(0);
         if (tid < TL::template tasks<0>()) {
             const int j = tid / W, c = tid % W;
+            const unsigned lane_in = (unsigned)j * (unsigned)a.n2 + (unsigned)(c0 + c);
+            unsigned raw[In::has_raw ? R : 1];
+            if constexpr (In::has_raw) {            // every load of the butterfly issued before anything waits
+                TWX_UNROLL
+                for (int r = 0; r < R; ++r) raw[r] = win.load_raw((long long)(r * (P1::L / R)) * a.n2, lane_in);
+            }
             // NCO factor exp(-j 2 pi df n/fs), n = (j + r*T)*N2 + n2:  E1[j]·E2[n2] per thread, E1[r*T] wave-uniform
             C ejc = mk<T>(1, 0);
             if (MODE == COL_MIX) ejc = cmul(a.e1[(long long)b * P1::L + j], a.e2[(long long)b * a.n2 + c0 + c]);
-            const unsigned lane_in = (unsigned)j * (unsigned)a.n2 + (unsigned)(c0 + c);
             TWX_UNROLL
             for (int r = 0; r < R; ++r) {
-                C x = (TWX_ABLF == 2) ? mk<T>((T)(tid + r), (T)(r - tid)) : win.template load2<T>((long long)(r * (P1::L / R)) * a.n2, lane_in);
+                C x;
+                if constexpr (In::has_raw) x = (TWX_ABLF == 2 || TWX_ABLF == 4) ? mk<T>((T)(tid + r), (T)(r - tid)) : In::template unpack<T>(raw[r]);
+                else x = win.template load2<T>((long long)(r * (P1::L / R)) * a.n2, lane_in);
                 x.x -= mx; x.y -= my;
                 if (MODE == COL_MIX) {
                     C e = (r == 0) ? ejc : cmul(a.e1[(long long)b * P1::L + r * (P1::L / R)], ejc);   // scalar load × per-thread constant
@@ -371,8 +408,8 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
                 }
                 v[r] = x;
             }
-            if (TWX_ABLF != 1) TL::template bfly<0>(v);
-            if (S > 1 && TWX_ABLF != 1) TL::template store_lds<0>(lds, j, c, v);
+            if (TWX_ABLF != 1 && TWX_ABLF < 4) TL::template bfly<0>(v);
+            if (S > 1 && TWX_ABLF != 1 && TWX_ABLF < 4) TL::template store_lds<0>(lds, j, c, v);
         }
     }
     if (S > 1) __syncthreads();
@@ -394,24 +431,37 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
         constexpr int R = P1::radix(s);
         if (tid < TL::template tasks<s>()) {
             const int j = tid / W, c = tid % W;
-            if (S > 1 && TWX_ABLF != 1) { TL::template load_lds<s>(lds, a.tw1, j, c, v); TL::template bfly<s>(v); }
+            if (S > 1 && TWX_ABLF != 1 && TWX_ABLF < 4) { TL::template load_lds<s>(lds, a.tw1, j, c, v); TL::template bfly<s>(v); }
             const unsigned n2i = c0 + c;
             const unsigned mask = (1u << a.tshift) - 1u;
-            C* out = a.out + (long long)b * a.n;
-            const unsigned lane_out = (unsigned)TL::template out_pos<s>(j, 0) * (unsigned)a.n2 + n2i;
+            // A is stored tile-blocked, A[b][tile][k1][c]: a workgroup writes ONE contiguous N1*W*8-byte block (strided
+            // 128-B row pieces were the slowest part of this kernel: 3.1 TB/s for the stores alone); the row pass
+            // gathers its row from the N2/W blocks in 128-B pieces, which reads handle well (a_index below)
+            char* out = reinterpret_cast<char*>(a.out + (long long)b * a.n + (long long)tile * (P1::L * W));
+            const unsigned lane_out = ((unsigned)TL::template out_pos<s>(j, 0) * W + c) * (unsigned)sizeof(C);
             constexpr int QS = (S == 1) ? 1 : P1::L / R;     // row step between a thread's outputs
             // W_N^{k1 n2}, k1 = j + q*QS, n2 = c0 + c  =  W_N^{j c0} (per thread) · W_N^{q QS c0} (wave-uniform)
             //                                            · W_N^{k1 c} (one coalesced 8-B load from tc[k1][c])
             const unsigned mj = (S == 1) ? 0u : (unsigned)j * (unsigned)c0;
             const C wj = cmul(a.ta[mj >> a.tshift], a.tb[mj & mask]);
-            const C* tcl = a.tc + (unsigned)TL::template out_pos<s>(j, 0) * W + c;
+            const char* tcb = reinterpret_cast<const char*>(a.tc);
+            const unsigned tcl = ((unsigned)TL::template out_pos<s>(j, 0) * W + c) * (unsigned)sizeof(C);
+            constexpr unsigned ostride = QS * W * sizeof(C);
+            // All twiddle loads first, all stores last: on gfx9 loads and stores share vmcnt, so a table load issued
+            // after a store can only be waited for together with that store — interleaving them made the epilogue a
+            // chain of 25 load + store-acknowledge round trips (12 us per workgroup).
             TWX_UNROLL
             for (int q = 0; q < R; ++q) {
                 const unsigned mq = (unsigned)(q * QS) * (unsigned)c0;                  // wave-uniform: scalar loads
                 const C wq = cmul(a.ta[mq >> a.tshift], a.tb[mq & mask]);
-                const C w = cmul(cmul(wq, wj), tcl[q * QS * W]);
-                C* orow = out + (long long)(q * QS) * a.n2;                             // wave-uniform
-                if (TWX_ABLF == 3) { C o = cmul(v[q], w); asm volatile("" ::"v"(o)); } else orow[lane_out] = cmul(v[q], w);
+                const C w = cmul(cmul(wq, wj), ld_su<C>(tcb + (q * QS * W * (int)sizeof(C)), tcl));
+                v[q] = cmul(v[q], w);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            TWX_UNROLL
+            for (int q = 0; q < R; ++q) {
+                if (TWX_ABLF == 3 || TWX_ABLF == 5) { asm volatile("" ::"v"(v[q])); }
+                else st_su<C>(out + q * ostride, lane_out, v[q]);                         // uniform base + 32-bit lane offset
             }
         }
     }
@@ -421,6 +471,10 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
 // k_row: second pass of the forward transform with a fused epilogue
 // ------------------------------------------------------------------------------------------
 enum { ROW_STORE = 0, ROW_BAND = 1, ROW_MID = 2 };
+// element (k1, n2) of the tile-blocked column-pass output A[tile][k1][c], tile = n2 >> wshift, c = n2 & (W-1)
+__device__ __forceinline__ unsigned a_index(unsigned n2, unsigned k1, unsigned n1, int wshift) {
+    return ((((n2 >> wshift) * n1 + k1) << wshift) | (n2 & ((1u << wshift) - 1u)));
+}
 #define TWX_MAX_PHASE 5
 #ifndef TWX_ROW_WAVES
 #define TWX_ROW_WAVES 1
@@ -428,7 +482,8 @@ enum { ROW_STORE = 0, ROW_BAND = 1, ROW_MID = 2 };
 
 template <typename T> struct RowArgs {
     long long n; int n1, nwin;
-    const cpx<T>* A;                 // [b][k1][n2]
+    const cpx<T>* A;                 // [b][tile][k1][c], tile = n2 >> wshift (see a_index)
+    int wshift;                      // log2 of the column-pass tile width
     const cpx<T>* stab_f;            // StageTabs<P2> entries (forward sign)
     const cpx<T>* stab_i;            // StageTabs<Rev<P2>> entries (forward sign; used conjugated)
     // STORE
@@ -504,7 +559,7 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
     const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
     const int k1 = logical / a.nwin, b = logical % a.nwin;   // same k1 of all windows adjacent → shared code-spectrum row
     const int tid = threadIdx.x;
-    const C* row = a.A + (long long)b * a.n + (long long)k1 * N2;
+    const C* Ab = a.A + (long long)b * a.n;
     C v[P2::rmax()];
     C csr[MODE == ROW_MID ? RL : 1];     // code-spectrum row, requested at kernel start (latency hidden by the forward FFT)
     if constexpr (MODE == ROW_MID) {
@@ -520,7 +575,7 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
         constexpr int R = P2::radix(0);
         if (tid < TF::template tasks<0>()) {
             TWX_UNROLL
-            for (int r = 0; r < R; ++r) v[r] = (TWX_ABL == 4 && MODE == ROW_MID) ? mk<T>((T)(tid + r), (T)r) : (row + r * (N2 / R))[(unsigned)tid];
+            for (int r = 0; r < R; ++r) v[r] = (TWX_ABL == 4 && MODE == ROW_MID) ? mk<T>((T)(tid + r), (T)r) : Ab[a_index((unsigned)(tid + r * (N2 / R)), (unsigned)k1, (unsigned)a.n1, a.wshift)];
         }
         for (int i = tid; i < NTF; i += NT) tab_f[i] = a.stab_f[i];
         if constexpr (MODE == ROW_MID) {
@@ -696,7 +751,7 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     const bool act = D::blk_map(tid, q0, qi);
     const int u = q0 * R + qi;
     const unsigned mask = (1u << a.tshift) - 1u;
-    const C* row = a.A + (long long)b * a.n + (long long)k1 * N2;
+    const C* Ab = a.A + (long long)b * a.n;
     C v[RMAX];
     C csr[MODE == ROW_MID ? R : 1];
     if constexpr (MODE == ROW_MID) {
@@ -708,7 +763,7 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     }
     if (tid < M) {
         TWX_UNROLL
-        for (int r = 0; r < R0; ++r) v[r] = (row + r * M)[(unsigned)tid];
+        for (int r = 0; r < R0; ++r) v[r] = Ab[a_index((unsigned)(tid + r * M), (unsigned)k1, (unsigned)a.n1, a.wshift)];
     }
     for (int i = tid; i < D::tab_total; i += NT) tabs[i] = ad.dtabs[i];
     if constexpr (MODE == ROW_MID) {
