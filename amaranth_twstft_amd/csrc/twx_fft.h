@@ -326,6 +326,23 @@ template <class P, typename T, bool INV, int W, int PADQ> struct Tile {
             v[r] = INV ? cmulc(v[r], w) : cmul(v[r], w);
         }
     }
+    // load_lds in two halves: the twiddle gather touches only the read-only table, so it can be issued BEFORE the
+    // workgroup barrier that publishes the previous stage's LDS writes (its latency then overlaps the barrier wait)
+    template <int s> static TWX_HD void load_tw(const C* tw, int j, C* twr /*[R-1]*/) {
+        constexpr int Ns = P::ns(s), Rr = P::radix(s);
+        constexpr int step = L / (Ns * Rr);
+        const int jm = (Ns * Rr == L) ? j : (j % Ns);
+        TWX_UNROLL
+        for (int r = 1; r < Rr; ++r) twr[r - 1] = tw[jm * r * step];
+    }
+    template <int s> static TWX_HD void load_lds_tw(const C* lds, const C* twr, int j, int c, C* v) {
+        constexpr int Rr = P::radix(s);
+        const int ib = in_base<s>(j);
+        TWX_UNROLL
+        for (int r = 0; r < Rr; ++r) v[r] = lds[in_idx<s>(ib, j, r) * W + c];
+        TWX_UNROLL
+        for (int r = 1; r < Rr; ++r) v[r] = INV ? cmulc(v[r], twr[r - 1]) : cmul(v[r], twr[r - 1]);
+    }
     template <int s> static TWX_HD void store_lds(C* lds, int j, int c, const C* v) {
         constexpr int Rr = P::radix(s);
         const int ob = out_base<s>(j);

@@ -412,6 +412,12 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
             if (S > 1 && TWX_ABLF != 1 && TWX_ABLF < 4) TL::template store_lds<0>(lds, j, c, v);
         }
     }
+    // S == 2: the last stage's twiddle gather is issued before the barrier (v is dead until then)
+    constexpr bool TWPRE = (S == 2);
+    C twr[TWPRE ? P1::radix(S - 1) - 1 : 1];
+    if constexpr (TWPRE) {
+        if (tid < TL::template tasks<S - 1>()) TL::template load_tw<S - 1>(a.tw1, tid / W, twr);
+    }
     if (S > 1) __syncthreads();
     if constexpr (S > 2) {
         if (tid < TL::template tasks<1>()) { TL::template load_lds<1>(lds, a.tw1, tid / W, tid % W, v); TL::template bfly<1>(v); }
@@ -431,7 +437,11 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
         constexpr int R = P1::radix(s);
         if (tid < TL::template tasks<s>()) {
             const int j = tid / W, c = tid % W;
-            if (S > 1 && TWX_ABLF != 1 && TWX_ABLF < 4) { TL::template load_lds<s>(lds, a.tw1, j, c, v); TL::template bfly<s>(v); }
+            if (S > 1 && TWX_ABLF != 1 && TWX_ABLF < 4) {
+                if constexpr (TWPRE) TL::template load_lds_tw<s>(lds, twr, j, c, v);
+                else TL::template load_lds<s>(lds, a.tw1, j, c, v);
+                TL::template bfly<s>(v);
+            }
             const unsigned n2i = c0 + c;
             const unsigned mask = (1u << a.tshift) - 1u;
             // A is stored tile-blocked, A[b][tile][k1][c]: a workgroup writes ONE contiguous N1*W*8-byte block (strided
@@ -1042,6 +1052,11 @@ __global__ __launch_bounds__(NT) void k_col_inv(ColInvArgs<T> a) {
             if (S > 1 && TWX_ABLC != 1) TL::template store_lds<0>(lds, j, c, v);
         }
     }
+    constexpr bool TWPRE = (S == 2);      // last stage's twiddle gather issued before the barrier (see k_col_fwd)
+    C twr[TWPRE ? P1R::radix(S - 1) - 1 : 1];
+    if constexpr (TWPRE) {
+        if (tid < TL::template tasks<S - 1>()) TL::template load_tw<S - 1>(a.tw1, tid / W, twr);
+    }
     if (S > 1) __syncthreads();
     if constexpr (S > 2) {
         if (tid < TL::template tasks<1>()) { TL::template load_lds<1>(lds, a.tw1, tid / W, tid % W, v); TL::template bfly<1>(v); }
@@ -1061,7 +1076,11 @@ __global__ __launch_bounds__(NT) void k_col_inv(ColInvArgs<T> a) {
         constexpr int R = P1R::radix(s);
         if (tid < TL::template tasks<s>()) {
             const int j = tid / W, c = tid % W;
-            if (S > 1 && TWX_ABLC != 1) { TL::template load_lds<s>(lds, a.tw1, j, c, v); TL::template bfly<s>(v); }
+            if (S > 1 && TWX_ABLC != 1) {
+                if constexpr (TWPRE) TL::template load_lds_tw<s>(lds, twr, j, c, v);
+                else TL::template load_lds<s>(lds, a.tw1, j, c, v);
+                TL::template bfly<s>(v);
+            }
             const unsigned int mbase = (unsigned int)(c0 + c) * (unsigned int)a.nphase + (unsigned int)rho;
             const unsigned int mstep = (unsigned int)a.n2 * (unsigned int)a.nphase;
             // per-thread arg-max in two cheap sweeps: max value (1 op per sample), then the first q that
