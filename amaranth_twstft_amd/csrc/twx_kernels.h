@@ -367,7 +367,7 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
     using TL = Tile<P1, T, false, W, 0>;
     using C = cpx<T>;
     constexpr int S = P1::S;
-    __shared__ C lds[TL::lds_elems];
+    __shared__ C lds[TL::lds_elems + 32];                    // + the wave-uniform output twiddles (s_wq)
     const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
     const int b = logical / a.ntiles, tile = logical % a.ntiles;
     const int c0 = tile * W;
@@ -412,11 +412,29 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
             if (S > 1 && TWX_ABLF != 1 && TWX_ABLF < 4) TL::template store_lds<0>(lds, j, c, v);
         }
     }
-    // S == 2: the last stage's twiddle gather is issued before the barrier (v is dead until then)
+    // S == 2: everything of the last stage that does not depend on the data is done before the barrier (v is dead
+    // until then): the stage-twiddle gather, the per-thread part W_N^{j c0} of the output twiddle folded into those
+    // twiddles (the butterfly is linear), and the wave-uniform parts W_N^{q QS c0} computed once per workgroup by
+    // RL threads into LDS instead of 2*RL dependent scalar loads per wave.
     constexpr bool TWPRE = (S == 2);
-    C twr[TWPRE ? P1::radix(S - 1) - 1 : 1];
+    constexpr int RLc = P1::radix(S - 1);
+    C twr[TWPRE ? RLc - 1 : 1];
+    C wj0 = mk<T>(1, 0);
+    C* s_wq = lds + TL::lds_elems;
     if constexpr (TWPRE) {
-        if (tid < TL::template tasks<S - 1>()) TL::template load_tw<S - 1>(a.tw1, tid / W, twr);
+        const unsigned mask = (1u << a.tshift) - 1u;
+        if (tid < TL::template tasks<S - 1>()) {
+            const int j = tid / W;
+            TL::template load_tw<S - 1>(a.tw1, j, twr);
+            const unsigned mj = (unsigned)j * (unsigned)c0;
+            wj0 = cmul(a.ta[mj >> a.tshift], a.tb[mj & mask]);
+            TWX_UNROLL
+            for (int r = 1; r < RLc; ++r) twr[r - 1] = cmul(twr[r - 1], wj0);
+        }
+        if (tid < RLc) {
+            const unsigned mq = (unsigned)(tid * (P1::L / RLc)) * (unsigned)c0;
+            s_wq[tid] = cmul(a.ta[mq >> a.tshift], a.tb[mq & mask]);
+        }
     }
     if (S > 1) __syncthreads();
     if constexpr (S > 2) {
@@ -438,7 +456,7 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
         if (tid < TL::template tasks<s>()) {
             const int j = tid / W, c = tid % W;
             if (S > 1 && TWX_ABLF != 1 && TWX_ABLF < 4) {
-                if constexpr (TWPRE) TL::template load_lds_tw<s>(lds, twr, j, c, v);
+                if constexpr (TWPRE) { TL::template load_lds_tw<s>(lds, twr, j, c, v); v[0] = cmul(v[0], wj0); }
                 else TL::template load_lds<s>(lds, a.tw1, j, c, v);
                 TL::template bfly<s>(v);
             }
@@ -452,8 +470,8 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
             constexpr int QS = (S == 1) ? 1 : P1::L / R;     // row step between a thread's outputs
             // W_N^{k1 n2}, k1 = j + q*QS, n2 = c0 + c  =  W_N^{j c0} (per thread) · W_N^{q QS c0} (wave-uniform)
             //                                            · W_N^{k1 c} (one coalesced 8-B load from tc[k1][c])
-            const unsigned mj = (S == 1) ? 0u : (unsigned)j * (unsigned)c0;
-            const C wj = cmul(a.ta[mj >> a.tshift], a.tb[mj & mask]);
+            const unsigned mj = (S == 1 || TWPRE) ? 0u : (unsigned)j * (unsigned)c0;
+            const C wj = TWPRE ? mk<T>(1, 0) : cmul(a.ta[mj >> a.tshift], a.tb[mj & mask]);
             const char* tcb = reinterpret_cast<const char*>(a.tc);
             const unsigned tcl = ((unsigned)TL::template out_pos<s>(j, 0) * W + c) * (unsigned)sizeof(C);
             constexpr unsigned ostride = QS * W * sizeof(C);
@@ -462,9 +480,13 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
             // chain of 25 load + store-acknowledge round trips (12 us per workgroup).
             TWX_UNROLL
             for (int q = 0; q < R; ++q) {
-                const unsigned mq = (unsigned)(q * QS) * (unsigned)c0;                  // wave-uniform: scalar loads
-                const C wq = cmul(a.ta[mq >> a.tshift], a.tb[mq & mask]);
-                const C w = cmul(cmul(wq, wj), ld_su<C>(tcb + (q * QS * W * (int)sizeof(C)), tcl));
+                C w;
+                if constexpr (TWPRE) w = cmul(s_wq[q], ld_su<C>(tcb + (q * QS * W * (int)sizeof(C)), tcl));
+                else {
+                    const unsigned mq = (unsigned)(q * QS) * (unsigned)c0;              // wave-uniform: scalar loads
+                    const C wq = cmul(a.ta[mq >> a.tshift], a.tb[mq & mask]);
+                    w = cmul(cmul(wq, wj), ld_su<C>(tcb + (q * QS * W * (int)sizeof(C)), tcl));
+                }
                 v[q] = cmul(v[q], w);
             }
             __builtin_amdgcn_sched_barrier(0);
