@@ -771,8 +771,10 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     constexpr int NEB = MODE == ROW_MID ? TWX_MAX_PHASE * 2 * R : 0;
     constexpr int NVC = MODE == ROW_MID ? R0 : 0;
     static_assert(NT >= D::NT_MIN, "not enough threads for RowD");
-    __shared__ C lds[D::lds_elems + D::tab_total + NEB + NVC + 16];
-    C* tabs = lds + D::lds_elems;
+    // data and tables are SEPARATE shared arrays: with one array the compiler must assume that a table read may
+    // alias an earlier data write and serialises read -> wait -> multiply -> write for every element of a stage
+    __shared__ C lds[D::lds_elems];
+    __shared__ C tabs[D::tab_total + NEB + NVC + 16];
     C* s_eb = tabs + D::tab_total;
     C* s_vc = s_eb + NEB;
     void* red = (void*)(s_vc + NVC);
@@ -786,24 +788,38 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     const C* Ab = a.A + (long long)b * a.n;
     C v[RMAX];
     C csr[MODE == ROW_MID ? R : 1];
+    // small tables first (they are needed first and loads return in order), then the row, then the code spectrum
+    constexpr int NTAB = (D::tab_total + NT - 1) / NT;
+    C treg[NTAB];
+    TWX_UNROLL
+    for (int k = 0; k < NTAB; ++k) treg[k] = ad.dtabs[min(tid + k * NT, D::tab_total - 1)];     // clamped: no branch, no select
+    C ebreg = mk<T>(0, 0), vca = mk<T>(1, 0), vcb = mk<T>(1, 0);
     if constexpr (MODE == ROW_MID) {
-        if (act) {
-            const C* cs = ad.cspec_perm + (long long)k1 * N2;
-            TWX_UNROLL
-            for (int q2 = 0; q2 < R; ++q2) csr[q2] = (cs + q2 * NU)[(unsigned)u];
-        }
+        static_assert(TWX_MAX_PHASE * 2 * R <= NT, "phase-ramp table larger than the workgroup");
+        ebreg = ad.eb_d[min(tid, a.nphase * 2 * R - 1)];
+        const unsigned m = (unsigned)k1 * (unsigned)min(tid, R0 - 1) * (unsigned)M;  // conj(W_N^{k1 * c * M})
+        vca = a.ta[m >> a.tshift]; vcb = a.tb[m & mask];
     }
-    if (tid < M) {
+    __builtin_amdgcn_sched_barrier(0);      // keep the table loads first in program order (loads return in order)
+    // the loads are unconditional (idle lanes of the last wave re-read a valid element): inside divergent branches
+    // the wait-count pass has to assume the branch was skipped and waits for far more than the tables
+    {
+        const int tl = min(tid, M - 1);
         TWX_UNROLL
-        for (int r = 0; r < R0; ++r) v[r] = Ab[a_index((unsigned)(tid + r * M), (unsigned)k1, (unsigned)a.n1, a.wshift)];
+        for (int r = 0; r < R0; ++r) v[r] = Ab[a_index((unsigned)(tl + r * M), (unsigned)k1, (unsigned)a.n1, a.wshift)];
     }
-    for (int i = tid; i < D::tab_total; i += NT) tabs[i] = ad.dtabs[i];
     if constexpr (MODE == ROW_MID) {
-        for (int i = tid; i < a.nphase * 2 * R; i += NT) s_eb[i] = ad.eb_d[i];
-        if (tid < R0) {
-            const unsigned m = (unsigned)k1 * (unsigned)tid * (unsigned)M;      // conj(W_N^{k1 * c * M})
-            s_vc[tid] = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
-        }
+        const C* cs = ad.cspec_perm + (long long)k1 * N2;
+        const unsigned ul = (unsigned)min(u, NU - 1);
+        TWX_UNROLL
+        for (int q2 = 0; q2 < R; ++q2) csr[q2] = (cs + q2 * NU)[ul];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    TWX_UNROLL
+    for (int k = 0; k < NTAB; ++k) { const int i = tid + k * NT; if (i < D::tab_total) tabs[i] = treg[k]; }
+    if constexpr (MODE == ROW_MID) {
+        if (tid < a.nphase * 2 * R) s_eb[tid] = ebreg;
+        if (tid < R0) s_vc[tid] = cconj(cmul(vca, vcb));
     }
     __syncthreads();                                   // tables visible (the row loads are in flight meanwhile)
     if (tid < M) {

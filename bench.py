@@ -183,7 +183,7 @@ def main():
     # --- roofline of the dominant kernel: HIP events around every launch on the library's stream
     if rank == 0 and not a.no_roofline:
         pc = Correlator(chips, fs=FS, Nint=1, device=local_rank, max_batch=a.batch, profile=True)
-        step_w = min(nwin, 32)
+        step_w = nwin
         def prof_pass():
             L.check(lib.twx_process_windows_dev(pc._h, iq.data_ptr(), step_w, 1, 0,
                                                 C.byref(band) if a.workload == "processing" else None,
@@ -191,7 +191,8 @@ def main():
                                                 res.data_ptr()), pc._h)
         prof_pass()
         pc.profile(reset=True)          # discard the warm-up pass
-        prof_pass()
+        for _ in range(3):
+            prof_pass()
         prof = pc.profile()
         kern = {k: dict(ms_avg=v["ms_total"] / v["launches"], launches=v["launches"],
                         samples_per_launch=v["units"] / v["launches"]) for k, v in prof.items()}
