@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-mkdir -p gpurun_out/r01f
+rm -rf gpurun_out/r01f; mkdir -p gpurun_out/r01f
 python3 bench.py --steps 5 --warmup 2 > gpurun_out/r01f/bench_default.json 2> gpurun_out/r01f/bench_default.err
 TWX_STREAMS=1 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r01f/bench_1slot.json 2>/dev/null
 TWX_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01f/stats_1slot -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r01f/stats_1slot.log 2>&1
