@@ -632,3 +632,16 @@ def test_plain_c_client_of_the_abi(tmp_path):
     out = subprocess.run([str(exe), "10000", "14", "43", "4321"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "indice0=12963" in out.stdout
+
+
+def test_stockham_row_pass_fallback(monkeypatch):
+    """TWX_ROWD=0 selects the Stockham row kernels (the form used by plans without equal inner radices)."""
+    monkeypatch.setenv("TWX_ROWD", "0")
+    chips, raw = _capture(17, 15, 100000, 2, seed=77)
+    n = 200000
+    band = band_numpy(FS, n)
+    with Correlator(chips, fs=FS, Nint=1) as cor:
+        got = cor.ranging(raw, n_channels=2, channels=(0,), band=band)
+    ref = orc.ranging(raw, chips, fs=FS, Nint=1, n_channels=2, channels=(0,), band="numpy")
+    for g, o in zip(got[0], ref[0]):
+        _check(g, o)
