@@ -122,6 +122,7 @@ def main():
             L.check(lib.twx_synchronize(c._h), c._h)        # results complete before RCCL reads them
             if a.backend == "nccl":
                 dist.all_gather_into_tensor(gathered, res)        # RCCL over xGMI, 240 B per window
+                torch.cuda.current_stream().synchronize()         # the next step rewrites `res` from the library's own streams
             else:
                 host = gathered.cpu()
                 dist.all_gather_into_tensor(host, res.cpu())
