@@ -247,6 +247,8 @@ struct CtxBase {
     virtual int sqspec_band(const void* iq_dev, long long L, int nch, int ch, long long k_lo, long long nk, double* out) = 0;
     virtual int process_file(const char* path, int nch, int ch, long long skip, const twx_band* band, double df_const,
                              twx_result* out, long long max_windows, long long* n_done) = 0;
+    virtual int process_host(const int16_t* iq, long long nwin, int nch, int ch, const twx_band* band, const double* df,
+                             twx_result* out) = 0;
 };
 
 template <typename T> static void host_twiddle(std::vector<cpx<T>>& v, long long count, long long num_mul, long long den, int sign) {
@@ -784,12 +786,16 @@ template <typename T> struct Ctx : CtxBase {
         return TWX_OK;
     }
 
-    int process_file(const char* path, int nch, int ch, long long skip, const twx_band* band, double df_const,
-                     twx_result* out, long long max_windows, long long* n_done) override {
+    // ---- pipelined ingest shared by twx_process_file and twx_process_windows (host buffer) -----------------
+    // read_at(dst, byte offset from the first window, length) -> bytes delivered (short only at the end of the
+    // source).  Chunk c = B windows lives in pipeline slot c % nslots: a helper thread fills the slot's pinned buffer
+    // (as io_threads concurrent pieces: one pread/memcpy runs at ~5 GB/s, PCIe takes ten times that), the H2D copy and
+    // the kernels of the chunk go to the slot's stream, and the results of the chunk that used the slot before are
+    // fetched when the slot comes round again.
+    template <class ReadAt>
+    int run_pipeline(ReadAt read_at, int nch, int ch, const twx_band* band, const double* df_arr, double df_const,
+                     twx_result* out, long long max_windows, long long* n_done) {
         *n_done = 0;
-        FILE* f = fopen(path, "rb");
-        if (!f) return fail(TWX_E_ARG, std::string("cannot open ") + path);
-        if (skip > 0 && fseeko(f, (off_t)skip * nch * 4, SEEK_SET) != 0) { fclose(f); return fail(TWX_E_ARG, "seek failed"); }
         const size_t win_bytes = (size_t)N * nch * 4;
         Stage* st = stage;
         int rc = TWX_OK;
@@ -804,6 +810,7 @@ template <typename T> struct Ctx : CtxBase {
             else if (hipMalloc((void**)&st[k].dev, win_bytes * B) != hipSuccess) rc = fail(TWX_E_NOMEM, "device staging allocation failed");
             else st[k].bytes = win_bytes * B;
         }
+        if (rc) return rc;
         auto drain = [&](int k) -> int {       // wait for slot k's batch and fetch its results
             if (st[k].nb == 0) return TWX_OK;
             if (hipStreamSynchronize(slots[k].stream) != hipSuccess) return fail(TWX_E_HIP, "stream synchronize failed");
@@ -812,37 +819,24 @@ template <typename T> struct Ctx : CtxBase {
             st[k].nb = 0;
             return TWX_OK;
         };
-        // chunk c lives at file offset base + c*B windows; up to nslots reads are in flight on helper
-        // threads (pread into the pinned buffers) while earlier chunks copy and compute
-        const int fd = fileno(f);
-        const off_t base_off = (off_t)skip * nch * 4;
         auto start_read = [&](int k, long long chunk) {
             const long long first = chunk * B;
             const long long want = std::max<long long>(0, std::min<long long>(B, max_windows - first));
+            char* dst = (char*)st[k].host;
+            const int nthr = io_threads;
             return std::async(std::launch::async, [=]() -> long long {
-                // one chunk = io_threads contiguous pieces read concurrently (a single pread out of the page cache is a
-                // ~5 GB/s memcpy; PCIe takes ten times that)
                 const size_t need = win_bytes * (size_t)want;
-                const off_t off0 = base_off + (off_t)first * (off_t)win_bytes;
-                char* dst = (char*)st[k].host;
-                auto read_piece = [=](size_t lo, size_t hi) -> size_t {
-                    size_t done = lo;
-                    while (done < hi) {
-                        const ssize_t r = pread(fd, dst + done, hi - done, off0 + (off_t)done);
-                        if (r <= 0) break;
-                        done += (size_t)r;
-                    }
-                    return done - lo;
-                };
-                const int P = (int)std::max<size_t>(1, std::min<size_t>((size_t)io_threads, need >> 22));
+                const size_t off0 = (size_t)first * win_bytes;
+                const int P = (int)std::max<size_t>(1, std::min<size_t>((size_t)nthr, need >> 22));
                 const size_t piece = ((need + P - 1) / P + 4095) & ~(size_t)4095;
                 std::vector<std::future<size_t>> parts;
                 for (int i = 1; i < P; ++i) {
                     const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));
-                    parts.push_back(std::async(std::launch::async, read_piece, lo, hi));
+                    parts.push_back(std::async(std::launch::async, [=]() { return read_at(dst + lo, off0 + lo, hi - lo); }));
                 }
-                size_t total = read_piece(0, std::min(need, piece));
-                bool contiguous = total == std::min(need, piece);
+                const size_t first_len = std::min(need, piece);
+                size_t total = read_at(dst, off0, first_len);
+                bool contiguous = total == first_len;
                 for (int i = 1; i < P; ++i) {
                     const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));
                     const size_t got = parts[i - 1].get();
@@ -869,7 +863,7 @@ template <typename T> struct Ctx : CtxBase {
                 use_slot(k);
                 if (hipMemcpyAsync(st[k].dev, st[k].host, win_bytes * nb, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = fail(TWX_E_HIP, "H2D copy failed"); break; }
                 (void)hipEventRecord(h2d_done[k], stream);
-                rc = run_batch(st[k].dev + ch, nb, nch, band, band ? nullptr : dfs.data(), slots[k].res_dev, nullptr);
+                rc = run_batch(st[k].dev + ch, nb, nch, band, band ? nullptr : (df_arr ? df_arr + w0 : dfs.data()), slots[k].res_dev, nullptr);
                 st[k].w0 = w0; st[k].nb = nb;
                 w0 += nb;
             }
@@ -881,7 +875,44 @@ template <typename T> struct Ctx : CtxBase {
         for (int k = 0; k < nslots; ++k) if (h2d_done[k]) { (void)hipEventSynchronize(h2d_done[k]); (void)hipEventDestroy(h2d_done[k]); }
         for (int k = 0; k < nslots; ++k) { int r2 = drain(k); if (rc == TWX_OK) rc = r2; }
         use_slot(0);
+        return rc;
+    }
+
+    int process_file(const char* path, int nch, int ch, long long skip, const twx_band* band, double df_const,
+                     twx_result* out, long long max_windows, long long* n_done) override {
+        *n_done = 0;
+        FILE* f = fopen(path, "rb");
+        if (!f) return fail(TWX_E_ARG, std::string("cannot open ") + path);
+        const int fd = fileno(f);
+        const off_t base_off = (off_t)skip * nch * 4;
+        auto read_at = [fd, base_off](char* dst, size_t off, size_t len) -> size_t {
+            size_t done = 0;
+            while (done < len) {
+                const ssize_t r = pread(fd, dst + done, len - done, base_off + (off_t)(off + done));
+                if (r <= 0) break;
+                done += (size_t)r;
+            }
+            return done;
+        };
+        const int rc = run_pipeline(read_at, nch, ch, band, nullptr, df_const, out, max_windows, n_done);
         fclose(f);
+        return rc;
+    }
+
+    int process_host(const int16_t* iq, long long nwin, int nch, int ch, const twx_band* band, const double* df,
+                     twx_result* out) override {
+        if (!band && !df) return fail(TWX_E_ARG, "either band or df must be given");
+        const char* src = reinterpret_cast<const char*>(iq);
+        const size_t total = (size_t)nwin * (size_t)N * nch * 4;
+        auto read_at = [src, total](char* dst, size_t off, size_t len) -> size_t {
+            if (off >= total) return 0;
+            const size_t n = std::min(len, total - off);
+            memcpy(dst, src + off, n);
+            return n;
+        };
+        long long done = 0;
+        const int rc = run_pipeline(read_at, nch, ch, band, df, 0.0, out, nwin, &done);
+        if (rc == TWX_OK && done != nwin) return fail(TWX_E_HIP, "host pipeline processed fewer windows than requested");
         return rc;
     }
 
@@ -1022,25 +1053,9 @@ int twx_process_windows(twx_ctx* ctx, const int16_t* iq, int64_t n_windows, int3
     if (!iq || !out || n_windows < 0 || n_channels < 1 || channel < 0 || channel >= n_channels) return c->fail(TWX_E_ARG, "bad argument");
     if (n_windows == 0) return TWX_OK;
     (void)hipSetDevice(c->dev);
-    // stage the capture in chunks of the batch size so host captures of any length fit
-    const long long chunk = (long long)c->B * c->pipeline_depth();   // one batch per pipeline slot in flight
-    const size_t win_bytes = (size_t)c->N * n_channels * 4;
-    void* d_in = nullptr; twx_result* d_res = nullptr;
-    if (hipMalloc(&d_in, win_bytes * chunk) != hipSuccess) return c->fail(TWX_E_NOMEM, "staging buffer allocation failed");
-    if (hipMalloc((void**)&d_res, sizeof(twx_result) * chunk) != hipSuccess) { (void)hipFree(d_in); return c->fail(TWX_E_NOMEM, "result buffer allocation failed"); }
-    int rc = TWX_OK;
-    for (long long w0 = 0; w0 < n_windows && rc == TWX_OK; w0 += chunk) {
-        const long long nb = std::min<long long>(chunk, n_windows - w0);
-        if (hipMemcpyAsync(d_in, (const char*)iq + (size_t)w0 * win_bytes, win_bytes * nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = c->fail(TWX_E_HIP, "H2D copy failed"); break; }
-        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = c->fail(TWX_E_HIP, "H2D copy failed"); break; }
-        rc = c->process(d_in, nb, n_channels, channel, band, df ? df + w0 : nullptr, d_res);
-        if (rc) break;
-        rc = c->sync_all();
-        if (rc) { c->err = "stream synchronize failed (kernel fault?): " + c->err; break; }
-        if (hipMemcpy(out + w0, d_res, sizeof(twx_result) * nb, hipMemcpyDeviceToHost) != hipSuccess) { rc = c->fail(TWX_E_HIP, "D2H copy failed"); break; }
-    }
-    (void)hipFree(d_in); (void)hipFree(d_res);
-    return rc;
+    // pinned double-buffered staging: the host-side copy, the H2D transfer and the kernels of consecutive
+    // chunks overlap (same pipeline as twx_process_file)
+    return c->process_host(iq, n_windows, n_channels, channel, band, df, out);
 }
 
 int twx_fft_forward(twx_ctx* ctx, const double* in, double* out) {
