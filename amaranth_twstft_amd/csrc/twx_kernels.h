@@ -891,8 +891,10 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                 const int rn = rho + 1;
                 TWX_UNROLL
                 for (int q2 = 0; q2 < R; ++q2) {
+                    // from the LDS copy, not from global memory: a global load issued after this phase's Bz stores can
+                    // only be waited for together with them (loads and stores share vmcnt) — a store round trip per phase
                     C e;
-                    if constexpr (R % 2 == 0) e = ad.eb_d[(rn * 2 + (q2 >= R / 2 ? 1 : 0)) * R + q2];   // wave-uniform → scalar load
+                    if constexpr (R % 2 == 0) e = s_eb[(rn * 2 + (q2 >= R / 2 ? 1 : 0)) * R + q2];      // uniform address: LDS broadcast
                     else e = s_eb[(rn * 2 + ((2 * D::k_of(lq0, lqi, q2) >= N2) ? 1 : 0)) * R + q2];
                     v[q2] = cmul(cmul(pr[q2], eaj), e);
                 }
