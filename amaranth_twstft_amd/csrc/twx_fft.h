@@ -63,14 +63,41 @@ __device__ __forceinline__ cpx<float> cmulc_f32_asm(cpx<float> a, cpx<float> b) 
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(t));   // (a.y b.y + t.x, -a.x b.y + t.y)
     return d;
 }
+// (a*b)*c and (a*conj(b))*conj(c) as ONE asm block of four packed instructions: the compiler puts a wait state
+// (s_nop) after every asm statement whose result feeds the next instruction, so a chain of two products costs one
+// instead of four.
+__device__ __forceinline__ cpx<float> cmul3_f32_asm(cpx<float> a, cpx<float> b, cpx<float> c) {
+    cpx<float> t, d;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_mul_f32 %0, %1, %4 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %1, %4, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(t), "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ cpx<float> cmulc3_f32_asm(cpx<float> a, cpx<float> b, cpx<float> c) {
+    cpx<float> t, d;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
+        "v_pk_mul_f32 %0, %1, %4 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %1, %1, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=&v"(t), "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 #define TWX_ASM_CMUL 1
 #endif
 TWX_HD cpx<double> cmul(cpx<double> a, cpx<double> b) { return cmul_g(a, b); }
 TWX_HD cpx<double> cmulc(cpx<double> a, cpx<double> b) { return cmulc_g(a, b); }
+TWX_HD cpx<double> cmul3(cpx<double> a, cpx<double> b, cpx<double> c) { return cmul_g(cmul_g(a, b), c); }
+TWX_HD cpx<double> cmulc3(cpx<double> a, cpx<double> b, cpx<double> c) { return cmulc_g(cmulc_g(a, b), c); }
 #if defined(TWX_ASM_CMUL)
 __device__ __forceinline__ cpx<float> cmul(cpx<float> a, cpx<float> b) { return cmul_f32_asm(a, b); }
 __device__ __forceinline__ cpx<float> cmulc(cpx<float> a, cpx<float> b) { return cmulc_f32_asm(a, b); }
+__device__ __forceinline__ cpx<float> cmul3(cpx<float> a, cpx<float> b, cpx<float> c) { return cmul3_f32_asm(a, b, c); }      // (a*b)*c
+__device__ __forceinline__ cpx<float> cmulc3(cpx<float> a, cpx<float> b, cpx<float> c) { return cmulc3_f32_asm(a, b, c); }    // a*conj(b)*conj(c)
 #else
+TWX_HD cpx<float> cmul3(cpx<float> a, cpx<float> b, cpx<float> c) { return cmul_g(cmul_g(a, b), c); }
+TWX_HD cpx<float> cmulc3(cpx<float> a, cpx<float> b, cpx<float> c) { return cmulc_g(cmulc_g(a, b), c); }
 TWX_HD cpx<float> cmul(cpx<float> a, cpx<float> b) { return cmul_g(a, b); }
 TWX_HD cpx<float> cmulc(cpx<float> a, cpx<float> b) { return cmulc_g(a, b); }
 #endif
@@ -86,6 +113,8 @@ template <typename T> TWX_HD cpx<T> cmul(cpx<T> a, cpx<T> b) {
 template <typename T> TWX_HD cpx<T> cmulc(cpx<T> a, cpx<T> b) {  // a * conj(b)
     return mk<T>(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
+template <typename T> TWX_HD cpx<T> cmul3(cpx<T> a, cpx<T> b, cpx<T> c) { return cmul(cmul(a, b), c); }
+template <typename T> TWX_HD cpx<T> cmulc3(cpx<T> a, cpx<T> b, cpx<T> c) { return cmulc(cmulc(a, b), c); }
 template <typename T> TWX_HD cpx<T> cconj(cpx<T> a) { return mk<T>(a.x, -a.y); }
 template <typename T> TWX_HD cpx<T> cscale(cpx<T> a, T s) { return mk<T>(a.x * s, a.y * s); }
 template <typename T> TWX_HD T cnorm(cpx<T> a) { return a.x * a.x + a.y * a.y; }
@@ -464,8 +493,7 @@ template <class P, typename T> struct RowD {
         lds[phys(0, i1, i2)] = v[0];
         TWX_UNROLL
         for (int q0 = 1; q0 < R0; ++q0) {
-            const C w = cmul(tabs[tab_b + q0 * R + i2], tabs[tab_c + q0 * R + i1]);
-            lds[phys(q0, i1, i2)] = cmul(v[q0], w);
+            lds[phys(q0, i1, i2)] = cmul3(v[q0], tabs[tab_b + q0 * R + i2], tabs[tab_c + q0 * R + i1]);
         }
     }
     static TWX_HD void f1(C* lds, const C* tabs, int q0, int i2, C* v) {
@@ -510,7 +538,7 @@ template <class P, typename T> struct RowD {
         } else {
             const C wa = tabs[tab_b + q0 * R + a];
             TWX_UNROLL
-            for (int b = 0; b < R; ++b) lds[phys(q0, b, a)] = cmulc(v[b], cmul(wa, tabs[tab_c + q0 * R + b]));
+            for (int b = 0; b < R; ++b) lds[phys(q0, b, a)] = cmulc3(v[b], wa, tabs[tab_c + q0 * R + b]);
         }
     }
     static TWX_HD void iC(const C* lds, int t, C* v) {                            // → v[c] = z[t + M c]

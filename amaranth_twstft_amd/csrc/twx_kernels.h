@@ -711,7 +711,7 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
                         C e;
                         if constexpr (RL % 2 == 0) e = a.eb[(rho * 2 + (r >= RL / 2 ? 1 : 0)) * RL + r];   // wave-uniform → scalar load
                         else e = s_eb[(rho * 2 + ((2 * (lt + r * NSL) >= N2) ? 1 : 0)) * RL + r];
-                        v[r] = cmul(cmul(pr[r], eaj), e);
+                        v[r] = cmul3(pr[r], eaj, e);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(NT, TWX_ROW_WAVES) void k_row(RowArgs<T> a) {
                 C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
                 TWX_UNROLL
                 for (int q = 0; q < RIL; ++q) {
-                    C o = cmul(cmul(v[q], u), s_vc[q]);                     // · W_N^{-k1 q2} · ramp1
+                    C o = cmul3(v[q], u, s_vc[q]);                     // · W_N^{-k1 q2} · ramp1
                     if (TWX_ABL == 1) { asm volatile("" ::"v"(o)); } else (out + q * NSI)[(unsigned)lt] = o;
                 }
             }
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                 const C uu = cmul(ub, r1);
                 C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
                 TWX_UNROLL
-                for (int c = 0; c < R0; ++c) (out + c * M)[(unsigned)lt] = cmul(cmul(v[c], uu), s_vc[c]);   // · W_N^{-k1 q2} · ramp1
+                for (int c = 0; c < R0; ++c) (out + c * M)[(unsigned)lt] = cmul3(v[c], uu, s_vc[c]);   // · W_N^{-k1 q2} · ramp1
             }
             if (rho + 1 < a.nphase && lact) {
                 const int rn = rho + 1;
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                     C e;
                     if constexpr (R % 2 == 0) e = s_eb[(rn * 2 + (q2 >= R / 2 ? 1 : 0)) * R + q2];      // uniform address: LDS broadcast
                     else e = s_eb[(rn * 2 + ((2 * D::k_of(lq0, lqi, q2) >= N2) ? 1 : 0)) * R + q2];
-                    v[q2] = cmul(cmul(pr[q2], eaj), e);
+                    v[q2] = cmul3(pr[q2], eaj, e);
                 }
                 D::iA_pre(tabs, lqi, v);
             }
