@@ -480,14 +480,12 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
             // chain of 25 load + store-acknowledge round trips (12 us per workgroup).
             TWX_UNROLL
             for (int q = 0; q < R; ++q) {
-                C w;
-                if constexpr (TWPRE) w = cmul(s_wq[q], ld_su<C>(tcb + (q * QS * W * (int)sizeof(C)), tcl));
+                if constexpr (TWPRE) v[q] = cmul3(v[q], s_wq[q], ld_su<C>(tcb + (q * QS * W * (int)sizeof(C)), tcl));
                 else {
                     const unsigned mq = (unsigned)(q * QS) * (unsigned)c0;              // wave-uniform: scalar loads
                     const C wq = cmul(a.ta[mq >> a.tshift], a.tb[mq & mask]);
-                    w = cmul(cmul(wq, wj), ld_su<C>(tcb + (q * QS * W * (int)sizeof(C)), tcl));
+                    v[q] = cmul(v[q], cmul3(wq, wj, ld_su<C>(tcb + (q * QS * W * (int)sizeof(C)), tcl)));
                 }
-                v[q] = cmul(v[q], w);
             }
             __builtin_amdgcn_sched_barrier(0);
             TWX_UNROLL
