@@ -645,3 +645,24 @@ def test_stockham_row_pass_fallback(monkeypatch):
     ref = orc.ranging(raw, chips, fs=FS, Nint=1, n_channels=2, channels=(0,), band="numpy")
     for g, o in zip(got[0], ref[0]):
         _check(g, o)
+
+
+def test_host_pipeline_many_chunks_per_window_df():
+    """twx_process_windows through the pinned pipeline: more chunks than slots, a ragged tail, per-window df."""
+    nchips, n, nwin = 10000, 20000, 64 * 3 + 64 + 5              # B = 64 for this length: 4 full chunks + a 5-window tail
+    chips = chips_for(14, 43, nchips)
+    p = synth.SynthParams(delay_q8=777 * 256, fstep=synth.fstep_for_df(1500.0, FS), phi0=3, amp=400,
+                          noise_gain=synth.noise_gain_for_sigma(300.0), seed=11)
+    raw = synth.synth_channel(n * nwin, chips, 2, p)
+    dfs = np.where(np.arange(nwin) % 3 == 0, 1500.0, 1500.0 + 40.0 * (np.arange(nwin) % 5))
+    with Correlator(chips, fs=FS, Nint=1) as cor:
+        assert cor.info.batch == 64
+        got = cor.process(raw, 1, 0, df=dfs)
+        assert len(got) == nwin
+        for w in (0, 1, 63, 64, 65, 191, 192, 255, 256, nwin - 1):
+            one = cor.process(raw[w * n:(w + 1) * n], 1, 0, df=float(dfs[w]))[0]
+            g = got[w]
+            assert g.indice == one.indice and g.xval == one.xval and g.correction == one.correction and g.df == dfs[w]
+        # windows mixed with the true offset see the full peak, the others a weaker one at the same lag
+        strong = [abs(got[w].xval) for w in range(nwin) if dfs[w] == 1500.0]
+        assert min(strong) > 0 and all(got[w].indice == 3 * 777 for w in range(nwin) if dfs[w] == 1500.0)
