@@ -666,3 +666,29 @@ def test_host_pipeline_many_chunks_per_window_df():
         # windows mixed with the true offset see the full peak, the others a weaker one at the same lag
         strong = [abs(got[w].xval) for w in range(nwin) if dfs[w] == 1500.0]
         assert min(strong) > 0 and all(got[w].indice == 3 * 777 for w in range(nwin) if dfs[w] == 1500.0)
+
+
+@pytest.mark.parametrize("snr_db", [-25.0, -20.0, -10.0])
+def test_wipeoff_snr_tracks_the_known_snr(snr_db):
+    """The property experiments/221127_SNR/interpolation_effect.m demonstrates (README table :43-51): the code
+    wipe-off estimate mean(y.*code)^2/var(y.*code) follows the known signal-to-noise ratio of a synthetic signal.
+    With the reference's rotate offset of -1 grid sample (godual_ranging.m:43) the estimate sits 0.4-0.7 dB low for
+    Nint = 1, 2 (the band-limited interpolation of a 2-samples-per-chip code) and 6 dB low for Nint = 0, where the
+    offset is a whole sample = half a chip; the reference only ever runs this formula with Nint = 1.  Above ~0 dB the
+    misaligned product's own variance dominates and the estimate saturates (+6.8 dB at a true +10 dB), so the check
+    covers the operating range of the link (README.md(221219):47: -9 dB)."""
+    nchips, n = 100000, 200000
+    chips = chips_for(17, 9, nchips)
+    amp = 300.0
+    sigma = amp / np.sqrt(2.0 * 10 ** (snr_db / 10))              # SNR = A^2 / (2 sigma^2): complex noise variance 2 sigma^2
+    p = synth.SynthParams(delay_q8=4321 * 256, fstep=0, phi0=123456789, amp=int(amp),
+                          noise_gain=synth.noise_gain_for_sigma(float(sigma)), seed=31)
+    raw = synth.synth_channel(n, chips, 2, p)
+    est = {}
+    for nint in (0, 1, 2):
+        with Correlator(chips, fs=FS, Nint=nint) as cor:
+            r = cor.process(raw, 1, 0, df=0.0)[0]
+        assert r.indice == (2 * nint + 1) * 4321
+        est[nint] = 10 * np.log10(r.SNRr + r.SNRi)
+    assert -0.9 < est[1] - snr_db < 0.1 and -1.1 < est[2] - snr_db < 0.1, est
+    assert abs(est[0] - (snr_db - 6.0)) < 0.6, est
