@@ -1000,6 +1000,7 @@ int twx_create(const twx_config* cfg, twx_ctx** out) {
         char b[200]; snprintf(b, sizeof b, "no compiled plan pair N1*N2 = %lld (see DESIGN.md §plans)", N);
         g_create_err = b; return TWX_E_SIZE;
     }
+    if ((col->W & (col->W - 1)) != 0) { g_create_err = "column tile width must be a power of two (tile-blocked A layout)"; return TWX_E_SIZE; }
     CtxBase* c = f64 ? static_cast<CtxBase*>(new Ctx<double>()) : static_cast<CtxBase*>(new Ctx<float>());
     c->cfg = *cfg; c->N = N; c->N1 = col->L; c->N2 = row->L; c->col = col; c->row = row;
     (void)hipGetDevice(&c->dev);
