@@ -18,6 +18,8 @@ TWX_F32, TWX_F64 = 0, 1
 TWX_OPT_REMOVE_MEAN = 1
 TWX_FLAG_PROFILE = 1
 TWX_FLAG_FINE_FREQ = 2
+TWX_FLAG_CODE_ZERO_MEAN = 4
+TWX_CODE_BIPOLAR, TWX_CODE_UNIPOLAR = 0, 1
 TWX_PROF_MAX = 16
 
 
@@ -33,7 +35,8 @@ class twx_config(C.Structure):
                 ("lfsr_bitlen", C.c_int32), ("lfsr_taps", C.c_int32),
                 ("convention", C.c_int32), ("window", C.c_int32), ("precision", C.c_int32),
                 ("var_ddof", C.c_int32), ("snr_rot", C.c_int32), ("device", C.c_int32),
-                ("max_batch", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("max_batch", C.c_int32), ("flags", C.c_int32), ("chips_q", C.POINTER(C.c_uint8)),
+                ("code_levels", C.c_int32), ("reserved", C.c_int32)]
 
 
 class twx_band(C.Structure):

@@ -89,7 +89,8 @@ class Correlator:
 
     def __init__(self, chips=None, fs: float = 5e6, sps: int = 2, Nint: int = 1, *, lfsr: tuple[int, int, int] | None = None,
                  precision: str = "f32", var_ddof: int = 0, snr_rot: int = -1, window: str = "none", convention: str = "godual",
-                 device: int = -1, max_batch: int = 0, profile: bool = False, fine_freq: bool = False):
+                 device: int = -1, max_batch: int = 0, profile: bool = False, fine_freq: bool = False,
+                 chips_q=None, code_levels: str = "bipolar", code_zero_mean: bool = False):
         self._lib = L.load()
         cfg = L.twx_config()
         cfg.fs, cfg.sps, cfg.nint = fs, sps, Nint
@@ -106,7 +107,15 @@ class Correlator:
         cfg.window = {"none": L.TWX_WIN_NONE, "hamming": L.TWX_WIN_HAMMING}[window]
         cfg.precision = {"f32": L.TWX_F32, "f64": L.TWX_F64}[precision]
         cfg.var_ddof, cfg.snr_rot, cfg.device, cfg.max_batch = var_ddof, snr_rot, device, max_batch
-        cfg.flags = (L.TWX_FLAG_PROFILE if profile else 0) | (L.TWX_FLAG_FINE_FREQ if fine_freq else 0)
+        cfg.flags = ((L.TWX_FLAG_PROFILE if profile else 0) | (L.TWX_FLAG_FINE_FREQ if fine_freq else 0)
+                     | (L.TWX_FLAG_CODE_ZERO_MEAN if code_zero_mean else 0))
+        # replica variants of the experiment scripts (220616_Besancon/godual.m:5-7, 220822_qpsk_vs_bpsk/goqpsk.m:10-14)
+        cfg.code_levels = {"bipolar": L.TWX_CODE_BIPOLAR, "unipolar": L.TWX_CODE_UNIPOLAR}[code_levels]
+        if chips_q is not None:
+            self._chips_q = np.ascontiguousarray(chips_q, dtype=np.uint8)
+            if chips is None or self._chips_q.size != self._chips.size:
+                raise ValueError("chips_q needs chips of the same length")
+            cfg.chips_q = self._chips_q.ctypes.data_as(C.POINTER(C.c_uint8))
         h = C.c_void_p()
         L.check(self._lib.twx_create(C.byref(cfg), C.byref(h)))
         self._h = h

@@ -73,6 +73,22 @@ __global__ void k_convert(const cpx<S>* __restrict__ in, cpx<D>* __restrict__ ou
         out[i] = mk<D>((D)(in[i].x * scale), (D)(in[i].y * scale));
 }
 
+// Replica variants on the finished code spectrum S = conj(FFT(2c-1)) (layout [k1][k2], DC at index 0), all exact in
+// the spectrum because they only differ by a constant in the time domain:
+//   0/1 levels:  conj(FFT(c)) = S/2 (+ N/2 at DC);  zero mean: DC = 0;  complex code ci + j cq: Si - j Sq.
+template <typename T>
+__global__ void k_code_variant(cpx<T>* __restrict__ si, const cpx<T>* __restrict__ sq, long long n, int unipolar, int zero_mean, double dc_add) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        double x = (double)si[i].x, y = (double)si[i].y, qx = 0, qy = 0;
+        if (sq) { qx = (double)sq[i].x; qy = (double)sq[i].y; }
+        if (unipolar) { x *= 0.5; y *= 0.5; qx *= 0.5; qy *= 0.5; if (i == 0) { x += dc_add; if (sq) qx += dc_add; } }
+        // Si - j*Sq
+        double rx = x + qy, ry = y - qx;
+        if (zero_mean && i == 0) { rx = 0; ry = 0; }
+        si[i] = mk<T>((T)rx, (T)ry);
+    }
+}
+
 // chips of LFSR(bitlen,taps), seed 1, one byte per chip (amaranth_twstft/common.py:23-30,59-73).
 // Every thread jumps to its segment by applying the 2^j-step transition matrices
 // (precomputed on the host), then runs the bit-serial recurrence.
@@ -233,6 +249,7 @@ struct CtxBase {
         prof_pending.clear();
     }
     int remove_mean = 1;          // TWX_OPT_REMOVE_MEAN
+    int snr_valid = 1;            // 0 for replicas that are not a +-1 code
     virtual int init() = 0;
     virtual int sync_all() = 0;
     virtual int pipeline_depth() const = 0;
@@ -497,6 +514,34 @@ template <typename T> struct Ctx : CtxBase {
         }
         if (int rc = make_tables()) return rc;
         if (int rc = make_code_spectrum()) return rc;
+        {   // replica variants (header: chips_q, code_levels, TWX_FLAG_CODE_ZERO_MEAN)
+            const int unipolar = cfg.code_levels == TWX_CODE_UNIPOLAR, zero_mean = (cfg.flags & TWX_FLAG_CODE_ZERO_MEAN) != 0;
+            if (cfg.code_levels != TWX_CODE_BIPOLAR && cfg.code_levels != TWX_CODE_UNIPOLAR) return fail(TWX_E_ARG, "bad code_levels");
+            snr_valid = !(unipolar || zero_mean || cfg.chips_q);
+            if (!snr_valid) {
+                if (cfg.window != TWX_WIN_NONE) return fail(TWX_E_ARG, "the Hamming-windowed replica is only defined for the +-1 code");
+                if (cfg.chips_q && !cfg.chips) return fail(TWX_E_ARG, "chips_q needs chips");
+                C* cq = nullptr;
+                if (cfg.chips_q) {
+                    for (long long i = 0; i < cfg.n_chips; ++i)
+                        if (cfg.chips_q[i] > 1) return fail(TWX_E_ARG, "chips_q must be bytes 0/1");
+                    unsigned char* ci_dev = chips_dev; unsigned char* cq_dev = nullptr;
+                    if (int rc = dalloc(&cq_dev, (size_t)cfg.n_chips)) return rc;
+                    HIPCHK(hipMemcpy(cq_dev, cfg.chips_q, (size_t)cfg.n_chips, hipMemcpyHostToDevice));
+                    C* ci_spec = cspec; cspec = nullptr; chips_dev = cq_dev;
+                    int rc = make_code_spectrum();            // allocates a fresh cspec for the quadrature chips
+                    cq = cspec; cspec = ci_spec; chips_dev = ci_dev;
+                    dfree(cq_dev);
+                    if (rc) return rc;
+                }
+                // spectrum values carry scale_pow2; DC of an all-ones window is N (the conj is real)
+                TWX_LAUNCH((k_code_variant<T>), dim3(1024), dim3(256), stream, cspec, (const C*)cq, (long long)N, unipolar, zero_mean,
+                           0.5 * (double)N * scale_pow2);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(stream));
+                if (cq) dfree(cq);
+            }
+        }
         if (use_rowd) {
             if (int rc = dalloc(&cspec_perm, (size_t)N)) return rc;
             const int Rr = row->R[row->S - 1], R0 = row->S == 3 ? row->R[0] : 1;
@@ -651,7 +696,7 @@ template <typename T> struct Ctx : CtxBase {
         PeakArgs<T> pa{};
         pa.n = N; pa.n1 = N1; pa.n2 = N2; pa.nphase = R; pa.nparts = R * ntiles; pa.part = part_peak; pa.Bz = Bz; pa.tw1d = tw1d;
         pa.sums = sums; pa.remove_mean = remove_mean; pa.dc = dc; pa.dfv = dfv; pa.dfidx = dfidx; pa.inv_scale = 1.0 / scale_pow2;
-        pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.convention = cfg.convention; pa.res = out_dev;
+        pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.convention = cfg.convention; pa.snr_valid = snr_valid; pa.res = out_dev;
         {
             ProfScope ps(this, PC_PEAK, nb);
             TWX_LAUNCH((k_peak<T>), dim3(nb), dim3(1024), stream, pa);

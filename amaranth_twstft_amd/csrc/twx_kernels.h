@@ -1168,6 +1168,7 @@ template <typename T> struct PeakArgs {
     double inv_scale;            // undoes RowArgs::scale
     int var_ddof, snr_rot;
     int convention;              // TWX_CONV_*
+    int snr_valid;               // 0: replica is not a +-1 code, the wipe-off statistics are undefined
     twx_result* res;             // [b]
 };
 
@@ -1248,6 +1249,7 @@ __global__ __launch_bounds__(1024) void k_peak(PeakArgs<T> a) {
         const double R2 = (double)a.nphase * (double)a.nphase;
         const double sum_yint = (double)M * (sumsq / N) / R2;                             // sum|yint|^2
         const double var = (sum_yint - (double)M * (mr * mr + mi * mi)) / ((double)M - a.var_ddof);
+        if (!a.snr_valid) ok = 0;
         r.SNRr = ok ? mr * mr / var : nan("");
         r.SNRi = ok ? mi * mi / var : nan("");
         r.puissancecode = ok ? mr * mr + mi * mi : nan("");

@@ -39,9 +39,13 @@ enum { TWX_CONV_GODUAL = 0,   /* fft(y).*conj(fft(code))   godual_ranging.m:26,6
 enum { TWX_WIN_NONE = 0, TWX_WIN_HAMMING = 1 };   /* Hamming on fcode: processing/CPP/main.cpp:717-719 */
 enum { TWX_F32 = 0, TWX_F64 = 1 };
 enum { TWX_FLAG_PROFILE = 1,                      /* time every kernel launch with HIP events */
-       TWX_FLAG_FINE_FREQ = 2 };                  /* add the phase-drift fine carrier step of
+       TWX_FLAG_FINE_FREQ = 2,                    /* add the phase-drift fine carrier step of
                                                      experiments/221219_twoway/processing/godual_ranging.py:26-30
                                                      (needs N >= fs/3; off = processing/Octave/godual_ranging.m) */
+       TWX_FLAG_CODE_ZERO_MEAN = 4 };             /* replica = code - mean(code): experiments/220616_Besancon/godual.m:7,
+                                                     experiments/220822_qpsk_vs_bpsk/goqpsk.m:13 */
+/* Replica chip levels: 2*c-1 (godual_ranging.m:65) or the raw 0/1 bytes (220616_Besancon/godual.m:5-7, goqpsk.m:5-12). */
+enum { TWX_CODE_BIPOLAR = 0, TWX_CODE_UNIPOLAR = 1 };
 
 /* Replaces the script constants / globals `fs Nint code fcode` (godual_ranging.m:3-5,62-66),
  * GoRanging's constructor arguments (processing/CPP/main.cpp:93-189). */
@@ -62,7 +66,12 @@ typedef struct twx_config {
     int32_t device;          /* HIP device ordinal, -1 = current */
     int32_t max_batch;       /* channel-windows per launch (0 = default) */
     int32_t flags;           /* TWX_FLAG_* */
-    int32_t reserved[4];
+    const uint8_t* chips_q;  /* NULL, or n_chips quadrature chips: complex replica chips + j*chips_q
+                                (QPSK code of experiments/220822_qpsk_vs_bpsk/goqpsk.m:10-12).  With a complex,
+                                unipolar or zero-mean replica the wipe-off statistics SNRr, SNRi, puissancecode and
+                                puissancenoise are not defined (they rely on |code| = 1) and are returned as NaN. */
+    int32_t code_levels;     /* TWX_CODE_* */
+    int32_t reserved;
 } twx_config;
 
 /* Carrier search band `k` of processing(d,k) (godual_ranging.m:83-89): inclusive range of

@@ -55,6 +55,21 @@ def make_code(chips: np.ndarray, sps: int = 2) -> np.ndarray:
     return np.repeat(np.asarray(chips, dtype=np.float64), sps) * 2.0 - 1.0
 
 
+def make_code_variant(chips, chips_q=None, sps: int = 2, unipolar: bool = False, zero_mean: bool = False) -> np.ndarray:
+    """Replica variants of the experiment scripts — UNPINNED (Octave only):
+    0/1 levels and ``code=code-mean(code)`` (experiments/220616_Besancon/godual.m:5-7, mean removed after repelems);
+    complex QPSK code ``codec=codei+j*codeq; codec=codec-mean(codec); repelems`` (experiments/220822_qpsk_vs_bpsk/
+    goqpsk.m:10-14, mean removed before repelems — the same thing, the hold does not change the mean)."""
+    lev = (lambda c: np.asarray(c, dtype=np.float64)) if unipolar else (lambda c: 2.0 * np.asarray(c, dtype=np.float64) - 1.0)
+    code = lev(chips).astype(np.complex128 if chips_q is not None else np.float64)
+    if chips_q is not None:
+        code = code + 1j * lev(chips_q)
+    code = np.repeat(code, sps)
+    if zero_mean:
+        code = code - code.mean()
+    return code
+
+
 def make_fcode(code: np.ndarray, convention: str = "godual") -> np.ndarray:
     """Code spectrum.
 

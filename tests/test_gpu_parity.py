@@ -692,3 +692,31 @@ def test_wipeoff_snr_tracks_the_known_snr(snr_db):
         est[nint] = 10 * np.log10(r.SNRr + r.SNRi)
     assert -0.9 < est[1] - snr_db < 0.1 and -1.1 < est[2] - snr_db < 0.1, est
     assert abs(est[0] - (snr_db - 6.0)) < 0.6, est
+
+
+@pytest.mark.parametrize("variant", ["besancon", "qpsk"])
+def test_replica_variants_of_the_experiment_scripts(variant):
+    """Zero-mean 0/1 code (experiments/220616_Besancon/godual.m:5-8) and complex QPSK code
+    (experiments/220822_qpsk_vs_bpsk/goqpsk.m:10-16), both with ``prnmap=ifft(fft(y).*fcode)`` (Nint = 0)."""
+    nchips, n = 10000, 20000
+    ci = chips_for(14, 43, nchips)
+    cq = chips_for(14, 57, nchips) if variant == "qpsk" else None
+    p = synth.SynthParams(delay_q8=2345 * 256, fstep=synth.fstep_for_df(900.0, FS), phi0=17, amp=400,
+                          noise_gain=synth.noise_gain_for_sigma(250.0), seed=13)
+    raw = synth.synth_channel(n, ci, 2, p)
+    code = orc.make_code_variant(ci, cq, 2, unipolar=True, zero_mean=True)
+    fcode = np.conj(np.fft.fft(code))
+    with Correlator(ci, fs=FS, Nint=0, chips_q=cq, code_levels="unipolar", code_zero_mean=True) as cor:
+        cs = cor.code_spectrum()
+        assert np.abs(cs - fcode).max() <= 2e-7 * np.abs(fcode).max() and abs(cs[0]) <= 1e-6 * np.abs(fcode).max()
+        g = cor.process(raw, 1, 0, df=900.0)[0]
+        zmap = cor.xcorr_map(raw, 900.0)
+    d = orc.deinterleave(raw, 1, 0)
+    d = d - d.mean()
+    y = d * np.exp(-2j * np.pi * 900.0 * np.arange(n) / FS)
+    ref = np.fft.ifft(np.fft.fft(y) * fcode)
+    assert np.abs(zmap - ref).max() <= 2e-6 * np.abs(ref).max()
+    ind = int(np.abs(ref).argmax())
+    assert g.indice == ind == 2345
+    assert abs(abs(g.xval) - abs(ref[ind])) <= MAG_TOL * abs(ref[ind])
+    assert np.isnan(g.SNRr) and np.isnan(g.puissancenoise) and g.puissance > 0          # wipe-off statistics undefined here
