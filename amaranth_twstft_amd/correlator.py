@@ -72,6 +72,17 @@ class WindowResult:
     puissancecode: float
     puissancenoise: float
 
+    def correction_polyfit(self, half_width: int) -> float:
+        """Parabola through 2·half_width+1 magnitude samples around the peak, ``[u,v]=polyfit([-h:+h]',abs(prnmap(indice-h:
+        indice+h)),2); -u(2)/2/u(1)`` — ``correction1_1/_2/_3`` of experiments/221207_twoway_codes/processing/
+        godual_ranging.m:73-78 (half_width 1, 2, 3), from the seven peak samples the device returns in ``zwin``."""
+        if not 1 <= half_width <= 3:
+            raise ValueError("half_width must be 1, 2 or 3")
+        x = np.arange(-half_width, half_width + 1, dtype=float)
+        y = np.abs(self.zwin[3 - half_width:3 + half_width + 1])
+        u = np.polyfit(x, y, 2)
+        return float(-u[1] / 2 / u[0])
+
     def delay(self, fs: float, nint: int, sign: int = +1) -> float:
         """``(indice-1±correction)/fs/(2*Nint+1)`` as printed by godual_ranging.m:96."""
         return (self.indice + sign * self.correction) / fs / (2 * nint + 1)

@@ -173,6 +173,14 @@ def peak_refine(prnmap: np.ndarray, wrap: bool = True):
     return indice, correction, xval, xvalm1, xvalp1
 
 
+def peak_refine_polyfit(prnmap: np.ndarray, indice: int, half_width: int) -> float:
+    """``correction1_1/_2/_3`` of experiments/221207_twoway_codes/processing/godual_ranging.m:73-78 (circular indices)."""
+    n = len(prnmap)
+    idx = (indice + np.arange(-half_width, half_width + 1)) % n
+    u = np.polyfit(np.arange(-half_width, half_width + 1, dtype=float), np.abs(prnmap[idx]), 2)
+    return float(-u[1] / 2 / u[0])
+
+
 def snr_wipeoff(ffty: np.ndarray, code: np.ndarray, indice: int, Nint: int,
                 rot: int = -1, ddof: int = 0):
     """godual_ranging.m:38-48 / godual_ranging.py:55-64.

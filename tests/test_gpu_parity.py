@@ -96,6 +96,12 @@ def test_df_supplied_and_full_map():
             zr = orc.xcorr_interp(np.fft.fft(d * np.exp(-2j * np.pi * df * temps)), fcode, 1)
             assert np.abs(z - zr).max() <= 1e-6 * np.abs(zr).max()
             assert int(np.abs(z).argmax()) == o["indice"]
+            # the seven peak samples and the 3/5/7-point parabola fits of 221207 godual_ranging.m:73-78
+            zw = zr[(o["indice"] + np.arange(-3, 4)) % len(zr)]
+            assert np.abs(got[w].zwin - zw).max() <= 2 * MAG_TOL * abs(o["xval"])
+            for h in (1, 2, 3):
+                assert abs(got[w].correction_polyfit(h) - orc.peak_refine_polyfit(zr, o["indice"], h)) < 2e-4
+            assert abs(got[w].correction_polyfit(1) - got[w].correction) < 1e-9       # 3 points: the same parabola as :33
 
 
 @pytest.mark.parametrize("Nint", [0, 2])
