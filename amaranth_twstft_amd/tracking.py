@@ -119,3 +119,17 @@ def tracking_update(cor: np.ndarray, phi: np.ndarray, nlag: int, state: dict) ->
     state["pt_prev"] = pt
     state["pt"] = int(round((g0 + g1) * fs / 1.0e9))
     return out
+
+
+def prn_sampling(nobs: int, code, rc: float, fs: float, delay_ns: float = 0.0) -> np.ndarray:
+    """Replica sampled at ``fs`` from a chip sequence clocked at ``rc`` chips/s and delayed by ``delay_ns``:
+    ``idx=floor(fmod((i/fs-delay*1e-9)*rc, clen))`` wrapped into [0, clen) — ``PRN_sampling`` of
+    experiments/231001_DLL_PLL/rxcomplex.cpp:965-978 (any fs/rc ratio, fractional delays).  ``code`` holds the chip
+    VALUES (±1 as ``SDRcode`` produces them); returns float32 of length ``nobs`` for :func:`sliding_dot`."""
+    code = np.asarray(code)
+    clen = code.size
+    i = np.arange(nobs, dtype=np.float64)
+    idx = np.floor(np.fmod((i / fs - delay_ns * 1.0e-9) * rc, float(clen))).astype(np.int64)
+    idx = np.where(idx < 0, idx + clen, idx)
+    idx = np.where(idx >= clen, idx - clen, idx)
+    return code[idx].astype(np.float32)

@@ -49,3 +49,28 @@ def test_tracking_epoch_needs_half_of_the_periods():
     cor[:, 0] = 1.0                                                      # peak at the window edge everywhere → unusable
     st = dict(fc=0.0, pt=0, last_phi=0.0, fs=fs, duration=nobs / fs)
     assert tracking.tracking_update(cor, phi, nlag, st) is None and st["fc"] == 0.0
+
+
+def test_prn_sampling_follows_the_reference_formula():
+    """rxcomplex.cpp:965-978 evaluated in the same double arithmetic (scalar loop), including its rounding: i/fs*rc
+    lands just below an integer for some i, so the replica is the x2 sample-and-hold of the chips
+    (godual_ranging.m:64 ``repelems``) except at those isolated samples."""
+    import math
+    rng = np.random.default_rng(3)
+    code = rng.integers(0, 2, 1000) * 2 - 1
+    fs, rc, clen = 5e6, 2.5e6, 1000
+    for delay in (0.0, 200.0, -100.0, 123.456):
+        got = tracking.prn_sampling(2000, code, rc, fs, delay)
+        want = np.empty(2000, dtype=np.float32)
+        for i in range(2000):
+            idx = int(math.floor(math.fmod((float(i) / fs - delay * 1.0e-9) * rc, float(clen))))
+            if idx < 0:
+                idx += clen
+            elif idx >= clen:
+                idx -= clen
+            want[i] = code[idx]
+        assert np.array_equal(got, want)
+    r0 = tracking.prn_sampling(2000, code, rc, fs, 0.0)
+    assert np.mean(r0 == np.repeat(code, 2)) > 0.97
+    r2 = tracking.prn_sampling(3000, code, rc, 7.5e6, 0.0)                  # 3 samples per chip
+    assert np.mean(r2 == np.repeat(code, 3)) > 0.97
