@@ -255,6 +255,13 @@ class Correlator:
                 break
         return fc, best_pk, best_lag
 
+    @staticmethod
+    def acquisition_gate(pk: float, px: float, snr_min: float, psbb: float = 1.0):
+        """Lock decision after :meth:`acquire`: peak signal power ``8*pk^2/psbb`` against the total received power ``px``,
+        ``(1+snr_min)*pk_power > snr_min*px`` (rxcomplex.cpp:570-573).  Returns (locked, pk_power)."""
+        pk_power = 8.0 * pk * pk / psbb
+        return (1.0 + snr_min) * pk_power > snr_min * px, pk_power
+
     # -- inspection ----------------------------------------------------------------------
     def fft(self, x) -> np.ndarray:
         x = np.ascontiguousarray(x, dtype=np.complex128)

@@ -110,3 +110,11 @@ def test_mex_gateway_type_checks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(root, "tests", "cpu", "mex_stub"),
                     "-I" + os.path.join(root, "include"), os.path.join(root, "mex", "twstft_processing_mex.cpp")], check=True)
+
+
+def test_acquisition_gate_formula():
+    """rxcomplex.cpp:570-573."""
+    locked, p = cor.Correlator.acquisition_gate(pk=0.5, px=10.0, snr_min=0.1, psbb=2.0)
+    assert p == 1.0 and locked == ((1.1 * 1.0) > (0.1 * 10.0))
+    locked, _ = cor.Correlator.acquisition_gate(pk=0.1, px=10.0, snr_min=0.1, psbb=2.0)
+    assert not locked
