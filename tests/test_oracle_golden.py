@@ -136,3 +136,21 @@ def test_claudio_convention_is_mirrored_godual():
     assert c["indice"] == (M - g["indice"]) % M
     assert abs(c["xval"] - np.conj(g["xval"])) < 1e-9 * abs(g["xval"])
     assert abs(c["correction"] + g["correction"]) < 1e-9
+
+
+def test_tracked_loop_restatement_aligns_the_window():
+    """oracle.ranging_tracked (claudio_aligned_code_ranging_separate.m:143-205): carrier found by search_df, the first
+    code re-aligns the window so the peak sits at sample 21 (:176), later codes stay aligned, the carry-over keeps
+    the code count equal to the number of whole code periods."""
+    from amaranth_twstft_amd import synth
+    nchips, n, ncodes = 10000, 20000, 120
+    chips = chips_for(14, 43, nchips)
+    p = synth.SynthParams(delay_q8=1500 * 256, fstep=synth.fstep_for_df(30.0, 5e6), phi0=5, amp=500,
+                          noise_gain=synth.noise_gain_for_sigma(300.0), seed=3)
+    raw = synth.synth_channel(n * ncodes, chips, 2, p)
+    out = orc.ranging_tracked(raw, chips, fs=5e6, ls_samples=50 * n)
+    assert out["kbon"] > 0 and abs(out["df"][0] - 30.0) < 2.5
+    assert out["moved"] == [1] and abs(out["movedval"][0] - ((n - 1500) + 1 + 1 / 3)) < 1.0
+    ind = np.array(out["indice1"])
+    assert ind[0] == 64.0 and np.all(np.abs(ind[1:] - 64.0 / 3) < 1e-9)          # raw 3N index after the move, /3 afterwards
+    assert len(ind) == 2 * 50 - 1                                                  # 2 whole chunks; the move costs one code
