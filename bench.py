@@ -173,8 +173,8 @@ def main():
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": ("processing(d,k) full chain" if a.workload == "processing" else "xcorr, df supplied")
-                      + ": the capture of BASELINE.json configs[1] (1 s windows, 5 Msps int16 IQ, 2.5 Mchip LFSR(22,3) code), Nint=1;"
-                        " configs[1]'s own code-phase-only xcorr is reported under other_workload",
+                      + ": the capture of BASELINE.json configs[1] (1 s windows, 5 Msps int16 IQ, 2.5 Mchip LFSR(22,3) code), Nint=1"
+                      + ("; configs[1]'s own code-phase-only xcorr is reported under other_workload" if a.workload == "processing" else ""),
                       "windows_per_gpu_per_step": nwin, "samples_per_window": N, "batch": int(cor.info.batch),
                       "n1": int(cor.info.n1), "n2": int(cor.info.n2), "sharding": f"windows/{world}"},
            "integer_lag_exact": bool(lag_ok),
