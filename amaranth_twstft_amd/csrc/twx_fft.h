@@ -541,6 +541,12 @@ template <class P, typename T> struct RowD {
             for (int b = 0; b < R; ++b) lds[phys(q0, b, a)] = cmulc3(v[b], wa, tabs[tab_c + q0 * R + b]);
         }
     }
+    // R0 == 1: stage B without the write-back — thread (block, a) ends with v[b] = z[a + R b]
+    static TWX_HD void iB_keep(const C* lds, int q0, int a, C* v) {
+        TWX_UNROLL
+        for (int r = 0; r < R; ++r) v[r] = lds[phys(q0, r, a)];
+        Bfly<T, R, true>::run(v);
+    }
     static TWX_HD void iC(const C* lds, int t, C* v) {                            // → v[c] = z[t + M c]
         const int b = t / R, a = t % R;
         TWX_UNROLL

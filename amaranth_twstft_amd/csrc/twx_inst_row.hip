@@ -35,9 +35,17 @@ template <typename T> int rowd(int mode, const void* args, unsigned nblk, hipStr
     if constexpr (HasRowD<P>::value) {
         constexpr int NTD = RowD<P, T>::NT_MIN;
         const RowDArgs<T>& a = *reinterpret_cast<const RowDArgs<T>*>(args);
+        if constexpr (RowD<P, T>::R0 == 1 && std::is_same<T, float>::value) {     // short rows: several rows per workgroup
+            constexpr int NTS = 448, G = (NTS / 64) * RowD<P, T>::BPW;
+            const unsigned grid = (nblk + G - 1) / G;
+            if (mode == ROW_BAND) TWX_LAUNCH((k_rowd_small<P, T, ROW_BAND, NTS>), dim3(grid), dim3(NTS), s, a, nblk);
+            else if (mode == ROW_MID) TWX_LAUNCH((k_rowd_small<P, T, ROW_MID, NTS>), dim3(grid), dim3(NTS), s, a, nblk);
+            else return -1;
+        } else {
         if (mode == ROW_BAND) TWX_LAUNCH((k_rowd<P, T, ROW_BAND, NTD>), dim3(nblk), dim3(NTD), s, a);
         else if (mode == ROW_MID) TWX_LAUNCH((k_rowd<P, T, ROW_MID, NTD>), dim3(nblk), dim3(NTD), s, a);
         else return -1;
+        }
         return (int)hipGetLastError();
     } else {
         return -1;

@@ -902,6 +902,135 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_rowd_small: the row pass for SHORT rows N2 = R*R (R0 = 1, e.g. 400 = 20*20: the 5 k ... 25 k chip codes).
+// A row is one block of RowD, i.e. the work of R lanes, so one workgroup takes G = (NT/64)*(64/R) rows — one per
+// R-lane group — instead of leaving all but R lanes of 448 idle.  After the load phase nothing crosses a wave:
+// one workgroup barrier in total.  Same epilogues and the same arithmetic as k_rowd.
+// grid = ceil(rows / G), rows = N1 * windows
+// ------------------------------------------------------------------------------------------
+template <class P2, typename T, int MODE, int NT>
+__global__ __launch_bounds__(NT) void k_rowd_small(RowDArgs<T> ad, unsigned int total_rows) {
+    using C = cpx<T>;
+    using D = RowD<P2, T>;
+    static_assert(D::R0 == 1, "k_rowd_small is the R0 == 1 form");
+    const RowArgs<T>& a = ad.r;
+    constexpr int N2 = D::L, R = D::R, M = D::M, BPW = D::BPW, G = (NT / 64) * BPW;
+    constexpr int NEB = MODE == ROW_MID ? TWX_MAX_PHASE * 2 * R : 0;
+    __shared__ C lds[G * D::BK];
+    static_assert(sizeof(ArgPart<T>) <= sizeof(C), "arg-max records share the per-row scratch");
+    __shared__ C tabs[R * R + NEB + G * R];                       // tab_a | phase ramp (MID) | per-row scratch [G][R]
+    C* s_eb = tabs + R * R;
+    C* s_vcr = s_eb + NEB;                                        // MID: W_N^{-k1 R b} per row
+    ArgPart<T>* s_red = reinterpret_cast<ArgPart<T>*>(s_vcr);     // BAND: per-lane arg-max records
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, l = tid & 63;
+    const int g = wv * BPW + l / R, q1 = l % R;                   // row slot of this lane, position inside the row
+    const unsigned row_id = blockIdx.x * G + (unsigned)g;
+    const bool act = (l < BPW * R) && row_id < total_rows;
+    const unsigned rid = act ? row_id : (blockIdx.x * G);         // a valid row for address arithmetic of idle lanes
+    const int k1 = rid / a.nwin, b = rid % a.nwin;
+    const unsigned mask = (1u << a.tshift) - 1u;
+    // ---- tables, then the rows: every thread copies elements t = tid, tid+NT, ... of the G*M element group
+    for (int i = tid; i < R * R; i += NT) tabs[i] = ad.dtabs[i];
+    if constexpr (MODE == ROW_MID) {
+        for (int i = tid; i < a.nphase * 2 * R; i += NT) s_eb[i] = ad.eb_d[i];
+        if (act) {
+            const unsigned m = (unsigned)k1 * (unsigned)(q1 * R);                  // conj(W_N^{k1 R b}), b = q1
+            s_vcr[g * R + q1] = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
+        }
+    }
+    constexpr int NLD = (G * M + NT - 1) / NT;
+    C ld[NLD];
+    TWX_UNROLL
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + k * NT;
+        const unsigned rr = blockIdx.x * G + (unsigned)(idx / M);
+        const int t = idx % M;
+        const bool ok = idx < G * M && rr < total_rows;
+        const unsigned r2 = ok ? rr : blockIdx.x * G;
+        ld[k] = (a.A + (long long)(r2 % a.nwin) * a.n)[a_index((unsigned)t, r2 / a.nwin, (unsigned)a.n1, a.wshift)];
+    }
+    C csr[MODE == ROW_MID ? R : 1];
+    if constexpr (MODE == ROW_MID) {
+        const C* cs = ad.cspec_perm + (long long)k1 * N2;
+        TWX_UNROLL
+        for (int q2 = 0; q2 < R; ++q2) csr[q2] = (cs + q2 * R)[(unsigned)q1];
+    }
+    TWX_UNROLL
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + k * NT;
+        if (idx < G * M) { const int t = idx % M; lds[D::phys(idx / M, t / R, t % R)] = ld[k]; }
+    }
+    __syncthreads();
+    C v[R];
+    if (act) D::f1(lds, tabs, g, q1, v);
+    wave_sync_lds();
+    if (act) D::f2(lds, g, q1, v);                                 // v[q2] = X[k1 + N1*(q1 + R q2)]
+
+    if constexpr (MODE == ROW_BAND) {
+        Best<T> best; best.val = T(-1); best.idx = 0xffffffffu;
+        if (act) {
+            const long long half = a.n / 2;
+            TWX_UNROLL
+            for (int q2 = 0; q2 < R; ++q2) {
+                const long long k = (long long)k1 + (long long)a.n1 * (q1 + R * q2);
+                long long i = k - (a.n - half); if (i < 0) i += a.n;
+                if (i >= a.band_lo && i <= a.band_hi) best.take(cnorm(v[q2]), (unsigned int)i);
+            }
+            ArgPart<T> p; p.val = best.val; p.idx = best.idx;
+            s_red[g * R + q1] = p;
+        }
+        wave_sync_lds();
+        if (act && q1 == 0) {
+            TWX_UNROLL
+            for (int j = 1; j < R; ++j) { const ArgPart<T> p = s_red[g * R + j]; best.take(p.val, p.idx); }
+            ArgPart<T> p; p.val = best.val; p.idx = best.idx;
+            a.part[(long long)b * a.n1 + k1] = p;
+        }
+    } else {
+        C pr[R];
+        C ua = mk<T>(1, 0);
+        if (act) {
+            const unsigned m = (unsigned)k1 * (unsigned)q1;                        // W_N^{-k1 a}, a = q1
+            ua = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
+            if (k1 == 0 && q1 == 0) a.dc[b] = v[0];
+            TWX_UNROLL
+            for (int q2 = 0; q2 < R; ++q2) pr[q2] = cmul(v[q2], csr[q2]);          // ffty.*fcode (godual_ranging.m:26)
+        }
+        for (int rho = 0; rho < a.nphase; ++rho) {
+            int lq = q1;
+            asm volatile("" : "+v"(lq));                                           // keep address arithmetic inside the loop
+            if (act) {
+                if (rho == 0) {
+                    TWX_UNROLL
+                    for (int q2 = 0; q2 < R; ++q2) v[q2] = pr[q2];
+                } else {
+                    const C eaj = ad.ea_d[rho * R + lq];
+                    TWX_UNROLL
+                    for (int q2 = 0; q2 < R; ++q2) {
+                        C e;
+                        if constexpr (R % 2 == 0) e = s_eb[(rho * 2 + (q2 >= R / 2 ? 1 : 0)) * R + q2];
+                        else e = s_eb[(rho * 2 + ((2 * (lq + R * q2) >= N2) ? 1 : 0)) * R + q2];
+                        v[q2] = cmul3(pr[q2], eaj, e);
+                    }
+                }
+                D::iA_pre(tabs, lq, v);
+            }
+            wave_sync_lds();                       // this wave's reads of the previous phase are done (blocks are wave-local)
+            if (act) D::iA_store(lds, g, lq, v);
+            wave_sync_lds();
+            if (act) {
+                D::iB_keep(lds, g, lq, v);                                         // v[bq] = z[lq + R bq]
+                const C uu = cmul(ua, a.ramp1[(long long)rho * a.n1 + k1]);
+                C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
+                TWX_UNROLL
+                for (int bq = 0; bq < R; ++bq) out[bq * R + lq] = cmul3(v[bq], uu, s_vcr[g * R + bq]);   // · W_N^{-k1 q2} · ramp1
+            }
+        }
+    }
+}
+
 // code spectrum in block-thread order for k_rowd<MID>
 template <typename T>
 __global__ void k_cspec_perm(const cpx<T>* __restrict__ nat, cpx<T>* __restrict__ perm, int n1, int n2, int r0, int r) {
