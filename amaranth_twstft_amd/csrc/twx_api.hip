@@ -493,11 +493,12 @@ template <typename T> struct Ctx : CtxBase {
         R = 2 * cfg.nint + 1;
         ntiles = N2 / col->W;
         if (cfg.max_batch > 0) B = cfg.max_batch;
-        else {   // largest power of two whose A+Bz buffers stay under ~1.5 GiB; at most 16 windows per launch, 64 for
-                 // windows under 64 k samples where a launch would otherwise be shorter than its own overhead
-                 // (tools/small_n.py: N = 20 000 runs 8.0 Gsample/s at 16, 11.3 at 64, no gain beyond)
+        else {   // largest power of two whose A+Bz buffers stay under ~1.5 GiB; at most 16 windows per launch, up to 256
+                 // for windows under 64 k samples where a launch would otherwise be shorter than its own overhead
+                 // (tools/small_n.py: N = 20 000 runs 9.8 Gsample/s at 16, 28 at 64, 36 at 256)
             const long long fit = std::max<long long>(1, (1536ll << 20) / (N * (long long)sizeof(C) * (1 + R)));
-            const int cap = N < 65536 ? 64 : 16;
+            int cap = 16;
+            if (N < 65536) { cap = 32; while (cap < 256 && (long long)cap * N < 5000000) cap *= 2; }   // ~5 M samples per launch
             B = 1; while (B * 2 <= fit && B * 2 <= cap) B *= 2;
         }
         // range safety: the unnormalised correlation peak reaches ~N^2*32768 — keep |z|^2 inside fp32

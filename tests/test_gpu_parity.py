@@ -655,13 +655,13 @@ def test_stockham_row_pass_fallback(monkeypatch):
 
 def test_host_pipeline_many_chunks_per_window_df():
     """twx_process_windows through the pinned pipeline: more chunks than slots, a ragged tail, per-window df."""
-    nchips, n, nwin = 10000, 20000, 64 * 3 + 64 + 5              # B = 64 for this length: 4 full chunks + a 5-window tail
+    nchips, n, nwin = 10000, 20000, 64 * 3 + 64 + 5              # batch 64: 4 full chunks + a 5-window tail
     chips = chips_for(14, 43, nchips)
     p = synth.SynthParams(delay_q8=777 * 256, fstep=synth.fstep_for_df(1500.0, FS), phi0=3, amp=400,
                           noise_gain=synth.noise_gain_for_sigma(300.0), seed=11)
     raw = synth.synth_channel(n * nwin, chips, 2, p)
     dfs = np.where(np.arange(nwin) % 3 == 0, 1500.0, 1500.0 + 40.0 * (np.arange(nwin) % 5))
-    with Correlator(chips, fs=FS, Nint=1) as cor:
+    with Correlator(chips, fs=FS, Nint=1, max_batch=64) as cor:
         assert cor.info.batch == 64
         got = cor.process(raw, 1, 0, df=dfs)
         assert len(got) == nwin
