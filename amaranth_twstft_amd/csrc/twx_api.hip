@@ -37,15 +37,21 @@ const RowOps* find_row(int L, int f64) {
     return nullptr;
 }
 bool choose_split(long long n, int f64, const ColOps** col, const RowOps** row) {
-    // prefer the longest row plan (fewest, longest contiguous rows; column tiles stay ≤ 80 KB)
+    // Preference: N2 = 4000 where it divides n (its rows leave room for a third resident workgroup and the column
+    // length N1 = n/4000 keeps the column workgroups full: measured 26.7 vs 22.8 Gsample/s at n = 2e5, 32.3 vs 29.2
+    // at n = 1e6 against N2 = 8000, tools/prof_n.py), otherwise the longest row plan.
     const ColOps* bc = nullptr; const RowOps* br = nullptr;
+    const char* force = getenv("TWX_N2");                 // experiments: force the row length
+    const int forced = force ? atoi(force) : 0;
     for (auto& r : row_reg()) {
         if (r.f64 != f64 || n % r.L || (r.L & 1)) continue;
+        if (forced && r.L != forced) continue;
         const long long n1 = n / r.L;
         if (n1 > 100000) continue;
         const ColOps* c = find_col((int)n1, f64);
         if (!c || r.L % c->W) continue;
-        if (!br || r.L > br->L) { br = &r; bc = c; }
+        auto rank = [](int L) { return L == 4000 ? (1 << 30) : L; };
+        if (!br || rank(r.L) > rank(br->L)) { br = &r; bc = c; }
     }
     if (!br) return false;
     *col = bc; *row = br;
