@@ -9,21 +9,22 @@ from amaranth_twstft_amd import _lib as L, prn, synth
 from amaranth_twstft_amd.correlator import Correlator, band_godual
 FS = 5e6
 bitlen, taps, nchips = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (17, 9, 100000)))
+precision = sys.argv[4] if len(sys.argv) > 4 else "f32"
 n = 2 * nchips
 lib = L.load()
 chips = prn.lfsr_chips(bitlen, taps, nchips)
-nwin = max(64, min(4096, int(160e6 // n)))
+nwin = max(16, min(4096, int(160e6 // n)))
 p = synth.SynthParams(delay_q8=(n // 3) * 256, fstep=synth.fstep_for_df(1780.75, FS), phi0=1, amp=300, noise_gain=synth.noise_gain_for_sigma(500.0), seed=5)
 raw = torch.from_numpy(synth.synth_channel(n * nwin, chips, 2, p).reshape(-1)).cuda()
 res = torch.zeros((nwin, C.sizeof(L.twx_result)), dtype=torch.uint8, device="cuda")
 band = L.twx_band(*band_godual(FS, n))
-with Correlator(chips, fs=FS, Nint=1, profile=True) as cor:
+with Correlator(chips, fs=FS, Nint=1, profile=True, precision=precision) as cor:
     def run():
         L.check(lib.twx_process_windows_dev(cor._h, raw.data_ptr(), nwin, 1, 0, C.byref(band), None, res.data_ptr()), cor._h)
         L.check(lib.twx_synchronize(cor._h), cor._h)
     run(); cor.profile(reset=True); run(); run()
     prof = cor.profile()
     tot = sum(v["ms_total"] for v in prof.values())
-    print(f"N={n} N1={cor.info.n1} N2={cor.info.n2} B={cor.info.batch}: {2 * nwin * n / tot / 1e6:.1f} Gsample/s (one slot)")
+    print(f"{precision} N={n} N1={cor.info.n1} N2={cor.info.n2} B={cor.info.batch}: {2 * nwin * n / tot / 1e6:.1f} Gsample/s (one slot)")
     for k, v in prof.items():
         print(f"  {k:18s} {v['ms_total'] / v['launches'] * 1e3:8.1f} us/launch  {v['ms_total'] / tot * 100:5.1f} %  {v['units'] / v['launches'] / 1e6:.2f} M samples/launch")
