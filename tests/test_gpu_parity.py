@@ -726,3 +726,44 @@ def test_replica_variants_of_the_experiment_scripts(variant):
     assert g.indice == ind == 2345
     assert abs(abs(g.xval) - abs(ref[ind])) <= MAG_TOL * abs(ref[ind])
     assert np.isnan(g.SNRr) and np.isnan(g.puissancenoise) and g.puissance > 0          # wipe-off statistics undefined here
+
+
+def test_randomised_parity_sweep():
+    """Seeded sweep over code lengths, delays, carrier offsets and SNRs down to noise-dominated maps (where the
+    arg-max is decided among noise peaks): integer lag and carrier bin identical to the oracle in every case."""
+    rng = np.random.default_rng(20260101)
+    cases = [(13, 27, 5000), (14, 57, 10000), (15, 17, 25000)]
+    mism = []
+    for bitlen, taps, nchips in cases:
+        chips = chips_for(bitlen, taps, nchips)
+        n = 2 * nchips
+        code = orc.make_code(chips, 2)
+        fcode = orc.make_fcode(code)
+        freq = orc.freq_axis(FS, n)
+        k = orc.band_numpy(freq)
+        temps = np.arange(n) / FS
+        band = band_numpy(FS, n)
+        nwin = int(os.environ.get("TWX_SWEEP_WINDOWS", "24"))       # raise for a longer hunt
+        params = []
+        raws = []
+        for w in range(nwin):
+            amp = int(rng.choice([0, 20, 60, 200, 1000]))
+            sigma = float(rng.choice([50.0, 300.0, 2000.0]))
+            df = float(rng.uniform(-7000, 7000))
+            p = synth.SynthParams(delay_q8=int(rng.integers(0, n)) * 256 + int(rng.integers(0, 256)),
+                                  fstep=synth.fstep_for_df(df, FS), phi0=int(rng.integers(0, 2 ** 32)), amp=amp,
+                                  noise_gain=synth.noise_gain_for_sigma(sigma), seed=int(rng.integers(1, 10 ** 6)))
+            raws.append(synth.synth_channel(n, chips, 2, p))
+            params.append((amp, sigma, df))
+        raw = np.concatenate(raws)
+        with Correlator(chips, fs=FS, Nint=1) as cor:
+            got = cor.process(raw, 1, 0, band=band)
+        for w, g in enumerate(got):
+            d = orc.deinterleave(raws[w], 1, 0)
+            d = d - d.mean()
+            o = orc.processing(d, k, freq, temps, fcode, code, Nint=1, fs=FS)
+            if g.indice != o["indice"] or abs(g.df - o["df"]) > 1e-9:
+                mism.append((nchips, w, params[w], g.indice, o["indice"], g.df, o["df"]))
+            else:
+                assert abs(abs(g.xval) - abs(o["xval"])) <= MAG_TOL * abs(o["xval"])
+    assert not mism, mism
