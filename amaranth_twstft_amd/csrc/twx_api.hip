@@ -1016,6 +1016,14 @@ template <typename T> struct Ctx : CtxBase {
 using namespace twx;
 struct twx_ctx { CtxBase* impl; };
 
+// No exception may cross the C boundary (std::async, std::vector and std::string can throw).
+template <class F> static int guarded(CtxBase* c, F f) noexcept {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return c ? c->fail(TWX_E_NOMEM, "out of host memory") : TWX_E_NOMEM; }
+    catch (const std::exception& e) { return c ? c->fail(TWX_E_STATE, std::string("internal error: ") + e.what()) : TWX_E_STATE; }
+    catch (...) { return c ? c->fail(TWX_E_STATE, "internal error") : TWX_E_STATE; }
+}
+
 extern "C" {
 
 int twx_abi_version(void) { return TWX_ABI_VERSION; }
@@ -1056,7 +1064,7 @@ int twx_create(const twx_config* cfg, twx_ctx** out) {
     CtxBase* c = f64 ? static_cast<CtxBase*>(new Ctx<double>()) : static_cast<CtxBase*>(new Ctx<float>());
     c->cfg = *cfg; c->N = N; c->N1 = col->L; c->N2 = row->L; c->col = col; c->row = row;
     (void)hipGetDevice(&c->dev);
-    int rc = c->init();
+    int rc = guarded(c, [&]() { return c->init(); });
     if (rc) { g_create_err = c->err; delete c; return rc; }
     c->cfg.chips = nullptr;
     *out = new twx_ctx{c};
@@ -1085,7 +1093,7 @@ int twx_process_windows_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_windows,
     CtxBase* c = ctx->impl;
     if (!iq_dev || !out_dev || n_windows < 0 || n_channels < 1 || channel < 0 || channel >= n_channels) return c->fail(TWX_E_ARG, "bad argument");
     (void)hipSetDevice(c->dev);
-    return c->process(iq_dev, n_windows, n_channels, channel, band, df, out_dev);
+    return guarded(c, [&]() { return c->process(iq_dev, n_windows, n_channels, channel, band, df, out_dev); });
 }
 
 int twx_synchronize(twx_ctx* ctx) {
@@ -1108,23 +1116,23 @@ int twx_process_windows(twx_ctx* ctx, const int16_t* iq, int64_t n_windows, int3
     (void)hipSetDevice(c->dev);
     // pinned double-buffered staging: the host-side copy, the H2D transfer and the kernels of consecutive
     // chunks overlap (same pipeline as twx_process_file)
-    return c->process_host(iq, n_windows, n_channels, channel, band, df, out);
+    return guarded(c, [&]() { return c->process_host(iq, n_windows, n_channels, channel, band, df, out); });
 }
 
 int twx_fft_forward(twx_ctx* ctx, const double* in, double* out) {
     if (!ctx || !in || !out) return TWX_E_ARG;
     (void)hipSetDevice(ctx->impl->dev);
-    return ctx->impl->fft_forward(in, out);
+    return guarded(ctx->impl, [&]() { return ctx->impl->fft_forward(in, out); });
 }
 int twx_get_code_spectrum(twx_ctx* ctx, double* out) {
     if (!ctx || !out) return TWX_E_ARG;
     (void)hipSetDevice(ctx->impl->dev);
-    return ctx->impl->code_spectrum(out);
+    return guarded(ctx->impl, [&]() { return ctx->impl->code_spectrum(out); });
 }
 int twx_xcorr_map(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, double df, double* out) {
     if (!ctx || !iq || !out || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
     (void)hipSetDevice(ctx->impl->dev);
-    return ctx->impl->xcorr_map(iq, n_channels, channel, df, out);
+    return guarded(ctx->impl, [&]() { return ctx->impl->xcorr_map(iq, n_channels, channel, df, out); });
 }
 
 int twx_debug_stamps(twx_ctx* ctx, unsigned long long* out, long long count) {
@@ -1150,25 +1158,25 @@ int twx_process_file(twx_ctx* ctx, const char* path, int32_t n_channels, int32_t
 int twx_caf_bins(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, int64_t k_lo, int64_t k_hi, double* pk, int64_t* lag) {
     if (!ctx || !iq || !pk || !lag || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
     (void)hipSetDevice(ctx->impl->dev);
-    return ctx->impl->caf_bins(iq, n_channels, channel, k_lo, k_hi, pk, (long long*)lag);
+    return guarded(ctx->impl, [&]() { return ctx->impl->caf_bins(iq, n_channels, channel, k_lo, k_hi, pk, (long long*)lag); });
 }
 int twx_caf_freqs(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, const double* freqs, int64_t n_freqs, twx_result* out) {
     if (!ctx || !iq || !freqs || !out || n_freqs < 0 || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
     (void)hipSetDevice(ctx->impl->dev);
-    return ctx->impl->caf_freqs(iq, n_channels, channel, freqs, n_freqs, out);
+    return guarded(ctx->impl, [&]() { return ctx->impl->caf_freqs(iq, n_channels, channel, freqs, n_freqs, out); });
 }
 
 int twx_sqspec_bins_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel,
                         const int64_t* bins, int32_t n_bins, double* out_re_im) {
     if (!ctx || !iq_dev || !bins || !out_re_im || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
     (void)hipSetDevice(ctx->impl->dev);
-    return ctx->impl->sqspec_bins(iq_dev, n_samples, n_channels, channel, (const long long*)bins, n_bins, out_re_im);
+    return guarded(ctx->impl, [&]() { return ctx->impl->sqspec_bins(iq_dev, n_samples, n_channels, channel, (const long long*)bins, n_bins, out_re_im); });
 }
 int twx_sqspec_band_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel,
                         int64_t k_lo, int64_t n_bins, double* out_mag) {
     if (!ctx || !iq_dev || !out_mag || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
     (void)hipSetDevice(ctx->impl->dev);
-    return ctx->impl->sqspec_band(iq_dev, n_samples, n_channels, channel, k_lo, n_bins, out_mag);
+    return guarded(ctx->impl, [&]() { return ctx->impl->sqspec_band(iq_dev, n_samples, n_channels, channel, k_lo, n_bins, out_mag); });
 }
 
 int twx_profile_reset(twx_ctx* ctx) {
