@@ -205,6 +205,9 @@ int twx_fir_decimate(const int16_t* iq, int64_t n_in, int32_t n_channels, int32_
 typedef struct twx_prof_entry { char name[32]; double ms_total; int64_t launches; int64_t units; } twx_prof_entry;
 int twx_profile_reset(twx_ctx* ctx);
 int twx_profile_get(twx_ctx* ctx, twx_prof_entry* entries, int32_t max_entries, int32_t* n_entries);
+/* Diagnostic builds only (-DTWX_STAMPS, tools/stamps.py): s_memtime stamps written by one wave per workgroup of
+ * the Stockham row kernel; TWX_E_STATE in a normal build. */
+int twx_debug_stamps(twx_ctx* ctx, unsigned long long* out, long long count);
 
 /* Device-side helpers (replica generation, synthetic captures) ---------------------------- */
 /* LFSR chips into host memory, generated on the device (common.py:59-73 semantics). */
