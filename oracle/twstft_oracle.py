@@ -18,7 +18,8 @@ Parity pinning (see tests/golden/README.md, tools/make_golden.py):
     godual_ranging.py:processing`` (full-precision return values, fine-frequency step on) and
     ``experiments/221207_twoway_codes/processing/godual_ranging.py:ranging`` (printed rows).
   * The reference holds NO test vectors of its own for the correlator, and the
-    Octave-only variants (``processing_claudio``, ``search_df``), the C++-only Hamming window
+    Octave-only variants (``processing_claudio``, ``search_df``, ``ranging_tracked``, ``make_code_variant``,
+    ``peak_refine_polyfit``), the C++-only Hamming window
     and the 231001_DLL_PLL acquisition/tracking restatements have no runnable twin here:
     for those functions parity is UNPINNED (hand restatement, cross-checked by identities).
 """
