@@ -118,3 +118,15 @@ def test_acquisition_gate_formula():
     assert p == 1.0 and locked == ((1.1 * 1.0) > (0.1 * 10.0))
     locked, _ = cor.Correlator.acquisition_gate(pk=0.1, px=10.0, snr_min=0.1, psbb=2.0)
     assert not locked
+
+
+def test_lowpass_taps_match_an_independent_windowed_sinc():
+    """frontend.lowpass_taps (GNU Radio ``firdes.low_pass(1, fs, fc, tw, WIN_HAMMING)`` of experiments/2403/zmq_rx.py:208-215,
+    not installable here) against scipy.signal.firwin with the same length, cut-off and window."""
+    from scipy.signal import firwin
+    from amaranth_twstft_amd.frontend import lowpass_taps
+    for fs, fc, tw in ((70e6, 2.1e6, 0.4e6), (5e6, 1.0e6, 0.2e6)):
+        h = lowpass_taps(fs, fc, tw)
+        assert h.size % 2 == 1 and h.size == int(53.0 * fs / (22.0 * tw)) | 1
+        g = firwin(h.size, fc, window="hamming", fs=fs)
+        assert np.abs(h - g).max() < 1e-7 and abs(h.sum() - 1.0) < 1e-6
