@@ -11,8 +11,8 @@ from __future__ import annotations
 import numpy as np
 
 
-def _vec(results, attr):
-    return np.array([[getattr(r, attr) for r in results]])
+def _vec(results, attr, dtype=np.float64):
+    return np.array([[getattr(r, attr) for r in results]], dtype=dtype)
 
 
 def mat_dict(res1, res2=None, code=None, remote: int = 0) -> dict:
@@ -29,9 +29,9 @@ def mat_dict(res1, res2=None, code=None, remote: int = 0) -> dict:
         d["puissance" + suffix] = _vec(res, "puissance")
         d[f"puissance{suffix}code"] = _vec(res, "puissancecode")
         d[f"puissance{suffix}noise"] = _vec(res, "puissancenoise")
-        d["xval" + suffix] = _vec(res, "xval")
-        d[f"xval{suffix}m1"] = _vec(res, "xvalm1")
-        d[f"xval{suffix}p1"] = _vec(res, "xvalp1")
+        d["xval" + suffix] = _vec(res, "xval", np.complex128)
+        d[f"xval{suffix}m1"] = _vec(res, "xvalm1", np.complex128)
+        d[f"xval{suffix}p1"] = _vec(res, "xvalp1", np.complex128)
     if code is not None:
         d["code"] = np.asarray(code, dtype=np.float64).reshape(1, -1)
     return d
@@ -65,7 +65,8 @@ def tracked_mat_dict(out: dict, code=None) -> dict:
     row = lambda v, dt=np.float64: np.asarray(v, dtype=dt).reshape(1, -1)
     d = {"xval1": row(out["xval"], np.complex128), "indice1": row(out["indice1"]), "correction1": row(out["correction1"]),
          "SNR1r": row(out["SNR1r"]), "SNR1i": row(out["SNR1i"]), "puissance1": row(out["puissance1"]),
-         "df": row(out["df"]), "moved": row(out["moved"]), "movedval": row(out["movedval"])}
+         "df": row(out["df"]), "moved": row(out["moved"]), "movedval": row(out["movedval"]),
+         "puissancecode": row([out.get("puissancecode", np.nan)]), "puissancenoise": row([out.get("puissancenoise", np.nan)])}
     if code is not None:
         d["code"] = np.asarray(code, dtype=np.float64).reshape(1, -1)
     return d

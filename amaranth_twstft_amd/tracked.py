@@ -194,6 +194,9 @@ class TrackedRanging:
     def _append(out, g, ind):
         out["xval"].append(g.xval); out["indice1"].append(ind); out["correction1"].append(g.correction)
         out["SNR1r"].append(g.SNRr); out["SNR1i"].append(g.SNRi); out["puissance1"].append(g.puissance)
+        # the script receives these two without an index (:168): its workspace keeps the last code's values
+        out["puissancecode"] = getattr(g, "puissancecode", float("nan"))
+        out["puissancenoise"] = getattr(g, "puissancenoise", float("nan"))
 
     def run_file(self, path: str, skip_seconds: float = 30.0, **kw) -> dict:
         """Whole single-channel sc16 capture file (``fseek(f,30*fs*2*2)`` :128 → ``skip_seconds``)."""

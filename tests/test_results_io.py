@@ -48,3 +48,37 @@ def test_tracked_mat_roundtrip_feeds_twoway(tmp_path):
     k, trunc = twoway.valid_codes(m["xval1"].ravel())
     d = twoway.delays_ns(m["indice1"].ravel(), m["correction1"].ravel(), k)
     assert not trunc and len(d) == n - 11 and abs(d[0] - (21.0 + 0.1 / 3) / 5e6 * 1e9) < 1e-9
+
+
+def test_mat_writers_follow_the_schema_of_the_reference_archives(tmp_path):
+    """tests/golden/mat_schema.json = names/shapes/dtypes of result files kept in the reference repository
+    (tools/make_golden.py:gen_mat_schema).  Every variable of the 2023 tracked-script archive must come out of
+    save_tracked_mat, every variable of the 2022 two-channel archive that the current script still saves must come out of
+    save_mat, as 1 x n rows of the same dtype kind."""
+    from scipy.io import loadmat
+    from amaranth_twstft_amd import results_io
+    from amaranth_twstft_amd.correlator import WindowResult
+    from tests.helpers import load_golden
+    schema = load_golden("mat_schema.json")["files"]
+    n = 7
+    out = dict(xval=[1 + 1j] * n, indice1=[21.0] * n, correction1=[0.1] * n, SNR1r=[1e-3] * n, SNR1i=[2e-3] * n,
+               puissance1=[5.0] * n, df=[12.5], moved=[1], movedval=[7.0], puissancecode=3.0, puissancenoise=4.0)
+    p = tmp_path / "t.mat"
+    results_io.save_tracked_mat(str(p), out, code=np.ones(10))
+    got = loadmat(str(p))
+    ref = schema["experiments/230315_analysis_100k/local1674402311.mat.gz"]
+    for name, d in ref.items():
+        assert name in got, name
+        assert got[name].ndim == 2 and got[name].shape[0] == 1 and got[name].dtype.kind == np.dtype(d["dtype"]).kind, name
+        if d["shape"] == [1, 1]:
+            assert got[name].shape == (1, 1), name
+    res = [WindowResult(10, 0.1, 1 + 1j, 1j, 1, np.zeros(7, complex), 5.0, 3, 1e-3, 1e-3, 2.0, 1.0, 1.0) for _ in range(n)]
+    q = tmp_path / "g.mat"
+    results_io.save_mat(str(q), res, res, code=np.ones(10))
+    got = loadmat(str(q))
+    ref = schema["experiments/220616_Besancon/1655300700.mat.gz"]
+    for name, d in ref.items():
+        if name == "df":                      # the 2022 variant saved one df; godual_ranging.m:126-131 saves df1 df2
+            assert "df1" in got and "df2" in got
+            continue
+        assert name in got and got[name].shape == (1, n) and got[name].dtype.kind == np.dtype(d["dtype"]).kind, name

@@ -171,13 +171,28 @@ def gen_221207():
             "cases": cases}
 
 
+def gen_mat_schema():
+    """Variable names / shapes / dtypes of result archives the reference repository keeps (the data itself cannot be
+    regenerated: the captures are not in the repository) — the schema the later analysis scripts load."""
+    import gzip, io
+    from scipy.io import loadmat
+    out = {}
+    for rel in ("experiments/220616_Besancon/1655300700.mat.gz", "experiments/230315_analysis_100k/local1674402311.mat.gz"):
+        m = loadmat(io.BytesIO(gzip.open(os.path.join(REF, rel)).read()))
+        out[rel] = {k: {"shape": list(v.shape), "dtype": str(v.dtype)} for k, v in m.items() if not k.startswith("__")}
+    return {"note": "schema only (names, shapes, dtypes) of result files in the reference repository", "files": out}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-5m", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["prn", "221207", "221219"]
+    todo = a.only.split(",") if a.only else ["prn", "221207", "221219", "mat"]
+    if "mat" in todo:
+        print("result-file schemas")
+        json.dump(gen_mat_schema(), open(os.path.join(GOLD, "mat_schema.json"), "w"), indent=1)
     if "prn" in todo:
         print("PRN fixtures")
         json.dump(gen_prn(), open(os.path.join(GOLD, "prn_codes.json"), "w"), indent=1)
