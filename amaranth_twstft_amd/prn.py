@@ -83,12 +83,87 @@ def lfsr_period(bit_len: int, taps: int, seed: int = 1) -> int:
             return n
 
 
-def write_prn_seq(bitlen: int, noiselen: int, taps_a: int, path: str | None = None) -> str:
-    """Write a BPSK code file (reference: common.py:59-73, BPSK branch)."""
+def write_prn_seq(bitlen: int, noiselen: int, taps_a: int, taps_b: int | None = None, path: str | None = None) -> str:
+    """Write a code file with the reference's naming (common.py:59-73): BPSK = one byte per chip; QPSK (``taps_b``) =
+    the two sequences interleaved a0 b0 a1 b1 … (read back as ``code(1:2:end)``, ``code(2:2:end)`` by
+    experiments/220822_qpsk_vs_bpsk/goqpsk.m:10-11)."""
     if path is None:
-        path = f"prn{taps_a}bpsk{bitlen}bits.bin"
-    lfsr_chips(bitlen, taps_a, noiselen).tofile(path)
+        path = f"prn{taps_a}{f'.{taps_b}q' if taps_b else 'b'}psk{bitlen}bits.bin"
+    a = lfsr_chips(bitlen, taps_a, noiselen)
+    if taps_b:
+        out = np.empty(2 * noiselen, dtype=np.uint8)
+        out[0::2] = a
+        out[1::2] = lfsr_chips(bitlen, taps_b, noiselen)
+        out.tofile(path)
+    else:
+        a.tofile(path)
     return path
+
+
+def _gf2_matmul(a: list[int], b: list[int]) -> list[int]:
+    """Rows as bit masks: (a·b)[i] = XOR of the rows b[j] over the set bits j of a[i]."""
+    out = []
+    for row in a:
+        acc, j = 0, 0
+        while row:
+            if row & 1:
+                acc ^= b[j]
+            row >>= 1
+            j += 1
+        out.append(acc)
+    return out
+
+
+def _gf2_matpow(m: list[int], e: int) -> list[int]:
+    n = len(m)
+    res = [1 << i for i in range(n)]
+    while e:
+        if e & 1:
+            res = _gf2_matmul(res, m)
+        m = _gf2_matmul(m, m)
+        e >>= 1
+    return res
+
+
+def lfsr_is_maximal(bit_len: int, taps: int) -> bool:
+    """True when LFSR(bit_len, taps) runs through all 2^bit_len - 1 non-zero states — the property
+    ``m_seq_codes`` (common.py:32-57) and tools/mseq_calculator.c:29-38 establish by stepping through the whole cycle;
+    here by the order of the transition matrix: M^(2^n-1) = I and M^((2^n-1)/p) != I for every prime p | 2^n-1."""
+    n = bit_len
+    if not (taps & 1):
+        return False                                  # singular transition: state 1 is not on a cycle through 1
+    # state' = (state >> 1) | (parity(state & taps) << (n-1)) as a matrix acting on bit vectors (row i = image of bit i)
+    rows = []
+    for i in range(n):
+        s = 1 << i
+        bit = bin(s & taps).count("1") & 1
+        rows.append((s >> 1) | (bit << (n - 1)))
+    order = (1 << n) - 1
+    ident = [1 << i for i in range(n)]
+    if _gf2_matpow(rows, order) != ident:
+        return False
+    m, p, primes = order, 2, []
+    while p * p <= m:
+        if m % p == 0:
+            primes.append(p)
+            while m % p == 0:
+                m //= p
+        p += 1
+    if m > 1:
+        primes.append(m)
+    return all(_gf2_matpow(rows, order // q) != ident for q in primes)
+
+
+def m_seq_codes(bit_len: int, limit: int = 10) -> list[int]:
+    """The first ``limit`` tap masks (odd values, ascending — the candidates and the order of common.py:32-57) that make
+    LFSR(bit_len) a maximum-length sequence generator."""
+    codes = []
+    for code in range(1, 1 << bit_len, 2):
+        if lfsr_is_maximal(bit_len, code):
+            codes.append(code)
+            if len(codes) == limit:
+                break
+    return codes
 
 
 def read_code_file(path: str) -> np.ndarray:

@@ -154,3 +154,29 @@ def test_tracked_loop_restatement_aligns_the_window():
     ind = np.array(out["indice1"])
     assert ind[0] == 64.0 and np.all(np.abs(ind[1:] - 64.0 / 3) < 1e-9)          # raw 3N index after the move, /3 afterwards
     assert len(ind) == 2 * 50 - 1                                                  # 2 whole chunks; the move costs one code
+
+
+def test_m_sequence_tap_search_known_answers(tmp_path):
+    """tools/README.md:1-11 lists the 17-bit taps below 100 that mseq_calculator reports OK; common.py:32-57 m_seq_codes
+    returns the same set in ascending order.  The matrix-order test must agree with stepping through the cycle."""
+    assert prn.m_seq_codes(17, 8) == [9, 15, 33, 45, 51, 63, 65, 85]
+    for n in (5, 6, 7, 8, 9):
+        for code in range(1, 1 << n, 2):
+            assert prn.lfsr_is_maximal(n, code) == (prn.lfsr_period(n, code) == (1 << n) - 1), (n, code)
+    for n, taps in ((13, 27), (14, 43), (14, 57), (15, 3), (15, 17), (17, 9), (17, 15), (18, 39), (19, 63), (22, 3), (22, 57)):
+        assert prn.lfsr_is_maximal(n, taps), (n, taps)           # every code family of the reference is maximal-length
+
+
+def test_qpsk_code_file_layout(tmp_path):
+    """common.py:59-73 with taps_b: a0 b0 a1 b1 ..., name prn<a>.<b>qpsk<bits>bits.bin; goqpsk.m:10-11 de-interleaves it."""
+    import os
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        name = prn.write_prn_seq(14, 1000, 43, 57)
+        assert name == "prn43.57qpsk14bits.bin"
+        code = prn.read_code_file(name)
+        assert np.array_equal(code[0::2], prn.lfsr_chips(14, 43, 1000)) and np.array_equal(code[1::2], prn.lfsr_chips(14, 57, 1000))
+        assert prn.write_prn_seq(14, 10, 43) == "prn43bpsk14bits.bin"
+    finally:
+        os.chdir(cwd)
