@@ -180,3 +180,22 @@ def test_qpsk_code_file_layout(tmp_path):
         assert prn.write_prn_seq(14, 10, 43) == "prn43bpsk14bits.bin"
     finally:
         os.chdir(cwd)
+
+
+def test_against_the_compiled_reference_period_checker():
+    """oracle/_ref/mseq_calculator = the reference's own tools/mseq_calculator.c compiled from where it lies
+    (oracle/Makefile).  Its period and OK verdict against prn.lfsr_period / lfsr_is_maximal.  (17, 10): an even tap mask,
+    the checker reports the length-1 cycle it falls into.)"""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "mseq_calculator")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/mseq_calculator not built (needs /root/reference)")
+    for n, taps in ((13, 27), (14, 43), (14, 57), (15, 3), (17, 9), (17, 15), (17, 33), (17, 11), (17, 13), (12, 83), (12, 9)):
+        out = subprocess.run([exe, str(n), str(taps)], capture_output=True, text=True).stdout
+        m = re.search(r"->\s*(\d+)/(\d+)(\s+OK)?", out)
+        assert m, out
+        period, full, ok = int(m.group(1)), int(m.group(2)), bool(m.group(3))
+        assert full == (1 << n) - 1
+        assert ok == prn.lfsr_is_maximal(n, taps), (n, taps, out)
+        if taps & 1:
+            assert period == prn.lfsr_period(n, taps), (n, taps, out)
