@@ -95,6 +95,9 @@ def _to_result(r: L.twx_result) -> WindowResult:
                         r.puissancecode, r.puissancenoise)
 
 
+ALL_CHANNELS = -1
+
+
 class Correlator:
     """One code + one GPU. Mirrors the globals ``fs Nint code fcode`` of godual_ranging.m:3-5,62-66."""
 
@@ -161,10 +164,14 @@ class Correlator:
         nwin = raw.size // per          # short final window is dropped (godual_ranging.m:81,102)
         return raw, nwin
 
-    def process(self, raw, n_channels=1, channel=0, band=None, df=None) -> list[WindowResult]:
-        """Run ``processing`` over every full window of an interleaved int16 capture (host memory)."""
+    def process(self, raw, n_channels=1, channel=0, band=None, df=None):
+        """Run ``processing`` over every full window of an interleaved int16 capture (host memory).
+        ``channel = -1`` (``ALL_CHANNELS``): every channel from one upload of the capture → ``{c: [WindowResult …]}``
+        (``df``, if given, broadcastable to [nwin, n_channels])."""
         raw, nwin = self._windows(raw, n_channels)
-        out = (L.twx_result * max(nwin, 1))()
+        allch = channel < 0
+        nrec = nwin * (n_channels if allch else 1)
+        out = (L.twx_result * max(nrec, 1))()
         bptr = None
         dptr = None
         if band is not None:
@@ -173,20 +180,26 @@ class Correlator:
         else:
             if df is None:
                 raise ValueError("give band (estimate df) or df (per window)")
-            dfa = np.ascontiguousarray(np.broadcast_to(np.asarray(df, dtype=np.float64), (nwin,)))
+            shape = (nwin, n_channels) if allch else (nwin,)
+            dfa = np.ascontiguousarray(np.broadcast_to(np.asarray(df, dtype=np.float64), shape))
             dptr = dfa.ctypes.data_as(C.c_void_p)
         L.check(self._lib.twx_process_windows(self._h, raw.ctypes.data_as(C.c_void_p), nwin, n_channels, channel,
                                               bptr, dptr, C.cast(out, C.c_void_p)), self._h)
+        if allch:
+            return {c: [_to_result(out[w * n_channels + c]) for w in range(nwin)] for c in range(n_channels)}
         return [_to_result(out[i]) for i in range(nwin)]
 
     def process_file(self, path: str, n_channels=1, channel=0, band=None, df=None, skip_samples: int = 0,
-                     max_windows: int | None = None) -> list[WindowResult]:
-        """Window loop over a capture file (godual_ranging.m:70-103), pinned double-buffered ingest."""
+                     max_windows: int | None = None):
+        """Window loop over a capture file (godual_ranging.m:70-103), pinned double-buffered ingest.
+        ``channel = -1``: every channel from one pass over the file → ``{c: [WindowResult …]}``."""
         import os
         per = self.n * 4 * n_channels
         avail = max(0, (os.path.getsize(path) - skip_samples * 4 * n_channels)) // per
         nmax = avail if max_windows is None else min(avail, max_windows)
-        out = (L.twx_result * max(nmax, 1))()
+        allch = channel < 0
+        nch_out = n_channels if allch else 1
+        out = (L.twx_result * max(nmax * nch_out, 1))()
         bptr = None
         if band is not None:
             b = L.twx_band(int(band[0]), int(band[1]))
@@ -196,6 +209,8 @@ class Correlator:
         ndone = C.c_int64()
         L.check(self._lib.twx_process_file(self._h, os.fsencode(path), n_channels, channel, skip_samples, bptr,
                                            float(df) if df is not None else 0.0, C.cast(out, C.c_void_p), nmax, C.byref(ndone)), self._h)
+        if allch:
+            return {c: [_to_result(out[w * n_channels + c]) for w in range(ndone.value)] for c in range(n_channels)}
         return [_to_result(out[i]) for i in range(ndone.value)]
 
     def processing(self, raw_window, k, n_channels=1, channel=0) -> WindowResult:
@@ -212,6 +227,8 @@ class Correlator:
         """Window loop of godual_ranging.m:75-102: {channel: [WindowResult …]}."""
         if band is None:
             band = band_godual(self.fs, self.n, remote, OP)
+        if tuple(channels) == tuple(range(n_channels)) and 1 < n_channels <= 4:
+            return self.process(raw, n_channels, ALL_CHANNELS, band=band)        # one upload for both channels (:91,95)
         return {c: self.process(raw, n_channels, c, band=band) for c in channels}
 
     # -- delay x Doppler search (experiments/231001_DLL_PLL/rxcomplex.cpp:521-572) -----------------

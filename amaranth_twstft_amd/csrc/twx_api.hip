@@ -22,6 +22,7 @@ namespace twx {
 // ------------------------------------------------------------------------------------------
 // registry
 // ------------------------------------------------------------------------------------------
+#define TWX_MAX_CHANNELS 4
 static int wshift_of(int w) { int sft = 0; while ((1 << sft) < w) ++sft; return sft; }
 LaunchEvents& launch_events() { static thread_local LaunchEvents le; return le; }
 static std::vector<ColOps>& col_reg() { static std::vector<ColOps> v; return v; }
@@ -581,7 +582,7 @@ template <typename T> struct Ctx : CtxBase {
             if (int rc = dalloc(&q.dc, (size_t)B)) return rc;
             if (int rc = dalloc(&q.part_band, (size_t)B * N1)) return rc;
             if (int rc = dalloc(&q.part_peak, (size_t)B * R * ntiles)) return rc;
-            if (int rc = dalloc(&q.res_dev, (size_t)B)) return rc;
+            if (int rc = dalloc(&q.res_dev, (size_t)B * TWX_MAX_CHANNELS)) return rc;   // all-channel mode: B windows x channels
             if (fine_M) { if (int rc = dalloc(&q.fine_u, (size_t)B * fine_M)) return rc; }
         }
         use_slot(0);
@@ -633,7 +634,7 @@ template <typename T> struct Ctx : CtxBase {
 
     // one batch of nb windows starting at `in` (short2 units: window stride N*nch, channel offset applied)
     int run_batch(const short2* in, int nb, int nch, const twx_band* band, const double* df_host, twx_result* out_dev,
-                  C* zout /*optional full map, nb must be 1*/, bool same_window = false) {
+                  C* zout /*optional full map, nb must be 1*/, bool same_window = false, int res_stride = 1) {
         const long long wstride = same_window ? 0 : (long long)N * nch;
         HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums) * nb, stream));
         {
@@ -703,7 +704,7 @@ template <typename T> struct Ctx : CtxBase {
         PeakArgs<T> pa{};
         pa.n = N; pa.n1 = N1; pa.n2 = N2; pa.nphase = R; pa.nparts = R * ntiles; pa.part = part_peak; pa.Bz = Bz; pa.tw1d = tw1d;
         pa.sums = sums; pa.remove_mean = remove_mean; pa.dc = dc; pa.dfv = dfv; pa.dfidx = dfidx; pa.inv_scale = 1.0 / scale_pow2;
-        pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.convention = cfg.convention; pa.snr_valid = snr_valid; pa.res = out_dev;
+        pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.convention = cfg.convention; pa.snr_valid = snr_valid; pa.res = out_dev; pa.res_stride = res_stride;
         {
             ProfScope ps(this, PC_PEAK, nb);
             TWX_LAUNCH((k_peak<T>), dim3(nb), dim3(1024), stream, pa);
@@ -712,15 +713,27 @@ template <typename T> struct Ctx : CtxBase {
         return TWX_OK;
     }
 
+    // ch >= 0: one channel, records out_dev[w].  ch == TWX_ALL_CHANNELS: every channel of every window from the same
+    // device copy, records out_dev[w*nch + c] and df[w*nch + c]
     int process(const void* iq_dev, long long nwin, int nch, int ch, const twx_band* band, const double* df,
                 twx_result* out_dev) override {
         if (!band && !df) return fail(TWX_E_ARG, "either band or df must be given");
-        const short2* base = reinterpret_cast<const short2*>(iq_dev) + ch;
+        const bool all = ch < 0;
+        const int c_lo = all ? 0 : ch, c_hi = all ? nch : ch + 1, ostride = all ? nch : 1;
+        std::vector<double> dfc;
         int k = 0;
-        for (long long w0 = 0; w0 < nwin; w0 += B, k = (k + 1) % nslots) {
+        for (long long w0 = 0; w0 < nwin; w0 += B) {
             const int nb = (int)std::min<long long>(B, nwin - w0);
-            use_slot(k);
-            if (int rc = run_batch(base + w0 * N * nch, nb, nch, band, df ? df + w0 : nullptr, out_dev + w0, nullptr)) { use_slot(0); return rc; }
+            for (int c = c_lo; c < c_hi; ++c, k = (k + 1) % nslots) {
+                const double* dfp = nullptr;
+                if (df) {
+                    if (all) { dfc.resize((size_t)nb); for (int i = 0; i < nb; ++i) dfc[(size_t)i] = df[(w0 + i) * nch + c]; dfp = dfc.data(); }
+                    else dfp = df + w0;
+                }
+                use_slot(k);
+                const short2* base = reinterpret_cast<const short2*>(iq_dev) + c;
+                if (int rc = run_batch(base + w0 * N * nch, nb, nch, band, dfp, out_dev + w0 * ostride + (all ? c : 0), nullptr, false, ostride)) { use_slot(0); return rc; }
+            }
         }
         use_slot(0);
         return TWX_OK;
@@ -851,7 +864,10 @@ template <typename T> struct Ctx : CtxBase {
         const size_t win_bytes = (size_t)N * nch * 4;
         Stage* st = stage;
         int rc = TWX_OK;
-        std::vector<double> dfs((size_t)B, df_const);
+        const bool all = ch < 0;
+        if (all && nch > TWX_MAX_CHANNELS) return fail(TWX_E_ARG, "too many channels for the all-channel mode");
+        const int c_lo = all ? 0 : ch, c_hi = all ? nch : ch + 1, ostride = all ? nch : 1;
+        std::vector<double> dfs((size_t)B, df_const), dfc((size_t)B);
         for (int k = 0; k < nslots && rc == TWX_OK; ++k) {
             st[k].nb = 0;
             if (st[k].bytes >= win_bytes * B) continue;
@@ -866,7 +882,7 @@ template <typename T> struct Ctx : CtxBase {
         auto drain = [&](int k) -> int {       // wait for slot k's batch and fetch its results
             if (st[k].nb == 0) return TWX_OK;
             if (hipStreamSynchronize(slots[k].stream) != hipSuccess) return fail(TWX_E_HIP, "stream synchronize failed");
-            if (hipMemcpy(out + st[k].w0, slots[k].res_dev, sizeof(twx_result) * st[k].nb, hipMemcpyDeviceToHost) != hipSuccess) return fail(TWX_E_HIP, "D2H copy failed");
+            if (hipMemcpy(out + st[k].w0 * ostride, slots[k].res_dev, sizeof(twx_result) * st[k].nb * ostride, hipMemcpyDeviceToHost) != hipSuccess) return fail(TWX_E_HIP, "D2H copy failed");
             *n_done += st[k].nb;
             st[k].nb = 0;
             return TWX_OK;
@@ -915,7 +931,15 @@ template <typename T> struct Ctx : CtxBase {
                 use_slot(k);
                 if (hipMemcpyAsync(st[k].dev, st[k].host, win_bytes * nb, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = fail(TWX_E_HIP, "H2D copy failed"); break; }
                 (void)hipEventRecord(h2d_done[k], stream);
-                rc = run_batch(st[k].dev + ch, nb, nch, band, band ? nullptr : (df_arr ? df_arr + w0 : dfs.data()), slots[k].res_dev, nullptr);
+                for (int c = c_lo; c < c_hi && rc == TWX_OK; ++c) {        // same staged copy for every requested channel
+                    const double* dfp = nullptr;
+                    if (!band) {
+                        if (!df_arr) dfp = dfs.data();
+                        else if (!all) dfp = df_arr + w0;
+                        else { for (int i = 0; i < nb; ++i) dfc[(size_t)i] = df_arr[(w0 + i) * nch + c]; dfp = dfc.data(); }
+                    }
+                    rc = run_batch(st[k].dev + c, nb, nch, band, dfp, slots[k].res_dev + (all ? c : 0), nullptr, false, ostride);
+                }
                 st[k].w0 = w0; st[k].nb = nb;
                 w0 += nb;
             }
@@ -1091,7 +1115,7 @@ int twx_process_windows_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_windows,
                             const twx_band* band, const double* df, twx_result* out_dev) {
     if (!ctx) return TWX_E_ARG;
     CtxBase* c = ctx->impl;
-    if (!iq_dev || !out_dev || n_windows < 0 || n_channels < 1 || channel < 0 || channel >= n_channels) return c->fail(TWX_E_ARG, "bad argument");
+    if (!iq_dev || !out_dev || n_windows < 0 || n_channels < 1 || channel < TWX_ALL_CHANNELS || channel >= n_channels || (channel < 0 && n_channels > TWX_MAX_CHANNELS)) return c->fail(TWX_E_ARG, "bad argument");
     (void)hipSetDevice(c->dev);
     return guarded(c, [&]() { return c->process(iq_dev, n_windows, n_channels, channel, band, df, out_dev); });
 }
@@ -1111,7 +1135,7 @@ int twx_process_windows(twx_ctx* ctx, const int16_t* iq, int64_t n_windows, int3
                         const twx_band* band, const double* df, twx_result* out) {
     if (!ctx) return TWX_E_ARG;
     CtxBase* c = ctx->impl;
-    if (!iq || !out || n_windows < 0 || n_channels < 1 || channel < 0 || channel >= n_channels) return c->fail(TWX_E_ARG, "bad argument");
+    if (!iq || !out || n_windows < 0 || n_channels < 1 || channel < TWX_ALL_CHANNELS || channel >= n_channels || (channel < 0 && n_channels > TWX_MAX_CHANNELS)) return c->fail(TWX_E_ARG, "bad argument");
     if (n_windows == 0) return TWX_OK;
     (void)hipSetDevice(c->dev);
     // pinned double-buffered staging: the host-side copy, the H2D transfer and the kernels of consecutive
@@ -1147,7 +1171,7 @@ int twx_process_file(twx_ctx* ctx, const char* path, int32_t n_channels, int32_t
                      double df_const, twx_result* out, int64_t max_windows, int64_t* n_done) {
     if (!ctx) return TWX_E_ARG;
     CtxBase* c = ctx->impl;
-    if (!path || !out || !n_done || max_windows < 0 || n_channels < 1 || channel < 0 || channel >= n_channels || skip_samples < 0) return c->fail(TWX_E_ARG, "bad argument");
+    if (!path || !out || !n_done || max_windows < 0 || n_channels < 1 || channel < TWX_ALL_CHANNELS || channel >= n_channels || (channel < 0 && n_channels > TWX_MAX_CHANNELS) || skip_samples < 0) return c->fail(TWX_E_ARG, "bad argument");
     (void)hipSetDevice(c->dev);
     long long nd = 0;
     int rc = c->process_file(path, n_channels, channel, skip_samples, band, df_const, out, max_windows, &nd);

@@ -1298,7 +1298,8 @@ template <typename T> struct PeakArgs {
     int var_ddof, snr_rot;
     int convention;              // TWX_CONV_*
     int snr_valid;               // 0: replica is not a +-1 code, the wipe-off statistics are undefined
-    twx_result* res;             // [b]
+    twx_result* res;             // record of window b at res[b * res_stride]
+    int res_stride;              // 1, or the channel count when all channels of a window are interleaved in the output
 };
 
 template <typename T>
@@ -1384,7 +1385,7 @@ __global__ __launch_bounds__(1024) void k_peak(PeakArgs<T> a) {
         r.puissancecode = ok ? mr * mr + mi * mi : nan("");
         r.puissancenoise = ok ? var : nan("");
         r.status = 0; r.reserved = 0;
-        a.res[b] = r;
+        a.res[(long long)b * a.res_stride] = r;
     }
 }
 

@@ -39,8 +39,11 @@ def run(datalocation="./", codelocation="./codes/", remote=0, OP=0, fs=5e6, Nint
                 out.write(f"{nom} already done\n")
                 continue
             out.write(base + "\n")
-            r1 = cor.process_file(cap, n_channels=2, channel=0, band=band)
-            r2 = cor.process_file(cap, n_channels=2, channel=1, band=band) if remote != 1 else None
+            if remote != 1:                    # both channels of every window from one pass over the file (:91,95)
+                both = cor.process_file(cap, n_channels=2, channel=-1, band=band)
+                r1, r2 = both[0], both[1]
+            else:
+                r1, r2 = cor.process_file(cap, n_channels=2, channel=0, band=band), None
             for row in results_io.tsv_rows(r1, r2, fs, Nint):
                 out.write(row)
             results_io.save_mat(nom, r1, r2, code=prn.chips_to_code(chips), remote=remote)

@@ -120,6 +120,11 @@ int twx_get_info(const twx_ctx* ctx, twx_info* info);
 int twx_process_windows(twx_ctx* ctx, const int16_t* iq, int64_t n_windows, int32_t n_channels,
                         int32_t channel, const twx_band* band, const double* df, twx_result* out);
 
+/* channel = TWX_ALL_CHANNELS in twx_process_windows, twx_process_windows_dev and twx_process_file processes every
+ * channel of every window from ONE copy of the capture (godual_ranging.m:91,95 calls processing() on both channels of
+ * each window): results out[w*n_channels + c], and df — where given — df[w*n_channels + c].  n_channels <= 4. */
+#define TWX_ALL_CHANNELS (-1)
+
 /* Same with the capture already resident in DEVICE memory (iq_dev) and results written to
  * DEVICE memory (out_dev, n_windows records).  Asynchronous on the context's stream:
  * call twx_synchronize() before reading.  df (host pointer) is copied at enqueue time. */

@@ -767,3 +767,28 @@ def test_randomised_parity_sweep():
             else:
                 assert abs(abs(g.xval) - abs(o["xval"])) <= MAG_TOL * abs(o["xval"])
     assert not mism, mism
+
+
+def test_all_channels_from_one_copy(tmp_path):
+    """channel = -1: both channels of every window from one upload / one pass over the file equal the per-channel calls
+    (host buffer with more chunks than slots, device-resident, file)."""
+    chips, raw = _capture(14, 43, 10000, 9, seed=23)
+    n = 20000
+    band = band_numpy(FS, n)
+    dfs = np.stack([np.full(9, 1780.75), np.zeros(9)], axis=1) + np.arange(9)[:, None] * 0.5
+    with Correlator(chips, fs=FS, Nint=1, max_batch=2) as cor:
+        sep = {c: cor.process(raw, 2, c, band=band) for c in (0, 1)}
+        both = cor.process(raw, 2, -1, band=band)
+        sep_df = {c: cor.process(raw, 2, c, df=dfs[:, c]) for c in (0, 1)}
+        both_df = cor.process(raw, 2, -1, df=dfs)
+        path = tmp_path / "1670000001.bin"
+        raw.tofile(path)
+        both_file = cor.process_file(str(path), 2, -1, band=band)
+        rng = cor.ranging(raw, n_channels=2)
+    for c in (0, 1):
+        for a, b_, f, r in zip(sep[c], both[c], both_file[c], rng[c]):
+            for x in (b_, f, r):
+                assert (a.indice, a.xval, a.correction, a.df, a.SNRr, a.puissance) == (x.indice, x.xval, x.correction, x.df, x.SNRr, x.puissance)
+        for a, b_ in zip(sep_df[c], both_df[c]):
+            assert (a.indice, a.xval, a.df) == (b_.indice, b_.xval, b_.df)
+    assert len(both[0]) == len(both[1]) == 9
