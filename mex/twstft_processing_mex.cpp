@@ -8,6 +8,7 @@
 //     [indice,correction,SNRr,SNRi,df,puissance,puissancecode,puissancenoise,xval] = ...
 //         twstft_processing_mex(raw_int16, nchan, chan, k_or_df, code_chips, fs, Nint)
 //   raw_int16 : int16 vector as returned by fread(f, N*2*nchan, 'int16=>int16') for whole windows
+//   chan      : 1-based channel, or 0 = every channel from one upload (outputs become nchan x nwin)
 //   k_or_df   : [k_lo k_hi] 1-based indices into the fftshifted axis (as find(...) gives), or a scalar df (Hz)
 //   code_chips: the code file bytes (0/1), before repelems
 //   outputs are 1 x nwin; indice is 1-based like Octave's max().
@@ -54,18 +55,19 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     twx_info info;
     twx_get_info(g_ctx, &info);
     const int64_t nwin = (int64_t)(mxGetNumberOfElements(prhs[0]) / (size_t)(info.n * 2 * nch));
-    std::vector<twx_result> res((size_t)(nwin > 0 ? nwin : 1));
+    const int nco = ch < 0 ? nch : 1;                    // chan = 0: all channels, results [window][channel]
+    std::vector<twx_result> res((size_t)(nwin > 0 ? nwin * nco : 1));
     twx_band band; std::vector<double> dfv;
     const bool estimate = mxGetNumberOfElements(prhs[3]) == 2;
     if (estimate) { band.k_lo = (int64_t)mxGetPr(prhs[3])[0] - 1; band.k_hi = (int64_t)mxGetPr(prhs[3])[1] - 1; }
-    else dfv.assign((size_t)(nwin > 0 ? nwin : 1), mxGetScalar(prhs[3]));
+    else dfv.assign((size_t)(nwin > 0 ? nwin * nco : 1), mxGetScalar(prhs[3]));
     int rc = twx_process_windows(g_ctx, raw, nwin, nch, ch, estimate ? &band : nullptr, estimate ? nullptr : dfv.data(), res.data());
     if (rc) mexErrMsgIdAndTxt("twstft:process", "%s", twx_last_error(g_ctx));
     double* o[8];
-    for (int i = 0; i < 8 && i < (nlhs > 0 ? nlhs : 1); ++i) { plhs[i] = mxCreateDoubleMatrix(1, (mwSize)nwin, mxREAL); o[i] = mxGetPr(plhs[i]); }
+    for (int i = 0; i < 8 && i < (nlhs > 0 ? nlhs : 1); ++i) { plhs[i] = mxCreateDoubleMatrix((mwSize)nco, (mwSize)nwin, mxREAL); o[i] = mxGetPr(plhs[i]); }
     mxArray* xv = nullptr;
-    if (nlhs > 8) { xv = mxCreateDoubleMatrix(1, (mwSize)nwin, mxCOMPLEX); plhs[8] = xv; }
-    for (int64_t w = 0; w < nwin; ++w) {
+    if (nlhs > 8) { xv = mxCreateDoubleMatrix((mwSize)nco, (mwSize)nwin, mxCOMPLEX); plhs[8] = xv; }
+    for (int64_t w = 0; w < nwin * nco; ++w) {          // column-major nco x nwin == the library's [window][channel] order
         const twx_result& r = res[(size_t)w];
         const double vals[8] = {(double)r.indice0 + 1.0, r.correction, r.SNRr, r.SNRi, r.df, r.puissance, r.puissancecode, r.puissancenoise};
         for (int i = 0; i < 8 && i < (nlhs > 0 ? nlhs : 1); ++i) o[i][w] = vals[i];
