@@ -312,9 +312,12 @@ class Correlator:
         return out
 
     # -- device-resident input (pointers from twx_dev_alloc or any HIP allocation) -------------
-    def process_dev(self, iq_dev: int, nwin: int, n_channels=1, channel=0, band=None, df=None) -> list[WindowResult]:
-        """``process`` on ``nwin`` consecutive windows that already sit in device memory at ``iq_dev``."""
-        nbytes = C.sizeof(L.twx_result) * max(nwin, 1)
+    def process_dev(self, iq_dev: int, nwin: int, n_channels=1, channel=0, band=None, df=None):
+        """``process`` on ``nwin`` consecutive windows that already sit in device memory at ``iq_dev``
+        (``channel = -1``: all channels → ``{c: [WindowResult …]}``)."""
+        allch = channel < 0
+        nrec = max(nwin * (n_channels if allch else 1), 1)
+        nbytes = C.sizeof(L.twx_result) * nrec
         res = self._lib.twx_dev_alloc(nbytes)
         if not res:
             raise MemoryError("twx_dev_alloc failed")
@@ -324,14 +327,17 @@ class Correlator:
                 b = L.twx_band(int(band[0]), int(band[1]))
                 bptr = C.byref(b)
             else:
-                dfa = np.ascontiguousarray(np.broadcast_to(np.asarray(df, dtype=np.float64), (nwin,)))
+                shape = (nwin, n_channels) if allch else (nwin,)
+                dfa = np.ascontiguousarray(np.broadcast_to(np.asarray(df, dtype=np.float64), shape))
                 dptr = dfa.ctypes.data_as(C.c_void_p)
             L.check(self._lib.twx_process_windows_dev(self._h, iq_dev, nwin, n_channels, channel, bptr, dptr, res), self._h)
             L.check(self._lib.twx_synchronize(self._h), self._h)
-            out = (L.twx_result * max(nwin, 1))()
+            out = (L.twx_result * nrec)()
             L.check(self._lib.twx_memcpy_d2h(C.cast(out, C.c_void_p), res, nbytes))
         finally:
             self._lib.twx_dev_free(res)
+        if allch:
+            return {c: [_to_result(out[w * n_channels + c]) for w in range(nwin)] for c in range(n_channels)}
         return [_to_result(out[i]) for i in range(nwin)]
 
     def sqspec_bins_dev(self, iq_dev: int, n_samples: int, bins, n_channels=1, channel=0) -> np.ndarray:
