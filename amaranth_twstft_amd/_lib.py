@@ -87,6 +87,8 @@ SYMBOLS = {
     "twx_sqspec_band_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _VP]),
     "twx_sliding_dot": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_double, C.c_double, C.c_double, _VP]),
     "twx_fir_decimate": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_int32, C.c_int32, _VP, _VP, C.POINTER(C.c_int64)]),
+    "twx_sliding_dot_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_double, C.c_double, C.c_double, _VP]),
+    "twx_fir_decimate_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_int32, C.c_int32, _VP, _VP, C.POINTER(C.c_int64)]),
     "twx_debug_stamps": (C.c_int, [_VP, _VP, C.c_longlong]),
     "twx_profile_reset": (C.c_int, [_VP]),
     "twx_profile_get": (C.c_int, [_VP, C.POINTER(twx_prof_entry), C.c_int32, C.POINTER(C.c_int32)]),

@@ -190,9 +190,11 @@ class Correlator:
         return [_to_result(out[i]) for i in range(nwin)]
 
     def process_file(self, path: str, n_channels=1, channel=0, band=None, df=None, skip_samples: int = 0,
-                     max_windows: int | None = None):
+                     max_windows: int | None = None, raw_records: bool = False):
         """Window loop over a capture file (godual_ranging.m:70-103), pinned double-buffered ingest.
-        ``channel = -1``: every channel from one pass over the file → ``{c: [WindowResult …]}``."""
+        ``channel = -1``: every channel from one pass over the file → ``{c: [WindowResult …]}``.
+        ``raw_records``: return the ``twx_result`` records as a uint8 array [n_records, sizeof(twx_result)] (record
+        w*n_channels + c in the all-channel mode) — what the ranks of a multi-GPU job exchange (dist.gather_results)."""
         import os
         per = self.n * 4 * n_channels
         avail = max(0, (os.path.getsize(path) - skip_samples * 4 * n_channels)) // per
@@ -209,6 +211,9 @@ class Correlator:
         ndone = C.c_int64()
         L.check(self._lib.twx_process_file(self._h, os.fsencode(path), n_channels, channel, skip_samples, bptr,
                                            float(df) if df is not None else 0.0, C.cast(out, C.c_void_p), nmax, C.byref(ndone)), self._h)
+        if raw_records:
+            nrec = ndone.value * nch_out
+            return np.frombuffer(bytes(out), dtype=np.uint8).reshape(-1, C.sizeof(L.twx_result))[:nrec].copy()
         if allch:
             return {c: [_to_result(out[w * n_channels + c]) for w in range(ndone.value)] for c in range(n_channels)}
         return [_to_result(out[i]) for i in range(ndone.value)]
@@ -339,6 +344,28 @@ class Correlator:
         if allch:
             return {c: [_to_result(out[w * n_channels + c]) for w in range(nwin)] for c in range(n_channels)}
         return [_to_result(out[i]) for i in range(nwin)]
+
+    # -- front end and short-code direct path on device-resident data (context's stream, no host round trip) ----
+    def fir_decimate_dev(self, iq_dev: int, n_in: int, taps, dec: int, out_i16_dev: int | None = None,
+                         out_f32_dev: int | None = None, n_channels=1, channel=0) -> int:
+        """``y[m] = sum_j taps[j]*x[m*dec+j]`` of a device-resident capture into device buffers (int16 ``[I Q]`` and/or
+        complex64); returns the number of outputs.  The int16 output feeds :meth:`process_dev` directly
+        (BASELINE.json configs[4]: 70 Msps → 5 Msps → correlator).  Asynchronous on the context's stream."""
+        t = np.ascontiguousarray(taps, dtype=np.float32)
+        nout = C.c_int64()
+        L.check(self._lib.twx_fir_decimate_dev(self._h, iq_dev, int(n_in), n_channels, channel, t.ctypes.data_as(C.c_void_p), t.size,
+                                               int(dec), out_i16_dev, out_f32_dev, C.byref(nout)), self._h)
+        return int(nout.value)
+
+    def sliding_dot_dev(self, iq_dev: int, n_samples: int, replica_dev: int, nobs: int, ncodes: int, nlag: int, out_dev: int,
+                        pt: int = 0, ff: float = 0.0, phi: float = 0.0, scale: float = 1.0, n_channels=1, channel=0) -> None:
+        """±nlag sliding dot products per code period (tracking.sliding_dot) on device-resident samples and replica;
+        ``out_dev``: ncodes*(2*nlag+1) complex128 on the device.  Asynchronous on the context's stream."""
+        L.check(self._lib.twx_sliding_dot_dev(self._h, iq_dev, int(n_samples), n_channels, channel, int(pt), int(nobs), int(ncodes),
+                                              int(nlag), replica_dev, float(ff), float(phi), float(scale), out_dev), self._h)
+
+    def synchronize(self):
+        L.check(self._lib.twx_synchronize(self._h), self._h)
 
     def sqspec_bins_dev(self, iq_dev: int, n_samples: int, bins, n_channels=1, channel=0) -> np.ndarray:
         """``fft(d.^2)`` of an ``n_samples`` chunk at the given signed DFT bins (complex128)."""

@@ -16,6 +16,7 @@
 
 #include "twx_kernels.h"
 #include "twx_plans.h"
+#include "twx_internal.h"
 
 namespace twx {
 
@@ -229,6 +230,14 @@ struct CtxBase {
             if (it->first == p) { dev_bytes -= (long long)it->second; allocs.erase(it); break; }
         (void)hipFree(p);
     }
+    // device temporaries of one call: returned to the allocator on every exit path
+    struct Scratch {
+        CtxBase* c; std::vector<void*> ptrs;
+        explicit Scratch(CtxBase* c_) : c(c_) {}
+        Scratch(const Scratch&) = delete;
+        ~Scratch() { for (void* p : ptrs) c->dfree(p); }
+        template <typename U> int get(U** p, size_t count) { int rc = c->dalloc(p, count); if (!rc) ptrs.push_back(*p); return rc; }
+    };
     hipEvent_t get_event() {
         if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
         hipEvent_t e; (void)hipEventCreate(&e); return e;
@@ -255,6 +264,7 @@ struct CtxBase {
         }
         prof_pending.clear();
     }
+    void* aux_buf[AUX_SCRATCH_SLOTS] = {}; size_t aux_cap[AUX_SCRATCH_SLOTS] = {};   // ctx_scratch (twx_internal.h)
     int remove_mean = 1;          // TWX_OPT_REMOVE_MEAN
     int snr_valid = 1;            // 0 for replicas that are not a +-1 code
     virtual int init() = 0;
@@ -325,6 +335,7 @@ template <typename T> struct Ctx : CtxBase {
         ArgPart<T>*part_band, *part_peak; twx_result* res_dev; double* fine_u;
     };
     Slot slots[4] = {}; int nslots = 1;
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {};   // ordering of slots 1.. against slot 0 = twx_stream() (process())
     struct Stage { void* host; short2* dev; size_t bytes; long long w0; int nb; };
     Stage stage[4] = {};     // pinned host + device staging of twx_process_file, kept across calls
     void use_slot(int k) {
@@ -491,6 +502,8 @@ template <typename T> struct Ctx : CtxBase {
     ~Ctx() override {
         for (int k = 0; k < 4; ++k) { if (stage[k].host) (void)hipHostFree(stage[k].host); if (stage[k].dev) (void)hipFree(stage[k].dev); }
         for (int k = 1; k < nslots; ++k) if (slots[k].stream) (void)hipStreamDestroy(slots[k].stream);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        for (auto e : ev_join) if (e) (void)hipEventDestroy(e);
         stream = slots[0].stream ? slots[0].stream : stream;   // base class destroys slot 0's stream
     }
     int init() override {
@@ -570,8 +583,11 @@ template <typename T> struct Ctx : CtxBase {
         for (int k = 0; k < nslots; ++k) {
             Slot& q = slots[k];
             memset(&q, 0, sizeof q);
-            if (k == 0) q.stream = stream;
-            else HIPCHK(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
+            if (k == 0) { q.stream = stream; HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); }
+            else {
+                HIPCHK(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming));
+            }
             if (int rc = dalloc(&q.sums, (size_t)B)) return rc;
             if (int rc = dalloc(&q.dfv, (size_t)B)) return rc;
             if (int rc = dalloc(&q.dfidx, (size_t)B)) return rc;
@@ -722,9 +738,19 @@ template <typename T> struct Ctx : CtxBase {
         const int c_lo = all ? 0 : ch, c_hi = all ? nch : ch + 1, ostride = all ? nch : 1;
         std::vector<double> dfc;
         int k = 0;
-        for (long long w0 = 0; w0 < nwin; w0 += B) {
+        // Everything is ordered against slot 0's stream (= twx_stream()): the other slots start after what the caller
+        // enqueued there before this call (the producer of iq_dev), and slot 0 ends up waiting for all of them, so a
+        // consumer of out_dev enqueued on twx_stream() after the call sees every record.
+        const long long nbatches = ((nwin + B - 1) / B) * (c_hi - c_lo);
+        const int nused = (int)std::min<long long>(nslots, nbatches);
+        if (nused > 1) {
+            HIPCHK(hipEventRecord(ev_fork, slots[0].stream));
+            for (int j = 1; j < nused; ++j) HIPCHK(hipStreamWaitEvent(slots[j].stream, ev_fork, 0));
+        }
+        int rc = TWX_OK;
+        for (long long w0 = 0; w0 < nwin && rc == TWX_OK; w0 += B) {
             const int nb = (int)std::min<long long>(B, nwin - w0);
-            for (int c = c_lo; c < c_hi; ++c, k = (k + 1) % nslots) {
+            for (int c = c_lo; c < c_hi && rc == TWX_OK; ++c, k = (k + 1) % nslots) {
                 const double* dfp = nullptr;
                 if (df) {
                     if (all) { dfc.resize((size_t)nb); for (int i = 0; i < nb; ++i) dfc[(size_t)i] = df[(w0 + i) * nch + c]; dfp = dfc.data(); }
@@ -732,18 +758,23 @@ template <typename T> struct Ctx : CtxBase {
                 }
                 use_slot(k);
                 const short2* base = reinterpret_cast<const short2*>(iq_dev) + c;
-                if (int rc = run_batch(base + w0 * N * nch, nb, nch, band, dfp, out_dev + w0 * ostride + (all ? c : 0), nullptr, false, ostride)) { use_slot(0); return rc; }
+                rc = run_batch(base + w0 * N * nch, nb, nch, band, dfp, out_dev + w0 * ostride + (all ? c : 0), nullptr, false, ostride);
             }
         }
         use_slot(0);
-        return TWX_OK;
+        for (int j = 1; j < nused; ++j) {
+            if (hipEventRecord(ev_join[j], slots[j].stream) != hipSuccess || hipStreamWaitEvent(slots[0].stream, ev_join[j], 0) != hipSuccess)
+                if (rc == TWX_OK) rc = fail(TWX_E_HIP, "slot join failed");
+        }
+        return rc;
     }
 
     int fft_forward(const double* in, double* out) override {
         cpx<double>* din = nullptr; C* tmp = nullptr; C* spec = nullptr;
-        if (int rc = dalloc(&din, (size_t)N)) return rc;
-        if (int rc = dalloc(&tmp, (size_t)N)) return rc;
-        if (int rc = dalloc(&spec, (size_t)N)) return rc;
+        Scratch sc(this);
+        if (int rc = sc.get(&din, (size_t)N)) return rc;
+        if (int rc = sc.get(&tmp, (size_t)N)) return rc;
+        if (int rc = sc.get(&spec, (size_t)N)) return rc;
         HIPCHK(hipMemcpy(din, in, (size_t)N * 16, hipMemcpyHostToDevice));
         ColFwdArgs<T> ca{};
         ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = 1; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.tc = tcw; ca.out = tmp;
@@ -759,7 +790,6 @@ template <typename T> struct Ctx : CtxBase {
                 const long long k = k1 + (long long)N1 * k2;
                 out[2 * k] = (double)h[(size_t)k1 * N2 + k2].x; out[2 * k + 1] = (double)h[(size_t)k1 * N2 + k2].y;
             }
-        dfree(din); dfree(tmp); dfree(spec);
         return TWX_OK;
     }
     int code_spectrum(double* out) override {
@@ -774,23 +804,24 @@ template <typename T> struct Ctx : CtxBase {
     }
     int xcorr_map(const int16_t* iq, int nch, int ch, double df, double* out) override {
         short2* din = nullptr; C* z = nullptr;
-        if (int rc = dalloc(&din, (size_t)N * nch)) return rc;
-        if (int rc = dalloc(&z, (size_t)N * R)) return rc;
+        Scratch sc(this);
+        if (int rc = sc.get(&din, (size_t)N * nch)) return rc;
+        if (int rc = sc.get(&z, (size_t)N * R)) return rc;
         HIPCHK(hipMemcpy(din, iq, (size_t)N * nch * 4, hipMemcpyHostToDevice));
         int rc = run_batch(din + ch, 1, nch, nullptr, &df, res_dev, z);
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(stream));
         std::vector<C> h((size_t)N * R);
         HIPCHK(hipMemcpy(h.data(), z, h.size() * sizeof(C), hipMemcpyDeviceToHost));
-        const double sc = 1.0 / scale_pow2 / ((double)N * R);
-        for (size_t i = 0; i < h.size(); ++i) { out[2 * i] = (double)h[i].x * sc; out[2 * i + 1] = (double)h[i].y * sc; }
-        dfree(din); dfree(z);
+        const double nrm = 1.0 / scale_pow2 / ((double)N * R);
+        for (size_t i = 0; i < h.size(); ++i) { out[2 * i] = (double)h[i].x * nrm; out[2 * i + 1] = (double)h[i].y * nrm; }
         return TWX_OK;
     }
 
     int caf_freqs(const int16_t* iq, int nch, int ch, const double* freqs, long long nf, twx_result* out) override {
         short2* din = nullptr;
-        if (int rc = dalloc(&din, (size_t)N * nch)) return rc;
+        Scratch sc(this);
+        if (int rc = sc.get(&din, (size_t)N * nch)) return rc;
         HIPCHK(hipMemcpy(din, iq, (size_t)N * nch * 4, hipMemcpyHostToDevice));
         for (long long f0 = 0; f0 < nf; f0 += B) {
             const int nb = (int)std::min<long long>(B, nf - f0);
@@ -798,7 +829,6 @@ template <typename T> struct Ctx : CtxBase {
             HIPCHK(hipMemcpyAsync(out + f0, res_dev, sizeof(twx_result) * nb, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
         }
-        dfree(din);
         return TWX_OK;
     }
 
@@ -808,8 +838,9 @@ template <typename T> struct Ctx : CtxBase {
         long long hb[64];
         for (int i = 0; i < nb; ++i) { hb[i] = bins[i] % L; if (hb[i] < 0) hb[i] += L; }
         long long* bd = nullptr; double* acc = nullptr;
-        if (int rc = dalloc(&bd, (size_t)nb)) return rc;
-        if (int rc = dalloc(&acc, (size_t)2 * nb)) return rc;
+        Scratch sc(this);
+        if (int rc = sc.get(&bd, (size_t)nb)) return rc;
+        if (int rc = sc.get(&acc, (size_t)2 * nb)) return rc;
         HIPCHK(hipMemcpyAsync(bd, hb, sizeof(long long) * nb, hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemsetAsync(acc, 0, sizeof(double) * 2 * nb, stream));
         const unsigned grid = (unsigned)std::min<long long>(2048, (L + 255) / 256);
@@ -817,7 +848,6 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(out, acc, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        dfree(bd); dfree(acc);
         return TWX_OK;
     }
     // |fft(d.^2)| of an L = M*N sample chunk over nk consecutive (signed) bins from k_lo: M decimated
@@ -828,8 +858,9 @@ template <typename T> struct Ctx : CtxBase {
         const long long M = L / N;
         if (M > 4096 || nch * M > 0x7fffffffll) return fail(TWX_E_ARG, "sqspec_band: chunk too long for this window length");
         C* spec = nullptr; double* mag = nullptr;
-        if (int rc = dalloc(&spec, (size_t)(M * N))) return rc;
-        if (int rc = dalloc(&mag, (size_t)nk)) return rc;
+        Scratch sc(this);
+        if (int rc = sc.get(&spec, (size_t)(M * N))) return rc;
+        if (int rc = sc.get(&mag, (size_t)nk)) return rc;
         if (int rc = sync_all()) return rc;
         use_slot(0);
         const short2* base = reinterpret_cast<const short2*>(iq_dev) + ch;
@@ -847,7 +878,6 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(out, mag, sizeof(double) * nk, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        dfree(spec); dfree(mag);
         return TWX_OK;
     }
 
@@ -914,8 +944,17 @@ template <typename T> struct Ctx : CtxBase {
             });
         };
         std::future<long long> rd[4];
-        hipEvent_t h2d_done[4] = {};
-        for (int k = 0; k < nslots; ++k) (void)hipEventCreateWithFlags(&h2d_done[k], hipEventDisableTiming);
+        struct Events {                          // destroyed on every exit path, exceptions included
+            hipEvent_t e[4] = {}; bool used[4] = {};
+            ~Events() { for (auto& x : e) if (x) { (void)hipEventSynchronize(x); (void)hipEventDestroy(x); } }
+        } h2d;
+        hipEvent_t* h2d_done = h2d.e;
+        struct Readers {                         // never leave a helper thread writing into a pinned buffer behind
+            std::future<long long>* r; int n;
+            ~Readers() { for (int k = 0; k < n; ++k) if (r[k].valid()) { try { (void)r[k].get(); } catch (...) {} } }
+        } readers{rd, nslots};
+        for (int k = 0; k < nslots; ++k)
+            if (hipEventCreateWithFlags(&h2d_done[k], hipEventDisableTiming) != hipSuccess) return fail(TWX_E_HIP, "hipEventCreate failed");
         long long next_chunk = 0;
         for (int k = 0; k < nslots; ++k) rd[k] = start_read(k, next_chunk++);
         long long w0 = 0;
@@ -923,6 +962,10 @@ template <typename T> struct Ctx : CtxBase {
         int kprev = -1;
         for (int k = 0; rc == TWX_OK && !eof; k = (k + 1) % nslots) {
             const long long want = std::max<long long>(0, std::min<long long>(B, max_windows - w0));
+            if (!rd[k].valid()) {                // single slot: nobody refilled this buffer while another slot ran
+                if (h2d.used[k]) (void)hipEventSynchronize(h2d_done[k]);
+                rd[k] = start_read(k, next_chunk++);
+            }
             const int nb = (int)rd[k].get();
             if ((long long)nb < want || want == 0) eof = true;
             rc = drain(k);                       // results of the batch that used this slot nslots chunks ago
@@ -930,7 +973,7 @@ template <typename T> struct Ctx : CtxBase {
             if (nb > 0) {
                 use_slot(k);
                 if (hipMemcpyAsync(st[k].dev, st[k].host, win_bytes * nb, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = fail(TWX_E_HIP, "H2D copy failed"); break; }
-                (void)hipEventRecord(h2d_done[k], stream);
+                (void)hipEventRecord(h2d_done[k], stream); h2d.used[k] = true;
                 for (int c = c_lo; c < c_hi && rc == TWX_OK; ++c) {        // same staged copy for every requested channel
                     const double* dfp = nullptr;
                     if (!band) {
@@ -944,11 +987,11 @@ template <typename T> struct Ctx : CtxBase {
                 w0 += nb;
             }
             // refill the pinned buffer of the PREVIOUS slot: its H2D copy had a whole iteration to finish
-            if (kprev >= 0 && !eof) { (void)hipEventSynchronize(h2d_done[kprev]); rd[kprev] = start_read(kprev, next_chunk++); }
+            if (kprev >= 0 && kprev != k && !eof) { (void)hipEventSynchronize(h2d_done[kprev]); rd[kprev] = start_read(kprev, next_chunk++); }
             kprev = k;
         }
         for (int k = 0; k < nslots; ++k) if (rd[k].valid()) (void)rd[k].get();
-        for (int k = 0; k < nslots; ++k) if (h2d_done[k]) { (void)hipEventSynchronize(h2d_done[k]); (void)hipEventDestroy(h2d_done[k]); }
+        for (int k = 0; k < nslots; ++k) if (h2d.used[k]) (void)hipEventSynchronize(h2d_done[k]);
         for (int k = 0; k < nslots; ++k) { int r2 = drain(k); if (rc == TWX_OK) rc = r2; }
         use_slot(0);
         return rc;
@@ -957,7 +1000,8 @@ template <typename T> struct Ctx : CtxBase {
     int process_file(const char* path, int nch, int ch, long long skip, const twx_band* band, double df_const,
                      twx_result* out, long long max_windows, long long* n_done) override {
         *n_done = 0;
-        FILE* f = fopen(path, "rb");
+        struct File { FILE* f; ~File() { if (f) fclose(f); } } file{fopen(path, "rb")};
+        FILE* f = file.f;
         if (!f) return fail(TWX_E_ARG, std::string("cannot open ") + path);
         const int fd = fileno(f);
         const off_t base_off = (off_t)skip * nch * 4;
@@ -970,9 +1014,7 @@ template <typename T> struct Ctx : CtxBase {
             }
             return done;
         };
-        const int rc = run_pipeline(read_at, nch, ch, band, nullptr, df_const, out, max_windows, n_done);
-        fclose(f);
-        return rc;
+        return run_pipeline(read_at, nch, ch, band, nullptr, df_const, out, max_windows, n_done);
     }
 
     int process_host(const int16_t* iq, long long nwin, int nch, int ch, const twx_band* band, const double* df,
@@ -996,10 +1038,12 @@ template <typename T> struct Ctx : CtxBase {
         if (k_hi < k_lo) return fail(TWX_E_ARG, "k_hi < k_lo");
         short2* din = nullptr; C* Ysp = nullptr; double* pk_d = nullptr; long long* lag_d = nullptr;
         const int nbmax = B * R;
-        if (int rc = dalloc(&din, (size_t)N * nch)) return rc;
-        if (int rc = dalloc(&Ysp, (size_t)N)) return rc;
-        if (int rc = dalloc(&pk_d, (size_t)nbmax)) return rc;
-        if (int rc = dalloc(&lag_d, (size_t)nbmax)) return rc;
+        const long long nbins = k_hi - k_lo + 1;
+        Scratch sc(this);
+        if (int rc = sc.get(&din, (size_t)N * nch)) return rc;
+        if (int rc = sc.get(&Ysp, (size_t)N)) return rc;
+        if (int rc = sc.get(&pk_d, (size_t)nbins)) return rc;       // every bin's record stays on the device until the end:
+        if (int rc = sc.get(&lag_d, (size_t)nbins)) return rc;      // one D2H copy and one synchronisation per call
         HIPCHK(hipMemcpy(din, iq, (size_t)N * nch * 4, hipMemcpyHostToDevice));
         const short2* in = din + ch;
         HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums), stream));
@@ -1021,13 +1065,12 @@ template <typename T> struct Ctx : CtxBase {
             ColInvArgs<T> ia{};
             ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = 1; ia.nwin = nb; ia.Bz = Bz; ia.tw1 = tw1; ia.part = part_peak; ia.zout = nullptr;
             if (col->inv(&ia, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_inv launch failed");
-            TWX_LAUNCH((k_caf_reduce<T>), dim3(nb), dim3(256), stream, part_peak, ntiles, 1.0 / scale_pow2 / (double)N, pk_d, lag_d);
+            TWX_LAUNCH((k_caf_reduce<T>), dim3(nb), dim3(256), stream, part_peak, ntiles, 1.0 / scale_pow2 / (double)N, pk_d + (k0 - k_lo), lag_d + (k0 - k_lo));
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(pk + (k0 - k_lo), pk_d, sizeof(double) * nb, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipMemcpyAsync(lag + (k0 - k_lo), lag_d, sizeof(long long) * nb, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
         }
-        dfree(din); dfree(Ysp); dfree(pk_d); dfree(lag_d);
+        HIPCHK(hipMemcpyAsync(pk, pk_d, sizeof(double) * (size_t)nbins, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(lag, lag_d, sizeof(long long) * (size_t)nbins, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
         return TWX_OK;
     }
 };
@@ -1039,6 +1082,23 @@ template <typename T> struct Ctx : CtxBase {
 // ------------------------------------------------------------------------------------------
 using namespace twx;
 struct twx_ctx { CtxBase* impl; };
+
+namespace twx {
+hipStream_t ctx_stream(twx_ctx* ctx) { return ctx->impl->stream; }
+int ctx_fail(twx_ctx* ctx, int code, const char* msg) { return ctx->impl->fail(code, msg); }
+int ctx_set_device(twx_ctx* ctx) { return hipSetDevice(ctx->impl->dev) == hipSuccess ? TWX_OK : ctx->impl->fail(TWX_E_HIP, "hipSetDevice failed"); }
+void* ctx_scratch(twx_ctx* ctx, int slot, size_t bytes) {
+    CtxBase* c = ctx->impl;
+    if (slot < 0 || slot >= AUX_SCRATCH_SLOTS) { c->fail(TWX_E_ARG, "bad scratch slot"); return nullptr; }
+    if (c->aux_cap[slot] >= bytes && c->aux_buf[slot]) return c->aux_buf[slot];
+    if (c->aux_buf[slot]) { (void)c->sync_all(); c->dfree(c->aux_buf[slot]); c->aux_buf[slot] = nullptr; c->aux_cap[slot] = 0; }
+    char* p = nullptr;
+    const size_t want = bytes + bytes / 8 + 256;          // a little head-room: sizes that creep up do not re-allocate every call
+    if (c->dalloc(&p, want)) return nullptr;
+    c->aux_buf[slot] = p; c->aux_cap[slot] = want;
+    return p;
+}
+}  // namespace twx
 
 // No exception may cross the C boundary (std::async, std::vector and std::string can throw).
 template <class F> static int guarded(CtxBase* c, F f) noexcept {
@@ -1174,7 +1234,7 @@ int twx_process_file(twx_ctx* ctx, const char* path, int32_t n_channels, int32_t
     if (!path || !out || !n_done || max_windows < 0 || n_channels < 1 || channel < TWX_ALL_CHANNELS || channel >= n_channels || (channel < 0 && n_channels > TWX_MAX_CHANNELS) || skip_samples < 0) return c->fail(TWX_E_ARG, "bad argument");
     (void)hipSetDevice(c->dev);
     long long nd = 0;
-    int rc = c->process_file(path, n_channels, channel, skip_samples, band, df_const, out, max_windows, &nd);
+    int rc = guarded(c, [&]() { return c->process_file(path, n_channels, channel, skip_samples, band, df_const, out, max_windows, &nd); });
     *n_done = nd;
     return rc;
 }

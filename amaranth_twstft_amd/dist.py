@@ -30,16 +30,17 @@ def max_shard(n_windows: int, world: int) -> int:
     return -(-n_windows // world)
 
 
-def gather_results(local, n_windows: int, rank: int, world: int, device=None):
+def gather_results(local, n_windows: int, rank: int, world: int, device=None, per_window: int = 1):
     """all_gather the local result records → numpy structured bytes for all ``n_windows``.
 
-    ``local``: torch uint8 tensor [n_local, RESULT_BYTES] (on the rank's GPU for RCCL, on CPU for
-    gloo).  Shards are padded to a common length so a single ``all_gather_into_tensor`` suffices
+    ``local``: torch uint8 tensor [n_local*per_window, RESULT_BYTES] (on the rank's GPU for RCCL, on CPU
+    for gloo); ``per_window`` records belong to one window (the channels of the all-channel mode).
+    Shards are padded to a common length so a single ``all_gather_into_tensor`` suffices
     (≈ 240 B × windows: latency-bound, one collective per capture).
     """
     import torch
     import torch.distributed as dist
-    cap = max_shard(n_windows, world)
+    cap = max_shard(n_windows, world) * per_window
     pad = torch.zeros((cap, RESULT_BYTES), dtype=torch.uint8, device=local.device)
     pad[: local.shape[0]] = local
     if world == 1:
@@ -52,7 +53,7 @@ def gather_results(local, n_windows: int, rank: int, world: int, device=None):
     pieces = []
     for r in range(world):
         s, e = shard_windows(n_windows, r, world)
-        pieces.append(out[r, : e - s])
+        pieces.append(out[r, : (e - s) * per_window])
     return np.concatenate(pieces, axis=0)
 
 

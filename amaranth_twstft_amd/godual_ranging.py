@@ -1,15 +1,21 @@
 """Script-level drop-in for processing/Octave/godual_ranging.m (file-in / delay-out contract).
 
-    python -m amaranth_twstft_amd.godual_ranging [--datalocation DIR] [--codelocation DIR] [--remote 0|1] [--OP 0|1]
+    python -m amaranth_twstft_amd.godual_ranging [--datalocation DIR] [--codelocation DIR] [--remote 0|1] [--OP 0|1] [--gpus N]
 
 Same flow as the reference script (godual_ranging.m:57-133): every capture ``1*.bin`` in
 ``datalocation`` (int16 ``[I1 Q1 I2 Q2]``) is correlated window by window against the code
-``n*.bin`` picked by the parity of OP+remote (:60); one TSV row per window goes to stdout (:74,96,98)
-and ``<capture>.mat`` (``remote<capture>.mat`` when remote=1) holds the result vectors (:126-131).
-Already processed captures are skipped (the idempotence rule of
-acquisition/claudio_aligned_code_ranging_separate.m:119).  Environment variables ``OP``,
-``processing_dir``, ``codelocation`` are honoured like in the newer reference scripts (:12-25).
+``n*.bin`` picked by the parity of OP+remote (:60); one TSV row per window goes to stdout (:74,96,98),
+the quadratic-fit residual statistics of :104-113 follow, and ``<capture>.mat`` (``remote<capture>.mat``
+when remote=1) holds the result vectors (:126-131).  Already processed captures are skipped (the
+idempotence rule of acquisition/claudio_aligned_code_ranging_separate.m:119).  Environment variables
+``OP``, ``processing_dir``, ``codelocation`` are honoured like in the newer reference scripts (:12-25).
 All sample arithmetic runs in libtwstft_hip.so.
+
+``--gpus N`` (BASELINE.json configs[3]; the reference's analogue is three parallel octave processes,
+acquisition/goprocess.sh:9-11): one process per GPU under torch.distributed.run, every rank correlates a
+contiguous block of the capture's windows (one contiguous file extent: ``skip_samples = start*N``), the
+fixed-size result records are exchanged with ONE all_gather (RCCL over xGMI) and rank 0 writes the same
+``.mat``/TSV a single-GPU run writes — byte for byte, since every window is computed independently.
 """
 from __future__ import annotations
 
@@ -18,11 +24,49 @@ import glob
 import os
 import sys
 
-from . import prn, results_io
+from . import launch, prn, results_io
 from .correlator import Correlator, band_godual
 
 
-def run(datalocation="./", codelocation="./codes/", remote=0, OP=0, fs=5e6, Nint=1, out=sys.stdout, device=-1):
+def _process_capture(cor, cap, band, all_channels, rank, world, backend):
+    """Records of every window of ``cap`` (all ranks return the full list; one collective)."""
+    from . import dist as D
+    nch = 2
+    nwin = os.path.getsize(cap) // (cor.n * 4 * nch)
+    start, stop = D.shard_windows(nwin, rank, world)
+    recs = cor.process_file(cap, n_channels=nch, channel=-1 if all_channels else 0, band=band,
+                            skip_samples=start * cor.n, max_windows=stop - start, raw_records=True)
+    per = nch if all_channels else 1
+    if recs.shape[0] != (stop - start) * per:
+        raise RuntimeError(f"rank {rank}: {recs.shape[0]} records for windows {start}..{stop} of {cap}")
+    if world > 1:
+        import torch
+        local = torch.from_numpy(recs)
+        if backend == "nccl":
+            local = local.cuda()
+        allb = D.gather_results(local, nwin, rank, world, per_window=per)
+    else:
+        allb = recs
+    res = D.results_from_bytes(allb)
+    if all_channels:
+        return res[0::2], res[1::2]
+    return res, None
+
+
+def run(datalocation="./", codelocation="./codes/", remote=0, OP=0, fs=5e6, Nint=1, out=sys.stdout, device=-1,
+        backend="nccl"):
+    rank, local_rank, world = launch.rank_world()
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if device < 0:
+            device = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(device)
+        if not dist.is_initialized():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
     caps = sorted(glob.glob(os.path.join(datalocation, "1*.bin")))
     codes = sorted(glob.glob(os.path.join(codelocation, "n*.bin")) + glob.glob(os.path.join(codelocation, "n*.bin.gz")))
     if not codes:
@@ -30,24 +74,31 @@ def run(datalocation="./", codelocation="./codes/", remote=0, OP=0, fs=5e6, Nint
     codefile = codes[(OP + remote) % 2 % len(codes)]              # LTFB=odd OP=even (godual_ranging.m:60)
     chips = prn.read_code_file(codefile)
     done = []
+    say = out.write if rank == 0 else (lambda s: None)
     with Correlator(chips, fs=fs, Nint=Nint, var_ddof=1, device=device) as cor:     # Octave var (N-1)
         band = band_godual(fs, cor.n, remote=remote, OP=OP)
         for cap in caps:
             base = os.path.basename(cap)
             nom = os.path.join(datalocation, ("remote" if remote == 1 else "") + base.replace(".bin", ".mat"))
             if os.path.exists(nom) or os.path.exists(nom + ".gz"):
-                out.write(f"{nom} already done\n")
+                say(f"{nom} already done\n")
                 continue
-            out.write(base + "\n")
-            if remote != 1:                    # both channels of every window from one pass over the file (:91,95)
-                both = cor.process_file(cap, n_channels=2, channel=-1, band=band)
-                r1, r2 = both[0], both[1]
-            else:
-                r1, r2 = cor.process_file(cap, n_channels=2, channel=0, band=band), None
-            for row in results_io.tsv_rows(r1, r2, fs, Nint):
-                out.write(row)
-            results_io.save_mat(nom, r1, r2, code=prn.chips_to_code(chips), remote=remote)
+            say(base + "\n")
+            # both channels of every window from one pass over the file (:91,95); remote: measurement channel only
+            r1, r2 = _process_capture(cor, cap, band, remote != 1, rank, world, backend)
+            if rank == 0:
+                for row in results_io.tsv_rows(r1, r2, fs, Nint):
+                    say(row)
+                for line in results_io.residual_report(r1, r2, fs, Nint):
+                    say(line)
+                results_io.save_mat(nom, r1, r2, code=prn.chips_to_code(chips), remote=remote)
+            if world > 1:
+                import torch.distributed as dist
+                dist.barrier()            # the .mat exists before any rank looks at the next capture's "already done"
             done.append(nom)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
     return done
 
 
@@ -59,8 +110,13 @@ def main(argv=None):
     ap.add_argument("--OP", type=int, default=int(os.environ.get("OP", "0") or 0))
     ap.add_argument("--fs", type=float, default=5e6)
     ap.add_argument("--Nint", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU) sharing every capture's windows")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) or gloo (several ranks on one GPU, tests)")
     a = ap.parse_args(argv)
-    run(a.datalocation, a.codelocation, a.remote, a.OP, a.fs, a.Nint)
+    if a.gpus > 1 and not launch.is_rank():
+        args = list(sys.argv[1:] if argv is None else argv)
+        sys.exit(launch.spawn_ranks(a.gpus, "", args, module="amaranth_twstft_amd.godual_ranging"))
+    run(a.datalocation, a.codelocation, a.remote, a.OP, a.fs, a.Nint, backend=a.backend)
 
 
 if __name__ == "__main__":

@@ -57,6 +57,28 @@ def tsv_rows(res1, res2, fs: float, Nint: int):
         yield row + "\r\n"
 
 
+def polyfit_residuals(results, fs: float, Nint: int, sign: int = +1):
+    """``[a,b]=polyfit([1:n],(solution)/(2*Nint+1)/fs,2); std(…-b.yf); mean(…-b.yf)`` of
+    processing/Octave/godual_ranging.m:104-113 with ``solution=indice-1+correction`` (:104,106; both channels use
+    ``+correction`` there).  Returns (std with Octave's N-1 normalisation, mean) of the quadratic-fit residual in
+    seconds; (nan, nan) for fewer than 4 windows."""
+    n = len(results)
+    if n < 4:
+        return float("nan"), float("nan")
+    sol = np.array([r.indice + sign * r.correction for r in results], dtype=np.float64) / (2 * Nint + 1) / fs
+    x = np.arange(1, n + 1, dtype=np.float64)
+    res = sol - np.polyval(np.polyfit(x, sol, 2), x)
+    return float(np.std(res, ddof=1)), float(np.mean(res))
+
+
+def residual_report(res1, res2, fs: float, Nint: int):
+    """The four ``ans = …`` lines Octave prints for godual_ranging.m:105-113 (loop-back channel first)."""
+    for res in ((res2, res1) if res2 is not None else (res1,)):
+        sd, mean = polyfit_residuals(res, fs, Nint)
+        yield "ans = %.4e\n" % sd
+        yield "ans = %.4e\n" % mean
+
+
 def tracked_mat_dict(out: dict, code=None) -> dict:
     """Variables the tracked script leaves in its workspace for ``save -mat … corr* df indic* SNR* code puissan*
     xval* moved*`` (acquisition/claudio_aligned_code_ranging_separate.m:207): per-code row vectors ``xval1

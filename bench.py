@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
 """Benchmark of the TWSTFT correlation hot path on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
 
-One *step* = one pass of ``processing(d,k)`` (processing/Octave/godual_ranging.m:12-49: coarse
-carrier estimate, NCO mix, FFT circular xcorr with ×3 interpolation, peak pick, parabolic
-refinement, wipe-off SNR) over ``--windows`` 1-second windows (5 Msps int16 IQ, 2.5 Mchip
-LFSR(22, taps 3) code = BASELINE.json configs[1]) that are already resident in HBM.  Windows are
-independent, so with N GPUs every rank processes its own shard (weak scaling) and the per-window
-results are gathered with one RCCL all_gather per step.  Prints ONE JSON line on rank 0.
+For N > 1 the ranks are ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...``
+(one process per GPU, RCCL); a plain ``python bench.py --gpus N`` starts exactly that as a child process before
+touching the GPU and relays its output.
+
+One *step* = one pass of ``processing(d,k)`` (processing/Octave/godual_ranging.m:12-49: coarse carrier estimate,
+NCO mix, FFT circular xcorr with x3 interpolation, peak pick, parabolic refinement, wipe-off SNR) over one
+10-minute recording per GPU: ``--windows`` (default 600) 1-second windows of 5 Msps int16 IQ against the 2.5 Mchip
+LFSR(22, taps 3) code (BASELINE.json configs[1]'s window, configs[3]'s recording length), already resident in HBM
+(12 GB per GPU).  Windows are independent, so with N GPUs every rank processes its own recording (weak scaling) and
+the per-window results are gathered with one RCCL all_gather per step.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -18,15 +21,13 @@ import ctypes as C
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this host driver
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 FS = 5e6
 BITLEN, TAPS, NCHIPS = 22, 3, 2_500_000
@@ -51,28 +52,126 @@ def window_params(p: int, rank: int):
                              amp=200, noise_gain=synth.noise_gain_for_sigma(400.0), seed=1000 + g, stream=0), delay
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (numpy fp64 restatement of processing(), = the reference's numpy path) on the host cores.
+# Runs in a CHILD process that never touches the GPU, started before the parent initialises HIP, so that its worker
+# pool can fork freely.
+# ------------------------------------------------------------------------------------------------------------------
+_CPU = {}
+
+
+def _cpu_gen(p):
+    from amaranth_twstft_amd import synth
+    sp, _ = window_params(p, 0)
+    return synth.synth_channel(N, _CPU["chips"], 2, sp)
+
+
+def _cpu_one(p):
+    import numpy as np
+    orc = _CPU["orc"]
+    d = orc.deinterleave(_CPU["raw"][p % len(_CPU["raw"])], 1, 0)
+    d = d - d.mean()
+    r = orc.processing(d, _CPU["k"], _CPU["freq"], _CPU["temps"], _CPU["fcode"], _CPU["code"], Nint=1, fs=FS, df=_CPU["df"])
+    return int(r["indice"])
+
+
+def cpu_baseline_child(n_win: int, workload: str, max_workers: int):
+    import multiprocessing as mp
+    import numpy as np
+    from amaranth_twstft_amd import prn
+    from oracle import twstft_oracle as orc
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        by_mem = max(1, int(psutil.virtual_memory().available // (3 << 30)))     # ~2.5 GB peak per worker (3N complex128 temporaries)
+    except Exception:
+        by_mem = cores
+    workers = max(1, min(cores, by_mem, max_workers))
+    chips = prn.lfsr_chips(BITLEN, TAPS, NCHIPS)
+    _CPU.update(chips=chips, orc=orc, df=None if workload == "processing" else 1780.75)
+    ctx = mp.get_context("fork")
+    with ctx.Pool(min(workers, n_win)) as pool:                  # synthetic windows (untimed), same bytes as the GPU generator
+        _CPU["raw"] = pool.map(_cpu_gen, range(n_win))
+    t1 = time.perf_counter()
+    code = orc.make_code(chips, 2)
+    fcode = orc.make_fcode(code)
+    freq = orc.freq_axis(FS, N)
+    _CPU.update(code=code, fcode=fcode, freq=freq, k=orc.band_godual(freq), temps=np.arange(N) / FS)
+    t2 = time.perf_counter()
+    indices = [_cpu_one(p) for p in range(n_win)]                # (i) one core, comparable with the README timings
+    t3 = time.perf_counter()
+    out = {"single_core": {"value": round(n_win * N / (t3 - t2) / 1e6, 4), "cores": 1, "windows": n_win, "seconds": round(t3 - t2, 2)},
+           "setup_seconds": round(t2 - t1, 2), "indices": indices, "host_cores": cores}
+    if workers > 1:                                              # (ii) one window per core over all cores
+        with ctx.Pool(workers) as pool:
+            pool.map(_cpu_one, range(workers))                   # warm-up: page in the inherited arrays
+            t4 = time.perf_counter()
+            got = pool.map(_cpu_one, range(2 * workers), chunksize=1)
+            t5 = time.perf_counter()
+        ok = all(got[i] == indices[i % n_win] for i in range(len(got)))
+        out["all_cores"] = {"value": round(2 * workers * N / (t5 - t4) / 1e6, 4), "cores": workers, "windows": 2 * workers,
+                            "seconds": round(t5 - t4, 2), "consistent": bool(ok)}
+    try:                                                         # (iii) multi-threaded FFT (scipy.fft workers=-1)
+        orc.use_fft_backend("scipy", workers=-1)
+        _CPU["fcode"] = orc.make_fcode(code)
+        t6 = time.perf_counter()
+        got = [_cpu_one(p) for p in range(n_win)]
+        t7 = time.perf_counter()
+        out["scipy_fft_workers_all"] = {"value": round(n_win * N / (t7 - t6) / 1e6, 4), "cores": cores, "windows": n_win,
+                                        "seconds": round(t7 - t6, 2), "consistent": got == indices}
+    except Exception as e:  # pragma: no cover
+        out["scipy_fft_workers_all"] = {"error": repr(e)}
+    finally:
+        orc.use_fft_backend("numpy")
+    print("CPU_BASELINE_JSON " + json.dumps(out), flush=True)
+
+
+def run_cpu_baseline(n_win: int, workload: str, max_workers: int):
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-windows", str(n_win),
+           "--workload", workload, "--cpu-max-workers", str(max_workers)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
+    for line in r.stdout.splitlines():
+        if line.startswith("CPU_BASELINE_JSON "):
+            return json.loads(line[len("CPU_BASELINE_JSON "):])
+    return {"error": (r.stdout[-500:] + r.stderr[-1500:])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--windows", type=int, default=64, help="1-s windows per GPU per step (resident in HBM)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--windows", type=int, default=600, help="1-s windows per GPU per step (resident in HBM; 600 = a 10-minute recording)")
     ap.add_argument("--batch", type=int, default=0, help="channel-windows per launch (0 = library default)")
     ap.add_argument("--workload", choices=["processing", "xcorr"], default="processing",
                     help="processing = full processing(d,k); xcorr = df supplied (code-phase-only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-windows", type=int, default=10, help="windows of the workload timed on the host CPU (oracle)")
+    ap.add_argument("--cpu-windows", type=int, default=6, help="windows of the workload timed on one host core (oracle)")
+    ap.add_argument("--cpu-max-workers", type=int, default=64)
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                     "multi-rank path on a box with fewer GPUs than ranks)")
     a = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.cpu_baseline_child:
+        cpu_baseline_child(a.cpu_windows, a.workload, a.cpu_max_workers)
+        return
+
+    from amaranth_twstft_amd import launch
+    if a.gpus > 1 and not launch.is_rank():
+        # not started by torchrun: start the N ranks as a child job (nothing here has touched the GPU yet)
+        sys.exit(launch.spawn_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    rank, local_rank, world = launch.rank_world()
     if world != a.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE {world}: start with --nproc-per-node {a.gpus}, or without torchrun")
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = run_cpu_baseline(a.cpu_windows, a.workload, a.cpu_max_workers)      # before the first GPU call
+
+    import numpy as np
+    import torch
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -97,7 +196,7 @@ def main():
     chips = prn.lfsr_chips(BITLEN, TAPS, NCHIPS)
     cor = Correlator(chips, fs=FS, Nint=1, device=local_rank, max_batch=a.batch)
     nwin = a.windows
-    # --- synthetic capture, generated on the device, resident in HBM
+    # --- synthetic recording, generated on the device, resident in HBM
     chips_dev = torch.from_numpy(chips).to(dev)
     iq = torch.empty((nwin, N, 2), dtype=torch.int16, device=dev)
     delays = []
@@ -132,34 +231,30 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
+        L.check(lib.twx_synchronize(cor._h), cor._h)
         torch.cuda.synchronize()
+
+    def timed(workload, steps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(cor, workload)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
 
     for _ in range(a.warmup):
         step(cor)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(cor)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = timed(a.workload, a.steps)
 
     # --- the other workload, timed the same way (reported beside `value`, never instead of it)
     other = "xcorr" if a.workload == "processing" else "processing"
     step(cor, other)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(cor, other)
-    barrier()
-    dt_other = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt_other], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt_other = float(tmax.item())
+    dt_other = timed(other, a.steps)
     step(cor)                            # leave the results of the headline workload in `res` for the checks below
     barrier()
 
@@ -174,10 +269,12 @@ def main():
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": ("processing(d,k) full chain" if a.workload == "processing" else "xcorr, df supplied")
-                      + ": the capture of BASELINE.json configs[1] (1 s windows, 5 Msps int16 IQ, 2.5 Mchip LFSR(22,3) code), Nint=1"
+                      + ": the window of BASELINE.json configs[1] (1 s, 5 Msps int16 IQ, 2.5 Mchip LFSR(22,3) code, fp32), Nint=1, "
+                      + f"one {nwin}-window recording per GPU per step (configs[3]'s 10-minute recording at 600), HBM-resident"
                       + ("; configs[1]'s own code-phase-only xcorr is reported under other_workload" if a.workload == "processing" else ""),
                       "windows_per_gpu_per_step": nwin, "samples_per_window": N, "batch": int(cor.info.batch),
-                      "n1": int(cor.info.n1), "n2": int(cor.info.n2), "sharding": f"windows/{world}"},
+                      "n1": int(cor.info.n1), "n2": int(cor.info.n2), "sharding": f"windows/{world}",
+                      "timed_region_s": round(dt, 3)},
            "integer_lag_exact": bool(lag_ok),
            "other_workload": {"workload": "xcorr, df supplied (code-phase only)" if other == "xcorr" else "processing(d,k) full chain",
                               "value": round(world * nwin * N * a.steps / dt_other / 1e6, 2), "unit": "Msamples/s",
@@ -186,7 +283,8 @@ def main():
     # --- roofline of the dominant kernel: HIP events around every launch on the library's stream
     if rank == 0 and not a.no_roofline:
         pc = Correlator(chips, fs=FS, Nint=1, device=local_rank, max_batch=a.batch, profile=True)
-        step_w = nwin
+        step_w = min(nwin, 192)
+
         def prof_pass():
             L.check(lib.twx_process_windows_dev(pc._h, iq.data_ptr(), step_w, 1, 0,
                                                 C.byref(band) if a.workload == "processing" else None,
@@ -202,11 +300,13 @@ def main():
         dom = max(kern, key=lambda k: prof[k]["ms_total"])
         byts = ALGO_BYTES[dom](kern[dom]["samples_per_launch"])
         ach = byts / (kern[dom]["ms_avg"] * 1e-3) / 1e9
-        out["roofline_note"] = ("per-kernel durations are HIP-event timed in a context with ONE pipeline slot (kernels of "
-                                "different batches do not overlap); the timed region above runs %d slots" % int(os.environ.get("TWX_STREAMS", "3")))
+        out["roofline_note"] = ("per-kernel durations are the dispatches' own begin/end timestamps (HIP events attached to every launch) in a "
+                                "context with ONE pipeline slot, i.e. kernels of different batches do not overlap; the timed region above runs "
+                                "%d slots" % int(os.environ.get("TWX_STREAMS", "3")))
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                           "algorithmic_bytes_per_launch": int(byts), "avg_ms": round(kern[dom]["ms_avg"], 4)}
+                           "algorithmic_bytes_per_launch": int(byts), "avg_ms": round(kern[dom]["ms_avg"], 4),
+                           "launches_timed": int(kern[dom]["launches"])}
         out["kernels"] = {k: {"avg_ms": round(v["ms_avg"], 4), "GB/s": round(ALGO_BYTES[k](v["samples_per_launch"]) / (v["ms_avg"] * 1e-3) / 1e9, 1)}
                           for k, v in kern.items()}
         tot = sum(ALGO_BYTES[k](kern[k]["samples_per_launch"]) for k in kern)
@@ -219,32 +319,25 @@ def main():
                 t = json.load(open(pmc))
                 if t.get("kernel") == dom:
                     out["roofline"]["traffic"] = t.get("bytes_per_launch")
+                    out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of %s, not measured in this run)"
+                                                         % t.get("source_commit", t.get("commit", "the commit named in that file")))
             except Exception:
                 pass
 
-    # --- CPU baseline: the oracle (numpy fp64 restatement = the reference's numpy path) on a bounded sample
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        from oracle import twstft_oracle as orc
-        n_cpu = min(nwin, a.cpu_windows)
-        raw = iq[:n_cpu].cpu().numpy()
-        t1 = time.perf_counter()
-        code = orc.make_code(chips, 2)
-        fcode = orc.make_fcode(code)
-        freq = orc.freq_axis(FS, N)
-        k = orc.band_godual(freq)
-        temps = np.arange(N) / FS
-        t2 = time.perf_counter()
-        ok = True
-        for p in range(n_cpu):
-            d = orc.deinterleave(raw[p], 1, 0)
-            d = d - d.mean()
-            r = orc.processing(d, k, freq, temps, fcode, code, Nint=1, fs=FS, df=None if a.workload == "processing" else 1780.75)
-            ok = ok and (r["indice"] == int(arr[p].indice0))
-        t3 = time.perf_counter()
-        out["cpu_baseline"] = {"value": round(n_cpu * N / (t3 - t2) / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
-                               "sample": f"{n_cpu} windows of the same workload ({n_cpu * N} samples, {t3 - t2:.1f} s of numpy fp64 "
-                                         f"processing(); one-off code-spectrum setup {t2 - t1:.1f} s excluded)",
-                               "indice_matches_gpu": bool(ok)}
+    if cpu is not None:
+        if "single_core" in cpu:
+            n_cpu = cpu["single_core"]["windows"]
+            best = max((cpu[k] for k in ("single_core", "all_cores", "scipy_fft_workers_all") if k in cpu and "value" in cpu[k]),
+                       key=lambda v: v["value"])
+            which = [k for k in ("single_core", "all_cores", "scipy_fft_workers_all") if cpu.get(k) is best][0]
+            out["cpu_baseline"] = {"value": best["value"], "unit": "Msamples/s", "cores": best["cores"], "kind": "port",
+                                   "sample": f"{which}: {best['windows']} windows of the same workload ({best['windows'] * N} samples, "
+                                             f"{best['seconds']} s of numpy fp64 processing() = oracle/twstft_oracle.py on the host's "
+                                             f"{cpu['host_cores']} cores; one-off code-spectrum setup {cpu['setup_seconds']} s excluded)",
+                                   "indice_matches_gpu": all(cpu["indices"][p] == int(arr[p].indice0) for p in range(min(n_cpu, nwin))),
+                                   "variants": {k: cpu[k] for k in ("single_core", "all_cores", "scipy_fft_workers_all") if k in cpu}}
+        else:
+            out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out))
     cor.close()

@@ -205,6 +205,18 @@ int twx_sliding_dot(const int16_t* iq, int64_t n_samples, int32_t n_channels, in
 int twx_fir_decimate(const int16_t* iq, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps, int32_t ntaps,
                      int32_t dec, int16_t* out_i16, float* out_f32, int64_t* n_out);
 
+/* The same two kernels on DEVICE-resident data, asynchronous on the context's stream (twx_stream(ctx)), work buffers
+ * owned by the context (no allocation per call once they have their size).  iq_dev, replica_dev, out*_dev are device
+ * pointers; taps is a HOST array (copied at enqueue time); *n_out is written before the call returns.  The int16
+ * output of twx_fir_decimate_dev is a 1-channel [I Q] capture that twx_process_windows_dev consumes directly, so the
+ * 70 Msps -> 5 Msps -> correlator chain of BASELINE.json configs[4] never leaves the device.  out_i16_dev must be
+ * 16-byte aligned, out_f32_dev 32-byte aligned (any hipMalloc pointer is). */
+int twx_sliding_dot_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t pt,
+                        int64_t nobs, int32_t ncodes, int32_t nlag, const float* replica_dev, double ff, double phi, double scale,
+                        double* out_dev);
+int twx_fir_decimate_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps,
+                         int32_t ntaps, int32_t dec, void* out_i16_dev, void* out_f32_dev, int64_t* n_out);
+
 /* Profiling (TWX_FLAG_PROFILE): per kernel class, HIP-event time on the context's stream. */
 #define TWX_PROF_MAX 16
 typedef struct twx_prof_entry { char name[32]; double ms_total; int64_t launches; int64_t units; } twx_prof_entry;

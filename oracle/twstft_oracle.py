@@ -27,6 +27,29 @@ from __future__ import annotations
 
 import numpy as np
 
+# FFT backend of the restatement: numpy's pocketfft (what the reference's numpy path calls) by default;
+# ``use_fft_backend("scipy", workers=-1)`` switches to scipy.fft with its internal thread pool — the multi-threaded
+# CPU baseline of SURVEY.md §8(d) (pyfftw ``threads=4`` in experiments/221207_twoway_codes/processing/godual_ranging_fftw.py:62).
+_backend = {"fft": np.fft.fft, "ifft": np.fft.ifft}
+
+
+def use_fft_backend(name: str = "numpy", workers: int | None = None) -> None:
+    if name == "numpy":
+        _backend.update(fft=np.fft.fft, ifft=np.fft.ifft)
+    elif name == "scipy":
+        import scipy.fft as sf
+        _backend.update(fft=lambda x: sf.fft(x, workers=workers), ifft=lambda x: sf.ifft(x, workers=workers))
+    else:
+        raise ValueError(name)
+
+
+def _fft(x):
+    return _backend["fft"](x)
+
+
+def _ifft(x):
+    return _backend["ifft"](x)
+
 
 # --------------------------------------------------------------------------------------------
 # PRN replica
@@ -80,7 +103,7 @@ def make_fcode(code: np.ndarray, convention: str = "godual") -> np.ndarray:
     ``hamming``: godual × Hamming window over the spectrum index, processing/CPP/main.cpp:717-719
                  (sigpack ``hamming(N)`` = 0.54-0.46*cos(2*pi*i/(N-1))).  UNPINNED.
     """
-    f = np.fft.fft(code)
+    f = _fft(code)
     if convention == "godual":
         return np.conj(f)
     if convention == "claudio":
@@ -131,7 +154,7 @@ def deinterleave(raw: np.ndarray, n_channels: int, channel: int) -> np.ndarray:
 
 def coarse_df(d: np.ndarray, k: np.ndarray, freq: np.ndarray):
     """godual_ranging.m:14-15 / godual_ranging.py:21-23. Returns (0-based shifted index, df)."""
-    d2_fft = np.fft.fftshift(np.abs(np.fft.fft(d * d)))
+    d2_fft = np.fft.fftshift(np.abs(_fft(d * d)))
     tmp = int(d2_fft[k].argmax() + k[0])
     return tmp, freq[tmp] / 2
 
@@ -151,11 +174,11 @@ def xcorr_interp(ffty: np.ndarray, fcode: np.ndarray, Nint: int) -> np.ndarray:
     n = len(ffty)
     multmp = ffty * fcode
     if Nint == 0:
-        return np.fft.ifft(multmp)
+        return _ifft(multmp)
     interpolation = np.zeros((2 * Nint + 1) * n, dtype=complex)
     interpolation[:n // 2] = multmp[:n // 2]
     interpolation[-(n // 2):] = multmp[-(n // 2):]
-    return np.fft.ifft(interpolation)
+    return _ifft(interpolation)
 
 
 def peak_refine(prnmap: np.ndarray, wrap: bool = True):
@@ -197,7 +220,7 @@ def snr_wipeoff(ffty: np.ndarray, code: np.ndarray, indice: int, Nint: int,
     yint = np.zeros(r * n, dtype=complex)
     yint[:n // 2] = ffty[:n // 2]
     yint[-(n // 2):] = ffty[-(n // 2):]
-    yinti = np.fft.ifft(yint)
+    yinti = _ifft(yint)
     codetmp = np.repeat(code, r)
     s = (indice + rot) % (r * n)
     yincode = np.concatenate((yinti[s:], yinti[:s])) * codetmp
@@ -227,7 +250,7 @@ def processing(d, k, freq, temps, fcode, code, Nint=1, fs=5e6, fine_freq=False,
         lo = np.exp(-1j * 2 * np.pi * dfleftover * temps)
         y = y * lo
         dftmp += dfleftover
-    ffttmp = np.fft.fft(y)
+    ffttmp = _fft(y)
     prnmap = xcorr_interp(ffttmp, fcode, Nint)
     indice, correction, xval, xvalm1, xvalp1 = peak_refine(prnmap)
     SNRr, SNRi, pcode, pnoise = snr_wipeoff(ffttmp, code, indice, Nint, rot=snr_rot, ddof=ddof)
@@ -273,16 +296,16 @@ def processing_claudio(d, df, temps, fcode_claudio, code, Nint=1, ddof=1):
     r = 2 * Nint + 1
     lo = np.exp(-1j * 2 * np.pi * df * temps)
     y = d * lo
-    ffty = np.fft.fft(y)
+    ffty = _fft(y)
     multmp = fcode_claudio * np.conj(ffty)                       # :59
     pad = np.zeros(r * n, dtype=complex)
     pad[:n // 2] = multmp[:n // 2]
     pad[-(n // 2):] = multmp[-(n // 2):]
-    prnmap = np.fft.ifft(pad)                                     # :60-61
+    prnmap = _ifft(pad)                                     # :60-61
     yint = np.zeros(r * n, dtype=complex)
     yint[:n // 2] = ffty[:n // 2]
     yint[-(n // 2):] = ffty[-(n // 2):]
-    yint = np.fft.ifft(yint)                                      # :62-65
+    yint = _ifft(yint)                                      # :62-65
     codetmp = np.repeat(code, r)
     indice = int(np.abs(prnmap).argmax())                         # :69
     xval = prnmap[indice]
@@ -306,14 +329,14 @@ def search_df(d, k, df_threshold, freq, temps, fcode_claudio):
     """acquisition/claudio_aligned_code_ranging_separate.m:27-47. ``k``/result 0-based; 0 → -1."""
     n = len(fcode_claudio)
     kbon = -1
-    d2 = np.fft.fftshift(np.abs(np.fft.fft(d ** 2)))
+    d2 = np.fft.fftshift(np.abs(_fft(d ** 2)))
     ktmp = np.nonzero(d2[k] > np.median(d2[k]) * df_threshold)[0] + k[0]
     if 0 < len(ktmp) < 100:
         for kk in ktmp:
             dftmp = freq[kk] / 2
             lo = np.exp(-1j * 2 * np.pi * dftmp * temps)
             y = d[:n] * lo
-            prnmap = np.abs(np.fft.ifft(fcode_claudio * np.conj(np.fft.fft(y))))
+            prnmap = np.abs(_ifft(fcode_claudio * np.conj(_fft(y))))
             b = int(prnmap.argmax())
             prnsig = prnmap[b]
             prnmap[max(b - 5, 0):b + 6] = 0
@@ -377,7 +400,7 @@ def ranging_tracked(raw, chips, fs=5e6, sps=2, Nint=1, ls_samples=None, band_hz=
         if df_found:
             kb = out["kbon"]
             d = np.concatenate((dold, d))
-            d2 = np.fft.fftshift(np.abs(np.fft.fft(d ** 2)))
+            d2 = np.fft.fftshift(np.abs(_fft(d ** 2)))
             j = int(np.argmax(d2[kb - 3:kb + 4]))
             df = freq[j + kb - 3] / 2
             out["df"].append(df)
@@ -432,7 +455,7 @@ def caf_bins(y0, fcode, fs, f_lo, f_hi, f_step):
     lag = np.empty(nb, dtype=np.int64)
     for i, f in enumerate(freqs):
         y = y0 * np.exp(-1j * 2 * np.pi * f * t)
-        m = np.abs(np.fft.ifft(np.fft.fft(y) * fcode))
+        m = np.abs(_ifft(_fft(y) * fcode))
         lag[i] = int(m.argmax())
         pk[i] = m[lag[i]]
     return freqs, pk, lag
@@ -441,12 +464,12 @@ def caf_bins(y0, fcode, fs, f_lo, f_hi, f_step):
 def caf_bins_shift(y0, fcode, k_lo, k_hi):
     """Same surface on the integer-bin Doppler grid f = k*fs/N: a frequency shift by k bins is a
     circular shift of FFT(y) by k, so one forward FFT serves all bins."""
-    Y = np.fft.fft(y0)
+    Y = _fft(y0)
     ks = np.arange(k_lo, k_hi + 1)
     pk = np.empty(len(ks))
     lag = np.empty(len(ks), dtype=np.int64)
     for i, kk in enumerate(ks):
-        m = np.abs(np.fft.ifft(np.roll(Y, -kk) * fcode))
+        m = np.abs(_ifft(np.roll(Y, -kk) * fcode))
         lag[i] = int(m.argmax())
         pk[i] = m[lag[i]]
     return ks, pk, lag

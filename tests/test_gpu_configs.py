@@ -1,0 +1,302 @@
+"""GPU (-m gpu): BASELINE.json configs[2], [3] and [4] at their STATED sizes, the multi-rank path with the real
+correlator, and the single-slot ingest pipeline.
+
+Gates as everywhere (north_star): integer lag bit-exact, |peak| within 1e-6 relative (fp32 vs the fp64 oracle / fp64 context).
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from amaranth_twstft_amd import _lib as L
+from amaranth_twstft_amd import dist as D
+from amaranth_twstft_amd import frontend, prn, synth
+from amaranth_twstft_amd.correlator import ALL_CHANNELS, Correlator, band_godual
+from oracle import twstft_oracle as orc
+from tests.helpers import chips_for
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FS = 5e6
+MAG_TOL = 1e-6
+NCHIPS, N = 2_500_000, 5_000_000
+
+
+def _params(p):
+    return np.array([p.delay_q8, p.fstep, p.phi0, p.amp, p.noise_gain, p.seed, p.stream, 0], dtype=np.int64)
+
+
+def _synth_dev(out, n, chips_dev, nchips, sps, chans, n0=0):
+    """Device generator (bit-identical to synth.synth_capture) into the torch int16 tensor ``out`` [n, 2*len(chans)]."""
+    lib = L.load()
+    params = np.concatenate([_params(p) for p in chans])
+    L.check(lib.twx_synth_capture_dev(out.data_ptr(), n, n0, chips_dev.data_ptr(), nchips, sps, len(chans),
+                                      params.ctypes.data_as(C.c_void_p), None))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# configs[2]: 1-s capture, full delay x Doppler surface, +-5 kHz at 1 Hz (10 001 bins of fs/N = 1 Hz), N = 5e6
+# --------------------------------------------------------------------------------------------------------------
+def test_config2_full_caf_grid_at_size():
+    import torch
+    chips = chips_for(22, 3, NCHIPS)
+    dev = torch.device("cuda", 0)
+    p = synth.SynthParams(delay_q8=1311765 * 256, fstep=synth.fstep_for_df(1780.75, FS), phi0=0, amp=200,
+                          noise_gain=synth.noise_gain_for_sigma(400.0), seed=7)
+    iq = torch.empty((N, 2), dtype=torch.int16, device=dev)
+    _synth_dev(iq, N, torch.from_numpy(chips).to(dev), NCHIPS, 2, [p])
+    torch.cuda.synchronize()
+    raw = iq.cpu().numpy()
+    del iq
+    k_lo, k_hi = -5000, 5000
+    with Correlator(chips, fs=FS, Nint=0) as cor:
+        pk, lag = cor.caf_bins(raw, k_lo, k_hi)
+        # second device route: the full processing(d,df) chain once per trial offset f = kappa*fs/N
+        res = cor.caf_freqs(raw, np.arange(k_lo, k_hi + 1, dtype=np.float64) * (FS / N))
+    assert pk.shape == (10001,)
+    best = int(np.argmax(pk))
+    assert best + k_lo == 1781 and lag[best] == 1311765            # df = 1780.75 Hz -> nearest 1-Hz bin; delay of the generator
+    assert pk[best] > 5 * np.median(pk)
+    # every bin against the second route: same lag, same peak; a differing lag is only tolerated as a tie inside fp32 resolution
+    lag2 = np.array([r.indice for r in res])
+    pk2 = np.array([abs(r.xval) for r in res])
+    assert np.abs(pk - pk2).max() <= 2 * MAG_TOL * pk.max()
+    bad = np.nonzero(lag != lag2)[0]
+    assert bad.size <= 3, bad
+    for i in bad:
+        assert abs(pk[i] - pk2[i]) <= MAG_TOL * pk[i]
+    # 64 bins spread over the grid (+ the peak bin and both edges) against the oracle, bit-exact lags
+    d = orc.deinterleave(raw, 1, 0)
+    d = d - d.mean()
+    fcode = orc.make_fcode(orc.make_code(chips, 2))
+    Y = np.fft.fft(d)
+    ks = sorted(set(list(np.linspace(k_lo, k_hi, 64).astype(int)) + [1781, 1780, 1782, 0]))
+    for kk in ks:
+        m = np.abs(np.fft.ifft(np.roll(Y, -kk) * fcode))
+        j = int(m.argmax())
+        assert lag[kk - k_lo] == j, kk
+        assert abs(pk[kk - k_lo] - m[j]) <= MAG_TOL * m[j], kk
+
+
+# --------------------------------------------------------------------------------------------------------------
+# configs[3]: 600 x 1-s windows, 2 channels, through shard -> process -> gather
+# --------------------------------------------------------------------------------------------------------------
+def _c4_channels(p):
+    import math
+    delay = 1311765 - int(round(0.025 * p))
+    df = 1780.75 + 0.05 * math.sin(2 * math.pi * p / 600)
+    ch1 = synth.SynthParams(delay_q8=delay * 256, fstep=synth.fstep_for_df(df, FS), phi0=(p * 2654435761) & 0xFFFFFFFF, amp=200,
+                            noise_gain=synth.noise_gain_for_sigma(400.0), seed=1000 + p, stream=0)
+    ch2 = synth.SynthParams(delay_q8=3626553 * 256, fstep=0, phi0=12345, amp=3000, noise_gain=synth.noise_gain_for_sigma(100.0),
+                            seed=1000 + p, stream=1)                                              # loop-back channel
+    return delay, [ch1, ch2]
+
+
+def test_config3_600_windows_two_channels_one_gpu():
+    """The whole C4 recording (600 windows x 2 channels, 24 GB of int16 resident in HBM) on ONE GPU: every lag equals
+    3*delay_p of the generator, df follows the generator's drift, results go through dist.shard/gather (world 1)."""
+    import torch
+    nwin = 600
+    chips = chips_for(22, 3, NCHIPS)
+    dev = torch.device("cuda", 0)
+    chips_dev = torch.from_numpy(chips).to(dev)
+    iq = torch.empty((nwin, N, 4), dtype=torch.int16, device=dev)
+    delays = []
+    for p in range(nwin):
+        delay, chans = _c4_channels(p)
+        delays.append(delay)
+        _synth_dev(iq[p], N, chips_dev, NCHIPS, 2, chans)
+    torch.cuda.synchronize()
+    start, stop = D.shard_windows(nwin, 0, 1)
+    assert (start, stop) == (0, 600) and D.shard_windows(nwin, 3, 8) == (225, 300)
+    res = torch.zeros((nwin * 2, D.RESULT_BYTES), dtype=torch.uint8, device=dev)
+    lib = L.load()
+    with Correlator(chips, fs=FS, Nint=1) as cor:
+        band = L.twx_band(*band_godual(FS, N))
+        L.check(lib.twx_process_windows_dev(cor._h, iq.data_ptr(), nwin, 2, ALL_CHANNELS, C.byref(band), None, res.data_ptr()), cor._h)
+        cor.synchronize()
+    allb = D.gather_results(res, nwin, 0, 1, per_window=2)
+    recs = D.results_from_bytes(allb)
+    r1, r2 = recs[0::2], recs[1::2]
+    assert len(r1) == len(r2) == nwin
+    import math
+    for p in range(nwin):
+        assert r1[p].indice == 3 * delays[p], p
+        assert r2[p].indice == 3 * 3626553, p
+        df_true = synth.df_of_fstep(synth.fstep_for_df(1780.75 + 0.05 * math.sin(2 * math.pi * p / 600), FS), FS)
+        # 0.5-Hz bins (fs/N/2) plus the +0.25 Hz the reference's linspace(-fs/2,fs/2,N) axis adds near DC (godual_ranging.m:73)
+        assert abs(r1[p].df - df_true) <= 0.6
+        assert abs(r2[p].df) <= 0.6
+        assert abs(r1[p].correction) < 0.1 and abs(r2[p].correction) < 0.1
+    # the same windows in 8 shards of 75, each as its own call on its own extent (what the 8 ranks do): identical records
+    with Correlator(chips, fs=FS, Nint=1) as cor:
+        for r in (0, 3, 7):
+            s, e = D.shard_windows(nwin, r, 8)
+            assert e - s == 75
+            part = torch.zeros(((e - s) * 2, D.RESULT_BYTES), dtype=torch.uint8, device=dev)
+            L.check(lib.twx_process_windows_dev(cor._h, iq[s].data_ptr(), e - s, 2, ALL_CHANNELS, C.byref(band), None, part.data_ptr()), cor._h)
+            cor.synchronize()
+            assert torch.equal(part, res[2 * s:2 * e])
+
+
+# --------------------------------------------------------------------------------------------------------------
+# configs[4]: two stations, 4 concurrent correlations, 70 Msps wideband capture, fp64 vs fp32 tolerance check
+# --------------------------------------------------------------------------------------------------------------
+def test_config4_two_station_wideband_chain_at_size():
+    """Each station records, at 70 Msps, its own (local) code near 0 Hz plus the other station's (remote) code near
+    +-50 kHz carrier offset, i.e. inside the +-(80..120) kHz band of the squared spectrum (godual_ranging.m:83-89).
+    Device chain: FIR low-pass + decimate by 14 (twx_fir_decimate_dev) -> 1-s window of N = 5e6 at 5 Msps ->
+    processing(d,k) in fp32 AND fp64 for the four correlations oplo/opre/ltlo/ltre of acquisition/go_1s.m:88,120,147,171
+    (codes: taps 57 = OP, taps 3 = LTFB).  Gates: same lag fp32 = fp64 = oracle, |xval| within 1e-6 relative."""
+    import torch
+    dev = torch.device("cuda", 0)
+    fs_in, dec, sps_in = 70e6, 14, 28
+    taps = frontend.lowpass_taps(fs_in, 2.1e6, 0.4e6)
+    ntaps = taps.size
+    n_in = (N - 1) * dec + ntaps
+    codes = {"OP": chips_for(22, 57, NCHIPS), "LTFB": chips_for(22, 3, NCHIPS)}
+    cdev = {k: torch.from_numpy(v).to(dev) for k, v in codes.items()}
+    half = (ntaps - 1) // 2
+    # (station, local delay [70 Msps samples], remote delay, remote carrier offset, OP flag of the remote band)
+    stations = [("OP", "LTFB", 18_364_717, 50_772_133, +50_000.0, 0), ("LTFB", "OP", 41_000_003, 9_123_457, -50_000.0, 1)]
+    narrow = {}
+    with Correlator(codes["OP"], fs=FS, Nint=1) as c_op32, Correlator(codes["OP"], fs=FS, Nint=1, precision="f64") as c_op64, \
+            Correlator(codes["LTFB"], fs=FS, Nint=1) as c_lt32, Correlator(codes["LTFB"], fs=FS, Nint=1, precision="f64") as c_lt64:
+        ctx = {"OP": (c_op32, c_op64), "LTFB": (c_lt32, c_lt64)}
+        results = {}
+        for st, other, d_loc, d_rem, f_rem, op_flag in stations:
+            wide = torch.empty((n_in, 2), dtype=torch.int16, device=dev)
+            tmp = torch.empty((n_in, 2), dtype=torch.int16, device=dev)
+            ploc = synth.SynthParams(delay_q8=d_loc * 256, fstep=synth.fstep_for_df(3.25, fs_in), phi0=99, amp=2500,
+                                     noise_gain=synth.noise_gain_for_sigma(2500.0), seed=401, stream=len(results))
+            prem = synth.SynthParams(delay_q8=d_rem * 256, fstep=synth.fstep_for_df(f_rem, fs_in), phi0=7, amp=1200,
+                                     noise_gain=0, seed=402, stream=len(results))
+            _synth_dev(wide, n_in, cdev[st], NCHIPS, sps_in, [ploc])
+            _synth_dev(tmp, n_in, cdev[other], NCHIPS, sps_in, [prem])
+            torch.cuda.synchronize()
+            wide = (wide.to(torch.int32) + tmp.to(torch.int32)).clamp_(-32768, 32767).to(torch.int16).contiguous()
+            del tmp
+            nar = torch.empty((N, 2), dtype=torch.int16, device=dev)
+            narf = torch.empty((N, 2), dtype=torch.float32, device=dev)
+            c32 = ctx[st][0]
+            nout = c32.fir_decimate_dev(wide.data_ptr(), n_in, taps, dec, out_i16_dev=nar.data_ptr(), out_f32_dev=narf.data_ptr())
+            assert nout == N
+            c32.synchronize()
+            # FIR parity on 4096 random outputs against the fp64 direct sum (the oracle's definition, orc.fir_decimate)
+            rng = np.random.default_rng(3)
+            ms = np.sort(rng.choice(N, 4096, replace=False))
+            idx = torch.from_numpy((ms[:, None] * dec + np.arange(ntaps)[None, :]).reshape(-1)).to(dev)
+            seg = wide[idx].cpu().numpy().astype(np.float64).reshape(4096, ntaps, 2)
+            ref = (seg * taps.astype(np.float64)[None, :, None]).sum(axis=1)
+            got = narf[torch.from_numpy(ms).to(dev)].cpu().numpy().astype(np.float64)
+            assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-3
+            g16 = nar[torch.from_numpy(ms).to(dev)].cpu().numpy()
+            assert np.abs(g16 - np.rint(ref)).max() <= 1
+            narrow[st] = nar
+            del wide, narf
+            # local correlation (own code, +-20 kHz band) and remote correlation (other code, remote band)
+            for name, code_key, band in ((st + "lo", st, band_godual(FS, N)), (st + "re", other, band_godual(FS, N, remote=1, OP=op_flag))):
+                g32 = ctx[code_key][0].process_dev(nar.data_ptr(), 1, band=band)[0]
+                g64 = ctx[code_key][1].process_dev(nar.data_ptr(), 1, band=band)[0]
+                results[name] = (g32, g64, code_key, band)
+            # expected lags: y[m] is centred on input sample m*dec + (ntaps-1)/2
+            for name, d70 in ((st + "lo", d_loc), (st + "re", d_rem)):
+                expect = (d70 - half) / dec
+                assert abs(results[name][0].indice / 3.0 - expect) < 1.0, name
+        assert sorted(results) == ["LTFBlo", "LTFBre", "OPlo", "OPre"]
+    # oracle on the same decimated int16 samples, all four correlations
+    for name, (g32, g64, code_key, band) in results.items():
+        st = name[:-2]
+        raw = narrow[st].cpu().numpy()
+        d = orc.deinterleave(raw, 1, 0)
+        d = d - d.mean()
+        code = orc.make_code(codes[code_key], 2)
+        freq = orc.freq_axis(FS, N)
+        k = np.arange(band[0], band[1] + 1)
+        o = orc.processing(d, k, freq, np.arange(N) / FS, orc.make_fcode(code), code, Nint=1, fs=FS)
+        assert g32.indice == g64.indice == o["indice"], name                       # delta indice = 0
+        assert abs(g32.df - o["df"]) <= 1e-9 and abs(g64.df - o["df"]) <= 1e-9, name
+        assert abs(abs(g32.xval) - abs(g64.xval)) <= MAG_TOL * abs(g64.xval), name  # fp32 vs fp64 peak magnitude
+        assert abs(abs(g32.xval) - abs(o["xval"])) <= MAG_TOL * abs(o["xval"]), name
+        assert abs(abs(g64.xval) - abs(o["xval"])) <= 1e-9 * abs(o["xval"]), name
+        assert abs(g32.correction - o["correction"]) <= 2e-4 and abs(g64.correction - o["correction"]) <= 1e-7, name
+        if name.endswith("re"):
+            assert 40_000.0 < abs(o["df"]) < 60_000.0
+
+
+# --------------------------------------------------------------------------------------------------------------
+# multi-rank path with the real correlator (ranks share GPU 0, records exchanged with gloo)
+# --------------------------------------------------------------------------------------------------------------
+def _write_capture(tmp_path, nchips, nwin, seed, bitlen=14):
+    from tests.test_gpu_parity import _capture
+    chips, raw = _capture(bitlen, 43, nchips, nwin, seed=seed)
+    (tmp_path / "codes").mkdir()
+    prn.lfsr_chips(bitlen, 43, nchips).tofile(tmp_path / "codes" / f"noiselen{nchips}_bitlen{bitlen}_taps43.bin")
+    prn.lfsr_chips(bitlen, 57, nchips).tofile(tmp_path / "codes" / f"noiselen{nchips}_bitlen{bitlen}_taps57.bin")
+    raw.tofile(tmp_path / "1670074501.bin")
+    return chips, raw
+
+
+@pytest.mark.parametrize("world,nwin", [(2, 13), (8, 600)])
+def test_ranks_share_one_capture_and_match_single_rank(tmp_path, world, nwin):
+    """python -m amaranth_twstft_amd.godual_ranging --gpus N: every rank correlates its contiguous block of windows of
+    the SAME capture file with the real HIP correlator, one all_gather of the records, rank 0 writes .mat/TSV.
+    Compared with the single-process run: same stdout, same .mat bytes.  (8 x 75 = configs[3]'s sharding.)"""
+    _write_capture(tmp_path, 10000, nwin, seed=77)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    base = [sys.executable, "-m", "amaranth_twstft_amd.godual_ranging", "--datalocation", str(tmp_path), "--codelocation", str(tmp_path / "codes")]
+    one = subprocess.run(base, capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    mat = tmp_path / "1670074501.mat"
+    ref_bytes = mat.read_bytes()
+    mat.unlink()
+    many = subprocess.run(base + ["--gpus", str(world), "--backend", "gloo"], capture_output=True, text=True, env=env, timeout=900)
+    assert many.returncode == 0, many.stdout[-2000:] + many.stderr[-3000:]
+    assert mat.read_bytes() == ref_bytes                               # byte for byte
+    rows = lambda s: [l for l in s.splitlines() if l[:1].isdigit() and "\t" in l]
+    assert rows(many.stdout) == rows(one.stdout) and len(rows(one.stdout)) == nwin
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` without torchrun starts two ranks itself (they share GPU 0 here: gloo) and prints n_gpus 2."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "9",
+                          "--backend", "gloo", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["integer_lag_exact"] and j["value"] > 0 and j["roofline"]["frac"] > 0.05
+
+
+# --------------------------------------------------------------------------------------------------------------
+# single-slot ingest pipeline (TWX_FLAG_PROFILE forces one slot; TWX_STREAMS=1)
+# --------------------------------------------------------------------------------------------------------------
+def test_single_slot_pipeline_matches_three_slots(tmp_path, monkeypatch):
+    from tests.test_gpu_parity import _capture
+    chips, raw = _capture(15, 3, 25000, 11, seed=93)
+    n = 50000
+    path = tmp_path / "1670074999.bin"
+    np.concatenate([raw, raw[:777]]).tofile(path)
+    band = band_godual(FS, n)
+    with Correlator(chips, fs=FS, Nint=1, max_batch=2) as cor:
+        ref_mem = cor.process(raw, n_channels=2, channel=0, band=band)
+        ref_fil = cor.process_file(str(path), n_channels=2, channel=-1, band=band)
+    with Correlator(chips, fs=FS, Nint=1, max_batch=2, profile=True) as cor:
+        got_mem = cor.process(raw, n_channels=2, channel=0, band=band)
+        got_fil = cor.process_file(str(path), n_channels=2, channel=-1, band=band)
+        assert cor.profile()["k_row_mid"]["launches"] > 0
+    monkeypatch.setenv("TWX_STREAMS", "1")
+    with Correlator(chips, fs=FS, Nint=1, max_batch=2) as cor:
+        got2_mem = cor.process(raw, n_channels=2, channel=0, band=band)
+        got2_fil = cor.process_file(str(path), n_channels=2, channel=-1, band=band)
+        one = cor.process(raw[:n], n_channels=2, channel=1, df=0.0)            # a single window, one chunk
+    assert len(ref_mem) == 11 and len(one) == 1
+    for got in (got_mem, got2_mem):
+        assert [(g.indice, g.xval, g.df, g.SNRr) for g in got] == [(g.indice, g.xval, g.df, g.SNRr) for g in ref_mem]
+    for got in (got_fil, got2_fil):
+        for c in (0, 1):
+            assert [(g.indice, g.xval, g.df) for g in got[c]] == [(g.indice, g.xval, g.df) for g in ref_fil[c]]
