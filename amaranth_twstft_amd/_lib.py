@@ -74,6 +74,7 @@ SYMBOLS = {
     "twx_get_info": (C.c_int, [_VP, C.POINTER(twx_info)]),
     "twx_process_windows": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
     "twx_process_windows_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
+    "twx_process_complex": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, C.POINTER(twx_band), _VP, _VP]),
     "twx_synchronize": (C.c_int, [_VP]),
     "twx_set_option": (C.c_int, [_VP, C.c_int32, C.c_int64]),
     "twx_stream": (_VP, [_VP]),

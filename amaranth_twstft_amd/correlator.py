@@ -218,6 +218,31 @@ class Correlator:
             return {c: [_to_result(out[w * n_channels + c]) for w in range(ndone.value)] for c in range(n_channels)}
         return [_to_result(out[i]) for i in range(ndone.value)]
 
+    def processing_complex(self, d, k=None, df=None):
+        """The reference's own call: ``processing(d,k)`` (godual_ranging.m:12) or ``processing(d,df)``
+        (claudio_aligned_code_ranging_separate.m:49) on the complex column ``d`` the scripts build (mean already removed
+        by the caller, :80).  ``d``: complex128, a whole number of windows; ``k``: (k_lo, k_hi) or an index array;
+        ``df``: scalar or one value per window.  Returns one WindowResult per window."""
+        d = np.ascontiguousarray(d, dtype=np.complex128).reshape(-1)
+        nwin = d.size // self.n
+        if nwin * self.n != d.size:
+            raise ValueError("d must hold a whole number of windows")
+        out = (L.twx_result * max(nwin, 1))()
+        bptr = dptr = None
+        if k is not None:
+            if not (isinstance(k, tuple) and len(k) == 2):
+                k = _band_range(np.asarray(k))
+            b = L.twx_band(int(k[0]), int(k[1]))
+            bptr = C.byref(b)
+        elif df is not None:
+            dfa = np.ascontiguousarray(np.broadcast_to(np.asarray(df, dtype=np.float64), (nwin,)))
+            dptr = dfa.ctypes.data_as(C.c_void_p)
+        else:
+            raise ValueError("give k (band) or df")
+        base = d.ctypes.data
+        L.check(self._lib.twx_process_complex(self._h, base, base + 8, 2, nwin, bptr, dptr, C.cast(out, C.c_void_p)), self._h)
+        return [_to_result(out[i]) for i in range(nwin)]
+
     def processing(self, raw_window, k, n_channels=1, channel=0) -> WindowResult:
         """``processing(d,k)`` (godual_ranging.m:12): ``k`` = (k_lo, k_hi) or an index array."""
         if not (isinstance(k, tuple) and len(k) == 2):

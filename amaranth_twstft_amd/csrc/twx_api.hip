@@ -283,6 +283,8 @@ struct CtxBase {
                              twx_result* out, long long max_windows, long long* n_done) = 0;
     virtual int process_host(const int16_t* iq, long long nwin, int nch, int ch, const twx_band* band, const double* df,
                              twx_result* out) = 0;
+    virtual int process_complex(const double* re, const double* im, long long stride, long long nwin, const twx_band* band,
+                                const double* df, twx_result* out) = 0;
 };
 
 template <typename T> static void host_twiddle(std::vector<cpx<T>>& v, long long count, long long num_mul, long long den, int sign) {
@@ -332,7 +334,7 @@ template <typename T> struct Ctx : CtxBase {
     // compute-heavy middle pass of one batch can share CUs with the memory-heavy column passes of the other.
     struct Slot {
         hipStream_t stream; WinSums* sums; double* dfv; long long* dfidx; C *e1, *e2, *A, *Bz, *dc;
-        ArgPart<T>*part_band, *part_peak; twx_result* res_dev; double* fine_u;
+        ArgPart<T>*part_band, *part_peak; twx_result* res_dev; double* fine_u; double* csum_part;
     };
     Slot slots[4] = {}; int nslots = 1;
     hipEvent_t ev_fork = nullptr, ev_join[4] = {};   // ordering of slots 1.. against slot 0 = twx_stream() (process())
@@ -341,7 +343,7 @@ template <typename T> struct Ctx : CtxBase {
     void use_slot(int k) {
         const Slot& q = slots[k];
         stream = q.stream; sums = q.sums; dfv = q.dfv; dfidx = q.dfidx; e1 = q.e1; e2 = q.e2; A = q.A; Bz = q.Bz; dc = q.dc;
-        part_band = q.part_band; part_peak = q.part_peak; res_dev = q.res_dev; fine_u = q.fine_u;
+        part_band = q.part_band; part_peak = q.part_peak; res_dev = q.res_dev; fine_u = q.fine_u; csum_part = q.csum_part;
     }
     int pipeline_depth() const override { return nslots; }
     int sync_all() override {
@@ -350,6 +352,7 @@ template <typename T> struct Ctx : CtxBase {
     }
     unsigned long long* stamps_dev = nullptr;   // TWX_STAMPS diagnostic builds
     double* fine_u = nullptr; int fine_M = 0;   // TWX_FLAG_FINE_FREQ
+    double* csum_part = nullptr;                // per-window partial sums of |d|^2 (complex-double input)
     int io_threads = 4;                         // TWX_IO_THREADS: concurrent preads per chunk in twx_process_file
     int ncu = 256;
     int ntiles = 0;
@@ -600,6 +603,7 @@ template <typename T> struct Ctx : CtxBase {
             if (int rc = dalloc(&q.part_peak, (size_t)B * R * ntiles)) return rc;
             if (int rc = dalloc(&q.res_dev, (size_t)B * TWX_MAX_CHANNELS)) return rc;   // all-channel mode: B windows x channels
             if (fine_M) { if (int rc = dalloc(&q.fine_u, (size_t)B * fine_M)) return rc; }
+            if (int rc = dalloc(&q.csum_part, (size_t)B * 64)) return rc;
         }
         use_slot(0);
         {
@@ -651,17 +655,33 @@ template <typename T> struct Ctx : CtxBase {
     // one batch of nb windows starting at `in` (short2 units: window stride N*nch, channel offset applied)
     int run_batch(const short2* in, int nb, int nch, const twx_band* band, const double* df_host, twx_result* out_dev,
                   C* zout /*optional full map, nb must be 1*/, bool same_window = false, int res_stride = 1) {
-        const long long wstride = same_window ? 0 : (long long)N * nch;
-        HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums) * nb, stream));
-        {
+        return run_batch_in(IN_I16, in, nullptr, nch, same_window ? 0 : (long long)N * nch, remove_mean, nb, band, df_host, out_dev, zout, res_stride);
+    }
+    // intype IN_I16: p0 = short2 samples, aux = channels per sample, wstride in short2;  IN_C64S: p0/p1 = real/imaginary
+    // doubles, aux = element stride, wstride in doubles (the mean-removed complex `d` of processing(d,k), godual_ranging.m:12)
+    int run_batch_in(int intype, const void* p0, const void* p1, int aux, long long wstride, int rm_mean, int nb, const twx_band* band,
+                     const double* df_host, twx_result* out_dev, C* zout, int res_stride) {
+        const short2* in = reinterpret_cast<const short2*>(p0);
+        const int nch = aux;
+        SplitPtr sp{reinterpret_cast<const double*>(p0), reinterpret_cast<const double*>(p1)};
+        const void* colin = intype == IN_C64S ? static_cast<const void*>(&sp) : p0;
+        if (intype == IN_I16) {
+            HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums) * nb, stream));
             ProfScope ps(this, PC_SUMS, (long long)nb * N);
             // few, fat chunks: the three 64-bit atomics per workgroup land on the same words of a window
             const int chunks = (int)std::min<long long>(64, std::max<long long>(1, N / 16384));
             TWX_LAUNCH((k_sums<0>), dim3(chunks, nb), dim3(256), stream, in, wstride, nch, N, sums);
             HIPCHK(hipGetLastError());
+        } else {
+            if (rm_mean) return fail(TWX_E_ARG, "complex input is taken as it is (the caller removed the mean, godual_ranging.m:80)");
+            ProfScope ps(this, PC_SUMS, (long long)nb * N);
+            TWX_LAUNCH((k_sums_c64<0>), dim3(64, nb), dim3(256), stream, InCplxSplit{sp.re, sp.im, aux}, wstride, (long long)N, csum_part);
+            HIPCHK(hipGetLastError());
+            TWX_LAUNCH((k_sums_c64_final<0>), dim3(nb), dim3(64), stream, csum_part, 64, sums);
+            HIPCHK(hipGetLastError());
         }
         ColFwdArgs<T> ca{};
-        ca.in_win_stride = wstride; ca.sums = sums; ca.remove_mean = remove_mean; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = nb;
+        ca.in_win_stride = wstride; ca.sums = sums; ca.remove_mean = rm_mean; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = nb;
         ca.e1 = e1; ca.e2 = e2; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.tc = tcw; ca.out = A;
         RowArgs<T> ra{};
         ra.n = N; ra.n1 = N1; ra.nwin = nb; ra.A = A; ra.wshift = wshift_of(col->W); ra.stab_f = stab_f; ra.stab_i = stab_i; ra.ea = ea; ra.eb = eb;
@@ -673,7 +693,7 @@ template <typename T> struct Ctx : CtxBase {
             ra.band_lo = band->k_lo; ra.band_hi = band->k_hi;
             {
                 ProfScope ps(this, PC_COL_SQ, (long long)nb * N);
-                if (col->fwd(COL_SQUARE, IN_I16, in, nch, &ca, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_fwd(square) launch failed");
+                if (col->fwd(COL_SQUARE, intype, colin, aux, &ca, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_fwd(square) launch failed");
             }
             {
                 ProfScope ps(this, PC_ROW_BAND, (long long)nb * N);
@@ -692,7 +712,8 @@ template <typename T> struct Ctx : CtxBase {
             HIPCHK(hipGetLastError());
         }
         if (cfg.flags & TWX_FLAG_FINE_FREQ) {
-            TWX_LAUNCH((k_fine_angle<0>), dim3(64, nb), dim3(256), stream, in, wstride, nch, (long long)N, sums, dfv, cfg.fs, fine_M, fine_u);
+            if (intype == IN_I16) TWX_LAUNCH((k_fine_angle<InI16>), dim3(64, nb), dim3(256), stream, InI16{in, nch}, wstride, rm_mean, (long long)N, sums, dfv, cfg.fs, fine_M, fine_u);
+            else TWX_LAUNCH((k_fine_angle<InCplxSplit>), dim3(64, nb), dim3(256), stream, InCplxSplit{sp.re, sp.im, aux}, wstride, rm_mean, (long long)N, sums, dfv, cfg.fs, fine_M, fine_u);
             HIPCHK(hipGetLastError());
             TWX_LAUNCH((k_fine_fit<0>), dim3(nb), dim3(1024), stream, fine_u, fine_M, cfg.fs, dfv);
             HIPCHK(hipGetLastError());
@@ -702,7 +723,7 @@ template <typename T> struct Ctx : CtxBase {
         }
         {
             ProfScope ps(this, PC_COL_MIX, (long long)nb * N);
-            if (col->fwd(COL_MIX, IN_I16, in, nch, &ca, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_fwd(mix) launch failed");
+            if (col->fwd(COL_MIX, intype, colin, aux, &ca, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_fwd(mix) launch failed");
         }
         {
             ProfScope ps(this, PC_ROW_MID, (long long)nb * N);
@@ -719,7 +740,7 @@ template <typename T> struct Ctx : CtxBase {
         }
         PeakArgs<T> pa{};
         pa.n = N; pa.n1 = N1; pa.n2 = N2; pa.nphase = R; pa.nparts = R * ntiles; pa.part = part_peak; pa.Bz = Bz; pa.tw1d = tw1d;
-        pa.sums = sums; pa.remove_mean = remove_mean; pa.dc = dc; pa.dfv = dfv; pa.dfidx = dfidx; pa.inv_scale = 1.0 / scale_pow2;
+        pa.sums = sums; pa.remove_mean = rm_mean; pa.dc = dc; pa.dfv = dfv; pa.dfidx = dfidx; pa.inv_scale = 1.0 / scale_pow2;
         pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.convention = cfg.convention; pa.snr_valid = snr_valid; pa.res = out_dev; pa.res_stride = res_stride;
         {
             ProfScope ps(this, PC_PEAK, nb);
@@ -1034,6 +1055,32 @@ template <typename T> struct Ctx : CtxBase {
         return rc;
     }
 
+    // processing(d,k) / processing(d,df) on complex-double windows in HOST memory, nwin consecutive windows of N samples,
+    // sample n of the capture at re[n*stride], im[n*stride].  No mean removal (the reference's callers do it).
+    int process_complex(const double* re, const double* im, long long stride, long long nwin, const twx_band* band,
+                        const double* df, twx_result* out) override {
+        if (!band && !df) return fail(TWX_E_ARG, "either band or df must be given");
+        if (stride < 1 || stride > 2) return fail(TWX_E_ARG, "stride must be 1 (separate arrays) or 2 (interleaved)");
+        const bool inter = stride == 2 && im == re + 1;
+        if (stride == 2 && !inter) return fail(TWX_E_ARG, "stride 2 means interleaved storage: im must be re + 1");
+        if (int rc = sync_all()) return rc;
+        use_slot(0);
+        Scratch sc(this);
+        double *dre = nullptr, *dim = nullptr;
+        const size_t per = (size_t)N * (size_t)stride;
+        if (int rc = sc.get(&dre, per * (size_t)B)) return rc;
+        if (!inter) { if (int rc = sc.get(&dim, per * (size_t)B)) return rc; } else dim = dre + 1;
+        for (long long w0 = 0; w0 < nwin; w0 += B) {
+            const int nb = (int)std::min<long long>(B, nwin - w0);
+            HIPCHK(hipMemcpyAsync(dre, re + (size_t)w0 * per, per * nb * sizeof(double), hipMemcpyHostToDevice, stream));
+            if (!inter) HIPCHK(hipMemcpyAsync(dim, im + (size_t)w0 * per, per * nb * sizeof(double), hipMemcpyHostToDevice, stream));
+            if (int rc = run_batch_in(IN_C64S, dre, dim, (int)stride, (long long)per, 0, nb, band, df ? df + w0 : nullptr, res_dev, nullptr, 1)) return rc;
+            HIPCHK(hipMemcpyAsync(out + w0, res_dev, sizeof(twx_result) * nb, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        }
+        return TWX_OK;
+    }
+
     int caf_bins(const int16_t* iq, int nch, int ch, long long k_lo, long long k_hi, double* pk, long long* lag) override {
         if (k_hi < k_lo) return fail(TWX_E_ARG, "k_hi < k_lo");
         short2* din = nullptr; C* Ysp = nullptr; double* pk_d = nullptr; long long* lag_d = nullptr;
@@ -1201,6 +1248,16 @@ int twx_process_windows(twx_ctx* ctx, const int16_t* iq, int64_t n_windows, int3
     // pinned double-buffered staging: the host-side copy, the H2D transfer and the kernels of consecutive
     // chunks overlap (same pipeline as twx_process_file)
     return guarded(c, [&]() { return c->process_host(iq, n_windows, n_channels, channel, band, df, out); });
+}
+
+int twx_process_complex(twx_ctx* ctx, const double* d_re, const double* d_im, int64_t stride, int64_t n_windows,
+                        const twx_band* band, const double* df, twx_result* out) {
+    if (!ctx) return TWX_E_ARG;
+    CtxBase* c = ctx->impl;
+    if (!d_re || !d_im || !out || n_windows < 0) return c->fail(TWX_E_ARG, "bad argument");
+    if (n_windows == 0) return TWX_OK;
+    (void)hipSetDevice(c->dev);
+    return guarded(c, [&]() { return c->process_complex(d_re, d_im, stride, n_windows, band, df, out); });
 }
 
 int twx_fft_forward(twx_ctx* ctx, const double* in, double* out) {

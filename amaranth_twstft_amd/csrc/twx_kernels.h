@@ -42,6 +42,8 @@ namespace twx {
 struct WinSums {            // exact integer sums over the raw int16 window
     long long sI, sQ;
     unsigned long long sP;  // sum(I^2+Q^2)
+    double fP;              // complex-double input (twx_process_complex): sum |d|^2 in fp64, valid when is_f != 0
+    int is_f, pad;
 };
 template <typename T> struct ArgPart { T val; unsigned int idx; };
 template <> struct ArgPart<double> { double val; unsigned int idx; unsigned int pad; };
@@ -116,6 +118,7 @@ template <typename V> __device__ __forceinline__ void st_su(void* ubase, unsigne
 // ------------------------------------------------------------------------------------------
 struct InI16 {   // interleaved int16 IQ, nch channels per sample (godual_ranging.m:76-79)
     const short2* p; int nch;
+    __device__ __forceinline__ void advance(long long e) { p += e; }
     template <typename T> __device__ __forceinline__ cpx<T> load(long long n) const {
         short2 s = p[n * nch];
         return mk<T>((T)s.x, (T)s.y);
@@ -139,14 +142,16 @@ struct InI16 {   // interleaved int16 IQ, nch channels per sample (godual_rangin
 };
 struct InChips {  // code replica: chips {0,1} held sps samples, value 2c-1 (godual_ranging.m:63-65)
     const unsigned char* p; int sps;
+    __device__ __forceinline__ void advance(long long e) { p += e; }
     template <typename T> __device__ __forceinline__ cpx<T> load(long long n) const {
         return mk<T>((T)(2 * (int)p[n / sps] - 1), (T)0);
     }
     template <typename T> __device__ __forceinline__ cpx<T> load2(long long ubase, unsigned lane) const { return load<T>(ubase + lane); }
     static constexpr bool has_raw = false;
 };
-template <typename S> struct InCplx {  // complex float/double samples (processing(d,k) entry)
+template <typename S> struct InCplx {  // complex float/double samples (FFT test entry)
     const cpx<S>* p;
+    __device__ __forceinline__ void advance(long long e) { p += e; }
     template <typename T> __device__ __forceinline__ cpx<T> load(long long n) const {
         cpx<S> s = p[n];
         return mk<T>((T)s.x, (T)s.y);
@@ -158,6 +163,49 @@ template <typename S> struct InCplx {  // complex float/double samples (processi
     }
     static constexpr bool has_raw = false;
 };
+
+// complex double samples as MATLAB/Octave hold them: d(n) = re[n*stride] + j*im[n*stride]  (stride 1: separate real
+// and imaginary arrays, mxGetPr/mxGetPi; stride 2 with im = re+1: interleaved, mxGetComplexDoubles) — the `d` of
+// processing(d,k), godual_ranging.m:12
+struct InCplxSplit {
+    const double* re; const double* im; int stride;
+    __device__ __forceinline__ void advance(long long e) { re += e; im += e; }       // e in doubles
+    template <typename T> __device__ __forceinline__ cpx<T> load(long long n) const {
+        return mk<T>((T)re[n * stride], (T)im[n * stride]);
+    }
+    template <typename T> __device__ __forceinline__ cpx<T> load2(long long ubase, unsigned lane) const {
+        const long long n = (ubase + lane) * stride;
+        return mk<T>((T)re[n], (T)im[n]);
+    }
+    static constexpr bool has_raw = false;
+};
+
+// sum |d|^2 of complex-double windows, deterministic two-step reduction (no atomics): grid = (64, windows), then (windows)
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_sums_c64(InCplxSplit in, long long win_stride, long long n, double* __restrict__ partial) {
+    in.advance((long long)blockIdx.y * win_stride);
+    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per, hi = min(n, lo + per);
+    double acc = 0;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const double x = in.re[i * in.stride], y = in.im[i * in.stride];
+        acc += x * x + y * y;
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d, 64);
+    __shared__ double sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(long long)blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+template <int UNUSED = 0>
+__global__ void k_sums_c64_final(const double* __restrict__ partial, int nparts, WinSums* __restrict__ sums) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    double a = 0;
+    for (int i = 0; i < nparts; ++i) a += partial[(long long)b * nparts + i];
+    WinSums s; s.sI = 0; s.sQ = 0; s.sP = 0; s.fP = a; s.is_f = 1; s.pad = 0;
+    sums[b] = s;
+}
 
 // ------------------------------------------------------------------------------------------
 // k_sums: exact integer statistics of a raw int16 window (mean removal godual_ranging.m:80,
@@ -284,22 +332,22 @@ __global__ __launch_bounds__(256) void k_df_tables(int estimate, const ArgPart<T
 // k_fine_fit:   100-tap moving average with the reference's edge handling, straight-line LSQ slope,
 //               df += slope/2pi.  grid = windows
 // ------------------------------------------------------------------------------------------
-template <int UNUSED = 0>
-__global__ __launch_bounds__(256) void k_fine_angle(const short2* __restrict__ in, long long win_stride, int nch, long long n,
+template <class In>
+__global__ __launch_bounds__(256) void k_fine_angle(In in, long long win_stride, int remove_mean, long long n,
                                                     const WinSums* __restrict__ sums, const double* __restrict__ dfv, double fs,
                                                     int M, double* __restrict__ u) {
     const int b = blockIdx.y;
-    const short2* p = in + (long long)b * win_stride;
+    in.advance((long long)b * win_stride);
     const WinSums s = sums[b];
-    const double mI = (double)s.sI / (double)n, mQ = (double)s.sQ / (double)n;
+    const double mI = remove_mean ? (double)s.sI / (double)n : 0.0, mQ = remove_mean ? (double)s.sQ / (double)n : 0.0;
     const double fn = dfv[b] / fs;
     for (int m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256) {
         const long long i = 10ll * m;
-        const short2 x = p[i * nch];
+        const cpx<double> x = in.template load<double>(i);
         double ph = fn * (double)i; ph -= rint(ph);
         double sn, cs;
         sincospi(-2.0 * ph, &sn, &cs);
-        const double re = (double)x.x - mI, im = (double)x.y - mQ;
+        const double re = x.x - mI, im = x.y - mQ;
         u[(long long)b * M + m] = atan2(re * sn + im * cs, re * cs - im * sn);
     }
 }
@@ -372,7 +420,7 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
     const int b = logical / a.ntiles, tile = logical % a.ntiles;
     const int c0 = tile * W;
     const int tid = threadIdx.x;
-    In win = in; win.p += (long long)b * a.in_win_stride;
+    In win = in; win.advance((long long)b * a.in_win_stride);
     T mx = 0, my = 0;
     if (a.remove_mean) {
         WinSums s = a.sums[b];
@@ -1373,7 +1421,7 @@ __global__ __launch_bounds__(1024) void k_peak(PeakArgs<T> a) {
         double mI = 0, mQ = 0;
         if (a.remove_mean) { mI = (double)s.sI / N; mQ = (double)s.sQ / N; }
         // sum|y|^2 = sum|d-mean|^2 (|lo|=1);   mean(y) = X[0]/N
-        const double sumsq = (double)s.sP - 2.0 * (mI * (double)s.sI + mQ * (double)s.sQ) + N * (mI * mI + mQ * mQ);
+        const double sumsq = s.is_f ? s.fP : (double)s.sP - 2.0 * (mI * (double)s.sI + mQ * (double)s.sQ) + N * (mI * mI + mQ * mQ);
         const double ybx = (double)a.dc[b].x / N, yby = (double)a.dc[b].y / N;
         r.puissance = (sumsq - N * (ybx * ybx + yby * yby)) / (N - a.var_ddof);          // var(y), :46
         const double R2 = (double)a.nphase * (double)a.nphase;

@@ -120,6 +120,16 @@ int twx_get_info(const twx_ctx* ctx, twx_info* info);
 int twx_process_windows(twx_ctx* ctx, const int16_t* iq, int64_t n_windows, int32_t n_channels,
                         int32_t channel, const twx_band* band, const double* df, twx_result* out);
 
+/* The reference's own signature: processing(d,k) (godual_ranging.m:12) and processing(d,df)
+ * (claudio_aligned_code_ranging_separate.m:49) on the complex DOUBLE column `d` the scripts build — n_windows
+ * consecutive windows of N samples in HOST memory, already mean-removed by the caller (godual_ranging.m:80,94; the
+ * library does not touch the mean here).  Sample n is d_re[n*stride] + j*d_im[n*stride]: stride 1 = separate real and
+ * imaginary arrays (mxGetPr/mxGetPi, Octave), stride 2 with d_im == d_re+1 = interleaved (mxGetComplexDoubles, numpy
+ * complex128).  band != NULL: coarse df per window; else df[w].  The context's convention selects the
+ * godual (fft(y).*conj(fft(code))) or claudio (fft(code).*conj(fft(y))) result. */
+int twx_process_complex(twx_ctx* ctx, const double* d_re, const double* d_im, int64_t stride, int64_t n_windows,
+                        const twx_band* band, const double* df, twx_result* out);
+
 /* channel = TWX_ALL_CHANNELS in twx_process_windows, twx_process_windows_dev and twx_process_file processes every
  * channel of every window from ONE copy of the capture (godual_ranging.m:91,95 calls processing() on both channels of
  * each window): results out[w*n_channels + c], and df — where given — df[w*n_channels + c].  n_channels <= 4. */

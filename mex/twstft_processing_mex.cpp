@@ -1,17 +1,27 @@
 // twstft_processing_mex.cpp — MEX / Octave gateway to libtwstft_hip.so (argument marshalling only).
 //
-// Cannot be compiled in the build image (no mex.h / mkoctfile); build on the MATLAB/Octave host:
+// Build on the MATLAB/Octave host (the build image has neither; tests run it against tests/cpu/mex_fake/mex.h):
 //     mkoctfile --mex -I../include twstft_processing_mex.cpp -L../amaranth_twstft_amd -ltwstft_hip
-//     mex -R2018a -I../include twstft_processing_mex.cpp -L../amaranth_twstft_amd -ltwstft_hip
+//     mex -I../include twstft_processing_mex.cpp -L../amaranth_twstft_amd -ltwstft_hip
 //
-// Usage from the scripts (drop-in for processing(d,k) of processing/Octave/godual_ranging.m:12):
+// Two call forms, told apart by the class of the first argument.
+//
+// (A) the reference's own signatures — `d` is the complex double column the scripts build, mean already removed:
 //     [indice,correction,SNRr,SNRi,df,puissance,puissancecode,puissancenoise,xval] = ...
-//         twstft_processing_mex(raw_int16, nchan, chan, k_or_df, code_chips, fs, Nint)
-//   raw_int16 : int16 vector as returned by fread(f, N*2*nchan, 'int16=>int16') for whole windows
-//   chan      : 1-based channel, or 0 = every channel from one upload (outputs become nchan x nwin)
-//   k_or_df   : [k_lo k_hi] 1-based indices into the fftshifted axis (as find(...) gives), or a scalar df (Hz)
-//   code_chips: the code file bytes (0/1), before repelems
-//   outputs are 1 x nwin; indice is 1-based like Octave's max().
+//         twstft_processing_mex(d, k, codeb, fs, Nint)                       % processing(d,k), godual_ranging.m:12
+//     [xval,indice,correction,SNRr,SNRi,puissance,puissancecode,puissancenoise] = ...
+//         twstft_processing_mex(d, df, codeb, fs, Nint, 'claudio')           % processing(d,df), claudio…separate.m:49
+//   d     : n_windows*length(code) complex doubles (one or several code lengths); outputs are 1 x n_windows
+//   k     : the index vector find(...) returns (1-based, fftshifted axis) or its two ends [k(1) k(end)]; a scalar
+//           is a carrier offset df in Hz (one value per window also accepted when numel == n_windows ~= 2)
+//   codeb : the code file bytes (0/1) before repelems;  convention 'godual' (default) or 'claudio':
+//           selects fft(y).*conj(fft(code)) or fft(code).*conj(fft(y)) and the order of the outputs above.
+//
+// (B) raw int16 windows straight from fread (mean removal, godual_ranging.m:80, happens on the GPU):
+//     [...] = twstft_processing_mex(raw_int16, nchan, chan, k_or_df, codeb, fs, Nint [, convention])
+//   chan  : 1-based channel, or 0 = every channel from one upload (outputs become nchan x n_windows)
+//
+// indice is 1-based like Octave's max(); variances use Octave's N-1 normalisation.
 #if __has_include("mex.h")
 #include <string.h>
 #include <vector>
@@ -21,61 +31,122 @@
 static twx_ctx* g_ctx = nullptr;
 static std::vector<uint8_t> g_chips;
 static double g_fs = 0;
-static int g_nint = -1;
+static int g_nint = -1, g_conv = -1;
 
 static void cleanup(void) {
     if (g_ctx) { twx_destroy(g_ctx); g_ctx = nullptr; }
 }
 
-void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
-    if (nrhs != 7) mexErrMsgIdAndTxt("twstft:args", "7 inputs expected");
-    if (!mxIsInt16(prhs[0])) mexErrMsgIdAndTxt("twstft:args", "raw samples must be int16");
-    const int16_t* raw = (const int16_t*)mxGetData(prhs[0]);
-    const int nch = (int)mxGetScalar(prhs[1]);
-    const int ch = (int)mxGetScalar(prhs[2]) - 1;
-    const double fs = mxGetScalar(prhs[5]);
-    const int nint = (int)mxGetScalar(prhs[6]);
-    const size_t nchips = mxGetNumberOfElements(prhs[4]);
+static int parse_convention(const mxArray* a) {
+    char b[32] = {0};
+    if (!mxIsChar(a) || mxGetString(a, b, sizeof b)) mexErrMsgIdAndTxt("twstft:args", "convention must be 'godual' or 'claudio'");
+    if (!strcmp(b, "godual")) return TWX_CONV_GODUAL;
+    if (!strcmp(b, "claudio")) return TWX_CONV_CLAUDIO;
+    mexErrMsgIdAndTxt("twstft:args", "unknown convention '%s'", b);
+    return TWX_CONV_GODUAL;
+}
+
+static void ensure_context(const mxArray* codeb, double fs, int nint, int conv) {
+    const size_t nchips = mxGetNumberOfElements(codeb);
+    if (nchips == 0) mexErrMsgIdAndTxt("twstft:args", "empty code");
     std::vector<uint8_t> chips(nchips);
-    const double* cd = mxIsDouble(prhs[4]) ? mxGetPr(prhs[4]) : nullptr;
-    const uint8_t* cb = cd ? nullptr : (const uint8_t*)mxGetData(prhs[4]);
+    const double* cd = mxIsDouble(codeb) ? mxGetPr(codeb) : nullptr;
+    const uint8_t* cb = cd ? nullptr : (const uint8_t*)mxGetData(codeb);
     for (size_t i = 0; i < nchips; ++i) chips[i] = cd ? (uint8_t)cd[i] : cb[i];
-    if (!g_ctx || chips != g_chips || fs != g_fs || nint != g_nint) {   // context cached across calls
-        cleanup();
-        twx_config cfg;
-        memset(&cfg, 0, sizeof cfg);
-        cfg.fs = fs; cfg.sps = 2; cfg.nint = nint; cfg.chips = chips.data(); cfg.n_chips = (int64_t)nchips;
-        cfg.convention = TWX_CONV_GODUAL; cfg.precision = TWX_F32; cfg.var_ddof = 1 /* Octave var */; cfg.snr_rot = -1; cfg.device = -1;
-        int rc = twx_create(&cfg, &g_ctx);
-        if (rc) mexErrMsgIdAndTxt("twstft:create", "%s", twx_last_error(nullptr));
-        g_chips = chips; g_fs = fs; g_nint = nint;
-        mexAtExit(cleanup);
-        mexLock();
+    if (g_ctx && chips == g_chips && fs == g_fs && nint == g_nint && conv == g_conv) return;   // cached across calls
+    cleanup();
+    twx_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.fs = fs; cfg.sps = 2; cfg.nint = nint; cfg.chips = chips.data(); cfg.n_chips = (int64_t)nchips;
+    cfg.convention = conv; cfg.precision = TWX_F32; cfg.var_ddof = 1 /* Octave var */; cfg.snr_rot = -1; cfg.device = -1;
+    if (twx_create(&cfg, &g_ctx)) mexErrMsgIdAndTxt("twstft:create", "%s", twx_last_error(nullptr));
+    g_chips = chips; g_fs = fs; g_nint = nint; g_conv = conv;
+    mexAtExit(cleanup);
+    if (!mexIsLocked()) mexLock();             // once: `clear mex` can unload after the exit handler has run
+}
+
+// k_or_df -> band (two ends of a 1-based index vector) or per-record carrier offsets
+static bool parse_band_or_df(const mxArray* a, size_t nrec, twx_band* band, std::vector<double>* dfv) {
+    const size_t ne = mxGetNumberOfElements(a);
+    const double* v = mxGetPr(a);
+    if (ne == 0) mexErrMsgIdAndTxt("twstft:args", "empty k / df");
+    if (ne == 1) { dfv->assign(nrec ? nrec : 1, v[0]); return false; }
+    if (ne == nrec && ne != 2) { dfv->assign(v, v + ne); return false; }
+    band->k_lo = (int64_t)v[0] - 1; band->k_hi = (int64_t)v[ne - 1] - 1;       // find(...) is contiguous: its ends define the band
+    return true;
+}
+
+static void emit(int nlhs, mxArray* plhs[], const std::vector<twx_result>& res, size_t rows, size_t cols, int conv) {
+    // output order of the two reference functions
+    //   godual : indice correction SNRr SNRi df puissance puissancecode puissancenoise [xval]
+    //   claudio: xval indice correction SNRr SNRi puissance puissancecode puissancenoise [df]
+    const int nout = nlhs > 0 ? (nlhs > 9 ? 9 : nlhs) : 1;
+    const int xpos = conv == TWX_CONV_CLAUDIO ? 0 : 8;
+    double* o[9] = {0};
+    double* oi = nullptr;
+    for (int i = 0; i < nout; ++i) {
+        plhs[i] = mxCreateDoubleMatrix((mwSize)rows, (mwSize)cols, i == xpos ? mxCOMPLEX : mxREAL);
+        o[i] = mxGetPr(plhs[i]);
+        if (i == xpos) oi = mxGetPi(plhs[i]);
     }
+    for (size_t w = 0; w < rows * cols; ++w) {           // column-major rows x cols == the library's [window][channel] order
+        const twx_result& r = res[w];
+        const double g[8] = {(double)r.indice0 + 1.0, r.correction, r.SNRr, r.SNRi, r.df, r.puissance, r.puissancecode, r.puissancenoise};
+        const double c[8] = {(double)r.indice0 + 1.0, r.correction, r.SNRr, r.SNRi, r.puissance, r.puissancecode, r.puissancenoise, r.df};
+        for (int i = 0; i < nout; ++i) {
+            if (i == xpos) { o[i][w] = r.xval[0]; oi[w] = r.xval[1]; }
+            else o[i][w] = conv == TWX_CONV_CLAUDIO ? c[i - 1] : g[i];
+        }
+    }
+}
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    if (nrhs < 5) mexErrMsgIdAndTxt("twstft:args", "usage: (d, k_or_df, codeb, fs, Nint [, convention]) or (raw_int16, nchan, chan, k_or_df, codeb, fs, Nint [, convention])");
+    const bool raw_form = mxIsInt16(prhs[0]);
+    if (raw_form ? (nrhs != 7 && nrhs != 8) : (nrhs != 5 && nrhs != 6)) mexErrMsgIdAndTxt("twstft:args", "wrong number of inputs");
+    const int base = raw_form ? 3 : 1;                   // position of k_or_df
+    const double fs = mxGetScalar(prhs[base + 2]);
+    const int nint = (int)mxGetScalar(prhs[base + 3]);
+    const int conv = nrhs == base + 5 ? parse_convention(prhs[base + 4]) : TWX_CONV_GODUAL;
+    ensure_context(prhs[base + 1], fs, nint, conv);
     twx_info info;
     twx_get_info(g_ctx, &info);
-    const int64_t nwin = (int64_t)(mxGetNumberOfElements(prhs[0]) / (size_t)(info.n * 2 * nch));
-    const int nco = ch < 0 ? nch : 1;                    // chan = 0: all channels, results [window][channel]
-    std::vector<twx_result> res((size_t)(nwin > 0 ? nwin * nco : 1));
     twx_band band; std::vector<double> dfv;
-    const bool estimate = mxGetNumberOfElements(prhs[3]) == 2;
-    if (estimate) { band.k_lo = (int64_t)mxGetPr(prhs[3])[0] - 1; band.k_hi = (int64_t)mxGetPr(prhs[3])[1] - 1; }
-    else dfv.assign((size_t)(nwin > 0 ? nwin * nco : 1), mxGetScalar(prhs[3]));
-    int rc = twx_process_windows(g_ctx, raw, nwin, nch, ch, estimate ? &band : nullptr, estimate ? nullptr : dfv.data(), res.data());
-    if (rc) mexErrMsgIdAndTxt("twstft:process", "%s", twx_last_error(g_ctx));
-    double* o[8];
-    for (int i = 0; i < 8 && i < (nlhs > 0 ? nlhs : 1); ++i) { plhs[i] = mxCreateDoubleMatrix((mwSize)nco, (mwSize)nwin, mxREAL); o[i] = mxGetPr(plhs[i]); }
-    mxArray* xv = nullptr;
-    if (nlhs > 8) { xv = mxCreateDoubleMatrix((mwSize)nco, (mwSize)nwin, mxCOMPLEX); plhs[8] = xv; }
-    for (int64_t w = 0; w < nwin * nco; ++w) {          // column-major nco x nwin == the library's [window][channel] order
-        const twx_result& r = res[(size_t)w];
-        const double vals[8] = {(double)r.indice0 + 1.0, r.correction, r.SNRr, r.SNRi, r.df, r.puissance, r.puissancecode, r.puissancenoise};
-        for (int i = 0; i < 8 && i < (nlhs > 0 ? nlhs : 1); ++i) o[i][w] = vals[i];
+    if (raw_form) {
+        const int16_t* raw = (const int16_t*)mxGetData(prhs[0]);
+        const int nch = (int)mxGetScalar(prhs[1]);
+        const int ch = (int)mxGetScalar(prhs[2]) - 1;
+        if (nch < 1 || ch < -1 || ch >= nch) mexErrMsgIdAndTxt("twstft:args", "bad channel");
+        const int64_t nwin = (int64_t)(mxGetNumberOfElements(prhs[0]) / (size_t)(info.n * 2 * nch));
+        const size_t nco = ch < 0 ? (size_t)nch : 1;     // chan = 0: all channels, results [window][channel]
+        std::vector<twx_result> res((size_t)(nwin > 0 ? nwin * nco : 1));
+        const bool est = parse_band_or_df(prhs[3], (size_t)nwin * nco, &band, &dfv);
+        if (twx_process_windows(g_ctx, raw, nwin, nch, ch, est ? &band : nullptr, est ? nullptr : dfv.data(), res.data()))
+            mexErrMsgIdAndTxt("twstft:process", "%s", twx_last_error(g_ctx));
+        emit(nlhs, plhs, res, nco, (size_t)nwin, conv);
+    } else {
+        if (!mxIsDouble(prhs[0])) mexErrMsgIdAndTxt("twstft:args", "d must be a (complex) double vector or int16 raw samples");
+        const size_t ne = mxGetNumberOfElements(prhs[0]);
+        if (ne == 0 || ne % (size_t)info.n) mexErrMsgIdAndTxt("twstft:args", "length(d) must be a multiple of the code length (%lld)", (long long)info.n);
+        const int64_t nwin = (int64_t)(ne / (size_t)info.n);
+        std::vector<twx_result> res((size_t)nwin);
+        const bool est = parse_band_or_df(prhs[1], (size_t)nwin, &band, &dfv);
+        std::vector<double> zero;
+        int rc;
 #if MX_HAS_INTERLEAVED_COMPLEX
-        if (xv) { mxComplexDouble* c = mxGetComplexDoubles(xv); c[w].real = r.xval[0]; c[w].imag = r.xval[1]; }
-#else
-        if (xv) { mxGetPr(xv)[w] = r.xval[0]; mxGetPi(xv)[w] = r.xval[1]; }
+        if (mxIsComplex(prhs[0])) {
+            const double* c = (const double*)mxGetComplexDoubles(prhs[0]);
+            rc = twx_process_complex(g_ctx, c, c + 1, 2, nwin, est ? &band : nullptr, est ? nullptr : dfv.data(), res.data());
+        } else
 #endif
+        {
+            const double* re = mxGetPr(prhs[0]);
+            const double* im = mxIsComplex(prhs[0]) ? mxGetPi(prhs[0]) : nullptr;
+            if (!im) { zero.assign(ne, 0.0); im = zero.data(); }       // a real d is a complex d with zero imaginary part
+            rc = twx_process_complex(g_ctx, re, im, 1, nwin, est ? &band : nullptr, est ? nullptr : dfv.data(), res.data());
+        }
+        if (rc) mexErrMsgIdAndTxt("twstft:process", "%s", twx_last_error(g_ctx));
+        emit(nlhs, plhs, res, 1, (size_t)nwin, conv);
     }
 }
 #else

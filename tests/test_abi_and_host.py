@@ -104,12 +104,31 @@ def test_header_is_plain_c_and_client_links(tmp_path):
     assert exe.exists()
 
 
-def test_mex_gateway_type_checks():
-    """mex/twstft_processing_mex.cpp against a declarations-only mex.h (no MATLAB/Octave in the image)."""
+def test_mex_gateway_builds_against_the_functional_fake(tmp_path):
+    """mex/twstft_processing_mex.cpp + tests/cpu/mex_harness.cpp compile and link against tests/cpu/mex_fake/mex.h and the
+    library (no MATLAB/Octave in the image); without a GPU the gateway's create call fails with the library's message."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(root, "tests", "cpu", "mex_stub"),
-                    "-I" + os.path.join(root, "include"), os.path.join(root, "mex", "twstft_processing_mex.cpp")], check=True)
+    exe = build_mex_harness(root, tmp_path)
+    import torch
+    if torch.cuda.is_available():
+        return
+    np.zeros(40000 * 2, dtype=np.int16).tofile(tmp_path / "cap.bin")
+    np.zeros(10000, dtype=np.uint8).tofile(tmp_path / "chips.bin")
+    r = subprocess.run([str(exe), "complex", str(tmp_path / "cap.bin"), str(tmp_path / "chips.bin"), str(tmp_path / "out.bin"),
+                        "2", "1", "df", "0", "5e6", "1"], capture_output=True, text=True)
+    assert r.returncode == 3 and "twstft:create" in r.stderr and "no CPU fallback" in r.stderr
+
+
+def build_mex_harness(root, tmp_path):
+    import subprocess
+    libdir = os.path.join(root, "amaranth_twstft_amd")
+    exe = tmp_path / "mex_harness"
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(root, "tests", "cpu", "mex_fake"),
+                    "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpu", "mex_harness.cpp"),
+                    os.path.join(root, "mex", "twstft_processing_mex.cpp"), "-L" + libdir, "-ltwstft_hip",
+                    "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
+    return exe
 
 
 def test_acquisition_gate_formula():

@@ -252,11 +252,11 @@ def test_ranks_share_one_capture_and_match_single_rank(tmp_path, world, nwin):
     one = subprocess.run(base, capture_output=True, text=True, env=env, timeout=600)
     assert one.returncode == 0, one.stderr[-3000:]
     mat = tmp_path / "1670074501.mat"
-    ref_bytes = mat.read_bytes()
+    ref_bytes = mat.read_bytes()[128:]                                 # MAT-v5 header (128 B) carries the creation time
     mat.unlink()
     many = subprocess.run(base + ["--gpus", str(world), "--backend", "gloo"], capture_output=True, text=True, env=env, timeout=900)
     assert many.returncode == 0, many.stdout[-2000:] + many.stderr[-3000:]
-    assert mat.read_bytes() == ref_bytes                               # byte for byte
+    assert mat.read_bytes()[128:] == ref_bytes                          # every variable, byte for byte
     rows = lambda s: [l for l in s.splitlines() if l[:1].isdigit() and "\t" in l]
     assert rows(many.stdout) == rows(one.stdout) and len(rows(one.stdout)) == nwin
 
@@ -300,3 +300,114 @@ def test_single_slot_pipeline_matches_three_slots(tmp_path, monkeypatch):
     for got in (got_fil, got2_fil):
         for c in (0, 1):
             assert [(g.indice, g.xval, g.df) for g in got[c]] == [(g.indice, g.xval, g.df) for g in ref_fil[c]]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the reference's own signatures: processing(d,k) / processing(d,df) on the complex double column d
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nchips,bitlen", [(10000, 14), (100000, 17)])
+def test_processing_complex_signature(nchips, bitlen):
+    """twx_process_complex = processing(d,k) of godual_ranging.m:12 as the script calls it: d complex double, mean
+    removed by the caller (:80).  Same results as the oracle on the same d, and as the raw-int16 entry point."""
+    from tests.test_gpu_parity import _capture, _check
+    chips, raw = _capture(bitlen, 43 if bitlen == 14 else 9, nchips, 3, seed=55)
+    n = 2 * nchips
+    code = orc.make_code(chips, 2)
+    fcode = orc.make_fcode(code)
+    freq = orc.freq_axis(FS, n)
+    k = orc.band_godual(freq)
+    temps = np.arange(n) / FS
+    ds = []
+    for w in range(3):
+        d = orc.deinterleave(raw[w * n:(w + 1) * n], 2, 0)
+        ds.append(d - d.mean())
+    dcat = np.concatenate(ds)
+    with Correlator(chips, fs=FS, Nint=1) as cor:
+        got = cor.processing_complex(dcat, k=k)                       # three windows in one call (vector outputs)
+        got_df = cor.processing_complex(ds[1], df=1780.75)
+        raw_path = cor.process(raw, n_channels=2, channel=0, band=(int(k[0]), int(k[-1])))
+    for w in range(3):
+        o = orc.processing(ds[w], k, freq, temps, fcode, code, Nint=1, fs=FS)
+        _check(got[w], o)
+        assert got[w].indice == raw_path[w].indice and abs(abs(got[w].xval) - abs(raw_path[w].xval)) <= MAG_TOL * abs(got[w].xval)
+    o = orc.processing(ds[1], None, None, temps, fcode, code, Nint=1, fs=FS, df=1780.75)
+    _check(got_df[0], o)
+    # processing(d,df) in the claudio convention (fcode.*conj(ffty), claudio_aligned_code_ranging_separate.m:49-102), Octave var
+    fc = orc.make_fcode(code, "claudio")
+    with Correlator(chips, fs=FS, Nint=1, convention="claudio", var_ddof=1) as cor:
+        g = cor.processing_complex(ds[2], df=1780.75)[0]
+    oc = orc.processing_claudio(ds[2], 1780.75, temps, fc, code, Nint=1, ddof=1)
+    _check(g, oc)
+    # a caller that did NOT remove the mean gets the result of the un-centred d (the library does not touch it)
+    dm = orc.deinterleave(raw[:n], 2, 0)
+    with Correlator(chips, fs=FS, Nint=1, precision="f64") as c64:
+        g64 = c64.processing_complex(dm, df=1780.75)[0]
+    om = orc.processing(dm, None, None, temps, fcode, code, Nint=1, fs=FS, df=1780.75)
+    assert g64.indice == om["indice"] and abs(g64.puissance - om["puissance"]) <= 1e-9 * om["puissance"]
+    assert abs(g64.xval - om["xval"]) <= 1e-9 * abs(om["xval"])
+
+
+def _read_mex_outputs(path):
+    b = open(path, "rb").read()
+    cnt = int(np.frombuffer(b, np.int32, 1, 0)[0])
+    off, outs = 4, []
+    for _ in range(cnt):
+        m, n, cplx = (int(v) for v in np.frombuffer(b, np.int32, 3, off))
+        off += 12
+        re = np.frombuffer(b, np.float64, m * n, off); off += 8 * m * n
+        if cplx:
+            im = np.frombuffer(b, np.float64, m * n, off); off += 8 * m * n
+            re = re + 1j * im
+        outs.append(re.reshape(n, m).T)              # column-major m x n
+    return outs
+
+
+def test_mex_gateway_runs_and_matches_the_ctypes_path(tmp_path):
+    """mexFunction() itself, executed on the GPU box on top of the functional fake mex.h: the reference's two signatures
+    (processing(d,k) in the godual output order, processing(d,df) in the claudio order with complex d) and the raw-int16
+    form, against the same calls through ctypes."""
+    import subprocess
+    from tests.test_abi_and_host import build_mex_harness
+    from tests.test_gpu_parity import _capture
+    exe = build_mex_harness(ROOT, tmp_path)
+    nchips, n, nwin = 10000, 20000, 4
+    chips, raw = _capture(14, 43, nchips, nwin, seed=63)
+    raw.tofile(tmp_path / "cap.bin")
+    chips.tofile(tmp_path / "chips.bin")
+    band = band_godual(FS, n)
+    common = [str(tmp_path / "cap.bin"), str(tmp_path / "chips.bin"), str(tmp_path / "out.bin"), "2"]
+
+    def run(mode, chan, kdf, *conv):
+        r = subprocess.run([str(exe), mode, *common, str(chan), *kdf, "5e6", "1", *conv], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return _read_mex_outputs(tmp_path / "out.bin")
+
+    ds = []
+    for w in range(nwin):
+        d = orc.deinterleave(raw[w * n:(w + 1) * n], 2, 0)
+        ds.append(d - d.mean())
+    with Correlator(chips, fs=FS, Nint=1, var_ddof=1) as cor, Correlator(chips, fs=FS, Nint=1, var_ddof=1, convention="claudio") as cc:
+        ref_k = cor.processing_complex(np.concatenate(ds), k=band)
+        ref_cl = cc.processing_complex(np.concatenate(ds), df=1780.75)
+        ref_raw = cor.process(raw, n_channels=2, channel=ALL_CHANNELS, band=band)
+    # (A) processing(d,k): indice correction SNRr SNRi df puissance puissancecode puissancenoise xval, 1 x nwin each
+    o = run("complex", 1, [str(band[0] + 1), str(band[1] + 1)])
+    assert len(o) == 9 and all(x.shape == (1, nwin) for x in o)
+    for w, r in enumerate(ref_k):
+        got = [x[0, w] for x in o]
+        assert got[0] == r.indice + 1                                    # Octave 1-based
+        assert (got[1], got[2], got[3], got[4], got[5], got[6], got[7]) == (r.correction, r.SNRr, r.SNRi, r.df, r.puissance, r.puissancecode, r.puissancenoise)
+        assert got[8] == r.xval
+    # (A') processing(d,df), claudio: xval indice correction SNRr SNRi puissance puissancecode puissancenoise [df]
+    o = run("complex", 1, ["df", "1780.75"], "claudio")
+    for w, r in enumerate(ref_cl):
+        got = [x[0, w] for x in o]
+        assert got[0] == r.xval and got[1] == r.indice + 1 and got[2] == r.correction and got[5] == r.puissance and got[8] == 1780.75
+    oc = orc.processing_claudio(ds[0], 1780.75, np.arange(n) / FS, orc.make_fcode(orc.make_code(chips, 2), "claudio"), orc.make_code(chips, 2), Nint=1, ddof=1)
+    assert o[1][0, 0] == oc["indice"] + 1 and abs(abs(o[0][0, 0]) - abs(oc["xval"])) <= MAG_TOL * abs(oc["xval"])
+    # (B) raw int16, every channel from one upload: nchan x nwin
+    o = run("raw", 0, [str(band[0] + 1), str(band[1] + 1)])
+    assert all(x.shape == (2, nwin) for x in o)
+    for c in (0, 1):
+        for w, r in enumerate(ref_raw[c]):
+            assert o[0][c, w] == r.indice + 1 and o[8][c, w] == r.xval and o[4][c, w] == r.df
