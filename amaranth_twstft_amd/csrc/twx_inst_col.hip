@@ -1,5 +1,6 @@
 // Instantiates the column-pass kernels of ONE plan: compile with
 //   -DTWX_PLAN='Plan<625,25,25>' -DTWX_W=16 -DTWX_NT=448
+#include <stdlib.h>
 #include <type_traits>
 #include "twx_kernels.h"
 #include "twx_plans.h"
@@ -14,6 +15,14 @@ static_assert(P::max_tasks * W <= NT, "one task per thread per stage");
 
 template <typename T, int MODE, class In>
 int launch_fwd(In in, const ColFwdArgs<T>& a, unsigned nblk, hipStream_t s) {
+    // measured on MI355X (N1 = 625, gpurun_out/ab3): MIX 0.1245 -> 0.119 ms per 8 windows, SQUARE 0.117 -> 0.129: only MIX uses it
+    if constexpr (P::S == 2 && std::is_same<T, float>::value && NT >= 384 && MODE == COL_MIX) {
+        static const bool split = [] { const char* e = getenv("TWX_COLFWD3"); return !e || atoi(e) != 0; }();
+        if (split) {                         // component-wise exchange: three or four workgroups per CU (twx_kernels.h)
+            TWX_LAUNCH((k_col_fwd3<P, T, W, MODE, In, NT>), dim3(nblk), dim3(NT), s, in, a);
+            return (int)hipGetLastError();
+        }
+    }
     TWX_LAUNCH((k_col_fwd<P, T, W, MODE, In, NT>), dim3(nblk), dim3(NT), s, in, a);
     return (int)hipGetLastError();
 }
@@ -41,6 +50,13 @@ template <typename T> int fwd(int mode, int intype, const void* inptr, int aux, 
 }
 template <typename T> int inv(const void* args, unsigned nblk, hipStream_t s) {
     const ColInvArgs<T>& a = *reinterpret_cast<const ColInvArgs<T>*>(args);
+    if constexpr (PR::S == 2 && std::is_same<T, float>::value && NT >= 384) {
+        static const bool split = [] { const char* e = getenv("TWX_COLINV3"); return !e || atoi(e) != 0; }();
+        if (split) {                         // component-wise exchange: three workgroups per CU (twx_kernels.h)
+            TWX_LAUNCH((k_col_inv3<PR, T, W, NT>), dim3(nblk), dim3(NT), s, a);
+            return (int)hipGetLastError();
+        }
+    }
     TWX_LAUNCH((k_col_inv<PR, T, W, NT>), dim3(nblk), dim3(NT), s, a);
     return (int)hipGetLastError();
 }

@@ -34,6 +34,13 @@
 #define TWX_ABLF 0      // k_col_fwd: 1 no transform, 2 no loads, 3 no stores, 4 stores only, 5 loads only
 #endif
 
+#ifndef TWX_NT_A
+#define TWX_NT_A 1      // k_rowd: non-temporal loads of the column-pass output A (read exactly once)
+#endif
+#ifndef TWX_NT_BZ
+#define TWX_NT_BZ 1     // k_rowd<MID>: non-temporal stores of Bz (written once, read once by k_col_inv 1 GB later)
+#endif
+
 namespace twx {
 
 // ------------------------------------------------------------------------------------------
@@ -546,6 +553,105 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_col_fwd3: k_col_fwd for two-stage fp32 column plans with the stage exchange done one component at a time
+// (40 KB of LDS instead of 80, ~70 registers instead of 100: three to four workgroups per CU instead of two; see
+// k_col_inv3).  Same arithmetic, same order of operations on every value as k_col_fwd's two-stage path.
+// ------------------------------------------------------------------------------------------
+template <class P1, typename T, int W, int MODE, class In, int NT>
+__global__ __launch_bounds__(NT, 6) void k_col_fwd3(In in, ColFwdArgs<T> a) {
+    static_assert(P1::S == 2 && sizeof(T) == 4, "two-stage fp32 plans only");
+    using TL = Tile<P1, T, false, W, 0>;
+    using C = cpx<T>;
+    constexpr int L = P1::L, R0 = P1::radix(0), R1 = P1::radix(1);
+    __shared__ T lf[L * W];
+    __shared__ C s_wq[32];
+    static_assert(R1 <= 32, "output-twiddle table");
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = logical / a.ntiles, tile = logical % a.ntiles;
+    const int c0 = tile * W;
+    const int tid = threadIdx.x;
+    const int j = tid / W, c = tid % W;
+    const bool p0 = tid < TL::template tasks<0>(), p1 = tid < TL::template tasks<1>();
+    const unsigned mask = (1u << a.tshift) - 1u;
+    In win = in; win.advance((long long)b * a.in_win_stride);
+    T mx = 0, my = 0;
+    if (a.remove_mean) {
+        WinSums s = a.sums[b];
+        mx = (T)((double)s.sI / (double)a.n);
+        my = (T)((double)s.sQ / (double)a.n);
+    }
+    C v[R0];
+    if (p0) {
+        const unsigned lane_in = (unsigned)j * (unsigned)a.n2 + (unsigned)(c0 + c);
+        unsigned raw[In::has_raw ? R0 : 1];
+        if constexpr (In::has_raw) {
+            TWX_UNROLL
+            for (int r = 0; r < R0; ++r) raw[r] = win.load_raw((long long)(r * (L / R0)) * a.n2, lane_in);
+        }
+        C ejc = mk<T>(1, 0);
+        if (MODE == COL_MIX) ejc = cmul(a.e1[(long long)b * L + j], a.e2[(long long)b * a.n2 + c0 + c]);
+        TWX_UNROLL
+        for (int r = 0; r < R0; ++r) {
+            C x;
+            if constexpr (In::has_raw) x = In::template unpack<T>(raw[r]);
+            else x = win.template load2<T>((long long)(r * (L / R0)) * a.n2, lane_in);
+            x.x -= mx; x.y -= my;
+            if (MODE == COL_MIX) {
+                C e = (r == 0) ? ejc : cmul(a.e1[(long long)b * L + r * (L / R0)], ejc);
+                x = cmul(x, e);
+            } else if (MODE == COL_SQUARE) {
+                x = mk<T>(x.x * x.x - x.y * x.y, T(2) * x.x * x.y);
+            }
+            v[r] = x;
+        }
+        TL::template bfly<0>(v);
+        const int ob = TL::template out_base<0>(j);
+        TWX_UNROLL
+        for (int q = 0; q < R0; ++q) lf[TL::template out_idx<0>(ob, j, q) * W + c] = v[q].x;
+    }
+    constexpr int QS = L / R1;                                   // row step between a thread's outputs
+    if (tid < R1) {                                              // wave-uniform parts W_N^{q QS c0} of the output twiddle
+        const unsigned mq = (unsigned)(tid * QS) * (unsigned)c0;
+        s_wq[tid] = cmul(a.ta[mq >> a.tshift], a.tb[mq & mask]);
+    }
+    __syncthreads();
+    C u[R1];
+    const int ib = TL::template in_base<1>(j);
+    if (p1) {
+        TWX_UNROLL
+        for (int r = 0; r < R1; ++r) u[r].x = lf[TL::template in_idx<1>(ib, j, r) * W + c];
+    }
+    __syncthreads();
+    if (p0) {
+        const int ob = TL::template out_base<0>(j);
+        TWX_UNROLL
+        for (int q = 0; q < R0; ++q) lf[TL::template out_idx<0>(ob, j, q) * W + c] = v[q].y;
+    }
+    __syncthreads();
+    if (p1) {
+        TWX_UNROLL
+        for (int r = 0; r < R1; ++r) u[r].y = lf[TL::template in_idx<1>(ib, j, r) * W + c];
+        // stage twiddles W_L^{j r} with the per-thread part W_N^{j c0} of the output twiddle folded in (the butterfly is linear)
+        const unsigned mj = (unsigned)j * (unsigned)c0;
+        const C wj0 = cmul(a.ta[mj >> a.tshift], a.tb[mj & mask]);
+        u[0] = cmul(u[0], wj0);
+        TWX_UNROLL
+        for (int r = 1; r < R1; ++r) u[r] = cmul(u[r], cmul(a.tw1[j * r], wj0));
+        TL::template bfly<1>(u);
+        // W_N^{k1 n2}, k1 = j + q*QS, n2 = c0 + c: remaining factors W_N^{q QS c0} (LDS) and W_N^{k1 c} (one coalesced 8-B load)
+        char* out = reinterpret_cast<char*>(a.out + (long long)b * a.n + (long long)tile * (L * W));
+        const unsigned lane_out = ((unsigned)TL::template out_pos<1>(j, 0) * W + c) * (unsigned)sizeof(C);
+        const char* tcb = reinterpret_cast<const char*>(a.tc);
+        constexpr unsigned ostride = QS * W * sizeof(C);
+        TWX_UNROLL
+        for (int q = 0; q < R1; ++q) u[q] = cmul3(u[q], s_wq[q], ld_su<C>(tcb + (q * QS * W * (int)sizeof(C)), lane_out));
+        __builtin_amdgcn_sched_barrier(0);                       // all table loads before the first store (shared vmcnt)
+        TWX_UNROLL
+        for (int q = 0; q < R1; ++q) st_su<C>(out + q * ostride, lane_out, u[q]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_row: second pass of the forward transform with a fused epilogue
 // ------------------------------------------------------------------------------------------
 enum { ROW_STORE = 0, ROW_BAND = 1, ROW_MID = 2 };
@@ -852,7 +958,10 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     {
         const int tl = min(tid, M - 1);
         TWX_UNROLL
-        for (int r = 0; r < R0; ++r) v[r] = Ab[a_index((unsigned)(tl + r * M), (unsigned)k1, (unsigned)a.n1, a.wshift)];
+        for (int r = 0; r < R0; ++r) {
+            const C* q = Ab + a_index((unsigned)(tl + r * M), (unsigned)k1, (unsigned)a.n1, a.wshift);
+            v[r] = TWX_NT_A ? __builtin_nontemporal_load(q) : *q;                   // A is read exactly once
+        }
     }
     if constexpr (MODE == ROW_MID) {
         const C* cs = ad.cspec_perm + (long long)k1 * N2;
@@ -931,7 +1040,10 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                 const C uu = cmul(ub, r1);
                 C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
                 TWX_UNROLL
-                for (int c = 0; c < R0; ++c) (out + c * M)[(unsigned)lt] = cmul3(v[c], uu, s_vc[c]);   // · W_N^{-k1 q2} · ramp1
+                for (int c = 0; c < R0; ++c) {
+                    const C o = cmul3(v[c], uu, s_vc[c]);                                  // · W_N^{-k1 q2} · ramp1
+                    if (TWX_NT_BZ) __builtin_nontemporal_store(o, out + c * M + (unsigned)lt); else (out + c * M)[(unsigned)lt] = o;
+                }
             }
             if (rho + 1 < a.nphase && lact) {
                 const int rn = rho + 1;
@@ -1320,6 +1432,98 @@ __global__ __launch_bounds__(NT) void k_col_inv(ColInvArgs<T> a) {
     }
     __syncthreads();   // LDS reads finished before it is reused as reduction scratch
     best = block_best<T, NT>(best, lds);
+    if (tid == 0) {
+        ArgPart<T> p; p.val = best.val; p.idx = best.idx;
+        a.part[(long long)b * (a.ntiles * a.nphase) + rho * a.ntiles + tile] = p;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_col_inv3: k_col_inv for two-stage column plans in fp32 with THREE workgroups resident per CU.
+// The column passes are latency-bound, not bandwidth-bound: a workgroup loads its tile, waits, transforms, reduces —
+// strictly in that order — and with the 80-KB tile exchange only two of them fit a CU, so HBM idles while both
+// compute (tools/bw_probe: the same read pattern alone sustains 5.9 TB/s, 6.6 with non-temporal loads, the kernel
+// 3.7).  Here the stage-0 -> stage-1 exchange goes through LDS one COMPONENT at a time (real parts, then imaginary
+// parts: the registers holding the written half are free before the other half is read, so the register peak stays
+// at one tile column per thread), which halves the LDS footprint to L*W*4 bytes (40 KB), and the last-stage
+// twiddles are fetched after the exchange instead of being parked in 48 registers, so that 3 x 7 waves fit.
+// Bz is read exactly once: non-temporal loads.   grid = ntiles * R * windows
+// ------------------------------------------------------------------------------------------
+template <class P1R, typename T, int W, int NT>
+__global__ __launch_bounds__(NT, 6) void k_col_inv3(ColInvArgs<T> a) {
+    static_assert(P1R::S == 2 && sizeof(T) == 4, "two-stage fp32 plans only");
+    using TL = Tile<P1R, T, true, W, 0>;
+    using C = cpx<T>;
+    constexpr int L = P1R::L, R0 = P1R::radix(0), R1 = P1R::radix(1);
+    __shared__ T lf[L * W];
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = logical % a.ntiles;
+    const int rho = (logical / a.ntiles) % a.nphase;
+    const int b = logical / (a.ntiles * a.nphase);
+    const int c0 = tile * W, tid = threadIdx.x;
+    const int j = tid / W, c = tid % W;
+    const bool p0 = tid < TL::template tasks<0>(), p1 = tid < TL::template tasks<1>();
+    const C* src = a.Bz + ((long long)b * a.nphase + rho) * a.n;
+    C v[R0];
+    if (p0) {
+        const unsigned int loff = ((unsigned int)j * (unsigned int)a.n2 + (unsigned int)(c0 + c)) * (unsigned int)sizeof(C);
+        const char* cbase = reinterpret_cast<const char*>(src);
+        const unsigned long long rstride = (unsigned long long)(L / R0) * (unsigned long long)a.n2 * sizeof(C);
+        TWX_UNROLL
+        for (int r = 0; r < R0; ++r) v[r] = (TWX_ABLC == 2) ? mk<T>((T)(tid + r), (T)(r - tid)) : __builtin_nontemporal_load(reinterpret_cast<const C*>(cbase + r * rstride + loff));
+        if (TWX_ABLC == 1) {                 // timing-only build: loads, no arithmetic, no exchange
+            TWX_UNROLL
+            for (int r = 0; r < R0; ++r) asm volatile("" ::"v"(v[r]));
+            return;
+        }
+        TL::template bfly<0>(v);
+        const int ob = TL::template out_base<0>(j);
+        TWX_UNROLL
+        for (int q = 0; q < R0; ++q) lf[TL::template out_idx<0>(ob, j, q) * W + c] = v[q].x;
+    }
+    __syncthreads();
+    C u[R1];
+    const int ib = TL::template in_base<1>(j);
+    if (p1) {
+        TWX_UNROLL
+        for (int r = 0; r < R1; ++r) u[r].x = lf[TL::template in_idx<1>(ib, j, r) * W + c];
+    }
+    __syncthreads();
+    if (p0) {
+        const int ob = TL::template out_base<0>(j);
+        TWX_UNROLL
+        for (int q = 0; q < R0; ++q) lf[TL::template out_idx<0>(ob, j, q) * W + c] = v[q].y;
+    }
+    __syncthreads();
+    Best<T> best; best.val = T(-1); best.idx = 0xffffffffu;
+    if (p1) {
+        TWX_UNROLL
+        for (int r = 0; r < R1; ++r) u[r].y = lf[TL::template in_idx<1>(ib, j, r) * W + c];
+        constexpr int step = L / (P1R::ns(1) * R1);             // == 1 for a two-stage plan; jm == j
+        TWX_UNROLL
+        for (int r = 1; r < R1; ++r) u[r] = cmulc(u[r], a.tw1[j * r * step]);
+        TL::template bfly<1>(u);
+        const unsigned int mbase = (unsigned int)(c0 + c) * (unsigned int)a.nphase + (unsigned int)rho;
+        const unsigned int mstep = (unsigned int)a.n2 * (unsigned int)a.nphase;
+        T nv[R1];
+        T bv = T(-1);
+        TWX_UNROLL
+        for (int q = 0; q < R1; ++q) { nv[q] = cnorm(u[q]); bv = nv[q] > bv ? nv[q] : bv; }
+        int bq = 0;
+        TWX_UNROLL
+        for (int q = R1 - 1; q >= 0; --q) bq = (nv[q] == bv) ? q : bq;
+        best.val = bv;
+        best.idx = (unsigned int)(j + bq * (L / R1)) * mstep + mbase;
+        if (a.zout) {       // test/inspection path only (twx_xcorr_map)
+            TWX_UNROLL
+            for (int q = 0; q < R1; ++q) {
+                const unsigned int m = (unsigned int)TL::template out_pos<1>(j, q) * mstep + mbase;
+                a.zout[(long long)b * a.n * a.nphase + m] = u[q];
+            }
+        }
+    }
+    __syncthreads();
+    best = block_best<T, NT>(best, lf);
     if (tid == 0) {
         ArgPart<T> p; p.val = best.val; p.idx = best.idx;
         a.part[(long long)b * (a.ntiles * a.nphase) + rho * a.ntiles + tile] = p;
