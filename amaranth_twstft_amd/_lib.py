@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TWX_LIB") or os.path.join(_HERE, "libtwstft_hip.so")   # TWX_LIB: kernel-variant experiments
 
 TWX_OK = 0
+TWX_E_SIZE = -2
 TWX_CONV_GODUAL, TWX_CONV_CLAUDIO = 0, 1
 TWX_WIN_NONE, TWX_WIN_HAMMING = 0, 1
 TWX_F32, TWX_F64 = 0, 1
@@ -69,6 +70,9 @@ SYMBOLS = {
     "twx_abi_version": (C.c_int, []),
     "twx_strerror": (C.c_char_p, [C.c_int]),
     "twx_last_error": (C.c_char_p, [_VP]),
+    "twx_load_plan": (C.c_int, [C.c_char_p]),
+    "twx_plan_available": (C.c_int, [C.c_int64, C.c_int32]),
+    "twx_plan_lengths": (C.c_int, [C.c_int32, C.c_int32, _VP, _VP, C.c_int32]),
     "twx_create": (C.c_int, [C.POINTER(twx_config), C.POINTER(_VP)]),
     "twx_destroy": (None, [_VP]),
     "twx_get_info": (C.c_int, [_VP, C.POINTER(twx_info)]),

@@ -131,7 +131,13 @@ class Correlator:
                 raise ValueError("chips_q needs chips of the same length")
             cfg.chips_q = self._chips_q.ctypes.data_as(C.POINTER(C.c_uint8))
         h = C.c_void_p()
-        L.check(self._lib.twx_create(C.byref(cfg), C.byref(h)))
+        rc = self._lib.twx_create(C.byref(cfg), C.byref(h))
+        if rc == L.TWX_E_SIZE:
+            # a window length the library has no plan pair for: build and load plan plug-ins (hipcc), then retry
+            from . import plans
+            plans.ensure(int(cfg.n_chips) * int(sps), int(cfg.precision), self._lib)
+            rc = self._lib.twx_create(C.byref(cfg), C.byref(h))
+        L.check(rc)
         self._h = h
         info = L.twx_info()
         L.check(self._lib.twx_get_info(self._h, C.byref(info)), self._h)

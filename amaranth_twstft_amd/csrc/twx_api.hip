@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <future>
 #include <unistd.h>
+#include <dlfcn.h>
+#include <dirent.h>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -50,8 +52,9 @@ bool choose_split(long long n, int f64, const ColOps** col, const RowOps** row) 
         if (forced && r.L != forced) continue;
         const long long n1 = n / r.L;
         if (n1 > 100000) continue;
-        const ColOps* c = find_col((int)n1, f64);
-        if (!c || r.L % c->W) continue;
+        const ColOps* c = nullptr;                        // widest column tile of that length whose width divides the row
+        for (auto& o : col_reg()) if (o.L == (int)n1 && o.f64 == f64 && r.L % o.W == 0 && (!c || o.W > c->W)) c = &o;
+        if (!c) continue;
         auto rank = [](int L) { return L == 4000 ? (1 << 30) : L; };
         if (!br || rank(r.L) > rank(br->L)) { br = &r; bc = c; }
     }
@@ -61,6 +64,44 @@ bool choose_split(long long n, int f64, const ColOps** col, const RowOps** row) 
 }
 
 static thread_local std::string g_create_err;
+
+// ------------------------------------------------------------------------------------------
+// plan plug-ins: shared objects built from twx_inst_col.hip / twx_inst_row.hip for one more transform length
+// (amaranth_twstft_amd/plans.py); loading one runs its static registration (register_col / register_row above)
+// ------------------------------------------------------------------------------------------
+static std::vector<std::string>& loaded_plugins() { static std::vector<std::string> v; return v; }
+static int load_plan_file(const std::string& path) {
+    for (auto& p : loaded_plugins()) if (p == path) return 0;
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { g_create_err = std::string("cannot load plan ") + path + ": " + dlerror(); return -1; }
+    loaded_plugins().push_back(path);
+    return 0;
+}
+static std::string default_plan_dir() {
+    if (const char* e = getenv("TWX_PLAN_DIR")) return e;
+    Dl_info info;
+    if (dladdr((const void*)&load_plan_file, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        const size_t k = p.rfind('/');
+        return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/plans";
+    }
+    return "plans";
+}
+static int scan_plan_dir() {                      // loads every *.so of the plan directory not loaded yet; returns how many
+    const std::string dir = default_plan_dir();
+    DIR* d = opendir(dir.c_str());
+    if (!d) return 0;
+    int n = 0;
+    while (dirent* e = readdir(d)) {
+        const std::string name = e->d_name;
+        if (name.size() > 3 && name.compare(name.size() - 3, 3, ".so") == 0) {
+            const size_t before = loaded_plugins().size();
+            if (load_plan_file(dir + "/" + name) == 0 && loaded_plugins().size() > before) ++n;
+        }
+    }
+    closedir(d);
+    return n;
+}
 
 #define HIPCHK(call)                                                                        \
     do {                                                                                    \
@@ -1188,8 +1229,11 @@ int twx_create(const twx_config* cfg, twx_ctx** out) {
     const ColOps* col; const RowOps* row;
     const int f64 = cfg->precision == TWX_F64;
     if (!choose_split(N, f64, &col, &row)) {
-        char b[200]; snprintf(b, sizeof b, "no compiled plan pair N1*N2 = %lld (see DESIGN.md §plans)", N);
-        g_create_err = b; return TWX_E_SIZE;
+        // plan plug-ins built earlier for other lengths (python -m amaranth_twstft_amd.plans N) live beside the library
+        if (scan_plan_dir() == 0 || !choose_split(N, f64, &col, &row)) {
+            char b[256]; snprintf(b, sizeof b, "no plan pair N1*N2 = %lld is built in or found in %s: build one with `python -m amaranth_twstft_amd.plans %lld` (DESIGN.md §plans)", N, default_plan_dir().c_str(), N);
+            g_create_err = b; return TWX_E_SIZE;
+        }
     }
     if ((col->W & (col->W - 1)) != 0) { g_create_err = "column tile width must be a power of two (tile-blocked A layout)"; return TWX_E_SIZE; }
     CtxBase* c = f64 ? static_cast<CtxBase*>(new Ctx<double>()) : static_cast<CtxBase*>(new Ctx<float>());
@@ -1208,6 +1252,25 @@ void twx_destroy(twx_ctx* ctx) {
     (void)ctx->impl->sync_all();
     delete ctx->impl;
     delete ctx;
+}
+
+int twx_load_plan(const char* path) {
+    if (!path) return TWX_E_ARG;
+    try { return load_plan_file(path) ? TWX_E_ARG : TWX_OK; } catch (...) { return TWX_E_STATE; }
+}
+int twx_plan_available(int64_t n, int32_t precision) {
+    const ColOps* c; const RowOps* r;
+    try {
+        if (choose_split(n, precision == TWX_F64, &c, &r)) return 1;
+        scan_plan_dir();
+        return choose_split(n, precision == TWX_F64, &c, &r) ? 1 : 0;
+    } catch (...) { return 0; }
+}
+int twx_plan_lengths(int32_t kind, int32_t precision, int32_t* lengths, int32_t* widths, int32_t max_entries) {
+    int n = 0;
+    if (kind == 0) { for (auto& o : col_reg()) if (o.f64 == (precision == TWX_F64)) { if (n < max_entries) { if (lengths) lengths[n] = o.L; if (widths) widths[n] = o.W; } ++n; } }
+    else { for (auto& o : row_reg()) if (o.f64 == (precision == TWX_F64)) { if (n < max_entries) { if (lengths) lengths[n] = o.L; if (widths) widths[n] = 0; } ++n; } }
+    return n;
 }
 
 int twx_get_info(const twx_ctx* ctx, twx_info* info) {

@@ -1,0 +1,227 @@
+"""Plan plug-ins: FFT pass kernels for transform lengths the library was not built with.
+
+The reference correlates against whatever code file it finds (``code=fread(f,inf,'int8')``,
+processing/Octave/godual_ranging.m:62-66), so the window length N = n_chips*sps is arbitrary.  The library does a
+length-N transform as N1 x N2 (column pass x row pass) with kernels instantiated at COMPILE time per
+length; it ships the pairs the reference's own code files need.  For any other N = 2^a 3^b 5^c this module
+
+* picks a split N = N1*N2 and stage radices that fit the kernels' budgets (one butterfly task per thread, <= 1024
+  threads, the exchange buffers in LDS, radices <= 25 so that a butterfly stays in registers),
+* compiles csrc/twx_inst_col.hip / csrc/twx_inst_row.hip for them with hipcc (seconds per file) into
+  ``amaranth_twstft_amd/plans/*.so``,
+* and hands them to the library (``twx_load_plan``); the library also picks up that directory by itself at the next
+  ``twx_create`` (C / MEX hosts need no Python at run time).
+
+    python -m amaranth_twstft_amd.plans 5000 25000        # build what these window lengths need
+
+``Correlator`` calls :func:`ensure` on its own when the library reports TWX_E_SIZE.
+"""
+from __future__ import annotations
+
+import itertools
+import os
+import shutil
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+PLAN_DIR = os.environ.get("TWX_PLAN_DIR") or os.path.join(_HERE, "plans")
+HIPCC = os.environ.get("HIPCC") or "/opt/rocm/bin/hipcc"
+MAX_RADIX = 25
+MAX_THREADS = 1024
+LDS_BUDGET = 80 * 1024            # bytes per workgroup that still leave room for a second one on the CU
+
+
+def _smooth(n: int) -> bool:
+    for p in (2, 3, 5):
+        while n % p == 0:
+            n //= p
+    return n == 1
+
+
+def _radix_ok(r: int) -> bool:
+    return 2 <= r <= MAX_RADIX and _smooth(r)
+
+
+def stage_radices(L: int, max_stages: int = 4):
+    """All ways to write L as a product of 1..max_stages radices (each 2^a 3^b 5^c <= 25), best first:
+    fewer stages, then the largest minimum radix (fewest tasks per stage)."""
+    cands = [r for r in range(2, MAX_RADIX + 1) if _radix_ok(r) and L % r == 0]
+    out = []
+    for s in range(1, max_stages + 1):
+        for combo in itertools.combinations_with_replacement(cands, s):
+            p = 1
+            for r in combo:
+                p *= r
+            if p == L:
+                out.append(tuple(sorted(combo)))
+    return sorted(set(out), key=lambda c: (len(c), -min(c), max(c)))
+
+
+def row_plan(L: int):
+    """Stage order and thread count of a row plan of length L, or None.  Preferred: the DIF/DIT form
+    [R0 *] R * R (RowD, csrc/twx_fft.h: one workgroup barrier per transform instead of one per stage)."""
+    if L % 2 or L < 4:
+        return None
+    best = None
+    for combo in stage_radices(L, 4):
+        if len(combo) < 2:
+            continue
+        rowd = False
+        order = combo
+        if len(combo) == 2 and combo[0] == combo[1] and combo[0] <= 64:
+            rowd = True
+        elif len(combo) == 3:
+            for r in set(combo):                   # two equal radices R, the third one is R0
+                rest = list(combo)
+                rest.remove(r)
+                if r in rest:
+                    rest.remove(r)
+                    order = (rest[0], r, r)
+                    rowd = True
+                    break
+        tasks = L // min(order)
+        if tasks > MAX_THREADS:
+            continue
+        padq = order[0]
+        lds = (L + L // padq) * 8 * 2             # fp64 contexts use the same plan: budget for complex double
+        if lds > 2 * LDS_BUDGET:
+            continue
+        nt = max(64, -(-tasks // 64) * 64)
+        key = (not rowd, len(order), -min(order))
+        if best is None or key < best[0]:
+            best = (key, dict(L=L, radices=order, nt=nt, padq=padq, rowd=rowd))
+    return best[1] if best else None
+
+
+def col_plan(L: int, row_len: int):
+    """Column plan of length L for rows of length ``row_len``: widest tile W in (16, 8, 4, 2, 1) that divides the row
+    and keeps tasks*W <= 1024 threads and the exchange in LDS; two-stage plans preferred (their fp32 kernels exchange
+    one component at a time: half the LDS)."""
+    for W in (16, 8, 4, 2, 1):
+        if row_len % W:
+            continue
+        for combo in stage_radices(L, 4):
+            # stage order: largest radix first keeps the first (global -> register) stage wide
+            order = tuple(sorted(combo, reverse=True))
+            tasks = (L // min(order)) * W
+            if tasks > MAX_THREADS:
+                continue
+            lds = L * W * 16 if len(order) > 1 else 0             # complex double
+            if lds > 2 * LDS_BUDGET:
+                continue
+            nt = max(64, -(-tasks // 64) * 64)
+            return dict(L=L, radices=order, W=W, nt=nt)
+    return None
+
+
+def choose(n: int):
+    """(column plan, row plan) for a window of n samples, or None."""
+    if n < 4 or n % 2 or not _smooth(n):
+        return None
+    best = None
+    for n2 in range(4, min(n, 10000) + 1, 2):
+        if n % n2:
+            continue
+        n1 = n // n2
+        if n1 > 4096:
+            continue
+        rp = row_plan(n2)
+        if rp is None:
+            continue
+        cp = col_plan(n1, n2) if n1 > 1 else None
+        if cp is None:
+            continue
+        # widest tile first (HBM pieces of 128 B), column workgroups of at least a wave, the DIF/DIT row form, few stages,
+        # long rows (fewer, fatter workgroups)
+        underfilled = (cp["L"] // min(cp["radices"])) * cp["W"] < 64
+        key = (-cp["W"], underfilled, not rp["rowd"], len(rp["radices"]) + len(cp["radices"]), -n2)
+        if best is None or key < best[0]:
+            best = (key, cp, rp)
+    return (best[1], best[2]) if best else None
+
+
+def _plan_macro(L, radices):
+    return "Plan<%d,%s>" % (L, ",".join(str(r) for r in radices))
+
+
+def _compile(src, out, defs):
+    os.makedirs(PLAN_DIR, exist_ok=True)
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        raise RuntimeError(f"{HIPCC} not found: plan plug-ins are compiled with hipcc (set HIPCC=...)")
+    tmp = out + ".tmp%d" % os.getpid()
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function",
+           os.path.join(CSRC, src), "-o", tmp, "-L" + _HERE, "-ltwstft_hip", "-Wl,-rpath,$ORIGIN/.."] + defs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError("plan build failed:\n" + " ".join(cmd) + "\n" + r.stderr[-3000:])
+    os.replace(tmp, out)
+    return out
+
+
+def build_col(cp) -> str:
+    out = os.path.join(PLAN_DIR, "col_%d_w%d.so" % (cp["L"], cp["W"]))
+    if not os.path.exists(out):
+        _compile("twx_inst_col.hip", out, ["-DTWX_PLAN=" + _plan_macro(cp["L"], cp["radices"]), "-DTWX_W=%d" % cp["W"], "-DTWX_NT=%d" % cp["nt"]])
+    return out
+
+
+def build_row(rp) -> str:
+    out = os.path.join(PLAN_DIR, "row_%d.so" % rp["L"])
+    if not os.path.exists(out):
+        _compile("twx_inst_row.hip", out, ["-DTWX_PLAN=" + _plan_macro(rp["L"], rp["radices"]), "-DTWX_NT=%d" % rp["nt"], "-DTWX_PADQ=%d" % rp["padq"]])
+    return out
+
+
+def ensure(n: int, precision: int = 0, lib=None, verbose: bool = False):
+    """Make a plan pair for a window of ``n`` samples available to the library; returns the plug-in files it loaded
+    ([] when the library already had one).  Raises ValueError for lengths outside 2^a 3^b 5^c or the kernels' budgets."""
+    from . import _lib as L
+    lib = lib or L.load()
+    if lib.twx_plan_available(int(n), int(precision)):
+        return []
+    ch = choose(int(n))
+    if ch is None:
+        raise ValueError(f"no N1 x N2 plan for a window of {n} samples (needs n even, = 2^a 3^b 5^c, N2 <= 10000, N1 <= 4096)")
+    cp, rp = ch
+    # reuse what the library already has (built-in or loaded) for either half
+    import ctypes as C
+    have = {}
+    for kind in (0, 1):
+        cnt = lib.twx_plan_lengths(kind, precision, None, None, 0)
+        ls, ws = (C.c_int32 * max(cnt, 1))(), (C.c_int32 * max(cnt, 1))()
+        lib.twx_plan_lengths(kind, precision, ls, ws, cnt)
+        have[kind] = {(ls[i], ws[i]) for i in range(cnt)}
+    files = []
+    if (cp["L"], cp["W"]) not in have[0]:
+        if verbose:
+            print("building column plan", cp, file=sys.stderr)
+        files.append(build_col(cp))
+    if (rp["L"], 0) not in have[1]:
+        if verbose:
+            print("building row plan", rp, file=sys.stderr)
+        files.append(build_row(rp))
+    for f in files:
+        if lib.twx_load_plan(os.fsencode(f)) != 0:
+            raise RuntimeError("twx_load_plan failed: " + (lib.twx_last_error(None) or b"").decode())
+    if not lib.twx_plan_available(int(n), int(precision)):
+        raise RuntimeError(f"plan plug-ins {files} loaded but no pair for n = {n} is usable")
+    return files
+
+
+def main(argv=None):
+    args = list(sys.argv[1:] if argv is None else argv)
+    if not args:
+        print(__doc__)
+        return 2
+    for a in args:
+        n = int(a)
+        ch = choose(n)
+        print(n, "->", ch)
+        print("   loaded:", ensure(n, verbose=True))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -105,6 +105,17 @@ const char* twx_strerror(int status);
 const char* twx_last_error(const twx_ctx* ctx);      /* ctx may be NULL: last create() error */
 int twx_abi_version(void);
 
+/* Transform lengths.  A window of N = n_chips*sps samples is transformed as N1 x N2 (column pass x row pass); the
+ * library is built with the pairs the reference's code lengths need and takes further lengths
+ * N = 2^a 3^b 5^c from plan plug-ins: shared objects compiled from the same kernel sources for one more length
+ * (`python -m amaranth_twstft_amd.plans N`, needs hipcc), loaded explicitly with twx_load_plan() or found by
+ * twx_create() in the directory `plans/` beside the library (TWX_PLAN_DIR overrides).  The reference reads any code
+ * file (godual_ranging.m:62-66); twx_create() answers TWX_E_SIZE only when no plan pair exists for the length.
+ * twx_plan_lengths: kind 0 = column plans (lengths[i], tile widths[i]), 1 = row plans; returns the count. */
+int twx_load_plan(const char* path);
+int twx_plan_available(int64_t n, int32_t precision);
+int twx_plan_lengths(int32_t kind, int32_t precision, int32_t* lengths, int32_t* widths, int32_t max_entries);
+
 /* Build plans/twiddles, upload or generate the code and compute conj(fft(code)) once
  * (godual_ranging.m:62-66; GoRanging::fill_fcode main.cpp:658-732). */
 int twx_create(const twx_config* cfg, twx_ctx** out);

@@ -149,3 +149,24 @@ def test_lowpass_taps_match_an_independent_windowed_sinc():
         assert h.size % 2 == 1 and h.size == int(53.0 * fs / (22.0 * tw)) | 1
         g = firwin(h.size, fc, window="hamming", fs=fs)
         assert np.abs(h - g).max() < 1e-7 and abs(h.sum() - 1.0) < 1e-6
+
+
+def test_plan_generator_covers_the_reference_code_lengths():
+    """amaranth_twstft_amd/plans.py: a split N1 x N2 with valid stage radices for every window length the reference's code files
+    give at 1, 2 and 4 samples per chip (experiments/221207_twoway_codes/codes/*, 231001_DLL_PLL/{0,1}.bin), the 1-ms
+    plumbing window and power-of-two acquisition transforms."""
+    from amaranth_twstft_amd import plans
+    lengths = [c * s for c in (2500, 5000, 10000, 25000, 50000, 100000, 250000, 500000, 2500000) for s in (1, 2, 4)] + [1 << 16, 1 << 20, 30000, 486000]
+    for n in lengths:
+        ch = plans.choose(n)
+        assert ch is not None, n
+        cp, rp = ch
+        assert cp["L"] * rp["L"] == n and rp["L"] % cp["W"] == 0
+        for pl in (cp, rp):
+            prod = 1
+            for r in pl["radices"]:
+                assert 2 <= r <= 25
+                prod *= r
+            assert prod == pl["L"]
+        assert (cp["L"] // min(cp["radices"])) * cp["W"] <= cp["nt"] <= 1024 and rp["L"] // min(rp["radices"]) <= rp["nt"] <= 1024
+    assert plans.choose(7000) is None and plans.choose(5001) is None        # a factor 7 / an odd length have no plan

@@ -411,3 +411,42 @@ def test_mex_gateway_runs_and_matches_the_ctypes_path(tmp_path):
     for c in (0, 1):
         for w, r in enumerate(ref_raw[c]):
             assert o[0][c, w] == r.indice + 1 and o[8][c, w] == r.xval and o[4][c, w] == r.df
+
+
+# --------------------------------------------------------------------------------------------------------------
+# window lengths outside the built-in plan list (plan plug-ins, amaranth_twstft_amd/plans.py)
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bitlen,taps,nchips,Nint", [(13, 27, 2500, 0), (13, 27, 2500, 1), (15, 3, 12500, 1), (16, 45, 32768, 1)])
+def test_plan_plugins_generic_lengths(bitlen, taps, nchips, Nint):
+    """BASELINE.json configs[0] (1-ms window: N = 5000, first 2500 chips of LFSR(13, 27); SURVEY §8d C1: delay 1234,
+    A = 300, sigma = 600, code-phase-only, Nint 0 and 1), an odd code length (N = 25000) and a power-of-two window
+    (N = 65536): none of them is in the built-in plan list, all run through plug-ins of the same kernels."""
+    from tests.test_gpu_parity import _check
+    from amaranth_twstft_amd import plans
+    chips = chips_for(bitlen, taps, nchips)
+    n = 2 * nchips
+    assert plans.choose(n) is not None
+    p = synth.SynthParams(delay_q8=1234 * 256, fstep=synth.fstep_for_df(0.0 if nchips == 2500 else 977.5, FS), phi0=0, amp=300,
+                          noise_gain=synth.noise_gain_for_sigma(600.0), seed=1)
+    raw = synth.synth_channel(3 * n, chips, 2, p)
+    code = orc.make_code(chips, 2)
+    fcode = orc.make_fcode(code)
+    freq = orc.freq_axis(FS, n)
+    k = orc.band_numpy(freq, 0.0, 8000.0)
+    temps = np.arange(n) / FS
+    with Correlator(chips, fs=FS, Nint=Nint) as cor:
+        assert cor.info.n == n and cor.info.n1 * cor.info.n2 == n
+        got = cor.process(raw, n_channels=1, channel=0, df=0.0) if nchips == 2500 else \
+            cor.process(raw, n_channels=1, channel=0, band=(int(k[0]), int(k[-1])))
+        spec = cor.code_spectrum()
+        x = (np.arange(n) % 7 - 3) + 1j * (np.arange(n) % 5 - 2)
+        f = cor.fft(x)
+    assert np.abs(spec - fcode).max() <= 2e-7 * np.abs(fcode).max()                 # computed in fp64 through the plug-in plans, held in fp32
+    ref = np.fft.fft(x)
+    assert np.abs(f - ref).max() <= 3e-6 * np.abs(ref).max()
+    for w in range(3):
+        d = orc.deinterleave(raw[w * n:(w + 1) * n], 1, 0)
+        d = d - d.mean()
+        o = orc.processing(d, k, freq, temps, fcode, code, Nint=Nint, fs=FS, df=0.0 if nchips == 2500 else None)
+        _check(got[w], o)
+        assert got[w].indice == (2 * Nint + 1) * 1234
