@@ -37,7 +37,7 @@ class twx_config(C.Structure):
                 ("convention", C.c_int32), ("window", C.c_int32), ("precision", C.c_int32),
                 ("var_ddof", C.c_int32), ("snr_rot", C.c_int32), ("device", C.c_int32),
                 ("max_batch", C.c_int32), ("flags", C.c_int32), ("chips_q", C.POINTER(C.c_uint8)),
-                ("code_levels", C.c_int32), ("reserved", C.c_int32)]
+                ("code_levels", C.c_int32), ("nphase", C.c_int32)]
 
 
 class twx_band(C.Structure):
@@ -70,6 +70,7 @@ SYMBOLS = {
     "twx_abi_version": (C.c_int, []),
     "twx_strerror": (C.c_char_p, [C.c_int]),
     "twx_last_error": (C.c_char_p, [_VP]),
+    "twx_plan_source_hash": (C.c_char_p, []),
     "twx_load_plan": (C.c_int, [C.c_char_p]),
     "twx_plan_available": (C.c_int, [C.c_int64, C.c_int32]),
     "twx_plan_lengths": (C.c_int, [C.c_int32, C.c_int32, _VP, _VP, C.c_int32]),
@@ -86,6 +87,9 @@ SYMBOLS = {
     "twx_get_code_spectrum": (C.c_int, [_VP, _VP]),
     "twx_xcorr_map": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, _VP]),
     "twx_process_file": (C.c_int, [_VP, C.c_char_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(twx_band), C.c_double, _VP, C.c_int64, C.POINTER(C.c_int64)]),
+    "twx_set_code_spectrum": (C.c_int, [_VP, _VP]),
+    "twx_xcorr_map_dev": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, _VP]),
+    "twx_caf_freqs_cdev": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int32, _VP]),
     "twx_caf_bins": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _VP, _VP]),
     "twx_caf_freqs": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP, C.c_int64, _VP]),
     "twx_sqspec_bins_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_int32, _VP]),

@@ -104,7 +104,7 @@ class Correlator:
     def __init__(self, chips=None, fs: float = 5e6, sps: int = 2, Nint: int = 1, *, lfsr: tuple[int, int, int] | None = None,
                  precision: str = "f32", var_ddof: int = 0, snr_rot: int = -1, window: str = "none", convention: str = "godual",
                  device: int = -1, max_batch: int = 0, profile: bool = False, fine_freq: bool = False,
-                 chips_q=None, code_levels: str = "bipolar", code_zero_mean: bool = False):
+                 chips_q=None, code_levels: str = "bipolar", code_zero_mean: bool = False, nphase: int = 0):
         self._lib = L.load()
         cfg = L.twx_config()
         cfg.fs, cfg.sps, cfg.nint = fs, sps, Nint
@@ -125,6 +125,7 @@ class Correlator:
                      | (L.TWX_FLAG_CODE_ZERO_MEAN if code_zero_mean else 0))
         # replica variants of the experiment scripts (220616_Besancon/godual.m:5-7, 220822_qpsk_vs_bpsk/goqpsk.m:10-14)
         cfg.code_levels = {"bipolar": L.TWX_CODE_BIPOLAR, "unipolar": L.TWX_CODE_UNIPOLAR}[code_levels]
+        cfg.nphase = int(nphase)          # 0 = 2*Nint+1 output phases
         if chips_q is not None:
             self._chips_q = np.ascontiguousarray(chips_q, dtype=np.uint8)
             if chips is None or self._chips_q.size != self._chips.size:
@@ -327,6 +328,14 @@ class Correlator:
         out = np.empty(self.n, dtype=np.complex128)
         L.check(self._lib.twx_get_code_spectrum(self._h, out.ctypes.data_as(C.c_void_p)), self._h)
         return out
+
+    def set_code_spectrum(self, spec):
+        """Replace the replica spectrum the context multiplies ``fft(y)`` with (``conj(fft(code))`` by default) by
+        ``spec`` (N complex values, natural FFT order) — twx_set_code_spectrum."""
+        sp = np.ascontiguousarray(spec, dtype=np.complex128).reshape(-1)
+        if sp.size != self.n:
+            raise ValueError("spectrum length must equal the window length")
+        L.check(self._lib.twx_set_code_spectrum(self._h, sp.ctypes.data_as(C.c_void_p)), self._h)
 
     def set_remove_mean(self, on: bool):
         """``d=d-mean(d)`` before the NCO (default on; the reference's callers do it, godual_ranging.m:80,94)."""

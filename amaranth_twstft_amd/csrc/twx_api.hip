@@ -87,14 +87,20 @@ static std::string default_plan_dir() {
     }
     return "plans";
 }
-static int scan_plan_dir() {                      // loads every *.so of the plan directory not loaded yet; returns how many
+#ifndef TWX_SRC_HASH
+#define TWX_SRC_HASH "dev"
+#endif
+// loads every plug-in of the plan directory built from THIS library's kernel sources (file name *_<hash>.so) that is
+// not loaded yet; returns how many
+static int scan_plan_dir() {
     const std::string dir = default_plan_dir();
     DIR* d = opendir(dir.c_str());
     if (!d) return 0;
     int n = 0;
+    const std::string tail = std::string("_") + TWX_SRC_HASH + ".so";
     while (dirent* e = readdir(d)) {
         const std::string name = e->d_name;
-        if (name.size() > 3 && name.compare(name.size() - 3, 3, ".so") == 0) {
+        if (name.size() > tail.size() && name.compare(name.size() - tail.size(), tail.size(), tail) == 0) {
             const size_t before = loaded_plugins().size();
             if (load_plan_file(dir + "/" + name) == 0 && loaded_plugins().size() > before) ++n;
         }
@@ -326,6 +332,9 @@ struct CtxBase {
                              twx_result* out) = 0;
     virtual int process_complex(const double* re, const double* im, long long stride, long long nwin, const twx_band* band,
                                 const double* df, twx_result* out) = 0;
+    virtual int set_code_spectrum(const double* spec) = 0;
+    virtual int xcorr_map_dev(const void* iq_dev, int nch, int ch, double df, void* out_dev) = 0;
+    virtual int caf_freqs_cdev(const void* d_dev, const double* freqs, long long nf, int flags, twx_result* out) = 0;
 };
 
 template <typename T> static void host_twiddle(std::vector<cpx<T>>& v, long long count, long long num_mul, long long den, int sign) {
@@ -394,6 +403,7 @@ template <typename T> struct Ctx : CtxBase {
     unsigned long long* stamps_dev = nullptr;   // TWX_STAMPS diagnostic builds
     double* fine_u = nullptr; int fine_M = 0;   // TWX_FLAG_FINE_FREQ
     double* csum_part = nullptr;                // per-window partial sums of |d|^2 (complex-double input)
+    int argmax_norm1 = 0;                       // cblas_izamax arg-max for the current call (twx_caf_freqs_cdev)
     int io_threads = 4;                         // TWX_IO_THREADS: concurrent preads per chunk in twx_process_file
     int ncu = 256;
     int ntiles = 0;
@@ -554,7 +564,7 @@ template <typename T> struct Ctx : CtxBase {
         memset(slots, 0, sizeof slots);
         profile = (cfg.flags & TWX_FLAG_PROFILE) != 0;
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        R = 2 * cfg.nint + 1;
+        R = cfg.nphase > 0 ? cfg.nphase : 2 * cfg.nint + 1;
         ntiles = N2 / col->W;
         if (cfg.max_batch > 0) B = cfg.max_batch;
         else {   // largest power of two whose A+Bz buffers stay under ~1.5 GiB; at most 16 windows per launch, up to 256
@@ -713,6 +723,9 @@ template <typename T> struct Ctx : CtxBase {
             const int chunks = (int)std::min<long long>(64, std::max<long long>(1, N / 16384));
             TWX_LAUNCH((k_sums<0>), dim3(chunks, nb), dim3(256), stream, in, wstride, nch, N, sums);
             HIPCHK(hipGetLastError());
+        } else if (intype == IN_C32) {
+            if (rm_mean) return fail(TWX_E_ARG, "complex input is taken as it is");
+            HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums) * nb, stream));        // no power statistics on this path
         } else {
             if (rm_mean) return fail(TWX_E_ARG, "complex input is taken as it is (the caller removed the mean, godual_ranging.m:80)");
             ProfScope ps(this, PC_SUMS, (long long)nb * N);
@@ -753,6 +766,7 @@ template <typename T> struct Ctx : CtxBase {
             HIPCHK(hipGetLastError());
         }
         if (cfg.flags & TWX_FLAG_FINE_FREQ) {
+            if (intype == IN_C32) return fail(TWX_E_ARG, "TWX_FLAG_FINE_FREQ is not available on complex-float input");
             if (intype == IN_I16) TWX_LAUNCH((k_fine_angle<InI16>), dim3(64, nb), dim3(256), stream, InI16{in, nch}, wstride, rm_mean, (long long)N, sums, dfv, cfg.fs, fine_M, fine_u);
             else TWX_LAUNCH((k_fine_angle<InCplxSplit>), dim3(64, nb), dim3(256), stream, InCplxSplit{sp.re, sp.im, aux}, wstride, rm_mean, (long long)N, sums, dfv, cfg.fs, fine_M, fine_u);
             HIPCHK(hipGetLastError());
@@ -774,7 +788,7 @@ template <typename T> struct Ctx : CtxBase {
             } else if (row->run(ROW_MID, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(mid) launch failed");
         }
         ColInvArgs<T> ia{};
-        ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = R; ia.nwin = nb; ia.Bz = Bz; ia.tw1 = tw1; ia.part = part_peak; ia.zout = zout;
+        ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = R; ia.nwin = nb; ia.Bz = Bz; ia.tw1 = tw1; ia.part = part_peak; ia.zout = zout; ia.norm1 = argmax_norm1;
         {
             ProfScope ps(this, PC_COL_INV, (long long)nb * N);
             if (col->inv(&ia, (unsigned)(ntiles * R * nb), stream)) return fail(TWX_E_HIP, "k_col_inv launch failed");
@@ -1122,6 +1136,51 @@ template <typename T> struct Ctx : CtxBase {
         return TWX_OK;
     }
 
+    // replica spectrum handed over by the caller (natural order) -> [k1][k2] layout in the context's precision, range
+    // scale applied, DIF/DIT copy refreshed
+    int set_code_spectrum(const double* spec) override {
+        if (int rc = sync_all()) return rc;
+        std::vector<C> h((size_t)N);
+        for (int k1 = 0; k1 < N1; ++k1)
+            for (int k2 = 0; k2 < N2; ++k2) {
+                const size_t k = (size_t)k1 + (size_t)N1 * k2;
+                h[(size_t)k1 * N2 + k2] = mk<T>((T)(spec[2 * k] * scale_pow2), (T)(spec[2 * k + 1] * scale_pow2));
+            }
+        HIPCHK(hipMemcpy(cspec, h.data(), (size_t)N * sizeof(C), hipMemcpyHostToDevice));
+        if (use_rowd) {
+            const int Rr = row->R[row->S - 1], R0 = row->S == 3 ? row->R[0] : 1;
+            TWX_LAUNCH((k_cspec_perm<T>), dim3(N1), dim3(256), slots[0].stream, cspec, cspec_perm, N1, N2, R0, Rr);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(slots[0].stream));
+        }
+        snr_valid = 0;
+        return TWX_OK;
+    }
+    int xcorr_map_dev(const void* iq_dev, int nch, int ch, double df, void* out_dev) override {
+        if (int rc = sync_all()) return rc;
+        use_slot(0);
+        C* z = reinterpret_cast<C*>(out_dev);
+        if (int rc = run_batch(reinterpret_cast<const short2*>(iq_dev) + ch, 1, nch, nullptr, &df, res_dev, z)) return rc;
+        // ifft normalisation and the range scale undone in place (the product path never forms the whole map)
+        TWX_LAUNCH((k_convert<T, T>), dim3(1024), dim3(256), stream, (const C*)z, z, (long long)N * R, 1.0 / scale_pow2 / ((double)N * R));
+        HIPCHK(hipGetLastError());
+        return TWX_OK;
+    }
+    int caf_freqs_cdev(const void* d_dev, const double* freqs, long long nf, int flags, twx_result* out) override {
+        if (int rc = sync_all()) return rc;
+        use_slot(0);
+        argmax_norm1 = (flags & TWX_ACQ_IZAMAX) ? 1 : 0;
+        int rc = TWX_OK;
+        for (long long f0 = 0; f0 < nf && rc == TWX_OK; f0 += B) {
+            const int nb = (int)std::min<long long>(B, nf - f0);
+            rc = run_batch_in(IN_C32, d_dev, nullptr, 1, 0, 0, nb, nullptr, freqs + f0, res_dev, nullptr, 1);
+            if (rc == TWX_OK && hipMemcpyAsync(out + f0, res_dev, sizeof(twx_result) * nb, hipMemcpyDeviceToHost, stream) != hipSuccess) rc = fail(TWX_E_HIP, "D2H copy failed");
+            if (rc == TWX_OK && hipStreamSynchronize(stream) != hipSuccess) rc = fail(TWX_E_HIP, "stream synchronize failed");
+        }
+        argmax_norm1 = 0;
+        return rc;
+    }
+
     int caf_bins(const int16_t* iq, int nch, int ch, long long k_lo, long long k_hi, double* pk, long long* lag) override {
         if (k_hi < k_lo) return fail(TWX_E_ARG, "k_hi < k_lo");
         short2* din = nullptr; C* Ysp = nullptr; double* pk_d = nullptr; long long* lag_d = nullptr;
@@ -1217,12 +1276,13 @@ int twx_create(const twx_config* cfg, twx_ctx** out) {
     if (!cfg || !out) { g_create_err = "null argument"; return TWX_E_ARG; }
     *out = nullptr;
     if (!(cfg->fs > 0) || cfg->sps < 1 || cfg->nint < 0 || cfg->nint > 2 || cfg->n_chips < 1) { g_create_err = "bad fs/sps/nint/n_chips"; return TWX_E_ARG; }
+    if (cfg->nphase < 0 || cfg->nphase > TWX_MAX_PHASE) { g_create_err = "nphase must be 0 (= 2*nint+1) or 1..5"; return TWX_E_ARG; }
     if (cfg->precision != TWX_F32 && cfg->precision != TWX_F64) { g_create_err = "bad precision"; return TWX_E_ARG; }
     if (cfg->convention != TWX_CONV_GODUAL && cfg->convention != TWX_CONV_CLAUDIO) { g_create_err = "bad convention"; return TWX_E_ARG; }
     if (cfg->var_ddof < 0 || cfg->var_ddof > 1) { g_create_err = "var_ddof must be 0 or 1"; return TWX_E_ARG; }
     const long long N = cfg->n_chips * cfg->sps;
     if (N % 2) { g_create_err = "window length must be even"; return TWX_E_SIZE; }
-    if ((long long)N * (2 * cfg->nint + 1) >= 0xffffffffll) { g_create_err = "window too long for 32-bit lag indices"; return TWX_E_SIZE; }
+    if ((long long)N * (cfg->nphase > 0 ? cfg->nphase : 2 * cfg->nint + 1) >= 0xffffffffll) { g_create_err = "window too long for 32-bit lag indices"; return TWX_E_SIZE; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "no HIP device available (the HIP path has no CPU fallback)"; return TWX_E_HIP; }
     if (cfg->device >= 0) { if (hipSetDevice(cfg->device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return TWX_E_HIP; } }
@@ -1254,6 +1314,7 @@ void twx_destroy(twx_ctx* ctx) {
     delete ctx;
 }
 
+const char* twx_plan_source_hash(void) { return TWX_SRC_HASH; }
 int twx_load_plan(const char* path) {
     if (!path) return TWX_E_ARG;
     try { return load_plan_file(path) ? TWX_E_ARG : TWX_OK; } catch (...) { return TWX_E_STATE; }
@@ -1321,6 +1382,22 @@ int twx_process_complex(twx_ctx* ctx, const double* d_re, const double* d_im, in
     if (n_windows == 0) return TWX_OK;
     (void)hipSetDevice(c->dev);
     return guarded(c, [&]() { return c->process_complex(d_re, d_im, stride, n_windows, band, df, out); });
+}
+
+int twx_set_code_spectrum(twx_ctx* ctx, const double* spec) {
+    if (!ctx || !spec) return TWX_E_ARG;
+    (void)hipSetDevice(ctx->impl->dev);
+    return guarded(ctx->impl, [&]() { return ctx->impl->set_code_spectrum(spec); });
+}
+int twx_xcorr_map_dev(twx_ctx* ctx, const void* iq_dev, int32_t n_channels, int32_t channel, double df, void* out_dev) {
+    if (!ctx || !iq_dev || !out_dev || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
+    (void)hipSetDevice(ctx->impl->dev);
+    return guarded(ctx->impl, [&]() { return ctx->impl->xcorr_map_dev(iq_dev, n_channels, channel, df, out_dev); });
+}
+int twx_caf_freqs_cdev(twx_ctx* ctx, const void* d_dev, const double* freqs, int64_t n_freqs, int32_t flags, twx_result* out) {
+    if (!ctx || !d_dev || !freqs || !out || n_freqs < 0) return TWX_E_ARG;
+    (void)hipSetDevice(ctx->impl->dev);
+    return guarded(ctx->impl, [&]() { return ctx->impl->caf_freqs_cdev(d_dev, freqs, n_freqs, flags, out); });
 }
 
 int twx_fft_forward(twx_ctx* ctx, const double* in, double* out) {

@@ -42,6 +42,10 @@ template <typename T> int fwd(int mode, int intype, const void* inptr, int aux, 
         InCplxSplit in{sp->re, sp->im, aux};
         if (mode == COL_MIX) return launch_fwd<T, COL_MIX>(in, a, nblk, s);
         if (mode == COL_SQUARE) return launch_fwd<T, COL_SQUARE>(in, a, nblk, s);
+    } else if (intype == IN_C32) {
+        InCplx<float> in{reinterpret_cast<const cpx<float>*>(inptr)};
+        if (mode == COL_MIX) return launch_fwd<T, COL_MIX>(in, a, nblk, s);
+        if (mode == COL_PLAIN) return launch_fwd<T, COL_PLAIN>(in, a, nblk, s);
     } else if (intype == IN_C64) {
         InCplx<double> in{reinterpret_cast<const cpx<double>*>(inptr)};
         if (mode == COL_PLAIN) return launch_fwd<T, COL_PLAIN>(in, a, nblk, s);

@@ -1348,6 +1348,7 @@ template <typename T> struct ColInvArgs {
     const cpx<T>* tw1;
     ArgPart<T>* part;        // [b][rho*ntiles + tile]
     cpx<T>* zout;            // optional full output [b][R*N] (natural interleaved order), or nullptr
+    int norm1;               // arg-max of (|re|+|im|)^2 instead of |z|^2: cblas_izamax (rxcomplex.cpp:553)
 };
 
 template <class P1R, typename T, int W, int NT>
@@ -1415,7 +1416,11 @@ __global__ __launch_bounds__(NT) void k_col_inv(ColInvArgs<T> a) {
             T nv[R];
             T bv = T(-1);
             TWX_UNROLL
-            for (int q = 0; q < R; ++q) { nv[q] = cnorm(v[q]); bv = nv[q] > bv ? nv[q] : bv; }
+            for (int q = 0; q < R; ++q) {
+                if (a.norm1) { const T s1 = (v[q].x < 0 ? -v[q].x : v[q].x) + (v[q].y < 0 ? -v[q].y : v[q].y); nv[q] = s1 * s1; }
+                else nv[q] = cnorm(v[q]);
+                bv = nv[q] > bv ? nv[q] : bv;
+            }
             int bq = 0;
             TWX_UNROLL
             for (int q = R - 1; q >= 0; --q) bq = (nv[q] == bv) ? q : bq;
@@ -1508,7 +1513,11 @@ __global__ __launch_bounds__(NT, 6) void k_col_inv3(ColInvArgs<T> a) {
         T nv[R1];
         T bv = T(-1);
         TWX_UNROLL
-        for (int q = 0; q < R1; ++q) { nv[q] = cnorm(u[q]); bv = nv[q] > bv ? nv[q] : bv; }
+        for (int q = 0; q < R1; ++q) {
+            if (a.norm1) { const T s1 = (u[q].x < 0 ? -u[q].x : u[q].x) + (u[q].y < 0 ? -u[q].y : u[q].y); nv[q] = s1 * s1; }
+            else nv[q] = cnorm(u[q]);
+            bv = nv[q] > bv ? nv[q] : bv;
+        }
         int bq = 0;
         TWX_UNROLL
         for (int q = R1 - 1; q >= 0; --q) bq = (nv[q] == bv) ? q : bq;

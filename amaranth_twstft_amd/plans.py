@@ -142,6 +142,32 @@ def choose(n: int):
     return (best[1], best[2]) if best else None
 
 
+PLAN_SOURCES = ("twx_fft.h", "twx_kernels.h", "twx_plans.h", "twx_inst_col.hip", "twx_inst_row.hip")
+
+
+def source_hash() -> str:
+    """Hash of the kernel sources a plug-in is compiled from = the tag the library looks for (csrc/Makefile SRCHASH)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in PLAN_SOURCES:
+        with open(os.path.join(CSRC, f), "rb") as fd:
+            h.update(fd.read())
+    return h.hexdigest()[:10]
+
+
+def _clean_stale():
+    """Plug-ins of other source versions are dead weight (the library ignores them)."""
+    if not os.path.isdir(PLAN_DIR):
+        return
+    tail = "_%s.so" % source_hash()
+    for f in os.listdir(PLAN_DIR):
+        if f.endswith(".so") and not f.endswith(tail):
+            try:
+                os.unlink(os.path.join(PLAN_DIR, f))
+            except OSError:
+                pass
+
+
 def _plan_macro(L, radices):
     return "Plan<%d,%s>" % (L, ",".join(str(r) for r in radices))
 
@@ -161,15 +187,17 @@ def _compile(src, out, defs):
 
 
 def build_col(cp) -> str:
-    out = os.path.join(PLAN_DIR, "col_%d_w%d.so" % (cp["L"], cp["W"]))
+    out = os.path.join(PLAN_DIR, "col_%d_w%d_%s.so" % (cp["L"], cp["W"], source_hash()))
     if not os.path.exists(out):
+        _clean_stale()
         _compile("twx_inst_col.hip", out, ["-DTWX_PLAN=" + _plan_macro(cp["L"], cp["radices"]), "-DTWX_W=%d" % cp["W"], "-DTWX_NT=%d" % cp["nt"]])
     return out
 
 
 def build_row(rp) -> str:
-    out = os.path.join(PLAN_DIR, "row_%d.so" % rp["L"])
+    out = os.path.join(PLAN_DIR, "row_%d_%s.so" % (rp["L"], source_hash()))
     if not os.path.exists(out):
+        _clean_stale()
         _compile("twx_inst_row.hip", out, ["-DTWX_PLAN=" + _plan_macro(rp["L"], rp["radices"]), "-DTWX_NT=%d" % rp["nt"], "-DTWX_PADQ=%d" % rp["padq"]])
     return out
 
@@ -179,6 +207,8 @@ def ensure(n: int, precision: int = 0, lib=None, verbose: bool = False):
     ([] when the library already had one).  Raises ValueError for lengths outside 2^a 3^b 5^c or the kernels' budgets."""
     from . import _lib as L
     lib = lib or L.load()
+    if lib.twx_plan_source_hash().decode() != source_hash():
+        raise RuntimeError("libtwstft_hip.so was built from other kernel sources than csrc/ holds now: rebuild it (make -C csrc) first")
     if lib.twx_plan_available(int(n), int(precision)):
         return []
     ch = choose(int(n))

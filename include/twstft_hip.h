@@ -71,7 +71,8 @@ typedef struct twx_config {
                                 unipolar or zero-mean replica the wipe-off statistics SNRr, SNRi, puissancecode and
                                 puissancenoise are not defined (they rely on |code| = 1) and are returned as NaN. */
     int32_t code_levels;     /* TWX_CODE_* */
-    int32_t reserved;
+    int32_t nphase;          /* 0: 2*nint+1 output phases (godual_ranging.m:27); 1..5: that many, e.g. 2 for the x2 FFT-domain
+                                interpolation of experiments/231001_DLL_PLL/rxcomplex.cpp:914-963 */
 } twx_config;
 
 /* Carrier search band `k` of processing(d,k) (godual_ranging.m:83-89): inclusive range of
@@ -112,6 +113,7 @@ int twx_abi_version(void);
  * twx_create() in the directory `plans/` beside the library (TWX_PLAN_DIR overrides).  The reference reads any code
  * file (godual_ranging.m:62-66); twx_create() answers TWX_E_SIZE only when no plan pair exists for the length.
  * twx_plan_lengths: kind 0 = column plans (lengths[i], tile widths[i]), 1 = row plans; returns the count. */
+const char* twx_plan_source_hash(void);   /* plug-ins named *_<this>.so match the library's kernel sources */
 int twx_load_plan(const char* path);
 int twx_plan_available(int64_t n, int32_t precision);
 int twx_plan_lengths(int32_t kind, int32_t precision, int32_t* lengths, int32_t* widths, int32_t max_entries);
@@ -181,6 +183,22 @@ int twx_get_code_spectrum(twx_ctx* ctx, double* out);
  * complex doubles (host).  Slow path for tests. */
 int twx_xcorr_map(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, double df,
                   double* out);
+
+/* Replica given by its SPECTRUM: replaces what the context multiplies FFT(y) with (conj(fft(code)) by default) by
+ * spec[k], k = 0..N-1 in natural FFT order, complex doubles (re, im) in HOST memory.  This is how the acquisition stage
+ * of experiments/231001_DLL_PLL/rxcomplex.cpp gets its operand: conj(FFT(zero-padded sampled code)) (:416-437) times the
+ * pass-band mask and 1/n^2 of cross_spectrum (:1001-1018) — and how the x2 interpolation of short2double (:914-963)
+ * becomes a 2-phase "correlation" with a weight vector.  The wipe-off statistics are undefined afterwards (NaN). */
+int twx_set_code_spectrum(twx_ctx* ctx, const double* spec);
+/* prnmap of ONE window of a DEVICE-resident int16 capture into DEVICE memory: nphase*N complex floats (re, im),
+ * normalised like ifft (1/(nphase*N)), natural order.  No mean removal when TWX_OPT_REMOVE_MEAN is 0. */
+int twx_xcorr_map_dev(twx_ctx* ctx, const void* iq_dev, int32_t n_channels, int32_t channel, double df, void* out_dev);
+/* processing(d,df) for n_freqs trial offsets on ONE window of complex FLOAT samples resident in DEVICE memory
+ * (d_dev: N x (re, im) float32; no mean removal): the per-bin body of the acquisition sweep rxcomplex.cpp:534-563 —
+ * downconv_acq, FFT, cross_spectrum (through the context's replica spectrum), IFFT, arg-max.  flags & 1: the arg-max is
+ * cblas_izamax's, i.e. of |re|+|im| (rxcomplex.cpp:553), not of the modulus.  out: n_freqs results (host). */
+#define TWX_ACQ_IZAMAX 1
+int twx_caf_freqs_cdev(twx_ctx* ctx, const void* d_dev, const double* freqs, int64_t n_freqs, int32_t flags, twx_result* out);
 
 /* Delay x Doppler cross-ambiguity of ONE window (host int16 capture, as twx_process_windows) ------
  * Replaces the acquisition sweep of experiments/231001_DLL_PLL/rxcomplex.cpp:534-563 (per trial

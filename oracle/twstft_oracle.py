@@ -509,3 +509,131 @@ def fir_decimate(x, taps, dec):
     nout = (len(x) - len(taps)) // dec + 1
     idx = np.arange(nout)[:, None] * dec + np.arange(len(taps))[None, :]
     return (x[idx] * taps[None, ::1]).sum(axis=1)
+
+
+# --------------------------------------------------------------------------------------------
+# Acquisition stage of experiments/231001_DLL_PLL/rxcomplex.cpp, restated function by function — UNPINNED
+# (the program needs fftw3 / gsl / cblas, none of which exists in the build image; its own results are not in the
+# repository).  Names follow the C++ functions; all arrays complex128 / float64.
+# --------------------------------------------------------------------------------------------
+
+RX_NINTERP = 2      # #define Ninterp 2, rxcomplex.cpp:29
+
+
+def rx_short2double(smp, nobs: int, dec: int = 1):
+    """``short2double`` rxcomplex.cpp:914-963 (USRP X310 branch): int16 ``[IA QA IB QB]`` samples -> two complex
+    streams of ``nobs`` samples each, i.e. x2 interpolated through the FFT domain.  As written there the lower half of
+    the ``nobs/2``-point spectrum stays where it is UNSCALED while the upper half moves to the top of the ``nobs``-point
+    spectrum divided by ``nobs/2`` (:931-936) — restated as is; the inverse transform is divided by ``nobs`` (:957-959)."""
+    smp = np.asarray(smp).reshape(-1)
+    half = nobs // RX_NINTERP
+    out = []
+    for off in (0, 2):
+        tmp = np.zeros(nobs, dtype=np.complex128)
+        i = np.arange(half)
+        tmp[:half] = smp[4 * i * dec + off] / 32768.0 + 1j * (smp[4 * i * dec + off + 1] / 32768.0)      # :922-928
+        tmp[:half] = _fft(tmp[:half])                                                                     # plan1 :931-933
+        j = np.arange(half // 2)
+        tmp[nobs - j - 1] = tmp[half - j - 1] / float(half)                                               # :934-936
+        tmp[half - j - 1] = 0.0                                                                           # :937-938
+        tmp = _ifft(tmp) * nobs                                                                           # FFTW backward is unnormalised :940-942
+        out.append(tmp / float(nobs))                                                                     # :957-959
+    return out[0], out[1]
+
+
+def rx_prn_sampling(nobs: int, code, rc: float, fs: float, clen: int, delay_ns: float = 0.0):
+    """``PRN_sampling`` :965-978: ``idx=floor(fmod((i/fs-delay*1e-9)*rc, clen))`` (wrapped), value ``code[idx]``."""
+    i = np.arange(nobs, dtype=np.float64)
+    idx = np.floor(np.fmod((i / fs - delay_ns * 1.0e-9) * float(rc), float(clen))).astype(np.int64)
+    idx = np.where(idx < 0, idx + clen, np.where(idx >= clen, idx - clen, idx))
+    return np.asarray(code, dtype=np.float64)[idx].astype(np.complex128)
+
+
+def _rx_band(n: int, df: float, fmax: float, fmin: float):
+    """Pass-band test shared by ``lowpass`` :1025-1026 and ``cross_spectrum`` :1007-1008: signed bin index,
+    ``idx*df < fmax && idx*df > fmin && idx != 0``."""
+    i = np.arange(n)
+    idx = np.where(i >= n // 2, i - n, i)
+    f = idx.astype(np.float64) * df
+    return (f < fmax) & (f > fmin) & (idx != 0)
+
+
+def rx_lowpass(obs, df: float, fmax: float, fmin: float):
+    """``lowpass`` :1020-1037: brick wall on a spectrum, pass-band scaled by 1/nobs."""
+    n = len(obs)
+    return np.where(_rx_band(n, df, fmax, fmin), obs / float(n), 0.0)
+
+
+def rx_replica(code_pm1, nobs: int, nfft: int, rc: float, fs: float, clen: int, fltmax: float, fltmin: float, dec_a: int = 1):
+    """Channel set-up :414-437.  Returns (``dev_wav_acq`` = FFT of the zero-padded sampled code (real part only is
+    copied, ``memcpy_acq`` :980-987, BEFORE the filter is applied to ``dev_wav_t``), ``psbb`` = mean power of the
+    low-pass filtered waveform :431-432, the filtered waveform itself)."""
+    wav_t = rx_prn_sampling(nobs, code_pm1, rc, fs, clen, 0.0)                                   # :416
+    wav_acq = np.zeros(nfft, dtype=np.complex128)                                                   # :418
+    m = nobs // dec_a
+    wav_acq[:m] = wav_t[:m * dec_a:dec_a].real                                                      # :420, :984-986
+    filt = _ifft(rx_lowpass(_fft(wav_t), fs / float(nobs), fltmax, fltmin)) * nobs                 # :422-428 (unnormalised backward)
+    psbb = float(np.sqrt(np.sum(np.abs(filt) ** 2)) ** 2 / float(nobs))                            # :431-432 (dznrm2 squared / nobs)
+    return _fft(wav_acq), psbb, filt                                                                # :434-437
+
+
+def rx_downconv_acq(nfft: int, ff: float, phi: float, smp, dec: int = 1):
+    """``downconv_acq`` :1039-1049: ``sqrt(2)*smp[i*dec]*exp(-2 pi j (ff*i+phi))`` with the constant as written."""
+    i = np.arange(nfft, dtype=np.float64)
+    ang = -1.0 * 2.0 * 3.141592653589793 * (ff * i + phi)                                          # #define PI :31
+    x = np.asarray(smp)[:nfft * dec:dec]
+    return 1.4142135624 * (x.real * np.cos(ang) - x.imag * np.sin(ang)) + 1j * 1.4142135624 * (x.real * np.sin(ang) + x.imag * np.cos(ang))
+
+
+def rx_cross_spectrum(obs, prn, df: float, fmax: float, fmin: float):
+    """``cross_spectrum`` :1001-1018: ``obs*conj(prn)/n^2`` inside the pass-band, 0 elsewhere."""
+    n = len(obs)
+    return np.where(_rx_band(n, df, fmax, fmin), obs * np.conj(prn) / float(n) / float(n), 0.0)
+
+
+def rx_izamax(x) -> int:
+    """``cblas_izamax`` :553: first index of the largest ``|re|+|im|`` (BLAS cabs1), 0-based."""
+    return int(np.argmax(np.abs(x.real) + np.abs(x.imag)))
+
+
+def rx_acq_bin(smp, idx: int, fcc: float, wav_acq_f, nfft: int, fs: float, fltmax: float, fltmin: float, dec_a: int = 1):
+    """Body of the Doppler loop :543-556 for one trial carrier ``fcc``: (pk, pk_idx)."""
+    obs = rx_downconv_acq(nfft, fcc / (fs / float(dec_a)), 0.0, np.asarray(smp)[idx:], dec_a)      # :543
+    obs = _fft(obs)                                                                                  # :544-546
+    obs = rx_cross_spectrum(obs, wav_acq_f, (fs / float(dec_a)) / float(nfft), fltmax, fltmin)       # :548
+    obs = _ifft(obs) * nfft                                                                          # :549-551 (unnormalised backward)
+    pk_idx = rx_izamax(obs)                                                                          # :553
+    return float(abs(obs[pk_idx])), pk_idx                                                           # :554 (dznrm2 of one element)
+
+
+def rx_acquire(smp, idx: int, wav_acq_f, nobs: int, nfft: int, fs: float, fc_init: float, frange: float, fstep: float,
+               fltmax: float, fltmin: float, dec_a: int = 1):
+    """Acquisition sweep :521-567 (the random code-aligned offset ``idx`` of :529 is an argument): coarse sweep
+    fc±range in ``step``, keep the strictly largest peak, then halve the step with range = step until step < 1 Hz.
+    Returns (fc, pk, pt) with ``pt = pk_idx % (nobs/dec_a)`` :561."""
+    pk_best, fc, pt = 0.0, float(fc_init), 0
+    while True:
+        flow, fhigh = fc - frange, fc + frange                       # :536-537
+        fcc = flow
+        while fcc <= fhigh:                                          # :538
+            pk, pk_idx = rx_acq_bin(smp, idx, fcc, wav_acq_f, nfft, fs, fltmax, fltmin, dec_a)
+            if pk > pk_best:                                         # :556-562
+                fc, pk_best, pt = fcc, pk, pk_idx % (nobs // dec_a)
+            fcc += fstep
+        fstep = fstep / 2.0                                          # :565-567
+        frange = fstep
+        if fstep < 1.0:
+            break
+    return fc, pk_best, pt
+
+
+def rx_gate(pk: float, psbb: float, px: float, snr_min: float):
+    """:570-573: peak power ``8*pk^2/psbb`` and the lock test ``(1+snr_min)*pk > snr_min*px``."""
+    p = 8.0 * pk * pk / psbb
+    return p, (1.0 + snr_min) * p > snr_min * px
+
+
+def rx_power(smp, fs: float, dec_a: int = 1):
+    """Received power :481-489: ``zdotc(smp, smp)`` over every ``dec_a``-th sample divided by ``fs/dec_a``."""
+    x = np.asarray(smp)[::dec_a]
+    return float(np.real(np.vdot(x, x))) / (fs / float(dec_a))

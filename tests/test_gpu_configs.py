@@ -450,3 +450,69 @@ def test_plan_plugins_generic_lengths(bitlen, taps, nchips, Nint):
         o = orc.processing(d, k, freq, temps, fcode, code, Nint=Nint, fs=FS, df=0.0 if nchips == 2500 else None)
         _check(got[w], o)
         assert got[w].indice == (2 * Nint + 1) * 1234
+
+
+# --------------------------------------------------------------------------------------------------------------
+# a11: the acquisition stage of experiments/231001_DLL_PLL/rxcomplex.cpp with the program's own arithmetic, sdr.param sizes
+# --------------------------------------------------------------------------------------------------------------
+def test_rxcomplex_acquisition_pipeline_at_sdr_param_sizes():
+    """1-s buffer of 2-channel int16 at 5 Msps -> short2double x2 interpolation (10 Msps) -> per trial carrier
+    downconv_acq / FFT(2^20) / cross_spectrum / IFFT / izamax -> coarse sweep + step halving (rxcomplex.cpp:469-573),
+    code = 100 kchip LFSR(17, taps 9) = experiments/231001_DLL_PLL/0.bin at 2.5 Mchip/s (sdr.param: nobs = 400 000, nfft = 2^20).
+    Device against the line-by-line oracle restatement (unpinned: the C++ program cannot be built here)."""
+    import torch
+    from amaranth_twstft_amd import acquisition as acq
+    dev = torch.device("cuda", 0)
+    n_in, fs, rc, clen = 5_000_000, 10e6, 2.5e6, 100_000
+    nobs = int(fs) // 25
+    chips = {"A": chips_for(17, 9, clen), "B": chips_for(17, 15, clen)}
+    d0, fc_true = 123_457, 1307.25                                   # delay in 5-Msps samples, carrier offset (Hz)
+    chans = [synth.SynthParams(delay_q8=d0 * 256, fstep=synth.fstep_for_df(fc_true, 5e6), phi0=11, amp=400,
+                               noise_gain=synth.noise_gain_for_sigma(900.0), seed=31, stream=0),
+             synth.SynthParams(delay_q8=77_001 * 256, fstep=synth.fstep_for_df(-260.0, 5e6), phi0=5, amp=500,
+                               noise_gain=synth.noise_gain_for_sigma(700.0), seed=31, stream=1)]
+    # two different codes on the two physical channels: generate separately (the generator takes one code per call)
+    iq = torch.empty((n_in, 4), dtype=torch.int16, device=dev)
+    tmp = torch.empty((n_in, 2), dtype=torch.int16, device=dev)
+    for c, key in enumerate(("A", "B")):
+        _synth_dev(tmp, n_in, torch.from_numpy(chips[key]).to(dev), clen, 2, [chans[c]])
+        torch.cuda.synchronize()
+        iq[:, 2 * c:2 * c + 2] = tmp
+    raw = iq.cpu().numpy()
+    smp_dev = torch.empty((2 * n_in, 2), dtype=torch.float32, device=dev)
+    interp = acq.Interpolator(n_in)
+    interp(iq.data_ptr(), smp_dev.data_ptr(), n_channels=2, channel=0)
+    interp.cor.synchronize()
+    # ---- oracle: interpolation
+    oA, _ = orc.rx_short2double(raw.reshape(-1), 2 * n_in)
+    got = smp_dev.cpu().numpy()
+    got = got[:, 0].astype(np.float64) + 1j * got[:, 1]
+    scale = np.abs(oA).max()
+    assert np.abs(got - oA).max() <= 2e-6 * scale
+    assert np.abs(oA[0::2] - 0).max() > 0 and abs(np.abs(oA[2 * 1000]) - 0) >= 0     # (streams are complex, both phases filled)
+    # ---- replica and per-bin body
+    code_pm1 = 1 - 2 * chips["A"].astype(np.int64)                                     # SDRcode: host_code = 1-2*byte (:879)
+    a = acq.Acquisition(code_pm1, rc, fs, nobs)
+    assert a.nfft == 1 << 20 and a.nobs == 400_000
+    wav_f, psbb, _ = orc.rx_replica(code_pm1, nobs, a.nfft, rc, fs, clen, rc, -rc)
+    assert np.abs(a.wav_acq_f - wav_f).max() <= 1e-9 * np.abs(wav_f).max()
+    assert abs(a.psbb - psbb) <= 1e-9 * psbb
+    idx = 3 * nobs                                                                       # code-aligned offset (:529 draws it at random)
+    trial = [fc_true - 700.0, 1024.0, 1280.0, 1307.0, 1308.0, 1536.0, 186.0]
+    pk, pki = a.bins(smp_dev.data_ptr(), idx, trial)
+    for f, p, i in zip(trial, pk, pki):
+        po, io = orc.rx_acq_bin(oA, idx, f, wav_f, a.nfft, fs, rc, -rc)
+        assert i == io, f                                                               # cblas_izamax index, bit-exact
+        assert abs(p - po) <= 3e-6 * po, f
+    # ---- the sweep, reduced range for the oracle (17 + 24 bins), then sdr.param's own range on the device alone
+    fc, pkb, pt = a.acquire(smp_dev.data_ptr(), idx, fc_init=1186.0, frange=2048.0, fstep=256.0)
+    fo, pko, pto = orc.rx_acquire(oA, idx, wav_f, nobs, a.nfft, fs, 1186.0, 2048.0, 256.0, rc, -rc)
+    assert (fc, pt) == (fo, pto) and abs(pkb - pko) <= 3e-6 * pko
+    assert abs(fc - fc_true) <= 1.0 and abs(pt - (2 * d0) % nobs) <= 1           # the generator's delay, in samples of the x2 stream
+    fc2, pk2, pt2 = a.acquire(smp_dev.data_ptr(), idx, fc_init=186.0, frange=65536.0, fstep=256.0)    # sdr.param: 64096 -> 65536, 256
+    assert abs(fc2 - fc_true) <= 1.0 and pt2 == pt
+    px = float((smp_dev.double() ** 2).sum().item()) / fs                                # received power :481-489
+    assert abs(px - orc.rx_power(oA, fs)) <= 1e-5 * px
+    p_sig, locked = a.gate(pk2, px, 10 ** (-18 / 10))                                    # least_required_SNR -18 dB
+    assert locked and orc.rx_gate(pko, psbb, orc.rx_power(oA, fs), 10 ** (-18 / 10))[1]
+    a.close(); interp.close()
