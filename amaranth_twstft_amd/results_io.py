@@ -97,3 +97,47 @@ def tracked_mat_dict(out: dict, code=None) -> dict:
 def save_tracked_mat(path: str, out: dict, code=None) -> None:
     from scipy.io import savemat
     savemat(path, tracked_mat_dict(out, code), do_compression=False)
+
+
+# --------------------------------------------------------------------------------------------
+# the C++ twin's container (processing/CPP/main.cpp:521-656) — what gofinal_ltfb.m:35-45 reads when the name has a "C"
+# --------------------------------------------------------------------------------------------
+
+def cpp_mat_name(capture_path: str, remote: int = 0) -> str:
+    """Output name of processing/CPP/main.cpp:786-798: directory kept, ``remote`` prefixed when remote=1, the
+    capture's ``.bin`` replaced by ``C.mat`` (``<capture>C.mat``)."""
+    import os
+    d, base = os.path.split(capture_path)
+    stem = base[:-4] if base.endswith(".bin") else base
+    return os.path.join(d, ("remote" if remote == 1 else "") + stem + "C.mat")
+
+
+def cpp_mat_dict(res1, res2=None) -> dict:
+    """Variable set of ``GoRanging::save`` (main.cpp:541-647), n x 1 column vectors: ``correction1`` already holds
+    ``indice+corr`` with the 0-based peak index (:310), ``SNR1`` = 10*log10(SNRr+SNRi) (:355), ``puissance1code`` in dB
+    (:343), ``df1``, ``puissance1`` (sum |y|^2 of the window, :287-295), complex ``xval1 xval1m1 xval1p1``; the same
+    with suffix 2 for the reference channel when it was processed."""
+    d = {}
+    col = lambda v, dt=np.float64: np.asarray(v, dtype=dt).reshape(-1, 1)
+    for suffix, res in (("1", res1), ("2", res2)):
+        if res is None:
+            continue
+        d["correction" + suffix] = col([r.indice + r.correction for r in res])
+        d["SNR" + suffix] = col([10 * np.log10(r.SNRr + r.SNRi) for r in res])
+        d["df" + suffix] = col([r.df for r in res])
+        d["puissance" + suffix] = col([r.puissance for r in res])
+        d[f"puissance{suffix}code"] = col([10 * np.log10(r.puissancecode) for r in res])
+        d["xval" + suffix] = col([r.xval for r in res], np.complex128)
+        d[f"xval{suffix}m1"] = col([r.xvalm1 for r in res], np.complex128)
+        d[f"xval{suffix}p1"] = col([r.xvalp1 for r in res], np.complex128)
+    return d
+
+
+def save_cpp_mat(capture_path: str, res1, res2=None, remote: int = 0) -> str:
+    """Write ``<capture>C.mat`` (MAT v5, uncompressed like MAT_COMPRESSION_NONE).  ``puissance`` of the results must come
+    from a context with ``var_ddof=0``; the C++ program stores the un-normalised window power sum |y|^2 (:295), which
+    is ``puissance*N`` plus N*|mean(y)|^2 — callers that need that exact number multiply by the window length."""
+    import scipy.io
+    path = cpp_mat_name(capture_path, remote)
+    scipy.io.savemat(path, cpp_mat_dict(res1, res2), format="5", do_compression=False)
+    return path

@@ -148,3 +148,103 @@ def session(op_local: dict, op_remote: dict, lt_local: dict, lt_remote: dict, fs
         ltlo = ltlo[:kkk[-1] + 1]
     ltre = delays_ns(lt_remote["indice1"], lt_remote["correction1"], k, fs, N)
     return combine(oplo, opre, ltlo, ltre, N=N, **kw)
+
+
+# --------------------------------------------------------------------------------------------
+# files: the four result records of a session and the delivered <MJD>.1s text (go_1s.m:83-95,126-139,251-268)
+# --------------------------------------------------------------------------------------------
+
+def julian_day(year: float, month: float, day: float) -> float:
+    """``julianDay`` of acquisition/go_1s.m:18-32 (the branch for dates after 1582; ``day`` may carry a fraction)."""
+    branch = year + (month - 1.0) / 12.0 + day / 365.25
+    if np.floor(month) < 3:
+        month += 12.0
+        year -= 1.0
+    if branch >= 1582.78:
+        return float(np.floor(year * 365.25) + np.floor(year / 400.0) - np.floor(year / 100.0) + np.floor(30.59 * (month - 2.0)) + day + 1721088.5)
+    if branch >= 0.0:
+        return float(np.floor(year * 365.25) + np.floor(30.59 * (month - 2.0)) + day + 1721086.5)
+    return float(np.sign(year) * np.floor(abs(year) * 365.25) + np.floor(30.59 * (month - 2.0)) + day + 1721085.5)
+
+
+def mjd_of_unix(ts: float) -> float:
+    """Session date as the script forms it from the 10-digit Unix time in the LTFB file name (go_1s.m:130-133):
+    ``datevec`` of the time stamp, ``julianDay(y,m,d+(h+mi/60+s/3600)/24)-2400000.5+0.5-8.4e-2``."""
+    import datetime
+    t = datetime.datetime(1970, 1, 1) + datetime.timedelta(seconds=float(ts))
+    sec = t.second + t.microsecond * 1e-6
+    return julian_day(t.year, t.month, t.day + (t.hour + t.minute / 60.0 + sec / 3600.0) / 24.0) - 2400000.5 + 0.5 - 8.4e-2
+
+
+def octave_num2str(x: float) -> str:
+    """Octave ``num2str`` of a real scalar (the ``<MJD>.1s`` file name, go_1s.m:252): integers as ``%d``, otherwise
+    ``%.Ng`` with N = floor(log10(|x|)) + 5 significant digits, at least 5."""
+    if x == np.floor(x):
+        return "%d" % int(x)
+    nd = max(int(np.floor(np.log10(abs(x)))) + 5, 5)
+    return ("%.*g" % (min(nd, 16), x)).strip()
+
+
+def write_1s(directory: str, mjd: float, one_second: np.ndarray) -> str:
+    """The ``<MJD>.1s`` file of go_1s.m:251-268: header line, then one row per second
+    ``MJD+cpt/86400  OPlocal  OPremote  LTFBlocal  LTFBremote`` (``%f`` each, tab separated).
+    ``one_second`` = :attr:`TwoWay.one_second` (column 0 = cpt).  Returns the path written."""
+    import os
+    path = os.path.join(directory, octave_num2str(mjd) + ".1s")
+    with open(path, "w") as fo:
+        fo.write("# MJD\t\tOPlocal\tOPremote\tLTFBlocal\tLTBBremote\n")            # header exactly as the script writes it
+        for row in np.asarray(one_second, dtype=float).reshape(-1, 5):
+            fo.write("%f\t%f\t%f\t%f\t%f\n" % (mjd + row[0] / 86400.0, row[1], row[2], row[3], row[4]))
+    return path
+
+
+def load_record(path: str) -> dict:
+    """One result file of the tracked correlator (``save -mat … corr* df indic* SNR* code puissan* xval* moved*``,
+    claudio_aligned_code_ranging_separate.m:207), optionally gzip'ed as the archive keeps them (``*.mat.gz``):
+    flat vectors ``xval1 indice1 correction1 SNR1r SNR1i``."""
+    import gzip
+    import io
+    from scipy.io import loadmat
+    raw = gzip.open(path, "rb").read() if path.endswith(".gz") else open(path, "rb").read()
+    m = loadmat(io.BytesIO(raw))
+    return {k: np.asarray(v).reshape(-1) for k, v in m.items() if not k.startswith("__")}
+
+
+def session_files(root: str, op_local_name: str):
+    """The four files of one session as go_1s.m finds them (:83,110-111,126-139,149-151): given the OP local record
+    ``OP/<name>`` → OP remote = same name with ``local``→``remote`` and ``_2``→``_1``; LTFB local = first file of
+    ``LTFB/`` starting with the first 21 characters of the name (prefix + 9 of the 10 time-stamp digits: the two sites
+    start within seconds of each other); LTFB remote = that name with ``local``→``remote``, ``_1.``→``_2.`` (first 22
+    characters).  Returns (paths dict, LTFB time stamp) or (None, None) when a file is missing."""
+    import glob
+    import os
+    op_lo = os.path.join(root, "OP", op_local_name)
+    op_re = os.path.join(root, "OP", op_local_name.replace("local", "remote").replace("_2", "_1"))
+    lt = sorted(glob.glob(os.path.join(root, "LTFB", op_local_name[:21] + "*")))
+    if not (os.path.exists(op_lo) and os.path.exists(op_re) and lt):
+        return None, None
+    nom = os.path.basename(lt[0])
+    nomre = nom.replace("local", "remote").replace("_1.", "_2.")
+    ltre = sorted(glob.glob(os.path.join(root, "LTFB", nomre[:22] + "*")))
+    if not ltre:
+        return None, None
+    return dict(op_local=op_lo, op_remote=op_re, lt_local=lt[0], lt_remote=ltre[0]), float(nom[12:22])
+
+
+def process_sessions(root: str, out_dir: str | None = None, fs: float = 5e6, N: int = 1, pattern: str = "lo*gz"):
+    """The loop of go_1s.m:77-268 over ``root/OP/lo*gz``: per session load the four records, combine
+    (:func:`session`), write ``<MJD>.1s``.  Returns [(mjd, TwoWay, path of the .1s file)]."""
+    import glob
+    import os
+    out = []
+    for p in sorted(glob.glob(os.path.join(root, "OP", pattern))):
+        files, ts = session_files(root, os.path.basename(p))
+        if files is None:
+            continue
+        recs = {k: load_record(v) for k, v in files.items()}
+        if any("xval1" not in r for r in recs.values()):
+            continue
+        tw = session(recs["op_local"], recs["op_remote"], recs["lt_local"], recs["lt_remote"], fs=fs, N=N)
+        mjd = mjd_of_unix(ts)
+        out.append((mjd, tw, write_1s(out_dir or root, mjd, tw.one_second)))
+    return out

@@ -141,7 +141,7 @@ def test_single_channel_layout_and_short_final_window():
         assert g.indice == 3 * 4321
 
 
-@pytest.mark.parametrize("case", ["c5k", "c10k", "c25k", "c100k"])
+@pytest.mark.parametrize("case", ["c5k", "c10k", "c25k", "c100k", "c250k", "c500k"])
 def test_golden_221207_rows(case):
     """Device path reproduces the reference's own printed rows (tests/golden/ref221207_ranging.json)."""
     g = load_golden("ref221207_ranging.json")
@@ -430,7 +430,7 @@ def test_wideband_chain_70msps():
     assert abs(g32.indice / 3.0 - expect) < 1.0
 
 
-@pytest.mark.parametrize("case", ["n2M", "n2M_loopback", "n5M_C2"])
+@pytest.mark.parametrize("case", ["n2M", "n2M_loopback", "n5M_C2", "n5M_taps57_remote"])
 def test_device_vs_reference_221219_processing_values(case):
     """The device path with the fine-frequency step on, against the RETURN VALUES of the reference's
     own processing() (experiments/221219_twoway/processing/godual_ranging.py:18-65) stored in
@@ -440,7 +440,7 @@ def test_device_vs_reference_221219_processing_values(case):
     chips, raw = capture_from_desc(c["synth"], c["input_sha256"])
     n = 2 * len(chips)
     with Correlator(chips, fs=c["fs"], Nint=c["Nint"], fine_freq=True) as cor:
-        got = cor.process(raw, n_channels=1, channel=0, band=band_numpy(c["fs"], n))[0]
+        got = cor.process(raw, n_channels=1, channel=0, band=tuple(c["band_k"]) if "band_k" in c else band_numpy(c["fs"], n))[0]
     ref = c["ref"]
     assert got.indice == ref["indice"]                                   # integer lag: bit-exact
     assert abs(got.correction - ref["correction"]) <= 2e-4

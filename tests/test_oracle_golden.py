@@ -58,7 +58,7 @@ def _rows_221207(raw, chips, fs, Nint):
     return rows
 
 
-@pytest.mark.parametrize("case", ["c5k", "c10k", "c25k", "c100k"])
+@pytest.mark.parametrize("case", ["c5k", "c10k", "c25k", "c100k", "c250k", "c500k"])
 def test_oracle_vs_221207_ranging_rows(case):
     g = load_golden("ref221207_ranging.json")
     c = next(x for x in g["cases"] if x["name"] == case)
@@ -75,7 +75,7 @@ def test_oracle_vs_221207_ranging_rows(case):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("case", ["n2M", "n2M_loopback"])
+@pytest.mark.parametrize("case", ["n2M", "n2M_loopback", "n5M_taps57_remote"])
 def test_oracle_vs_221219_processing(case):
     g = load_golden("ref221219_processing.json")
     c = next(x for x in g["cases"] if x["name"] == case)
@@ -86,6 +86,9 @@ def test_oracle_vs_221219_processing(case):
     n = len(code)
     freq = orc.freq_axis(fs, n)
     k = orc.band_numpy(freq, 0.0, 8000.0)
+    if case == "n5M_taps57_remote":                 # LTFB code (taps 57) received ~50 kHz off: the remote band of godual_ranging.m:88
+        k = orc.band_godual(freq, remote=1, OP=0)
+    assert [int(k[0]), int(k[-1])] == c.get("band_k", [int(k[0]), int(k[-1])])
     temps = np.arange(n) / fs
     d = orc.deinterleave(raw, 1, 0)
     d = d - d.mean()

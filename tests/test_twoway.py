@@ -55,3 +55,54 @@ def test_outliers_become_nan():
     tw = twoway.combine(oplo, opre, ltlo, ltre)
     assert np.isnan(tw.res[40]) and np.count_nonzero(np.isnan(tw.res)) == 1
     assert abs(tw.resmean - 125.0) < 1e-9
+
+
+def test_session_files_and_1s_writer(tmp_path):
+    """go_1s.m:83-139,251-268: the four files of a session found by the script's naming rules, combined, and the
+    <MJD>.1s file written with the script's header/row format and file name (Octave num2str of the MJD)."""
+    import gzip, io, os
+    from scipy.io import savemat
+    rng = np.random.default_rng(9)
+    n = 25 * 6 + 11
+    t = np.arange(n) / 25.0
+    sat = 0.26e9 + 5.0 * t
+    recs = {"OP/localclaudio1674402311_2.mat.gz": _record(n, 700.0, rng), "OP/remoteclaudio1674402311_1.mat.gz": _record(n, sat + 700.0 + 37.5, rng),
+            "LTFB/localclaudio1674402314_1.mat.gz": _record(n, 900.0, rng), "LTFB/remoteclaudio1674402314_2.mat.gz": _record(n, sat + 900.0 - 37.5, rng)}
+    for rel, r in recs.items():
+        os.makedirs(tmp_path / os.path.dirname(rel), exist_ok=True)
+        buf = io.BytesIO()
+        savemat(buf, {k: np.asarray(v).reshape(1, -1) for k, v in r.items()} | {"SNR1r": np.ones((1, len(r["xval1"]))), "SNR1i": np.ones((1, len(r["xval1"])))})
+        with gzip.open(tmp_path / rel, "wb") as f:
+            f.write(buf.getvalue())
+    files, ts = twoway.session_files(str(tmp_path), "localclaudio1674402311_2.mat.gz")
+    assert ts == 1674402314.0 and files["lt_remote"].endswith("remoteclaudio1674402314_2.mat.gz")
+    out = twoway.process_sessions(str(tmp_path), out_dir=str(tmp_path))
+    assert len(out) == 1
+    mjd, tw, path = out[0]
+    # 2023-01-22 15:45:14 UTC = MJD 59966.6564 ; the script adds +0.5-0.084 on top of JD-2400000.5 (:133)
+    assert abs(mjd - (59966.0 + (15 + 45 / 60 + 14 / 3600) / 24 + 0.5 - 0.084)) < 1e-9
+    assert os.path.basename(path) == twoway.octave_num2str(mjd) + ".1s" and os.path.basename(path).startswith("59967.0")
+    lines = open(path).read().split("\n")
+    assert lines[0] == "# MJD\t\tOPlocal\tOPremote\tLTFBlocal\tLTBBremote"
+    rows = [[float(v) for v in l.split("\t")] for l in lines[1:] if l]
+    assert len(rows) == tw.one_second.shape[0] >= 4
+    assert abs(rows[1][0] - (mjd + 1 / 86400)) < 1e-6 and abs(rows[0][1] - 700.0) < 0.1 and abs(rows[0][3] - 900.0) < 0.1
+    assert abs(0.5 * ((rows[2][2] - rows[2][1]) - (rows[2][4] - rows[2][3])) - 37.5) < 0.1
+    assert twoway.octave_num2str(60000.0) == "60000" and twoway.octave_num2str(3.14159265) == "3.1416"
+    assert abs(twoway.julian_day(2000, 1, 1.5) - 2451545.0) < 1e-9
+
+
+def test_cpp_twin_container(tmp_path):
+    """processing/CPP/main.cpp:541-647,786-798: <capture>C.mat with correction = indice+corr, SNR in dB, n x 1 columns."""
+    from scipy.io import loadmat
+    from amaranth_twstft_amd import results_io
+    from amaranth_twstft_amd.correlator import WindowResult
+    res = [WindowResult(3935295 + i, -0.25 + 0.1 * i, 1 + 2j, 0.5j, 0.25, np.zeros(7, complex), 1780.75, -1, 2e-7, 1e-7, 4e4, 1e-3, 5e3) for i in range(3)]
+    assert results_io.cpp_mat_name("/data/1670074501.bin", 0) == "/data/1670074501C.mat"
+    assert results_io.cpp_mat_name("1670074501.bin", 1) == "remote1670074501C.mat"
+    path = results_io.save_cpp_mat(str(tmp_path / "1670074501.bin"), res, res)
+    m = loadmat(path)
+    assert m["correction1"].shape == (3, 1) and abs(m["correction1"][1, 0] - (3935296 - 0.15)) < 1e-9
+    assert abs(m["SNR2"][0, 0] - 10 * np.log10(3e-7)) < 1e-12 and abs(m["puissance1code"][0, 0] - (-30.0)) < 1e-9
+    assert m["xval1m1"][2, 0] == 0.5j and set(k for k in m if not k.startswith("__")) == {
+        f"{v}{c}{s}" for c in "12" for v, s in (("correction", ""), ("SNR", ""), ("df", ""), ("puissance", ""), ("puissance", "code"), ("xval", ""), ("xval", "m1"), ("xval", "p1"))}

@@ -107,11 +107,14 @@ def gen_221219(skip_5m: bool):
     ns = load_ref_module("experiments/221219_twoway/processing/godual_ranging.py")
     fs = ns["fs"]
     cases = []
-    specs = [("n2M", 22, 3, 1000000, 1780.75, 733211 * 256 + 77, 200, 400.0, 11),
-             ("n2M_loopback", 22, 57, 1000000, 0.0, 1200345 * 256, 3000, 100.0, 12)]
+    # (name, bitlen, taps, nchips, df, delay_q8, amp, sigma, seed, band): band "numpy" = the script's own 2*(foffset±frange),
+    # "remote" = the 80..120 kHz band of processing/Octave/godual_ranging.m:88 (carrier offset 40..60 kHz)
+    specs = [("n2M", 22, 3, 1000000, 1780.75, 733211 * 256 + 77, 200, 400.0, 11, "numpy"),
+             ("n2M_loopback", 22, 57, 1000000, 0.0, 1200345 * 256, 3000, 100.0, 12, "numpy")]
     if not skip_5m:
-        specs.append(("n5M_C2", 22, 3, 2500000, 1780.75, 1311765 * 256, 200, 400.0, 7))
-    for name, bitlen, taps, nchips, df, delay_q8, amp, sigma, seed in specs:
+        specs.append(("n5M_C2", 22, 3, 2500000, 1780.75, 1311765 * 256, 200, 400.0, 7, "numpy"))
+        specs.append(("n5M_taps57_remote", 22, 57, 2500000, 50000.0 + 377.5, 2718281 * 256 + 128, 250, 450.0, 57, "remote"))
+    for name, bitlen, taps, nchips, df, delay_q8, amp, sigma, seed, bandname in specs:
         chips = prn.lfsr_chips(bitlen, taps, nchips)
         n = 2 * nchips
         p = synth.SynthParams(delay_q8=delay_q8, fstep=synth.fstep_for_df(df, fs), phi0=0x12345678, amp=amp,
@@ -120,7 +123,10 @@ def gen_221219(skip_5m: bool):
         code = np.repeat(chips.astype(np.int64), 2) * 2 - 1          # as reference :74-77
         fcode = np.conj(np.fft.fft(code))
         freq = np.linspace(-fs / 2, fs / 2, num=len(code), dtype=float)
-        k = np.nonzero((freq < 2 * (0 + 8000)) & (freq > 2 * (0 - 8000)))[0]
+        if bandname == "numpy":
+            k = np.nonzero((freq < 2 * (0 + 8000)) & (freq > 2 * (0 - 8000)))[0]
+        else:
+            k = np.nonzero((freq < 120000) & (freq > 80000))[0]
         temps = np.array(range(0, len(code))) / fs
         d = raw[:, 0].astype(complex)
         d.imag = raw[:, 1]
@@ -129,7 +135,8 @@ def gen_221219(skip_5m: bool):
         indice, correction, SNRr, SNRi, dftmp, puissance, pcode, pnoise = r
         cases.append({"name": name, "synth": synth_desc(n, bitlen, taps, nchips, 2, [p]),
                       "input_sha256": hashlib.sha256(raw.tobytes()).hexdigest(),
-                      "band": "numpy(foffset=0,frange=8000)", "Nint": ns["Nint"], "fs": fs,
+                      "band": "numpy(foffset=0,frange=8000)" if bandname == "numpy" else "godual_ranging.m:88 remote band 80..120 kHz",
+                      "band_k": [int(k[0]), int(k[-1])], "Nint": ns["Nint"], "fs": fs,
                       "ref": {"indice": int(indice), "correction": float(correction), "SNRr": float(SNRr),
                               "SNRi": float(SNRi), "df": float(dftmp), "puissance": float(puissance),
                               "puissancecode": float(pcode), "puissancenoise": float(pnoise)}})
@@ -142,7 +149,8 @@ def gen_221207():
     fs = ns["fs"]
     cases = []
     specs = [("c5k", 13, 27, 5000, 4, 843.75, 11), ("c10k", 14, 43, 10000, 4, -1210.5, 12),
-             ("c25k", 15, 3, 25000, 3, 2000.0, 13), ("c100k", 17, 9, 100000, 2, 1780.75, 14)]
+             ("c25k", 15, 3, 25000, 3, 2000.0, 13), ("c100k", 17, 9, 100000, 2, 1780.75, 14),
+             ("c250k", 18, 39, 250000, 2, -915.25, 15), ("c500k", 19, 39, 500000, 2, 433.0, 16)]
     for name, bitlen, taps, nchips, nwin, df, seed in specs:
         chips = prn.lfsr_chips(bitlen, taps, nchips)
         n = 2 * nchips
