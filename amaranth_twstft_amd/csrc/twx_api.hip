@@ -312,6 +312,7 @@ struct CtxBase {
         prof_pending.clear();
     }
     void* aux_buf[AUX_SCRATCH_SLOTS] = {}; size_t aux_cap[AUX_SCRATCH_SLOTS] = {};   // ctx_scratch (twx_internal.h)
+    std::vector<unsigned char> aux_shadow[AUX_SCRATCH_SLOTS];
     int remove_mean = 1;          // TWX_OPT_REMOVE_MEAN
     int snr_valid = 1;            // 0 for replicas that are not a +-1 code
     virtual int init() = 0;
@@ -1234,10 +1235,12 @@ namespace twx {
 hipStream_t ctx_stream(twx_ctx* ctx) { return ctx->impl->stream; }
 int ctx_fail(twx_ctx* ctx, int code, const char* msg) { return ctx->impl->fail(code, msg); }
 int ctx_set_device(twx_ctx* ctx) { return hipSetDevice(ctx->impl->dev) == hipSuccess ? TWX_OK : ctx->impl->fail(TWX_E_HIP, "hipSetDevice failed"); }
+std::vector<unsigned char>& ctx_scratch_shadow(twx_ctx* ctx, int slot) { return ctx->impl->aux_shadow[slot < 0 || slot >= AUX_SCRATCH_SLOTS ? 0 : slot]; }
 void* ctx_scratch(twx_ctx* ctx, int slot, size_t bytes) {
     CtxBase* c = ctx->impl;
     if (slot < 0 || slot >= AUX_SCRATCH_SLOTS) { c->fail(TWX_E_ARG, "bad scratch slot"); return nullptr; }
     if (c->aux_cap[slot] >= bytes && c->aux_buf[slot]) return c->aux_buf[slot];
+    c->aux_shadow[slot].clear();
     if (c->aux_buf[slot]) { (void)c->sync_all(); c->dfree(c->aux_buf[slot]); c->aux_buf[slot] = nullptr; c->aux_cap[slot] = 0; }
     char* p = nullptr;
     const size_t want = bytes + bytes / 8 + 256;          // a little head-room: sizes that creep up do not re-allocate every call

@@ -27,15 +27,15 @@ namespace {
 constexpr int SD_NT = 256, SD_S = 64, SD_CH = SD_NT * SD_S;      // 16384 samples per workgroup
 
 template <int NLAG>
-__global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict__ x, int nch, long long pt, long long nobs, int nlag,
+__global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict__ x, int nch, long long pt, long long nobs, int nlag, int chunk_len,
                                                        const float* __restrict__ w, double ff, double phi, float scale,
                                                        double* __restrict__ partial /*[ncodes][chunks][2*nlag+1][2]*/) {
     constexpr int NL = 2 * NLAG + 1;
     __shared__ float sw[SD_CH + 2 * NLAG + 2];                    // replica segment; reused by the final reduction
     static_assert(NL * SD_NT <= SD_CH + 2 * NLAG + 2, "reduction buffer must fit the replica segment");
     const int p = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
-    const long long s0 = (long long)chunk * SD_CH;
-    const int cnt = (int)min((long long)SD_CH, nobs - s0);
+    const long long s0 = (long long)chunk * chunk_len;
+    const int cnt = (int)min((long long)chunk_len, nobs - s0);
     const int tid = threadIdx.x;
     // entry u <-> w[(s0 - NLAG + u) mod nobs]
     for (int u = tid; u < cnt + 2 * NLAG; u += SD_NT) {
@@ -43,9 +43,10 @@ __global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict_
         sw[u] = w[k];
     }
     __syncthreads();
-    float ar[NL], ai[NL];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 acc[NL];                                                    // (re, im) pairs: one v_pk_fma_f32 per lag and sample
 #pragma unroll
-    for (int l = 0; l < NL; ++l) { ar[l] = 0.f; ai[l] = 0.f; }
+    for (int l = 0; l < NL; ++l) acc[l] = f2{0.f, 0.f};
     for (int t = tid; t < cnt; t += SD_NT) {
         const long long i = (long long)p * nobs + s0 + t;         // the NCO runs over the whole block of codes
         const short2 s = x[(pt + i) * nch];
@@ -54,13 +55,12 @@ __global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict_
         float sn, cs;
         sincospif(-2.0f * (float)ph, &sn, &cs);
         const float re = (float)s.x, im = (float)s.y;
-        const float yr = scale * (re * cs - im * sn), yi = scale * (re * sn + im * cs);
+        const f2 y = {scale * (re * cs - im * sn), scale * (re * sn + im * cs)};
         const float* c = sw + t + 2 * NLAG;                        // lag index l: replica index (s0+t) - (l - NLAG)
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const float cv = c[-l];
-            ar[l] = fmaf(yr, cv, ar[l]);
-            ai[l] = fmaf(yi, cv, ai[l]);
+            acc[l] = __builtin_elementwise_fma(y, f2{cv, cv}, acc[l]);
         }
     }
     // block reduction through LDS, one component at a time: buf[l][tid]; thread r = (l, quarter) sums 64 lanes,
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict_
     for (int comp = 0; comp < 2; ++comp) {
         __syncthreads();
 #pragma unroll
-        for (int l = 0; l < NL; ++l) buf[l * SD_NT + tid] = comp ? ai[l] : ar[l];
+        for (int l = 0; l < NL; ++l) buf[l * SD_NT + tid] = comp ? acc[l].y : acc[l].x;
         __syncthreads();
         if (rl < NL) {
             float a = 0.f;
@@ -108,11 +108,26 @@ __global__ void k_sliding_reduce(const double* __restrict__ partial, int nchunks
     out[((long long)p * nl + li) * 2 + 1] = si * inv_nobs;
 }
 
+// samples per workgroup: at most SD_CH (the LDS segment), chosen so that the grid is a whole number of "rounds" of two
+// workgroups per CU (a 600-workgroup grid on 512 slots runs a second, mostly empty round)
+int sliding_chunk(long long nobs, int ncodes) {
+    int ncu = 256;
+    hipDeviceProp_t prop; int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    const long long slots = 2ll * ncu;
+    const long long min_chunks = (nobs + SD_CH - 1) / SD_CH;
+    const long long rounds = std::max<long long>(1, (min_chunks * ncodes + slots - 1) / slots);
+    long long nchunks = std::max<long long>(min_chunks, rounds * slots / ncodes);
+    long long len = (nobs + nchunks - 1) / nchunks;
+    len = std::min<long long>(SD_CH, ((len + SD_NT - 1) / SD_NT) * SD_NT);
+    return (int)std::max<long long>(len, SD_NT);
+}
 int launch_sliding(hipStream_t st, const short2* dx, int nch, long long pt, long long nobs, int ncodes, int nlag, const float* dw,
                    double ff, double phi, double scale, double* dpart, double* dout) {
-    const int nchunks = (int)((nobs + SD_CH - 1) / SD_CH);
+    const int clen = sliding_chunk(nobs, ncodes);
+    const int nchunks = (int)((nobs + clen - 1) / clen);
     const dim3 grid(nchunks, ncodes), block(SD_NT);
-#define SD_GO(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_>), grid, block, 0, st, dx, nch, pt, nobs, nlag, dw, ff, phi, (float)scale, dpart)
+#define SD_GO(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, dpart)
     if (nlag <= 4) SD_GO(4); else if (nlag <= 8) SD_GO(8); else if (nlag <= 16) SD_GO(16); else if (nlag <= 28) SD_GO(28); else SD_GO(31);
 #undef SD_GO
     if (hipGetLastError() != hipSuccess) return TWX_E_HIP;
@@ -120,7 +135,8 @@ int launch_sliding(hipStream_t st, const short2* dx, int nch, long long pt, long
     return hipGetLastError() == hipSuccess ? TWX_OK : TWX_E_HIP;
 }
 size_t sliding_part_bytes(long long nobs, int ncodes, int nlag) {
-    return (size_t)ncodes * (size_t)((nobs + SD_CH - 1) / SD_CH) * (2 * nlag + 1) * 16;
+    const int clen = sliding_chunk(nobs, ncodes);
+    return (size_t)ncodes * (size_t)((nobs + clen - 1) / clen) * (2 * nlag + 1) * 16;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -129,9 +145,11 @@ size_t sliding_part_bytes(long long nobs, int ncodes, int nlag) {
 // component, i.e. bounded by the fp32 vector rate, not by the 4.6 B/sample it moves).
 // Polyphase form  y[m] = sum_p sum_a h[a*D+p] * x_p[m+a],  x_p[q] = x[q*D+p]:  D stride-1 filters of A = ceil(ntaps/D) taps.
 // A workgroup of FIR_NT threads produces FIR_NT*4 consecutive outputs, thread t the four outputs 4t..4t+3:
-//   * its input span is converted to float once and staged in LDS phase by phase, "transposed" so that what the
-//     64 lanes of a wave read together is contiguous: slot(p, q) = p*PS + (q mod 4)*QS + q div 4  (lane t, step s
-//     reads q = 4t+s -> p*PS + (s mod 4)*QS + t + s div 4): conflict-free ds_read_b64;
+//   * its input span is staged in LDS as the raw int16 pairs (4 B per sample: 31 KB per workgroup, so five workgroups
+//     share a CU and cover each other's latencies; as floats it was one wave per SIMD), phase by phase and
+//     "transposed" so that what the 64 lanes of a wave read together is contiguous: slot(p, q) = p*PS + (q mod 4)*QS
+//     + q div 4  (lane t, step s reads q = 4t+s -> p*PS + (s mod 4)*QS + t + s div 4): conflict-free ds_read_b32,
+//     converted to float as it is read (two sign-extending converts per four packed FMAs);
 //   * each value read feeds the four outputs (8 FMAs) with four different taps; the taps are wave-uniform, read with
 //     scalar loads from a phase-major table hp[p][3 + a] that carries 3 zeros in front and zeros behind, so the
 //     loop has no edge cases;
@@ -144,36 +162,76 @@ FirGeom fir_geom(int ntaps, int dec) {
     FirGeom g;
     g.A = (ntaps + dec - 1) / dec;
     g.SH = (g.A + FIR_K - 1 + 3) / 4;            // groups of four steps s = 0 .. A+K-2
+    if (g.SH <= 16) g.SH = std::max(4, g.SH + (g.SH & 1));   // even counts 4..16 have unrolled kernels (the extra steps meet zero taps)
     g.QS = (FIR_NT + g.SH) | 1;                  // odd: staging writes of one phase spread over the banks
     g.PS = FIR_K * g.QS + 1;
     g.HROW = 4 * g.SH + 4;                       // taps per phase incl. padding (7 are read per group of steps)
-    g.lds = (size_t)dec * g.PS * sizeof(float2);
+    g.lds = (size_t)dec * g.PS * sizeof(unsigned);
     return g;
 }
 
+// SHT > 0: the number of 4-step groups is a compile-time constant, so a whole phase is one straight-line block: all
+// its taps are fetched with a few scalar loads up front (they then sit in SGPRs) and the LDS reads run ahead of the
+// FMAs; with the 60 KB a workgroup stages only one wave per SIMD is resident, so nothing else would hide those
+// latencies.  SHT == 0: generic loop for any tap count.
+template <int SHT>
 __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ x, int nch, long long nin, const float* __restrict__ hp,
-                                                     int D, int SH, int QS, int PS, int HROW, long long nout,
+                                                     int D, int SH_rt, int QS, int PS, int HROW, long long nout,
                                                      short2* __restrict__ y16, float2* __restrict__ yf) {
-    extern __shared__ float2 X[];
+    extern __shared__ unsigned X[];                                 // raw int16 IQ pairs: 4 B per sample, converted when read
+    const int SH = SHT > 0 ? SHT : SH_rt;
     const int tid = threadIdx.x;
     const long long m0 = (long long)blockIdx.x * FIR_OUT;
     const long long e0 = m0 * D;
     const int nq = FIR_K * (FIR_NT + SH);                          // q values staged per phase
     const int span = nq * D;
-    for (int eb = 0; eb < span; eb += 8 * FIR_NT) {                // eight independent loads in flight per thread
-        unsigned raw[8];
+    // sample e = q*D + p of the span goes to slot(p, q); (q, p) of this thread's samples e = tid, tid+NT, ... advance by a
+    // fixed step, so no division runs per sample.
+    // Loads are UNCONDITIONAL (clamped indices, values masked afterwards): a load inside a divergent branch gets its own
+    // s_waitcnt vmcnt(0), which turns "eight loads in flight" into eight round trips — and with one wave per SIMD
+    // nothing else hides them (that was most of this kernel's time).
+    const int nvec = (span + 3) >> 2;
+    if (nch == 1 && ((reinterpret_cast<unsigned long long>(x + e0) & 15ull) == 0) && e0 + 4ll * nvec <= nin) {
+        // interior workgroup, one channel, aligned: 16-B loads, four samples per lane
+        const int4* xv = reinterpret_cast<const int4*>(x + e0);
+        const int dq4 = (4 * FIR_NT) / D, dp4 = 4 * FIR_NT - dq4 * D;
+        int q = (4 * tid) / D, p = 4 * tid - q * D;
+        for (int jb = 0; jb < nvec; jb += 8 * FIR_NT) {
+            int4 raw[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = eb + u * FIR_NT + tid;
-            const long long g = e0 + e;
-            raw[u] = (e < span && g < nin) ? *reinterpret_cast<const unsigned*>(x + g * nch) : 0u;
+            for (int u = 0; u < 8; ++u) raw[u] = xv[min(jb + u * FIR_NT + tid, nvec - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = jb + u * FIR_NT + tid;
+                const int w4[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+                int qq = q, pp = p;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (4 * j + i < span) X[pp * PS + (qq & 3) * QS + (qq >> 2)] = (unsigned)w4[i];
+                    if (++pp >= D) { pp = 0; ++qq; }
+                }
+                q += dq4; p += dp4;
+                if (p >= D) { p -= D; ++q; }
+            }
         }
+    } else {
+        const int dq = FIR_NT / D, dp = FIR_NT - dq * D;
+        int q = tid / D, p = tid - q * D;
+        const unsigned* xs = reinterpret_cast<const unsigned*>(x);
+        for (int eb = 0; eb < span; eb += 8 * FIR_NT) {
+            unsigned raw[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = eb + u * FIR_NT + tid;
-            if (e < span) {
-                const int q = e / D, p = e - q * D;
-                X[p * PS + (q & 3) * QS + (q >> 2)] = make_float2((float)(short)(raw[u] & 0xffffu), (float)(short)(raw[u] >> 16));
+            for (int u = 0; u < 8; ++u) {
+                const long long g = e0 + eb + u * FIR_NT + tid;
+                const unsigned v = xs[min(g, nin - 1) * nch];
+                raw[u] = g < nin ? v : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = eb + u * FIR_NT + tid;
+                if (e < span) X[p * PS + (q & 3) * QS + (q >> 2)] = raw[u];
+                q += dq; p += dp;
+                if (p >= D) { p -= D; ++q; }
             }
         }
     }
@@ -182,22 +240,41 @@ __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ 
 #pragma unroll
     for (int k = 0; k < FIR_K; ++k) acc[k] = make_float2(0.f, 0.f);
     for (int p = 0; p < D; ++p) {
-        const float2* Xp = X + p * PS + tid;
+        const unsigned* Xp = X + p * PS + tid;
         const float* h = hp + p * HROW;
-        for (int sh = 0; sh < SH; ++sh) {
-            float t[7];
+        if constexpr (SHT > 0) {
+            float t[4 * SHT + 4];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) t[j] = h[4 * sh + j];      // wave-uniform: scalar loads
-            float2 v[4];
+            for (int j = 0; j < 4 * SHT + 4; ++j) t[j] = h[j];     // wave-uniform: scalar loads, once per phase
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) v[sl] = Xp[sl * QS + sh];
+            for (int sh = 0; sh < SHT; ++sh) {
+                float2 v[4];
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl)
+                for (int sl = 0; sl < 4; ++sl) { const unsigned w = Xp[sl * QS + sh]; v[sl] = make_float2((float)(short)(w & 0xffffu), (float)(short)(w >> 16)); }
 #pragma unroll
-                for (int k = 0; k < FIR_K; ++k) {                  // step s = 4sh+sl feeds output k with tap a = s-k (table index a+3)
-                    acc[k].x = fmaf(v[sl].x, t[sl - k + 3], acc[k].x);
-                    acc[k].y = fmaf(v[sl].y, t[sl - k + 3], acc[k].y);
-                }
+                for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                    for (int k = 0; k < FIR_K; ++k) {              // step s = 4sh+sl feeds output k with tap a = s-k (table index a+3)
+                        acc[k].x = fmaf(v[sl].x, t[4 * sh + sl - k + 3], acc[k].x);
+                        acc[k].y = fmaf(v[sl].y, t[4 * sh + sl - k + 3], acc[k].y);
+                    }
+            }
+        } else {
+            for (int sh = 0; sh < SH; ++sh) {
+                float t[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) t[j] = h[4 * sh + j];
+                float2 v[4];
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) { const unsigned w = Xp[sl * QS + sh]; v[sl] = make_float2((float)(short)(w & 0xffffu), (float)(short)(w >> 16)); }
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                    for (int k = 0; k < FIR_K; ++k) {
+                        acc[k].x = fmaf(v[sl].x, t[sl - k + 3], acc[k].x);
+                        acc[k].y = fmaf(v[sl].y, t[sl - k + 3], acc[k].y);
+                    }
+            }
         }
     }
     const long long m = m0 + (long long)FIR_K * tid;
@@ -238,11 +315,19 @@ int launch_fir(hipStream_t st, const short2* dx, int nch, long long nin, const f
     const FirGeom g = fir_geom(ntaps, dec);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fir_poly), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return TWX_E_HIP;
+        const void* fns[] = {(const void*)&k_fir_poly<0>, (const void*)&k_fir_poly<4>, (const void*)&k_fir_poly<6>, (const void*)&k_fir_poly<8>,
+                             (const void*)&k_fir_poly<10>, (const void*)&k_fir_poly<12>, (const void*)&k_fir_poly<14>, (const void*)&k_fir_poly<16>};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return TWX_E_HIP;
         attr_set = true;
     }
     const unsigned grid = (unsigned)((nout + FIR_OUT - 1) / FIR_OUT);
-    hipLaunchKernelGGL(k_fir_poly, dim3(grid), dim3(FIR_NT), g.lds, st, dx, nch, nin, hp_dev, dec, g.SH, g.QS, g.PS, g.HROW, nout, dy16, dyf);
+#define FIR_GO(SHT_) hipLaunchKernelGGL((k_fir_poly<SHT_>), dim3(grid), dim3(FIR_NT), g.lds, st, dx, nch, nin, hp_dev, dec, g.SH, g.QS, g.PS, g.HROW, nout, dy16, dyf)
+    switch (g.SH) {                                       // unrolled instantiations for the usual tap counts, generic loop otherwise
+        case 4: FIR_GO(4); break;   case 6: FIR_GO(6); break;   case 8: FIR_GO(8); break;   case 10: FIR_GO(10); break;
+        case 12: FIR_GO(12); break; case 14: FIR_GO(14); break; case 16: FIR_GO(16); break; default: FIR_GO(0); break;
+    }
+#undef FIR_GO
     return hipGetLastError() == hipSuccess ? TWX_OK : TWX_E_HIP;
 }
 
@@ -289,9 +374,14 @@ int twx_fir_decimate_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_in, int32_t
     float* hp_dev = static_cast<float*>(twx::ctx_scratch(ctx, 1, hp.size() * sizeof(float)));
     if (!hp_dev) return TWX_E_NOMEM;
     hipStream_t st = twx::ctx_stream(ctx);
-    if (hipMemcpyAsync(hp_dev, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)            // hp is a local: the copy must have left it before we return
-        return twx::ctx_fail(ctx, TWX_E_HIP, "twx_fir_decimate_dev: tap upload failed");
+    std::vector<unsigned char>& shadow = twx::ctx_scratch_shadow(ctx, 1);
+    const size_t hp_bytes = hp.size() * sizeof(float);
+    if (shadow.size() != hp_bytes || memcmp(shadow.data(), hp.data(), hp_bytes) != 0) {      // same filter as last time: nothing to upload
+        if (hipMemcpyAsync(hp_dev, hp.data(), hp_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)        // hp is a local: the copy must have left it before we return
+            return twx::ctx_fail(ctx, TWX_E_HIP, "twx_fir_decimate_dev: tap upload failed");
+        shadow.assign(reinterpret_cast<const unsigned char*>(hp.data()), reinterpret_cast<const unsigned char*>(hp.data()) + hp_bytes);
+    }
     const int rc = launch_fir(st, reinterpret_cast<const short2*>(iq_dev) + channel, n_channels, n_in, hp_dev, ntaps, dec, nout,
                               reinterpret_cast<short2*>(out_i16_dev), reinterpret_cast<float2*>(out_f32_dev));
     return rc ? twx::ctx_fail(ctx, rc, "twx_fir_decimate_dev: launch failed") : TWX_OK;

@@ -56,12 +56,14 @@ template <typename T> int inv(const void* args, unsigned nblk, hipStream_t s) {
     const ColInvArgs<T>& a = *reinterpret_cast<const ColInvArgs<T>*>(args);
     if constexpr (PR::S == 2 && std::is_same<T, float>::value && NT >= 384) {
         static const bool split = [] { const char* e = getenv("TWX_COLINV3"); return !e || atoi(e) != 0; }();
-        if (split) {                         // component-wise exchange: three workgroups per CU (twx_kernels.h)
-            TWX_LAUNCH((k_col_inv3<PR, T, W, NT>), dim3(nblk), dim3(NT), s, a);
+        if (split) {                         // component-wise exchange: three or four workgroups per CU (twx_kernels.h)
+            if (a.norm1) TWX_LAUNCH((k_col_inv3<PR, T, W, NT, 1>), dim3(nblk), dim3(NT), s, a);
+            else TWX_LAUNCH((k_col_inv3<PR, T, W, NT, 0>), dim3(nblk), dim3(NT), s, a);
             return (int)hipGetLastError();
         }
     }
-    TWX_LAUNCH((k_col_inv<PR, T, W, NT>), dim3(nblk), dim3(NT), s, a);
+    if (a.norm1) TWX_LAUNCH((k_col_inv<PR, T, W, NT, 1>), dim3(nblk), dim3(NT), s, a);
+    else TWX_LAUNCH((k_col_inv<PR, T, W, NT, 0>), dim3(nblk), dim3(NT), s, a);
     return (int)hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <vector>
 #include "../../include/twstft_hip.h"
 
 #define TWX_HIDDEN __attribute__((visibility("hidden")))
@@ -15,4 +16,6 @@ TWX_HIDDEN hipStream_t ctx_stream(twx_ctx* ctx);                        // = twx
 TWX_HIDDEN void* ctx_scratch(twx_ctx* ctx, int slot, size_t bytes);
 TWX_HIDDEN int ctx_fail(twx_ctx* ctx, int code, const char* msg);       // sets twx_last_error, returns code
 TWX_HIDDEN int ctx_set_device(twx_ctx* ctx);
+// host-side shadow of a scratch slot's contents (lets a caller skip an upload when the bytes have not changed)
+TWX_HIDDEN std::vector<unsigned char>& ctx_scratch_shadow(twx_ctx* ctx, int slot);
 }  // namespace twx

@@ -1348,10 +1348,10 @@ template <typename T> struct ColInvArgs {
     const cpx<T>* tw1;
     ArgPart<T>* part;        // [b][rho*ntiles + tile]
     cpx<T>* zout;            // optional full output [b][R*N] (natural interleaved order), or nullptr
-    int norm1;               // arg-max of (|re|+|im|)^2 instead of |z|^2: cblas_izamax (rxcomplex.cpp:553)
+    int norm1;               // arg-max of (|re|+|im|)^2 instead of |z|^2: cblas_izamax (rxcomplex.cpp:553) — selects the NORM1 instantiation
 };
 
-template <class P1R, typename T, int W, int NT>
+template <class P1R, typename T, int W, int NT, int NORM1 = 0>
 __global__ __launch_bounds__(NT) void k_col_inv(ColInvArgs<T> a) {
     using TL = Tile<P1R, T, true, W, 0>;
     using C = cpx<T>;
@@ -1417,7 +1417,7 @@ __global__ __launch_bounds__(NT) void k_col_inv(ColInvArgs<T> a) {
             T bv = T(-1);
             TWX_UNROLL
             for (int q = 0; q < R; ++q) {
-                if (a.norm1) { const T s1 = (v[q].x < 0 ? -v[q].x : v[q].x) + (v[q].y < 0 ? -v[q].y : v[q].y); nv[q] = s1 * s1; }
+                if constexpr (NORM1) { const T s1 = (v[q].x < 0 ? -v[q].x : v[q].x) + (v[q].y < 0 ? -v[q].y : v[q].y); nv[q] = s1 * s1; }
                 else nv[q] = cnorm(v[q]);
                 bv = nv[q] > bv ? nv[q] : bv;
             }
@@ -1454,7 +1454,7 @@ __global__ __launch_bounds__(NT) void k_col_inv(ColInvArgs<T> a) {
 // twiddles are fetched after the exchange instead of being parked in 48 registers, so that 3 x 7 waves fit.
 // Bz is read exactly once: non-temporal loads.   grid = ntiles * R * windows
 // ------------------------------------------------------------------------------------------
-template <class P1R, typename T, int W, int NT>
+template <class P1R, typename T, int W, int NT, int NORM1 = 0>
 __global__ __launch_bounds__(NT, 6) void k_col_inv3(ColInvArgs<T> a) {
     static_assert(P1R::S == 2 && sizeof(T) == 4, "two-stage fp32 plans only");
     using TL = Tile<P1R, T, true, W, 0>;
@@ -1514,7 +1514,7 @@ __global__ __launch_bounds__(NT, 6) void k_col_inv3(ColInvArgs<T> a) {
         T bv = T(-1);
         TWX_UNROLL
         for (int q = 0; q < R1; ++q) {
-            if (a.norm1) { const T s1 = (u[q].x < 0 ? -u[q].x : u[q].x) + (u[q].y < 0 ? -u[q].y : u[q].y); nv[q] = s1 * s1; }
+            if constexpr (NORM1) { const T s1 = (u[q].x < 0 ? -u[q].x : u[q].x) + (u[q].y < 0 ? -u[q].y : u[q].y); nv[q] = s1 * s1; }
             else nv[q] = cnorm(u[q]);
             bv = nv[q] > bv ? nv[q] : bv;
         }

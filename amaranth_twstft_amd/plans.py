@@ -121,7 +121,7 @@ def choose(n: int):
     if n < 4 or n % 2 or not _smooth(n):
         return None
     best = None
-    for n2 in range(4, min(n, 10000) + 1, 2):
+    for n2 in range(16, min(n, 10000) + 1, 2):
         if n % n2:
             continue
         n1 = n // n2

@@ -637,3 +637,47 @@ def rx_power(smp, fs: float, dec_a: int = 1):
     """Received power :481-489: ``zdotc(smp, smp)`` over every ``dec_a``-th sample divided by ``fs/dec_a``."""
     x = np.asarray(smp)[::dec_a]
     return float(np.real(np.vdot(x, x))) / (fs / float(dec_a))
+
+
+# --------------------------------------------------------------------------------------------
+# C++ twin: file-level carrier estimate, processing/CPP/main.cpp:363-450 — UNPINNED (fftw3/matio/sigpack absent)
+# --------------------------------------------------------------------------------------------
+
+def cpp_file_df(raw, fs: float = 5e6, N: int = 25, remote: int = 0, foffset: float = 0.0):
+    """``GoRanging::df``: every N-th ``[I1 Q1 I2 Q2]`` sample of the whole capture, mixed by ``foffset`` (time base
+    accumulated ``t += N/fs`` :392), minus the mean of the RAW samples (:384,416-418), squared, FFT of the arbitrary
+    length ``nrec`` (:419-421), halves swapped by two memcpy of ``nrec/2`` elements (:423-424), channel 1 arg-max inside
+    ``freq < 2*8000`` / ``freq <= -2*8000`` (:401-406,427-430), channel 2 over everything (:443); returns
+    (``freq[pos]/2 + foffset``, same for channel 2 or None)."""
+    raw = np.asarray(raw).reshape(-1, 4)
+    nrec = raw.shape[0] // N
+    rec = raw[: nrec * N][::N]
+    t = np.zeros(nrec)
+    acc = 0.0
+    step = float(N) / fs
+    for i in range(nrec):
+        t[i] = acc
+        acc += step
+    tlo = complex(0, -1) * float(np.float32(2.0)) * np.pi                    # :28
+    lo = np.exp(tlo * foffset * t)
+    start, end = -fs / 2 / N, fs / 2 / N
+    freq = start + ((end - start) / (nrec - 1)) * np.arange(nrec)
+    freq[-1] = end                                                              # linspace :734-757
+    kmax = kmin = 0
+    for i in range(nrec):
+        if freq[i] < 2 * 8000.0:
+            kmax = i
+        if freq[i] <= -2 * 8000.0:
+            kmin = i
+    res = [None, None]
+    h = nrec // 2
+    for ch in ((0,) if remote else (0, 1)):
+        dx = rec[:, 2 * ch].astype(np.float64) + 1j * rec[:, 2 * ch + 1]
+        x = dx * lo - dx.sum() / nrec
+        f = _fft(x * x)
+        out = np.zeros(nrec, dtype=complex)
+        out[:h] = f[h:2 * h]
+        out[h:2 * h] = f[:h]
+        pos = int(np.abs(out[kmin:kmax]).argmax()) + kmin if ch == 0 else int(np.abs(out).argmax())
+        res[ch] = float(freq[pos] / 2.0 + float(np.float32(foffset)))
+    return res[0], res[1]

@@ -170,3 +170,25 @@ def test_plan_generator_covers_the_reference_code_lengths():
             assert prod == pl["L"]
         assert (cp["L"] // min(cp["radices"])) * cp["W"] <= cp["nt"] <= 1024 and rp["L"] // min(rp["radices"]) <= rp["nt"] <= 1024
     assert plans.choose(7000) is None and plans.choose(5001) is None        # a factor 7 / an odd length have no plan
+
+
+@pytest.mark.slow
+def test_hot_kernels_compile_without_register_spills(tmp_path):
+    """The three-workgroups-per-CU column kernels live under a hard register cap (__launch_bounds__(448, 6): 80 VGPRs);
+    a spill there costs 2x in time and no GPU test would notice.  Cross-compile the N1 = 625 column plan and read the
+    kernels' resource records."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "c625.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--offload-device-only",
+                    os.path.join(root, "amaranth_twstft_amd", "csrc", "twx_inst_col.hip"), "-DTWX_PLAN=Plan<625,25,25>", "-DTWX_W=16",
+                    "-DTWX_NT=448", "-DTWX_NO_F64", "-o", str(out)], check=True, capture_output=True)
+    txt = out.read_text()
+    recs = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", txt)
+    seen = 0
+    for name, vgpr, spill in recs:
+        if ("k_col_inv3" in name) or ("k_col_fwd3" in name and "InI16" in name):
+            seen += 1
+            assert int(spill) == 0 and int(vgpr) <= 80, (name, vgpr, spill)
+    assert seen >= 3

@@ -516,3 +516,61 @@ def test_rxcomplex_acquisition_pipeline_at_sdr_param_sizes():
     p_sig, locked = a.gate(pk2, px, 10 ** (-18 / 10))                                    # least_required_SNR -18 dB
     assert locked and orc.rx_gate(pko, psbb, orc.rx_power(oA, fs), 10 ** (-18 / 10))[1]
     a.close(); interp.close()
+
+
+def test_aux_kernels_device_resident_forms_match_host_forms():
+    """twx_sliding_dot_dev / twx_fir_decimate_dev (context stream, context-owned work buffers) against the host-pointer
+    entry points on the same data, bit for bit; odd sizes exercise the ragged last workgroup of both kernels."""
+    import torch
+    from amaranth_twstft_amd import tracking
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    nobs, ncodes, nlag = 20000 + 37, 3, 28
+    raw = np.clip(rng.normal(0, 2500, (nobs * ncodes + 5, 2)), -32768, 32767).astype(np.int16)
+    rep = rng.choice([-1.0, 1.0], nobs).astype(np.float32)
+    host = tracking.sliding_dot(raw, rep, nobs, ncodes, nlag, pt=3, ff=2.5e-5, phi=0.125, scale=1 / 32768)
+    x = torch.from_numpy(raw).to(dev)
+    r = torch.from_numpy(rep).to(dev)
+    out = torch.empty((ncodes, 2 * nlag + 1, 2), dtype=torch.float64, device=dev)
+    taps = frontend.lowpass_taps(70e6, 2.1e6, 0.4e6)
+    n_in = 70_001
+    wide = np.clip(rng.normal(0, 3000, (n_in, 2)), -32768, 32767).astype(np.int16)
+    h16 = frontend.fir_decimate(wide, taps, 14, out="int16")
+    hf = frontend.fir_decimate(wide, taps, 14, out="f32")
+    w = torch.from_numpy(wide).to(dev)
+    y16 = torch.zeros((h16.shape[0], 2), dtype=torch.int16, device=dev)
+    yf = torch.zeros((h16.shape[0], 2), dtype=torch.float32, device=dev)
+    with Correlator(lfsr=(14, 43, 10000), fs=FS) as cor:
+        for _ in range(2):                                             # second call reuses the context's buffers
+            cor.sliding_dot_dev(x.data_ptr(), raw.shape[0], r.data_ptr(), nobs, ncodes, nlag, out.data_ptr(), pt=3, ff=2.5e-5, phi=0.125, scale=1 / 32768)
+            nout = cor.fir_decimate_dev(w.data_ptr(), n_in, taps, 14, y16.data_ptr(), yf.data_ptr())
+        cor.synchronize()
+    o = out.cpu().numpy()
+    assert np.array_equal(o[..., 0] + 1j * o[..., 1], host)
+    assert nout == h16.shape[0] == (n_in - taps.size) // 14 + 1
+    assert np.array_equal(y16.cpu().numpy(), h16)
+    f = yf.cpu().numpy()
+    assert np.array_equal((f[:, 0] + 1j * f[:, 1]).astype(np.complex64), hf)
+    ref = orc.fir_decimate(wide[:, 0].astype(np.float64) + 1j * wide[:, 1], taps.astype(np.float64), 14)
+    assert np.abs(hf - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-3
+
+
+def test_cpp_twin_file_level_carrier_estimate(tmp_path):
+    """GoRanging::df (processing/CPP/main.cpp:363-450): one carrier estimate per file from every 25th sample, an FFT of
+    ARBITRARY length (here 39 999 and 40 003 records: odd, with prime factors far from 2/3/5) — Bluestein on the
+    library's FFT against the oracle restatement (unpinned)."""
+    from amaranth_twstft_amd import cpp_twin
+    from tests.test_gpu_parity import _capture
+    chips, raw = _capture(15, 3, 25000, 20, seed=5, df=(1780.75, -3.5))            # 1 000 000 samples x 2 channels
+    for nsamp, foff in ((999_975 + 24, 0.0), (1_000_000, 250.0), (40_003 * 25, -1000.0)):
+        r = np.concatenate([raw, raw])[:nsamp]
+        path = tmp_path / f"cap{nsamp}.bin"
+        r.tofile(path)
+        got = cpp_twin.file_level_df(str(path), FS, 25, 0, foff)
+        ref = orc.cpp_file_df(r, FS, 25, 0, foff)
+        assert got == ref, (nsamp, got, ref)
+        assert abs(got[0] - 1780.75) < 3.0 and abs(got[1] + 3.5) < 3.0               # 2.5 Hz bins (fs/25/nrec*... /2)
+    eng = cpp_twin.ArbitraryFFT(1237)
+    x = np.random.default_rng(2).normal(size=1237) + 1j * np.random.default_rng(3).normal(size=1237)
+    assert np.abs(eng(x) - np.fft.fft(x)).max() <= 1e-10 * np.abs(np.fft.fft(x)).max()
+    eng.close()

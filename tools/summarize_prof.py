@@ -25,6 +25,12 @@ def short(name):
         mm = re.search(r">, (float|double), (\d),", targs)
         if mm:
             return "k_row" + {"1": "_band", "2": "_mid"}.get(mm.group(2), "") + ("_f64" if mm.group(1) == "double" else "") + "(dif)"
+    elif k == "k_col_fwd3":
+        mm = re.search(r">, (float|double), \d+, (\d),", targs)
+        if mm:
+            return "k_col_fwd" + {"0": "_mix", "1": "_square", "2": "_plain"}[mm.group(2)] + "(split)"
+    elif k == "k_col_inv3":
+        return "k_col_inv(split)"
     elif k == "k_col_fwd":
         mm = re.search(r">, (float|double), \d+, (\d),", targs)
         if mm:
