@@ -238,9 +238,20 @@ def test_context_from_lfsr_parameters_equals_context_from_chips():
 
 
 def test_unsupported_length_is_a_clean_error():
-    with pytest.raises(L.TwxError) as e:
-        Correlator(chips_for(13, 27, 5000)[:4999], fs=FS)
-    assert e.value.status in (-2,)
+    """A window length with a prime factor other than 2, 3, 5 (9998 = 2 x 4999) has no N1 x N2 plan: the C entry point
+    answers TWX_E_SIZE with a message that says what to do, the Python wrapper (which would otherwise build a plan
+    plug-in) says why none can exist."""
+    chips = chips_for(13, 27, 5000)[:4999]
+    lib = L.load()
+    cfg = L.twx_config()
+    cfg.fs, cfg.sps, cfg.nint, cfg.n_chips = FS, 2, 1, chips.size
+    cfg.chips = chips.ctypes.data_as(C.POINTER(C.c_uint8))
+    h = C.c_void_p()
+    assert lib.twx_create(C.byref(cfg), C.byref(h)) == -2
+    assert b"no plan pair" in lib.twx_last_error(None) and b"amaranth_twstft_amd.plans" in lib.twx_last_error(None)
+    with pytest.raises(ValueError) as e:
+        Correlator(chips, fs=FS)
+    assert "2^a 3^b 5^c" in str(e.value)
 
 
 def test_fp64_context_tighter_than_fp32():
