@@ -12,6 +12,7 @@ from collections import defaultdict
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     m = re.match(r"(?:void )?(?:twx::)?(k_\w+)(?:<(.*)>)?\(", name)
     if not m:
         return name.split("(")[0][:60]
