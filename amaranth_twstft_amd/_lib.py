@@ -91,6 +91,7 @@ SYMBOLS = {
     "twx_xcorr_map_dev": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, _VP]),
     "twx_caf_freqs_cdev": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int32, _VP]),
     "twx_caf_bins": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _VP, _VP]),
+    "twx_caf_bins_dev": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _VP, _VP]),
     "twx_caf_freqs": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP, C.c_int64, _VP]),
     "twx_sqspec_bins_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_int32, _VP]),
     "twx_sqspec_band_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _VP]),

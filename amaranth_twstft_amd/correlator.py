@@ -280,6 +280,15 @@ class Correlator:
                                        pk.ctypes.data_as(C.c_void_p), lag.ctypes.data_as(C.c_void_p)), self._h)
         return pk, lag
 
+    def caf_bins_dev(self, iq_dev: int, k_lo: int, k_hi: int, n_channels=1, channel=0):
+        """:meth:`caf_bins` on a window that already sits in device memory."""
+        nb = int(k_hi) - int(k_lo) + 1
+        pk = np.empty(nb, dtype=np.float64)
+        lag = np.empty(nb, dtype=np.int64)
+        L.check(self._lib.twx_caf_bins_dev(self._h, iq_dev, n_channels, channel, int(k_lo), int(k_hi),
+                                           pk.ctypes.data_as(C.c_void_p), lag.ctypes.data_as(C.c_void_p)), self._h)
+        return pk, lag
+
     def caf_freqs(self, raw_window, freqs, n_channels=1, channel=0) -> list[WindowResult]:
         """processing(d,df) of the same window for every trial offset in ``freqs`` (Hz)."""
         raw = np.ascontiguousarray(raw_window, dtype=np.int16).reshape(-1)

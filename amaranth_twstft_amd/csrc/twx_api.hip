@@ -324,6 +324,7 @@ struct CtxBase {
     virtual int code_spectrum(double* out) = 0;
     virtual int xcorr_map(const int16_t* iq, int nch, int ch, double df, double* out) = 0;
     virtual int caf_bins(const int16_t* iq, int nch, int ch, long long k_lo, long long k_hi, double* pk, long long* lag) = 0;
+    virtual int caf_bins_dev(const void* iq_dev, int nch, int ch, long long k_lo, long long k_hi, double* pk, long long* lag) = 0;
     virtual int caf_freqs(const int16_t* iq, int nch, int ch, const double* freqs, long long nf, twx_result* out) = 0;
     virtual int sqspec_bins(const void* iq_dev, long long L, int nch, int ch, const long long* bins, int nb, double* out) = 0;
     virtual int sqspec_band(const void* iq_dev, long long L, int nch, int ch, long long k_lo, long long nk, double* out) = 0;
@@ -1184,16 +1185,25 @@ template <typename T> struct Ctx : CtxBase {
 
     int caf_bins(const int16_t* iq, int nch, int ch, long long k_lo, long long k_hi, double* pk, long long* lag) override {
         if (k_hi < k_lo) return fail(TWX_E_ARG, "k_hi < k_lo");
-        short2* din = nullptr; C* Ysp = nullptr; double* pk_d = nullptr; long long* lag_d = nullptr;
+        short2* din = nullptr;
+        Scratch sc(this);
+        if (int rc = sc.get(&din, (size_t)N * nch)) return rc;
+        HIPCHK(hipMemcpy(din, iq, (size_t)N * nch * 4, hipMemcpyHostToDevice));
+        return caf_bins_dev(din, nch, ch, k_lo, k_hi, pk, lag);
+    }
+    // the window already in device memory (outputs to the host: 16 bytes per bin)
+    int caf_bins_dev(const void* iq_dev, int nch, int ch, long long k_lo, long long k_hi, double* pk, long long* lag) override {
+        if (k_hi < k_lo) return fail(TWX_E_ARG, "k_hi < k_lo");
+        if (int rc = sync_all()) return rc;
+        use_slot(0);
+        C* Ysp = nullptr; double* pk_d = nullptr; long long* lag_d = nullptr;
         const int nbmax = B * R;
         const long long nbins = k_hi - k_lo + 1;
         Scratch sc(this);
-        if (int rc = sc.get(&din, (size_t)N * nch)) return rc;
         if (int rc = sc.get(&Ysp, (size_t)N)) return rc;
         if (int rc = sc.get(&pk_d, (size_t)nbins)) return rc;       // every bin's record stays on the device until the end:
         if (int rc = sc.get(&lag_d, (size_t)nbins)) return rc;      // one D2H copy and one synchronisation per call
-        HIPCHK(hipMemcpy(din, iq, (size_t)N * nch * 4, hipMemcpyHostToDevice));
-        const short2* in = din + ch;
+        const short2* in = reinterpret_cast<const short2*>(iq_dev) + ch;
         HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums), stream));
         TWX_LAUNCH((k_sums<0>), dim3((unsigned)std::min<long long>(64, std::max<long long>(1, N / 16384)), 1), dim3(256), stream, in, 0ll, nch, N, sums);
         HIPCHK(hipGetLastError());
@@ -1443,6 +1453,11 @@ int twx_caf_bins(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t ch
     if (!ctx || !iq || !pk || !lag || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
     (void)hipSetDevice(ctx->impl->dev);
     return guarded(ctx->impl, [&]() { return ctx->impl->caf_bins(iq, n_channels, channel, k_lo, k_hi, pk, (long long*)lag); });
+}
+int twx_caf_bins_dev(twx_ctx* ctx, const void* iq_dev, int32_t n_channels, int32_t channel, int64_t k_lo, int64_t k_hi, double* pk, int64_t* lag) {
+    if (!ctx || !iq_dev || !pk || !lag || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;
+    (void)hipSetDevice(ctx->impl->dev);
+    return guarded(ctx->impl, [&]() { return ctx->impl->caf_bins_dev(iq_dev, n_channels, channel, k_lo, k_hi, pk, (long long*)lag); });
 }
 int twx_caf_freqs(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, const double* freqs, int64_t n_freqs, twx_result* out) {
     if (!ctx || !iq || !freqs || !out || n_freqs < 0 || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;

@@ -213,6 +213,9 @@ int twx_caf_bins(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t ch
                  double* pk, int64_t* lag);
 int twx_caf_freqs(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, const double* freqs,
                   int64_t n_freqs, twx_result* out);
+/* twx_caf_bins with the window already in DEVICE memory (iq_dev); pk / lag are host arrays (16 bytes per bin). */
+int twx_caf_bins_dev(twx_ctx* ctx, const void* iq_dev, int32_t n_channels, int32_t channel, int64_t k_lo, int64_t k_hi,
+                     double* pk, int64_t* lag);
 
 /* Long squared spectra for carrier acquisition ----------------------------------------------------
  * Replaces d2=fftshift(abs(fft(d.^2))) over a whole ls-second chunk in

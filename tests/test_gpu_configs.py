@@ -574,3 +574,58 @@ def test_cpp_twin_file_level_carrier_estimate(tmp_path):
     x = np.random.default_rng(2).normal(size=1237) + 1j * np.random.default_rng(3).normal(size=1237)
     assert np.abs(eng(x) - np.fft.fft(x)).max() <= 1e-10 * np.abs(np.fft.fft(x)).max()
     eng.close()
+
+
+def test_stream_contract_of_the_device_entry_point():
+    """include/twstft_hip.h: twx_process_windows_dev is ordered against twx_stream(ctx) on both sides although batches run
+    on several internal streams — a producer enqueued on that stream before the call (here the synthetic generator) and a
+    consumer after it need no device-wide synchronisation.  Same records as the fully synchronised sequence, 40 windows
+    = 5 batches over 3 slots, repeated with fresh data so that a race would have several chances to show."""
+    import torch
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    nchips, n, nwin = 100000, 200000, 40
+    chips = chips_for(17, 9, nchips)
+    cd = torch.from_numpy(chips).to(dev)
+    band = L.twx_band(*band_godual(FS, n))
+    with Correlator(chips, fs=FS, Nint=1, max_batch=8) as cor:
+        st = lib.twx_stream(cor._h)
+        for rep in range(4):
+            iq = torch.zeros((nwin, n, 2), dtype=torch.int16, device=dev)
+            res = torch.zeros((nwin, D.RESULT_BYTES), dtype=torch.uint8, device=dev)
+            ref = torch.zeros((nwin, D.RESULT_BYTES), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            delays = []
+            for w in range(nwin):
+                d = 1000 + 37 * w + rep
+                delays.append(d)
+                p = synth.SynthParams(delay_q8=d * 256, fstep=synth.fstep_for_df(500.0 + w, FS), phi0=w, amp=300,
+                                      noise_gain=synth.noise_gain_for_sigma(500.0), seed=900 + rep, stream=w)
+                L.check(lib.twx_synth_capture_dev(iq[w].data_ptr(), n, 0, cd.data_ptr(), nchips, 2, 1, _params(p).ctypes.data_as(C.c_void_p), st))
+            # producer still running on twx_stream(ctx): no synchronisation here
+            L.check(lib.twx_process_windows_dev(cor._h, iq.data_ptr(), nwin, 1, 0, C.byref(band), None, res.data_ptr()), cor._h)
+            host = np.empty((nwin, D.RESULT_BYTES), dtype=np.uint8)
+            # consumer on the same stream: a plain stream synchronise of twx_stream(ctx) must be enough to see every record
+            assert torch.cuda.ExternalStream(st).synchronize() is None
+            L.check(lib.twx_memcpy_d2h(host.ctypes.data_as(C.c_void_p), res.data_ptr(), host.nbytes))
+            torch.cuda.synchronize()
+            L.check(lib.twx_process_windows_dev(cor._h, iq.data_ptr(), nwin, 1, 0, C.byref(band), None, ref.data_ptr()), cor._h)
+            cor.synchronize(); torch.cuda.synchronize()
+            assert np.array_equal(host, ref.cpu().numpy())
+            recs = D.results_from_bytes(host)
+            assert [r.indice for r in recs] == [3 * d for d in delays]
+
+
+def test_caf_bins_device_pointer_form():
+    import torch
+    dev = torch.device("cuda", 0)
+    nchips, n = 10000, 20000
+    chips = chips_for(14, 43, nchips)
+    p = synth.SynthParams(delay_q8=6543 * 256, fstep=synth.fstep_for_df(7 * FS / n, FS), phi0=77, amp=400,
+                          noise_gain=synth.noise_gain_for_sigma(300.0), seed=8)
+    raw = synth.synth_channel(n, chips, 2, p)
+    iq = torch.from_numpy(raw).to(dev)
+    with Correlator(chips, fs=FS, Nint=0) as cor:
+        pk, lag = cor.caf_bins(raw, -40, 40)
+        pkd, lagd = cor.caf_bins_dev(iq.data_ptr(), -40, 40)
+    assert np.array_equal(lag, lagd) and np.array_equal(pk, pkd) and lag[47] == 6543
