@@ -111,9 +111,11 @@ __global__ void k_sliding_reduce(const double* __restrict__ partial, int nchunks
 // samples per workgroup: at most SD_CH (the LDS segment), chosen so that the grid is a whole number of "rounds" of two
 // workgroups per CU (a 600-workgroup grid on 512 slots runs a second, mostly empty round)
 int sliding_chunk(long long nobs, int ncodes) {
-    int ncu = 256;
-    hipDeviceProp_t prop; int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    static const int ncu = [] {                                    // one process drives one GPU (or GPUs of one kind)
+        int n = 256, dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) return n;
+        return 256;
+    }();
     const long long slots = 2ll * ncu;
     const long long min_chunks = (nobs + SD_CH - 1) / SD_CH;
     const long long rounds = std::max<long long>(1, (min_chunks * ncodes + slots - 1) / slots);
