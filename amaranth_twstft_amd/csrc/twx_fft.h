@@ -179,7 +179,7 @@ template <typename T, int R, int E, bool INV> TWX_HD cpx<T> cmul_const(cpx<T> a)
 // ------------------------------------------------------------------------------------------
 template <int R> struct FirstFactor {
     static constexpr int value = (R % 4 == 0 && R > 4) ? 4 : (R % 5 == 0 && R > 5) ? 5
-                               : (R % 2 == 0 && R > 2) ? 2 : (R % 3 == 0 && R > 3) ? 3 : R;
+                               : (R % 2 == 0 && R > 2) ? 2 : (R % 3 == 0 && R > 3) ? 3 : (R % 7 == 0 && R > 7) ? 7 : R;
 };
 
 template <typename T, int R, bool INV, int A = FirstFactor<R>::value> struct Bfly {
@@ -260,6 +260,33 @@ template <typename T, bool INV> struct Bfly<T, 5, INV, 5> {
         v[0] = v[0] + t1 + t2;
         v[1] = INV ? cadd_pi(a1, b1) : cadd_mi(a1, b1); v[4] = INV ? cadd_mi(a1, b1) : cadd_pi(a1, b1);
         v[2] = INV ? cadd_pi(a2, b2) : cadd_mi(a2, b2); v[3] = INV ? cadd_mi(a2, b2) : cadd_pi(a2, b2);
+    }
+};
+
+// radix 7 (prime): pairs (n, 7-n) → three sums a_j and three differences b_j;  y[k] = x0 + sum_j a_j cos(2 pi j k/7)
+// -+ i sum_j b_j sin(2 pi j k/7), and y[7-k] is its mirror.  Needed for window lengths with a factor 7 (a native
+// 70 Msps x 1 s window is 2^7 5^7 7 samples); 14 = 2*7 and 21 = 3*7 build on it.
+template <typename T, bool INV> struct Bfly<T, 7, INV, 7> {
+    static TWX_HD void run(cpx<T>* v) {
+        constexpr T c1 = T(0.62348980185873353052500488400424), c2 = T(-0.22252093395631440428890256449679),
+                    c3 = T(-0.90096886790241912623610231950745);                       // cos(2 pi j/7)
+        constexpr T s1 = T(0.78183148246802980870844452667406), s2 = T(0.97492791218182360701813168299393),
+                    s3 = T(0.43388373911755812047576833284836);                        // sin(2 pi j/7)
+        const cpx<T> a1 = v[1] + v[6], a2 = v[2] + v[5], a3 = v[3] + v[4];
+        const cpx<T> b1 = v[1] - v[6], b2 = v[2] - v[5], b3 = v[3] - v[4];
+        const cpx<T> x0 = v[0];
+        // k = 1: cos(1,2,3 · 2pi/7) = c1 c2 c3, sin = s1 s2 s3;  k = 2: indices 2,4,6 → c2 c3 c1, s2 -s3 -s1;  k = 3: 3,6,9 → c3 c1 c2, s3 -s1 s2
+        const cpx<T> p1 = x0 + cscale(a1, c1) + cscale(a2, c2) + cscale(a3, c3);
+        const cpx<T> p2 = x0 + cscale(a1, c2) + cscale(a2, c3) + cscale(a3, c1);
+        const cpx<T> p3 = x0 + cscale(a1, c3) + cscale(a2, c1) + cscale(a3, c2);
+        const cpx<T> q1 = cscale(b1, s1) + cscale(b2, s2) + cscale(b3, s3);
+        const cpx<T> q2 = cscale(b1, s2) - cscale(b2, s3) - cscale(b3, s1);
+        const cpx<T> q3 = cscale(b1, s3) - cscale(b2, s1) + cscale(b3, s2);
+        v[0] = x0 + a1 + a2 + a3;
+        // forward: y[k] = p_k - i q_k, y[7-k] = p_k + i q_k
+        v[1] = INV ? cadd_pi(p1, q1) : cadd_mi(p1, q1); v[6] = INV ? cadd_mi(p1, q1) : cadd_pi(p1, q1);
+        v[2] = INV ? cadd_pi(p2, q2) : cadd_mi(p2, q2); v[5] = INV ? cadd_mi(p2, q2) : cadd_pi(p2, q2);
+        v[3] = INV ? cadd_pi(p3, q3) : cadd_mi(p3, q3); v[4] = INV ? cadd_mi(p3, q3) : cadd_pi(p3, q3);
     }
 };
 

@@ -3,7 +3,7 @@
 The reference correlates against whatever code file it finds (``code=fread(f,inf,'int8')``,
 processing/Octave/godual_ranging.m:62-66), so the window length N = n_chips*sps is arbitrary.  The library does a
 length-N transform as N1 x N2 (column pass x row pass) with kernels instantiated at COMPILE time per
-length; it ships the pairs the reference's own code files need.  For any other N = 2^a 3^b 5^c this module
+length; it ships the pairs the reference's own code files need.  For any other N = 2^a 3^b 5^c 7^d this module
 
 * picks a split N = N1*N2 and stage radices that fit the kernels' budgets (one butterfly task per thread, <= 1024
   threads, the exchange buffers in LDS, radices <= 25 so that a butterfly stays in registers),
@@ -30,11 +30,12 @@ PLAN_DIR = os.environ.get("TWX_PLAN_DIR") or os.path.join(_HERE, "plans")
 HIPCC = os.environ.get("HIPCC") or "/opt/rocm/bin/hipcc"
 MAX_RADIX = 25
 MAX_THREADS = 1024
+MAX_N1 = 10240                    # a column of complex double, one per workgroup, still fits the 160 KB of LDS
 LDS_BUDGET = 80 * 1024            # bytes per workgroup that still leave room for a second one on the CU
 
 
 def _smooth(n: int) -> bool:
-    for p in (2, 3, 5):
+    for p in (2, 3, 5, 7):
         while n % p == 0:
             n //= p
     return n == 1
@@ -45,7 +46,7 @@ def _radix_ok(r: int) -> bool:
 
 
 def stage_radices(L: int, max_stages: int = 4):
-    """All ways to write L as a product of 1..max_stages radices (each 2^a 3^b 5^c <= 25), best first:
+    """All ways to write L as a product of 1..max_stages radices (each 2^a 3^b 5^c 7^d <= 25), best first:
     fewer stages, then the largest minimum radix (fewest tasks per stage)."""
     cands = [r for r in range(2, MAX_RADIX + 1) if _radix_ok(r) and L % r == 0]
     out = []
@@ -125,7 +126,7 @@ def choose(n: int):
         if n % n2:
             continue
         n1 = n // n2
-        if n1 > 4096:
+        if n1 > MAX_N1:
             continue
         rp = row_plan(n2)
         if rp is None:
@@ -180,6 +181,10 @@ def _compile(src, out, defs):
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function",
            os.path.join(CSRC, src), "-o", tmp, "-L" + _HERE, "-ltwstft_hip", "-Wl,-rpath,$ORIGIN/.."] + defs
     r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode and "local memory" in r.stderr and "double" in r.stderr and "-DTWX_NO_F64" not in defs:
+        # the complex-double instantiation of a long plan does not fit the 160 KB of LDS: fp32 contexts only
+        # (the code spectrum is then computed in fp32 as well, Ctx::make_code_spectrum)
+        return _compile(src, out, defs + ["-DTWX_NO_F64"])
     if r.returncode:
         raise RuntimeError("plan build failed:\n" + " ".join(cmd) + "\n" + r.stderr[-3000:])
     os.replace(tmp, out)
@@ -204,7 +209,7 @@ def build_row(rp) -> str:
 
 def ensure(n: int, precision: int = 0, lib=None, verbose: bool = False):
     """Make a plan pair for a window of ``n`` samples available to the library; returns the plug-in files it loaded
-    ([] when the library already had one).  Raises ValueError for lengths outside 2^a 3^b 5^c or the kernels' budgets."""
+    ([] when the library already had one).  Raises ValueError for lengths outside 2^a 3^b 5^c 7^d or the kernels' budgets."""
     from . import _lib as L
     lib = lib or L.load()
     if lib.twx_plan_source_hash().decode() != source_hash():
@@ -213,7 +218,7 @@ def ensure(n: int, precision: int = 0, lib=None, verbose: bool = False):
         return []
     ch = choose(int(n))
     if ch is None:
-        raise ValueError(f"no N1 x N2 plan for a window of {n} samples (needs n even, = 2^a 3^b 5^c, N2 <= 10000, N1 <= 4096)")
+        raise ValueError(f"no N1 x N2 plan for a window of {n} samples (needs n even, = 2^a 3^b 5^c 7^d, N2 <= 10000, N1 <= %d)" % MAX_N1 + "")
     cp, rp = ch
     # reuse what the library already has (built-in or loaded) for either half
     import ctypes as C

@@ -108,7 +108,7 @@ int twx_abi_version(void);
 
 /* Transform lengths.  A window of N = n_chips*sps samples is transformed as N1 x N2 (column pass x row pass); the
  * library is built with the pairs the reference's code lengths need and takes further lengths
- * N = 2^a 3^b 5^c from plan plug-ins: shared objects compiled from the same kernel sources for one more length
+ * N = 2^a 3^b 5^c 7^d from plan plug-ins: shared objects compiled from the same kernel sources for one more length
  * (`python -m amaranth_twstft_amd.plans N`, needs hipcc), loaded explicitly with twx_load_plan() or found by
  * twx_create() in the directory `plans/` beside the library (TWX_PLAN_DIR overrides).  The reference reads any code
  * file (godual_ranging.m:62-66); twx_create() answers TWX_E_SIZE only when no plan pair exists for the length.

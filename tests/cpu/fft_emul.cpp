@@ -103,6 +103,9 @@ int main() {
     using P25 = Plan<25, 25>; using P6 = Plan<6, 6>; using P12 = Plan<12, 12>; using P15 = Plan<15, 15>;
     CK(P2, 1, 0); CK(P3, 1, 0); CK(P4, 1, 0); CK(P5, 2, 0); CK(P8, 1, 0); CK(P10, 1, 0); CK(P16, 1, 0);
     CK(P20, 1, 0); CK(P25, 4, 0); CK(P6, 1, 0); CK(P12, 1, 0); CK(P15, 1, 0);
+    using P7 = Plan<7, 7>; using P14 = Plan<14, 14>; using P21 = Plan<21, 21>; using P490 = Plan<490, 7, 14, 5>;
+    using P8750 = Plan<8750, 14, 25, 25>; using P7000 = Plan<7000, 14, 20, 25>;
+    CK(P7, 1, 0); CK(P14, 2, 0); CK(P21, 1, 0); CK(P490, 2, 0); CK(P8750, 1, 20); CK(P7000, 1, 0);
     using P50 = Plan<50, 5, 10>; using P100 = Plan<100, 10, 10>; using P200 = Plan<200, 10, 20>;
     using P625 = Plan<625, 25, 25>; using P500 = Plan<500, 20, 25>; using P1000 = Plan<1000, 10, 10, 10>;
     using P8000 = Plan<8000, 20, 20, 20>; using P4000 = Plan<4000, 10, 20, 20>; using P400 = Plan<400, 20, 20>;

@@ -154,9 +154,9 @@ def test_lowpass_taps_match_an_independent_windowed_sinc():
 def test_plan_generator_covers_the_reference_code_lengths():
     """amaranth_twstft_amd/plans.py: a split N1 x N2 with valid stage radices for every window length the reference's code files
     give at 1, 2 and 4 samples per chip (experiments/221207_twoway_codes/codes/*, 231001_DLL_PLL/{0,1}.bin), the 1-ms
-    plumbing window and power-of-two acquisition transforms."""
+    plumbing window, power-of-two acquisition transforms and lengths with a factor 7 (a native 70 Msps x 1 s window)."""
     from amaranth_twstft_amd import plans
-    lengths = [c * s for c in (2500, 5000, 10000, 25000, 50000, 100000, 250000, 500000, 2500000) for s in (1, 2, 4)] + [1 << 16, 1 << 20, 30000, 486000]
+    lengths = [c * s for c in (2500, 5000, 10000, 25000, 50000, 100000, 250000, 500000, 2500000) for s in (1, 2, 4)] + [1 << 16, 1 << 20, 30000, 486000, 14000, 70_000_000]
     for n in lengths:
         ch = plans.choose(n)
         assert ch is not None, n
@@ -169,7 +169,7 @@ def test_plan_generator_covers_the_reference_code_lengths():
                 prod *= r
             assert prod == pl["L"]
         assert (cp["L"] // min(cp["radices"])) * cp["W"] <= cp["nt"] <= 1024 and rp["L"] // min(rp["radices"]) <= rp["nt"] <= 1024
-    assert plans.choose(7000) is None and plans.choose(5001) is None        # a factor 7 / an odd length have no plan
+    assert plans.choose(22000) is None and plans.choose(5001) is None        # a factor 11 / an odd length have no plan
 
 
 @pytest.mark.slow

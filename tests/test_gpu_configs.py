@@ -416,11 +416,12 @@ def test_mex_gateway_runs_and_matches_the_ctypes_path(tmp_path):
 # --------------------------------------------------------------------------------------------------------------
 # window lengths outside the built-in plan list (plan plug-ins, amaranth_twstft_amd/plans.py)
 # --------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("bitlen,taps,nchips,Nint", [(13, 27, 2500, 0), (13, 27, 2500, 1), (15, 3, 12500, 1), (16, 45, 32768, 1)])
+@pytest.mark.parametrize("bitlen,taps,nchips,Nint", [(13, 27, 2500, 0), (13, 27, 2500, 1), (15, 3, 12500, 1), (16, 45, 32768, 1), (13, 27, 7000, 1)])
 def test_plan_plugins_generic_lengths(bitlen, taps, nchips, Nint):
     """BASELINE.json configs[0] (1-ms window: N = 5000, first 2500 chips of LFSR(13, 27); SURVEY §8d C1: delay 1234,
     A = 300, sigma = 600, code-phase-only, Nint 0 and 1), an odd code length (N = 25000) and a power-of-two window
-    (N = 65536): none of them is in the built-in plan list, all run through plug-ins of the same kernels."""
+    (N = 65536) and one with a factor 7 (N = 14000: radix-7 butterflies): none of them is in the built-in plan list,
+    all run through plug-ins of the same kernels."""
     from tests.test_gpu_parity import _check
     from amaranth_twstft_amd import plans
     chips = chips_for(bitlen, taps, nchips)
@@ -450,6 +451,53 @@ def test_plan_plugins_generic_lengths(bitlen, taps, nchips, Nint):
         o = orc.processing(d, k, freq, temps, fcode, code, Nint=Nint, fs=FS, df=0.0 if nchips == 2500 else None)
         _check(got[w], o)
         assert got[w].indice == (2 * Nint + 1) * 1234
+
+
+def test_native_70msps_window_without_decimation():
+    """BASELINE.json configs[4] read the other way: the 70 Msps capture correlated at its NATIVE rate, one window of
+    N = 7e7 samples (28 samples per chip, 2^7 5^7 7: an 8000 x 8750 plan with radix-14 rows, fp32 only: the complex-double
+    rows do not fit the LDS).  Gates: lag = 3 x the generator's delay, the same lag as the FIR + decimate-by-14 route sees
+    (configs[4] test above), and - when the host has the memory for a 2.1e8-point numpy ifft - bit-exact lag and 1e-6
+    |peak| against the oracle on the same samples."""
+    import psutil
+    import torch
+    dev = torch.device("cuda", 0)
+    fs, sps, n = 70e6, 28, 70_000_000
+    chips = chips_for(22, 57, NCHIPS)
+    d0 = 18_364_717
+    p = synth.SynthParams(delay_q8=d0 * 256, fstep=synth.fstep_for_df(3.25, fs), phi0=99, amp=2500,
+                          noise_gain=synth.noise_gain_for_sigma(2500.0), seed=401)
+    wide = torch.empty((n, 2), dtype=torch.int16, device=dev)
+    _synth_dev(wide, n, torch.from_numpy(chips).to(dev), NCHIPS, sps, [p])
+    torch.cuda.synchronize()
+    band = band_godual(fs, n)
+    with Correlator(chips, fs=fs, sps=sps, Nint=1) as cor:
+        assert cor.info.n == n and cor.info.n1 * cor.info.n2 == n
+        g = cor.process_dev(wide.data_ptr(), 1, band=band)[0]
+        x = (np.arange(n) % 7 - 3) + 1j * (np.arange(n) % 5 - 2)
+        f = cor.fft(x)
+    assert g.indice == 3 * d0
+    assert abs(g.df - 3.25) <= 0.5 + 1e-9                       # the squared-spectrum arg-max resolves fs/(2N) = 0.5 Hz
+    assert abs(g.correction) < 0.5
+    idx = np.concatenate([np.arange(0, 4096), np.random.default_rng(5).integers(0, n, 4096)])
+    # the transform itself against a direct evaluation of 8192 output bins of a sparse-support input would need the full
+    # FFT; use numpy's (fp64) on the same input
+    ref = np.fft.fft(x)
+    assert np.abs(f[idx] - ref[idx]).max() <= 3e-6 * np.abs(ref).max()
+    del ref, f, x
+    if psutil.virtual_memory().available < 56 * 2 ** 30:
+        pytest.skip("lag and transform checked; the fp64 oracle at N = 7e7 needs ~40 GiB of host memory")
+    raw = wide.cpu().numpy()
+    del wide
+    d = orc.deinterleave(raw, 1, 0)
+    d = d - d.mean()
+    code = orc.make_code(chips, sps)
+    k = np.arange(band[0], band[1] + 1)
+    o = orc.processing(d, k, orc.freq_axis(fs, n), np.arange(n) / fs, orc.make_fcode(code), code, Nint=1, fs=fs)
+    assert g.indice == o["indice"]
+    assert abs(g.df - o["df"]) <= 1e-9
+    assert abs(abs(g.xval) - abs(o["xval"])) <= MAG_TOL * abs(o["xval"])
+    assert abs(g.correction - o["correction"]) <= 2e-4
 
 
 # --------------------------------------------------------------------------------------------------------------
