@@ -241,6 +241,8 @@ def ensure(n: int, precision: int = 0, lib=None, verbose: bool = False):
         if lib.twx_load_plan(os.fsencode(f)) != 0:
             raise RuntimeError("twx_load_plan failed: " + (lib.twx_last_error(None) or b"").decode())
     if not lib.twx_plan_available(int(n), int(precision)):
+        if precision == 1 and lib.twx_plan_available(int(n), 0):
+            raise ValueError(f"window of {n} samples: the complex-double kernels of this plan do not fit the LDS, use precision='f32'")
         raise RuntimeError(f"plan plug-ins {files} loaded but no pair for n = {n} is usable")
     return files
 
