@@ -1214,16 +1214,38 @@ template <typename T> struct Ctx : CtxBase {
         RowArgs<T> ra{};
         ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = A; ra.wshift = wshift_of(col->W); ra.stab_f = stab_f; ra.stab_i = stab_i; ra.spec_out = Ysp;
         if (row->run(ROW_STORE, &ra, (unsigned)N1, stream)) return fail(TWX_E_HIP, "k_row(store) launch failed");
-        for (long long k0 = k_lo; k0 <= k_hi; k0 += nbmax) {
-            const int nb = (int)std::min<long long>(nbmax, k_hi - k0 + 1);
+        // DIF/DIT form of the per-bin row pass (k_rowd_caf) where the row plan has one: Y in block-thread order, several
+        // bins per workgroup, and a bin buffer of its own (up to 64 bins or 2.5 GB per launch instead of the B*R batch windows)
+        static const int caf_bpl = [] { const char* e = getenv("TWX_CAF_BPL"); return e ? std::max(1, atoi(e)) : 64; }();   // bins per launch (measured: 64 x 32 per workgroup best, tools/caf_rate.py)
+        static const bool caf_stockham = getenv("TWX_CAF_STOCKHAM") != nullptr;     // experiments: force the Stockham form
+        const bool dform = cspec_perm && row->rowd && row->S == 3 && !caf_stockham;
+        C* Yperm = nullptr; C* Bzc = Bz; ArgPart<T>* partc = part_peak;
+        int nbpl = nbmax, bpw = 1;
+        if (dform) {
+            if (int rc = sc.get(&Yperm, (size_t)N)) return rc;
+            TWX_LAUNCH((k_cspec_perm<T>), dim3(N1), dim3(256), stream, Ysp, Yperm, N1, N2, row->R[0], row->R[2]);
+            HIPCHK(hipGetLastError());
+            const long long want = std::min<long long>(std::min<long long>(caf_bpl, nbins), std::max<long long>(1, (2560ll << 20) / (N * (long long)sizeof(C))));
+            if (want > nbmax) {
+                if (int rc = sc.get(&Bzc, (size_t)N * want)) return rc;
+                if (int rc = sc.get(&partc, (size_t)ntiles * want)) return rc;
+                nbpl = (int)want;
+            }
+            static const int bpw_env = [] { const char* e = getenv("TWX_CAF_BPW"); return e ? std::max(1, atoi(e)) : 32; }();
+            bpw = bpw_env;
+        }
+        for (long long k0 = k_lo; k0 <= k_hi; k0 += nbpl) {
+            const int nb = (int)std::min<long long>(nbpl, k_hi - k0 + 1);
             CafArgs<T> fa{};
             fa.n = N; fa.n1 = N1; fa.nbins = nb; fa.kappa0 = k0; fa.Y = Ysp; fa.cspec = cspec; fa.stab_i = stab_i;
-            fa.ta = ta; fa.tb = tb; fa.tshift = tshift; fa.scale = (T)scale_pow2; fa.Bz = Bz;
-            if (row->caf(&fa, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row_caf launch failed");
+            fa.ta = ta; fa.tb = tb; fa.tshift = tshift; fa.scale = (T)scale_pow2; fa.Bz = Bzc;
+            fa.Yperm = Yperm; fa.cspec_perm = cspec_perm; fa.dtabs = dtabs; fa.bpw = bpw;
+            const unsigned grid = dform ? (unsigned)(N1 * ((nb + bpw - 1) / bpw)) : (unsigned)(N1 * nb);
+            if (row->caf(&fa, grid, stream)) return fail(TWX_E_HIP, "k_row_caf launch failed");
             ColInvArgs<T> ia{};
-            ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = 1; ia.nwin = nb; ia.Bz = Bz; ia.tw1 = tw1; ia.part = part_peak; ia.zout = nullptr;
+            ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = 1; ia.nwin = nb; ia.Bz = Bzc; ia.tw1 = tw1; ia.part = partc; ia.zout = nullptr;
             if (col->inv(&ia, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_inv launch failed");
-            TWX_LAUNCH((k_caf_reduce<T>), dim3(nb), dim3(256), stream, part_peak, ntiles, 1.0 / scale_pow2 / (double)N, pk_d + (k0 - k_lo), lag_d + (k0 - k_lo));
+            TWX_LAUNCH((k_caf_reduce<T>), dim3(nb), dim3(256), stream, partc, ntiles, 1.0 / scale_pow2 / (double)N, pk_d + (k0 - k_lo), lag_d + (k0 - k_lo));
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipMemcpyAsync(pk, pk_d, sizeof(double) * (size_t)nbins, hipMemcpyDeviceToHost, stream));

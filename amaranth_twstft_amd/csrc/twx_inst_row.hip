@@ -20,17 +20,26 @@ template <typename T> int run(int mode, const void* args, unsigned nblk, hipStre
     return (int)hipGetLastError();
 }
 
+template <class PP> struct HasRowD {
+    static constexpr bool value = (PP::S == 2 && PP::radix(0) == PP::radix(1) && 64 / PP::radix(1) >= 1) ||
+                                  (PP::S == 3 && PP::radix(1) == PP::radix(2));
+};
+
 template <typename T> int caf(const void* args, unsigned nblk, hipStream_t s) {
     const CafArgs<T>& a = *reinterpret_cast<const CafArgs<T>*>(args);
+    if constexpr (HasRowD<P>::value && P::S == 3) {
+        if (a.Yperm) {                                     // DIF/DIT form: the caller passes nblk = N1 * ceil(nbins / bpw)
+            constexpr int NTD = RowD<P, T>::NT_MIN;
+            TWX_LAUNCH((k_rowd_caf<P, T, NTD>), dim3(nblk), dim3(NTD), s, a);
+            return (int)hipGetLastError();
+        }
+    }
+    if (a.Yperm) return -1;
     TWX_LAUNCH((k_row_caf<P, T, PADQ, NT>), dim3(nblk), dim3(NT), s, a);
     return (int)hipGetLastError();
 }
 
 
-template <class PP> struct HasRowD {
-    static constexpr bool value = (PP::S == 2 && PP::radix(0) == PP::radix(1) && 64 / PP::radix(1) >= 1) ||
-                                  (PP::S == 3 && PP::radix(1) == PP::radix(2));
-};
 template <typename T> int rowd(int mode, const void* args, unsigned nblk, hipStream_t s) {
     if constexpr (HasRowD<P>::value) {
         constexpr int NTD = RowD<P, T>::NT_MIN;

@@ -1219,6 +1219,11 @@ template <typename T> struct CafArgs {
     const cpx<T>* ta; const cpx<T>* tb; int tshift;
     T scale;
     cpx<T>* Bz;             // [bin][k1][q2]
+    // DIF/DIT form (k_rowd_caf): Y and the code spectrum in block-thread order, RowD tables, bins per workgroup
+    const cpx<T>* Yperm;    // [k1][q2][u] = Y[k1][q0 + R0 q1 + R0 R q2], u = q0*R + q1 (k_cspec_perm applied to Y); nullptr: Stockham form
+    const cpx<T>* cspec_perm;
+    const cpx<T>* dtabs;
+    int bpw;
 };
 
 template <class P2, typename T, int PADQ, int NT>
@@ -1265,6 +1270,89 @@ __global__ __launch_bounds__(NT) void k_row_caf(CafArgs<T> a) {
         C* out = a.Bz + (long long)bin * a.n + (long long)k1 * N2;
         TWX_UNROLL
         for (int q = 0; q < RIL; ++q) (out + q * NSI)[(unsigned)tid] = cmul(cmul(v[q], ub), s_vc[q]);
+    }
+}
+
+// The same on the DIF/DIT row transform (RowD): one workgroup takes row k1 of `bpw` consecutive bins, so the tables, the
+// W_N^{-k1 q2} factors and the block-thread mapping are set up once, and each bin costs the inverse transform alone
+// (2 workgroup barriers instead of 5).  The k2 rotation of the shifted row becomes an address computation on the
+// block-thread layout: k2' = k2 + cr = s_lo + R0 R ((q2 + s_hi) mod R) with s = q0 + R0 q1 + cr.
+// grid = N1 * ceil(nbins / bpw)
+template <class P2, typename T, int NT>
+__global__ __launch_bounds__(NT, (sizeof(T) == 4 ? 4 : 1)) void k_rowd_caf(CafArgs<T> a) {
+    using C = cpx<T>;
+    using D = RowD<P2, T>;
+    constexpr int N2 = D::L, R = D::R, R0 = D::R0, M = D::M, NU = R0 * R;
+    constexpr int RMAX = R > R0 ? R : R0;
+    static_assert(NT >= D::NT_MIN, "not enough threads for RowD");
+    __shared__ C lds[D::lds_elems];
+    __shared__ C tabs[D::tab_total + R0];
+    C* s_vc = tabs + D::tab_total;
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    // k1 fastest: neighbouring workgroups (one XCD takes a contiguous range of logical ids) read rows k1+kappa .. +bpw-1
+    // of Y shifted by one, so all but one of them are L2 hits; the code-spectrum row is private to the workgroup and
+    // stays in registers for all its bins
+    const int grp = logical / a.n1, k1 = logical % a.n1;
+    const int tid = threadIdx.x;
+    int q0, qi;
+    const bool act = D::blk_map(tid, q0, qi);
+    const int q0c = min(q0, R0 - 1);                       // idle lanes compute valid addresses (their loads are unconditional)
+    const unsigned mask = (1u << a.tshift) - 1u;
+    for (int i = tid; i < D::tab_total; i += NT) tabs[i] = a.dtabs[i];
+    if (tid < R0) {
+        const unsigned m = (unsigned)k1 * (unsigned)tid * (unsigned)M;
+        s_vc[tid] = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
+    }
+    C ub = mk<T>(1, 0);
+    if (tid < M) {
+        const unsigned m = (unsigned)k1 * (unsigned)tid;
+        ub = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
+    }
+    constexpr bool HOLD = sizeof(T) == 4;                  // complex double: 2 x 80 registers would spill, re-read the row per bin
+    C v[RMAX], csr[HOLD ? R : 1];
+    const C* cs = a.cspec_perm + (long long)k1 * N2 + (q0c * R + qi);
+    if constexpr (HOLD) {
+        TWX_UNROLL
+        for (int q2 = 0; q2 < R; ++q2) csr[q2] = cs[q2 * NU];
+    }
+    __syncthreads();
+    const int bin_end = min(a.nbins, (grp + 1) * a.bpw);
+    for (int bin = grp * a.bpw; bin < bin_end; ++bin) {
+        const long long sft = (long long)k1 + a.kappa0 + bin;
+        long long k1s = sft % a.n1; if (k1s < 0) k1s += a.n1;
+        long long cr = ((sft - k1s) / a.n1) % N2; if (cr < 0) cr += N2;
+        {
+            const int sh = q0c + R0 * qi + (int)cr;        // < NU + N2
+            const int s_hi = sh / NU, s_lo = sh - s_hi * NU;
+            const int up = (s_lo % R0) * R + s_lo / R0;
+            const C* yrow = a.Yperm + k1s * N2 + up;
+            TWX_UNROLL
+            for (int q2 = 0; q2 < R; ++q2) {
+                int qq = q2 + s_hi; if (qq >= R) qq -= R;
+                if constexpr (HOLD) v[q2] = yrow[qq * NU]; else v[q2] = cmul(yrow[qq * NU], cs[q2 * NU]);
+            }
+        }
+        if (act) {
+            if constexpr (HOLD) {
+                TWX_UNROLL
+                for (int q2 = 0; q2 < R; ++q2) v[q2] = cmul(v[q2], csr[q2]);
+            }
+            D::iA_pre(tabs, qi, v);
+        }
+        if (bin > grp * a.bpw) __syncthreads();            // the previous bin's stage C has read every block
+        if (act) D::iA_store(lds, q0, qi, v);
+        wave_sync_lds();
+        if (act) D::iB(lds, tabs, q0, qi, v);
+        __syncthreads();
+        if (tid < M) {
+            D::iC(lds, tid, v);
+            C* out = a.Bz + (long long)bin * a.n + (long long)k1 * N2;
+            TWX_UNROLL
+            for (int c = 0; c < R0; ++c) {
+                const C o = cmul3(v[c], ub, s_vc[c]);
+                if (TWX_NT_BZ) __builtin_nontemporal_store(o, out + c * M + (unsigned)tid); else (out + c * M)[(unsigned)tid] = o;
+            }
+        }
     }
 }
 
