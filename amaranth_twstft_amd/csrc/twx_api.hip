@@ -7,6 +7,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <deque>
 #include <future>
 #include <unistd.h>
 #include <dlfcn.h>
@@ -28,15 +29,21 @@ namespace twx {
 #define TWX_MAX_CHANNELS 4
 static int wshift_of(int w) { int sft = 0; while ((1 << sft) < w) ++sft; return sft; }
 LaunchEvents& launch_events() { static thread_local LaunchEvents le; return le; }
-static std::vector<ColOps>& col_reg() { static std::vector<ColOps> v; return v; }
-static std::vector<RowOps>& row_reg() { static std::vector<RowOps> v; return v; }
-void register_col(const ColOps& o) { col_reg().push_back(o); }
-void register_row(const RowOps& o) { row_reg().push_back(o); }
+// Live contexts keep pointers to their plans while plug-ins loaded later register more: a deque never moves its
+// elements on push_back (a vector would leave those pointers dangling), and the mutex orders registration (dlopen's
+// static initialisers, possibly from another thread's twx_create) against lookups.
+static std::deque<ColOps>& col_reg() { static std::deque<ColOps> v; return v; }
+static std::deque<RowOps>& row_reg() { static std::deque<RowOps> v; return v; }
+static std::recursive_mutex& reg_mu() { static std::recursive_mutex m; return m; }
+void register_col(const ColOps& o) { std::lock_guard<std::recursive_mutex> g(reg_mu()); col_reg().push_back(o); }
+void register_row(const RowOps& o) { std::lock_guard<std::recursive_mutex> g(reg_mu()); row_reg().push_back(o); }
 const ColOps* find_col(int L, int f64) {
+    std::lock_guard<std::recursive_mutex> g(reg_mu());
     for (auto& o : col_reg()) if (o.L == L && o.f64 == f64) return &o;
     return nullptr;
 }
 const RowOps* find_row(int L, int f64) {
+    std::lock_guard<std::recursive_mutex> g(reg_mu());
     for (auto& o : row_reg()) if (o.L == L && o.f64 == f64) return &o;
     return nullptr;
 }
@@ -44,6 +51,7 @@ bool choose_split(long long n, int f64, const ColOps** col, const RowOps** row) 
     // Preference: N2 = 4000 where it divides n (its rows leave room for a third resident workgroup and the column
     // length N1 = n/4000 keeps the column workgroups full: measured 26.7 vs 22.8 Gsample/s at n = 2e5, 32.3 vs 29.2
     // at n = 1e6 against N2 = 8000, tools/prof_n.py), otherwise the longest row plan.
+    std::lock_guard<std::recursive_mutex> g(reg_mu());
     const ColOps* bc = nullptr; const RowOps* br = nullptr;
     const char* force = getenv("TWX_N2");                 // experiments: force the row length
     const int forced = force ? atoi(force) : 0;
@@ -1364,6 +1372,7 @@ int twx_plan_available(int64_t n, int32_t precision) {
 }
 int twx_plan_lengths(int32_t kind, int32_t precision, int32_t* lengths, int32_t* widths, int32_t max_entries) {
     int n = 0;
+    std::lock_guard<std::recursive_mutex> g(reg_mu());
     if (kind == 0) { for (auto& o : col_reg()) if (o.f64 == (precision == TWX_F64)) { if (n < max_entries) { if (lengths) lengths[n] = o.L; if (widths) widths[n] = o.W; } ++n; } }
     else { for (auto& o : row_reg()) if (o.f64 == (precision == TWX_F64)) { if (n < max_entries) { if (lengths) lengths[n] = o.L; if (widths) widths[n] = 0; } ++n; } }
     return n;

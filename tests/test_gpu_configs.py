@@ -453,6 +453,30 @@ def test_plan_plugins_generic_lengths(bitlen, taps, nchips, Nint):
         assert got[w].indice == (2 * Nint + 1) * 1234
 
 
+def test_contexts_survive_later_plan_registrations():
+    """A live context keeps pointers to its column/row plans; plug-ins loaded afterwards (another code length) append to
+    the same registry.  The first context must keep working (the registry never moves its entries)."""
+    from amaranth_twstft_amd import plans
+    chips_a = chips_for(14, 43, 10000)                    # N = 20 000: built-in plans
+    n_a = 20000
+    p = synth.SynthParams(delay_q8=4321 * 256, fstep=synth.fstep_for_df(410.0, FS), phi0=3, amp=300,
+                          noise_gain=synth.noise_gain_for_sigma(500.0), seed=9)
+    raw = synth.synth_channel(2 * n_a, chips_a, 2, p)
+    band = band_godual(FS, n_a)
+    with Correlator(chips_a, fs=FS, Nint=1) as a:
+        before = a.process(raw, n_channels=1, channel=0, band=band)
+        others = []
+        for nchips in (2500, 12500, 7000, 3000, 6000, 9000):      # lengths outside the built-in list (plug-ins pre-built by build())
+            n = 2 * nchips
+            assert plans.choose(n) is not None
+            others.append(Correlator(chips_for(15, 3, nchips), fs=FS, Nint=1))
+        after = a.process(raw, n_channels=1, channel=0, band=band)
+        for o in others:
+            o.close()
+    for x, y in zip(before, after):
+        assert x.indice == y.indice == 3 * 4321 and x.xval == y.xval and x.df == y.df
+
+
 def test_native_70msps_window_without_decimation():
     """BASELINE.json configs[4] read the other way: the 70 Msps capture correlated at its NATIVE rate, one window of
     N = 7e7 samples (28 samples per chip, 2^7 5^7 7: an 8000 x 8750 plan with radix-14 rows, fp32 only: the complex-double
