@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <dirent.h>
 #include <mutex>
+#include <new>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -1315,7 +1316,7 @@ const char* twx_strerror(int status) {
 }
 const char* twx_last_error(const twx_ctx* ctx) { return ctx ? ctx->impl->err.c_str() : g_create_err.c_str(); }
 
-int twx_create(const twx_config* cfg, twx_ctx** out) {
+static int create_impl(const twx_config* cfg, twx_ctx** out) {
     if (!cfg || !out) { g_create_err = "null argument"; return TWX_E_ARG; }
     *out = nullptr;
     if (!(cfg->fs > 0) || cfg->sps < 1 || cfg->nint < 0 || cfg->nint > 2 || cfg->n_chips < 1) { g_create_err = "bad fs/sps/nint/n_chips"; return TWX_E_ARG; }
@@ -1345,8 +1346,16 @@ int twx_create(const twx_config* cfg, twx_ctx** out) {
     int rc = guarded(c, [&]() { return c->init(); });
     if (rc) { g_create_err = c->err; delete c; return rc; }
     c->cfg.chips = nullptr;
-    *out = new twx_ctx{c};
+    twx_ctx* h = new (std::nothrow) twx_ctx{c};
+    if (!h) { delete c; g_create_err = "out of host memory"; return TWX_E_NOMEM; }
+    *out = h;
     return TWX_OK;
+}
+// strings, the plan-directory scan and the context allocation can throw: nothing may cross the C boundary
+int twx_create(const twx_config* cfg, twx_ctx** out) {
+    try { return create_impl(cfg, out); }
+    catch (const std::bad_alloc&) { if (out) *out = nullptr; return TWX_E_NOMEM; }
+    catch (...) { if (out) *out = nullptr; return TWX_E_STATE; }
 }
 
 void twx_destroy(twx_ctx* ctx) {

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
+#include <new>
 #include <vector>
 #include "twx_internal.h"
 
@@ -348,10 +349,10 @@ struct DevBuf {          // host-pointer entry points: temporaries of one call
 
 }  // namespace
 
-extern "C" {
+// bodies of the C entry points (std::vector, the context's scratch bookkeeping can throw: see aux_guard below)
 
 // ---- device-resident, on the context's stream, context-owned work buffers ------------------------------------
-int twx_sliding_dot_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t pt, int64_t nobs,
+static int twx_sliding_dot_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t pt, int64_t nobs,
                         int32_t ncodes, int32_t nlag, const float* replica_dev, double ff, double phi, double scale, double* out_dev) {
     if (!ctx) return TWX_E_ARG;
     if (!sliding_args_ok(iq_dev, replica_dev, out_dev, n_channels, channel, nobs, ncodes, nlag, pt, n_samples)) return twx::ctx_fail(ctx, TWX_E_ARG, "twx_sliding_dot_dev: bad argument");
@@ -363,7 +364,7 @@ int twx_sliding_dot_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int
     return rc ? twx::ctx_fail(ctx, rc, "twx_sliding_dot_dev: launch failed") : TWX_OK;
 }
 
-int twx_fir_decimate_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps, int32_t ntaps,
+static int twx_fir_decimate_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps, int32_t ntaps,
                          int32_t dec, void* out_i16_dev, void* out_f32_dev, int64_t* n_out) {
     if (!ctx) return TWX_E_ARG;
     if (!fir_args_ok(iq_dev, taps, n_out, out_i16_dev, out_f32_dev, n_channels, channel, ntaps, dec, n_in)) return twx::ctx_fail(ctx, TWX_E_ARG, "twx_fir_decimate_dev: bad argument");
@@ -390,7 +391,7 @@ int twx_fir_decimate_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_in, int32_t
 }
 
 // ---- host-pointer convenience forms (no context): upload, run on the null stream, download -------------------
-int twx_sliding_dot(const int16_t* iq, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t pt, int64_t nobs,
+static int twx_sliding_dot_impl(const int16_t* iq, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t pt, int64_t nobs,
                     int32_t ncodes, int32_t nlag, const float* replica, double ff, double phi, double scale, double* out) {
     if (!sliding_args_ok(iq, replica, out, n_channels, channel, nobs, ncodes, nlag, pt, n_samples)) return TWX_E_ARG;
     DevBuf dx, dw, dpart, dout;
@@ -404,7 +405,7 @@ int twx_sliding_dot(const int16_t* iq, int64_t n_samples, int32_t n_channels, in
     return hipMemcpy(out, dout.p, out_bytes, hipMemcpyDeviceToHost) == hipSuccess ? TWX_OK : TWX_E_HIP;
 }
 
-int twx_fir_decimate(const int16_t* iq, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps, int32_t ntaps,
+static int twx_fir_decimate_impl(const int16_t* iq, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps, int32_t ntaps,
                      int32_t dec, int16_t* out_i16, float* out_f32, int64_t* n_out) {
     if (!fir_args_ok(iq, taps, n_out, out_i16, out_f32, n_channels, channel, ntaps, dec, n_in)) return TWX_E_ARG;
     const long long nout = (n_in - ntaps) / dec + 1;
@@ -423,4 +424,28 @@ int twx_fir_decimate(const int16_t* iq, int64_t n_in, int32_t n_channels, int32_
     return TWX_OK;
 }
 
+// No exception may cross the C boundary.
+template <class F> static int aux_guard(F f) noexcept {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return TWX_E_NOMEM; }
+    catch (...) { return TWX_E_STATE; }
+}
+
+extern "C" {
+int twx_sliding_dot_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t pt, int64_t nobs,
+                        int32_t ncodes, int32_t nlag, const float* replica_dev, double ff, double phi, double scale, double* out_dev) {
+    return aux_guard([&]() { return twx_sliding_dot_dev_impl(ctx, iq_dev, n_samples, n_channels, channel, pt, nobs, ncodes, nlag, replica_dev, ff, phi, scale, out_dev); });
+}
+int twx_fir_decimate_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps, int32_t ntaps,
+                         int32_t dec, void* out_i16_dev, void* out_f32_dev, int64_t* n_out) {
+    return aux_guard([&]() { return twx_fir_decimate_dev_impl(ctx, iq_dev, n_in, n_channels, channel, taps, ntaps, dec, out_i16_dev, out_f32_dev, n_out); });
+}
+int twx_sliding_dot(const int16_t* iq, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t pt, int64_t nobs,
+                    int32_t ncodes, int32_t nlag, const float* replica, double ff, double phi, double scale, double* out) {
+    return aux_guard([&]() { return twx_sliding_dot_impl(iq, n_samples, n_channels, channel, pt, nobs, ncodes, nlag, replica, ff, phi, scale, out); });
+}
+int twx_fir_decimate(const int16_t* iq, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps, int32_t ntaps,
+                     int32_t dec, int16_t* out_i16, float* out_f32, int64_t* n_out) {
+    return aux_guard([&]() { return twx_fir_decimate_impl(iq, n_in, n_channels, channel, taps, ntaps, dec, out_i16, out_f32, n_out); });
+}
 }  // extern "C"
