@@ -653,15 +653,24 @@ def test_plain_c_client_of_the_abi(tmp_path):
 
 def test_stockham_row_pass_fallback(monkeypatch):
     """TWX_ROWD=0 selects the Stockham row kernels (the form used by plans without equal inner radices)."""
-    monkeypatch.setenv("TWX_ROWD", "0")
     chips, raw = _capture(17, 15, 100000, 2, seed=77)
     n = 200000
     band = band_numpy(FS, n)
+    with Correlator(chips, fs=FS, Nint=0) as cor:                 # default: the DIF/DIT CAF row pass (k_rowd_caf, N2 = 4000)
+        pk_d, lag_d = cor.caf_bins(raw[:n], -70, 70, n_channels=2, channel=0)
+    monkeypatch.setenv("TWX_ROWD", "0")
     with Correlator(chips, fs=FS, Nint=1) as cor:
         got = cor.ranging(raw, n_channels=2, channels=(0,), band=band)
+    with Correlator(chips, fs=FS, Nint=0) as cor:                 # Stockham CAF row pass (k_row_caf) on the same window
+        pk_s, lag_s = cor.caf_bins(raw[:n], -70, 70, n_channels=2, channel=0)
     ref = orc.ranging(raw, chips, fs=FS, Nint=1, n_channels=2, channels=(0,), band="numpy")
     for g, o in zip(got[0], ref[0]):
         _check(g, o)
+    assert np.array_equal(lag_d, lag_s) and np.abs(pk_d - pk_s).max() <= MAG_TOL * pk_s.max()
+    d = orc.deinterleave(raw[:n], 2, 0)
+    d = d - d.mean()
+    ks, pk_o, lag_o = orc.caf_bins_shift(d, orc.make_fcode(orc.make_code(chips, 2)), -70, 70)
+    assert np.array_equal(lag_d, lag_o) and np.abs(pk_d - pk_o).max() <= MAG_TOL * pk_o.max()
 
 
 def test_host_pipeline_many_chunks_per_window_df():
