@@ -16,9 +16,11 @@ Parity pinning (see tests/golden/README.md, tools/make_golden.py):
   * ``processing()`` is pinned by outputs of the reference's own numpy code run in the build
     container on seeded synthetic captures: ``experiments/221219_twoway/processing/
     godual_ranging.py:processing`` (full-precision return values, fine-frequency step on) and
-    ``experiments/221207_twoway_codes/processing/godual_ranging.py:ranging`` (printed rows).
+    ``experiments/221207_twoway_codes/processing/godual_ranging.py:ranging`` (printed rows);
+    with the zero-mean 0/1 replica of ``make_code_variant`` by ``experiments/220830_OP/
+    godual_ranging_OP.py:ranging`` (printed lag, correction and complex peak sample).
   * The reference holds NO test vectors of its own for the correlator, and the
-    Octave-only variants (``processing_claudio``, ``search_df``, ``ranging_tracked``, ``make_code_variant``,
+    Octave-only variants (``processing_claudio``, ``search_df``, ``ranging_tracked``, the QPSK form of ``make_code_variant``,
     ``peak_refine_polyfit``), the C++-only Hamming window
     and the 231001_DLL_PLL acquisition/tracking restatements have no runnable twin here:
     for those functions parity is UNPINNED (hand restatement, cross-checked by identities).
@@ -80,7 +82,9 @@ def make_code(chips: np.ndarray, sps: int = 2) -> np.ndarray:
 
 
 def make_code_variant(chips, chips_q=None, sps: int = 2, unipolar: bool = False, zero_mean: bool = False) -> np.ndarray:
-    """Replica variants of the experiment scripts — UNPINNED (Octave only):
+    """Replica variants of the experiment scripts.  The real zero-mean 0/1 replica is PINNED: it is also what
+    experiments/220830_OP/godual_ranging_OP.py:17-24 builds, and tests/golden/ref220830_op_ranging.json holds that
+    script's own output (tools/make_golden.py gen_220830; tests/test_oracle_golden.py).  The QPSK form is unpinned (Octave only).
     0/1 levels and ``code=code-mean(code)`` (experiments/220616_Besancon/godual.m:5-7, mean removed after repelems);
     complex QPSK code ``codec=codei+j*codeq; codec=codec-mean(codec); repelems`` (experiments/220822_qpsk_vs_bpsk/
     goqpsk.m:10-14, mean removed before repelems — the same thing, the hold does not change the mean)."""

@@ -162,6 +162,25 @@ def test_golden_221207_rows(case):
             assert abs(x - y) <= 0.051
 
 
+def test_golden_220830_op_rows():
+    """Device path with the zero-mean 0/1 replica reproduces the rows printed by the reference's own
+    experiments/220830_OP/godual_ranging_OP.py (tests/golden/ref220830_op_ranging.json): lag bit-exact, correction,
+    and the COMPLEX peak sample (magnitude 1e-6, phase through the complex difference)."""
+    g = load_golden("ref220830_op_ranging.json")
+    c = g["cases"][0]
+    chips, raw = capture_from_desc(c["synth"], c["input_sha256"])
+    fs, n = g["fs"], 2 * len(chips)
+    with Correlator(chips, fs=fs, Nint=g["Nint"], code_levels="unipolar", code_zero_mean=True) as cor:
+        got = cor.process(raw, n_channels=2, channel=0, band=band_numpy(fs, n))
+    assert len(got) == c["nwin"] == len(c["rows"])
+    for a, ref in zip(got, c["rows"]):
+        z = complex(*ref["xval"])
+        assert a.indice == ref["indice"]
+        assert abs(a.correction - ref["correction"]) <= 2e-4
+        assert abs(abs(a.xval) - abs(z)) <= MAG_TOL * abs(z)
+        assert abs(a.xval - z) <= 5e-6 * abs(z)
+
+
 def test_full_size_window_vs_golden_and_oracle():
     """N = 5 000 000 (BASELINE.json configs[1]): lag equals the reference's (221219 golden, C2) and
     everything else matches the oracle run on the same input."""

@@ -75,6 +75,28 @@ def test_oracle_vs_221207_ranging_rows(case):
 
 
 @pytest.mark.slow
+def test_oracle_vs_220830_op_rows():
+    """experiments/220830_OP/godual_ranging_OP.py run by tools/make_golden.py: zero-mean 0/1 replica (:17-24), x3
+    interpolation written with concatenate/fftshift (:50-57), complex peak sample printed (:73).  The oracle's
+    make_code_variant + processing() on the first 1-s window of the same capture."""
+    g = load_golden("ref220830_op_ranging.json")
+    c = g["cases"][0]
+    chips, raw = capture_from_desc(c["synth"], c["input_sha256"])
+    fs, n = g["fs"], 2 * len(chips)
+    code = orc.make_code_variant(chips, None, 2, unipolar=True, zero_mean=True)
+    fcode = np.conj(np.fft.fft(code))
+    freq = orc.freq_axis(fs, n)
+    k = orc.band_numpy(freq, 0.0, 8000.0)
+    d = orc.deinterleave(raw[:n], 2, 0)
+    d = d - d.mean()
+    r = orc.processing(d, k, freq, np.arange(n) / fs, fcode, code, Nint=g["Nint"], fs=fs)
+    ref = c["rows"][0]
+    assert r["indice"] == ref["indice"]
+    assert abs(r["correction"] - ref["correction"]) < 1e-9
+    assert abs(r["xval"] - complex(*ref["xval"])) <= 1e-9 * abs(complex(*ref["xval"]))
+
+
+@pytest.mark.slow
 @pytest.mark.parametrize("case", ["n2M", "n2M_loopback", "n5M_taps57_remote"])
 def test_oracle_vs_221219_processing(case):
     g = load_golden("ref221219_processing.json")

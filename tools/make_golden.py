@@ -11,6 +11,7 @@ What is imported from the reference (never copied):
   * amaranth_twstft/common.py            nextstate()           → LFSR state/chip vectors
   * experiments/221219_twoway/processing/godual_ranging.py     processing() return values
   * experiments/221207_twoway_codes/processing/godual_ranging.py  ranging() printed rows
+  * experiments/220830_OP/godual_ranging_OP.py                    ranging() printed rows (zero-mean 0/1 replica)
   * the code files under experiments/** (data)                 → SHA-256 + prefix
 
 Inputs are synthetic captures from amaranth_twstft_amd.synth (integer-only generator), so the
@@ -179,6 +180,46 @@ def gen_221207():
             "cases": cases}
 
 
+def gen_220830():
+    """experiments/220830_OP/godual_ranging_OP.py: the one-second numpy script of the OP station — zero-mean 0/1 replica
+    (``code=np.repeat(code,2); code=code-np.mean(code)``, :17-24), coarse carrier + mix on channel 1, ×3 zero-padded
+    interpolation written with concatenate/fftshift (:50-57), printed ``p: indice+correction -- xval`` (complex peak
+    sample) per 1-s window (:73).  Hard-wired to fs = 5e6 samples per window, two channels."""
+    ns = load_ref_module("experiments/220830_OP/godual_ranging_OP.py")
+    fs = ns["fs"]
+    bitlen, taps, nchips, nwin = 22, 3, 2500000, 2
+    chips = prn.lfsr_chips(bitlen, taps, nchips)
+    n = 2 * nchips
+    assert n == int(fs)
+    chans = [synth.SynthParams(delay_q8=3141592 * 256 + 64, fstep=synth.fstep_for_df(-2345.5, fs), phi0=987654321, amp=260,
+                               noise_gain=synth.noise_gain_for_sigma(420.0), seed=83, stream=0),
+             synth.SynthParams(delay_q8=1000003 * 256, fstep=0, phi0=0, amp=2500,
+                               noise_gain=synth.noise_gain_for_sigma(120.0), seed=83, stream=1)]
+    raw = synth.synth_capture(n * nwin, chips, 2, chans)
+    with tempfile.TemporaryDirectory() as td:
+        cap = os.path.join(td, "17h05.bin")
+        codef = os.path.join(td, "code.bin")
+        raw.tofile(cap)
+        chips.tofile(codef)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            ns["ranging"](cap, codef)                               # REFERENCE CALL
+    rows = []
+    for ln in buf.getvalue().split("\n"):
+        m = re.match(r"^(\d+): (\d+)\+(\S+) -- \((\S+?)([+-][^+-]+(?:e[+-]?\d+)?)j\)$", ln)
+        if m:
+            rows.append({"p": int(m.group(1)), "indice": int(m.group(2)), "correction": float(m.group(3)),
+                         "xval": [float(m.group(4)), float(m.group(5))], "line": ln})
+    assert len(rows) == nwin, buf.getvalue()[-2000:]
+    for r in rows:
+        print(f"  220830 {r['line']}")
+    return {"source": "experiments/220830_OP/godual_ranging_OP.py:ranging (stdout, channel 1)",
+            "row_format": "p: indice1+correction1 -- xval1   (indice 0-based on the x3 grid; xval = prnmap01[indice1], complex)",
+            "replica": "zero-mean 0/1 code, 2 samples per chip", "band": "numpy(foffset=0,frange=8000)", "Nint": 1, "fs": fs,
+            "cases": [{"name": "op_2win", "synth": synth_desc(n * nwin, bitlen, taps, nchips, 2, chans), "nwin": nwin,
+                       "input_sha256": hashlib.sha256(raw.tobytes()).hexdigest(), "rows": rows}]}
+
+
 def gen_mat_schema():
     """Variable names / shapes / dtypes of result archives the reference repository keeps (the data itself cannot be
     regenerated: the captures are not in the repository) — the schema the later analysis scripts load."""
@@ -197,7 +238,7 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["prn", "221207", "221219", "mat"]
+    todo = a.only.split(",") if a.only else ["prn", "221207", "221219", "220830", "mat"]
     if "mat" in todo:
         print("result-file schemas")
         json.dump(gen_mat_schema(), open(os.path.join(GOLD, "mat_schema.json"), "w"), indent=1)
@@ -207,6 +248,9 @@ def main():
     if "221207" in todo:
         print("221207 ranging() rows")
         json.dump(gen_221207(), open(os.path.join(GOLD, "ref221207_ranging.json"), "w"), indent=1)
+    if "220830" in todo and not a.skip_5m:
+        print("220830 OP ranging() rows")
+        json.dump(gen_220830(), open(os.path.join(GOLD, "ref220830_op_ranging.json"), "w"), indent=1)
     if "221219" in todo:
         print("221219 processing() values")
         json.dump(gen_221219(a.skip_5m), open(os.path.join(GOLD, "ref221219_processing.json"), "w"), indent=1)
