@@ -32,6 +32,8 @@ MAX_RADIX = 25
 MAX_THREADS = 1024
 MAX_N1 = 10240                    # a column of complex double, one per workgroup, still fits the 160 KB of LDS
 LDS_BUDGET = 80 * 1024            # bytes per workgroup that still leave room for a second one on the CU
+LDS_MAX = 160 * 1024               # bytes of LDS a workgroup can have
+ROW_TABLES = 12 * 1024            # stage / ramp tables of the row kernels beside the exchange buffer (complex float)
 
 
 def _smooth(n: int) -> bool:
@@ -86,20 +88,22 @@ def row_plan(L: int):
         if tasks > MAX_THREADS:
             continue
         padq = order[0]
-        lds = (L + L // padq) * 8 * 2             # fp64 contexts use the same plan: budget for complex double
-        if lds > 2 * LDS_BUDGET:
+        lds = (L + L // padq) * 8                 # complex float exchange buffer; fp64 contexts need twice that
+        if lds > LDS_MAX - ROW_TABLES:
             continue
+        f64 = 2 * lds <= LDS_MAX - 2 * ROW_TABLES
         nt = max(64, -(-tasks // 64) * 64)
-        key = (not rowd, len(order), -min(order))
+        key = (not f64, not rowd, len(order), -min(order))
         if best is None or key < best[0]:
-            best = (key, dict(L=L, radices=order, nt=nt, padq=padq, rowd=rowd))
+            best = (key, dict(L=L, radices=order, nt=nt, padq=padq, rowd=rowd, f64=f64))
     return best[1] if best else None
 
 
-def col_plan(L: int, row_len: int):
+def col_plan(L: int, row_len: int, f64: bool = True):
     """Column plan of length L for rows of length ``row_len``: widest tile W in (16, 8, 4, 2, 1) that divides the row
     and keeps tasks*W <= 1024 threads and the exchange in LDS; two-stage plans preferred (their fp32 kernels exchange
-    one component at a time: half the LDS)."""
+    one component at a time: half the LDS).  ``f64``: budget the exchange for complex double as well (False when the row
+    plan of the pair exists in fp32 only: the pair is fp32-only anyway and the tile may be twice as wide)."""
     for W in (16, 8, 4, 2, 1):
         if row_len % W:
             continue
@@ -109,16 +113,18 @@ def col_plan(L: int, row_len: int):
             tasks = (L // min(order)) * W
             if tasks > MAX_THREADS:
                 continue
-            lds = L * W * 16 if len(order) > 1 else 0             # complex double
-            if lds > 2 * LDS_BUDGET:
+            lds = L * W * (16 if f64 else 8) if len(order) > 1 else 0
+            if lds > LDS_MAX:
                 continue
             nt = max(64, -(-tasks // 64) * 64)
-            return dict(L=L, radices=order, W=W, nt=nt)
+            return dict(L=L, radices=order, W=W, nt=nt, f64=f64)
     return None
 
 
-def choose(n: int):
-    """(column plan, row plan) for a window of n samples, or None."""
+def choose(n: int, f64: bool = False):
+    """(column plan, row plan) for a window of n samples, or None.  ``f64``: only pairs whose complex-double kernels fit
+    the LDS as well (fp32 contexts take the widest column tile first, which for very long windows is an fp32-only pair:
+    N = 7e7 runs 16.7 Gsample/s as 7000 x 10000 at W = 2, 11.9 as the fp64-capable 8750 x 8000 at W = 1, tools/n70_rate.py)."""
     if n < 4 or n % 2 or not _smooth(n):
         return None
     best = None
@@ -131,13 +137,15 @@ def choose(n: int):
         rp = row_plan(n2)
         if rp is None:
             continue
-        cp = col_plan(n1, n2) if n1 > 1 else None
+        if f64 and not rp["f64"]:
+            continue
+        cp = col_plan(n1, n2, rp["f64"]) if n1 > 1 else None
         if cp is None:
             continue
         # widest tile first (HBM pieces of 128 B), column workgroups of at least a wave, the DIF/DIT row form, few stages,
         # long rows (fewer, fatter workgroups)
         underfilled = (cp["L"] // min(cp["radices"])) * cp["W"] < 64
-        key = (-cp["W"], underfilled, not rp["rowd"], len(rp["radices"]) + len(cp["radices"]), -n2)
+        key = (-cp["W"], not rp["f64"], underfilled, not rp["rowd"], len(rp["radices"]) + len(cp["radices"]), -n2)   # fp32-only rows: one workgroup per CU
         if best is None or key < best[0]:
             best = (key, cp, rp)
     return (best[1], best[2]) if best else None
@@ -195,7 +203,8 @@ def build_col(cp) -> str:
     out = os.path.join(PLAN_DIR, "col_%d_w%d_%s.so" % (cp["L"], cp["W"], source_hash()))
     if not os.path.exists(out):
         _clean_stale()
-        _compile("twx_inst_col.hip", out, ["-DTWX_PLAN=" + _plan_macro(cp["L"], cp["radices"]), "-DTWX_W=%d" % cp["W"], "-DTWX_NT=%d" % cp["nt"]])
+        _compile("twx_inst_col.hip", out, ["-DTWX_PLAN=" + _plan_macro(cp["L"], cp["radices"]), "-DTWX_W=%d" % cp["W"], "-DTWX_NT=%d" % cp["nt"]]
+                 + ([] if cp.get("f64", True) else ["-DTWX_NO_F64"]))
     return out
 
 
@@ -203,7 +212,8 @@ def build_row(rp) -> str:
     out = os.path.join(PLAN_DIR, "row_%d_%s.so" % (rp["L"], source_hash()))
     if not os.path.exists(out):
         _clean_stale()
-        _compile("twx_inst_row.hip", out, ["-DTWX_PLAN=" + _plan_macro(rp["L"], rp["radices"]), "-DTWX_NT=%d" % rp["nt"], "-DTWX_PADQ=%d" % rp["padq"]])
+        _compile("twx_inst_row.hip", out, ["-DTWX_PLAN=" + _plan_macro(rp["L"], rp["radices"]), "-DTWX_NT=%d" % rp["nt"], "-DTWX_PADQ=%d" % rp["padq"]]
+                 + ([] if rp.get("f64", True) else ["-DTWX_NO_F64"]))
     return out
 
 
@@ -216,7 +226,7 @@ def ensure(n: int, precision: int = 0, lib=None, verbose: bool = False):
         raise RuntimeError("libtwstft_hip.so was built from other kernel sources than csrc/ holds now: rebuild it (make -C csrc) first")
     if lib.twx_plan_available(int(n), int(precision)):
         return []
-    ch = choose(int(n))
+    ch = choose(int(n), precision == 1)
     if ch is None:
         raise ValueError(f"no N1 x N2 plan for a window of {n} samples (needs n even, = 2^a 3^b 5^c 7^d, N2 <= 10000, N1 <= %d)" % MAX_N1 + "")
     cp, rp = ch

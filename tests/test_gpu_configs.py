@@ -479,8 +479,8 @@ def test_contexts_survive_later_plan_registrations():
 
 def test_native_70msps_window_without_decimation():
     """BASELINE.json configs[4] read the other way: the 70 Msps capture correlated at its NATIVE rate, one window of
-    N = 7e7 samples (28 samples per chip, 2^7 5^7 7: an 8000 x 8750 plan with radix-14 rows, fp32 only: the complex-double
-    rows do not fit the LDS).  Gates: lag = 3 x the generator's delay, the same lag as the FIR + decimate-by-14 route sees
+    N = 7e7 samples (28 samples per chip, 2^7 5^7 7: a 7000 x 10000 plan with radix-14 columns, fp32 only: the complex-double
+    forms do not fit the LDS).  Gates: lag = 3 x the generator's delay, the same lag as the FIR + decimate-by-14 route sees
     (configs[4] test above), and - when the host has the memory for a 2.1e8-point numpy ifft - bit-exact lag and 1e-6
     |peak| against the oracle on the same samples."""
     import psutil
