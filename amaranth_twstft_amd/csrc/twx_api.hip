@@ -64,8 +64,11 @@ bool choose_split(long long n, int f64, const ColOps** col, const RowOps** row) 
         const ColOps* c = nullptr;                        // widest column tile of that length whose width divides the row
         for (auto& o : col_reg()) if (o.L == (int)n1 && o.f64 == f64 && r.L % o.W == 0 && (!c || o.W > c->W)) c = &o;
         if (!c) continue;
-        auto rank = [](int L) { return L == 4000 ? (1 << 30) : L; };
-        if (!br || rank(r.L) > rank(br->L)) { br = &r; bc = c; }
+        // widest column tile first (HBM piece size), then the row: 4000, then the longest row that still leaves room for
+        // two workgroups per CU (<= 8192), long rows last — the choice must not change when a plug-in for another length
+        // (e.g. the 10000-point rows of a 7e7 window) happens to be loaded
+        auto rank = [](int L) { return L == 4000 ? (1 << 30) : (L <= 8192 ? L : L - (1 << 20)); };
+        if (!br || c->W > bc->W || (c->W == bc->W && rank(r.L) > rank(br->L))) { br = &r; bc = c; }
     }
     if (!br) return false;
     *col = bc; *row = br;
