@@ -38,9 +38,9 @@ static std::deque<RowOps>& row_reg() { static std::deque<RowOps> v; return v; }
 static std::recursive_mutex& reg_mu() { static std::recursive_mutex m; return m; }
 void register_col(const ColOps& o) { std::lock_guard<std::recursive_mutex> g(reg_mu()); col_reg().push_back(o); }
 void register_row(const RowOps& o) { std::lock_guard<std::recursive_mutex> g(reg_mu()); row_reg().push_back(o); }
-const ColOps* find_col(int L, int f64) {
+const ColOps* find_col(int L, int f64, int W) {            // W = 0: any tile width
     std::lock_guard<std::recursive_mutex> g(reg_mu());
-    for (auto& o : col_reg()) if (o.L == L && o.f64 == f64) return &o;
+    for (auto& o : col_reg()) if (o.L == L && o.f64 == f64 && (W == 0 || o.W == W)) return &o;
     return nullptr;
 }
 const RowOps* find_row(int L, int f64) {
@@ -518,7 +518,7 @@ template <typename T> struct Ctx : CtxBase {
     // conj(fft(code)) in [k1][k2] layout, computed in fp64 when the fp64 plans exist
     int make_code_spectrum() {
         if (int rc = dalloc(&cspec, (size_t)N)) return rc;
-        const ColOps* c64 = find_col(N1, 1); const RowOps* r64 = find_row(N2, 1);
+        const ColOps* c64 = find_col(N1, 1, col->W); const RowOps* r64 = find_row(N2, 1);
         const bool use64 = !std::is_same<T, double>::value && c64 && r64 && c64->W == col->W;
         if (std::is_same<T, double>::value || !use64) return code_spectrum_T<T>(cspec, col, row, tw1, stab_f, ta, tb, tcw, scale_pow2 == 1.0 ? 0.0 : scale_pow2);
         // temporary fp64 tables and buffers

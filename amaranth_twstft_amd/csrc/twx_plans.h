@@ -41,7 +41,7 @@ struct RowOps {
 
 void register_col(const ColOps& o);
 void register_row(const RowOps& o);
-const ColOps* find_col(int L, int f64);
+const ColOps* find_col(int L, int f64, int W = 0);
 const RowOps* find_row(int L, int f64);
 // pick N1 (column plan) × N2 (row plan) for n at the given precision
 bool choose_split(long long n, int f64, const ColOps** col, const RowOps** row);
