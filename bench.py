@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                     "multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the collectives even with one "
+                    "rank (exercises the RCCL calls of the N > 1 path on a one-GPU box)")
     a = ap.parse_args()
 
     if a.cpu_baseline_child:
@@ -180,7 +182,8 @@ def main():
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -208,7 +211,7 @@ def main():
                                           params.ctypes.data_as(C.c_void_p), None))
     torch.cuda.synchronize()
     res = torch.zeros((nwin, C.sizeof(L.twx_result)), dtype=torch.uint8, device=dev)
-    gathered = torch.zeros((world * nwin, C.sizeof(L.twx_result)), dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered = torch.zeros((world * nwin, C.sizeof(L.twx_result)), dtype=torch.uint8, device=dev) if use_dist else None
     band = L.twx_band(*band_godual(FS, N))
     df_true = np.array([1780.75] * nwin, dtype=np.float64)
 
@@ -218,7 +221,7 @@ def main():
         else:
             L.check(lib.twx_process_windows_dev(c._h, iq.data_ptr(), nwin, 1, 0, None, df_true.ctypes.data_as(C.c_void_p),
                                                 res.data_ptr()), c._h)
-        if world > 1:
+        if use_dist:
             L.check(lib.twx_synchronize(c._h), c._h)        # results complete before RCCL reads them
             if a.backend == "nccl":
                 dist.all_gather_into_tensor(gathered, res)        # RCCL over xGMI, 240 B per window
@@ -229,7 +232,7 @@ def main():
                 gathered.copy_(host)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         L.check(lib.twx_synchronize(cor._h), cor._h)
         torch.cuda.synchronize()
@@ -241,7 +244,7 @@ def main():
             step(cor, workload)
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
@@ -341,7 +344,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     cor.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()                   # rank 0 may still have been profiling; leave together
         dist.destroy_process_group()
 

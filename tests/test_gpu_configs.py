@@ -272,6 +272,18 @@ def test_bench_self_launches_its_ranks():
     assert j["n_gpus"] == 2 and j["integer_lag_exact"] and j["value"] > 0 and j["roofline"]["frac"] > 0.05
 
 
+def test_bench_rccl_calls_with_a_world_of_one():
+    """The N > 1 path of bench.py talks to RCCL (backend "nccl"): process group bound to the device, all_gather_into_tensor of
+    the uint8 result records, all_reduce(MAX) of the step time, barrier.  Two ranks cannot share one GPU under RCCL, so the
+    calls themselves run here with one rank (--force-dist); the two-rank logic runs above on gloo."""
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--windows", "9",
+                          "--force-dist", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["integer_lag_exact"] and j["value"] > 0
+
+
 # --------------------------------------------------------------------------------------------------------------
 # single-slot ingest pipeline (TWX_FLAG_PROFILE forces one slot; TWX_STREAMS=1)
 # --------------------------------------------------------------------------------------------------------------
