@@ -1229,7 +1229,7 @@ template <typename T> struct Ctx : CtxBase {
         // DIF/DIT form of the per-bin row pass (k_rowd_caf) where the row plan has one: Y in block-thread order, several
         // bins per workgroup, and a bin buffer of its own (up to 64 bins or 2.5 GB per launch instead of the B*R batch windows)
         static const int caf_bpl = [] { const char* e = getenv("TWX_CAF_BPL"); return e ? std::max(1, atoi(e)) : 64; }();   // bins per launch (measured: 64 x 32 per workgroup best, tools/caf_rate.py)
-        static const bool caf_stockham = getenv("TWX_CAF_STOCKHAM") != nullptr;     // experiments: force the Stockham form
+        const bool caf_stockham = getenv("TWX_CAF_STOCKHAM") != nullptr;            // tests/experiments: force the Stockham form (read per call)
         const bool dform = cspec_perm && row->rowd && row->S == 3 && !caf_stockham;
         C* Yperm = nullptr; C* Bzc = Bz; ArgPart<T>* partc = part_peak;
         int nbpl = nbmax, bpw = 1;

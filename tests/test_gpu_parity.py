@@ -342,6 +342,30 @@ def test_caf_integer_bins_vs_oracle():
     assert ks[best] == df_bins and lag[best] == 6543
 
 
+def test_caf_row_pass_forms_agree_on_random_windows(monkeypatch):
+    """k_rowd_caf (DIF/DIT, several bins per workgroup, rotated block-thread addressing) against k_row_caf (Stockham) on
+    seeded windows from strong signal to pure noise, bins on both sides of zero and far enough out that the k2 rotation
+    carries (|kappa| > N1): every bin's lag identical, peaks within 1e-6."""
+    nchips, n = 100000, 200000                                   # N1 = 50, N2 = 4000
+    chips = chips_for(17, 9, nchips)
+    rng = np.random.default_rng(4242)
+    with Correlator(chips, fs=FS, Nint=0) as cor:
+        assert (cor.info.n1, cor.info.n2) == (50, 4000)
+        for amp in (600, 60, 0):
+            p = synth.SynthParams(delay_q8=int(rng.integers(0, n)) * 256, fstep=synth.fstep_for_df(float(rng.uniform(-3000, 3000)), FS),
+                                  phi0=int(rng.integers(0, 1 << 30)), amp=amp, noise_gain=synth.noise_gain_for_sigma(500.0),
+                                  seed=int(rng.integers(1, 1 << 20)))
+            raw = synth.synth_channel(n, chips, 2, p)
+            for lo, hi in ((-130, 75), (9_990, 10_060), (-100_003, -99_950)):
+                monkeypatch.delenv("TWX_CAF_STOCKHAM", raising=False)
+                pk_d, lag_d = cor.caf_bins(raw, lo, hi)
+                monkeypatch.setenv("TWX_CAF_STOCKHAM", "1")
+                pk_s, lag_s = cor.caf_bins(raw, lo, hi)
+                assert np.array_equal(lag_d, lag_s), (amp, lo, hi)
+                assert np.abs(pk_d - pk_s).max() <= MAG_TOL * pk_s.max()
+    monkeypatch.delenv("TWX_CAF_STOCKHAM", raising=False)
+
+
 def test_caf_arbitrary_frequencies_and_acquire():
     nchips, n = 10000, 20000
     chips = chips_for(14, 57, nchips)
