@@ -399,8 +399,10 @@ template <typename T> struct Ctx : CtxBase {
     struct Slot {
         hipStream_t stream; WinSums* sums; double* dfv; long long* dfidx; C *e1, *e2, *A, *Bz, *dc;
         ArgPart<T>*part_band, *part_peak; twx_result* res_dev; double* fine_u; double* csum_part;
+        short2* planar; WinSums* sums2;      // two-channel captures in all-channel mode: planar copies + both channels' sums (lazy)
     };
     Slot slots[4] = {}; int nslots = 1;
+    bool sums_ready = false;                 // run_batch_in: `sums` already holds this batch's statistics (k_sums_deint2)
     hipEvent_t ev_fork = nullptr, ev_join[4] = {};   // ordering of slots 1.. against slot 0 = twx_stream() (process())
     struct Stage { void* host; short2* dev; size_t bytes; long long w0; int nb; };
     Stage stage[4] = {};     // pinned host + device staging of twx_process_file, kept across calls
@@ -722,6 +724,36 @@ template <typename T> struct Ctx : CtxBase {
                   C* zout /*optional full map, nb must be 1*/, bool same_window = false, int res_stride = 1) {
         return run_batch_in(IN_I16, in, nullptr, nch, same_window ? 0 : (long long)N * nch, remove_mean, nb, band, df_host, out_dev, zout, res_stride);
     }
+    // Both channels of nb windows of a two-channel capture ([I1 Q1 I2 Q2] frames, 16-byte aligned) on the CURRENT slot: one
+    // pass over the frames takes both channels' statistics and writes planar copies (k_sums_deint2), then the chain runs
+    // per channel on 4-byte samples.  df2: per-channel pointers or null.  Records go to out_dev[w*2 + c].
+    static bool frames_ok_2ch(const void* frames) {
+        static const bool off = getenv("TWX_NO_DEINT") != nullptr;      // experiments: the strided path
+        return !off && (reinterpret_cast<unsigned long long>(frames) & 15ull) == 0;
+    }
+    int run_batch_2ch(int slot, const short2* frames, int nb, const twx_band* band, const double* const df2[2], twx_result* out_dev) {
+        Slot& q = slots[slot];
+        if (!q.planar) {
+            if (int rc = dalloc(&q.planar, (size_t)2 * B * N)) return rc;
+            if (int rc = dalloc(&q.sums2, (size_t)2 * B)) return rc;
+        }
+        HIPCHK(hipMemsetAsync(q.sums2, 0, sizeof(WinSums) * 2 * B, stream));
+        {
+            ProfScope ps(this, PC_SUMS, 2ll * nb * N);
+            const int chunks = (int)std::min<long long>(64, std::max<long long>(1, N / 16384));
+            TWX_LAUNCH((k_sums_deint2<0>), dim3(chunks, nb), dim3(256), stream, reinterpret_cast<const int4*>(frames), (long long)N, (long long)N,
+                       q.planar, q.planar + (size_t)B * N, q.sums2, q.sums2 + B);
+            HIPCHK(hipGetLastError());
+        }
+        int rc = TWX_OK;
+        WinSums* keep = sums;
+        for (int c = 0; c < 2 && rc == TWX_OK; ++c) {
+            sums = q.sums2 + (size_t)c * B; sums_ready = true;
+            rc = run_batch(q.planar + (size_t)c * B * N, nb, 1, band, df2 ? df2[c] : nullptr, out_dev + c, nullptr, false, 2);
+        }
+        sums = keep; sums_ready = false;
+        return rc;
+    }
     // intype IN_I16: p0 = short2 samples, aux = channels per sample, wstride in short2;  IN_C64S: p0/p1 = real/imaginary
     // doubles, aux = element stride, wstride in doubles (the mean-removed complex `d` of processing(d,k), godual_ranging.m:12)
     int run_batch_in(int intype, const void* p0, const void* p1, int aux, long long wstride, int rm_mean, int nb, const twx_band* band,
@@ -730,7 +762,9 @@ template <typename T> struct Ctx : CtxBase {
         const int nch = aux;
         SplitPtr sp{reinterpret_cast<const double*>(p0), reinterpret_cast<const double*>(p1)};
         const void* colin = intype == IN_C64S ? static_cast<const void*>(&sp) : p0;
-        if (intype == IN_I16) {
+        if (intype == IN_I16 && sums_ready) {
+            // statistics taken by the de-interleaving pre-pass (run_batch_2ch)
+        } else if (intype == IN_I16) {
             HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums) * nb, stream));
             ProfScope ps(this, PC_SUMS, (long long)nb * N);
             // few, fat chunks: the three 64-bit atomics per workgroup land on the same words of a window
@@ -838,8 +872,22 @@ template <typename T> struct Ctx : CtxBase {
             for (int j = 1; j < nused; ++j) HIPCHK(hipStreamWaitEvent(slots[j].stream, ev_fork, 0));
         }
         int rc = TWX_OK;
+        const bool deint = all && nch == 2 && frames_ok_2ch(iq_dev);
+        std::vector<double> dfc1;
         for (long long w0 = 0; w0 < nwin && rc == TWX_OK; w0 += B) {
             const int nb = (int)std::min<long long>(B, nwin - w0);
+            if (deint) {                                            // both channels of the batch on one slot, next batch on the next
+                const double* d2[2] = {nullptr, nullptr};
+                if (df) {
+                    dfc.resize((size_t)nb); dfc1.resize((size_t)nb);
+                    for (int i = 0; i < nb; ++i) { dfc[(size_t)i] = df[(w0 + i) * 2]; dfc1[(size_t)i] = df[(w0 + i) * 2 + 1]; }
+                    d2[0] = dfc.data(); d2[1] = dfc1.data();
+                }
+                use_slot(k);
+                rc = run_batch_2ch(k, reinterpret_cast<const short2*>(iq_dev) + w0 * N * 2, nb, band, df ? d2 : nullptr, out_dev + w0 * 2);
+                k = (k + 1) % nslots;
+                continue;
+            }
             for (int c = c_lo; c < c_hi && rc == TWX_OK; ++c, k = (k + 1) % nslots) {
                 const double* dfp = nullptr;
                 if (df) {
@@ -987,7 +1035,7 @@ template <typename T> struct Ctx : CtxBase {
         const bool all = ch < 0;
         if (all && nch > TWX_MAX_CHANNELS) return fail(TWX_E_ARG, "too many channels for the all-channel mode");
         const int c_lo = all ? 0 : ch, c_hi = all ? nch : ch + 1, ostride = all ? nch : 1;
-        std::vector<double> dfs((size_t)B, df_const), dfc((size_t)B);
+        std::vector<double> dfs((size_t)B, df_const), dfc((size_t)B), dfc_b((size_t)B);
         for (int k = 0; k < nslots && rc == TWX_OK; ++k) {
             st[k].nb = 0;
             if (st[k].bytes >= win_bytes * B) continue;
@@ -1064,6 +1112,18 @@ template <typename T> struct Ctx : CtxBase {
                 use_slot(k);
                 if (hipMemcpyAsync(st[k].dev, st[k].host, win_bytes * nb, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = fail(TWX_E_HIP, "H2D copy failed"); break; }
                 (void)hipEventRecord(h2d_done[k], stream); h2d.used[k] = true;
+                if (all && nch == 2 && frames_ok_2ch(st[k].dev)) {         // one pass over the frames serves both channels
+                    const double* d2[2] = {nullptr, nullptr};
+                    if (!band) {
+                        if (!df_arr) { d2[0] = d2[1] = dfs.data(); }
+                        else {
+                            dfc.resize((size_t)nb); dfc_b.resize((size_t)nb);
+                            for (int i = 0; i < nb; ++i) { dfc[(size_t)i] = df_arr[(w0 + i) * 2]; dfc_b[(size_t)i] = df_arr[(w0 + i) * 2 + 1]; }
+                            d2[0] = dfc.data(); d2[1] = dfc_b.data();
+                        }
+                    }
+                    rc = run_batch_2ch(k, st[k].dev, nb, band, band ? nullptr : d2, slots[k].res_dev);
+                } else
                 for (int c = c_lo; c < c_hi && rc == TWX_OK; ++c) {        // same staged copy for every requested channel
                     const double* dfp = nullptr;
                     if (!band) {

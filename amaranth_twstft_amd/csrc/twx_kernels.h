@@ -287,6 +287,77 @@ __global__ __launch_bounds__(256) void k_sums(const short2* __restrict__ in, lon
 }
 
 // ------------------------------------------------------------------------------------------
+// k_sums_deint2: two-channel captures ([I1 Q1 I2 Q2] per sample, the B210-era files of godual_ranging.m:76-79) in
+// all-channel mode.  The three input passes of the chain (k_sums, 2 x k_col_fwd) would each fetch the 8-byte frames to
+// use 4 bytes of them, once per channel: 24 B of traffic per channel-sample.  This pass reads the frames ONCE, takes
+// the integer statistics of both channels and writes two planar [I Q] copies (8 B per channel-sample in all); the
+// column passes then read 4 B each.  grid = (chunks, windows); frames must be 16-byte aligned (two per load).
+// ------------------------------------------------------------------------------------------
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_sums_deint2(const int4* __restrict__ in /*two frames per element*/, long long win_stride /*frames*/,
+                                                     long long n, short2* __restrict__ p0, short2* __restrict__ p1,
+                                                     WinSums* __restrict__ sums0, WinSums* __restrict__ sums1) {
+    const int b = blockIdx.y;
+    const int4* p = in + ((long long)b * win_stride >> 1);
+    int2* o0 = reinterpret_cast<int2*>(p0 + (long long)b * n);
+    int2* o1 = reinterpret_cast<int2*>(p1 + (long long)b * n);
+    const long long nv = n >> 1;                                      // n is even (window lengths are)
+    const long long per = (nv + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per, hi = min(nv, lo + per);
+    long long sI[2] = {0, 0}, sQ[2] = {0, 0};
+    unsigned long long sP[2] = {0, 0};
+    auto take = [&](int w, int& aI, int& aQ, unsigned long long& aP) {
+        const int xi = (short)(w & 0xffff), xq = w >> 16;
+        aI += xi; aQ += xq;
+        aP += (unsigned long long)(unsigned int)(xi * xi + xq * xq);
+    };
+    long long k = lo + threadIdx.x;
+    for (; k + 3 * 256 < hi; k += 4 * 256) {
+        typedef int i4v __attribute__((ext_vector_type(4)));            // the nontemporal builtin wants a plain vector type
+        i4v q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = __builtin_nontemporal_load(reinterpret_cast<const i4v*>(p + k + u * 256));   // read exactly once
+        int aI[2] = {0, 0}, aQ[2] = {0, 0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            take(q[u].x, aI[0], aQ[0], sP[0]); take(q[u].z, aI[0], aQ[0], sP[0]);
+            take(q[u].y, aI[1], aQ[1], sP[1]); take(q[u].w, aI[1], aQ[1], sP[1]);
+            o0[k + u * 256] = make_int2(q[u].x, q[u].z);
+            o1[k + u * 256] = make_int2(q[u].y, q[u].w);
+        }
+        sI[0] += aI[0]; sQ[0] += aQ[0]; sI[1] += aI[1]; sQ[1] += aQ[1];
+    }
+    for (; k < hi; k += 256) {
+        const int4 q = p[k];
+        int aI[2] = {0, 0}, aQ[2] = {0, 0};
+        take(q.x, aI[0], aQ[0], sP[0]); take(q.z, aI[0], aQ[0], sP[0]);
+        take(q.y, aI[1], aQ[1], sP[1]); take(q.w, aI[1], aQ[1], sP[1]);
+        o0[k] = make_int2(q.x, q.z);
+        o1[k] = make_int2(q.y, q.w);
+        sI[0] += aI[0]; sQ[0] += aQ[0]; sI[1] += aI[1]; sQ[1] += aQ[1];
+    }
+    __shared__ long long sh[6][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            sI[c] += shfl_down_ll(sI[c], d);
+            sQ[c] += shfl_down_ll(sQ[c], d);
+            sP[c] += (unsigned long long)shfl_down_ll((long long)sP[c], d);
+        }
+        if (lane == 0) { sh[3 * c][wv] = sI[c]; sh[3 * c + 1][wv] = sQ[c]; sh[3 * c + 2][wv] = (long long)sP[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int c = threadIdx.x;
+        WinSums* s = (c == 0 ? sums0 : sums1) + b;
+        atomicAdd((unsigned long long*)&s->sI, (unsigned long long)(sh[3 * c][0] + sh[3 * c][1] + sh[3 * c][2] + sh[3 * c][3]));
+        atomicAdd((unsigned long long*)&s->sQ, (unsigned long long)(sh[3 * c + 1][0] + sh[3 * c + 1][1] + sh[3 * c + 1][2] + sh[3 * c + 1][3]));
+        atomicAdd(&s->sP, (unsigned long long)(sh[3 * c + 2][0] + sh[3 * c + 2][1] + sh[3 * c + 2][2] + sh[3 * c + 2][3]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_df_tables: (optionally) finish the coarse carrier estimate, then build the per-window NCO
 // tables  E1[n1] = exp(-2*pi*i*df*n1*N2/fs),  E2[n2] = exp(-2*pi*i*df*n2/fs)
 // (lo=exp(-j*2*pi*df*temps), godual_ranging.m:17 with temps=[0:N-1]/fs :72).  grid = windows
