@@ -182,10 +182,50 @@ template <int R> struct FirstFactor {
                                : (R % 2 == 0 && R > 2) ? 2 : (R % 3 == 0 && R > 3) ? 3 : (R % 7 == 0 && R > 7) ? 7 : R;
 };
 
+constexpr int cx_gcd(int a, int b) { return b == 0 ? a : cx_gcd(b, a % b); }
+constexpr int cx_inv_mod(int a, int m) {                // a^-1 mod m for coprime a, m (m small)
+    for (int x = 1; x < m; ++x) if ((a * x) % m == 1) return x;
+    return 1;                                           // m == 1
+}
+#ifndef TWX_PFA
+#define TWX_PFA 1
+#endif
+
 template <typename T, int R, bool INV, int A = FirstFactor<R>::value> struct Bfly {
     // composite: R = A*B, input r = A*b + a, output q = qb + B*qa
     static constexpr int B = R / A;
     static TWX_HD void run(cpx<T>* v) {
+        if constexpr (TWX_PFA && cx_gcd(A, B) == 1) {
+            // Coprime factors (20 = 4*5, 10 = 5*2, 12, 14, 15, 18, 21 ...): Good-Thomas prime-factor mapping — with
+            // n = (B a + A b) mod R and k = (B u ka + A w kb) mod R, u = B^-1 mod A, w = A^-1 mod B, the cross terms of
+            // n*k are multiples of R, so DFT_R = (DFT_A x DFT_B) between two permutations and there are NO twiddle
+            // factors between the two layers.  The permutations are compile-time register renamings: a radix-20
+            // butterfly loses its 12 constant complex multiplications (a fifth of its instructions).
+            constexpr int U = cx_inv_mod(B % A, A), W_ = cx_inv_mod(A % B, B);
+            cpx<T> y[A][B];
+            TWX_UNROLL
+            for (int a = 0; a < A; ++a) {
+                cpx<T> t[B];
+                TWX_UNROLL
+                for (int b = 0; b < B; ++b) t[b] = v[(B * a + A * b) % R];
+                Bfly<T, B, INV>::run(t);
+                TWX_UNROLL
+                for (int kb = 0; kb < B; ++kb) y[a][kb] = t[kb];
+            }
+            cpx<T> o[R];
+            TWX_UNROLL
+            for (int kb = 0; kb < B; ++kb) {
+                cpx<T> t[A];
+                TWX_UNROLL
+                for (int a = 0; a < A; ++a) t[a] = y[a][kb];
+                Bfly<T, A, INV>::run(t);
+                TWX_UNROLL
+                for (int ka = 0; ka < A; ++ka) o[(B * U * ka + A * W_ * kb) % R] = t[ka];
+            }
+            TWX_UNROLL
+            for (int i = 0; i < R; ++i) v[i] = o[i];
+            return;
+        }
         cpx<T> y[A][B];
         TWX_UNROLL
         for (int a = 0; a < A; ++a) {
