@@ -119,6 +119,26 @@ template <typename V> __device__ __forceinline__ void st_su(void* ubase, unsigne
     TWX_GLOBAL char* g = (TWX_GLOBAL char*)sgpr_u64(reinterpret_cast<unsigned long long>(ubase));
     *(TWX_GLOBAL V*)(g + lane_bytes) = val;
 }
+// With a base that is ALREADY pinned in SGPRs (sgpr_u64 once, then scalar arithmetic on it): base + uniform_bytes + lane_bytes
+template <typename V, bool NT> __device__ __forceinline__ V ld_pin(unsigned long long pinned, unsigned long long uniform_bytes, unsigned lane_bytes) {
+    const TWX_GLOBAL char* g = (const TWX_GLOBAL char*)(pinned + uniform_bytes);
+    if constexpr (NT) return __builtin_nontemporal_load((const TWX_GLOBAL V*)(g + lane_bytes));
+    else return *(const TWX_GLOBAL V*)(g + lane_bytes);
+}
+template <typename V, bool NT> __device__ __forceinline__ void st_pin(unsigned long long pinned, unsigned long long uniform_bytes, unsigned lane_bytes, V val) {
+    TWX_GLOBAL char* g = (TWX_GLOBAL char*)(pinned + uniform_bytes);
+    if constexpr (NT) __builtin_nontemporal_store(val, (TWX_GLOBAL V*)(g + lane_bytes));
+    else *(TWX_GLOBAL V*)(g + lane_bytes) = val;
+}
+// the same with the non-temporal hint (V must be a plain vector type)
+template <typename V> __device__ __forceinline__ V ld_su_nt(const void* ubase, unsigned lane_bytes) {
+    const TWX_GLOBAL char* g = (const TWX_GLOBAL char*)sgpr_u64(reinterpret_cast<unsigned long long>(ubase));
+    return __builtin_nontemporal_load((const TWX_GLOBAL V*)(g + lane_bytes));
+}
+template <typename V> __device__ __forceinline__ void st_su_nt(void* ubase, unsigned lane_bytes, V val) {
+    TWX_GLOBAL char* g = (TWX_GLOBAL char*)sgpr_u64(reinterpret_cast<unsigned long long>(ubase));
+    __builtin_nontemporal_store(val, (TWX_GLOBAL V*)(g + lane_bytes));
+}
 
 // ------------------------------------------------------------------------------------------
 // input loaders (sample n of the current window → complex T)
@@ -1036,9 +1056,10 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     }
     if constexpr (MODE == ROW_MID) {
         const C* cs = ad.cspec_perm + (long long)k1 * N2;
-        const unsigned ul = (unsigned)min(u, NU - 1);
+        const unsigned ulb = (unsigned)min(u, NU - 1) * (unsigned)sizeof(C);
+        const unsigned long long csb = sgpr_u64(reinterpret_cast<unsigned long long>(cs));
         TWX_UNROLL
-        for (int q2 = 0; q2 < R; ++q2) csr[q2] = (cs + q2 * NU)[ul];
+        for (int q2 = 0; q2 < R; ++q2) csr[q2] = ld_pin<C, false>(csb, (unsigned long long)q2 * NU * sizeof(C), ulb);
     }
     __builtin_amdgcn_sched_barrier(0);
     TWX_UNROLL
@@ -1110,10 +1131,12 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                 D::iC(lds, lt, v);
                 const C uu = cmul(ub, r1);
                 C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
+                const unsigned ltb = (unsigned)lt * (unsigned)sizeof(C);
+                const unsigned long long ob = sgpr_u64(reinterpret_cast<unsigned long long>(out));
                 TWX_UNROLL
                 for (int c = 0; c < R0; ++c) {
                     const C o = cmul3(v[c], uu, s_vc[c]);                                  // · W_N^{-k1 q2} · ramp1
-                    if (TWX_NT_BZ) __builtin_nontemporal_store(o, out + c * M + (unsigned)lt); else (out + c * M)[(unsigned)lt] = o;
+                    st_pin<C, TWX_NT_BZ != 0>(ob, (unsigned long long)c * M * sizeof(C), ltb, o);     // SGPR base + lane offset
                 }
             }
             if (rho + 1 < a.nphase && lact) {
