@@ -330,6 +330,20 @@ template <typename T, bool INV> struct Bfly<T, 7, INV, 7> {
     }
 };
 
+// Gather from a small read-only table in global memory at a 32-bit element index: on the device the wave-uniform base is
+// pinned in SGPRs and the lane part stays a 32-bit byte offset (`global_load v, v_off, s[base:base+1]`); written as
+// tw[idx] the compiler forms a 64-bit VALU address (v_mad_i64_i32) per element.
+template <typename V> TWX_HD V tw_load(const V* tw, unsigned idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long u = reinterpret_cast<unsigned long long>(tw);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    const __attribute__((address_space(1))) char* g = (const __attribute__((address_space(1))) char*)(((unsigned long long)hi << 32) | lo);
+    return *(const __attribute__((address_space(1))) V*)(g + idx * (unsigned)sizeof(V));
+#else
+    return tw[idx];
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // plan: length L as a product of up to four radices (Stockham stage order)
 // ------------------------------------------------------------------------------------------
@@ -418,7 +432,7 @@ template <class P, typename T, bool INV, int W, int PADQ> struct Tile {
         for (int r = 0; r < Rr; ++r) v[r] = lds[in_idx<s>(ib, j, r) * W + c];
         TWX_UNROLL
         for (int r = 1; r < Rr; ++r) {
-            C w = tw[jm * r * step];
+            C w = tw_load(tw, (unsigned)(jm * r * step));
             v[r] = INV ? cmulc(v[r], w) : cmul(v[r], w);
         }
     }
@@ -429,7 +443,7 @@ template <class P, typename T, bool INV, int W, int PADQ> struct Tile {
         constexpr int step = L / (Ns * Rr);
         const int jm = (Ns * Rr == L) ? j : (j % Ns);
         TWX_UNROLL
-        for (int r = 1; r < Rr; ++r) twr[r - 1] = tw[jm * r * step];
+        for (int r = 1; r < Rr; ++r) twr[r - 1] = tw_load(tw, (unsigned)(jm * r * step));
     }
     template <int s> static TWX_HD void load_lds_tw(const C* lds, const C* twr, int j, int c, C* v) {
         constexpr int Rr = P::radix(s);

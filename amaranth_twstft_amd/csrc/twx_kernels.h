@@ -727,7 +727,7 @@ __global__ __launch_bounds__(NT, 6) void k_col_fwd3(In in, ColFwdArgs<T> a) {
         const C wj0 = cmul(a.ta[mj >> a.tshift], a.tb[mj & mask]);
         u[0] = cmul(u[0], wj0);
         TWX_UNROLL
-        for (int r = 1; r < R1; ++r) u[r] = cmul(u[r], cmul(a.tw1[j * r], wj0));
+        for (int r = 1; r < R1; ++r) u[r] = cmul(u[r], cmul(tw_load(a.tw1, (unsigned)(j * r)), wj0));
         TL::template bfly<1>(u);
         // W_N^{k1 n2}, k1 = j + q*QS, n2 = c0 + c: remaining factors W_N^{q QS c0} (LDS) and W_N^{k1 c} (one coalesced 8-B load)
         char* out = reinterpret_cast<char*>(a.out + (long long)b * a.n + (long long)tile * (L * W));
@@ -1656,8 +1656,10 @@ __global__ __launch_bounds__(NT, 6) void k_col_inv3(ColInvArgs<T> a) {
         const unsigned int loff = ((unsigned int)j * (unsigned int)a.n2 + (unsigned int)(c0 + c)) * (unsigned int)sizeof(C);
         const char* cbase = reinterpret_cast<const char*>(src);
         const unsigned long long rstride = (unsigned long long)(L / R0) * (unsigned long long)a.n2 * sizeof(C);
+        // base and row stride pinned in SGPRs, the lane part a 32-bit offset: no 64-bit VALU address per load
+        const unsigned long long cb = sgpr_u64(reinterpret_cast<unsigned long long>(cbase)), rs = sgpr_u64(rstride);
         TWX_UNROLL
-        for (int r = 0; r < R0; ++r) v[r] = (TWX_ABLC == 2) ? mk<T>((T)(tid + r), (T)(r - tid)) : __builtin_nontemporal_load(reinterpret_cast<const C*>(cbase + r * rstride + loff));
+        for (int r = 0; r < R0; ++r) v[r] = (TWX_ABLC == 2) ? mk<T>((T)(tid + r), (T)(r - tid)) : ld_pin<C, true>(cb, r * rs, loff);
         if (TWX_ABLC == 1) {                 // timing-only build: loads, no arithmetic, no exchange
             TWX_UNROLL
             for (int r = 0; r < R0; ++r) asm volatile("" ::"v"(v[r]));
@@ -1688,7 +1690,7 @@ __global__ __launch_bounds__(NT, 6) void k_col_inv3(ColInvArgs<T> a) {
         for (int r = 0; r < R1; ++r) u[r].y = lf[TL::template in_idx<1>(ib, j, r) * W + c];
         constexpr int step = L / (P1R::ns(1) * R1);             // == 1 for a two-stage plan; jm == j
         TWX_UNROLL
-        for (int r = 1; r < R1; ++r) u[r] = cmulc(u[r], a.tw1[j * r * step]);
+        for (int r = 1; r < R1; ++r) u[r] = cmulc(u[r], tw_load(a.tw1, (unsigned)(j * r * step)));
         TL::template bfly<1>(u);
         const unsigned int mbase = (unsigned int)(c0 + c) * (unsigned int)a.nphase + (unsigned int)rho;
         const unsigned int mstep = (unsigned int)a.n2 * (unsigned int)a.nphase;
