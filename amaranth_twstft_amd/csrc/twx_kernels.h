@@ -87,6 +87,9 @@ template <typename T> __device__ __forceinline__ Best<T> wave_best(Best<T> b) {
     }
     return b;
 }
+// max of two finite values as ONE instruction (v_max_f32 / v_max_f64); `a > b ? a : b` compiles to compare + select
+__device__ __forceinline__ float tmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double tmax(double a, double b) { return __builtin_fmax(a, b); }
 // block-wide arg-max; result valid in thread 0. scratch: >= 2*nwaves words of T/uint
 template <typename T, int NT> __device__ __forceinline__ Best<T> block_best(Best<T> b, void* scratch) {
     constexpr int NW = NT / 64;
@@ -1601,7 +1604,7 @@ __global__ __launch_bounds__(NT) void k_col_inv(ColInvArgs<T> a) {
             for (int q = 0; q < R; ++q) {
                 if constexpr (NORM1) { const T s1 = (v[q].x < 0 ? -v[q].x : v[q].x) + (v[q].y < 0 ? -v[q].y : v[q].y); nv[q] = s1 * s1; }
                 else nv[q] = cnorm(v[q]);
-                bv = nv[q] > bv ? nv[q] : bv;
+                bv = tmax(nv[q], bv);
             }
             int bq = 0;
             TWX_UNROLL
@@ -1700,7 +1703,7 @@ __global__ __launch_bounds__(NT, 6) void k_col_inv3(ColInvArgs<T> a) {
         for (int q = 0; q < R1; ++q) {
             if constexpr (NORM1) { const T s1 = (u[q].x < 0 ? -u[q].x : u[q].x) + (u[q].y < 0 ? -u[q].y : u[q].y); nv[q] = s1 * s1; }
             else nv[q] = cnorm(u[q]);
-            bv = nv[q] > bv ? nv[q] : bv;
+            bv = tmax(nv[q], bv);
         }
         int bq = 0;
         TWX_UNROLL
