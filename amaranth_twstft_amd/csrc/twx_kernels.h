@@ -1051,10 +1051,21 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     // the wait-count pass has to assume the branch was skipped and waits for far more than the tables
     {
         const int tl = min(tid, M - 1);
-        TWX_UNROLL
-        for (int r = 0; r < R0; ++r) {
-            const C* q = Ab + a_index((unsigned)(tl + r * M), (unsigned)k1, (unsigned)a.n1, a.wshift);
-            v[r] = TWX_NT_A ? __builtin_nontemporal_load(q) : *q;                   // A is read exactly once
+        if constexpr (M % 16 == 0) {
+            // M is a multiple of every tile width (W <= 16): element tl + r*M of the row sits r*M*N1 elements after element
+            // tl — one a_index per thread (its integer multiply runs at quarter rate) instead of one per element, the
+            // r-dependent part is scalar: SGPR base + scalar offset + 32-bit lane offset
+            const unsigned lb = a_index((unsigned)tl, (unsigned)k1, (unsigned)a.n1, a.wshift) * (unsigned)sizeof(C);
+            const unsigned long long ab = sgpr_u64(reinterpret_cast<unsigned long long>(Ab));
+            const unsigned long long rstep = sgpr_u64((unsigned long long)M * (unsigned long long)a.n1 * sizeof(C));
+            TWX_UNROLL
+            for (int r = 0; r < R0; ++r) v[r] = ld_pin<C, TWX_NT_A != 0>(ab, r * rstep, lb);       // A is read exactly once
+        } else {
+            TWX_UNROLL
+            for (int r = 0; r < R0; ++r) {
+                const C* q = Ab + a_index((unsigned)(tl + r * M), (unsigned)k1, (unsigned)a.n1, a.wshift);
+                v[r] = TWX_NT_A ? __builtin_nontemporal_load(q) : *q;
+            }
         }
     }
     if constexpr (MODE == ROW_MID) {
