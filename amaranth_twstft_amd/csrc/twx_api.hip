@@ -387,6 +387,7 @@ template <typename T> struct Ctx : CtxBase {
     cpx<double>* tw1d = nullptr;
     C* cspec = nullptr;
     C *cspec_perm = nullptr, *dtabs = nullptr, *ea_d = nullptr, *eb_d = nullptr;   // DIF/DIT row pass (k_rowd)
+    C* wr_d = nullptr;            // exp(-2 pi i j/R), j < R: pruned last stage of k_rowd<BAND>
     int use_rowd = 0;
     unsigned char* chips_dev = nullptr;
     // batch buffers
@@ -498,6 +499,9 @@ template <typename T> struct Ctx : CtxBase {
                 t[(size_t)Rr * Rr + (size_t)R0 * Rr + (size_t)q * Rr + x] = Wf((long long)x * q, N2 / Rr);
             }
             if (int rc = upload(&dtabs, t)) return rc;
+            std::vector<C> wr((size_t)Rr);
+            for (int j = 0; j < Rr; ++j) wr[(size_t)j] = Wf(j, Rr);
+            if (int rc = upload(&wr_d, wr)) return rc;
             std::vector<C> a1((size_t)R * NU), b1((size_t)R * 2 * Rr);
             for (int rho = 0; rho < R; ++rho) {
                 for (int q0 = 0; q0 < R0; ++q0) for (int q1 = 0; q1 < Rr; ++q1) {
@@ -754,6 +758,30 @@ template <typename T> struct Ctx : CtxBase {
         sums = keep; sums_ready = false;
         return rc;
     }
+    // The (q1, q2) digit pairs of the row bins k2 = q0 + R0 q1 + R0 R q2 that a search band can touch (k = k1 + N1 k2, every k1
+    // and q0): at most 8 pairs -> the pruned last stage of k_rowd<BAND>, otherwise 0 (full stage).  Rows with R0 > 1 only.
+    void band_pairs(const twx_band* band, int* np, unsigned long long* pq1, unsigned long long* pq2) const {
+        static const bool off = getenv("TWX_NO_PRUNE") != nullptr;
+        *np = 0; *pq1 = 0; *pq2 = 0;
+        if (off || !band || row->S != 3) return;
+        const int R0 = row->R[0], Rr = row->R[2];
+        const long long half = N / 2, cnt = band->k_hi - band->k_lo + 1;
+        const long long kA = (band->k_lo + (N - half)) % N;          // shifted index i -> bin k = (i + N - half) mod N
+        const long long nk2 = (kA % N1 + cnt + N1 - 1) / N1;          // row bins touched, contiguous modulo N2
+        if (nk2 > 64 * (long long)R0) return;
+        int n = 0; unsigned long long a1 = 0, a2 = 0;
+        for (long long j = 0; j < nk2; ++j) {
+            const long long k2 = (kA / N1 + j) % N2, m = k2 / R0;
+            const unsigned q1 = (unsigned)(m % Rr), q2 = (unsigned)(m / Rr);
+            bool seen = false;
+            for (int p = 0; p < n; ++p) if (((a1 >> (8 * p)) & 0xff) == q1 && ((a2 >> (8 * p)) & 0xff) == q2) seen = true;
+            if (seen) continue;
+            if (n == 8) return;
+            a1 |= (unsigned long long)q1 << (8 * n); a2 |= (unsigned long long)q2 << (8 * n); ++n;
+        }
+        if (R0 * n > row->NT) return;
+        *np = n; *pq1 = a1; *pq2 = a2;
+    }
     // intype IN_I16: p0 = short2 samples, aux = channels per sample, wstride in short2;  IN_C64S: p0/p1 = real/imaginary
     // doubles, aux = element stride, wstride in doubles (the mean-removed complex `d` of processing(d,k), godual_ranging.m:12)
     int run_batch_in(int intype, const void* p0, const void* p1, int aux, long long wstride, int rm_mean, int nb, const twx_band* band,
@@ -801,6 +829,7 @@ template <typename T> struct Ctx : CtxBase {
                 ProfScope ps(this, PC_ROW_BAND, (long long)nb * N);
                 if (use_rowd) {
                     RowDArgs<T> rd{}; rd.r = ra; rd.dtabs = dtabs; rd.cspec_perm = cspec_perm; rd.ea_d = ea_d; rd.eb_d = eb_d;
+                    rd.wr = wr_d; band_pairs(band, &rd.nprune, &rd.pr_q1, &rd.pr_q2);
                     if (row->rowd(ROW_BAND, &rd, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_rowd(band) launch failed");
                 } else if (row->run(ROW_BAND, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(band) launch failed");
             }

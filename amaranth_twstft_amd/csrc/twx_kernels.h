@@ -999,6 +999,12 @@ template <typename T> struct RowDArgs {
     const cpx<T>* cspec_perm;        // [k1][q2][u]
     const cpx<T>* ea_d;              // [rho][u]      exp(+2 pi i rho (q0 + R0 q1)/(Rint N2)), u = q0*R + q1
     const cpx<T>* eb_d;              // [rho][2][q2]  exp(+2 pi i rho (R0 R q2 - wrap N2)/(Rint N2))
+    // ROW_BAND with a narrow search band: only the bins k2 = q0 + R0 q1 + R0 R q2 of a few (q1, q2) pairs can lie inside it
+    // (k = k1 + N1 k2; +-20 kHz of a 5-Msps second = |k2| <= 32 of 8000: 4 pairs).  nprune > 0: the last stage is replaced
+    // by one R-term sum per (q0, pair) instead of a full radix-R butterfly in every lane.
+    const cpx<T>* wr;                // [R] exp(-2 pi i j / R)
+    int nprune;                      // number of (q1, q2) pairs, 0 = full last stage
+    unsigned long long pr_q1, pr_q2; // pair p in byte p
 };
 
 __device__ __forceinline__ void wave_sync_lds() {
@@ -1089,11 +1095,33 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     }
     __syncthreads();                                   // all-to-all exchange of the stride-M stage
     if (act) D::f1(lds, tabs, q0, qi, v);
-    wave_sync_lds();
-    if (act) D::f2(lds, q0, qi, v);                    // v[q2] = X[k1 + N1*(q0 + R0 qi + R0 R q2)]
+    bool pruned = false;
+    if constexpr (MODE == ROW_BAND) pruned = ad.nprune > 0;
+    if (!pruned) {
+        wave_sync_lds();
+        if (act) D::f2(lds, q0, qi, v);                // v[q2] = X[k1 + N1*(q0 + R0 qi + R0 R q2)]
+    }
 
     if constexpr (MODE == ROW_BAND) {
         Best<T> best; best.val = T(-1); best.idx = 0xffffffffu;
+        if (pruned) {
+            __syncthreads();                           // stage f1 of every block visible to the whole workgroup
+            if (tid < R0 * ad.nprune) {
+                const int pq0 = tid % R0, p = tid / R0;
+                const int q1 = (int)((ad.pr_q1 >> (8 * p)) & 0xffu), q2 = (int)((ad.pr_q2 >> (8 * p)) & 0xffu);
+                C acc = lds[D::phys(pq0, q1, 0)];
+                int e = 0;
+                TWX_UNROLL
+                for (int i2 = 1; i2 < R; ++i2) {
+                    e += q2; if (e >= R) e -= R;       // (i2 * q2) mod R
+                    acc = acc + cmul(lds[D::phys(pq0, q1, i2)], ad.wr[e]);
+                }
+                const long long half = a.n / 2;
+                const long long k = (long long)k1 + (long long)a.n1 * D::k_of(pq0, q1, q2);
+                long long i = k - (a.n - half); if (i < 0) i += a.n;
+                if (i >= a.band_lo && i <= a.band_hi) best.take(cnorm(acc), (unsigned int)i);
+            }
+        } else
         if (act) {
             const long long half = a.n / 2;
             TWX_UNROLL
