@@ -22,6 +22,9 @@ TWX_FLAG_FINE_FREQ = 2
 TWX_FLAG_CODE_ZERO_MEAN = 4
 TWX_CODE_BIPOLAR, TWX_CODE_UNIPOLAR = 0, 1
 TWX_PROF_MAX = 16
+TWX_TRK_RANGING, TWX_TRK_RE, TWX_TRK_LO = 0, 1, 2
+TWX_CARRIER_SEARCH_DF, TWX_CARRIER_CHUNK_BAND = 0, 1
+TWX_ABI_VERSION = 2
 
 
 class TwxError(RuntimeError):
@@ -58,6 +61,25 @@ class twx_info(C.Structure):
     _fields_ = [("n", C.c_int64), ("n1", C.c_int32), ("n2", C.c_int32), ("nphase", C.c_int32),
                 ("batch", C.c_int32), ("precision", C.c_int32), ("col_w", C.c_int32),
                 ("device_bytes", C.c_int64)]
+
+
+class twx_tracked_config(C.Structure):
+    _fields_ = [("fs", C.c_double), ("sps", C.c_int32), ("nint", C.c_int32),
+                ("chips", C.POINTER(C.c_uint8)), ("n_chips", C.c_int64),
+                ("lfsr_bitlen", C.c_int32), ("lfsr_taps", C.c_int32), ("chunk_samples", C.c_int64),
+                ("band_lo_hz", C.c_double), ("band_hi_hz", C.c_double), ("carrier", C.c_int32), ("indice_floor", C.c_int32),
+                ("df_threshold", C.c_double), ("skip_samples", C.c_int64), ("precision", C.c_int32), ("device", C.c_int32),
+                ("max_batch", C.c_int32), ("reserved", C.c_int32)]
+
+
+class twx_tracked_code(C.Structure):
+    _fields_ = [("xval", C.c_double * 2), ("indice1", C.c_double), ("correction1", C.c_double), ("SNR1r", C.c_double),
+                ("SNR1i", C.c_double), ("puissance1", C.c_double)]
+
+
+class twx_tracked_summary(C.Structure):
+    _fields_ = [("n_codes", C.c_int64), ("n_chunks", C.c_int64), ("n_moved", C.c_int64), ("kbon", C.c_int64),
+                ("batches", C.c_int64), ("puissancecode", C.c_double), ("puissancenoise", C.c_double)]
 
 
 class twx_prof_entry(C.Structure):
@@ -99,6 +121,15 @@ SYMBOLS = {
     "twx_fir_decimate": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_int32, C.c_int32, _VP, _VP, C.POINTER(C.c_int64)]),
     "twx_sliding_dot_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_double, C.c_double, C.c_double, _VP]),
     "twx_fir_decimate_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_int32, C.c_int32, _VP, _VP, C.POINTER(C.c_int64)]),
+    "twx_tracked_defaults": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.POINTER(twx_tracked_config)]),
+    "twx_tracked_create": (C.c_int, [C.POINTER(twx_tracked_config), C.POINTER(_VP)]),
+    "twx_tracked_destroy": (None, [_VP]),
+    "twx_tracked_last_error": (C.c_char_p, [_VP]),
+    "twx_tracked_context": (_VP, [_VP]),
+    "twx_tracked_file": (C.c_int, [_VP, C.c_char_p, C.c_int64, C.c_int64, C.POINTER(twx_tracked_summary)]),
+    "twx_tracked_host": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.POINTER(twx_tracked_summary)]),
+    "twx_tracked_fetch": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "twx_tracked_search_df": (C.c_int, [_VP, _VP, C.c_int64, C.POINTER(C.c_int64)]),
     "twx_debug_stamps": (C.c_int, [_VP, _VP, C.c_longlong]),
     "twx_profile_reset": (C.c_int, [_VP]),
     "twx_profile_get": (C.c_int, [_VP, C.POINTER(twx_prof_entry), C.c_int32, C.POINTER(C.c_int32)]),
@@ -135,7 +166,7 @@ def load():
         fn = getattr(lib, name)            # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.twx_abi_version() != 1:
+    if lib.twx_abi_version() != TWX_ABI_VERSION:
         raise ImportError("libtwstft_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -326,6 +326,8 @@ struct CtxBase {
     void* aux_buf[AUX_SCRATCH_SLOTS] = {}; size_t aux_cap[AUX_SCRATCH_SLOTS] = {};   // ctx_scratch (twx_internal.h)
     std::vector<unsigned char> aux_shadow[AUX_SCRATCH_SLOTS];
     int remove_mean = 1;          // TWX_OPT_REMOVE_MEAN
+    int dbg_only = -1, dbg_repeat = 1;   // TWX_OPT_DEBUG_ONLY / _REPEAT: launch one kernel class of the chain, n times (power / clock probes)
+    int reps(int cls) const { return dbg_only < 0 ? 1 : (dbg_only == cls ? dbg_repeat : 0); }
     int snr_valid = 1;            // 0 for replicas that are not a +-1 code
     virtual int init() = 0;
     virtual int sync_all() = 0;
@@ -797,6 +799,7 @@ template <typename T> struct Ctx : CtxBase {
             ProfScope ps(this, PC_SUMS, (long long)nb * N);
             // few, fat chunks: the three 64-bit atomics per workgroup land on the same words of a window
             const int chunks = (int)std::min<long long>(64, std::max<long long>(1, N / 16384));
+            for (int it = 0, ne = reps(PC_SUMS); it < ne; ++it)
             TWX_LAUNCH((k_sums<0>), dim3(chunks, nb), dim3(256), stream, in, wstride, nch, N, sums);
             HIPCHK(hipGetLastError());
         } else if (intype == IN_C32) {
@@ -823,10 +826,12 @@ template <typename T> struct Ctx : CtxBase {
             ra.band_lo = band->k_lo; ra.band_hi = band->k_hi;
             {
                 ProfScope ps(this, PC_COL_SQ, (long long)nb * N);
+                for (int it = 0, ne = reps(PC_COL_SQ); it < ne; ++it)
                 if (col->fwd(COL_SQUARE, intype, colin, aux, &ca, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_fwd(square) launch failed");
             }
             {
                 ProfScope ps(this, PC_ROW_BAND, (long long)nb * N);
+                for (int it = 0, ne = reps(PC_ROW_BAND); it < ne; ++it)
                 if (use_rowd) {
                     RowDArgs<T> rd{}; rd.r = ra; rd.dtabs = dtabs; rd.cspec_perm = cspec_perm; rd.ea_d = ea_d; rd.eb_d = eb_d;
                     rd.wr = wr_d; band_pairs(band, &rd.nprune, &rd.pr_q1, &rd.pr_q2);
@@ -838,6 +843,7 @@ template <typename T> struct Ctx : CtxBase {
         }
         {
             ProfScope ps(this, PC_DFT, nb);
+            for (int it = 0, ne = reps(PC_DFT); it < ne; ++it)
             TWX_LAUNCH((k_df_tables<T>), dim3(nb), dim3(256), stream, band ? 1 : 0, part_band, N1, dfv, dfidx, cfg.fs,
                                (long long)N, N1, N2, e1, e2);
             HIPCHK(hipGetLastError());
@@ -855,10 +861,12 @@ template <typename T> struct Ctx : CtxBase {
         }
         {
             ProfScope ps(this, PC_COL_MIX, (long long)nb * N);
+            for (int it = 0, ne = reps(PC_COL_MIX); it < ne; ++it)
             if (col->fwd(COL_MIX, intype, colin, aux, &ca, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_fwd(mix) launch failed");
         }
         {
             ProfScope ps(this, PC_ROW_MID, (long long)nb * N);
+            for (int it = 0, ne = reps(PC_ROW_MID); it < ne; ++it)
             if (use_rowd) {
                 RowDArgs<T> rd{}; rd.r = ra; rd.dtabs = dtabs; rd.cspec_perm = cspec_perm; rd.ea_d = ea_d; rd.eb_d = eb_d;
                 if (row->rowd(ROW_MID, &rd, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_rowd(mid) launch failed");
@@ -868,6 +876,7 @@ template <typename T> struct Ctx : CtxBase {
         ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = R; ia.nwin = nb; ia.Bz = Bz; ia.tw1 = tw1; ia.part = part_peak; ia.zout = zout; ia.norm1 = argmax_norm1;
         {
             ProfScope ps(this, PC_COL_INV, (long long)nb * N);
+            for (int it = 0, ne = reps(PC_COL_INV); it < ne; ++it)
             if (col->inv(&ia, (unsigned)(ntiles * R * nb), stream)) return fail(TWX_E_HIP, "k_col_inv launch failed");
         }
         PeakArgs<T> pa{};
@@ -876,6 +885,7 @@ template <typename T> struct Ctx : CtxBase {
         pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.convention = cfg.convention; pa.snr_valid = snr_valid; pa.res = out_dev; pa.res_stride = res_stride;
         {
             ProfScope ps(this, PC_PEAK, nb);
+            for (int it = 0, ne = reps(PC_PEAK); it < ne; ++it)
             TWX_LAUNCH((k_peak<T>), dim3(nb), dim3(1024), stream, pa);
             HIPCHK(hipGetLastError());
         }
@@ -1503,6 +1513,8 @@ int twx_synchronize(twx_ctx* ctx) {
 int twx_set_option(twx_ctx* ctx, int32_t option, int64_t value) {
     if (!ctx) return TWX_E_ARG;
     if (option == TWX_OPT_REMOVE_MEAN) { (void)ctx->impl->sync_all(); ctx->impl->remove_mean = value ? 1 : 0; return TWX_OK; }
+    if (option == TWX_OPT_DEBUG_ONLY) { if (value >= PC_COUNT) return ctx->impl->fail(TWX_E_ARG, "no such kernel class"); ctx->impl->dbg_only = value < 0 ? -1 : (int)value; return TWX_OK; }
+    if (option == TWX_OPT_DEBUG_REPEAT) { ctx->impl->dbg_repeat = (int)std::max<long long>(1, std::min<long long>(value, 1000000)); return TWX_OK; }
     return ctx->impl->fail(TWX_E_ARG, "unknown option");
 }
 void* twx_stream(twx_ctx* ctx) { return ctx ? (void*)ctx->impl->stream : nullptr; }

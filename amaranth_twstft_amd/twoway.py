@@ -120,13 +120,17 @@ def combine(oplo, opre, ltlo, ltre, N: int = 1, codes_per_s: int = 25, outlier_n
                   np.array(rows).reshape(-1, 5))
 
 
-def session(op_local: dict, op_remote: dict, lt_local: dict, lt_remote: dict, fs: float = 5e6, N: int = 1, **kw) -> TwoWay:
+def session(op_local: dict, op_remote: dict, lt_local: dict, lt_remote: dict, fs: float = 5e6, N: int = 1, min_codes: int = 102,
+            **kw) -> TwoWay | None:
     """The per-session body of go_1s.m:83-182: select codes on the LOCAL records, apply the same index set to the
     REMOTE records of the same station, cut at sample losses/gaps, then :func:`combine`.  Each argument is a dict
-    with ``xval1 indice1 correction1`` (the tracked correlator's output)."""
+    with ``xval1 indice1 correction1`` (the tracked correlator's output).  Returns None where the script skips the
+    session: no more than ``min_codes`` usable loop-back codes (``if (length(oplo)>102)``, :102)."""
     k, _ = valid_codes(op_local["xval1"])
     oplo = delays_ns(op_local["indice1"], op_local["correction1"], k, fs, N)
     oplo, _ = cut_at_sample_loss(oplo)
+    if not len(oplo) > min_codes:
+        return None
     xr = np.abs(np.asarray(op_remote["xval1"])[k])
     kkk = np.nonzero(xr > xr.max() / 2)[0]
     gaps = np.nonzero(np.diff(kkk) > 1)[0]
@@ -245,6 +249,8 @@ def process_sessions(root: str, out_dir: str | None = None, fs: float = 5e6, N: 
         if any("xval1" not in r for r in recs.values()):
             continue
         tw = session(recs["op_local"], recs["op_remote"], recs["lt_local"], recs["lt_remote"], fs=fs, N=N)
+        if tw is None:
+            continue
         mjd = mjd_of_unix(ts)
         out.append((mjd, tw, write_1s(out_dir or root, mjd, tw.one_second)))
     return out

@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the collectives even with one "
                     "rank (exercises the RCCL calls of the N > 1 path on a one-GPU box)")
     a = ap.parse_args()
+    t_start = time.perf_counter()
 
     if a.cpu_baseline_child:
         cpu_baseline_child(a.cpu_windows, a.workload, a.cpu_max_workers)
@@ -250,6 +251,7 @@ def main():
             dt = float(tmax.item())
         return dt
 
+    t_ready = time.perf_counter()
     for _ in range(a.warmup):
         step(cor)
     dt = timed(a.workload, a.steps)
@@ -266,6 +268,25 @@ def main():
     arr = (L.twx_result * nwin).from_buffer_copy(host)
     lag_ok = all(int(arr[p].indice0) == 3 * delays[p] for p in range(nwin))
 
+    # --- the collective moved the right data: every rank's block of the gathered buffer must hold THAT rank's lags
+    # (window_params is a pure function of (window, rank), so rank 0 can recompute what every other rank was given)
+    collective = None
+    if use_dist:
+        gh = gathered.cpu().numpy()
+        garr = (L.twx_result * (world * nwin)).from_buffer_copy(gh.tobytes())
+        per_rank = []
+        for r in range(world):
+            ok = all(int(garr[r * nwin + p].indice0) == 3 * window_params(p, r)[1] for p in range(nwin))
+            per_rank.append(bool(ok))
+        own = gh[rank * nwin:(rank + 1) * nwin].tobytes() == host
+        collective = {"op": "all_gather_into_tensor", "backend": a.backend + (" (RCCL)" if a.backend == "nccl" else ""), "world": world,
+                      "records": world * nwin, "bytes_per_rank": nwin * C.sizeof(L.twx_result), "ranks_with_exact_lags": int(sum(per_rank)),
+                      "gathered_lag_exact": bool(all(per_rank)), "own_block_identical": bool(own), "checked_on_rank": rank}
+        # every rank checks its copy; rank 0 reports whether ALL copies were right
+        flag = torch.tensor([1 if (all(per_rank) and own) else 0], dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        collective["all_ranks_agree"] = bool(int(flag.item()) == 1)
+
     samples = world * nwin * N * a.steps
     value = samples / dt / 1e6
     out = {"metric": "Msamples/s correlated (1 s integrations, 2.5 Mchip PRN)", "value": round(value, 2), "unit": "Msamples/s",
@@ -279,6 +300,9 @@ def main():
                       "n1": int(cor.info.n1), "n2": int(cor.info.n2), "sharding": f"windows/{world}",
                       "timed_region_s": round(dt, 3)},
            "integer_lag_exact": bool(lag_ok),
+           "startup_s": {"to_first_step": round(t_ready - t_start, 2),
+                         "note": "process start to the first warm-up step on this rank: imports, CPU baseline (N=1 only), context "
+                                 "creation, synthesis of this rank's recording on its own GPU (ranks start up in parallel)"},
            "other_workload": {"workload": "xcorr, df supplied (code-phase only)" if other == "xcorr" else "processing(d,k) full chain",
                               "value": round(world * nwin * N * a.steps / dt_other / 1e6, 2), "unit": "Msamples/s",
                               "ms_per_step": round(dt_other / a.steps * 1e3, 3)}}
@@ -327,6 +351,8 @@ def main():
             except Exception:
                 pass
 
+    if collective is not None:
+        out["collective"] = collective
     if cpu is not None:
         if "single_core" in cpu:
             n_cpu = cpu["single_core"]["windows"]

@@ -20,7 +20,9 @@
 extern "C" {
 #endif
 
-#define TWX_ABI_VERSION 1
+/* 2: twx_config.reserved became the live field nphase (the struct must be zero-initialised), the tracked-ranging,
+ *    acquisition and *_dev entry points were added.  twx_abi_version() of an older library answers 1. */
+#define TWX_ABI_VERSION 2
 
 typedef struct twx_ctx twx_ctx;
 
@@ -159,7 +161,12 @@ int twx_synchronize(twx_ctx* ctx);
  * NCO (d=d-mean(d), godual_ranging.m:80,94, done by the caller of processing() in the reference);
  * 0 leaves the samples as they are (search_df mixes the raw chunk,
  * acquisition/claudio_aligned_code_ranging_separate.m:34). */
-enum { TWX_OPT_REMOVE_MEAN = 1 };
+enum { TWX_OPT_REMOVE_MEAN = 1,
+       /* Diagnostics (tools/kernel_alone.py): launch only kernel class `value` of the chain (order of twx_profile_get's
+        * names: 0 k_sums, 1 k_col_fwd_square, 2 k_row_band, 3 k_df_tables, 4 k_col_fwd_mix, 5 k_row_mid, 6 k_col_inv,
+        * 7 k_peak; -1 = the whole chain again), TWX_OPT_DEBUG_REPEAT times per batch, on whatever the batch buffers hold
+        * from the last complete call.  Results of such a call are meaningless. */
+       TWX_OPT_DEBUG_ONLY = 100, TWX_OPT_DEBUG_REPEAT = 101 };
 int twx_set_option(twx_ctx* ctx, int32_t option, int64_t value);
 void* twx_stream(twx_ctx* ctx);                      /* hipStream_t of the context */
 
@@ -258,6 +265,65 @@ int twx_sliding_dot_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int
                         double* out_dev);
 int twx_fir_decimate_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps,
                          int32_t ntaps, int32_t dec, void* out_i16_dev, void* out_f32_dev, int64_t* n_out);
+
+/* Tracked multi-code ranging: a whole capture in, per-code delay records out ---------------------------------
+ * Replaces the capture loops of the three production scripts, everything between fopen and `save`:
+ *   acquisition/claudio_aligned_code_ranging_separate.m:143-205 — search_df (:27-47) on the first chunk(s), per chunk the
+ *     carrier from the 7 bins around kbon of fft([dold;d].^2) (:166-169), the 40-ms code loop with processing(dpart,df),
+ *     the MOVED re-alignment (:170-193) and the `dold` carry (:196-200);
+ *   acquisition/claudio_aligned_code_re_separate.m — the same text with the remote band (:137-141);
+ *   acquisition/claudio_aligned_code_lo_separate.m:117-164 — no search: carrier = arg-max of the fresh chunk's
+ *     fftshift(abs(fft(d.^2))) over the whole band k (:126,129), processing(dpart,k,df), floor() of the lag (:134).
+ * The capture is a single-channel int16 [I Q] file (:148-151) or host buffer; chunks stay in device memory and the
+ * codes of a chunk are measured in one batched launch, cut and re-measured where the script re-aligns.
+ * A twx_tracked owns its correlator context (convention claudio, Octave variances); not thread-safe. */
+typedef struct twx_tracked twx_tracked;
+enum { TWX_TRK_RANGING = 0, TWX_TRK_RE = 1, TWX_TRK_LO = 2 };
+enum { TWX_CARRIER_SEARCH_DF = 0,        /* search_df once, then kbon-3..kbon+3 per chunk (ranging, re) */
+       TWX_CARRIER_CHUNK_BAND = 1 };     /* arg-max over the band on every fresh chunk (lo) */
+typedef struct twx_tracked_config {
+    double fs;                /* 5e6 */
+    int32_t sps, nint;        /* 2, 1 */
+    const uint8_t* chips;     /* code file bytes 0/1, or NULL with the LFSR fields below */
+    int64_t n_chips;
+    int32_t lfsr_bitlen, lfsr_taps;
+    int64_t chunk_samples;    /* fs*ls complex samples per fread (:16,148); a whole number of code periods */
+    double band_lo_hz, band_hi_hz;   /* k=find((freq>lo)&(freq<hi)) on freq=linspace(-fs/2,fs/2-1,chunk_samples) (:132-141) */
+    int32_t carrier;          /* TWX_CARRIER_* */
+    int32_t indice_floor;     /* 1: indice1=floor(indice/(2*Nint+1)) (lo :134); 0: plain division (:174) */
+    double df_threshold;      /* 20 (:20) */
+    int64_t skip_samples;     /* the script's fseek(f,30*fs*2*2) (:128) in complex samples; what twx_tracked_file uses when
+                                 its own skip argument is negative */
+    int32_t precision;        /* TWX_F32 / TWX_F64 */
+    int32_t device;           /* -1 = current */
+    int32_t max_batch, reserved;
+} twx_tracked_config;
+/* Fills every mode-dependent field (band, carrier, indice_floor, skip_samples, chunk_samples = 2*fs, df_threshold) and the
+ * script constants sps = 2, nint = 1 for TWX_TRK_*; OP is the station flag of the scripts (band sign of the remote
+ * channel, :137-141).  chips / n_chips / lfsr_* / precision / device are left as they are. */
+int twx_tracked_defaults(int32_t mode, int32_t OP, double fs, twx_tracked_config* cfg);
+/* one code period: xval1(p) indice1(p) correction1(p) SNR1r(p) SNR1i(p) puissance1(p) (:173-174,185) */
+typedef struct twx_tracked_code { double xval[2]; double indice1, correction1, SNR1r, SNR1i, puissance1; } twx_tracked_code;
+typedef struct twx_tracked_summary {
+    int64_t n_codes, n_chunks, n_moved;
+    int64_t kbon;             /* 0-based index of the accepted carrier bin on the shifted chunk axis, -1: none (script: 0) */
+    int64_t batches;          /* batched correlation calls issued (diagnostic) */
+    double puissancecode, puissancenoise;   /* the script's workspace keeps the LAST code's values (:173) */
+} twx_tracked_summary;
+int twx_tracked_create(const twx_tracked_config* cfg, twx_tracked** out);
+void twx_tracked_destroy(twx_tracked* trk);
+const char* twx_tracked_last_error(const twx_tracked* trk);     /* trk may be NULL: last create error */
+twx_ctx* twx_tracked_context(twx_tracked* trk);                /* the correlator context it owns (inspection, profiling) */
+/* Run over a capture file / a host buffer of n_samples complex samples.  skip_samples < 0: the configured skip.
+ * kbon_hint >= 0: carrier bin known beforehand (no search_df).  The records stay in the object until the next run. */
+int twx_tracked_file(twx_tracked* trk, const char* path, int64_t skip_samples, int64_t kbon_hint, twx_tracked_summary* summary);
+int twx_tracked_host(twx_tracked* trk, const int16_t* iq, int64_t n_samples, int64_t skip_samples, int64_t kbon_hint,
+                     twx_tracked_summary* summary);
+/* Copies the records of the last run: codes[n_codes], df[n_chunks] (Hz, one per chunk), moved[n_moved] (the 1-based p
+ * of every re-alignment) and movedval[n_moved]; any pointer may be NULL. */
+int twx_tracked_fetch(twx_tracked* trk, twx_tracked_code* codes, double* df, int64_t* moved, double* movedval);
+/* search_df alone (:27-47) on the first chunk_samples of a host buffer: *kbon as in the summary. */
+int twx_tracked_search_df(twx_tracked* trk, const int16_t* iq, int64_t n_samples, int64_t* kbon);
 
 /* Profiling (TWX_FLAG_PROFILE): per kernel class, HIP-event time on the context's stream. */
 #define TWX_PROF_MAX 16

@@ -20,7 +20,7 @@ Parity pinning (see tests/golden/README.md, tools/make_golden.py):
     with the zero-mean 0/1 replica of ``make_code_variant`` by ``experiments/220830_OP/
     godual_ranging_OP.py:ranging`` (printed lag, correction and complex peak sample).
   * The reference holds NO test vectors of its own for the correlator, and the
-    Octave-only variants (``processing_claudio``, ``search_df``, ``ranging_tracked``, the QPSK form of ``make_code_variant``,
+    Octave-only variants (``processing_claudio``, ``search_df``, ``ranging_tracked``, ``go_1s_session``, the QPSK form of ``make_code_variant``,
     ``peak_refine_polyfit``), the C++-only Hamming window
     and the 231001_DLL_PLL acquisition/tracking restatements have no runnable twin here:
     for those functions parity is UNPINNED (hand restatement, cross-checked by identities).
@@ -355,8 +355,29 @@ def _oround(x: float) -> int:
     return int(np.floor(abs(x) + 0.5)) * (1 if x >= 0 else -1)
 
 
+def tracked_mode(mode: str, OP: int = 0):
+    """The constants that tell the three tracked scripts apart (all else is the same text):
+    ``ranging`` acquisition/claudio_aligned_code_ranging_separate.m (remote=0, ranging=1: band :135, 30-s skip :128),
+    ``re``      acquisition/claudio_aligned_code_re_separate.m (remote=1, ranging=0: band :137-141, skip :127),
+    ``lo``      acquisition/claudio_aligned_code_lo_separate.m (remote=0: band :106, no skip, carrier = arg-max of the
+                fresh chunk's squared spectrum over the whole band :126-129, ``floor`` of the lag :134).
+    Returns dict(band=(lo, hi) open interval in Hz, carrier, indice_floor, skip_seconds, prefix, code_index) with
+    ``code_index`` = the 0-based position in ``dir('n*.bin')`` (:107 / lo :82)."""
+    if mode == "ranging":
+        return dict(band=(-8000.0, 8000.0), carrier="search_df", indice_floor=False, skip_seconds=30.0,
+                    prefix="rangingclaudio", code_index=(OP + 0 + 2) % 2)
+    if mode == "re":
+        band = (-108000.0, -92000.0) if OP == 1 else (92000.0, 108000.0)
+        return dict(band=band, carrier="search_df", indice_floor=False, skip_seconds=30.0,
+                    prefix="remoteclaudio", code_index=(OP + 1) % 2)
+    if mode == "lo":
+        return dict(band=(-20000.0, 20000.0), carrier="chunk_band", indice_floor=True, skip_seconds=0.0,
+                    prefix="localclaudio", code_index=OP % 2)
+    raise ValueError(mode)
+
+
 def ranging_tracked(raw, chips, fs=5e6, sps=2, Nint=1, ls_samples=None, band_hz=8000.0, df_threshold=20.0,
-                    skip_samples=0, kbon=None):
+                    skip_samples=0, kbon=None, band=None, carrier="search_df", indice_floor=False):
     """Tracked multi-code loop of acquisition/claudio_aligned_code_ranging_separate.m:143-205 — UNPINNED
     (Octave only).  ``raw`` = single-channel interleaved int16 ``[I Q]…`` file contents; ``ls_samples``
     = samples per chunk (``fs*ls`` :157).  1-based bookkeeping is kept as in the script, including
@@ -365,6 +386,11 @@ def ranging_tracked(raw, chips, fs=5e6, sps=2, Nint=1, ls_samples=None, band_hz=
     carrier search the file is re-read from its START (:153-155), so ``skip_samples`` only moves the
     chunk that ``search_df`` sees.  Deviation: where the script would index past the chunk after a
     re-alignment (Octave aborts), the first measurement is kept and the chunk ends.
+    ``carrier="chunk_band"`` + ``indice_floor`` restate the ``lo`` sibling
+    (acquisition/claudio_aligned_code_lo_separate.m:117-164): no ``search_df``; every chunk takes its carrier from
+    the arg-max of ``fftshift(abs(fft(d.^2)))`` of the FRESH chunk over the whole band ``k`` (:126,129, before ``dold``
+    is prepended :127), and the stored lag is ``floor(indice/(2*Nint+1))`` (:134).  ``band`` = (lo, hi) open interval in
+    Hz (``tracked_mode``); default ±``band_hz``.
     Returns a dict of per-code lists plus ``df`` per chunk, ``kbon`` (0-based), ``moved``/``movedval``.
     """
     raw = np.asarray(raw).reshape(-1)
@@ -374,13 +400,15 @@ def ranging_tracked(raw, chips, fs=5e6, sps=2, Nint=1, ls_samples=None, band_hz=
     temps = np.arange(n) / fs
     L = int(ls_samples if ls_samples is not None else fs * 2)
     freq = np.linspace(-fs / 2, fs / 2 - 1.0, L)                    # :131 (fs/fs = 1)
-    k = np.nonzero((freq < band_hz) & (freq > -band_hz))[0]          # :134
+    if band is None:
+        band = (-band_hz, band_hz)
+    k = np.nonzero((freq < band[1]) & (freq > band[0]))[0]          # :134-141 / lo :105-113
     r = 2 * Nint + 1
     out = dict(xval=[], indice1=[], correction1=[], SNR1r=[], SNR1i=[], puissance1=[], df=[], moved=[], movedval=[], kbon=-1)
     pos = skip_samples * 2
     dold = np.zeros(0, dtype=complex)
-    df_found = kbon is not None
-    if df_found:
+    df_found = kbon is not None or carrier == "chunk_band"
+    if kbon is not None:
         out["kbon"] = int(kbon)
     p = 1
     guard = 0
@@ -402,11 +430,16 @@ def ranging_tracked(raw, chips, fs=5e6, sps=2, Nint=1, ls_samples=None, band_hz=
             if not df_found and guard > 2:                             # the script would loop forever here
                 break
         if df_found:
-            kb = out["kbon"]
-            d = np.concatenate((dold, d))
-            d2 = np.fft.fftshift(np.abs(_fft(d ** 2)))
-            j = int(np.argmax(d2[kb - 3:kb + 4]))
-            df = freq[j + kb - 3] / 2
+            if carrier == "chunk_band":                                # lo :126-129
+                d2 = np.fft.fftshift(np.abs(_fft(d ** 2)))
+                df = freq[int(np.argmax(d2[k])) + k[0]] / 2
+                d = np.concatenate((dold, d))
+            else:
+                kb = out["kbon"]
+                d = np.concatenate((dold, d))
+                d2 = np.fft.fftshift(np.abs(_fft(d ** 2)))
+                j = int(np.argmax(d2[kb - 3:kb + 4]))
+                df = freq[j + kb - 3] / 2
             out["df"].append(df)
             dindex = 1.0
             while True:
@@ -415,6 +448,8 @@ def ranging_tracked(raw, chips, fs=5e6, sps=2, Nint=1, ls_samples=None, band_hz=
                 dpart = dpart - dpart.mean()
                 o = processing_claudio(dpart, df, temps, fc, code, Nint=Nint, ddof=1)
                 ind = (o["indice"] + 1) / r
+                if indice_floor:                                       # lo :134
+                    ind = float(np.floor(ind))
                 stop = False
                 if 10 * np.log10(o["SNRi"] + o["SNRr"]) > -30:
                     if (43 < ind < n / 2) or (n / 2 < ind < n - 2):
@@ -441,6 +476,128 @@ def ranging_tracked(raw, chips, fs=5e6, sps=2, Nint=1, ls_samples=None, band_hz=
                     break
             dold = d[_oround(dindex) - 1:] if dindex < len(d) else np.zeros(0, dtype=complex)
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# Two-way combination, acquisition/go_1s.m — UNPINNED (Octave only; no recorded result files in the reference)
+# --------------------------------------------------------------------------------------------
+
+def _o_find(mask):
+    """Octave ``find`` → 1-based indices."""
+    return np.nonzero(np.asarray(mask))[0] + 1
+
+
+def _o_idx(v, k1):
+    """``v(k)`` with 1-based index vector ``k``."""
+    return np.asarray(v)[np.asarray(k1, dtype=int) - 1]
+
+
+def _o_polyfit_yf(x, y, n):
+    """``[~,S]=polyfit(x,y,n); S.yf`` (fitted values)."""
+    return np.polyval(np.polyfit(np.asarray(x, dtype=float), np.asarray(y, dtype=float), n), np.asarray(x, dtype=float))
+
+
+def go_1s_session(op_lo, op_re, lt_lo, lt_re, fs=5e6, N=1):
+    """The per-session body of acquisition/go_1s.m:77-268 on the four result records already loaded (dicts with the
+    tracked scripts' row vectors ``xval1 indice1 correction1 SNR1r SNR1i``): OP local (:78-101), OP remote (:103-124),
+    LTFB local (:137-150), LTFB remote (:152-174), equalised lengths (:176-182), ``res2`` from the quadratic fits
+    (:183-190), ``res`` (:192-194), the code-ambiguity shifts exactly as written (:208-211), statistics (:234-241,
+    269-274: ``pkg load nan`` is active :16, so mean/median/std skip NaN) and the rows of the ``<MJD>.1s`` file
+    (:251-268, without the date column: ``cpt`` instead).  1-based index vectors are kept as in the script.
+    Returns None where the script skips the session (:102 ``length(oplo)>102``, a missing variable)."""
+    r = 2 * N + 1
+    xval1, indice1, correction1 = (np.asarray(op_lo[k]).reshape(-1) for k in ("xval1", "indice1", "correction1"))
+    k = _o_find(np.abs(xval1) > np.max(np.abs(xval1)) / 2)                     # :80
+    kk = _o_find(np.diff(k) > 1)                                               # :81
+    if kk.size:
+        k = k[11 - 1:kk[0]]                                                    # :83  k(11:kk(1))
+    else:
+        k = k[11 - 1:len(k) - 1]                                               # :86  k(11:end-1)
+    oplo = (_o_idx(indice1, k) + _o_idx(correction1, k) / r) / fs * 1e9        # :88,90
+    kk = _o_find(np.abs(np.diff(oplo)) > 2)                                    # :94
+    if kk.size:
+        kk = kk[0]
+        if kk > 1:
+            oplo = oplo[:kk - 1]                                               # :99
+    if not len(oplo) > 102:                                                    # :102
+        return None
+    xval1, indice1, correction1 = (np.asarray(op_re[q]).reshape(-1) for q in ("xval1", "indice1", "correction1"))
+    xv = _o_idx(xval1, k)                                                      # :107
+    kkk = _o_find(np.abs(xv) > np.max(np.abs(xv)) / 2)                         # :109
+    kkkk = _o_find(np.diff(kkk) > 1)
+    if kkkk.size:                                                              # :111-118
+        k = k[:kkkk[0]]
+        if kkkk[0] < len(oplo):
+            oplo = oplo[:kkkk[0]]
+    opre = (_o_idx(indice1, k) + _o_idx(correction1, k) / r) / fs * 1e9        # :120,122
+    opre = opre[:len(oplo)]                                                    # :123
+    snrop = float(np.median(10 * np.log10(np.abs(_o_idx(op_re["SNR1r"], k) + _o_idx(op_re["SNR1i"], k)) * fs)))   # :124
+    xval1, indice1, correction1 = (np.asarray(lt_lo[q]).reshape(-1) for q in ("xval1", "indice1", "correction1"))
+    k = _o_find(np.abs(xval1) > np.max(np.abs(xval1)) / 2)                     # :139
+    kk = _o_find(np.diff(k) > 1)
+    if kk.size:
+        k = k[11 - 1:kk[0]]                                                    # :142
+    else:
+        k = k[11 - 1:len(k) - 1]                                               # :145
+    ltlo = (_o_idx(indice1, k) + _o_idx(correction1, k) / r) / fs * 1e9        # :147,149
+    xval1, indice1, correction1 = (np.asarray(lt_re[q]).reshape(-1) for q in ("xval1", "indice1", "correction1"))
+    xv = _o_idx(xval1, k)                                                      # :158
+    kkk = _o_find(np.abs(xv) > np.max(np.abs(xv)) / 2)                         # :159
+    kkkk = _o_find(np.diff(kkk) > 1)
+    if kkkk.size:                                                              # :161-165
+        k = k[:kkkk[0]]
+        ltlo = ltlo[:kkkk[0]]
+    if len(kkk) < len(ltlo):                                                   # :166-170
+        k = k[:kkk[-1]]
+        ltlo = ltlo[:kkk[-1]]
+    ltre = (_o_idx(indice1, k) + _o_idx(correction1, k) / r) / fs * 1e9        # :171,173
+    snrlt = float(np.median(10 * np.log10(np.abs(_o_idx(lt_re["SNR1r"], k) + _o_idx(lt_re["SNR1i"], k)) * fs)))   # :174
+    if len(oplo) > len(ltlo):                                                  # :176-182
+        oplo = oplo[:len(ltlo)]
+        opre = opre[:len(ltlo)]
+    else:
+        ltlo = ltlo[:len(oplo)]
+        ltre = ltre[:len(oplo)]
+    res2 = None
+    if len(opre) > 2 and len(ltre) > 2:                                        # :183-190
+        x = np.arange(1, len(opre) + 1)
+        res2 = 0.5 * ((_o_polyfit_yf(x, opre, 2) - oplo) - (_o_polyfit_yf(x, ltre, 2) - ltlo))
+        res2[np.abs(res2 - np.nanmedian(res2)) > 5] = np.nan
+    res = 0.5 * ((opre - oplo) - (ltre - ltlo))                                # :192
+    res[np.abs(res - np.nanmedian(res)) > 5] = np.nan                          # :193-194
+    ki = res > np.nanmedian(res) + 10                                          # :208-211 (as written: the second test hits every element)
+    res[ki] = res[ki] - 200 / r
+    ki = res > np.nanmedian(res) - 10
+    res[ki] = res[ki] + 200 / r
+    out = dict(oplo=oplo, opre=opre, ltlo=ltlo, ltre=ltre, res=res, res2=res2, snrop=snrop, snrlt=snrlt,
+               resmean=float(np.nanmean(res)), resstd=float(np.nanstd(res, ddof=1)))                              # :234,239
+    rows = []
+    cpt = 0
+    for kq in range(1, len(opre) - 25 + 1, 25):                                # :255  k=1:25:length(opre)-25
+        x = np.arange(kq - 1, kq + 25 - 2 + 1) / 25                            # [k-1:k+25-2]/25
+        row = [float(cpt)]
+        for series in (oplo, opre, ltlo, ltre):                                # :256-263  yf(13)
+            row.append(float(_o_polyfit_yf(x, series[kq - 1:kq + 25 - 1], 1)[13 - 1]))
+        rows.append(row)
+        cpt += 1
+    out["rows"] = np.array(rows).reshape(-1, 5)
+    res25 = np.convolve(res, np.ones(25) / 25)                                 # :269  conv(res,ones(25,1)/25)(25:end-25)
+    res25 = res25[25 - 1:len(res25) - 25]
+    out["resmean25"] = float(np.nanmean(res25)) if res25.size else float("nan")
+    out["resstd25"] = float(np.nanstd(res25, ddof=1)) if res25.size > 1 else float("nan")
+    if len(opre) > 2:                                                          # :275-277
+        t = np.arange(len(opre)) / 25
+        out["opslope"] = np.polyfit(t, opre, 1)
+        out["ltslope"] = np.polyfit(t, ltre, 1)
+    return out
+
+
+def go_1s_text(mjd: float, rows) -> str:
+    """The ``<MJD>.1s`` file body, go_1s.m:252-267 (``fprintf`` formats verbatim)."""
+    txt = "# MJD\t\tOPlocal\tOPremote\tLTFBlocal\tLTBBremote\n"
+    for row in rows:
+        txt += "%f\t%f\t%f\t%f\t%f\n" % (mjd + row[0] / 86400, row[1], row[2], row[3], row[4])
+    return txt
 
 
 # --------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/twstft_hip.h but not exported"
     assert set(names) == set(L.SYMBOLS), (set(names) ^ set(L.SYMBOLS))
-    assert lib.twx_abi_version() == 1
+    assert lib.twx_abi_version() == L.TWX_ABI_VERSION == 2          # 2: nphase became live, tracked/acquisition entries (header)
 
 
 def test_struct_layouts_match_header():
@@ -36,6 +36,27 @@ def test_struct_layouts_match_header():
     assert C.sizeof(L.twx_band) == 16
     assert C.sizeof(L.twx_info) == 40
     assert L.twx_result.df.offset == 176 and L.twx_result.zwin.offset == 64
+    assert C.sizeof(L.twx_tracked_config) == 104 and L.twx_tracked_config.band_lo_hz.offset == 48
+    assert C.sizeof(L.twx_tracked_code) == 56 and C.sizeof(L.twx_tracked_summary) == 56
+
+
+def test_tracked_defaults_mirror_the_three_scripts():
+    """twx_tracked_defaults = the constants that tell claudio_aligned_code_{ranging,re,lo}_separate.m apart (band :134-141 /
+    lo :105-113, carrier rule, floor :134, 30-s skip :128), compared with the oracle's table of the same constants."""
+    lib = L.load()
+    for mode, code in L_MODES.items():
+        for OP in (0, 1):
+            cfg = L.twx_tracked_config()
+            assert lib.twx_tracked_defaults(code, OP, 5e6, C.byref(cfg)) == 0
+            m = orc.tracked_mode(mode, OP)
+            assert (cfg.band_lo_hz, cfg.band_hi_hz) == m["band"]
+            assert cfg.carrier == (1 if m["carrier"] == "chunk_band" else 0) and cfg.indice_floor == int(m["indice_floor"])
+            assert cfg.skip_samples == int(m["skip_seconds"] * 5e6) and cfg.chunk_samples == 10_000_000
+            assert (cfg.sps, cfg.nint, cfg.df_threshold) == (2, 1, 20.0)
+    assert lib.twx_tracked_defaults(7, 0, 5e6, C.byref(cfg)) == -1 and lib.twx_tracked_create(None, None) == -1
+
+
+L_MODES = {"ranging": 0, "re": 1, "lo": 2}
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -120,15 +141,60 @@ def test_mex_gateway_builds_against_the_functional_fake(tmp_path):
     assert r.returncode == 3 and "twstft:create" in r.stderr and "no CPU fallback" in r.stderr
 
 
-def build_mex_harness(root, tmp_path):
+def build_mex_harness(root, tmp_path, harness="mex_harness", gateway="twstft_processing_mex"):
     import subprocess
     libdir = os.path.join(root, "amaranth_twstft_amd")
-    exe = tmp_path / "mex_harness"
+    exe = tmp_path / harness
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(root, "tests", "cpu", "mex_fake"),
-                    "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpu", "mex_harness.cpp"),
-                    os.path.join(root, "mex", "twstft_processing_mex.cpp"), "-L" + libdir, "-ltwstft_hip",
+                    "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpu", harness + ".cpp"),
+                    os.path.join(root, "mex", gateway + ".cpp"), "-L" + libdir, "-ltwstft_hip",
                     "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
     return exe
+
+
+def test_tracked_mex_gateway_builds_and_fails_loudly_without_gpu(tmp_path):
+    """mex/twstft_tracked_mex.cpp (one call per capture file = the whole tracked flow) on the functional fake mex.h."""
+    import subprocess
+    exe = build_mex_harness(ROOT, tmp_path, "mex_tracked_harness", "twstft_tracked_mex")
+    import torch
+    if torch.cuda.is_available():
+        return
+    np.zeros(40000 * 2, dtype=np.int16).tofile(tmp_path / "cap.bin")
+    np.zeros(10000, dtype=np.uint8).tofile(tmp_path / "chips.bin")
+    r = subprocess.run([str(exe), str(tmp_path / "cap.bin"), str(tmp_path / "chips.bin"), str(tmp_path / "out.bin"), "lo", "0", "5e6", "1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and "twstft:create" in r.stderr and "no CPU fallback" in r.stderr
+    r = subprocess.run([str(exe), str(tmp_path / "cap.bin"), str(tmp_path / "chips.bin"), str(tmp_path / "out.bin"), "sideways", "0", "5e6", "1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and "mode must be" in r.stderr
+
+
+def _octave_statements(path):
+    """Statements of an Octave file with comments and all whitespace removed (what a copy check compares)."""
+    out = []
+    for line in open(path, encoding="utf-8", errors="replace"):
+        line = re.sub(r"[%#].*$", "", line)
+        for st in re.split(r"[;\n]", line):
+            st = re.sub(r"\s+", "", st)
+            if st:
+                out.append(st)
+    return out
+
+
+def test_octave_drivers_share_only_contract_strings_with_the_reference():
+    """The Octave drivers under mex/ keep the reference scripts' CONTRACT (file patterns, result names, saved variables) but
+    none of their text: count the statements that are character-identical to a statement of the reference's tracked scripts."""
+    ref_dir = "/root/reference/acquisition"
+    if not os.path.isdir(ref_dir):
+        pytest.skip("reference tree not present (GPU box)")
+    ref = set()
+    for f in ("claudio_aligned_code_ranging_separate.m", "claudio_aligned_code_re_separate.m", "claudio_aligned_code_lo_separate.m"):
+        ref.update(_octave_statements(os.path.join(ref_dir, f)))
+    trivial = {"end", "else", "do", "continue", "return"}
+    mine = [s for s in _octave_statements(os.path.join(ROOT, "mex", "claudio_tracked_hip.m")) if s not in trivial]
+    same = [s for s in mine if s in ref]
+    assert len(mine) > 60 and len(same) <= 2, same
+    assert not os.path.exists(os.path.join(ROOT, "mex", "claudio_aligned_code_ranging_separate_hip.m"))
 
 
 def test_acquisition_gate_formula():

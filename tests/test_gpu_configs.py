@@ -270,6 +270,26 @@ def test_bench_self_launches_its_ranks():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["integer_lag_exact"] and j["value"] > 0 and j["roofline"]["frac"] > 0.05
+    # the gathered buffer was checked against what each rank was given (window_params(p, rank)): both ranks' blocks exact
+    c = j["collective"]
+    assert c["world"] == 2 and c["records"] == 18 and c["ranks_with_exact_lags"] == 2 and c["gathered_lag_exact"]
+    assert c["own_block_identical"] and c["all_ranks_agree"] and c["backend"] == "gloo"
+
+
+def test_bench_two_ranks_over_real_rccl():
+    """`python bench.py --gpus 2` with the nccl (= RCCL) backend, one GPU per rank: runs wherever the box has two GPUs
+    (the driver's 8-GPU node), skipped on a one-GPU box.  The gathered records of BOTH ranks must carry their own lags."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL ranks cannot share a device")
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "24",
+                          "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    c = j["collective"]
+    assert j["n_gpus"] == 2 and j["integer_lag_exact"] and c["backend"].startswith("nccl")
+    assert c["records"] == 48 and c["ranks_with_exact_lags"] == 2 and c["gathered_lag_exact"] and c["all_ranks_agree"]
 
 
 def test_bench_rccl_calls_with_a_world_of_one():
@@ -282,6 +302,9 @@ def test_bench_rccl_calls_with_a_world_of_one():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 1 and j["integer_lag_exact"] and j["value"] > 0
+    c = j["collective"]
+    assert c["backend"].startswith("nccl") and c["world"] == 1 and c["gathered_lag_exact"] and c["own_block_identical"]
+    assert j["startup_s"]["to_first_step"] > 0
 
 
 # --------------------------------------------------------------------------------------------------------------

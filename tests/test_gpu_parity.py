@@ -681,6 +681,96 @@ def test_tracked_loop_reference_sizes():
     assert np.abs(gx - wx).max() <= MAG_TOL * wx.max()
 
 
+def _tracked_agrees(got, want, floor=False):
+    assert got["kbon"] == want["kbon"] and got["df"] == want["df"]
+    assert got["moved"] == want["moved"] and np.allclose(got["movedval"], want["movedval"])
+    assert got["indice1"] == want["indice1"]                     # integer lags and the script's /3 (or floor) bookkeeping
+    gx, wx = np.abs(np.array(got["xval"])), np.abs(np.array(want["xval"]))
+    assert np.abs(gx - wx).max() <= MAG_TOL * wx.max()
+    assert np.abs(np.array(got["correction1"]) - np.array(want["correction1"])).max() < 2e-4
+    for key in ("SNR1r", "SNR1i", "puissance1"):
+        a, b = np.array(got[key]), np.array(want[key])
+        assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max() + 1e-12, key
+
+
+@pytest.mark.parametrize("mode,OP", [("lo", 0), ("re", 0), ("re", 1)])
+def test_tracked_lo_and_re_siblings_vs_oracle(mode, OP):
+    """claudio_aligned_code_lo_separate.m:117-164 (carrier = full-band arg-max of every fresh chunk :126-129, floor of the
+    lag :134, no search) and claudio_aligned_code_re_separate.m (search_df in the remote band :137-141) through
+    twx_tracked_host, against the oracle's restatement of those scripts (unpinned: Octave only)."""
+    from amaranth_twstft_amd.tracked import TrackedRanging
+    m = orc.tracked_mode(mode, OP)
+    car = 1234.5 if mode == "lo" else (m["band"][0] + m["band"][1]) / 4
+    chips, n, a = _tracked_capture(ncodes=60, df=car, delay=1500, seed=14)
+    _, _, b = _tracked_capture(ncodes=60, df=car, delay=1500 + 333, seed=15)
+    raw = np.concatenate((a, b))
+    Lc = 50 * n
+    want = orc.ranging_tracked(raw, chips, fs=FS, ls_samples=Lc, band=m["band"], carrier=m["carrier"], indice_floor=m["indice_floor"])
+    with TrackedRanging(chips, fs=FS, Nint=1, ls_samples=Lc, mode=mode, OP=OP) as tr:
+        got = tr.run(raw)
+    assert len(want["indice1"]) >= 100 and len(want["moved"]) >= 2 and (want["kbon"] > 0) == (mode != "lo")
+    _tracked_agrees(got, want)
+    if mode == "lo":
+        assert all(float(v).is_integer() for v in got["indice1"])
+
+
+def test_tracked_file_entry_skip_and_search_df(tmp_path):
+    """twx_tracked_file: the capture FILE in, records out (what the MEX gateway calls) — the 30-s skip of :128 only moves the
+    chunk search_df sees, the file is then re-read from its start (:156-159); twx_tracked_search_df alone; an unreadable
+    path and a capture shorter than one chunk."""
+    from amaranth_twstft_amd.tracked import TrackedRanging
+    from amaranth_twstft_amd import _lib as L
+    chips, n, raw = _tracked_capture(ncodes=130, seed=33)
+    Lc = 50 * n
+    path = tmp_path / "cap_2.bin"
+    raw.tofile(path)
+    with TrackedRanging(chips, fs=FS, Nint=1, ls_samples=Lc) as tr:
+        for skip in (0.0, 30 * n / FS):
+            want = orc.ranging_tracked(raw, chips, fs=FS, ls_samples=Lc, skip_samples=int(skip * FS))
+            got = tr.run_file(str(path), skip_seconds=skip)
+            assert want["kbon"] > 0 and len(want["indice1"]) >= 100
+            _tracked_agrees(got, want)
+        assert tr.search_df(raw[:2 * Lc]) == want["kbon"]
+        assert tr.run(raw[:Lc])["indice1"] == []                   # shorter than one chunk: no codes, no error
+        with pytest.raises(L.TwxError) as e:
+            tr.run_file(str(tmp_path / "missing.bin"))
+        assert "cannot open" in str(e.value)
+        assert tr.default_skip_samples == 30 * 5_000_000           # fseek(f,30*fs*2*2)
+
+
+def test_tracked_mex_gateway_runs_the_whole_flow(tmp_path):
+    """mexFunction() of mex/twstft_tracked_mex.cpp executed on the GPU box (functional fake mex.h): capture file + code bytes
+    + mode in, the script's workspace variables out (1-based kbon), equal to the ctypes path record for record."""
+    import subprocess
+    from tests.test_abi_and_host import build_mex_harness
+    from tests.test_gpu_configs import _read_mex_outputs
+    from amaranth_twstft_amd.tracked import TrackedRanging
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = build_mex_harness(root, tmp_path, "mex_tracked_harness", "twstft_tracked_mex")
+    nchips, n = 100000, 200000                                     # the script's own sizes: 2-s chunks of 10^7 samples
+    chips = chips_for(17, 9, nchips)
+    p = synth.SynthParams(delay_q8=4321 * 256, fstep=synth.fstep_for_df(-17.0, FS), phi0=9, amp=300,
+                          noise_gain=synth.noise_gain_for_sigma(500.0), seed=23)
+    raw = synth.synth_channel(n * 101, chips, 2, p)
+    raw.tofile(tmp_path / "cap_2.bin")
+    chips.tofile(tmp_path / "n0.bin")
+    for mode in ("ranging", "lo"):
+        r = subprocess.run([str(exe), str(tmp_path / "cap_2.bin"), str(tmp_path / "n0.bin"), str(tmp_path / "out.bin"), mode, "0", "5e6", "1", "0"],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        o = _read_mex_outputs(tmp_path / "out.bin")
+        with TrackedRanging(chips, fs=FS, Nint=1, mode=mode) as tr:
+            ref = tr.run(raw, skip_samples=0)
+        nc = len(ref["indice1"])
+        assert nc >= 98 and all(x.shape == (1, nc) for x in o[:6]) and o[6].shape == (1, len(ref["df"]))
+        assert list(o[0][0]) == ref["xval"] and list(o[1][0]) == ref["indice1"] and list(o[2][0]) == ref["correction1"]
+        assert list(o[3][0]) == ref["SNR1r"] and list(o[5][0]) == ref["puissance1"] and list(o[6][0]) == ref["df"]
+        assert list(o[7][0]) == ref["moved"] and list(o[8][0]) == ref["movedval"] and o[9][0, 0] == ref["kbon"] + 1
+        assert o[10][0, 0] == ref["puissancecode"] and o[11][0, 0] == ref["puissancenoise"]
+    want = orc.ranging_tracked(raw, chips, fs=FS, band=(-20000.0, 20000.0), carrier="chunk_band", indice_floor=True)
+    assert ref["indice1"] == want["indice1"] and ref["df"] == want["df"]      # the `lo` flow at the reference's sizes
+
+
 def test_plain_c_client_of_the_abi(tmp_path):
     """A C99 program (no Python, no torch) drives the library end to end: tests/cpu/abi_smoke.c."""
     import subprocess

@@ -1,5 +1,6 @@
 """CPU: two-way combination (acquisition/go_1s.m:83-268) — known-answer checks on synthetic series."""
 import numpy as np
+import pytest
 
 from amaranth_twstft_amd import twoway
 
@@ -90,6 +91,62 @@ def test_session_files_and_1s_writer(tmp_path):
     assert abs(0.5 * ((rows[2][2] - rows[2][1]) - (rows[2][4] - rows[2][3])) - 37.5) < 0.1
     assert twoway.octave_num2str(60000.0) == "60000" and twoway.octave_num2str(3.14159265) == "3.1416"
     assert abs(twoway.julian_day(2000, 1, 1.5) - 2451545.0) < 1e-9
+
+
+def _tracked_like_record(rng, n, base_ns, drift_ns_s=0.0, lead=4, gap_at=None, loss_at=None, weak_tail=0):
+    """What the tracked correlator writes: xval1/indice1/correction1/SNR1r/SNR1i rows, with optional faults — a run of weak
+    codes in the middle (gap), a delay jump (sample loss), weak codes at the end."""
+    t = np.arange(n) / 25.0
+    d = base_ns + drift_ns_s * t + rng.normal(0, 0.05, n)
+    if loss_at is not None:
+        d[loss_at:] += 200.0                                      # one sample at 5 Msps
+    s = d * 1e-9 * 5e6
+    ind = np.floor(s)
+    amp = np.full(n, 1000.0)
+    amp[:lead] = 20.0
+    if gap_at is not None:
+        amp[gap_at:gap_at + 3] = 15.0
+    if weak_tail:
+        amp[-weak_tail:] = 10.0
+    return dict(xval1=amp * np.exp(1j * rng.uniform(0, 6.28, n)), indice1=ind, correction1=(s - ind) * 3,
+                SNR1r=np.full(n, 2e-3) + rng.uniform(0, 1e-4, n), SNR1i=np.full(n, 1e-3))
+
+
+@pytest.mark.parametrize("case", ["clean", "op_gap", "op_loss", "re_gap", "lt_gap", "lt_re_gap", "lt_re_weak_tail", "lt_short", "too_short"])
+def test_session_matches_the_oracle_restatement_of_go_1s(case):
+    """twoway.session (product, host arithmetic on the device's records) against oracle.go_1s_session, the line-by-line
+    restatement of acquisition/go_1s.m:77-268, over the fault cases the script handles: gaps (:81-84,110-118,140-143,
+    160-165), sample loss in the loop-back (:94-101), remote records weaker at the end (:166-170), unequal lengths
+    (:176-182), sessions with too few codes (:102)."""
+    from oracle import twstft_oracle as orc
+    rng = np.random.default_rng(hash(case) % 1000)
+    n = 25 * 9 + 17
+    kw = dict(op_lo={}, op_re={}, lt_lo={}, lt_re={})
+    if case == "op_gap": kw["op_lo"] = dict(gap_at=180)
+    if case == "op_loss": kw["op_lo"] = dict(loss_at=170)
+    if case == "re_gap": kw["op_re"] = dict(gap_at=150)
+    if case == "lt_gap": kw["lt_lo"] = dict(gap_at=200)
+    if case == "lt_re_gap": kw["lt_re"] = dict(gap_at=190)
+    if case == "lt_re_weak_tail": kw["lt_re"] = dict(weak_tail=30)
+    n_lt = n - 40 if case == "lt_short" else n
+    n_op = 110 if case == "too_short" else n
+    recs = dict(op_lo=_tracked_like_record(rng, n_op, 700.0, **kw["op_lo"]), op_re=_tracked_like_record(rng, n_op, 0.26e9 + 737.5, 5.0, **kw["op_re"]),
+                lt_lo=_tracked_like_record(rng, n_lt, 900.0, **kw["lt_lo"]), lt_re=_tracked_like_record(rng, n_lt, 0.26e9 + 862.5, 5.0, **kw["lt_re"]))
+    want = orc.go_1s_session(recs["op_lo"], recs["op_re"], recs["lt_lo"], recs["lt_re"])
+    got = twoway.session(recs["op_lo"], recs["op_re"], recs["lt_lo"], recs["lt_re"], unwrap=True)
+    if case == "too_short":
+        assert want is None and got is None
+        return
+    for name in ("oplo", "opre", "ltlo", "ltre"):
+        assert np.array_equal(getattr(got, name), want[name]), name
+    assert len(want["oplo"]) > 100 and (case == "clean") == (len(want["oplo"]) == n - 15)    # 4 weak leading codes, 10 dropped, the last one dropped
+    assert np.allclose(got.res, want["res"], equal_nan=True, atol=1e-9) and np.allclose(got.res2, want["res2"], equal_nan=True, atol=1e-6)
+    assert abs(np.nanmean(want["res"]) - (37.5 + 200 / 3)) < 0.1             # the shift of :210-211 hits every code
+    assert np.allclose(got.one_second, want["rows"], atol=1e-9) and want["rows"].shape[0] >= 3
+    for name in ("resmean", "resstd", "resmean25", "resstd25"):
+        assert abs(getattr(got, name) - want[name]) < 1e-9, name
+    assert np.allclose(got.opslope, want["opslope"]) and np.allclose(got.ltslope, want["ltslope"])
+    assert abs(twoway.snr_db(recs["op_re"]["SNR1r"], recs["op_re"]["SNR1i"], slice(None)) - want["snrop"]) < 0.2
 
 
 def test_cpp_twin_container(tmp_path):
