@@ -736,3 +736,67 @@ def test_caf_bins_device_pointer_form():
         pk, lag = cor.caf_bins(raw, -40, 40)
         pkd, lagd = cor.caf_bins_dev(iq.data_ptr(), -40, 40)
     assert np.array_equal(lag, lagd) and np.array_equal(pk, pkd) and lag[47] == 6543
+
+
+# --------------------------------------------------------------------------------------------------------------
+# captures -> device tracked flow -> result files -> two-way combination -> <MJD>.1s  (acquisition/go_1s.m)
+# --------------------------------------------------------------------------------------------------------------
+def test_two_way_end_to_end_from_four_captures(tmp_path):
+    """One session as the sites record it: OP and LTFB each capture their own loop-back (claudio_aligned_code_lo_separate.m)
+    and the partner's signal ~50 kHz off (claudio_aligned_code_re_separate.m).  Product chain: four capture FILES ->
+    twx_tracked_file (lo / re modes) -> the scripts' .mat records (gzip'ed, archive naming) -> twoway.process_sessions ->
+    <MJD>.1s.  Oracle chain on the same captures: oracle.ranging_tracked -> oracle.go_1s_session (go_1s.m:77-268) ->
+    oracle.go_1s_text.  Lags must agree exactly, the delivered 1-s delays to 0.02 ns (fp32 parabola vs fp64)."""
+    import gzip
+    from amaranth_twstft_amd import results_io, twoway
+    from amaranth_twstft_amd.tracked import TrackedRanging
+    nchips, n, ncodes = 10000, 20000, 155
+    Lc = 50 * n
+    codes = {"OP": prn.lfsr_chips(14, 43, nchips), "LTFB": prn.lfsr_chips(14, 57, nchips)}
+    ts = {"OP": 1674402311, "LTFB": 1674402314}
+    # (station, flavour) -> (code it correlates with, carrier Hz, delay samples, script OP flag, file name)
+    plan = {("OP", "lo"): ("OP", 1234.5, 1500, 1, "OP/localclaudio%d_2" % ts["OP"]),
+            ("OP", "re"): ("LTFB", -50007.0, 6400, 1, "OP/remoteclaudio%d_1" % ts["OP"]),
+            ("LTFB", "lo"): ("LTFB", -777.25, 900, 0, "LTFB/localclaudio%d_1" % ts["LTFB"]),
+            ("LTFB", "re"): ("OP", 49991.0, 7100, 0, "LTFB/remoteclaudio%d_2" % ts["LTFB"])}
+    (tmp_path / "OP").mkdir(); (tmp_path / "LTFB").mkdir()
+    oracle_rec = {}
+    for i, ((station, flavour), (code_of, car, delay, OP, name)) in enumerate(plan.items()):
+        chips = codes[code_of]
+        p = synth.SynthParams(delay_q8=delay * 256, fstep=synth.fstep_for_df(car, FS), phi0=7 + i, amp=900,
+                              noise_gain=synth.noise_gain_for_sigma(120.0), seed=400 + i)
+        raw = synth.synth_channel(n * ncodes, chips, 2, p)
+        cap = tmp_path / f"cap_{station}_{flavour}.bin"
+        raw.tofile(cap)
+        m = orc.tracked_mode(flavour, OP)
+        with TrackedRanging(chips, fs=FS, Nint=1, ls_samples=Lc, mode=flavour, OP=OP) as tr:
+            got = tr.run_file(str(cap), skip_seconds=0.0)
+        want = orc.ranging_tracked(raw, chips, fs=FS, ls_samples=Lc, band=m["band"], carrier=m["carrier"], indice_floor=m["indice_floor"])
+        assert got["indice1"] == want["indice1"] and len(want["indice1"]) >= 148 and got["df"] == want["df"], (station, flavour)
+        mat = tmp_path / (name + ".mat")
+        results_io.save_tracked_mat(str(mat), got, code=orc.make_code(chips, 2))
+        with open(mat, "rb") as f, gzip.open(str(mat) + ".gz", "wb") as g:
+            g.write(f.read())
+        mat.unlink()
+        oracle_rec[(station, flavour)] = {k: np.asarray(want[k2]) for k, k2 in (("xval1", "xval"), ("indice1", "indice1"), ("correction1", "correction1"),
+                                                                                 ("SNR1r", "SNR1r"), ("SNR1i", "SNR1i"))}
+    out = twoway.process_sessions(str(tmp_path), out_dir=str(tmp_path))
+    assert len(out) == 1
+    mjd, tw, path = out[0]
+    want = orc.go_1s_session(oracle_rec[("OP", "lo")], oracle_rec[("OP", "re")], oracle_rec[("LTFB", "lo")], oracle_rec[("LTFB", "re")])
+    assert want is not None and want["rows"].shape[0] >= 4 and len(want["oplo"]) > 102
+    assert len(tw.oplo) == len(want["oplo"]) and tw.one_second.shape == want["rows"].shape
+    got_lines = open(path).read().split("\n")
+    want_lines = orc.go_1s_text(twoway.mjd_of_unix(ts["LTFB"]), want["rows"]).split("\n")
+    assert got_lines[0] == want_lines[0] and len(got_lines) == len(want_lines)
+    for a, b in zip(got_lines[1:], want_lines[1:]):
+        if not b:
+            continue
+        ga, wb = [float(v) for v in a.split("\t")], [float(v) for v in b.split("\t")]
+        assert ga[0] == wb[0] and max(abs(x - y) for x, y in zip(ga[1:], wb[1:])) <= 0.02, (a, b)
+    # the two-way observable itself: res (ns), NaN pattern included
+    res_w = want["res"] - 200 / 3                                  # the oracle restates the shift of :210-211, the product leaves it off by default
+    assert np.array_equal(np.isnan(tw.res), np.isnan(res_w)) and np.nanmax(np.abs(tw.res - res_w)) <= 0.03
+    # every channel was re-aligned to sample 21 by the tracked loop (:183), so the four series sit at 21 samples = 4200 ns
+    for series in (tw.oplo, tw.opre, tw.ltlo, tw.ltre):
+        assert np.abs(series - 21 / FS * 1e9).max() < 70.0          # the remote series keep indice/3 = 21 1/3 (:174)

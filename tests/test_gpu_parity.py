@@ -728,7 +728,7 @@ def test_tracked_file_entry_skip_and_search_df(tmp_path):
         for skip in (0.0, 30 * n / FS):
             want = orc.ranging_tracked(raw, chips, fs=FS, ls_samples=Lc, skip_samples=int(skip * FS))
             got = tr.run_file(str(path), skip_seconds=skip)
-            assert want["kbon"] > 0 and len(want["indice1"]) >= 100
+            assert want["kbon"] > 0 and len(want["indice1"]) >= 95
             _tracked_agrees(got, want)
         assert tr.search_df(raw[:2 * Lc]) == want["kbon"]
         assert tr.run(raw[:Lc])["indice1"] == []                   # shorter than one chunk: no codes, no error
