@@ -25,6 +25,11 @@ TWX_PROF_MAX = 16
 TWX_TRK_RANGING, TWX_TRK_RE, TWX_TRK_LO = 0, 1, 2
 TWX_CARRIER_SEARCH_DF, TWX_CARRIER_CHUNK_BAND = 0, 1
 TWX_ABI_VERSION = 2
+TWX_ACQ_IZAMAX = 1
+
+
+def TWX_ACQ_DEC(d: int) -> int:
+    return (int(d) & 0xFF) << 8
 
 
 class TwxError(RuntimeError):
@@ -82,6 +87,10 @@ class twx_tracked_summary(C.Structure):
                 ("batches", C.c_int64), ("puissancecode", C.c_double), ("puissancenoise", C.c_double)]
 
 
+class twx_acq_result(C.Structure):
+    _fields_ = [("fc", C.c_double), ("pk", C.c_double), ("pt", C.c_int64), ("n_trials", C.c_int64)]
+
+
 class twx_prof_entry(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("ms_total", C.c_double), ("launches", C.c_int64), ("units", C.c_int64)]
 
@@ -112,6 +121,7 @@ SYMBOLS = {
     "twx_set_code_spectrum": (C.c_int, [_VP, _VP]),
     "twx_xcorr_map_dev": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, _VP]),
     "twx_caf_freqs_cdev": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int32, _VP]),
+    "twx_acquire_cdev": (C.c_int, [_VP, _VP, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int32, C.POINTER(twx_acq_result)]),
     "twx_caf_bins": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _VP, _VP]),
     "twx_caf_bins_dev": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _VP, _VP]),
     "twx_caf_freqs": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP, C.c_int64, _VP]),

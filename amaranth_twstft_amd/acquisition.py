@@ -97,20 +97,32 @@ class Acquisition:
         self.cor.set_code_spectrum(spec)
         self.cor.set_remove_mean(False)
 
+    def _flags(self) -> int:
+        return L.TWX_ACQ_IZAMAX | (L.TWX_ACQ_DEC(self.dec_a) if self.dec_a > 1 else 0)
+
     def bins(self, smp_dev: int, idx: int, freqs):
         """(pk, pk_idx) of the loop body :543-556 for every trial carrier in ``freqs``; ``smp_dev`` = device pointer to
-        the interpolated complex64 stream, ``idx`` = start sample."""
-        if self.dec_a != 1:
-            raise NotImplementedError("dec_a > 1: decimate the stream first (rxcomplex.cpp runs the X310 with dec_a = 1, :226-227)")
+        the interpolated complex64 stream, ``idx`` = start sample.  ``dec_a`` > 1 (the B210 build, :228-230): every
+        ``dec_a``-th sample of the stream is correlated (``smp[i*dec]``, :1046-1047)."""
         f = np.ascontiguousarray(freqs, dtype=np.float64)
         out = (L.twx_result * max(f.size, 1))()
         L.check(self.cor._lib.twx_caf_freqs_cdev(self.cor._h, smp_dev + 8 * int(idx), f.ctypes.data_as(C.c_void_p), f.size,
-                                                 1, C.cast(out, C.c_void_p)), self.cor._h)
+                                                 self._flags(), C.cast(out, C.c_void_p)), self.cor._h)
         pk = np.array([np.hypot(out[i].xval[0], out[i].xval[1]) for i in range(f.size)])
         return pk, np.array([out[i].indice0 for i in range(f.size)], dtype=np.int64)
 
     def acquire(self, smp_dev: int, idx: int, fc_init: float, frange: float, fstep: float):
-        """The sweep :534-567: returns (fc, pk, pt)."""
+        """The sweep :534-567 in one library call (``twx_acquire_cdev``: coarse sweep, strict ``pk >`` rule, step halving
+        until < 1 Hz, bookkeeping between rounds on the device): returns (fc, pk, pt)."""
+        r = L.twx_acq_result()
+        L.check(self.cor._lib.twx_acquire_cdev(self.cor._h, smp_dev + 8 * int(idx), float(fc_init), float(frange), float(fstep),
+                                               self.nobs // self.dec_a, self._flags(), C.byref(r)), self.cor._h)
+        self.n_trials = int(r.n_trials)
+        return float(r.fc), float(r.pk), int(r.pt)
+
+    def acquire_host_loop(self, smp_dev: int, idx: int, fc_init: float, frange: float, fstep: float):
+        """The same sweep with the rounds driven from the host through :meth:`bins` (one synchronisation per round):
+        the cross-check of :meth:`acquire`."""
         pk_best, fc, pt = 0.0, float(fc_init), 0
         while True:
             flow, fhigh = fc - frange, fc + frange

@@ -140,6 +140,36 @@ __global__ void k_convert(const cpx<S>* __restrict__ in, cpx<D>* __restrict__ ou
         out[i] = mk<D>((D)(in[i].x * scale), (D)(in[i].y * scale));
 }
 
+// every dec-th sample of a complex-float stream -> contiguous (downconv_acq reads smp[i*dec], rxcomplex.cpp:1039-1049)
+__global__ void k_stride_copy(const cpx<float>* __restrict__ in, cpx<float>* __restrict__ out, long long n, int dec) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = in[i * dec];
+}
+
+// Sweep bookkeeping of the acquisition loop (rxcomplex.cpp:534-567) kept ON THE DEVICE, so the rounds of the step halving
+// are enqueued back to back without a host round trip: scan the records of the round that just finished in trial order
+// (`if (pk > ci[i].pk)`, :556-562: strictly larger wins, pk = |z| of the izamax element), then halve the step (:565-567)
+// and write the next round's trial carriers fc-step, fc, fc+step... (`for (fcc = flow; fcc <= fhigh; fcc += fstep)`,
+// :538: repeated addition, at most `cap` of them) into the batch's df vector.  One thread.
+struct AcqState { double fc, pk, step; long long pt, n_trials; int cnt, pad; };
+__global__ void k_acq_update(const twx_result* __restrict__ rec, int n_host, AcqState* st, double* __restrict__ dfv, int cap, long long ptmod) {
+    if (threadIdx.x || blockIdx.x) return;
+    AcqState s = *st;
+    const int n = n_host >= 0 ? n_host : s.cnt;
+    for (int i = 0; i < n; ++i) {
+        const double pk = sqrt(rec[i].xval[0] * rec[i].xval[0] + rec[i].xval[1] * rec[i].xval[1]);
+        if (pk > s.pk) { s.fc = rec[i].df; s.pk = pk; s.pt = ptmod > 0 ? rec[i].indice0 % ptmod : rec[i].indice0; }
+    }
+    s.n_trials += n;
+    s.step = s.step / 2.0;
+    const double frange = s.step, flow = s.fc - frange, fhigh = s.fc + frange;
+    int c = 0;
+    for (double fcc = flow; fcc <= fhigh && c < cap; fcc += s.step) dfv[c++] = fcc;
+    s.cnt = c;
+    for (int i = c; i < cap; ++i) dfv[i] = s.fc;          // unused slots of the batch: a valid carrier, records ignored
+    *st = s;
+}
+
 // Replica variants on the finished code spectrum S = conj(FFT(2c-1)) (layout [k1][k2], DC at index 0), all exact in
 // the spectrum because they only differ by a constant in the time domain:
 //   0/1 levels:  conj(FFT(c)) = S/2 (+ N/2 at DC);  zero mean: DC = 0;  complex code ci + j cq: Si - j Sq.
@@ -351,6 +381,7 @@ struct CtxBase {
     virtual int set_code_spectrum(const double* spec) = 0;
     virtual int xcorr_map_dev(const void* iq_dev, int nch, int ch, double df, void* out_dev) = 0;
     virtual int caf_freqs_cdev(const void* d_dev, const double* freqs, long long nf, int flags, twx_result* out) = 0;
+    virtual int acquire_cdev(const void* d_dev, double fc0, double frange, double fstep, long long ptmod, int flags, twx_acq_result* out) = 0;
 };
 
 template <typename T> static void host_twiddle(std::vector<cpx<T>>& v, long long count, long long num_mul, long long den, int sign) {
@@ -838,9 +869,9 @@ template <typename T> struct Ctx : CtxBase {
                     if (row->rowd(ROW_BAND, &rd, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_rowd(band) launch failed");
                 } else if (row->run(ROW_BAND, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(band) launch failed");
             }
-        } else {
+        } else if (df_host) {
             HIPCHK(hipMemcpyAsync(dfv, df_host, sizeof(double) * nb, hipMemcpyHostToDevice, stream));
-        }
+        }                                            // else: the batch's df vector was written on the device (acquire_cdev)
         {
             ProfScope ps(this, PC_DFT, nb);
             for (int it = 0, ne = reps(PC_DFT); it < ne; ++it)
@@ -1282,16 +1313,77 @@ template <typename T> struct Ctx : CtxBase {
     int caf_freqs_cdev(const void* d_dev, const double* freqs, long long nf, int flags, twx_result* out) override {
         if (int rc = sync_all()) return rc;
         use_slot(0);
+        Scratch sc(this);
+        const void* win = nullptr;
+        if (int rc = strided_window(sc, d_dev, flags, &win)) return rc;
         argmax_norm1 = (flags & TWX_ACQ_IZAMAX) ? 1 : 0;
         int rc = TWX_OK;
         for (long long f0 = 0; f0 < nf && rc == TWX_OK; f0 += B) {
             const int nb = (int)std::min<long long>(B, nf - f0);
-            rc = run_batch_in(IN_C32, d_dev, nullptr, 1, 0, 0, nb, nullptr, freqs + f0, res_dev, nullptr, 1);
+            rc = run_batch_in(IN_C32, win, nullptr, 1, 0, 0, nb, nullptr, freqs + f0, res_dev, nullptr, 1);
             if (rc == TWX_OK && hipMemcpyAsync(out + f0, res_dev, sizeof(twx_result) * nb, hipMemcpyDeviceToHost, stream) != hipSuccess) rc = fail(TWX_E_HIP, "D2H copy failed");
             if (rc == TWX_OK && hipStreamSynchronize(stream) != hipSuccess) rc = fail(TWX_E_HIP, "stream synchronize failed");
         }
         argmax_norm1 = 0;
         return rc;
+    }
+    // complex-float stream with a decimation stride in flags bits 8..15 -> contiguous window (or d_dev itself)
+    int strided_window(Scratch& sc, const void* d_dev, int flags, const void** win) {
+        const int dec = std::max(1, (flags >> 8) & 0xff);
+        *win = d_dev;
+        if (dec == 1) return TWX_OK;
+        cpx<float>* tmp = nullptr;
+        if (int rc = sc.get(&tmp, (size_t)N)) return rc;
+        TWX_LAUNCH(k_stride_copy, dim3(1024), dim3(256), stream, reinterpret_cast<const cpx<float>*>(d_dev), tmp, (long long)N, dec);
+        HIPCHK(hipGetLastError());
+        *win = tmp;
+        return TWX_OK;
+    }
+    // The whole sweep of rxcomplex.cpp:534-567 in one call: coarse sweep fc0 +- frange in fstep, then step halving with
+    // range = step until the step drops under 1 Hz.  Every round's records stay on the device, the bookkeeping between
+    // rounds is k_acq_update, and the host synchronises once, at the end.
+    int acquire_cdev(const void* d_dev, double fc0, double frange, double fstep, long long ptmod, int flags, twx_acq_result* out) override {
+        if (!(fstep > 0) || !(frange >= 0)) return fail(TWX_E_ARG, "acquire: need fstep > 0 and frange >= 0");
+        if (int rc = sync_all()) return rc;
+        use_slot(0);
+        Scratch sc(this);
+        const void* win = nullptr;
+        if (int rc = strided_window(sc, d_dev, flags, &win)) return rc;
+        std::vector<double> trial;
+        for (double fcc = fc0 - frange; fcc <= fc0 + frange; fcc += fstep) {        // :536-538, the same repeated addition
+            trial.push_back(fcc);
+            if (trial.size() > (1u << 20)) return fail(TWX_E_ARG, "acquire: more than 2^20 trial carriers in the coarse sweep");
+        }
+        int later = 0;
+        for (double st = fstep / 2.0; !(st < 1.0); st /= 2.0) ++later;              // rounds after the coarse one (:565-567)
+        const int cap = std::min(B, 4);                                              // fc-step, fc, fc+step (+1 for rounding slack)
+        twx_result* rec = nullptr; AcqState* st_dev = nullptr;
+        if (int rc = sc.get(&rec, trial.size() + (size_t)later * cap + 1)) return rc;
+        if (int rc = sc.get(&st_dev, 1)) return rc;
+        AcqState h{}; h.fc = fc0; h.pk = 0.0; h.step = fstep; h.pt = 0; h.n_trials = 0; h.cnt = 0;
+        HIPCHK(hipMemcpyAsync(st_dev, &h, sizeof h, hipMemcpyHostToDevice, stream));
+        argmax_norm1 = (flags & TWX_ACQ_IZAMAX) ? 1 : 0;
+        int rc = TWX_OK;
+        const long long n1 = (long long)trial.size();
+        for (long long f0 = 0; f0 < n1 && rc == TWX_OK; f0 += B) {
+            const int nb = (int)std::min<long long>(B, n1 - f0);
+            rc = run_batch_in(IN_C32, win, nullptr, 1, 0, 0, nb, nullptr, trial.data() + f0, rec + f0, nullptr, 1);
+        }
+        twx_result* cur = rec + n1;
+        int n_prev = (int)n1; const twx_result* prev = rec;
+        for (int r = 0; r <= later && rc == TWX_OK; ++r) {
+            TWX_LAUNCH(k_acq_update, dim3(1), dim3(1), stream, prev, n_prev, st_dev, dfv, cap, ptmod);
+            if (hipGetLastError() != hipSuccess) { rc = fail(TWX_E_HIP, "k_acq_update launch failed"); break; }
+            if (r == later) break;                                                   // the last update only folds the last round in
+            rc = run_batch_in(IN_C32, win, nullptr, 1, 0, 0, cap, nullptr, nullptr, cur, nullptr, 1);
+            prev = cur; cur += cap; n_prev = -1;
+        }
+        argmax_norm1 = 0;
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(&h, st_dev, sizeof h, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        out->fc = h.fc; out->pk = h.pk; out->pt = h.pt; out->n_trials = h.n_trials;
+        return TWX_OK;
     }
 
     int caf_bins(const int16_t* iq, int nch, int ch, long long k_lo, long long k_hi, double* pk, long long* lag) override {
@@ -1555,6 +1647,13 @@ int twx_caf_freqs_cdev(twx_ctx* ctx, const void* d_dev, const double* freqs, int
     if (!ctx || !d_dev || !freqs || !out || n_freqs < 0) return TWX_E_ARG;
     (void)hipSetDevice(ctx->impl->dev);
     return guarded(ctx->impl, [&]() { return ctx->impl->caf_freqs_cdev(d_dev, freqs, n_freqs, flags, out); });
+}
+
+int twx_acquire_cdev(twx_ctx* ctx, const void* d_dev, double fc_init, double frange, double fstep, int64_t pt_modulus, int32_t flags,
+                     twx_acq_result* out) {
+    if (!ctx || !d_dev || !out || pt_modulus < 0) return TWX_E_ARG;
+    (void)hipSetDevice(ctx->impl->dev);
+    return guarded(ctx->impl, [&]() { return ctx->impl->acquire_cdev(d_dev, fc_init, frange, fstep, pt_modulus, flags, out); });
 }
 
 int twx_fft_forward(twx_ctx* ctx, const double* in, double* out) {

@@ -26,42 +26,72 @@ namespace {
 // grid = (chunks of SD_CH samples, ncodes), block = 256
 // ---------------------------------------------------------------------------------------------
 constexpr int SD_NT = 256, SD_S = 64, SD_CH = SD_NT * SD_S;      // 16384 samples per workgroup
+constexpr int SD_T = 4;                                          // consecutive samples per lane and pass
 
+// Register tile: a lane owns SD_T = 4 CONSECUTIVE samples per pass, so the replica values it needs for all NL lags are
+// the NL+3 consecutive entries c[4g-l+j] — every value read from LDS feeds four packed FMAs (was: one read per FMA, which
+// left the VALU waiting for the LDS pipe).  The replica segment is stored transposed, entry u = 4q+r at r*QS+q, so that
+// what the 64 lanes read together (same r, consecutive q) is contiguous: conflict-free ds_read_b32.  The NCO is evaluated
+// once per lane and pass (fp64 phase reduction + sincospi) and stepped over the other three samples by the fp32 rotation
+// exp(-2 pi j ff) (three steps: 2e-7 relative at most).
 template <int NLAG>
 __global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict__ x, int nch, long long pt, long long nobs, int nlag, int chunk_len,
-                                                       const float* __restrict__ w, double ff, double phi, float scale,
+                                                       const float* __restrict__ w, double ff, double phi, float scale, float rot_c, float rot_s,
                                                        double* __restrict__ partial /*[ncodes][chunks][2*nlag+1][2]*/) {
     constexpr int NL = 2 * NLAG + 1;
-    __shared__ float sw[SD_CH + 2 * NLAG + 2];                    // replica segment; reused by the final reduction
-    static_assert(NL * SD_NT <= SD_CH + 2 * NLAG + 2, "reduction buffer must fit the replica segment");
+    constexpr int NE = SD_CH + 2 * NLAG + 4;                       // replica entries of a full chunk (+ the tile's overhang)
+    constexpr int QS = ((NE + 3) / 4) | 1;                         // odd quarter stride: the four r of one q land in four banks
+    __shared__ float sw[4 * QS];                                   // replica segment; reused by the final reduction
+    static_assert(NL * SD_NT <= 4 * QS, "reduction buffer must fit the replica segment");
     const int p = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const long long s0 = (long long)chunk * chunk_len;
     const int cnt = (int)min((long long)chunk_len, nobs - s0);
     const int tid = threadIdx.x;
     // entry u <-> w[(s0 - NLAG + u) mod nobs]
-    for (int u = tid; u < cnt + 2 * NLAG; u += SD_NT) {
-        long long k = (s0 - NLAG + u) % nobs; if (k < 0) k += nobs;
-        sw[u] = w[k];
+    {
+        long long k = (s0 - NLAG + tid) % nobs; if (k < 0) k += nobs;          // one 64-bit division per thread, then steps
+        const long long step = SD_NT % nobs;
+        for (int u = tid; u < cnt + 2 * NLAG + 3; u += SD_NT) {
+            sw[(u & 3) * QS + (u >> 2)] = w[k];
+            k += step; if (k >= nobs) k -= nobs;
+        }
     }
     __syncthreads();
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 acc[NL];                                                    // (re, im) pairs: one v_pk_fma_f32 per lag and sample
 #pragma unroll
     for (int l = 0; l < NL; ++l) acc[l] = f2{0.f, 0.f};
-    for (int t = tid; t < cnt; t += SD_NT) {
-        const long long i = (long long)p * nobs + s0 + t;         // the NCO runs over the whole block of codes
-        const short2 s = x[(pt + i) * nch];
-        double ph = ff * (double)i + phi;                          // fp64 phase reduction, fp32 sincos
+    const int ngrp = (cnt + SD_T - 1) / SD_T;
+    for (int g = tid; g < ngrp; g += SD_NT) {
+        const int t0 = SD_T * g;
+        const long long i0 = (long long)p * nobs + s0 + t0;        // the NCO runs over the whole block of codes
+        short2 sm[SD_T];
+#pragma unroll
+        for (int j = 0; j < SD_T; ++j) sm[j] = x[(pt + min(i0 + j, (long long)p * nobs + s0 + cnt - 1)) * nch];    // clamped, masked below
+        double ph = ff * (double)i0 + phi;                          // fp64 phase reduction, fp32 sincos
         ph -= rint(ph);
         float sn, cs;
         sincospif(-2.0f * (float)ph, &sn, &cs);
-        const float re = (float)s.x, im = (float)s.y;
-        const f2 y = {scale * (re * cs - im * sn), scale * (re * sn + im * cs)};
-        const float* c = sw + t + 2 * NLAG;                        // lag index l: replica index (s0+t) - (l - NLAG)
+        f2 y[SD_T];
+#pragma unroll
+        for (int j = 0; j < SD_T; ++j) {
+            const float re = (float)sm[j].x, im = (float)sm[j].y;
+            const float m = (t0 + j < cnt) ? scale : 0.f;
+            y[j] = f2{m * (re * cs - im * sn), m * (re * sn + im * cs)};
+            const float c2 = cs * rot_c - sn * rot_s, s2 = cs * rot_s + sn * rot_c;
+            cs = c2; sn = s2;
+        }
+        // sample t0+j, lag index l  <->  replica entry 4g + (j + 2*NLAG - l)
+        float cw[NL + SD_T - 1];
+#pragma unroll
+        for (int m = 0; m < NL + SD_T - 1; ++m) cw[m] = sw[(m & 3) * QS + g + (m >> 2)];
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            const float cv = c[-l];
-            acc[l] = __builtin_elementwise_fma(y, f2{cv, cv}, acc[l]);
+#pragma unroll
+            for (int j = 0; j < SD_T; ++j) {
+                const float cv = cw[j + 2 * NLAG - l];
+                acc[l] = __builtin_elementwise_fma(y[j], f2{cv, cv}, acc[l]);
+            }
         }
     }
     // block reduction through LDS, one component at a time: buf[l][tid]; thread r = (l, quarter) sums 64 lanes,
@@ -130,7 +160,9 @@ int launch_sliding(hipStream_t st, const short2* dx, int nch, long long pt, long
     const int clen = sliding_chunk(nobs, ncodes);
     const int nchunks = (int)((nobs + clen - 1) / clen);
     const dim3 grid(nchunks, ncodes), block(SD_NT);
-#define SD_GO(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, dpart)
+    const double two_pi = 6.283185307179586476925286766559;
+    const float rot_c = (float)cos(two_pi * ff), rot_s = (float)(-sin(two_pi * ff));          // exp(-2 pi j ff)
+#define SD_GO(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, dpart)
     if (nlag <= 4) SD_GO(4); else if (nlag <= 8) SD_GO(8); else if (nlag <= 16) SD_GO(16); else if (nlag <= 28) SD_GO(28); else SD_GO(31);
 #undef SD_GO
     if (hipGetLastError() != hipSuccess) return TWX_E_HIP;

@@ -205,7 +205,18 @@ int twx_xcorr_map_dev(twx_ctx* ctx, const void* iq_dev, int32_t n_channels, int3
  * downconv_acq, FFT, cross_spectrum (through the context's replica spectrum), IFFT, arg-max.  flags & 1: the arg-max is
  * cblas_izamax's, i.e. of |re|+|im| (rxcomplex.cpp:553), not of the modulus.  out: n_freqs results (host). */
 #define TWX_ACQ_IZAMAX 1
+/* flags | TWX_ACQ_DEC(d): the window is every d-th sample of the stream at d_dev (downconv_acq's smp[i*dec] with dec = dec_a,
+ * rxcomplex.cpp:543,1039-1049; the B210 build runs dec_a = 2, :228-230); d_dev then holds at least N*d samples. */
+#define TWX_ACQ_DEC(d) (((d) & 0xff) << 8)
 int twx_caf_freqs_cdev(twx_ctx* ctx, const void* d_dev, const double* freqs, int64_t n_freqs, int32_t flags, twx_result* out);
+/* The acquisition sweep itself, rxcomplex.cpp:534-567, as ONE call: trial carriers fc_init-frange .. fc_init+frange in
+ * fstep (`for (fcc = flow; fcc <= fhigh; fcc += fstep)`), keep the strictly highest peak (:556-562), then halve the step
+ * with range = step until it drops under 1 Hz (:565-567).  The bookkeeping between rounds runs on the device; the host
+ * synchronises once.  out: fc (Hz), pk = |z| at the arg-max, pt = its 0-based lag modulo pt_modulus (`% (nobs/dec_a)`,
+ * :561; 0 = no modulus), n_trials = carriers evaluated.  flags: TWX_ACQ_IZAMAX, TWX_ACQ_DEC(d). */
+typedef struct twx_acq_result { double fc, pk; int64_t pt, n_trials; } twx_acq_result;
+int twx_acquire_cdev(twx_ctx* ctx, const void* d_dev, double fc_init, double frange, double fstep, int64_t pt_modulus, int32_t flags,
+                     twx_acq_result* out);
 
 /* Delay x Doppler cross-ambiguity of ONE window (host int16 capture, as twx_process_windows) ------
  * Replaces the acquisition sweep of experiments/231001_DLL_PLL/rxcomplex.cpp:534-563 (per trial

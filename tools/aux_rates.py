@@ -90,13 +90,21 @@ def acq():
     print(json.dumps({"kernel": "interpolation chain (short2double)", "case": "5e6 -> 1e7 samples, one channel", "ms": round(dt * 1e3, 3),
                       "input_Gsample_s": round(n_in / dt / 1e9, 2), "algorithmic_bytes": byts, "GB_s": round(byts / dt / 1e9, 1), "frac_hbm": round(byts / dt / 1e9 / HBM, 4)}))
     a = A.Acquisition(1 - 2 * chips.astype(np.int64), rc, fs, nobs)
-    t = time.perf_counter()
-    fc, pk, pt = a.acquire(smp.data_ptr(), 3 * nobs, 186.0, 65536.0, 256.0)
-    dt = time.perf_counter() - t
     nb = 513 + 24
     byts = nb * a.nfft * (8 + 8 + 8 + 8 + 8)                    # per trial carrier: samples in, A out/in, Bz out/in
-    print(json.dumps({"kernel": "acquisition sweep (rxcomplex.cpp:534-567)", "case": f"{nb} trial carriers x 2^20 samples, sdr.param range/step", "ms": round(dt * 1e3, 2),
-                      "carriers_per_s": round(nb / dt, 0), "algorithmic_bytes": byts, "GB_s": round(byts / dt / 1e9, 1), "frac_hbm": round(byts / dt / 1e9 / HBM, 4)}))
+    for name, fn in (("one call: twx_acquire_cdev (bookkeeping between rounds on the device, one synchronisation)", a.acquire),
+                     ("host-driven rounds: twx_caf_freqs_cdev per round (9 synchronisations + D2H)", a.acquire_host_loop)):
+        fn(smp.data_ptr(), 3 * nobs, 186.0, 65536.0, 256.0)                                      # cold call (allocations)
+        times = []
+        for _ in range(10):                                                                        # warm x 10
+            t = time.perf_counter()
+            fc, pk, pt = fn(smp.data_ptr(), 3 * nobs, 186.0, 65536.0, 256.0)
+            times.append(time.perf_counter() - t)
+        dt = float(np.median(times))
+        print(json.dumps({"kernel": "acquisition sweep (rxcomplex.cpp:534-567)", "variant": name,
+                          "case": f"{nb} trial carriers x 2^20 samples, sdr.param range/step", "ms_median_of_10_warm": round(dt * 1e3, 3),
+                          "ms_min": round(min(times) * 1e3, 3), "ms_max": round(max(times) * 1e3, 3),
+                          "carriers_per_s": round(nb / dt, 0), "algorithmic_bytes": byts, "GB_s": round(byts / dt / 1e9, 1), "frac_hbm": round(byts / dt / 1e9 / HBM, 4)}))
     a.close(); interp.close()
 
 
