@@ -17,15 +17,40 @@ from . import plans
 from .correlator import Correlator
 
 
+MAX_F64_LEN = plans.MAX_N1 * 10000          # no N1 x N2 pair is longer (plans.choose: N1 <= MAX_N1, N2 <= 10000)
+
+
+def _smooth_candidates(lo: int, hi: int):
+    """Even 2^a 3^b 5^c 7^d in [lo, hi], ascending (enumerated, not searched: a handful of thousand numbers at most)."""
+    out = []
+    p7 = 1
+    while p7 <= hi:
+        p5 = p7
+        while p5 <= hi:
+            p3 = p5
+            while p3 <= hi:
+                v = p3 * 2
+                while v <= hi:
+                    if v >= lo:
+                        out.append(v)
+                    v *= 2
+                p3 *= 3
+            p5 *= 5
+        p7 *= 7
+    return sorted(out)
+
+
 def _smooth_len(lo: int) -> int:
-    """Smallest even 2^a 3^b 5^c >= lo that the plan generator can split."""
-    m = lo + (lo & 1)
-    while True:
-        if plans._smooth(m) and plans.choose(m) is not None:
+    """Smallest even 2^a 3^b 5^c 7^d >= lo for which the plan generator has a COMPLEX-DOUBLE pair (the Bluestein context is
+    opened with precision f64).  Fails at once for series the library cannot transform in one piece."""
+    if lo > MAX_F64_LEN:
+        raise ValueError(f"series too long for the file-level carrier estimate: a transform of >= {lo} points is needed and the "
+                         f"longest fp64 plan pair holds {MAX_F64_LEN} (captures over ~{MAX_F64_LEN // 2 * 25 / 5e6:.0f} s at 5 Msps "
+                         "and N = 25: estimate the carrier on a part of the file)")
+    for m in _smooth_candidates(lo, min(4 * lo + 64, MAX_F64_LEN)):
+        if plans.choose(m, f64=True) is not None:
             return m
-        m += 2
-        if m > 4 * lo + 64:
-            raise ValueError(f"no transform length near {lo} fits the library's plans (series too long)")
+    raise ValueError(f"no fp64 transform length near {lo} fits the library's plans (series too long)")
 
 
 class ArbitraryFFT:
@@ -69,7 +94,8 @@ def file_level_df(path: str, fs: float = 5e6, N: int = 25, remote: int = 0, foff
     Returns (foffset1, foffset2 or None)."""
     raw = np.memmap(path, dtype=np.int16, mode="r")
     nrec = raw.size // (4 * N)                                     # file_size :375 (records of N samples)
-    rec = np.asarray(raw[: nrec * N * 4]).reshape(nrec * N, 4)[::N]  # every N-th sample: fread 4 shorts, fseek 4(N-1) :379-382
+    # every N-th sample: fread 4 shorts, fseek 4(N-1) :379-382 — a strided view of the mapping: only the rows used are copied
+    rec = np.ascontiguousarray(raw[: nrec * N * 4].reshape(nrec * N, 4)[::N])
     t = np.concatenate(([0.0], np.cumsum(np.full(nrec - 1, float(N) / fs))))          # t += N/fs, accumulated :392
     lo = np.exp((-1j * 2.0 * np.float64(np.float32(2.0)) / 2.0 * np.pi * foffset) * t)   # tlo*foffset*t, tlo = -j*2*pi :28,372,386
     out = [None, None]

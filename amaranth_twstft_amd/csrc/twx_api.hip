@@ -33,40 +33,51 @@ LaunchEvents& launch_events() { static thread_local LaunchEvents le; return le; 
 // Live contexts keep pointers to their plans while plug-ins loaded later register more: a deque never moves its
 // elements on push_back (a vector would leave those pointers dangling), and the mutex orders registration (dlopen's
 // static initialisers, possibly from another thread's twx_create) against lookups.
-static std::deque<ColOps>& col_reg() { static std::deque<ColOps> v; return v; }
-static std::deque<RowOps>& row_reg() { static std::deque<RowOps> v; return v; }
+static thread_local std::string g_create_err;
+struct ColEntry { ColOps o; bool plugin; };
+struct RowEntry { RowOps o; bool plugin; };
+static std::deque<ColEntry>& col_reg() { static std::deque<ColEntry> v; return v; }
+static std::deque<RowEntry>& row_reg() { static std::deque<RowEntry> v; return v; }
 static std::recursive_mutex& reg_mu() { static std::recursive_mutex m; return m; }
-void register_col(const ColOps& o) { std::lock_guard<std::recursive_mutex> g(reg_mu()); col_reg().push_back(o); }
-void register_row(const RowOps& o) { std::lock_guard<std::recursive_mutex> g(reg_mu()); row_reg().push_back(o); }
+static bool& registering_plugin() { static bool b = false; return b; }      // true while load_plan_file() runs a plug-in's static initialisers (under reg_mu)
+void register_col(const ColOps& o) { std::lock_guard<std::recursive_mutex> g(reg_mu()); col_reg().push_back(ColEntry{o, registering_plugin()}); }
+void register_row(const RowOps& o) { std::lock_guard<std::recursive_mutex> g(reg_mu()); row_reg().push_back(RowEntry{o, registering_plugin()}); }
 const ColOps* find_col(int L, int f64, int W) {            // W = 0: any tile width
     std::lock_guard<std::recursive_mutex> g(reg_mu());
-    for (auto& o : col_reg()) if (o.L == L && o.f64 == f64 && (W == 0 || o.W == W)) return &o;
+    for (auto& e : col_reg()) if (e.o.L == L && e.o.f64 == f64 && (W == 0 || e.o.W == W)) return &e.o;
     return nullptr;
 }
 const RowOps* find_row(int L, int f64) {
     std::lock_guard<std::recursive_mutex> g(reg_mu());
-    for (auto& o : row_reg()) if (o.L == L && o.f64 == f64) return &o;
+    for (auto& e : row_reg()) if (e.o.L == L && e.o.f64 == f64) return &e.o;
     return nullptr;
 }
-bool choose_split(long long n, int f64, const ColOps** col, const RowOps** row) {
+// The pair (N1, N2, W) for a window of n samples is a function of n ALONE: pairs made of built-in plans win over anything a
+// plug-in brings (so the fp32 rounding of a length the library was built for does not depend on which other lengths the
+// process happened to load), and among plug-ins the ranking below does not depend on the load order.
+static bool choose_split_from(long long n, int f64, bool builtin_only, const ColOps** col, const RowOps** row) {
     // Preference: N2 = 4000 where it divides n (its rows leave room for a third resident workgroup and the column
     // length N1 = n/4000 keeps the column workgroups full: measured 26.7 vs 22.8 Gsample/s at n = 2e5, 32.3 vs 29.2
     // at n = 1e6 against N2 = 8000, tools/prof_n.py), otherwise the longest row plan.
-    std::lock_guard<std::recursive_mutex> g(reg_mu());
     const ColOps* bc = nullptr; const RowOps* br = nullptr;
     const char* force = getenv("TWX_N2");                 // experiments: force the row length
     const int forced = force ? atoi(force) : 0;
-    for (auto& r : row_reg()) {
+    for (auto& re : row_reg()) {
+        const RowOps& r = re.o;
+        if (builtin_only && re.plugin) continue;
         if (r.f64 != f64 || n % r.L || (r.L & 1)) continue;
         if (forced && r.L != forced) continue;
         const long long n1 = n / r.L;
         if (n1 > 100000) continue;
         const ColOps* c = nullptr;                        // widest column tile of that length whose width divides the row
-        for (auto& o : col_reg()) if (o.L == (int)n1 && o.f64 == f64 && r.L % o.W == 0 && (!c || o.W > c->W)) c = &o;
+        for (auto& ce : col_reg()) {
+            const ColOps& o = ce.o;
+            if (builtin_only && ce.plugin) continue;
+            if (o.L == (int)n1 && o.f64 == f64 && r.L % o.W == 0 && (!c || o.W > c->W)) c = &o;
+        }
         if (!c) continue;
         // widest column tile first (HBM piece size), then the row: 4000, then the longest row that still leaves room for
-        // two workgroups per CU (<= 8192), long rows last — the choice must not change when a plug-in for another length
-        // (e.g. the 10000-point rows of a 7e7 window) happens to be loaded
+        // two workgroups per CU (<= 8192), long rows last
         auto rank = [](int L) { return L == 4000 ? (1 << 30) : (L <= 8192 ? L : L - (1 << 20)); };
         if (!br || c->W > bc->W || (c->W == bc->W && rank(r.L) > rank(br->L))) { br = &r; bc = c; }
     }
@@ -74,17 +85,34 @@ bool choose_split(long long n, int f64, const ColOps** col, const RowOps** row) 
     *col = bc; *row = br;
     return true;
 }
+bool choose_split(long long n, int f64, const ColOps** col, const RowOps** row) {
+    std::lock_guard<std::recursive_mutex> g(reg_mu());
+    return choose_split_from(n, f64, true, col, row) || choose_split_from(n, f64, false, col, row);
+}
 
-static thread_local std::string g_create_err;
 
 // ------------------------------------------------------------------------------------------
 // plan plug-ins: shared objects built from twx_inst_col.hip / twx_inst_row.hip for one more transform length
 // (amaranth_twstft_amd/plans.py); loading one runs its static registration (register_col / register_row above)
 // ------------------------------------------------------------------------------------------
+#ifndef TWX_SRC_HASH
+#define TWX_SRC_HASH "dev"
+#endif
 static std::vector<std::string>& loaded_plugins() { static std::vector<std::string> v; return v; }
+// A plug-in registers kernels whose argument structs come from the kernel sources it was compiled with: only files named
+// *_<hash of THIS library's kernel sources>.so are accepted (amaranth_twstft_amd/plans.py names them so).  The whole of it
+// runs under the registry mutex: two threads creating contexts for unknown lengths do not dlopen the same file twice.
 static int load_plan_file(const std::string& path) {
+    std::lock_guard<std::recursive_mutex> g(reg_mu());
     for (auto& p : loaded_plugins()) if (p == path) return 0;
+    const std::string tail = std::string("_") + TWX_SRC_HASH + ".so";
+    if (path.size() <= tail.size() || path.compare(path.size() - tail.size(), tail.size(), tail) != 0) {
+        g_create_err = std::string("plan ") + path + " was not built from this library's kernel sources (expected *" + tail + ")";
+        return -1;
+    }
+    registering_plugin() = true;
     void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    registering_plugin() = false;
     if (!h) { g_create_err = std::string("cannot load plan ") + path + ": " + dlerror(); return -1; }
     loaded_plugins().push_back(path);
     return 0;
@@ -99,12 +127,10 @@ static std::string default_plan_dir() {
     }
     return "plans";
 }
-#ifndef TWX_SRC_HASH
-#define TWX_SRC_HASH "dev"
-#endif
 // loads every plug-in of the plan directory built from THIS library's kernel sources (file name *_<hash>.so) that is
 // not loaded yet; returns how many
 static int scan_plan_dir() {
+    std::lock_guard<std::recursive_mutex> g(reg_mu());
     const std::string dir = default_plan_dir();
     DIR* d = opendir(dir.c_str());
     if (!d) return 0;
@@ -280,8 +306,9 @@ __global__ void k_synth(short2* __restrict__ out, long long n, long long n0, con
 // ------------------------------------------------------------------------------------------
 struct ProfRec { hipEvent_t a, b; int cls; long long units; };
 static const char* kProfNames[] = {"k_sums", "k_col_fwd_square", "k_row_band", "k_df_tables", "k_col_fwd_mix",
-                                   "k_row_mid", "k_col_inv", "k_peak"};
-enum { PC_SUMS = 0, PC_COL_SQ, PC_ROW_BAND, PC_DFT, PC_COL_MIX, PC_ROW_MID, PC_COL_INV, PC_PEAK, PC_COUNT };
+                                   "k_row_mid", "k_col_inv", "k_peak", "k_row_caf", "k_col_inv_caf", "k_caf_reduce", "caf_forward"};
+enum { PC_SUMS = 0, PC_COL_SQ, PC_ROW_BAND, PC_DFT, PC_COL_MIX, PC_ROW_MID, PC_COL_INV, PC_PEAK, PC_ROW_CAF, PC_COL_INV_CAF, PC_CAF_REDUCE,
+       PC_CAF_FWD, PC_COUNT };
 
 struct CtxBase {
     twx_config cfg{};
@@ -355,6 +382,19 @@ struct CtxBase {
     }
     void* aux_buf[AUX_SCRATCH_SLOTS] = {}; size_t aux_cap[AUX_SCRATCH_SLOTS] = {};   // ctx_scratch (twx_internal.h)
     std::vector<unsigned char> aux_shadow[AUX_SCRATCH_SLOTS];
+    // Context-owned device buffer number `slot`, at least `bytes` long, kept across calls (slots 0-1: twx_aux.hip, 2-5: the CAF
+    // surface): re-allocated only when it has to grow, after synchronising the context.  nullptr on failure (error text set).
+    void* scratch_slot(int slot, size_t bytes) {
+        if (slot < 0 || slot >= AUX_SCRATCH_SLOTS) { fail(TWX_E_ARG, "bad scratch slot"); return nullptr; }
+        if (aux_cap[slot] >= bytes && aux_buf[slot]) return aux_buf[slot];
+        aux_shadow[slot].clear();
+        if (aux_buf[slot]) { (void)sync_all(); dfree(aux_buf[slot]); aux_buf[slot] = nullptr; aux_cap[slot] = 0; }
+        char* p = nullptr;
+        const size_t want = bytes + bytes / 8 + 256;          // a little head-room: sizes that creep up do not re-allocate every call
+        if (dalloc(&p, want)) return nullptr;
+        aux_buf[slot] = p; aux_cap[slot] = want;
+        return p;
+    }
     int remove_mean = 1;          // TWX_OPT_REMOVE_MEAN
     int dbg_only = -1, dbg_repeat = 1;   // TWX_OPT_DEBUG_ONLY / _REPEAT: launch one kernel class of the chain, n times (power / clock probes)
     int reps(int cls) const { return dbg_only < 0 ? 1 : (dbg_only == cls ? dbg_repeat : 0); }
@@ -421,6 +461,7 @@ template <typename T> struct Ctx : CtxBase {
     C* cspec = nullptr;
     C *cspec_perm = nullptr, *dtabs = nullptr, *ea_d = nullptr, *eb_d = nullptr;   // DIF/DIT row pass (k_rowd)
     C* wr_d = nullptr;            // exp(-2 pi i j/R), j < R: pruned last stage of k_rowd<BAND>
+    C* vc_d = nullptr;            // [k1][c] exp(+2 pi i k1 c M/N): stage C's per-row output twiddle of k_rowd<MID> (scalar loads)
     int use_rowd = 0;
     unsigned char* chips_dev = nullptr;
     // batch buffers
@@ -535,6 +576,16 @@ template <typename T> struct Ctx : CtxBase {
             std::vector<C> wr((size_t)Rr);
             for (int j = 0; j < Rr; ++j) wr[(size_t)j] = Wf(j, Rr);
             if (int rc = upload(&wr_d, wr)) return rc;
+            {
+                const long long Mblk = (long long)N2 / R0;
+                std::vector<C> vc((size_t)N1 * R0);
+                for (int k1 = 0; k1 < N1; ++k1) for (int c = 0; c < R0; ++c) {
+                    const long long num = (long long)(((__int128)k1 * c * Mblk) % N);
+                    const long double a = tp * (long double)num / (long double)N;
+                    vc[(size_t)k1 * R0 + c] = mk<T>((T)cosl(a), (T)sinl(a));
+                }
+                if (int rc = upload(&vc_d, vc)) return rc;
+            }
             std::vector<C> a1((size_t)R * NU), b1((size_t)R * 2 * Rr);
             for (int rho = 0; rho < R; ++rho) {
                 for (int q0 = 0; q0 < R0; ++q0) for (int q1 = 0; q1 < Rr; ++q1) {
@@ -899,7 +950,7 @@ template <typename T> struct Ctx : CtxBase {
             ProfScope ps(this, PC_ROW_MID, (long long)nb * N);
             for (int it = 0, ne = reps(PC_ROW_MID); it < ne; ++it)
             if (use_rowd) {
-                RowDArgs<T> rd{}; rd.r = ra; rd.dtabs = dtabs; rd.cspec_perm = cspec_perm; rd.ea_d = ea_d; rd.eb_d = eb_d;
+                RowDArgs<T> rd{}; rd.r = ra; rd.dtabs = dtabs; rd.cspec_perm = cspec_perm; rd.ea_d = ea_d; rd.eb_d = eb_d; rd.vc = vc_d;
                 if (row->rowd(ROW_MID, &rd, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_rowd(mid) launch failed");
             } else if (row->run(ROW_MID, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(mid) launch failed");
         }
@@ -1403,7 +1454,9 @@ template <typename T> struct Ctx : CtxBase {
         const int nbmax = B * R;
         const long long nbins = k_hi - k_lo + 1;
         Scratch sc(this);
-        if (int rc = sc.get(&Ysp, (size_t)N)) return rc;
+        // the surface's work buffers stay with the context (a 2.5-GB bin buffer allocated and freed per call cost a third of
+        // the call, profiles/r03_caf_sweep.txt)
+        if (!(Ysp = static_cast<C*>(scratch_slot(2, (size_t)N * sizeof(C))))) return TWX_E_NOMEM;
         if (int rc = sc.get(&pk_d, (size_t)nbins)) return rc;       // every bin's record stays on the device until the end:
         if (int rc = sc.get(&lag_d, (size_t)nbins)) return rc;      // one D2H copy and one synchronisation per call
         const short2* in = reinterpret_cast<const short2*>(iq_dev) + ch;
@@ -1419,37 +1472,51 @@ template <typename T> struct Ctx : CtxBase {
         if (row->run(ROW_STORE, &ra, (unsigned)N1, stream)) return fail(TWX_E_HIP, "k_row(store) launch failed");
         // DIF/DIT form of the per-bin row pass (k_rowd_caf) where the row plan has one: Y in block-thread order, several
         // bins per workgroup, and a bin buffer of its own (up to 64 bins or 2.5 GB per launch instead of the B*R batch windows)
-        static const int caf_bpl = [] { const char* e = getenv("TWX_CAF_BPL"); return e ? std::max(1, atoi(e)) : 64; }();   // bins per launch (measured: 64 x 32 per workgroup best, tools/caf_rate.py)
+        // bins per launch / per workgroup: tools/caf_rate.py sweeps (profiles/r03_caf_sweep.txt)
+        static const int caf_bpl = [] { const char* e = getenv("TWX_CAF_BPL"); return e ? std::max(1, atoi(e)) : 64; }();
+        static const long long caf_maxmb = [] { const char* e = getenv("TWX_CAF_MAXMB"); return e ? std::max(64ll, atoll(e)) : 2560ll; }();
         const bool caf_stockham = getenv("TWX_CAF_STOCKHAM") != nullptr;            // tests/experiments: force the Stockham form (read per call)
         const bool dform = cspec_perm && row->rowd && row->S == 3 && !caf_stockham;
         C* Yperm = nullptr; C* Bzc = Bz; ArgPart<T>* partc = part_peak;
         int nbpl = nbmax, bpw = 1;
         if (dform) {
-            if (int rc = sc.get(&Yperm, (size_t)N)) return rc;
+            if (!(Yperm = static_cast<C*>(scratch_slot(3, (size_t)N * sizeof(C))))) return TWX_E_NOMEM;
             TWX_LAUNCH((k_cspec_perm<T>), dim3(N1), dim3(256), stream, Ysp, Yperm, N1, N2, row->R[0], row->R[2]);
             HIPCHK(hipGetLastError());
-            const long long want = std::min<long long>(std::min<long long>(caf_bpl, nbins), std::max<long long>(1, (2560ll << 20) / (N * (long long)sizeof(C))));
+            const long long want = std::min<long long>(std::min<long long>(caf_bpl, nbins), std::max<long long>(1, (caf_maxmb << 20) / (N * (long long)sizeof(C))));
             if (want > nbmax) {
-                if (int rc = sc.get(&Bzc, (size_t)N * want)) return rc;
-                if (int rc = sc.get(&partc, (size_t)ntiles * want)) return rc;
-                nbpl = (int)want;
+                if (!(Bzc = static_cast<C*>(scratch_slot(4, (size_t)N * want * sizeof(C))))) return TWX_E_NOMEM;
+                if (!(partc = static_cast<ArgPart<T>*>(scratch_slot(5, (size_t)ntiles * want * sizeof(ArgPart<T>))))) return TWX_E_NOMEM;
             }
+            nbpl = (int)want;                        // <= nbmax: the batch buffers of the chain serve as the bin buffer
             static const int bpw_env = [] { const char* e = getenv("TWX_CAF_BPW"); return e ? std::max(1, atoi(e)) : 32; }();
-            bpw = bpw_env;
+            bpw = std::min(bpw_env, nbpl);
         }
+        // non-temporal bin-buffer stores only when the launch's bins cannot stay cached (TWX_CAF_NT=0/1 forces)
+        static const int nt_env = [] { const char* e = getenv("TWX_CAF_NT"); return e ? atoi(e) : -1; }();
+        const int nt = nt_env >= 0 ? nt_env : ((long long)nbpl * N * (long long)sizeof(C) > (192ll << 20) ? 1 : 0);
         for (long long k0 = k_lo; k0 <= k_hi; k0 += nbpl) {
             const int nb = (int)std::min<long long>(nbpl, k_hi - k0 + 1);
             CafArgs<T> fa{};
             fa.n = N; fa.n1 = N1; fa.nbins = nb; fa.kappa0 = k0; fa.Y = Ysp; fa.cspec = cspec; fa.stab_i = stab_i;
             fa.ta = ta; fa.tb = tb; fa.tshift = tshift; fa.scale = (T)scale_pow2; fa.Bz = Bzc;
-            fa.Yperm = Yperm; fa.cspec_perm = cspec_perm; fa.dtabs = dtabs; fa.bpw = bpw;
+            fa.Yperm = Yperm; fa.cspec_perm = cspec_perm; fa.dtabs = dtabs; fa.vc = vc_d; fa.bpw = bpw; fa.nt = nt;
             const unsigned grid = dform ? (unsigned)(N1 * ((nb + bpw - 1) / bpw)) : (unsigned)(N1 * nb);
-            if (row->caf(&fa, grid, stream)) return fail(TWX_E_HIP, "k_row_caf launch failed");
+            {
+                ProfScope ps(this, PC_ROW_CAF, (long long)nb * N);
+                if (row->caf(&fa, grid, stream)) return fail(TWX_E_HIP, "k_row_caf launch failed");
+            }
             ColInvArgs<T> ia{};
             ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = 1; ia.nwin = nb; ia.Bz = Bzc; ia.tw1 = tw1; ia.part = partc; ia.zout = nullptr;
-            if (col->inv(&ia, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_inv launch failed");
-            TWX_LAUNCH((k_caf_reduce<T>), dim3(nb), dim3(256), stream, partc, ntiles, 1.0 / scale_pow2 / (double)N, pk_d + (k0 - k_lo), lag_d + (k0 - k_lo));
-            HIPCHK(hipGetLastError());
+            {
+                ProfScope ps(this, PC_COL_INV_CAF, (long long)nb * N);
+                if (col->inv(&ia, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_inv launch failed");
+            }
+            {
+                ProfScope ps(this, PC_CAF_REDUCE, nb);
+                TWX_LAUNCH((k_caf_reduce<T>), dim3(nb), dim3(256), stream, partc, ntiles, 1.0 / scale_pow2 / (double)N, pk_d + (k0 - k_lo), lag_d + (k0 - k_lo));
+                HIPCHK(hipGetLastError());
+            }
         }
         HIPCHK(hipMemcpyAsync(pk, pk_d, sizeof(double) * (size_t)nbins, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(lag, lag_d, sizeof(long long) * (size_t)nbins, hipMemcpyDeviceToHost, stream));
@@ -1471,18 +1538,7 @@ hipStream_t ctx_stream(twx_ctx* ctx) { return ctx->impl->stream; }
 int ctx_fail(twx_ctx* ctx, int code, const char* msg) { return ctx->impl->fail(code, msg); }
 int ctx_set_device(twx_ctx* ctx) { return hipSetDevice(ctx->impl->dev) == hipSuccess ? TWX_OK : ctx->impl->fail(TWX_E_HIP, "hipSetDevice failed"); }
 std::vector<unsigned char>& ctx_scratch_shadow(twx_ctx* ctx, int slot) { return ctx->impl->aux_shadow[slot < 0 || slot >= AUX_SCRATCH_SLOTS ? 0 : slot]; }
-void* ctx_scratch(twx_ctx* ctx, int slot, size_t bytes) {
-    CtxBase* c = ctx->impl;
-    if (slot < 0 || slot >= AUX_SCRATCH_SLOTS) { c->fail(TWX_E_ARG, "bad scratch slot"); return nullptr; }
-    if (c->aux_cap[slot] >= bytes && c->aux_buf[slot]) return c->aux_buf[slot];
-    c->aux_shadow[slot].clear();
-    if (c->aux_buf[slot]) { (void)c->sync_all(); c->dfree(c->aux_buf[slot]); c->aux_buf[slot] = nullptr; c->aux_cap[slot] = 0; }
-    char* p = nullptr;
-    const size_t want = bytes + bytes / 8 + 256;          // a little head-room: sizes that creep up do not re-allocate every call
-    if (c->dalloc(&p, want)) return nullptr;
-    c->aux_buf[slot] = p; c->aux_cap[slot] = want;
-    return p;
-}
+void* ctx_scratch(twx_ctx* ctx, int slot, size_t bytes) { return ctx->impl->scratch_slot(slot, bytes); }
 }  // namespace twx
 
 // No exception may cross the C boundary (std::async, std::vector and std::string can throw).
@@ -1576,8 +1632,8 @@ int twx_plan_available(int64_t n, int32_t precision) {
 int twx_plan_lengths(int32_t kind, int32_t precision, int32_t* lengths, int32_t* widths, int32_t max_entries) {
     int n = 0;
     std::lock_guard<std::recursive_mutex> g(reg_mu());
-    if (kind == 0) { for (auto& o : col_reg()) if (o.f64 == (precision == TWX_F64)) { if (n < max_entries) { if (lengths) lengths[n] = o.L; if (widths) widths[n] = o.W; } ++n; } }
-    else { for (auto& o : row_reg()) if (o.f64 == (precision == TWX_F64)) { if (n < max_entries) { if (lengths) lengths[n] = o.L; if (widths) widths[n] = 0; } ++n; } }
+    if (kind == 0) { for (auto& e : col_reg()) if (e.o.f64 == (precision == TWX_F64)) { if (n < max_entries) { if (lengths) lengths[n] = e.o.L; if (widths) widths[n] = e.o.W; } ++n; } }
+    else { for (auto& e : row_reg()) if (e.o.f64 == (precision == TWX_F64)) { if (n < max_entries) { if (lengths) lengths[n] = e.o.L; if (widths) widths[n] = 0; } ++n; } }
     return n;
 }
 
@@ -1605,7 +1661,7 @@ int twx_synchronize(twx_ctx* ctx) {
 int twx_set_option(twx_ctx* ctx, int32_t option, int64_t value) {
     if (!ctx) return TWX_E_ARG;
     if (option == TWX_OPT_REMOVE_MEAN) { (void)ctx->impl->sync_all(); ctx->impl->remove_mean = value ? 1 : 0; return TWX_OK; }
-    if (option == TWX_OPT_DEBUG_ONLY) { if (value >= PC_COUNT) return ctx->impl->fail(TWX_E_ARG, "no such kernel class"); ctx->impl->dbg_only = value < 0 ? -1 : (int)value; return TWX_OK; }
+    if (option == TWX_OPT_DEBUG_ONLY) { if (value > PC_PEAK) return ctx->impl->fail(TWX_E_ARG, "no such kernel class"); ctx->impl->dbg_only = value < 0 ? -1 : (int)value; return TWX_OK; }
     if (option == TWX_OPT_DEBUG_REPEAT) { ctx->impl->dbg_repeat = (int)std::max<long long>(1, std::min<long long>(value, 1000000)); return TWX_OK; }
     return ctx->impl->fail(TWX_E_ARG, "unknown option");
 }

@@ -84,6 +84,24 @@ __device__ __forceinline__ cpx<float> cmulc3_f32_asm(cpx<float> a, cpx<float> b,
         : "=&v"(t), "=&v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// a*s and (a*b)*s with s WAVE-UNIFORM: the same packed instructions with the uniform operand left in a scalar register pair
+// (op_sel / neg work on SGPR-pair sources as on VGPR pairs; one SGPR source per instruction = the constant-bus limit)
+__device__ __forceinline__ cpx<float> cmul_us_f32_asm(cpx<float> a, cpx<float> s) {
+    cpx<float> t, d;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(t), "=&v"(d) : "v"(a), "s"(s));
+    return d;
+}
+__device__ __forceinline__ cpx<float> cmul3_us_f32_asm(cpx<float> a, cpx<float> b, cpx<float> s) {
+    cpx<float> t, d;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_mul_f32 %0, %1, %4 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %1, %4, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(t), "=&v"(d) : "v"(a), "v"(b), "s"(s));
+    return d;
+}
 #define TWX_ASM_CMUL 1
 #endif
 TWX_HD cpx<double> cmul(cpx<double> a, cpx<double> b) { return cmul_g(a, b); }
@@ -91,6 +109,10 @@ TWX_HD cpx<double> cmulc(cpx<double> a, cpx<double> b) { return cmulc_g(a, b); }
 TWX_HD cpx<double> cmul3(cpx<double> a, cpx<double> b, cpx<double> c) { return cmul_g(cmul_g(a, b), c); }
 TWX_HD cpx<double> cmulc3(cpx<double> a, cpx<double> b, cpx<double> c) { return cmulc_g(cmulc_g(a, b), c); }
 #if defined(TWX_ASM_CMUL)
+__device__ __forceinline__ cpx<float> cmul_us(cpx<float> a, cpx<float> s) { return cmul_us_f32_asm(a, s); }
+__device__ __forceinline__ cpx<float> cmul3_us(cpx<float> a, cpx<float> b, cpx<float> s) { return cmul3_us_f32_asm(a, b, s); }
+TWX_HD cpx<double> cmul_us(cpx<double> a, cpx<double> s) { return cmul_g(a, s); }
+TWX_HD cpx<double> cmul3_us(cpx<double> a, cpx<double> b, cpx<double> s) { return cmul_g(cmul_g(a, b), s); }
 __device__ __forceinline__ cpx<float> cmul(cpx<float> a, cpx<float> b) { return cmul_f32_asm(a, b); }
 __device__ __forceinline__ cpx<float> cmulc(cpx<float> a, cpx<float> b) { return cmulc_f32_asm(a, b); }
 __device__ __forceinline__ cpx<float> cmul3(cpx<float> a, cpx<float> b, cpx<float> c) { return cmul3_f32_asm(a, b, c); }      // (a*b)*c
@@ -98,6 +120,10 @@ __device__ __forceinline__ cpx<float> cmulc3(cpx<float> a, cpx<float> b, cpx<flo
 #else
 TWX_HD cpx<float> cmul3(cpx<float> a, cpx<float> b, cpx<float> c) { return cmul_g(cmul_g(a, b), c); }
 TWX_HD cpx<float> cmulc3(cpx<float> a, cpx<float> b, cpx<float> c) { return cmulc_g(cmulc_g(a, b), c); }
+TWX_HD cpx<float> cmul_us(cpx<float> a, cpx<float> s) { return cmul_g(a, s); }
+TWX_HD cpx<float> cmul3_us(cpx<float> a, cpx<float> b, cpx<float> s) { return cmul_g(cmul_g(a, b), s); }
+TWX_HD cpx<double> cmul_us(cpx<double> a, cpx<double> s) { return cmul_g(a, s); }
+TWX_HD cpx<double> cmul3_us(cpx<double> a, cpx<double> b, cpx<double> s) { return cmul_g(cmul_g(a, b), s); }
 TWX_HD cpx<float> cmul(cpx<float> a, cpx<float> b) { return cmul_g(a, b); }
 TWX_HD cpx<float> cmulc(cpx<float> a, cpx<float> b) { return cmulc_g(a, b); }
 #endif
@@ -115,6 +141,8 @@ template <typename T> TWX_HD cpx<T> cmulc(cpx<T> a, cpx<T> b) {  // a * conj(b)
 }
 template <typename T> TWX_HD cpx<T> cmul3(cpx<T> a, cpx<T> b, cpx<T> c) { return cmul(cmul(a, b), c); }
 template <typename T> TWX_HD cpx<T> cmulc3(cpx<T> a, cpx<T> b, cpx<T> c) { return cmulc(cmulc(a, b), c); }
+template <typename T> TWX_HD cpx<T> cmul_us(cpx<T> a, cpx<T> s) { return cmul(a, s); }
+template <typename T> TWX_HD cpx<T> cmul3_us(cpx<T> a, cpx<T> b, cpx<T> s) { return cmul(cmul(a, b), s); }
 template <typename T> TWX_HD cpx<T> cconj(cpx<T> a) { return mk<T>(a.x, -a.y); }
 template <typename T> TWX_HD cpx<T> cscale(cpx<T> a, T s) { return mk<T>(a.x * s, a.y * s); }
 template <typename T> TWX_HD T cnorm(cpx<T> a) { return a.x * a.x + a.y * a.y; }
@@ -621,6 +649,16 @@ template <class P, typename T> struct RowD {
             TWX_UNROLL
             for (int b = 0; b < R; ++b) lds[phys(q0, b, a)] = cmulc3(v[b], wa, tabs[tab_c + q0 * R + b]);
         }
+    }
+    // stage B with the factors handed over ready-made: lds(q0,b,a) = IDFT(...)[b] * wa * tabs[tab_c + q0 R + b] — the caller has
+    // folded everything that does not depend on q0's partner index into them (k_rowd<MID>: conjugated twiddles, the output
+    // twiddle W_N^{-k1 (a + R b)} and the interpolation ramp of the phase), so stage C needs one product per output less
+    static TWX_HD void iB_folded(C* lds, const C* tabs, int q0, int a, C wa, C* v) {
+        TWX_UNROLL
+        for (int r = 0; r < R; ++r) v[r] = lds[phys(q0, r, a)];
+        Bfly<T, R, true>::run(v);
+        TWX_UNROLL
+        for (int b = 0; b < R; ++b) lds[phys(q0, b, a)] = cmul3(v[b], wa, tabs[tab_c + q0 * R + b]);
     }
     // R0 == 1: stage B without the write-back — thread (block, a) ends with v[b] = z[a + R b]
     static TWX_HD void iB_keep(const C* lds, int q0, int a, C* v) {

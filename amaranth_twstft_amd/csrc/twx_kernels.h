@@ -37,6 +37,12 @@
 #ifndef TWX_NT_A
 #define TWX_NT_A 1      // k_rowd: non-temporal loads of the column-pass output A (read exactly once)
 #endif
+#ifndef TWX_MID_FOLD
+#define TWX_MID_FOLD 1   // k_rowd<MID>: output twiddle W_N^{-k1 t} and phase ramp folded into stage B's factors (one product per output less)
+#endif
+#ifndef TWX_MID_SGPR
+#define TWX_MID_SGPR 1   // k_rowd<MID>: wave-uniform factors (stage C's W_N^{-k1 c M}, the ramp's q2 part) through scalar loads, not LDS reads
+#endif
 #ifndef TWX_NT_BZ
 #define TWX_NT_BZ 1     // k_rowd<MID>: non-temporal stores of Bz (written once, read once by k_col_inv 1 GB later)
 #endif
@@ -121,6 +127,12 @@ template <typename V> __device__ __forceinline__ V ld_su(const void* ubase, unsi
 template <typename V> __device__ __forceinline__ void st_su(void* ubase, unsigned lane_bytes, V val) {
     TWX_GLOBAL char* g = (TWX_GLOBAL char*)sgpr_u64(reinterpret_cast<unsigned long long>(ubase));
     *(TWX_GLOBAL V*)(g + lane_bytes) = val;
+}
+// Load from a read-only table at a WAVE-UNIFORM index through the constant address space: compiles to s_load_* (the value
+// arrives in SGPRs and is counted by lgkmcnt, so it neither occupies a VGPR nor waits behind earlier vector stores).
+#define TWX_CONSTAS __attribute__((address_space(4)))
+template <typename V> __device__ __forceinline__ V ld_uniform(const V* table, int idx) {
+    return ((const TWX_CONSTAS V*)(unsigned long long)table)[idx];
 }
 // With a base that is ALREADY pinned in SGPRs (sgpr_u64 once, then scalar arithmetic on it): base + uniform_bytes + lane_bytes
 template <typename V, bool NT> __device__ __forceinline__ V ld_pin(unsigned long long pinned, unsigned long long uniform_bytes, unsigned lane_bytes) {
@@ -1002,6 +1014,7 @@ template <typename T> struct RowDArgs {
     // ROW_BAND with a narrow search band: only the bins k2 = q0 + R0 q1 + R0 R q2 of a few (q1, q2) pairs can lie inside it
     // (k = k1 + N1 k2; +-20 kHz of a 5-Msps second = |k2| <= 32 of 8000: 4 pairs).  nprune > 0: the last stage is replaced
     // by one R-term sum per (q0, pair) instead of a full radix-R butterfly in every lane.
+    const cpx<T>* vc;                // [k1][c]  exp(+2 pi i k1 c M/N), c < R0: the per-row output twiddle of stage C, read with scalar loads
     const cpx<T>* wr;                // [R] exp(-2 pi i j / R)
     int nprune;                      // number of (q1, q2) pairs, 0 = full last stage
     unsigned long long pr_q1, pr_q2; // pair p in byte p
@@ -1046,11 +1059,19 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     TWX_UNROLL
     for (int k = 0; k < NTAB; ++k) treg[k] = ad.dtabs[min(tid + k * NT, D::tab_total - 1)];     // clamped: no branch, no select
     C ebreg = mk<T>(0, 0), vca = mk<T>(1, 0), vcb = mk<T>(1, 0);
+    C fa1 = mk<T>(1, 0), fa2 = mk<T>(1, 0), fb1 = mk<T>(1, 0), fb2 = mk<T>(1, 0);
     if constexpr (MODE == ROW_MID) {
         static_assert(TWX_MAX_PHASE * 2 * R <= NT, "phase-ramp table larger than the workgroup");
         ebreg = ad.eb_d[min(tid, a.nphase * 2 * R - 1)];
         const unsigned m = (unsigned)k1 * (unsigned)min(tid, R0 - 1) * (unsigned)M;  // conj(W_N^{k1 * c * M})
         vca = a.ta[m >> a.tshift]; vcb = a.tb[m & mask];
+        if constexpr (TWX_MID_FOLD && R0 > 1) {
+            // the output twiddle W_N^{-k1 t}, t = a + R b, split into the part of stage B's thread (a = qi) and the part
+            // that goes into the table of stage B (b = tid mod R): gathered here, with the other prologue loads
+            const unsigned ma = (unsigned)k1 * (unsigned)min(qi, R - 1), mb = (unsigned)k1 * (unsigned)R * (unsigned)(tid % R);
+            fa1 = a.ta[ma >> a.tshift]; fa2 = a.tb[ma & mask];
+            fb1 = a.ta[mb >> a.tshift]; fb2 = a.tb[mb & mask];
+        }
     }
     __builtin_amdgcn_sched_barrier(0);      // keep the table loads first in program order (loads return in order)
     // the loads are unconditional (idle lanes of the last wave re-read a valid element): inside divergent branches
@@ -1094,6 +1115,11 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
         D::f0_twiddle_store(lds, tabs, tid, v);
     }
     __syncthreads();                                   // all-to-all exchange of the stride-M stage
+    if constexpr (MODE == ROW_MID && TWX_MID_FOLD && R0 > 1) {
+        // stage 0 was the last reader of the forward table tc: turn it into stage B's table, conj(tc[q0][b]) * W_N^{-k1 R b}
+        // (visible to every wave after the barrier at the top of the first phase)
+        if (tid < R0 * R) tabs[D::tab_c + tid] = cmulc(cconj(cmul(fb1, fb2)), tabs[D::tab_c + tid]);
+    }
     if (act) D::f1(lds, tabs, q0, qi, v);
     bool pruned = false;
     if constexpr (MODE == ROW_BAND) pruned = ad.nprune > 0;
@@ -1135,11 +1161,18 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
         if (tid == 0) { ArgPart<T> p; p.val = best.val; p.idx = best.idx; a.part[(long long)b * a.n1 + k1] = p; }
     } else {
         C pr[R];
+        constexpr bool FOLD = TWX_MID_FOLD && R0 > 1;
+        constexpr bool USGPR = TWX_MID_SGPR != 0;
         C ub = mk<T>(1, 0);
-        if (tid < M) {
+        C wa0 = mk<T>(1, 0);
+        if constexpr (FOLD) {
+            // stage B's per-thread factor without the phase ramp: conj(W_L^{q0 a}) * W_N^{-k1 a}
+            if (act) wa0 = cmulc(cconj(cmul(fa1, fa2)), tabs[D::tab_b + q0 * R + qi]);
+        } else if (tid < M) {
             const unsigned m = (unsigned)k1 * (unsigned)tid;
             ub = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
         }
+        const C* vcrow = ad.vc + (long long)k1 * R0;                              // wave-uniform address: scalar loads
         if (act) {
             if (k1 == 0 && u == 0) a.dc[b] = v[0];
             TWX_UNROLL
@@ -1164,10 +1197,11 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                 r1_cur = a.ramp1[(long long)(rho + 1) * a.n1 + k1];
                 if (lact) eaj = ad.ea_d[(rho + 1) * NU + lq0 * R + lqi];
             }
-            if (rho > 0) __syncthreads();              // previous phase's stage C has read every block
+            if (rho > 0 || FOLD) __syncthreads();      // previous phase's stage C has read every block (rho = 0: the folded table is complete)
             if (lact) D::iA_store(lds, lq0, lqi, v);
             wave_sync_lds();
-            if (lact) D::iB(lds, tabs, lq0, lqi, v);
+            if constexpr (FOLD) { if (lact) D::iB_folded(lds, tabs, lq0, lqi, cmul(wa0, r1), v); }
+            else if (lact) D::iB(lds, tabs, lq0, lqi, v);
             __syncthreads();
             if (lt < M) {
                 D::iC(lds, lt, v);
@@ -1177,7 +1211,9 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                 const unsigned long long ob = sgpr_u64(reinterpret_cast<unsigned long long>(out));
                 TWX_UNROLL
                 for (int c = 0; c < R0; ++c) {
-                    const C o = cmul3(v[c], uu, s_vc[c]);                                  // · W_N^{-k1 q2} · ramp1
+                    C o;                                                                       // · W_N^{-k1 (t + c M)} · ramp1
+                    if constexpr (FOLD) o = USGPR ? cmul_us(v[c], ld_uniform(vcrow, c)) : cmul(v[c], s_vc[c]);
+                    else o = USGPR ? cmul3_us(v[c], uu, ld_uniform(vcrow, c)) : cmul3(v[c], uu, s_vc[c]);
                     st_pin<C, TWX_NT_BZ != 0>(ob, (unsigned long long)c * M * sizeof(C), ltb, o);     // SGPR base + lane offset
                 }
             }
@@ -1185,12 +1221,13 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                 const int rn = rho + 1;
                 TWX_UNROLL
                 for (int q2 = 0; q2 < R; ++q2) {
-                    // from the LDS copy, not from global memory: a global load issued after this phase's Bz stores can
-                    // only be waited for together with them (loads and stores share vmcnt) — a store round trip per phase
-                    C e;
-                    if constexpr (R % 2 == 0) e = s_eb[(rn * 2 + (q2 >= R / 2 ? 1 : 0)) * R + q2];      // uniform address: LDS broadcast
-                    else e = s_eb[(rn * 2 + ((2 * D::k_of(lq0, lqi, q2) >= N2) ? 1 : 0)) * R + q2];
-                    v[q2] = cmul3(pr[q2], eaj, e);
+                    // from the LDS copy (or, uniform, with scalar loads), not with vector loads from global memory: a vector load
+                    // issued after this phase's Bz stores can only be waited for together with them (loads and stores share
+                    // vmcnt) — a store round trip per phase
+                    if constexpr (R % 2 == 0) {
+                        if constexpr (USGPR) v[q2] = cmul3_us(pr[q2], eaj, ld_uniform(ad.eb_d, (rn * 2 + (q2 >= R / 2 ? 1 : 0)) * R + q2));
+                        else v[q2] = cmul3(pr[q2], eaj, s_eb[(rn * 2 + (q2 >= R / 2 ? 1 : 0)) * R + q2]);      // uniform address: LDS broadcast
+                    } else v[q2] = cmul3(pr[q2], eaj, s_eb[(rn * 2 + ((2 * D::k_of(lq0, lqi, q2) >= N2) ? 1 : 0)) * R + q2]);
                 }
                 D::iA_pre(tabs, lqi, v);
             }
@@ -1359,7 +1396,10 @@ template <typename T> struct CafArgs {
     const cpx<T>* Yperm;    // [k1][q2][u] = Y[k1][q0 + R0 q1 + R0 R q2], u = q0*R + q1 (k_cspec_perm applied to Y); nullptr: Stockham form
     const cpx<T>* cspec_perm;
     const cpx<T>* dtabs;
+    const cpx<T>* vc;       // [k1][c] exp(+2 pi i k1 c M/N) (k_rowd_caf: stage C's output twiddle, scalar loads)
     int bpw;
+    int nt;                 // 1: non-temporal bin-buffer stores (a buffer far larger than the caches); 0: the few bins of a launch
+                            // are meant to stay in L2 / Infinity Cache until the last pass reads them
 };
 
 template <class P2, typename T, int PADQ, int NT>
@@ -1434,16 +1474,32 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 4 ? 4 : 1)) void k_rowd_caf(CafAr
     const bool act = D::blk_map(tid, q0, qi);
     const int q0c = min(q0, R0 - 1);                       // idle lanes compute valid addresses (their loads are unconditional)
     const unsigned mask = (1u << a.tshift) - 1u;
-    for (int i = tid; i < D::tab_total; i += NT) tabs[i] = a.dtabs[i];
+    // As in k_rowd<MID>: the output twiddle W_N^{-k1 t}, t = a + R b, goes into stage B's factors (the table tc becomes
+    // conj(tc[q0][b]) * W_N^{-k1 R b}, the thread's scalar conj(W_L^{q0 a}) * W_N^{-k1 a}), and stage C's W_N^{-k1 c M} is read
+    // with scalar loads from the per-row table vc: one product and one LDS read per output less.
+    constexpr bool FOLD = TWX_MID_FOLD && R0 > 1;
+    for (int i = tid; i < D::tab_total; i += NT) {
+        C t = a.dtabs[i];
+        if (FOLD && i >= D::tab_c && i < D::tab_c + R0 * R) {
+            const unsigned mb = (unsigned)k1 * (unsigned)R * (unsigned)((i - D::tab_c) % R);
+            t = cmulc(cconj(cmul(a.ta[mb >> a.tshift], a.tb[mb & mask])), t);
+        }
+        tabs[i] = t;
+    }
     if (tid < R0) {
         const unsigned m = (unsigned)k1 * (unsigned)tid * (unsigned)M;
         s_vc[tid] = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
     }
     C ub = mk<T>(1, 0);
-    if (tid < M) {
+    C wa0 = mk<T>(1, 0);
+    if constexpr (FOLD) {
+        const unsigned ma = (unsigned)k1 * (unsigned)qi;
+        wa0 = cmulc(cconj(cmul(a.ta[ma >> a.tshift], a.tb[ma & mask])), a.dtabs[D::tab_b + q0c * R + qi]);
+    } else if (tid < M) {
         const unsigned m = (unsigned)k1 * (unsigned)tid;
         ub = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
     }
+    const C* vcrow = a.vc + (long long)k1 * R0;
     constexpr bool HOLD = sizeof(T) == 4;                  // complex double: 2 x 80 registers would spill, re-read the row per bin
     C v[RMAX], csr[HOLD ? R : 1];
     const C* cs = a.cspec_perm + (long long)k1 * N2 + (q0c * R + qi);
@@ -1478,15 +1534,18 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 4 ? 4 : 1)) void k_rowd_caf(CafAr
         if (bin > grp * a.bpw) __syncthreads();            // the previous bin's stage C has read every block
         if (act) D::iA_store(lds, q0, qi, v);
         wave_sync_lds();
-        if (act) D::iB(lds, tabs, q0, qi, v);
+        if constexpr (FOLD) { if (act) D::iB_folded(lds, tabs, q0, qi, wa0, v); }
+        else if (act) D::iB(lds, tabs, q0, qi, v);
         __syncthreads();
         if (tid < M) {
             D::iC(lds, tid, v);
             C* out = a.Bz + (long long)bin * a.n + (long long)k1 * N2;
             TWX_UNROLL
             for (int c = 0; c < R0; ++c) {
-                const C o = cmul3(v[c], ub, s_vc[c]);
-                if (TWX_NT_BZ) __builtin_nontemporal_store(o, out + c * M + (unsigned)tid); else (out + c * M)[(unsigned)tid] = o;
+                C o;
+                if constexpr (FOLD) o = TWX_MID_SGPR ? cmul_us(v[c], ld_uniform(vcrow, c)) : cmul(v[c], s_vc[c]);
+                else o = cmul3(v[c], ub, s_vc[c]);
+                if (TWX_NT_BZ && a.nt) __builtin_nontemporal_store(o, out + c * M + (unsigned)tid); else (out + c * M)[(unsigned)tid] = o;
             }
         }
     }

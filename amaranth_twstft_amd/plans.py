@@ -182,6 +182,8 @@ def _plan_macro(L, radices):
 
 
 def _compile(src, out, defs):
+    """hipcc one plug-in.  Returns (path, f64_built): a plan whose complex-double instantiation does not fit the 160 KB of
+    LDS is rebuilt for fp32 only, and the caller names the file after what it really holds."""
     os.makedirs(PLAN_DIR, exist_ok=True)
     if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
         raise RuntimeError(f"{HIPCC} not found: plan plug-ins are compiled with hipcc (set HIPCC=...)")
@@ -192,29 +194,54 @@ def _compile(src, out, defs):
     if r.returncode and "local memory" in r.stderr and "double" in r.stderr and "-DTWX_NO_F64" not in defs:
         # the complex-double instantiation of a long plan does not fit the 160 KB of LDS: fp32 contexts only
         # (the code spectrum is then computed in fp32 as well, Ctx::make_code_spectrum)
-        return _compile(src, out, defs + ["-DTWX_NO_F64"])
+        return _compile(src, out.replace("_f64_", "_f32_"), defs + ["-DTWX_NO_F64"])
     if r.returncode:
         raise RuntimeError("plan build failed:\n" + " ".join(cmd) + "\n" + r.stderr[-3000:])
     os.replace(tmp, out)
     return out
 
 
+def _plan_file(kind: str, plan: dict, f64: bool) -> str:
+    """File name of a plug-in: everything that decides what the object holds is in it — length, stage radices, tile width
+    (columns), precision set (f64 = fp32 + complex-double kernels, f32 = fp32 only) and the hash of the kernel sources.
+    The library only looks at the trailing _<hash>.so."""
+    rad = "x".join(str(r) for r in plan["radices"])
+    w = "_w%d" % plan["W"] if kind == "col" else ""
+    return os.path.join(PLAN_DIR, "%s_%d_%s%s_%s_%s.so" % (kind, plan["L"], rad, w, "f64" if f64 else "f32", source_hash()))
+
+
+def _build(kind: str, src: str, plan: dict, defs) -> str:
+    want64 = bool(plan.get("f64", True))
+    out64, out32 = _plan_file(kind, plan, True), _plan_file(kind, plan, False)
+    if os.path.exists(out64):
+        return out64                                   # holds the fp32 kernels as well
+    if not want64 and os.path.exists(out32):
+        return out32
+    _clean_stale()
+    return _compile(src, out64 if want64 else out32, defs + ([] if want64 else ["-DTWX_NO_F64"]))
+
+
 def build_col(cp) -> str:
-    out = os.path.join(PLAN_DIR, "col_%d_w%d_%s.so" % (cp["L"], cp["W"], source_hash()))
-    if not os.path.exists(out):
-        _clean_stale()
-        _compile("twx_inst_col.hip", out, ["-DTWX_PLAN=" + _plan_macro(cp["L"], cp["radices"]), "-DTWX_W=%d" % cp["W"], "-DTWX_NT=%d" % cp["nt"]]
-                 + ([] if cp.get("f64", True) else ["-DTWX_NO_F64"]))
-    return out
+    return _build("col", "twx_inst_col.hip", cp, ["-DTWX_PLAN=" + _plan_macro(cp["L"], cp["radices"]), "-DTWX_W=%d" % cp["W"], "-DTWX_NT=%d" % cp["nt"]])
 
 
 def build_row(rp) -> str:
-    out = os.path.join(PLAN_DIR, "row_%d_%s.so" % (rp["L"], source_hash()))
-    if not os.path.exists(out):
-        _clean_stale()
-        _compile("twx_inst_row.hip", out, ["-DTWX_PLAN=" + _plan_macro(rp["L"], rp["radices"]), "-DTWX_NT=%d" % rp["nt"], "-DTWX_PADQ=%d" % rp["padq"]]
-                 + ([] if rp.get("f64", True) else ["-DTWX_NO_F64"]))
-    return out
+    return _build("row", "twx_inst_row.hip", rp, ["-DTWX_PLAN=" + _plan_macro(rp["L"], rp["radices"]), "-DTWX_NT=%d" % rp["nt"], "-DTWX_PADQ=%d" % rp["padq"]])
+
+
+def builtin_plans(lib=None) -> dict:
+    """{(kind, precision): {(L, W)}} of what the library holds right now (kind 0 = columns, 1 = rows; W = 0 for rows)."""
+    import ctypes as C
+    from . import _lib as L
+    lib = lib or L.load()
+    have = {}
+    for kind in (0, 1):
+        for precision in (0, 1):
+            cnt = lib.twx_plan_lengths(kind, precision, None, None, 0)
+            ls, ws = (C.c_int32 * max(cnt, 1))(), (C.c_int32 * max(cnt, 1))()
+            lib.twx_plan_lengths(kind, precision, ls, ws, cnt)
+            have[(kind, precision)] = {(ls[i], ws[i]) for i in range(cnt)}
+    return have
 
 
 def ensure(n: int, precision: int = 0, lib=None, verbose: bool = False):
@@ -231,13 +258,8 @@ def ensure(n: int, precision: int = 0, lib=None, verbose: bool = False):
         raise ValueError(f"no N1 x N2 plan for a window of {n} samples (needs n even, = 2^a 3^b 5^c 7^d, N2 <= 10000, N1 <= %d)" % MAX_N1 + "")
     cp, rp = ch
     # reuse what the library already has (built-in or loaded) for either half
-    import ctypes as C
-    have = {}
-    for kind in (0, 1):
-        cnt = lib.twx_plan_lengths(kind, precision, None, None, 0)
-        ls, ws = (C.c_int32 * max(cnt, 1))(), (C.c_int32 * max(cnt, 1))()
-        lib.twx_plan_lengths(kind, precision, ls, ws, cnt)
-        have[kind] = {(ls[i], ws[i]) for i in range(cnt)}
+    hp = builtin_plans(lib)
+    have = {0: hp[(0, int(precision))], 1: hp[(1, int(precision))]}
     files = []
     if (cp["L"], cp["W"]) not in have[0]:
         if verbose:

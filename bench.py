@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--cpu-max-workers", type=int, default=64)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-caf", action="store_true", help="skip the BASELINE.json configs[2] leg (delay x Doppler CAF of one window)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                     "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the collectives even with one "
@@ -351,6 +352,43 @@ def main():
             except Exception:
                 pass
 
+    # --- BASELINE.json configs[2]: full delay x Doppler surface of ONE window, +-5 kHz at 1 Hz (10 001 bins of fs/N), with its own
+    # roofline (reported beside the headline metric, never instead of it)
+    if rank == 0 and world == 1 and not a.no_caf and not a.no_roofline:
+        cc = Correlator(chips, fs=FS, Nint=0, device=local_rank)
+        cc.caf_bins_dev(iq[0].data_ptr(), -100, 100)
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            pkc, lagc = cc.caf_bins_dev(iq[0].data_ptr(), -5000, 5000)
+            ts.append(time.perf_counter() - t0)
+        cc.close()
+        bi = int(np.argmax(pkc))
+        pcx = Correlator(chips, fs=FS, Nint=0, device=local_rank, profile=True)
+        pcx.caf_bins_dev(iq[0].data_ptr(), -100, 100)
+        pcx.profile(reset=True)
+        pcx.caf_bins_dev(iq[0].data_ptr(), -5000, 5000)
+        cprof = pcx.profile()
+        pcx.close()
+        bpl = cprof["k_row_caf"]["units"] / cprof["k_row_caf"]["launches"] / N          # bins per launch
+        cbytes = {"k_row_caf": lambda nb: nb * N * 16 + 8 * N * math.ceil(nb / 32),      # Y row in + bin buffer out per bin, code spectrum per 32-bin group
+                  "k_col_inv_caf": lambda nb: nb * N * 8}                                 # bin buffer in
+        ck = {k: v["ms_total"] / v["launches"] for k, v in cprof.items() if k in cbytes}
+        cdom = max(ck, key=lambda k: cprof[k]["ms_total"])
+        cach = cbytes[cdom](bpl) / (ck[cdom] * 1e-3) / 1e9
+        sw = min(ts)
+        out["caf_workload"] = {"workload": "BASELINE.json configs[2]: one 1-s window, +-5 kHz at 1 Hz = 10001 Doppler bins x 5e6 lags, HBM-resident",
+                               "s_per_window": round(sw, 4), "Gsample_bins_per_s": round(10001 * N / sw / 1e9, 1),
+                               "Msamples_per_s": round(N / sw / 1e6, 2), "peak_bin_hz": bi - 5000, "peak_lag": int(lagc[bi]),
+                               "peak_exact": bool(bi - 5000 == 1781 and int(lagc[bi]) == delays[0]),
+                               "bins_per_launch": int(round(bpl)),
+                               "kernels": {k: {"avg_ms": round(v, 4), "us_per_bin": round(v * 1e3 / bpl, 3),
+                                               "GB/s": round(cbytes[k](bpl) / (v * 1e-3) / 1e9, 1)} for k, v in ck.items()},
+                               "roofline": {"bound": "hbm", "kernel": cdom, "achieved": round(cach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": round(cach / HBM_PEAK_GBS, 4), "traffic": None,
+                                            "algorithmic_bytes_per_launch": int(cbytes[cdom](bpl)), "avg_ms": round(ck[cdom], 4),
+                                            "note": "algorithmic bytes of the kernel's own interface; the Y rows and the bin buffer of a launch "
+                                                    "are mostly served by L2 / Infinity Cache, so HBM traffic is below this figure"}}
     if collective is not None:
         out["collective"] = collective
     if cpu is not None:

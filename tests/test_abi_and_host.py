@@ -258,3 +258,34 @@ def test_hot_kernels_compile_without_register_spills(tmp_path):
             seen += 1
             assert int(spill) == 0 and int(vgpr) <= 80, (name, vgpr, spill)
     assert seen >= 3
+
+
+def test_bluestein_length_search_is_fp64_aware_and_bounded():
+    """cpp_twin._smooth_len: the context is opened in fp64, so only fp64-capable pairs count; lengths beyond every plan pair fail
+    at once (a 10-minute capture used to spin for minutes in a pure-Python search before raising)."""
+    import time
+    from amaranth_twstft_amd import cpp_twin, plans
+    m = cpp_twin._smooth_len(2 * 200_000 - 1)
+    assert m >= 399_999 and plans.choose(m, f64=True) is not None and plans._smooth(m)
+    assert cpp_twin._smooth_candidates(10, 40) == [10, 12, 14, 16, 18, 20, 24, 28, 30, 32, 36, 40]
+    for lo in (2 * 48_000_000 - 1, 2 * 120_000_000 - 1):          # 240-s capture: fp32-only pairs; 10 minutes: no pair at all
+        t = time.time()
+        with pytest.raises(ValueError):
+            cpp_twin._smooth_len(lo)
+        assert time.time() - t < 2.0
+
+
+def test_plan_file_names_carry_radices_and_precision(tmp_path, monkeypatch):
+    """A plug-in's file name says what it holds (length, stage radices, tile width, fp32-only or fp32+fp64, source hash): an
+    fp32-only object can no longer be mistaken for the fp64 build of the same length."""
+    from amaranth_twstft_amd import plans
+    cp, rp = plans.choose(5000)
+    h = plans.source_hash()
+    a = os.path.basename(plans._plan_file("col", cp, True))
+    b = os.path.basename(plans._plan_file("col", cp, False))
+    r = os.path.basename(plans._plan_file("row", rp, True))
+    assert a == "col_%d_%s_w%d_f64_%s.so" % (cp["L"], "x".join(map(str, cp["radices"])), cp["W"], h)
+    assert b == a.replace("_f64_", "_f32_") and r.startswith("row_%d_" % rp["L"]) and r.endswith("_f64_%s.so" % h)
+    lib = L.load()
+    assert lib.twx_load_plan(os.fsencode(str(tmp_path / "col_25_5x5_w16_f64_0000000000.so"))) != 0      # another source hash: refused
+    assert b"kernel sources" in lib.twx_last_error(None)
