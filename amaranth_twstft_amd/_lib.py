@@ -91,6 +91,16 @@ class twx_acq_result(C.Structure):
     _fields_ = [("fc", C.c_double), ("pk", C.c_double), ("pt", C.c_int64), ("n_trials", C.c_int64)]
 
 
+class twx_track_state(C.Structure):
+    _fields_ = [("fs", C.c_double), ("duration", C.c_double), ("psbb", C.c_double), ("fc", C.c_double), ("df", C.c_double),
+                ("phi", C.c_double), ("last_phi", C.c_double), ("pt", C.c_int64), ("fc_prev", C.c_double), ("pt_prev", C.c_int64)]
+
+
+class twx_track_result(C.Structure):
+    _fields_ = [("freq", C.c_double), ("phi", C.c_double), ("gd", C.c_double), ("dg", C.c_double), ("sdgd", C.c_double),
+                ("pk", C.c_double), ("cnt", C.c_int32), ("updated", C.c_int32)]
+
+
 class twx_prof_entry(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("ms_total", C.c_double), ("launches", C.c_int64), ("units", C.c_int64)]
 
@@ -128,6 +138,9 @@ SYMBOLS = {
     "twx_sqspec_bins_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_int32, _VP]),
     "twx_sqspec_band_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _VP]),
     "twx_sliding_dot": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_double, C.c_double, C.c_double, _VP]),
+    "twx_track_update": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.POINTER(twx_track_state), C.POINTER(twx_track_result)]),
+    "twx_track_epoch_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_double,
+                                      C.POINTER(twx_track_state), C.POINTER(twx_track_result)]),
     "twx_fir_decimate": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_int32, C.c_int32, _VP, _VP, C.POINTER(C.c_int64)]),
     "twx_sliding_dot_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_double, C.c_double, C.c_double, _VP]),
     "twx_fir_decimate_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_int32, C.c_int32, _VP, _VP, C.POINTER(C.c_int64)]),

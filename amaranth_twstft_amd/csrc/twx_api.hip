@@ -176,15 +176,30 @@ __global__ void k_stride_copy(const cpx<float>* __restrict__ in, cpx<float>* __r
 // are enqueued back to back without a host round trip: scan the records of the round that just finished in trial order
 // (`if (pk > ci[i].pk)`, :556-562: strictly larger wins, pk = |z| of the izamax element), then halve the step (:565-567)
 // and write the next round's trial carriers fc-step, fc, fc+step... (`for (fcc = flow; fcc <= fhigh; fcc += fstep)`,
-// :538: repeated addition, at most `cap` of them) into the batch's df vector.  One thread.
+// :538: repeated addition, at most `cap` of them) into the batch's df vector.  One workgroup.
 struct AcqState { double fc, pk, step; long long pt, n_trials; int cnt, pad; };
-__global__ void k_acq_update(const twx_result* __restrict__ rec, int n_host, AcqState* st, double* __restrict__ dfv, int cap, long long ptmod) {
-    if (threadIdx.x || blockIdx.x) return;
-    AcqState s = *st;
-    const int n = n_host >= 0 ? n_host : s.cnt;
-    for (int i = 0; i < n; ++i) {
+__global__ __launch_bounds__(256) void k_acq_update(const twx_result* __restrict__ rec, int n_host, AcqState* st, double* __restrict__ dfv, int cap, long long ptmod) {
+    __shared__ double spk[256];
+    __shared__ int sidx[256];
+    const int t = threadIdx.x;
+    const int n = n_host >= 0 ? n_host : st->cnt;
+    // the sequential rule `pk > best` keeps the FIRST occurrence of the largest peak: a first-index arg-max, done in parallel
+    double bp = -1.0; int bi = 0x7fffffff;
+    for (int i = t; i < n; i += 256) {
         const double pk = sqrt(rec[i].xval[0] * rec[i].xval[0] + rec[i].xval[1] * rec[i].xval[1]);
-        if (pk > s.pk) { s.fc = rec[i].df; s.pk = pk; s.pt = ptmod > 0 ? rec[i].indice0 % ptmod : rec[i].indice0; }
+        if (pk > bp) { bp = pk; bi = i; }
+    }
+    spk[t] = bp; sidx[t] = bi;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (t < h && (spk[t + h] > spk[t] || (spk[t + h] == spk[t] && sidx[t + h] < sidx[t]))) { spk[t] = spk[t + h]; sidx[t] = sidx[t + h]; }
+        __syncthreads();
+    }
+    if (t) return;
+    AcqState s = *st;
+    if (n > 0 && spk[0] > s.pk) {
+        const int i = sidx[0];
+        s.fc = rec[i].df; s.pk = spk[0]; s.pt = ptmod > 0 ? rec[i].indice0 % ptmod : rec[i].indice0;
     }
     s.n_trials += n;
     s.step = s.step / 2.0;
@@ -1423,7 +1438,7 @@ template <typename T> struct Ctx : CtxBase {
         twx_result* cur = rec + n1;
         int n_prev = (int)n1; const twx_result* prev = rec;
         for (int r = 0; r <= later && rc == TWX_OK; ++r) {
-            TWX_LAUNCH(k_acq_update, dim3(1), dim3(1), stream, prev, n_prev, st_dev, dfv, cap, ptmod);
+            TWX_LAUNCH(k_acq_update, dim3(1), dim3(256), stream, prev, n_prev, st_dev, dfv, cap, ptmod);
             if (hipGetLastError() != hipSuccess) { rc = fail(TWX_E_HIP, "k_acq_update launch failed"); break; }
             if (r == later) break;                                                   // the last update only folds the last round in
             rc = run_batch_in(IN_C32, win, nullptr, 1, 0, 0, cap, nullptr, nullptr, cur, nullptr, 1);

@@ -44,9 +44,18 @@ __global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict_
     __shared__ float sw[4 * QS];                                   // replica segment; reused by the final reduction
     static_assert(NL * SD_NT <= 4 * QS, "reduction buffer must fit the replica segment");
     const int p = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
-    const long long s0 = (long long)chunk * chunk_len;
-    const int cnt = (int)min((long long)chunk_len, nobs - s0);
     const int tid = threadIdx.x;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 acc[NL];                                                    // (re, im) pairs: one v_pk_fma_f32 per lag and sample
+#pragma unroll
+    for (int l = 0; l < NL; ++l) acc[l] = f2{0.f, 0.f};
+    // a workgroup's chunk may be longer than the LDS segment: it is walked in pieces of SD_CH samples with ONE set of
+    // accumulators, so the block reduction below (as many LDS operations as 3/4 of a full piece) runs once per workgroup
+    const long long c0 = (long long)chunk * chunk_len;
+    const long long c1 = min(c0 + (long long)chunk_len, nobs);
+    for (long long s0 = c0; s0 < c1; s0 += SD_CH) {
+    const int cnt = (int)min((long long)SD_CH, c1 - s0);
+    if (s0 > c0) __syncthreads();                                  // the previous piece's replica segment is no longer read
     // entry u <-> w[(s0 - NLAG + u) mod nobs]
     {
         long long k = (s0 - NLAG + tid) % nobs; if (k < 0) k += nobs;          // one 64-bit division per thread, then steps
@@ -57,17 +66,27 @@ __global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict_
         }
     }
     __syncthreads();
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 acc[NL];                                                    // (re, im) pairs: one v_pk_fma_f32 per lag and sample
-#pragma unroll
-    for (int l = 0; l < NL; ++l) acc[l] = f2{0.f, 0.f};
     const int ngrp = (cnt + SD_T - 1) / SD_T;
+    // the samples of the NEXT pass are requested before this pass's arithmetic (two waves per SIMD do not hide a global
+    // load round trip per pass by themselves); loads are unconditional with clamped indices, values masked below
+    const long long ilast = (long long)p * nobs + s0 + cnt - 1;
+    short2 nx[SD_T];
+    {
+        const long long i0 = (long long)p * nobs + s0 + (long long)SD_T * min(tid, ngrp - 1);
+#pragma unroll
+        for (int j = 0; j < SD_T; ++j) nx[j] = x[(pt + min(i0 + j, ilast)) * nch];
+    }
     for (int g = tid; g < ngrp; g += SD_NT) {
         const int t0 = SD_T * g;
         const long long i0 = (long long)p * nobs + s0 + t0;        // the NCO runs over the whole block of codes
         short2 sm[SD_T];
 #pragma unroll
-        for (int j = 0; j < SD_T; ++j) sm[j] = x[(pt + min(i0 + j, (long long)p * nobs + s0 + cnt - 1)) * nch];    // clamped, masked below
+        for (int j = 0; j < SD_T; ++j) sm[j] = nx[j];
+        {
+            const long long i1 = (long long)p * nobs + s0 + (long long)SD_T * min(g + SD_NT, ngrp - 1);
+#pragma unroll
+            for (int j = 0; j < SD_T; ++j) nx[j] = x[(pt + min(i1 + j, ilast)) * nch];
+        }
         double ph = ff * (double)i0 + phi;                          // fp64 phase reduction, fp32 sincos
         ph -= rint(ph);
         float sn, cs;
@@ -93,6 +112,7 @@ __global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict_
                 acc[l] = __builtin_elementwise_fma(y[j], f2{cv, cv}, acc[l]);
             }
         }
+    }
     }
     // block reduction through LDS, one component at a time: buf[l][tid]; thread r = (l, quarter) sums 64 lanes,
     // starting at a lane-dependent rotation so that the 64 lanes of a wave hit 64 different banks
@@ -147,13 +167,13 @@ int sliding_chunk(long long nobs, int ncodes) {
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) return n;
         return 256;
     }();
+    // one workgroup per slot (two per CU) where the work allows it: chunks of a code of nobs/ceil(...) samples, any length (the
+    // kernel walks a chunk in LDS-sized pieces), at least 4096 samples so that the block reduction stays a small part
     const long long slots = 2ll * ncu;
-    const long long min_chunks = (nobs + SD_CH - 1) / SD_CH;
-    const long long rounds = std::max<long long>(1, (min_chunks * ncodes + slots - 1) / slots);
-    long long nchunks = std::max<long long>(min_chunks, rounds * slots / ncodes);
-    long long len = (nobs + nchunks - 1) / nchunks;
-    len = std::min<long long>(SD_CH, ((len + SD_NT - 1) / SD_NT) * SD_NT);
-    return (int)std::max<long long>(len, SD_NT);
+    const long long per_code = std::max<long long>(1, slots / ncodes);                    // chunks per code in one round
+    long long len = (nobs + per_code - 1) / per_code;
+    len = std::max<long long>(4096, ((len + SD_NT * SD_T - 1) / (SD_NT * SD_T)) * (SD_NT * SD_T));
+    return (int)std::min<long long>(len, 1ll << 24);
 }
 int launch_sliding(hipStream_t st, const short2* dx, int nch, long long pt, long long nobs, int ncodes, int nlag, const float* dw,
                    double ff, double phi, double scale, double* dpart, double* dout) {
@@ -197,7 +217,7 @@ FirGeom fir_geom(int ntaps, int dec) {
     FirGeom g;
     g.A = (ntaps + dec - 1) / dec;
     g.SH = (g.A + FIR_K - 1 + 3) / 4;            // groups of four steps s = 0 .. A+K-2
-    if (g.SH <= 16) g.SH = std::max(4, g.SH + (g.SH & 1));   // even counts 4..16 have unrolled kernels (the extra steps meet zero taps)
+    if (g.SH <= 16) g.SH = std::max(4, g.SH);                 // counts 4..16 have unrolled kernels
     g.QS = (FIR_NT + g.SH) | 1;                  // odd: staging writes of one phase spread over the banks
     g.PS = FIR_K * g.QS + 1;
     g.HROW = 4 * g.SH + 4;                       // taps per phase incl. padding (7 are read per group of steps)
@@ -350,8 +370,10 @@ int launch_fir(hipStream_t st, const short2* dx, int nch, long long nin, const f
     const FirGeom g = fir_geom(ntaps, dec);
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[] = {(const void*)&k_fir_poly<0>, (const void*)&k_fir_poly<4>, (const void*)&k_fir_poly<6>, (const void*)&k_fir_poly<8>,
-                             (const void*)&k_fir_poly<10>, (const void*)&k_fir_poly<12>, (const void*)&k_fir_poly<14>, (const void*)&k_fir_poly<16>};
+        const void* fns[] = {(const void*)&k_fir_poly<0>, (const void*)&k_fir_poly<4>, (const void*)&k_fir_poly<5>, (const void*)&k_fir_poly<6>,
+                             (const void*)&k_fir_poly<7>, (const void*)&k_fir_poly<8>, (const void*)&k_fir_poly<9>, (const void*)&k_fir_poly<10>,
+                             (const void*)&k_fir_poly<11>, (const void*)&k_fir_poly<12>, (const void*)&k_fir_poly<13>, (const void*)&k_fir_poly<14>,
+                             (const void*)&k_fir_poly<15>, (const void*)&k_fir_poly<16>};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return TWX_E_HIP;
         attr_set = true;
@@ -359,8 +381,10 @@ int launch_fir(hipStream_t st, const short2* dx, int nch, long long nin, const f
     const unsigned grid = (unsigned)((nout + FIR_OUT - 1) / FIR_OUT);
 #define FIR_GO(SHT_) hipLaunchKernelGGL((k_fir_poly<SHT_>), dim3(grid), dim3(FIR_NT), g.lds, st, dx, nch, nin, hp_dev, dec, g.SH, g.QS, g.PS, g.HROW, nout, dy16, dyf)
     switch (g.SH) {                                       // unrolled instantiations for the usual tap counts, generic loop otherwise
-        case 4: FIR_GO(4); break;   case 6: FIR_GO(6); break;   case 8: FIR_GO(8); break;   case 10: FIR_GO(10); break;
-        case 12: FIR_GO(12); break; case 14: FIR_GO(14); break; case 16: FIR_GO(16); break; default: FIR_GO(0); break;
+        case 4: FIR_GO(4); break;   case 5: FIR_GO(5); break;   case 6: FIR_GO(6); break;   case 7: FIR_GO(7); break;
+        case 8: FIR_GO(8); break;   case 9: FIR_GO(9); break;   case 10: FIR_GO(10); break; case 11: FIR_GO(11); break;
+        case 12: FIR_GO(12); break; case 13: FIR_GO(13); break; case 14: FIR_GO(14); break; case 15: FIR_GO(15); break;
+        case 16: FIR_GO(16); break; default: FIR_GO(0); break;
     }
 #undef FIR_GO
     return hipGetLastError() == hipSuccess ? TWX_OK : TWX_E_HIP;
@@ -456,6 +480,109 @@ static int twx_fir_decimate_impl(const int16_t* iq, int64_t n_in, int32_t n_chan
     return TWX_OK;
 }
 
+// ---- tracking epoch (rxcomplex.cpp:620-745): host arithmetic on the handful of correlation results ------------------
+namespace {
+// gsl_fit_wlinear: weighted least squares y = c0 + c1 x over the entries with w > 0; chisq = sum w (y - c0 - c1 x)^2
+void fit_wlinear(const std::vector<double>& x, const std::vector<double>& w, const std::vector<double>& y, double* c0, double* c1, double* chisq) {
+    double W = 0, wx = 0, wy = 0;
+    for (size_t i = 0; i < x.size(); ++i) if (w[i] > 0) { W += w[i]; wx += w[i] * x[i]; wy += w[i] * y[i]; }
+    const double xm = wx / W, ym = wy / W;
+    double sxx = 0, sxy = 0;
+    for (size_t i = 0; i < x.size(); ++i) if (w[i] > 0) { const double dx = x[i] - xm, dy = y[i] - ym; sxx += w[i] * dx * dx; sxy += w[i] * dx * dy; }
+    *c1 = sxy / sxx; *c0 = ym - *c1 * xm;
+    double chi = 0;
+    for (size_t i = 0; i < x.size(); ++i) if (w[i] > 0) { const double d = y[i] - (*c0 + *c1 * x[i]); chi += w[i] * d * d; }
+    *chisq = chi;
+}
+int track_update_impl(const double* cor, const double* phi, int bps, int nlag, twx_track_state* st, twx_track_result* out) {
+    if (!cor || !phi || !st || !out || bps < 2 || nlag < 2 || !(st->fs > 0) || !(st->duration > 0)) return TWX_E_ARG;
+    const int nl = 2 * nlag + 1;
+    const double psbb = st->psbb != 0.0 ? st->psbb : 1.0;
+    std::vector<double> res_gd((size_t)bps, 0.0), res_phi((size_t)bps, 0.0), ps((size_t)bps, 0.0), w((size_t)bps, 0.0), ttag_phi((size_t)bps, 0.0), ttag_gd((size_t)bps);
+    memset(out, 0, sizeof *out);
+    int cnt = 0;
+    for (int p = 0; p < bps - 1; ++p) {
+        const double* c = cor + (size_t)p * nl;
+        int k = 0;                                                         // cblas_idamax: first index of the largest |value| (:630)
+        for (int i = 1; i < nl; ++i) if (fabs(c[i]) > fabs(c[k])) k = i;
+        ttag_phi[(size_t)p] = (double)p * st->duration + (double)st->pt / st->fs;      // :632
+        ps[(size_t)p] = c[k] / psbb;                                                     // :633
+        if (k - 2 >= 0 && k + 2 < nl) {                                                  // :634
+            res_phi[(size_t)p] = phi[(size_t)p * nl + k];
+            res_gd[(size_t)p] = ((c[k - 1] - c[k + 1]) / (c[k - 1] - 2.0 * c[k] + c[k + 1])          // high-resolution correlator (:649-659)
+                                 - (c[k - 2] - c[k + 2]) / (c[k - 2] - 2.0 * c[k] + c[k + 2])
+                                 + (double)(st->pt + k - nlag)) * 1.0e+9 / st->fs;
+            w[(size_t)p] = 1.0;
+            ++cnt;
+        }
+    }
+    if (!(cnt * 2 > bps)) return TWX_OK;                                                 // :667: not enough usable periods
+    std::vector<double> sel;
+    for (int p = 0; p < bps; ++p) if (w[(size_t)p] > 0.0) sel.push_back(res_gd[(size_t)p]);          // :692-698
+    std::sort(sel.begin(), sel.end());                                                   // kth_smallest = order statistics (:840-865)
+    const int ii = (int)sel.size();
+    const double med = sel[(size_t)(ii / 2)];
+    const double stddev = (sel[(size_t)(ii * 3 / 4)] - sel[(size_t)(ii / 4)]) / 1.349;   // :699-700
+    double last_phi = st->last_phi;
+    cnt = 0;
+    for (int p = 0; p < bps - 1; ++p) {                                                  // :703-716
+        if (w[(size_t)p] == 0.0) continue;
+        if (fabs(res_gd[(size_t)p] - med) < 3.0 * stddev) {
+            ++cnt;
+            int guard = 0;
+            while (fabs(res_phi[(size_t)p] - last_phi) > 0.25 && guard++ < 1000000)
+                res_phi[(size_t)p] += res_phi[(size_t)p] > last_phi ? -0.5 : 0.5;
+            last_phi = res_phi[(size_t)p];
+        } else w[(size_t)p] = 0.0;
+    }
+    if (cnt == 0) return TWX_OK;                                           // every period filtered out (the program would divide by zero)
+    st->last_phi = last_phi;
+    double c0, c1, chi;
+    fit_wlinear(ttag_phi, w, res_phi, &c0, &c1, &chi);                                   // :728
+    st->fc_prev = st->fc;
+    st->fc += round(c1);                                                                 // :730-732
+    st->df = c1 - round(c1);
+    st->phi = fmod(c0 + 1000.0, 1.0);
+    for (int p = 0; p < bps; ++p) ttag_gd[(size_t)p] = (double)p * st->duration;         // :410
+    double g0, g1;
+    fit_wlinear(ttag_gd, w, res_gd, &g0, &g1, &chi);                                     // :739
+    out->freq = st->fc + st->df; out->phi = st->phi; out->cnt = cnt;
+    out->sdgd = sqrt(chi / (double)cnt);                                                 // :740
+    out->gd = g0 + 0.5 * g1; out->dg = g1;                                               // :741-742
+    st->pt_prev = st->pt;
+    st->pt = (int64_t)llround((g0 + g1) * st->fs / 1.0e+9);                              // :744
+    double acc = 0; int na = 0;
+    for (int p = 0; p < bps; ++p) if (w[(size_t)p] > 0.0) { acc += ps[(size_t)p]; ++na; }            // average() :887-901
+    out->pk = na ? acc / (double)na : 0.0;
+    out->updated = 1;
+    return TWX_OK;
+}
+}  // namespace
+
+static int twx_track_epoch_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t nobs,
+                                    int32_t bps, int32_t nlag, const float* replica_dev, double scale, twx_track_state* st, twx_track_result* out) {
+    if (!ctx) return TWX_E_ARG;
+    if (!st || !out || bps < 2 || nlag < 2 || nlag > 31 || !(st->fs > 0)) return twx::ctx_fail(ctx, TWX_E_ARG, "twx_track_epoch_dev: bad argument");
+    const int ncodes = bps - 1, nl = 2 * nlag + 1;
+    if (int rc = twx::ctx_set_device(ctx)) return rc;
+    double* res_dev = static_cast<double*>(twx::ctx_scratch(ctx, 6, (size_t)ncodes * nl * 16));
+    if (!res_dev) return TWX_E_NOMEM;
+    const double ph0 = fmod((double)st->pt * st->fc / st->fs, 1.0);                      // :594
+    if (int rc = twx_sliding_dot_dev_impl(ctx, iq_dev, n_samples, n_channels, channel, st->pt, nobs, ncodes, nlag, replica_dev, st->fc / st->fs, ph0, scale, res_dev)) return rc;
+    std::vector<double> res((size_t)ncodes * nl * 2), cor((size_t)ncodes * nl), ph((size_t)ncodes * nl);
+    hipStream_t s = twx::ctx_stream(ctx);
+    if (hipMemcpyAsync(res.data(), res_dev, res.size() * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return twx::ctx_fail(ctx, TWX_E_HIP, "twx_track_epoch_dev: D2H copy failed");
+    const double two_pi = 2.0 * 3.141592653589793;
+    for (size_t i = 0; i < cor.size(); ++i) {                                            // get_cor_and_phi :1063-1072
+        const double re = res[2 * i], im = res[2 * i + 1];
+        cor[i] = re * re + im * im;
+        ph[i] = atan2(im, re) / two_pi;
+    }
+    const int rc = track_update_impl(cor.data(), ph.data(), bps, nlag, st, out);
+    return rc ? twx::ctx_fail(ctx, rc, "twx_track_epoch_dev: bad state") : TWX_OK;
+}
+
 // No exception may cross the C boundary.
 template <class F> static int aux_guard(F f) noexcept {
     try { return f(); }
@@ -471,6 +598,13 @@ int twx_sliding_dot_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int
 int twx_fir_decimate_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps, int32_t ntaps,
                          int32_t dec, void* out_i16_dev, void* out_f32_dev, int64_t* n_out) {
     return aux_guard([&]() { return twx_fir_decimate_dev_impl(ctx, iq_dev, n_in, n_channels, channel, taps, ntaps, dec, out_i16_dev, out_f32_dev, n_out); });
+}
+int twx_track_update(const double* cor, const double* phi, int32_t bps, int32_t nlag, twx_track_state* state, twx_track_result* out) {
+    return aux_guard([&]() { return track_update_impl(cor, phi, bps, nlag, state, out); });
+}
+int twx_track_epoch_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t nobs,
+                        int32_t bps, int32_t nlag, const float* replica_dev, double scale, twx_track_state* state, twx_track_result* out) {
+    return aux_guard([&]() { return twx_track_epoch_dev_impl(ctx, iq_dev, n_samples, n_channels, channel, nobs, bps, nlag, replica_dev, scale, state, out); });
 }
 int twx_sliding_dot(const int16_t* iq, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t pt, int64_t nobs,
                     int32_t ncodes, int32_t nlag, const float* replica, double ff, double phi, double scale, double* out) {

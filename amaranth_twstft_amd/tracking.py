@@ -59,66 +59,55 @@ def _wlinear(x, w, y):
     return c0, c1, float((w * (y - c0 - c1 * x) ** 2).sum())
 
 
-def tracking_update(cor: np.ndarray, phi: np.ndarray, nlag: int, state: dict) -> dict | None:
-    """One tracking epoch of experiments/231001_DLL_PLL/rxcomplex.cpp:620-745 on the ``bps-1`` code periods
-    whose power/phase matrices ``cor``/``phi`` ([bps-1, 2·nlag+1]) came from :func:`sliding_dot` +
-    :func:`get_cor_and_phi`: per-code peak and high-resolution-correlator delay (:630-661), 3-sigma filter on
-    median/IQR (:689-716), BPSK half-cycle phase unwrap against ``last_phi`` (:710-715), weighted linear fits of
-    phase → carrier update and of delay → code-phase update (:728-745).
+_STATE_KEYS = ("fs", "duration", "psbb", "fc", "df", "phi", "last_phi", "pt", "fc_prev", "pt_prev")
 
-    ``state`` holds ``fc pt last_phi fs duration psbb`` (the ``ci[i]`` fields) and is updated in place; the
-    returned dict has the printed quantities (``freq phi cnt gd dg sdgd pk``).  ``None`` when fewer than half of
-    the periods produced a usable peak (:667), in which case ``state`` is left alone.  UNPINNED (GSL/CBLAS
-    program, cannot be built here).
-    """
-    bps = cor.shape[0] + 1
-    fs, duration, pt = state["fs"], state["duration"], state["pt"]
-    psbb = state.get("psbb", 1.0)
-    res_gd, res_phi, ps, w = (np.zeros(bps) for _ in range(4))
-    ttag_phi = np.zeros(bps)
-    nl = 2 * nlag + 1
-    for p in range(bps - 1):
-        k = int(np.argmax(cor[p]))                                    # cblas_idamax on non-negative powers (:630)
-        ttag_phi[p] = p * duration + pt / fs
-        ps[p] = cor[p, k] / psbb
-        if k - 2 >= 0 and k + 2 < nl:
-            c = cor[p]
-            res_phi[p] = phi[p, k]
-            res_gd[p] = ((c[k - 1] - c[k + 1]) / (c[k - 1] - 2.0 * c[k] + c[k + 1])
-                         - (c[k - 2] - c[k + 2]) / (c[k - 2] - 2.0 * c[k] + c[k + 2])
-                         + float(pt + k - nlag)) * 1.0e9 / fs
-            w[p] = 1.0
-    cnt = int(w.sum())
-    if cnt * 2 <= bps:
+
+def _state_in(state: dict) -> L.twx_track_state:
+    st = L.twx_track_state()
+    st.fs, st.duration, st.psbb = float(state["fs"]), float(state["duration"]), float(state.get("psbb", 1.0))
+    st.fc, st.df, st.phi = float(state["fc"]), float(state.get("df", 0.0)), float(state.get("phi", 0.0))
+    st.last_phi, st.pt = float(state["last_phi"]), int(state["pt"])
+    st.fc_prev, st.pt_prev = float(state.get("fc_prev", 0.0)), int(state.get("pt_prev", 0))
+    return st
+
+
+def _state_out(st: L.twx_track_state, state: dict, r: L.twx_track_result):
+    if not r.updated:
         return None
-    sel = np.sort(res_gd[w > 0])                                      # kth_smallest ≡ order statistics
-    ii = sel.size
-    c0 = sel[ii // 2]
-    stddev = (sel[ii * 3 // 4] - sel[ii // 4]) / 1.349
-    last_phi = state["last_phi"]
-    cnt = 0
-    for p in range(bps - 1):
-        if w[p] != 0.0:
-            if abs(res_gd[p] - c0) < 3.0 * stddev:
-                cnt += 1
-                while abs(res_phi[p] - last_phi) > 0.25:
-                    res_phi[p] += -0.5 if res_phi[p] > last_phi else 0.5
-                last_phi = res_phi[p]
-            else:
-                w[p] = 0.0
-    state["last_phi"] = last_phi
-    c0, c1, _ = _wlinear(ttag_phi, w, res_phi)
-    state["fc_prev"] = state["fc"]
-    state["fc"] += round(c1)
-    state["df"] = c1 - round(c1)
-    state["phi"] = float(np.fmod(c0 + 1000.0, 1.0))
-    ttag_gd = np.arange(bps) * duration
-    g0, g1, chi = _wlinear(ttag_gd, w, res_gd)
-    out = dict(freq=state["fc"] + state["df"], phi=state["phi"], cnt=cnt, gd=g0 + 0.5 * g1, dg=g1,
-               sdgd=float(np.sqrt(chi / cnt)), pk=float(ps[w > 0].mean()) if cnt else 0.0)
-    state["pt_prev"] = pt
-    state["pt"] = int(round((g0 + g1) * fs / 1.0e9))
-    return out
+    for k in ("fc", "df", "phi", "last_phi", "fc_prev"):
+        state[k] = float(getattr(st, k))
+    state["pt"], state["pt_prev"] = int(st.pt), int(st.pt_prev)
+    return dict(freq=r.freq, phi=r.phi, cnt=int(r.cnt), gd=r.gd, dg=r.dg, sdgd=r.sdgd, pk=r.pk)
+
+
+def tracking_update(cor: np.ndarray, phi: np.ndarray, nlag: int, state: dict) -> dict | None:
+    """One tracking epoch of experiments/231001_DLL_PLL/rxcomplex.cpp:620-745 on the ``bps-1`` code periods whose power/phase
+    matrices ``cor``/``phi`` ([bps-1, 2·nlag+1]) came from :func:`sliding_dot` + :func:`get_cor_and_phi` — binding of the
+    library's ``twx_track_update`` (host arithmetic in C++, no GPU needed): per-code peak and high-resolution-correlator delay
+    (:630-661), 3-sigma filter on median/IQR (:689-700), BPSK half-cycle phase unwrap against ``last_phi`` (:703-716), weighted
+    linear fits of phase → carrier update and of delay → code-phase update (:728-745).
+
+    ``state`` holds ``fc pt last_phi fs duration psbb`` (the ``ci[i]`` fields) and is updated in place; the returned dict has
+    the printed quantities (``freq phi cnt gd dg sdgd pk``).  ``None`` when no more than half of the periods produced a usable
+    peak (:667), in which case ``state`` is left alone.  UNPINNED (GSL/CBLAS program, cannot be built here)."""
+    cor = np.ascontiguousarray(cor, dtype=np.float64)
+    phi = np.ascontiguousarray(phi, dtype=np.float64)
+    st, r = _state_in(state), L.twx_track_result()
+    L.check(L.load().twx_track_update(cor.ctypes.data_as(C.c_void_p), phi.ctypes.data_as(C.c_void_p), cor.shape[0] + 1, int(nlag),
+                                      C.byref(st), C.byref(r)))
+    return _state_out(st, state, r)
+
+
+def track_epoch_dev(cor_ctx, iq_dev: int, n_samples: int, replica_dev: int, nobs: int, bps: int, nlag: int, state: dict,
+                    scale: float = 1.0, n_channels: int = 1, channel: int = 0) -> dict | None:
+    """The whole epoch (rxcomplex.cpp:593-745) on a device-resident capture in one library call (``twx_track_epoch_dev``):
+    down-conversion at ``state['fc']`` from ``state['pt']`` with phase ``fmod(pt*fc/fs, 1)`` (:594), ±nlag sliding dot products
+    of ``bps-1`` code periods, power/phase, then :func:`tracking_update`'s arithmetic.  ``cor_ctx``: any ``Correlator`` (its
+    stream and scratch buffers are used)."""
+    st, r = _state_in(state), L.twx_track_result()
+    L.check(cor_ctx._lib.twx_track_epoch_dev(cor_ctx._h, iq_dev, int(n_samples), n_channels, channel, int(nobs), int(bps), int(nlag),
+                                             replica_dev, float(scale), C.byref(st), C.byref(r)), cor_ctx._h)
+    return _state_out(st, state, r)
 
 
 def prn_sampling(nobs: int, code, rc: float, fs: float, delay_ns: float = 0.0) -> np.ndarray:

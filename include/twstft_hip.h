@@ -259,6 +259,31 @@ int twx_sqspec_band_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int
 int twx_sliding_dot(const int16_t* iq, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t pt, int64_t nobs,
                     int32_t ncodes, int32_t nlag, const float* replica, double ff, double phi, double scale, double* out);
 
+/* One tracking epoch of experiments/231001_DLL_PLL/rxcomplex.cpp:593-745 ------------------------------------------
+ * twx_track_update: the arithmetic on the (bps-1) x (2*nlag+1) power / phase matrices of get_cor_and_phi (:1063-1072,
+ *   row-major, HOST arrays): per code period cblas_idamax and the high-resolution-correlator delay (:630-661), the
+ *   3-sigma filter on median / inter-quartile range (:689-700), the BPSK half-cycle phase unwrap against last_phi
+ *   (:703-716), gsl_fit_wlinear of phase -> carrier update and of delay -> code-phase update (:728-745).  `state` holds
+ *   the channel_info fields the epoch reads and writes; out->updated = 0 when no more than half of the periods had a
+ *   usable peak (:667; state untouched).  No GPU needed.
+ * twx_track_epoch_dev: the whole epoch on a DEVICE-resident int16 capture: phi = fmod(pt*fc/fs, 1) (:594), downconv_trk +
+ *   cblas_dgemm against the lagged replicas (:599-605) as twx_sliding_dot_dev with pt = state->pt, ff = fc/fs, then
+ *   get_cor_and_phi and twx_track_update.  One host synchronisation per epoch. */
+typedef struct twx_track_state {
+    double fs, duration, psbb;      /* sample rate, code period in s (ci.duration), reference power (ci.psbb) */
+    double fc, df, phi, last_phi;   /* carrier (Hz, integer part), its fractional part, phase (cycles), unwrap reference */
+    int64_t pt;                     /* code phase in samples */
+    double fc_prev; int64_t pt_prev;
+} twx_track_state;
+typedef struct twx_track_result {
+    double freq, phi, gd, dg, sdgd, pk;   /* fc+df (Hz), phase (cycles), delay (ns), its slope (ns/epoch), sqrt(chisq/cnt), mean signal power */
+    int32_t cnt, updated;
+} twx_track_result;
+int twx_track_update(const double* cor, const double* phi, int32_t bps, int32_t nlag, twx_track_state* state, twx_track_result* out);
+int twx_track_epoch_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t nobs,
+                        int32_t bps, int32_t nlag, const float* replica_dev, double scale, twx_track_state* state,
+                        twx_track_result* out);
+
 /* FIR low-pass + decimation front end (BASELINE.json configs[4], 70 Msps → 5 Msps): y[m] = sum_j taps[j]*x[m*dec+j],
  * "valid" part only: *n_out = (n_in-ntaps)/dec+1.  ntaps <= 1024, dec <= 16.  out_i16 (interleaved IQ, rounded
  * half-to-even, saturated) and/or out_f32 (interleaved re,im) may be NULL.  No twin in the reference. */

@@ -801,6 +801,113 @@ def rx_power(smp, fs: float, dec_a: int = 1):
 
 
 # --------------------------------------------------------------------------------------------
+# Tracking epoch of experiments/231001_DLL_PLL/rxcomplex.cpp:593-745, restated function by function — UNPINNED
+# --------------------------------------------------------------------------------------------
+
+def rx_prn_mapping(snobs: int, knobs: int, prn):
+    """``PRN_mapping`` :989-999 for ``nobs = snobs*(2*knobs+1)``: row ``l`` of the (2*knobs+1) x snobs replica matrix is the
+    waveform delayed by ``l-knobs`` samples (circular): ``pn[l*snobs+i] = real(prn[(i - (l-knobs)) mod snobs])``."""
+    prn = np.asarray(prn)
+    out = np.empty((2 * knobs + 1, snobs))
+    i = np.arange(snobs)
+    for l in range(2 * knobs + 1):
+        idx = i - (l - knobs)
+        idx = np.where(idx >= snobs, idx - snobs, idx)
+        idx = np.where(idx < 0, idx + snobs, idx)
+        out[l] = prn[idx].real
+    return out
+
+
+def rx_downconv_trk(nobs: int, ld: int, ff: float, phi: float, smp):
+    """``downconv_trk`` :1051-1061: ``sqrt(2)*smp[i]*exp(-2 pi j (ff*i+phi))`` for ``nobs`` samples, returned as the complex
+    matrix [nobs/ld, ld] (the program stores real and imaginary rows interleaved for the dgemm)."""
+    i = np.arange(nobs, dtype=np.float64)
+    ang = -1.0 * 2.0 * 3.141592653589793 * (ff * i + phi)
+    x = np.asarray(smp)[:nobs]
+    re = 1.4142135624 * (x.real * np.cos(ang) - x.imag * np.sin(ang))
+    im = 1.4142135624 * (x.real * np.sin(ang) + x.imag * np.cos(ang))
+    return (re + 1j * im).reshape(nobs // ld, ld)
+
+
+def rx_kth_smallest(a, k: int) -> float:
+    """``kth_smallest`` :840-865 (Wirth's selection) returns the element of rank ``k`` of the array = ``sorted(a)[k]``."""
+    return float(np.sort(np.asarray(a, dtype=np.float64))[k])
+
+
+def rx_fit_wlinear(x, w, y):
+    """``gsl_fit_wlinear(x,1,w,1,y,1,n,&c0,&c1,...,&chisq)``: weighted least squares over the entries with ``w > 0``."""
+    x, w, y = (np.asarray(v, dtype=np.float64) for v in (x, w, y))
+    m = w > 0
+    W = w[m].sum()
+    xm, ym = (w[m] * x[m]).sum() / W, (w[m] * y[m]).sum() / W
+    dx, dy = x[m] - xm, y[m] - ym
+    c1 = (w[m] * dx * dy).sum() / (w[m] * dx * dx).sum()
+    c0 = ym - xm * c1
+    return float(c0), float(c1), float((w[m] * (y[m] - (c0 + c1 * x[m])) ** 2).sum())
+
+
+def rx_track_epoch(smp, wav_t, st: dict, nobs: int, bps: int, nlag: int, fs: float):
+    """One pass of the tracking branch :589-745 for a locked channel.  ``smp`` = the complex sample stream (``ci.dev_smp``),
+    ``wav_t`` = the sampled (and filtered) code waveform of ``nobs`` samples (``ci.dev_wav_t``), ``st`` = dict with the
+    ``channel_info`` fields ``fc pt last_phi psbb duration`` (updated in place as the program does).  Returns the printed
+    quantities (``freq phi cnt gd dg sdgd pk``) or None where ``cnt*2 <= bps`` (:667)."""
+    pt, fc = int(st["pt"]), float(st["fc"])
+    nl = 2 * nlag + 1
+    alpha = 1.0 / float(nobs)                                                         # :593
+    phi = float(np.fmod(float(pt) * fc / fs, 1.0))                                    # :594
+    obs = rx_downconv_trk(nobs * (bps - 1), nobs, fc / fs, phi, np.asarray(smp)[pt:])   # :602
+    wav = rx_prn_mapping(nobs, nlag, wav_t)                                           # :430
+    res = alpha * (obs @ wav.T)                                                       # cblas_dgemm :605: [bps-1, nl], re and im columns
+    cor = res.real ** 2 + res.imag ** 2                                               # get_cor_and_phi :1063-1072
+    ph = np.arctan2(res.imag, res.real) / 2.0 / 3.141592653589793
+    res_gd, res_phi, ps, w, ttag_phi = (np.zeros(bps) for _ in range(5))
+    cnt = 0
+    for p in range(bps - 1):
+        k = int(np.argmax(np.abs(cor[p])))                                            # cblas_idamax :630
+        ttag_phi[p] = float(p) * st["duration"] + float(pt) / fs                      # :632
+        ps[p] = cor[p, k] / st["psbb"]                                                # :633
+        if k - 2 >= 0 and k + 2 < nl:                                                 # :634
+            res_phi[p] = ph[p, k]
+            c = cor[p]
+            res_gd[p] = ((c[k - 1] - c[k + 1]) / (c[k - 1] - 2.0 * c[k] + c[k + 1])
+                         - (c[k - 2] - c[k + 2]) / (c[k - 2] - 2.0 * c[k] + c[k + 2])
+                         + float(pt + k - nlag)) * 1.0e+9 / fs                        # :649-659
+            w[p] = 1.0
+            cnt += 1
+    if not cnt * 2 > bps:                                                             # :667
+        return None
+    sel = [res_gd[p] for p in range(bps) if w[p] > 0.0]                               # :692-698
+    ii = len(sel)
+    c0 = rx_kth_smallest(sel, ii // 2)                                                # :699
+    stddev = (rx_kth_smallest(sel, ii * 3 // 4) - rx_kth_smallest(sel, ii // 4)) / 1.349
+    cnt = 0
+    for p in range(bps - 1):                                                          # :703-716
+        if w[p] != 0.0:
+            if abs(res_gd[p] - c0) < 3.0 * stddev:
+                cnt += 1
+                while abs(res_phi[p] - st["last_phi"]) > 0.25:
+                    if res_phi[p] > st["last_phi"]:
+                        res_phi[p] -= 0.5
+                    else:
+                        res_phi[p] += 0.5
+                st["last_phi"] = res_phi[p]
+            else:
+                w[p] = 0.0
+    c0, c1, _ = rx_fit_wlinear(ttag_phi, w, res_phi)                                  # :728
+    st["fc_prev"] = st["fc"]
+    st["fc"] = st["fc"] + round(c1)                                                   # :730 (C round: half away from zero; c1 is never a tie here)
+    st["df"] = c1 - round(c1)
+    st["phi"] = float(np.fmod(c0 + 1000.0, 1.0))
+    ttag_gd = np.arange(bps, dtype=np.float64) * st["duration"]                       # :410
+    g0, g1, chisq = rx_fit_wlinear(ttag_gd, w, res_gd)                                # :739
+    out = dict(freq=st["fc"] + st["df"], phi=st["phi"], cnt=cnt, sdgd=float(np.sqrt(chisq / float(cnt))),
+               gd=g0 + 0.5 * g1, dg=g1, pk=float(np.mean(ps[w > 0.0])))              # :740-742, average() :887-901
+    st["pt_prev"] = pt
+    st["pt"] = int(np.floor((g0 + g1) * fs / 1.0e+9 + 0.5)) if (g0 + g1) >= 0 else -int(np.floor(-(g0 + g1) * fs / 1.0e+9 + 0.5))   # round() :744
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # C++ twin: file-level carrier estimate, processing/CPP/main.cpp:363-450 — UNPINNED (fftw3/matio/sigpack absent)
 # --------------------------------------------------------------------------------------------
 

@@ -657,6 +657,41 @@ def test_rxcomplex_acquisition_pipeline_at_sdr_param_sizes():
     a2.close(); interp.close()
 
 
+def test_track_epoch_on_the_device_vs_oracle_epoch():
+    """twx_track_epoch_dev: ONE call from a device-resident capture to the epoch's (fc, gd, pt) update — down-conversion at the
+    channel's carrier and code phase, +-28 lags x 24 code periods of 400 000 samples (sdr.param sizes), power / phase,
+    high-resolution correlator, 3-sigma filter, phase unwrap, the two weighted fits (rxcomplex.cpp:593-745) — against
+    oracle.rx_track_epoch on the same samples.  Three epochs in a row: the state of one feeds the next."""
+    import torch
+    from amaranth_twstft_amd import tracking
+    dev = torch.device("cuda", 0)
+    fs, rc, clen, nobs, bps, nlag = 10e6, 2.5e6, 100_000, 400_000, 25, 28
+    code = 1 - 2 * chips_for(17, 9, clen).astype(np.int64)
+    wav = tracking.prn_sampling(nobs, code, rc, fs)
+    n = nobs * (bps + 1) + 4096
+    rng = np.random.default_rng(5)
+    delay, f_true = 1237, 1000.0 + 3.3
+    x = np.roll(np.tile(wav.astype(np.float64), bps + 2)[:n], delay) * np.exp(2j * np.pi * (f_true / fs * np.arange(n) + 0.05))
+    x = x * np.repeat(rng.integers(0, 2, bps + 2) * 2 - 1, nobs)[:n]                    # data bits: BPSK flips per code period
+    raw = np.empty((n, 2), dtype=np.int16)
+    raw[:, 0] = np.round(900 * x.real + rng.normal(0, 1500, n)); raw[:, 1] = np.round(900 * x.imag + rng.normal(0, 1500, n))
+    xq = raw[:, 0].astype(np.float64) + 1j * raw[:, 1].astype(np.float64)
+    iq = torch.from_numpy(raw).to(dev)
+    rep = torch.from_numpy(wav).to(dev)
+    st = dict(fc=1000.0, pt=delay - 3, last_phi=0.0, psbb=1.0, duration=nobs / fs, fs=fs)
+    so = dict(st)
+    with Correlator(lfsr=(14, 43, 10000), fs=5e6) as cor:
+        for epoch in range(3):
+            got = tracking.track_epoch_dev(cor, iq.data_ptr(), n, rep.data_ptr(), nobs, bps, nlag, st, scale=1.4142135624)
+            want = orc.rx_track_epoch(xq, wav.astype(np.complex128), so, nobs, bps, nlag, fs)
+            assert got is not None and want is not None and got["cnt"] == want["cnt"] >= bps - 3
+            assert (st["pt"], st["fc"]) == (so["pt"], so["fc"]) and st["pt"] == delay
+            assert abs(got["freq"] - want["freq"]) <= 2e-4 and abs(got["phi"] - want["phi"]) <= 1e-4
+            assert abs(got["gd"] - want["gd"]) <= 0.02 and abs(got["dg"] - want["dg"]) <= 0.05 and abs(got["sdgd"] - want["sdgd"]) <= 0.05
+            assert abs(got["pk"] - want["pk"]) <= 3e-6 * want["pk"]
+            assert abs(got["freq"] - f_true) < 0.3
+
+
 def test_aux_kernels_device_resident_forms_match_host_forms():
     """twx_sliding_dot_dev / twx_fir_decimate_dev (context stream, context-owned work buffers) against the host-pointer
     entry points on the same data, bit for bit; odd sizes exercise the ragged last workgroup of both kernels."""

@@ -74,3 +74,32 @@ def test_prn_sampling_follows_the_reference_formula():
     assert np.mean(r0 == np.repeat(code, 2)) > 0.97
     r2 = tracking.prn_sampling(3000, code, rc, 7.5e6, 0.0)                  # 3 samples per chip
     assert np.mean(r2 == np.repeat(code, 3)) > 0.97
+
+
+def test_track_update_equals_the_oracle_restatement_of_the_epoch():
+    """twx_track_update (C++, behind the C ABI; tracking.tracking_update is its binding) against oracle.rx_track_epoch, the
+    function-by-function restatement of rxcomplex.cpp:593-745, fed with the SAME correlation matrices (computed by the oracle's
+    downconv_trk / PRN_mapping / dgemm restatement): every printed quantity and the updated channel state."""
+    from oracle import twstft_oracle as orc
+    rng = np.random.default_rng(1)
+    fs, nobs, bps, nlag = 10e6, 4000, 25, 28
+    code = rng.integers(0, 2, 1000) * 2 - 1
+    wav = orc.rx_prn_sampling(nobs, code, 2.5e6, fs, 1000).real
+    n = nobs * (bps + 2)
+    for delay, fres, flips in ((17, 3.4, False), (40, -7.8, True)):
+        x = np.roll(np.tile(wav, bps + 2), delay) * np.exp(2j * np.pi * ((1000.0 + fres) / fs * np.arange(n) + 0.1)) * 0.2
+        if flips:                                                          # BPSK data: half-cycle phase jumps between code periods
+            x = x * np.repeat(rng.integers(0, 2, bps + 2) * 2 - 1, nobs)
+        x = x + rng.normal(0, 0.3, n) + 1j * rng.normal(0, 0.3, n)
+        st = dict(fc=1000.0, pt=delay - 2, last_phi=0.0, psbb=0.7, duration=nobs / fs, fs=fs)
+        st2 = dict(st)
+        want = orc.rx_track_epoch(x, wav.astype(complex), st, nobs, bps, nlag, fs)
+        pt = st2["pt"]
+        obs = orc.rx_downconv_trk(nobs * (bps - 1), nobs, st2["fc"] / fs, float(np.fmod(pt * st2["fc"] / fs, 1.0)), x[pt:])
+        res = (obs @ orc.rx_prn_mapping(nobs, nlag, wav.astype(complex)).T) / nobs
+        got = tracking.tracking_update(res.real ** 2 + res.imag ** 2, np.arctan2(res.imag, res.real) / 2 / np.pi, nlag, st2)
+        assert want is not None and got is not None and got["cnt"] == want["cnt"] >= bps - 3
+        for k in ("freq", "phi", "gd", "dg", "sdgd", "pk"):
+            assert abs(got[k] - want[k]) <= 1e-9 * max(1.0, abs(want[k])), k
+        assert (st2["pt"], st2["fc"], st2["pt_prev"]) == (st["pt"], st["fc"], st["pt_prev"]) and abs(st2["last_phi"] - st["last_phi"]) < 1e-12
+        assert abs(want["freq"] - (1000.0 + fres)) < 0.5 and st["pt"] == delay
