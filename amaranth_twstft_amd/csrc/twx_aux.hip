@@ -28,21 +28,22 @@ namespace {
 constexpr int SD_NT = 256, SD_S = 64, SD_CH = SD_NT * SD_S;      // 16384 samples per workgroup
 constexpr int SD_T = 4;                                          // consecutive samples per lane and pass
 
-// Register tile: a lane owns SD_T = 4 CONSECUTIVE samples per pass, so the replica values it needs for all NL lags are
-// the NL+3 consecutive entries c[4g-l+j] — every value read from LDS feeds four packed FMAs (was: one read per FMA, which
-// left the VALU waiting for the LDS pipe).  The replica segment is stored transposed, entry u = 4q+r at r*QS+q, so that
+// Register tile: a lane owns SD_T = 8 CONSECUTIVE samples per pass, so the replica values it needs for all NL lags are
+// the NL+7 consecutive entries c[8g-l+j] — every value read from LDS feeds eight packed FMAs (was: one read per FMA, which
+// left the VALU waiting for the LDS pipe).  The replica segment is stored transposed, entry u = SD_T*q+r at r*QS+q, so that
 // what the 64 lanes read together (same r, consecutive q) is contiguous: conflict-free ds_read_b32.  The NCO is evaluated
-// once per lane and pass (fp64 phase reduction + sincospi) and stepped over the other three samples by the fp32 rotation
-// exp(-2 pi j ff) (three steps: 2e-7 relative at most).
+// once per lane and pass (fp64 phase reduction + sincospi) and stepped over the other seven samples by the fp32 rotation
+// exp(-2 pi j ff) (seven steps: 5e-7 relative at most).
 template <int NLAG>
 __global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict__ x, int nch, long long pt, long long nobs, int nlag, int chunk_len,
                                                        const float* __restrict__ w, double ff, double phi, float scale, float rot_c, float rot_s,
                                                        double* __restrict__ partial /*[ncodes][chunks][2*nlag+1][2]*/) {
     constexpr int NL = 2 * NLAG + 1;
-    constexpr int NE = SD_CH + 2 * NLAG + 4;                       // replica entries of a full chunk (+ the tile's overhang)
-    constexpr int QS = ((NE + 3) / 4) | 1;                         // odd quarter stride: the four r of one q land in four banks
-    __shared__ float sw[4 * QS];                                   // replica segment; reused by the final reduction
-    static_assert(NL * SD_NT <= 4 * QS, "reduction buffer must fit the replica segment");
+    constexpr int NE = SD_CH + 2 * NLAG + SD_T;                    // replica entries of a full chunk (+ the tile's overhang)
+    constexpr int QS = ((NE + SD_T - 1) / SD_T) | 1;               // odd stride between the SD_T residue classes: they land in different banks
+    __shared__ float sw[SD_T * QS];                                // replica segment; reused by the final reduction
+    static_assert(NL * SD_NT <= SD_T * QS, "reduction buffer must fit the replica segment");
+    static_assert((SD_T & (SD_T - 1)) == 0, "SD_T must be a power of two");
     const int p = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const int tid = threadIdx.x;
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -60,8 +61,8 @@ __global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict_
     {
         long long k = (s0 - NLAG + tid) % nobs; if (k < 0) k += nobs;          // one 64-bit division per thread, then steps
         const long long step = SD_NT % nobs;
-        for (int u = tid; u < cnt + 2 * NLAG + 3; u += SD_NT) {
-            sw[(u & 3) * QS + (u >> 2)] = w[k];
+        for (int u = tid; u < cnt + 2 * NLAG + SD_T - 1; u += SD_NT) {
+            sw[(u % SD_T) * QS + u / SD_T] = w[k];
             k += step; if (k >= nobs) k -= nobs;
         }
     }
@@ -100,10 +101,10 @@ __global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict_
             const float c2 = cs * rot_c - sn * rot_s, s2 = cs * rot_s + sn * rot_c;
             cs = c2; sn = s2;
         }
-        // sample t0+j, lag index l  <->  replica entry 4g + (j + 2*NLAG - l)
+        // sample t0+j, lag index l  <->  replica entry SD_T*g + (j + 2*NLAG - l)
         float cw[NL + SD_T - 1];
 #pragma unroll
-        for (int m = 0; m < NL + SD_T - 1; ++m) cw[m] = sw[(m & 3) * QS + g + (m >> 2)];
+        for (int m = 0; m < NL + SD_T - 1; ++m) cw[m] = sw[(m % SD_T) * QS + g + m / SD_T];
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
 #pragma unroll

@@ -289,3 +289,14 @@ def test_plan_file_names_carry_radices_and_precision(tmp_path, monkeypatch):
     lib = L.load()
     assert lib.twx_load_plan(os.fsencode(str(tmp_path / "col_25_5x5_w16_f64_0000000000.so"))) != 0      # another source hash: refused
     assert b"kernel sources" in lib.twx_last_error(None)
+
+
+def test_design_quotes_the_committed_profiles():
+    """DESIGN.md's key-number table (chain rate, roofline fraction, per-kernel averages, CAF, acquisition, aux kernels) against
+    the files under profiles/ it names: more than 5 % apart fails (tools/check_design.py, also the last step of
+    tools/update_profiles.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_design", os.path.join(ROOT, "tools", "check_design.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.check(verbose=False) == 0

@@ -684,7 +684,7 @@ def test_track_epoch_on_the_device_vs_oracle_epoch():
         for epoch in range(3):
             got = tracking.track_epoch_dev(cor, iq.data_ptr(), n, rep.data_ptr(), nobs, bps, nlag, st, scale=1.4142135624)
             want = orc.rx_track_epoch(xq, wav.astype(np.complex128), so, nobs, bps, nlag, fs)
-            assert got is not None and want is not None and got["cnt"] == want["cnt"] >= bps - 3
+            assert got is not None and want is not None and got["cnt"] == want["cnt"] >= bps - 6      # the 3-sigma filter on the IQR drops a few
             assert (st["pt"], st["fc"]) == (so["pt"], so["fc"]) and st["pt"] == delay
             assert abs(got["freq"] - want["freq"]) <= 2e-4 and abs(got["phi"] - want["phi"]) <= 1e-4
             assert abs(got["gd"] - want["gd"]) <= 0.02 and abs(got["dg"] - want["dg"]) <= 0.05 and abs(got["sdgd"] - want["sdgd"]) <= 0.05

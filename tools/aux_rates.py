@@ -77,6 +77,22 @@ def sliding():
                       "frac_fp32_vector": round(flops / dt / 1e12 / VEC, 4)}))
 
 
+def sliding_scan():
+    """time against the lag count and the code count: which part of k_sliding_dot's time is the FMA stream?"""
+    nobs = 400_000
+    for ncodes, nlag in ((24, 4), (24, 8), (24, 16), (24, 28), (6, 28), (96, 28)):
+        n = nobs * ncodes + 64
+        x = torch.randint(-3000, 3000, (n, 2), dtype=torch.int16, device=dev)
+        rep = (torch.randint(0, 2, (nobs,), device=dev).float() * 2 - 1).contiguous()
+        out = torch.empty((ncodes, 2 * nlag + 1, 2), dtype=torch.float64, device=dev)
+        with Correlator(lfsr=(14, 43, 10000), fs=5e6) as cor:
+            dt = timed(lambda: cor.sliding_dot_dev(x.data_ptr(), n, rep.data_ptr(), nobs, ncodes, nlag, out.data_ptr(), ff=1.234e-5, scale=1.0 / 32768),
+                       cor.synchronize, 50)
+        flops = nobs * ncodes * (2 * nlag + 1) * 4
+        print(json.dumps({"kernel": "k_sliding_dot scan", "ncodes": ncodes, "nlag": nlag, "ms": round(dt * 1e3, 4), "Gsample_s": round(nobs * ncodes / dt / 1e9, 1),
+                          "TFLOP_s": round(flops / dt / 1e12, 2), "frac_fp32_vector": round(flops / dt / 1e12 / VEC, 4)}))
+
+
 def acq():
     from amaranth_twstft_amd import acquisition as A
     n_in, fs, rc, clen = 5_000_000, 10e6, 2.5e6, 100_000

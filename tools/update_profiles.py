@@ -64,3 +64,6 @@ json.dump({"note": "rocprofv3 --pmc SQ_* (two passes, tools/prof_round2.sh), sum
 d = json.loads(open(f"profiles/{tag}_bench_line.json").read().strip().splitlines()[-1])
 print(d["value"], d["roofline"], d.get("other_workload"))
 print(open(f"profiles/{tag}_kernel_stats.md").read()[:900])
+# the text must follow the numbers: DESIGN.md's key-number table is compared with the files just written (5 % tolerance)
+import check_design  # noqa: E402
+sys.exit(check_design.check())
