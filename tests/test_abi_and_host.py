@@ -80,6 +80,27 @@ def test_bad_arguments_are_errors_not_crashes():
     assert lib.twx_get_info(None, None) == -1
 
 
+def test_round3_entry_points_reject_bad_arguments():
+    """The tracked / acquisition / tracking entry points answer misuse with a status, never with a crash (no GPU involved)."""
+    lib = L.load()
+    h = C.c_void_p()
+    cfg = L.twx_tracked_config()
+    assert lib.twx_tracked_defaults(L.TWX_TRK_RE, 1, 5e6, C.byref(cfg)) == 0 and (cfg.band_lo_hz, cfg.band_hi_hz) == (-108000.0, -92000.0)
+    cfg.chunk_samples = 0
+    assert lib.twx_tracked_create(C.byref(cfg), C.byref(h)) == -1 and b"chunk_samples" in lib.twx_tracked_last_error(None)
+    assert lib.twx_tracked_file(None, b"x", 0, -1, None) == -1 and lib.twx_tracked_fetch(None, None, None, None, None) == -1
+    assert lib.twx_tracked_search_df(None, None, 0, None) == -1 and lib.twx_tracked_context(None) is None
+    lib.twx_tracked_destroy(None)
+    assert lib.twx_acquire_cdev(None, None, 0.0, 1.0, 1.0, 0, 0, None) == -1
+    st, r = L.twx_track_state(), L.twx_track_result()
+    z = np.zeros(24 * 57)
+    assert lib.twx_track_update(z.ctypes.data, z.ctypes.data, 25, 28, C.byref(st), C.byref(r)) == -1      # fs = 0
+    st.fs, st.duration = 5e6, 0.004
+    assert lib.twx_track_update(None, z.ctypes.data, 25, 28, C.byref(st), C.byref(r)) == -1
+    assert lib.twx_track_update(z.ctypes.data, z.ctypes.data, 25, 28, C.byref(st), C.byref(r)) == 0 and r.updated == 0   # all-zero powers: peak at the edge
+    assert lib.twx_track_epoch_dev(None, None, 0, 1, 0, 10, 25, 28, None, 1.0, None, None) == -1
+
+
 def test_band_helpers_match_reference_band_definitions():
     fs = 5e6
     for n in (20000, 200000):

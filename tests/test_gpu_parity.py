@@ -782,6 +782,7 @@ def test_plain_c_client_of_the_abi(tmp_path):
     out = subprocess.run([str(exe), "10000", "14", "43", "4321"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "indice0=12963" in out.stdout
+    assert "tracked(lo): codes=" in out.stdout and "moved=1 first_moved_p=1" in out.stdout      # twx_tracked_* from plain C
 
 
 def test_stockham_row_pass_fallback(monkeypatch):
