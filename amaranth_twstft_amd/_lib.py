@@ -158,6 +158,8 @@ SYMBOLS = {
     "twx_profile_get": (C.c_int, [_VP, C.POINTER(twx_prof_entry), C.c_int32, C.POINTER(C.c_int32)]),
     "twx_lfsr_chips": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _VP]),
     "twx_synth_capture_dev": (C.c_int, [_VP, C.c_int64, C.c_int64, _VP, C.c_int64, C.c_int32, C.c_int32, _VP, _VP]),
+    "twx_ctx_alloc": (_VP, [_VP, C.c_size_t]),
+    "twx_ctx_free": (None, [_VP, _VP]),
     "twx_dev_alloc": (_VP, [C.c_size_t]),
     "twx_dev_free": (None, [_VP]),
     "twx_memcpy_h2d": (C.c_int, [_VP, _VP, C.c_size_t]),

@@ -65,7 +65,8 @@ class Acquisition:
     """One receiver channel of rxcomplex.cpp (``channel_info``): replica set-up at construction (:414-437), then
     :meth:`acquire` per buffer."""
 
-    def __init__(self, code_pm1, rc: float, fs: float, nobs: int, fltmax: float | None = None, dec_a: int = 1, device: int = -1):
+    def __init__(self, code_pm1, rc: float, fs: float, nobs: int, fltmax: float | None = None, dec_a: int = 1, device: int = -1,
+                 max_batch: int = 0):
         self.code = np.asarray(code_pm1, dtype=np.float64)
         self.clen = self.code.size
         self.rc, self.fs, self.nobs, self.dec_a = float(rc), float(fs), int(nobs), int(dec_a)
@@ -77,7 +78,7 @@ class Acquisition:
             if nfft > self.nobs * 2 // self.dec_a:
                 break
         self.nfft = nfft
-        self.cor = Correlator(lfsr=(20, 9, nfft), fs=self.fs / self.dec_a, sps=1, Nint=0, device=device)
+        self.cor = Correlator(lfsr=(20, 9, nfft), fs=self.fs / self.dec_a, sps=1, Nint=0, device=device, max_batch=max_batch)
         wav_t = prn_sampling(self.nobs, self.code, self.rc, self.fs, self.clen)
         wav_acq = np.zeros(nfft, dtype=np.complex128)
         m = self.nobs // self.dec_a

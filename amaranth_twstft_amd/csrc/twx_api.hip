@@ -1845,6 +1845,18 @@ int twx_synth_capture_dev(void* out_dev, int64_t n, int64_t n0, const uint8_t* c
     return hipGetLastError() == hipSuccess ? TWX_OK : TWX_E_HIP;
 }
 
+void* twx_ctx_alloc(twx_ctx* ctx, size_t bytes) {
+    if (!ctx) return nullptr;
+    (void)hipSetDevice(ctx->impl->dev);
+    char* p = nullptr;
+    try { return ctx->impl->dalloc(&p, bytes) == TWX_OK ? p : nullptr; } catch (...) { return nullptr; }
+}
+void twx_ctx_free(twx_ctx* ctx, void* p) {
+    if (!ctx || !p) return;
+    (void)hipSetDevice(ctx->impl->dev);
+    (void)ctx->impl->sync_all();
+    ctx->impl->dfree(p);
+}
 void* twx_dev_alloc(size_t bytes) { void* p = nullptr; return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr; }
 void twx_dev_free(void* p) { (void)hipFree(p); }
 int twx_memcpy_h2d(void* d, const void* s, size_t b) { return hipMemcpy(d, s, b, hipMemcpyHostToDevice) == hipSuccess ? TWX_OK : TWX_E_HIP; }

@@ -378,6 +378,10 @@ int twx_lfsr_chips(int32_t bitlen, int32_t taps, int64_t n, uint8_t* out_host);
  * {delay_q8, fstep, phi0, amp, noise_gain, seed, stream, 0}; sample indices start at n0. */
 int twx_synth_capture_dev(void* out_dev, int64_t n, int64_t n0, const uint8_t* chips_dev, int64_t n_chips,
                           int32_t sps, int32_t n_channels, const int64_t* params_host, void* stream);
+/* Device memory OWNED BY THE CONTEXT (on its device): released by twx_ctx_free or, at the latest, by twx_destroy — a host that
+ * bails out on an error leaks nothing.  twx_dev_alloc / twx_dev_free are the context-free forms (plain hipMalloc / hipFree). */
+void* twx_ctx_alloc(twx_ctx* ctx, size_t bytes);
+void twx_ctx_free(twx_ctx* ctx, void* p);
 void* twx_dev_alloc(size_t bytes);
 void twx_dev_free(void* p);
 int twx_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);

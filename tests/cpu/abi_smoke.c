@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
     if (twx_lfsr_chips(bitlen, taps, n_chips, chips)) return 3;
     void* chips_dev = twx_dev_alloc((size_t)n_chips);
     void* iq_dev = twx_dev_alloc((size_t)n * 4);
-    void* res_dev = twx_dev_alloc(sizeof(twx_result));
+    void* res_dev = twx_ctx_alloc(ctx, sizeof(twx_result));      /* context-owned: released by twx_destroy at the latest */
     if (!chips_dev || !iq_dev || !res_dev) return 4;
     if (twx_memcpy_h2d(chips_dev, chips, (size_t)n_chips)) return 5;
     /* {delay_q8, fstep, phi0, amp, noise_gain, seed, stream, 0}: 0 Hz offset, amplitude 400, noise off */
@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
         free(codes); free(cap); twx_dev_free(cap_dev);
         twx_tracked_destroy(trk);
     }
-    twx_dev_free(chips_dev); twx_dev_free(iq_dev); twx_dev_free(res_dev); free(chips);
+    twx_dev_free(chips_dev); twx_dev_free(iq_dev); free(chips);
     twx_destroy(ctx);
     return ok ? 0 : 1;
 }

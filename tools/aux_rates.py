@@ -93,6 +93,22 @@ def sliding_scan():
                           "TFLOP_s": round(flops / dt / 1e12, 2), "frac_fp32_vector": round(flops / dt / 1e12 / VEC, 4)}))
 
 
+def acq_batch():
+    """the acquisition sweep against the trial carriers per launch (context batch size)"""
+    from amaranth_twstft_amd import acquisition as A
+    n_in, fs, rc, clen, nobs = 5_000_000, 10e6, 2.5e6, 100_000, 400_000
+    chips = prn.lfsr_chips(17, 9, clen)
+    smp = torch.randn((2 * n_in, 2), dtype=torch.float32, device=dev)
+    for mb in (8, 16, 32, 64, 128):
+        a = A.Acquisition(1 - 2 * chips.astype(np.int64), rc, fs, nobs, max_batch=mb)
+        a.acquire(smp.data_ptr(), 3 * nobs, 186.0, 65536.0, 256.0)
+        ts = []
+        for _ in range(10):
+            t = time.perf_counter(); a.acquire(smp.data_ptr(), 3 * nobs, 186.0, 65536.0, 256.0); ts.append(time.perf_counter() - t)
+        print(json.dumps({"kernel": "acquisition sweep, one call", "max_batch": mb, "batch": int(a.cor.info.batch), "ms_median_of_10_warm": round(float(np.median(ts)) * 1e3, 3)}))
+        a.close()
+
+
 def acq():
     from amaranth_twstft_amd import acquisition as A
     n_in, fs, rc, clen = 5_000_000, 10e6, 2.5e6, 100_000
