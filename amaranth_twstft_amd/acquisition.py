@@ -63,10 +63,11 @@ class Interpolator:
 
 class Acquisition:
     """One receiver channel of rxcomplex.cpp (``channel_info``): replica set-up at construction (:414-437), then
-    :meth:`acquire` per buffer."""
+    :meth:`acquire` per buffer.  ``max_batch``: trial carriers per launch (64: 5.05 ms for the 537-carrier sweep at sdr.param
+    sizes against 5.45 ms at 16, ``tools/aux_rates.py acq_batch``)."""
 
     def __init__(self, code_pm1, rc: float, fs: float, nobs: int, fltmax: float | None = None, dec_a: int = 1, device: int = -1,
-                 max_batch: int = 0):
+                 max_batch: int = 64):
         self.code = np.asarray(code_pm1, dtype=np.float64)
         self.clen = self.code.size
         self.rc, self.fs, self.nobs, self.dec_a = float(rc), float(fs), int(nobs), int(dec_a)

@@ -229,3 +229,60 @@ def test_lo_and_re_siblings(emul, mode, OP):
     assert np.allclose(got["xval"], want["xval"])
     if mode == "lo":
         assert all(float(v).is_integer() for v in want["indice1"])
+
+
+@pytest.mark.parametrize("delay,jump_at,jump", [(500, None, 0), (15000, 29, 4000), (300, 28, -250), (12000, 57, 9000)])
+def test_edge_paths_of_the_realignment(emul, delay, jump_at, jump):
+    """The branches of :176-193 that ordinary captures do not reach: a peak in the upper half of the code (``dindex-indice1+1 < 0``
+    -> one code period is skipped, :180-182), a re-alignment asked for by the LAST code of a chunk (the script would index past
+    the chunk; restated as: keep the first measurement, end the chunk), jumps backwards."""
+    nchips, n = 10000, 20000
+    chips = chips_for(14, 43, nchips)
+    Lc = 30 * n
+
+    def seg(ncodes, d, seed):
+        p = synth.SynthParams(delay_q8=d * 256, fstep=synth.fstep_for_df(30.0, FS), phi0=5, amp=500,
+                              noise_gain=synth.noise_gain_for_sigma(300.0), seed=seed)
+        return synth.synth_channel(n * ncodes, chips, 2, p)
+
+    if jump_at is None:
+        raw = seg(70, delay, 41)
+    else:
+        raw = np.concatenate((seg(jump_at, delay, 42), seg(70 - jump_at, delay + jump, 43)))
+    want = orc.ranging_tracked(raw, chips, fs=FS, ls_samples=Lc)
+    got = _run(emul, raw, chips, n, Lc)
+    assert want["kbon"] > 0 and len(want["indice1"]) >= 55 and len(want["moved"]) >= (1 if jump_at is None else 2)
+    assert got["indice1"] == want["indice1"] and got["moved"] == want["moved"] and got["movedval"] == want["movedval"]
+    assert got["df"] == want["df"] and np.allclose(got["xval"], want["xval"])
+    if jump_at is None:                                           # claudio convention: the peak of a small delay sits at n - delay
+        assert want["movedval"][0] > n / 2                       # the upper-half branch was taken
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_captures_through_the_same_loop(emul, seed):
+    """Random delays, carriers, jump positions and sizes, chunk lengths and skips, all three flavours: the C++ loop and the
+    oracle's restatement must agree on every stored lag, every re-alignment and every carrier."""
+    rng = np.random.default_rng(100 + seed)
+    nchips, n = 10000, 20000
+    chips = chips_for(14, 43, nchips)
+    mode = ("ranging", "lo", "re")[seed % 3]
+    OP = int(rng.integers(0, 2))
+    m = orc.tracked_mode(mode, OP)
+    car = float(rng.uniform(-3000, 3000)) if mode != "re" else (m["band"][0] + m["band"][1]) / 4 + float(rng.uniform(-500, 500))
+    segs, d = [], int(rng.integers(100, n - 100))
+    for k in range(int(rng.integers(2, 5))):
+        p = synth.SynthParams(delay_q8=d * 256, fstep=synth.fstep_for_df(car, FS), phi0=int(rng.integers(0, 2 ** 31)), amp=500,
+                              noise_gain=synth.noise_gain_for_sigma(300.0), seed=1000 * seed + k)
+        segs.append(synth.synth_channel(n * int(rng.integers(12, 30)), chips, 2, p))
+        d = int((d + rng.integers(-3000, 3000)) % n)
+    raw = np.concatenate(segs)
+    Lc = n * int(rng.integers(8, 20))
+    skip = int(rng.integers(0, 3)) * n
+    kw = dict(band=m["band"], carrier=m["carrier"], indice_floor=m["indice_floor"])
+    want = orc.ranging_tracked(raw, chips, fs=FS, ls_samples=Lc, skip_samples=skip, **kw)
+    got = _run(emul, raw, chips, n, Lc, band=m["band"], carrier=1 if m["carrier"] == "chunk_band" else 0,
+               indice_floor=int(m["indice_floor"]), skip=skip)
+    assert got["kbon"] == want["kbon"] and got["df"] == want["df"]
+    assert got["indice1"] == want["indice1"] and got["moved"] == want["moved"] and got["movedval"] == want["movedval"]
+    assert np.allclose(got["xval"], want["xval"]) and np.allclose(got["correction1"], want["correction1"])
+    assert len(want["indice1"]) >= 8
