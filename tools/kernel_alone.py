@@ -13,6 +13,7 @@ from amaranth_twstft_amd.correlator import Correlator, band_godual
 NAMES = ["k_sums", "k_col_fwd_square", "k_row_band", "k_df_tables", "k_col_fwd_mix", "k_row_mid", "k_col_inv", "k_peak"]
 cls = NAMES.index(sys.argv[1]) if len(sys.argv) > 1 else 5
 seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
+zero = len(sys.argv) > 3 and sys.argv[3] == "zero"      # all-zero capture: same instruction stream, (almost) no data toggling
 FS, NCH = 5e6, 2_500_000
 n = 2 * NCH
 lib = L.load()
@@ -25,6 +26,8 @@ params = np.array([p.delay_q8, p.fstep, p.phi0, p.amp, p.noise_gain, p.seed, p.s
 for w in range(nwin):
     params[5] = 1000 + w
     L.check(lib.twx_synth_capture_dev(iq[w].data_ptr(), n, 0, chips_dev.data_ptr(), NCH, 2, 1, params.ctypes.data_as(C.c_void_p), None))
+if zero:
+    iq.zero_()
 torch.cuda.synchronize()
 res = torch.zeros((nwin, C.sizeof(L.twx_result)), dtype=torch.uint8, device="cuda")
 band = L.twx_band(*band_godual(FS, n))
@@ -40,5 +43,5 @@ with Correlator(chips, fs=FS, Nint=1) as cor:
     reps = max(20, int(seconds / dt))
     L.check(lib.twx_set_option(cor._h, 101, reps), cor._h)
     t = time.perf_counter(); run(B); el = time.perf_counter() - t
-    print(f"{NAMES[cls]} alone, 1 slot, batch {B}: {reps} launches in {el:.2f} s = {el / reps * 1e3:.4f} ms per launch")
+    print(f"{NAMES[cls]} alone{' (all-zero capture)' if zero else ''}, 1 slot, batch {B}: {reps} launches in {el:.2f} s = {el / reps * 1e3:.4f} ms per launch")
     L.check(lib.twx_set_option(cor._h, 100, -1), cor._h)
