@@ -918,6 +918,10 @@ template <typename T> struct Ctx : CtxBase {
         ra.part = part_band; ra.cspec = cspec; ra.ramp1 = ramp1; ra.nphase = R; ra.scale = (T)scale_pow2;
         ra.ta = ta; ra.tb = tb; ra.tshift = tshift; ra.Bz = Bz; ra.dc = dc;
         ra.stamps = stamps_dev;
+        {
+            static const int pf = [] { const char* e = getenv("TWX_ROW_PF"); return e ? atoi(e) : -1; }();      // experiments: 0 = off, n = stride
+            ra.pf_stride = pf >= 0 ? pf : 2 * ncu;          // two workgroups of k_rowd<MID> per CU are resident
+        }
         if (band) {
             if (band->k_lo < 0 || band->k_hi >= N || band->k_lo > band->k_hi) return fail(TWX_E_ARG, "band outside 0..N-1");
             ra.band_lo = band->k_lo; ra.band_hi = band->k_hi;

@@ -37,6 +37,9 @@
 #ifndef TWX_NT_A
 #define TWX_NT_A 1      // k_rowd: non-temporal loads of the column-pass output A (read exactly once)
 #endif
+#ifndef TWX_ROW_PREFETCH
+#define TWX_ROW_PREFETCH 1   // k_rowd<MID>: L2 touch of the successor workgroup's A row during the last phase
+#endif
 #ifndef TWX_MID_FOLD
 #define TWX_MID_FOLD 1   // k_rowd<MID>: output twiddle W_N^{-k1 t} and phase ramp folded into stage B's factors (one product per output less)
 #endif
@@ -794,6 +797,8 @@ template <typename T> struct RowArgs {
     cpx<T>* Bz;                      // [b][rho][k1][q2]
     cpx<T>* dc;                      // [b]  X[0] of the window (mean(y) for puissance, :46)
     unsigned long long* stamps;      // diagnostic builds (TWX_STAMPS) only
+    int pf_stride;                   // k_rowd<MID>: workgroups resident at a time (0: off) — a workgroup touches the A row of the workgroup
+                                     // that will take its place, blockIdx + pf_stride (same XCD), so that row is an L2 hit when it is asked for
 };
 
 // reverse of a plan (inverse transform consumes the forward's last-stage register layout)
@@ -1051,6 +1056,7 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     const int u = q0 * R + qi;
     const unsigned mask = (1u << a.tshift) - 1u;
     const C* Ab = a.A + (long long)b * a.n;
+    TWX_STAMP(0);
     C v[RMAX];
     C csr[MODE == ROW_MID ? R : 1];
     // small tables first (they are needed first and loads return in order), then the row, then the code spectrum
@@ -1109,18 +1115,23 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
         if (tid < a.nphase * 2 * R) s_eb[tid] = ebreg;
         if (tid < R0) s_vc[tid] = cconj(cmul(vca, vcb));
     }
+    TWX_STAMP(1);
     __syncthreads();                                   // tables visible (the row loads are in flight meanwhile)
+    TWX_STAMP(2);
     if (tid < M) {
         Bfly<T, R0, false>::run(v);
         D::f0_twiddle_store(lds, tabs, tid, v);
     }
+    TWX_STAMP(3);
     __syncthreads();                                   // all-to-all exchange of the stride-M stage
+    TWX_STAMP(4);
     if constexpr (MODE == ROW_MID && TWX_MID_FOLD && R0 > 1) {
         // stage 0 was the last reader of the forward table tc: turn it into stage B's table, conj(tc[q0][b]) * W_N^{-k1 R b}
         // (visible to every wave after the barrier at the top of the first phase)
         if (tid < R0 * R) tabs[D::tab_c + tid] = cmulc(cconj(cmul(fb1, fb2)), tabs[D::tab_c + tid]);
     }
     if (act) D::f1(lds, tabs, q0, qi, v);
+    TWX_STAMP(5);
     bool pruned = false;
     if constexpr (MODE == ROW_BAND) pruned = ad.nprune > 0;
     if (!pruned) {
@@ -1186,6 +1197,8 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
             for (int q2 = 0; q2 < R; ++q2) v[q2] = pr[q2];
             D::iA_pre(tabs, qi, v);
         }
+        TWX_STAMP(6);
+        unsigned pf_sink = 0;                      // landing register of the L2 touch loads (never read)
         for (int rho = 0; rho < a.nphase; ++rho) {
             int lt = tid;
             asm volatile("" : "+v"(lt));               // keep address arithmetic inside the loop (see k_row)
@@ -1198,11 +1211,31 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                 if (lact) eaj = ad.ea_d[(rho + 1) * NU + lq0 * R + lqi];
             }
             if (rho > 0 || FOLD) __syncthreads();      // previous phase's stage C has read every block (rho = 0: the folded table is complete)
+            TWX_STAMP(7 + rho * 6);
+            if (TWX_ROW_PREFETCH && a.pf_stride > 0 && rho == a.nphase - 1) {
+                // The first 30 % of a workgroup's life is the wait for its row (tools/stamps_rowd.py: 18 k of 61 k cycles until
+                // stage 0 is done, the memory pipes being full of the other workgroups' streams).  Nobody has registers or LDS to
+                // hold a second row, but the L2 has: during its last phase a workgroup touches the 128-B pieces of the row that
+                // the workgroup taking its slot will gather (blockIdx + pf_stride lands on the same XCD), one dword per piece.
+                const unsigned nb = blockIdx.x + (unsigned)a.pf_stride;
+                const unsigned npieces = (unsigned)N2 >> a.wshift;
+                if (nb < gridDim.x && (unsigned)lt < npieces) {
+                    const unsigned lg = xcd_remap(nb, gridDim.x);
+                    const unsigned nk1 = lg / (unsigned)a.nwin, nbw = lg % (unsigned)a.nwin;
+                    const C* pa = a.A + (long long)nbw * a.n + a_index((unsigned)lt << a.wshift, nk1, (unsigned)a.n1, a.wshift);
+                    // the destination register stays reserved to the end of the kernel (pf_sink below): the compiler does not know
+                    // that this asm is a load whose data arrives later, and would hand the register to another value at once
+                    asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pa) : "memory");
+                }
+            }
             if (lact) D::iA_store(lds, lq0, lqi, v);
             wave_sync_lds();
+            TWX_STAMP(8 + rho * 6);
             if constexpr (FOLD) { if (lact) D::iB_folded(lds, tabs, lq0, lqi, cmul(wa0, r1), v); }
             else if (lact) D::iB(lds, tabs, lq0, lqi, v);
+            TWX_STAMP(9 + rho * 6);
             __syncthreads();
+            TWX_STAMP(10 + rho * 6);
             if (lt < M) {
                 D::iC(lds, lt, v);
                 const C uu = cmul(ub, r1);
@@ -1217,6 +1250,7 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                     st_pin<C, TWX_NT_BZ != 0>(ob, (unsigned long long)c * M * sizeof(C), ltb, o);     // SGPR base + lane offset
                 }
             }
+            TWX_STAMP(11 + rho * 6);
             if (rho + 1 < a.nphase && lact) {
                 const int rn = rho + 1;
                 TWX_UNROLL
@@ -1231,7 +1265,9 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                 }
                 D::iA_pre(tabs, lqi, v);
             }
+            TWX_STAMP(12 + rho * 6);
         }
+        asm volatile("" ::"v"(pf_sink));           // keeps the landing register allocated until here
     }
 }
 
