@@ -1059,18 +1059,25 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     TWX_STAMP(0);
     C v[RMAX];
     C csr[MODE == ROW_MID ? R : 1];
-    // small tables first (they are needed first and loads return in order), then the row, then the code spectrum
+    // small tables first (they are needed first and loads return in order), then the row, then the code spectrum.
+    // (Computing stage 0's tables in the kernel instead of loading them was tried in round 3 and changed nothing: what the
+    // first 18 k cycles of a workgroup wait for is its 64-KB row at the CU's share of the HBM bandwidth, not a round trip.)
     constexpr int NTAB = (D::tab_total + NT - 1) / NT;
     C treg[NTAB];
     TWX_UNROLL
     for (int k = 0; k < NTAB; ++k) treg[k] = ad.dtabs[min(tid + k * NT, D::tab_total - 1)];     // clamped: no branch, no select
+    // MID with the folded output twiddle and the uniform factors in scalar registers reads neither s_vc nor s_eb
+    constexpr bool NEED_SVC = MODE == ROW_MID && !(TWX_MID_SGPR && TWX_MID_FOLD && R0 > 1);
+    constexpr bool NEED_SEB = MODE == ROW_MID && !(TWX_MID_SGPR && R % 2 == 0);
     C ebreg = mk<T>(0, 0), vca = mk<T>(1, 0), vcb = mk<T>(1, 0);
     C fa1 = mk<T>(1, 0), fa2 = mk<T>(1, 0), fb1 = mk<T>(1, 0), fb2 = mk<T>(1, 0);
     if constexpr (MODE == ROW_MID) {
         static_assert(TWX_MAX_PHASE * 2 * R <= NT, "phase-ramp table larger than the workgroup");
-        ebreg = ad.eb_d[min(tid, a.nphase * 2 * R - 1)];
-        const unsigned m = (unsigned)k1 * (unsigned)min(tid, R0 - 1) * (unsigned)M;  // conj(W_N^{k1 * c * M})
-        vca = a.ta[m >> a.tshift]; vcb = a.tb[m & mask];
+        if constexpr (NEED_SEB) ebreg = ad.eb_d[min(tid, a.nphase * 2 * R - 1)];
+        if constexpr (NEED_SVC) {
+            const unsigned m = (unsigned)k1 * (unsigned)min(tid, R0 - 1) * (unsigned)M;  // conj(W_N^{k1 * c * M})
+            vca = a.ta[m >> a.tshift]; vcb = a.tb[m & mask];
+        }
         if constexpr (TWX_MID_FOLD && R0 > 1) {
             // the output twiddle W_N^{-k1 t}, t = a + R b, split into the part of stage B's thread (a = qi) and the part
             // that goes into the table of stage B (b = tid mod R): gathered here, with the other prologue loads
@@ -1112,8 +1119,8 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     TWX_UNROLL
     for (int k = 0; k < NTAB; ++k) { const int i = tid + k * NT; if (i < D::tab_total) tabs[i] = treg[k]; }
     if constexpr (MODE == ROW_MID) {
-        if (tid < a.nphase * 2 * R) s_eb[tid] = ebreg;
-        if (tid < R0) s_vc[tid] = cconj(cmul(vca, vcb));
+        if constexpr (NEED_SEB) { if (tid < a.nphase * 2 * R) s_eb[tid] = ebreg; }
+        if constexpr (NEED_SVC) { if (tid < R0) s_vc[tid] = cconj(cmul(vca, vcb)); }
     }
     TWX_STAMP(1);
     __syncthreads();                                   // tables visible (the row loads are in flight meanwhile)
