@@ -292,9 +292,14 @@ __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ 
         }
     }
     __syncthreads();
-    float2 acc[FIR_K];
+    // (I, Q) of an output as one 2-vector: one v_pk_fma_f32 per tap and output with the wave-uniform tap broadcast from its
+    // scalar register.  Measured equal to the two v_fmac_f32 with a scalar operand it replaces (0.187 ms both: a packed fp32
+    // instruction takes two passes, profiles/r02_valu_probe.txt): the kernel is bound by vector issue slots — per four LDS
+    // reads 8 sign-extending converts and 16 packed FMAs, of which 86 % meet a real tap.
+    typedef float pk2 __attribute__((ext_vector_type(2)));
+    pk2 acc[FIR_K];
 #pragma unroll
-    for (int k = 0; k < FIR_K; ++k) acc[k] = make_float2(0.f, 0.f);
+    for (int k = 0; k < FIR_K; ++k) acc[k] = pk2{0.f, 0.f};
     for (int p = 0; p < D; ++p) {
         const unsigned* Xp = X + p * PS + tid;
         const float* h = hp + p * HROW;
@@ -304,15 +309,15 @@ __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ 
             for (int j = 0; j < 4 * SHT + 4; ++j) t[j] = h[j];     // wave-uniform: scalar loads, once per phase
 #pragma unroll
             for (int sh = 0; sh < SHT; ++sh) {
-                float2 v[4];
+                pk2 v[4];
 #pragma unroll
-                for (int sl = 0; sl < 4; ++sl) { const unsigned w = Xp[sl * QS + sh]; v[sl] = make_float2((float)(short)(w & 0xffffu), (float)(short)(w >> 16)); }
+                for (int sl = 0; sl < 4; ++sl) { const unsigned w = Xp[sl * QS + sh]; v[sl] = pk2{(float)(short)(w & 0xffffu), (float)(short)(w >> 16)}; }
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl)
 #pragma unroll
                     for (int k = 0; k < FIR_K; ++k) {              // step s = 4sh+sl feeds output k with tap a = s-k (table index a+3)
-                        acc[k].x = fmaf(v[sl].x, t[4 * sh + sl - k + 3], acc[k].x);
-                        acc[k].y = fmaf(v[sl].y, t[4 * sh + sl - k + 3], acc[k].y);
+                        const float tv = t[4 * sh + sl - k + 3];
+                        acc[k] = __builtin_elementwise_fma(v[sl], pk2{tv, tv}, acc[k]);
                     }
             }
         } else {
@@ -320,15 +325,15 @@ __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ 
                 float t[7];
 #pragma unroll
                 for (int j = 0; j < 7; ++j) t[j] = h[4 * sh + j];
-                float2 v[4];
+                pk2 v[4];
 #pragma unroll
-                for (int sl = 0; sl < 4; ++sl) { const unsigned w = Xp[sl * QS + sh]; v[sl] = make_float2((float)(short)(w & 0xffffu), (float)(short)(w >> 16)); }
+                for (int sl = 0; sl < 4; ++sl) { const unsigned w = Xp[sl * QS + sh]; v[sl] = pk2{(float)(short)(w & 0xffffu), (float)(short)(w >> 16)}; }
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl)
 #pragma unroll
                     for (int k = 0; k < FIR_K; ++k) {
-                        acc[k].x = fmaf(v[sl].x, t[sl - k + 3], acc[k].x);
-                        acc[k].y = fmaf(v[sl].y, t[sl - k + 3], acc[k].y);
+                        const float tv = t[sl - k + 3];
+                        acc[k] = __builtin_elementwise_fma(v[sl], pk2{tv, tv}, acc[k]);
                     }
             }
         }
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ 
         }
     } else {
         for (int k = 0; k < FIR_K && m + k < nout; ++k) {
-            if (yf) yf[m + k] = acc[k];
+            if (yf) yf[m + k] = make_float2(acc[k].x, acc[k].y);
             if (y16) {
                 const float r = fminf(fmaxf(rintf(acc[k].x), -32768.f), 32767.f), q = fminf(fmaxf(rintf(acc[k].y), -32768.f), 32767.f);
                 y16[m + k] = make_short2((short)r, (short)q);
