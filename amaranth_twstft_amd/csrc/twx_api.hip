@@ -476,6 +476,7 @@ template <typename T> struct Ctx : CtxBase {
     C* cspec = nullptr;
     C *cspec_perm = nullptr, *dtabs = nullptr, *ea_d = nullptr, *eb_d = nullptr;   // DIF/DIT row pass (k_rowd)
     C* wr_d = nullptr;            // exp(-2 pi i j/R), j < R: pruned last stage of k_rowd<BAND>
+    C* vw_d = nullptr;            // [k1][2][R] exp(+2 pi i k1 a/N), exp(+2 pi i k1 R b/N): k_rowd<MID>'s folded output twiddle
     C* vc_d = nullptr;            // [k1][c] exp(+2 pi i k1 c M/N): stage C's per-row output twiddle of k_rowd<MID> (scalar loads)
     int use_rowd = 0;
     unsigned char* chips_dev = nullptr;
@@ -600,6 +601,14 @@ template <typename T> struct Ctx : CtxBase {
                     vc[(size_t)k1 * R0 + c] = mk<T>((T)cosl(a), (T)sinl(a));
                 }
                 if (int rc = upload(&vc_d, vc)) return rc;
+                std::vector<C> vw((size_t)N1 * 2 * Rr);
+                for (int k1 = 0; k1 < N1; ++k1) for (int j = 0; j < Rr; ++j) {
+                    const long double aa = tp * (long double)(((long long)k1 * j) % N) / (long double)N;
+                    const long double ab = tp * (long double)(((long long)k1 * Rr * j) % N) / (long double)N;
+                    vw[((size_t)k1 * 2 + 0) * Rr + j] = mk<T>((T)cosl(aa), (T)sinl(aa));
+                    vw[((size_t)k1 * 2 + 1) * Rr + j] = mk<T>((T)cosl(ab), (T)sinl(ab));
+                }
+                if (int rc = upload(&vw_d, vw)) return rc;
             }
             std::vector<C> a1((size_t)R * NU), b1((size_t)R * 2 * Rr);
             for (int rho = 0; rho < R; ++rho) {
@@ -919,8 +928,10 @@ template <typename T> struct Ctx : CtxBase {
         ra.ta = ta; ra.tb = tb; ra.tshift = tshift; ra.Bz = Bz; ra.dc = dc;
         ra.stamps = stamps_dev;
         {
-            static const int pf = [] { const char* e = getenv("TWX_ROW_PF"); return e ? atoi(e) : -1; }();      // experiments: 0 = off, n = stride
-            ra.pf_stride = pf >= 0 ? pf : 2 * ncu;          // two workgroups of k_rowd<MID> per CU are resident
+            // k_rowd<MID>: workgroups in the launch.  Two are resident per CU (LDS); five per CU = 3.9 rows each balance the tail
+            // better than two per CU with 9 or 10 rows each (profiles/r03_rowd_resident.txt: 0.326 against 0.334 ms).
+            static const int pf = [] { const char* e = getenv("TWX_ROW_PF"); return e ? atoi(e) : -1; }();      // experiments: 0 = one workgroup per row
+            ra.pf_stride = pf >= 0 ? pf : 5 * ncu;
         }
         if (band) {
             if (band->k_lo < 0 || band->k_hi >= N || band->k_lo > band->k_hi) return fail(TWX_E_ARG, "band outside 0..N-1");
@@ -969,7 +980,7 @@ template <typename T> struct Ctx : CtxBase {
             ProfScope ps(this, PC_ROW_MID, (long long)nb * N);
             for (int it = 0, ne = reps(PC_ROW_MID); it < ne; ++it)
             if (use_rowd) {
-                RowDArgs<T> rd{}; rd.r = ra; rd.dtabs = dtabs; rd.cspec_perm = cspec_perm; rd.ea_d = ea_d; rd.eb_d = eb_d; rd.vc = vc_d;
+                RowDArgs<T> rd{}; rd.r = ra; rd.dtabs = dtabs; rd.cspec_perm = cspec_perm; rd.ea_d = ea_d; rd.eb_d = eb_d; rd.vc = vc_d; rd.vw = vw_d;
                 if (row->rowd(ROW_MID, &rd, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_rowd(mid) launch failed");
             } else if (row->run(ROW_MID, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(mid) launch failed");
         }

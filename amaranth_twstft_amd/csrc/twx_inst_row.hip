@@ -43,7 +43,8 @@ template <typename T> int caf(const void* args, unsigned nblk, hipStream_t s) {
 template <typename T> int rowd(int mode, const void* args, unsigned nblk, hipStream_t s) {
     if constexpr (HasRowD<P>::value) {
         constexpr int NTD = RowD<P, T>::NT_MIN;
-        const RowDArgs<T>& a = *reinterpret_cast<const RowDArgs<T>*>(args);
+        RowDArgs<T> a = *reinterpret_cast<const RowDArgs<T>*>(args);
+        a.total_rows = nblk;
         if constexpr (RowD<P, T>::R0 == 1 && std::is_same<T, float>::value) {     // short rows: several rows per workgroup
             constexpr int NTS = 448, G = (NTS / 64) * RowD<P, T>::BPW;
             const unsigned grid = (nblk + G - 1) / G;
@@ -52,8 +53,11 @@ template <typename T> int rowd(int mode, const void* args, unsigned nblk, hipStr
             else return -1;
         } else {
         if (mode == ROW_BAND) TWX_LAUNCH((k_rowd<P, T, ROW_BAND, NTD>), dim3(nblk), dim3(NTD), s, a);
-        else if (mode == ROW_MID) TWX_LAUNCH((k_rowd<P, T, ROW_MID, NTD>), dim3(nblk), dim3(NTD), s, a);
-        else return -1;
+        else if (mode == ROW_MID) {
+            unsigned grid = nblk;                          // resident workgroups walk the rows (a.total_rows = nblk)
+            if (rowd_mid_resident<P, T>() && a.r.pf_stride > 0 && (unsigned)a.r.pf_stride < nblk) grid = (unsigned)a.r.pf_stride;
+            TWX_LAUNCH((k_rowd<P, T, ROW_MID, NTD>), dim3(grid), dim3(NTD), s, a);
+        } else return -1;
         }
         return (int)hipGetLastError();
     } else {

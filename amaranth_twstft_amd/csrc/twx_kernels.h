@@ -30,6 +30,9 @@
 #ifndef TWX_ABLC
 #define TWX_ABLC 0      // k_col_inv: 1 no transforms, 2 no global loads
 #endif
+#ifndef TWX_ABLR
+#define TWX_ABLR 0      // k_rowd<MID> (diagnostic variants): 1 no Bz stores (loads + arithmetic), 2 no arithmetic (row in, nphase copies out)
+#endif
 #ifndef TWX_ABLF
 #define TWX_ABLF 0      // k_col_fwd: 1 no transform, 2 no loads, 3 no stores, 4 stores only, 5 loads only
 #endif
@@ -37,8 +40,8 @@
 #ifndef TWX_NT_A
 #define TWX_NT_A 1      // k_rowd: non-temporal loads of the column-pass output A (read exactly once)
 #endif
-#ifndef TWX_ROW_PREFETCH
-#define TWX_ROW_PREFETCH 1   // k_rowd<MID>: L2 touch of the successor workgroup's A row during the last phase
+#ifndef TWX_MID_PERSIST
+#define TWX_MID_PERSIST 1  // k_rowd<MID>: resident workgroups loop over the rows; the next row's A is loaded during the last phase
 #endif
 #ifndef TWX_MID_FOLD
 #define TWX_MID_FOLD 1   // k_rowd<MID>: output twiddle W_N^{-k1 t} and phase ramp folded into stage B's factors (one product per output less)
@@ -797,8 +800,8 @@ template <typename T> struct RowArgs {
     cpx<T>* Bz;                      // [b][rho][k1][q2]
     cpx<T>* dc;                      // [b]  X[0] of the window (mean(y) for puissance, :46)
     unsigned long long* stamps;      // diagnostic builds (TWX_STAMPS) only
-    int pf_stride;                   // k_rowd<MID>: workgroups resident at a time (0: off) — a workgroup touches the A row of the workgroup
-                                     // that will take its place, blockIdx + pf_stride (same XCD), so that row is an L2 hit when it is asked for
+    int pf_stride;                   // k_rowd<MID>: workgroups in the launch (a few per CU, two resident at a time); 0: one per row.  The launch
+                                     // has min(rows, pf_stride) workgroups, workgroup g takes the rows g, g + grid, g + 2 grid, ... (same XCD)
 };
 
 // reverse of a plan (inverse transform consumes the forward's last-stage register layout)
@@ -1020,15 +1023,23 @@ template <typename T> struct RowDArgs {
     // (k = k1 + N1 k2; +-20 kHz of a 5-Msps second = |k2| <= 32 of 8000: 4 pairs).  nprune > 0: the last stage is replaced
     // by one R-term sum per (q0, pair) instead of a full radix-R butterfly in every lane.
     const cpx<T>* vc;                // [k1][c]  exp(+2 pi i k1 c M/N), c < R0: the per-row output twiddle of stage C, read with scalar loads
+    const cpx<T>* vw;                // [k1][2][R]  exp(+2 pi i k1 a/N), exp(+2 pi i k1 R b/N): the folded output twiddle of k_rowd<MID>
     const cpx<T>* wr;                // [R] exp(-2 pi i j / R)
     int nprune;                      // number of (q1, q2) pairs, 0 = full last stage
     unsigned long long pr_q1, pr_q2; // pair p in byte p
+    unsigned total_rows;             // N1 * windows (the grid is smaller when k_rowd<MID> runs with resident workgroups)
 };
 
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+}
+
+// k_rowd<MID> with resident workgroups (see the kernel): the launcher sizes the grid with the same predicate
+template <class P2, typename T> constexpr bool rowd_mid_resident() {
+    using D = RowD<P2, T>;
+    return TWX_MID_PERSIST && TWX_MID_FOLD && D::R0 > 1 && sizeof(T) == 4 && D::M % 16 == 0;
 }
 
 template <class P2, typename T, int MODE, int NT>
@@ -1038,104 +1049,162 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     const RowArgs<T>& a = ad.r;
     constexpr int N2 = D::L, R = D::R, R0 = D::R0, M = D::M, NU = R0 * R;
     constexpr int RMAX = R > R0 ? R : R0;
-    constexpr int NEB = MODE == ROW_MID ? TWX_MAX_PHASE * 2 * R : 0;
-    constexpr int NVC = MODE == ROW_MID ? R0 : 0;
+    // MID with the folded output twiddle and the uniform factors in scalar registers reads neither s_vc nor s_eb
+    constexpr bool NEED_SVC = MODE == ROW_MID && !(TWX_MID_SGPR && TWX_MID_FOLD && R0 > 1);
+    constexpr bool NEED_SEB = MODE == ROW_MID && !(TWX_MID_SGPR && R % 2 == 0);
+    constexpr int NEB = NEED_SEB ? TWX_MAX_PHASE * 2 * R : 0;
+    constexpr int NVC = NEED_SVC ? R0 : 0;
     static_assert(NT >= D::NT_MIN, "not enough threads for RowD");
+    // Row-walking workgroups (MID, fp32, folded tables): the launch has a few workgroups per CU and each walks the rows
+    // g, g + grid, g + 2 grid, ... — the tables go to LDS once per workgroup, and the next row's A is loaded into the registers
+    // of the product pr[], dead during the last phase, while that phase runs: the wait for the row (30 % of a one-row
+    // workgroup's life, tools/stamps_rowd.py) is gone.  What remains is the kernel's two balanced halves: its memory traffic
+    // alone takes 0.26 ms, its loads + arithmetic without the stores 0.245 ms, together 0.326 ms (profiles/r03_rowd_resident.txt).
+    constexpr bool PERSIST = MODE == ROW_MID && rowd_mid_resident<P2, T>();
+    constexpr int NTC = PERSIST ? R0 * R : 0;
     // data and tables are SEPARATE shared arrays: with one array the compiler must assume that a table read may
     // alias an earlier data write and serialises read -> wait -> multiply -> write for every element of a stage
     __shared__ C lds[D::lds_elems];
-    __shared__ C tabs[D::tab_total + NEB + NVC + 16];
+    __shared__ C tabs[D::tab_total + NEB + NVC + NTC + 16];
     C* s_eb = tabs + D::tab_total;
     C* s_vc = s_eb + NEB;
-    void* red = (void*)(s_vc + NVC);
-    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int k1 = logical / a.nwin, b = logical % a.nwin;
-    const int tid = threadIdx.x;
+    C* s_tc = s_vc + NVC;                   // PERSIST: the forward table tc as loaded (tabs[tab_c..] is folded per row and restored from here)
+    void* red = (void*)(s_tc + NTC);
+    const unsigned total = PERSIST ? ad.total_rows : gridDim.x;
+    const int tid0 = threadIdx.x;
+    TWX_STAMP(30);
+    C v[RMAX];
+    C csr[MODE == ROW_MID ? R : 1];
+    C pr[MODE == ROW_MID ? RMAX : 1];
+    // the row loads are unconditional (idle lanes of the last wave re-read a valid element): inside divergent branches
+    // the wait-count pass has to assume the branch was skipped and waits for far more than the tables
+    auto load_row = [&](unsigned vb, int tl, C* dst) {
+        const unsigned lg = xcd_remap(vb, total);
+        const int rk1 = lg / a.nwin, rb = lg % a.nwin;
+        const C* Ab = a.A + (long long)rb * a.n;
+        if constexpr (M % 16 == 0) {
+            // M is a multiple of every tile width (W <= 16): element tl + r*M of the row sits r*M*N1 elements after element
+            // tl — one a_index per thread (its integer multiply runs at quarter rate) instead of one per element, the
+            // r-dependent part is scalar: SGPR base + scalar offset + 32-bit lane offset
+            const unsigned lb = a_index((unsigned)tl, (unsigned)rk1, (unsigned)a.n1, a.wshift) * (unsigned)sizeof(C);
+            const unsigned long long ab = sgpr_u64(reinterpret_cast<unsigned long long>(Ab));
+            const unsigned long long rstep = sgpr_u64((unsigned long long)M * (unsigned long long)a.n1 * sizeof(C));
+            TWX_UNROLL
+            for (int r = 0; r < R0; ++r) dst[r] = ld_pin<C, TWX_NT_A != 0>(ab, r * rstep, lb);       // A is read exactly once
+        } else {
+            TWX_UNROLL
+            for (int r = 0; r < R0; ++r) {
+                const C* q = Ab + a_index((unsigned)(tl + r * M), (unsigned)rk1, (unsigned)a.n1, a.wshift);
+                dst[r] = TWX_NT_A ? __builtin_nontemporal_load(q) : *q;
+            }
+        }
+    };
+    {
+        // small tables first (they are needed first and loads return in order), then the row, then the code spectrum.
+        // (Computing stage 0's tables in the kernel instead of loading them was tried in round 3 and changed nothing: what the
+        // first 18 k cycles of a workgroup wait for is its 64-KB row at the CU's share of the HBM bandwidth, not a round trip.)
+        constexpr int NTAB = (D::tab_total + NT - 1) / NT;
+        C treg[NTAB];
+        TWX_UNROLL
+        for (int k = 0; k < NTAB; ++k) treg[k] = ad.dtabs[min(tid0 + k * NT, D::tab_total - 1)];     // clamped: no branch, no select
+        C tc0 = mk<T>(1, 0);
+        if constexpr (PERSIST) tc0 = ad.dtabs[D::tab_c + min(tid0, R0 * R - 1)];
+        C ebreg = mk<T>(0, 0);
+        if constexpr (NEED_SEB) {
+            static_assert(!NEED_SEB || TWX_MAX_PHASE * 2 * R <= NT, "phase-ramp table larger than the workgroup");
+            ebreg = ad.eb_d[min(tid0, a.nphase * 2 * R - 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the table loads first in program order (loads return in order)
+        if constexpr (PERSIST) load_row(blockIdx.x, min(tid0, M - 1), pr);      // the first row arrives where every later one does
+        else load_row(blockIdx.x, min(tid0, M - 1), v);
+        __builtin_amdgcn_sched_barrier(0);
+        TWX_UNROLL
+        for (int k = 0; k < NTAB; ++k) { const int i = tid0 + k * NT; if (i < D::tab_total) tabs[i] = treg[k]; }
+        if constexpr (NEED_SEB) { if (tid0 < a.nphase * 2 * R) s_eb[tid0] = ebreg; }
+        if constexpr (PERSIST) {
+            if (tid0 < R0 * R) s_tc[tid0] = tc0;
+            // The first row is waited for HERE, with a wait the compiler sees: entering the row loop with these loads pending,
+            // the wait-count pass merges "the 20 youngest memory operations" with the steady state "20 loads, then the last
+            // phase's 20 stores" and makes every row's first butterfly wait for the previous row's stores (vmcnt(4..0)).
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt and lgkmcnt untouched
+        }
+    }
+
+    unsigned vb = blockIdx.x;
+    do {                                                   // one trip unless PERSIST
+    TWX_STAMP(0);
+    int tid = tid0;
+    if constexpr (PERSIST) asm volatile("" : "+v"(tid));   // per-row address arithmetic stays inside the row loop (hoisted, it is spilled)
     int q0, qi;
     const bool act = D::blk_map(tid, q0, qi);
     const int u = q0 * R + qi;
     const unsigned mask = (1u << a.tshift) - 1u;
-    const C* Ab = a.A + (long long)b * a.n;
-    TWX_STAMP(0);
-    C v[RMAX];
-    C csr[MODE == ROW_MID ? R : 1];
-    // small tables first (they are needed first and loads return in order), then the row, then the code spectrum.
-    // (Computing stage 0's tables in the kernel instead of loading them was tried in round 3 and changed nothing: what the
-    // first 18 k cycles of a workgroup wait for is its 64-KB row at the CU's share of the HBM bandwidth, not a round trip.)
-    constexpr int NTAB = (D::tab_total + NT - 1) / NT;
-    C treg[NTAB];
-    TWX_UNROLL
-    for (int k = 0; k < NTAB; ++k) treg[k] = ad.dtabs[min(tid + k * NT, D::tab_total - 1)];     // clamped: no branch, no select
-    // MID with the folded output twiddle and the uniform factors in scalar registers reads neither s_vc nor s_eb
-    constexpr bool NEED_SVC = MODE == ROW_MID && !(TWX_MID_SGPR && TWX_MID_FOLD && R0 > 1);
-    constexpr bool NEED_SEB = MODE == ROW_MID && !(TWX_MID_SGPR && R % 2 == 0);
-    C ebreg = mk<T>(0, 0), vca = mk<T>(1, 0), vcb = mk<T>(1, 0);
-    C fa1 = mk<T>(1, 0), fa2 = mk<T>(1, 0), fb1 = mk<T>(1, 0), fb2 = mk<T>(1, 0);
+    const unsigned logical = xcd_remap(vb, total);
+    const int k1 = logical / a.nwin, b = logical % a.nwin;
+    const bool has_next = PERSIST && vb + gridDim.x < total;
+    C vca = mk<T>(1, 0), vcb = mk<T>(1, 0);
+    C fa = mk<T>(1, 0), fb = mk<T>(1, 0);
+    if constexpr (PERSIST) {
+        TWX_UNROLL
+        for (int r = 0; r < R0; ++r) v[r] = pr[r];
+    }
+    // the code spectrum of the row: needed after the forward transform.  One trip: issued with the row's start.  Resident
+    // workgroups: after stage 0 has put its outputs into LDS, when v[] is free — at the row's start the butterfly's temporaries,
+    // v[] and 40 landing registers do not fit into 128 (the L2 round trip is covered by the barrier and two stages either way)
+    auto load_cspec = [&]() {
+        const C* cs = ad.cspec_perm + (long long)k1 * N2;
+        const unsigned ulb = (unsigned)min(u, NU - 1) * (unsigned)sizeof(C);
+        const unsigned long long csb = sgpr_u64(reinterpret_cast<unsigned long long>(cs));
+        TWX_UNROLL
+        for (int q2 = 0; q2 < (MODE == ROW_MID ? R : 0); ++q2) csr[q2] = ld_pin<C, false>(csb, (unsigned long long)q2 * NU * sizeof(C), ulb);
+    };
     if constexpr (MODE == ROW_MID) {
-        static_assert(TWX_MAX_PHASE * 2 * R <= NT, "phase-ramp table larger than the workgroup");
-        if constexpr (NEED_SEB) ebreg = ad.eb_d[min(tid, a.nphase * 2 * R - 1)];
         if constexpr (NEED_SVC) {
             const unsigned m = (unsigned)k1 * (unsigned)min(tid, R0 - 1) * (unsigned)M;  // conj(W_N^{k1 * c * M})
             vca = a.ta[m >> a.tshift]; vcb = a.tb[m & mask];
         }
         if constexpr (TWX_MID_FOLD && R0 > 1) {
             // the output twiddle W_N^{-k1 t}, t = a + R b, split into the part of stage B's thread (a = qi) and the part
-            // that goes into the table of stage B (b = tid mod R): gathered here, with the other prologue loads
-            const unsigned ma = (unsigned)k1 * (unsigned)min(qi, R - 1), mb = (unsigned)k1 * (unsigned)R * (unsigned)(tid % R);
-            fa1 = a.ta[ma >> a.tshift]; fa2 = a.tb[ma & mask];
-            fb1 = a.ta[mb >> a.tshift]; fb2 = a.tb[mb & mask];
+            // that goes into the table of stage B (b = tid mod R): one load each from the per-row table, with the other
+            // loads of the row's start
+            fb = ad.vw[((long long)k1 * 2 + 1) * R + tid % R];
         }
-    }
-    __builtin_amdgcn_sched_barrier(0);      // keep the table loads first in program order (loads return in order)
-    // the loads are unconditional (idle lanes of the last wave re-read a valid element): inside divergent branches
-    // the wait-count pass has to assume the branch was skipped and waits for far more than the tables
-    {
-        const int tl = min(tid, M - 1);
-        if constexpr (M % 16 == 0) {
-            // M is a multiple of every tile width (W <= 16): element tl + r*M of the row sits r*M*N1 elements after element
-            // tl — one a_index per thread (its integer multiply runs at quarter rate) instead of one per element, the
-            // r-dependent part is scalar: SGPR base + scalar offset + 32-bit lane offset
-            const unsigned lb = a_index((unsigned)tl, (unsigned)k1, (unsigned)a.n1, a.wshift) * (unsigned)sizeof(C);
-            const unsigned long long ab = sgpr_u64(reinterpret_cast<unsigned long long>(Ab));
-            const unsigned long long rstep = sgpr_u64((unsigned long long)M * (unsigned long long)a.n1 * sizeof(C));
-            TWX_UNROLL
-            for (int r = 0; r < R0; ++r) v[r] = ld_pin<C, TWX_NT_A != 0>(ab, r * rstep, lb);       // A is read exactly once
-        } else {
-            TWX_UNROLL
-            for (int r = 0; r < R0; ++r) {
-                const C* q = Ab + a_index((unsigned)(tl + r * M), (unsigned)k1, (unsigned)a.n1, a.wshift);
-                v[r] = TWX_NT_A ? __builtin_nontemporal_load(q) : *q;
-            }
+        if constexpr (!PERSIST) load_cspec();
+        if constexpr (NEED_SVC) {
+            __syncthreads();                               // (previous row's stage C has read s_vc)
+            if (tid < R0) s_vc[tid] = cconj(cmul(vca, vcb));
         }
-    }
-    if constexpr (MODE == ROW_MID) {
-        const C* cs = ad.cspec_perm + (long long)k1 * N2;
-        const unsigned ulb = (unsigned)min(u, NU - 1) * (unsigned)sizeof(C);
-        const unsigned long long csb = sgpr_u64(reinterpret_cast<unsigned long long>(cs));
-        TWX_UNROLL
-        for (int q2 = 0; q2 < R; ++q2) csr[q2] = ld_pin<C, false>(csb, (unsigned long long)q2 * NU * sizeof(C), ulb);
     }
     __builtin_amdgcn_sched_barrier(0);
-    TWX_UNROLL
-    for (int k = 0; k < NTAB; ++k) { const int i = tid + k * NT; if (i < D::tab_total) tabs[i] = treg[k]; }
-    if constexpr (MODE == ROW_MID) {
-        if constexpr (NEED_SEB) { if (tid < a.nphase * 2 * R) s_eb[tid] = ebreg; }
-        if constexpr (NEED_SVC) { if (tid < R0) s_vc[tid] = cconj(cmul(vca, vcb)); }
+    if constexpr (PERSIST && TWX_ABLR == 2) {              // diagnostic: the kernel's memory traffic without its arithmetic
+        for (int rho = 0; rho < a.nphase; ++rho) {
+            if (has_next && rho == a.nphase - 1) load_row(vb + gridDim.x, min(tid, M - 1), pr);
+            C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
+            const unsigned ltb = (unsigned)min(tid, M - 1) * (unsigned)sizeof(C);
+            const unsigned long long ob = sgpr_u64(reinterpret_cast<unsigned long long>(out));
+            TWX_UNROLL
+            for (int c = 0; c < R0; ++c) st_pin<C, TWX_NT_BZ != 0>(ob, (unsigned long long)c * M * sizeof(C), ltb, v[c]);
+        }
+        continue;
     }
+    if constexpr (PERSIST) { if (tid < M) Bfly<T, R0, false>::run(v); }     // register work ahead of the barrier
     TWX_STAMP(1);
-    __syncthreads();                                   // tables visible (the row loads are in flight meanwhile)
+    // first row: tables visible (the row loads are in flight meanwhile); later rows: the previous row's stage C has read every
+    // block, and the restored table tc is visible
+    __syncthreads();
     TWX_STAMP(2);
     if (tid < M) {
-        Bfly<T, R0, false>::run(v);
+        if constexpr (!PERSIST) Bfly<T, R0, false>::run(v);
         D::f0_twiddle_store(lds, tabs, tid, v);
     }
+    if constexpr (PERSIST) load_cspec();
     TWX_STAMP(3);
     __syncthreads();                                   // all-to-all exchange of the stride-M stage
     TWX_STAMP(4);
     if constexpr (MODE == ROW_MID && TWX_MID_FOLD && R0 > 1) {
         // stage 0 was the last reader of the forward table tc: turn it into stage B's table, conj(tc[q0][b]) * W_N^{-k1 R b}
         // (visible to every wave after the barrier at the top of the first phase)
-        if (tid < R0 * R) tabs[D::tab_c + tid] = cmulc(cconj(cmul(fb1, fb2)), tabs[D::tab_c + tid]);
+        if (tid < R0 * R) tabs[D::tab_c + tid] = cmulc(fb, PERSIST ? s_tc[tid] : tabs[D::tab_c + tid]);
     }
     if (act) D::f1(lds, tabs, q0, qi, v);
     TWX_STAMP(5);
@@ -1178,34 +1247,34 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
         best = block_best<T, NT>(best, red);
         if (tid == 0) { ArgPart<T> p; p.val = best.val; p.idx = best.idx; a.part[(long long)b * a.n1 + k1] = p; }
     } else {
-        C pr[R];
         constexpr bool FOLD = TWX_MID_FOLD && R0 > 1;
         constexpr bool USGPR = TWX_MID_SGPR != 0;
         C ub = mk<T>(1, 0);
         C wa0 = mk<T>(1, 0);
-        if constexpr (FOLD) {
-            // stage B's per-thread factor without the phase ramp: conj(W_L^{q0 a}) * W_N^{-k1 a}
-            if (act) wa0 = cmulc(cconj(cmul(fa1, fa2)), tabs[D::tab_b + q0 * R + qi]);
-        } else if (tid < M) {
+        if constexpr (!FOLD) { if (tid < M) {
             const unsigned m = (unsigned)k1 * (unsigned)tid;
             ub = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
-        }
+        } }
         const C* vcrow = ad.vc + (long long)k1 * R0;                              // wave-uniform address: scalar loads
-        if (act) {
-            if (k1 == 0 && u == 0) a.dc[b] = v[0];
-            TWX_UNROLL
-            for (int q2 = 0; q2 < R; ++q2) pr[q2] = cmul(v[q2], csr[q2]);      // ffty.*fcode (godual_ranging.m:26)
-        }
+        if (act && k1 == 0 && u == 0) a.dc[b] = v[0];
+        // in every lane (the idle ones of the last wave multiply leftovers): a conditional definition would keep the previous
+        // contents of pr[] — the row loaded ahead — alive through the whole forward part
+        TWX_UNROLL
+        for (int q2 = 0; q2 < R; ++q2) pr[q2] = cmul(v[q2], csr[q2]);      // ffty.*fcode (godual_ranging.m:26)
+        // the thread's part of the folded output twiddle: asked for here, where csr[] has just left its registers, and met
+        // after the first inverse butterfly (held from the row's start it was spilled)
+        if constexpr (FOLD) fa = ad.vw[(long long)k1 * 2 * R + min(qi, R - 1)];
         // Phase rho's register work (ramp, first inverse butterfly, its twiddles) is done BEFORE the barrier
         // that ends phase rho-1, so waves that finish stage C early spend the wait on arithmetic.
-        C r1_cur = a.ramp1[k1];
+        C r1_cur = USGPR ? ld_uniform(a.ramp1, k1) : a.ramp1[k1];                  // uniform per row: no vector load, no vmcnt
         if (act) {
             TWX_UNROLL
             for (int q2 = 0; q2 < R; ++q2) v[q2] = pr[q2];
             D::iA_pre(tabs, qi, v);
+            // stage B's per-thread factor without the phase ramp: conj(W_L^{q0 a}) * W_N^{-k1 a}
+            if constexpr (FOLD) wa0 = cmulc(fa, tabs[D::tab_b + q0 * R + qi]);
         }
         TWX_STAMP(6);
-        unsigned pf_sink = 0;                      // landing register of the L2 touch loads (never read)
         for (int rho = 0; rho < a.nphase; ++rho) {
             int lt = tid;
             asm volatile("" : "+v"(lt));               // keep address arithmetic inside the loop (see k_row)
@@ -1214,26 +1283,16 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
             const C r1 = r1_cur;
             C eaj = mk<T>(1, 0);
             if (rho + 1 < a.nphase) {                  // next phase's ramp factors: in flight during this phase
-                r1_cur = a.ramp1[(long long)(rho + 1) * a.n1 + k1];
-                if (lact) eaj = ad.ea_d[(rho + 1) * NU + lq0 * R + lqi];
+                r1_cur = USGPR ? ld_uniform(a.ramp1, (rho + 1) * a.n1 + k1) : a.ramp1[(long long)(rho + 1) * a.n1 + k1];
+                eaj = ad.ea_d[(rho + 1) * NU + min(lq0 * R + lqi, NU - 1)];      // every lane (see the stores of stage C below)
             }
             if (rho > 0 || FOLD) __syncthreads();      // previous phase's stage C has read every block (rho = 0: the folded table is complete)
             TWX_STAMP(7 + rho * 6);
-            if (TWX_ROW_PREFETCH && a.pf_stride > 0 && rho == a.nphase - 1) {
-                // The first 30 % of a workgroup's life is the wait for its row (tools/stamps_rowd.py: 18 k of 61 k cycles until
-                // stage 0 is done, the memory pipes being full of the other workgroups' streams).  Nobody has registers or LDS to
-                // hold a second row, but the L2 has: during its last phase a workgroup touches the 128-B pieces of the row that
-                // the workgroup taking its slot will gather (blockIdx + pf_stride lands on the same XCD), one dword per piece.
-                const unsigned nb = blockIdx.x + (unsigned)a.pf_stride;
-                const unsigned npieces = (unsigned)N2 >> a.wshift;
-                if (nb < gridDim.x && (unsigned)lt < npieces) {
-                    const unsigned lg = xcd_remap(nb, gridDim.x);
-                    const unsigned nk1 = lg / (unsigned)a.nwin, nbw = lg % (unsigned)a.nwin;
-                    const C* pa = a.A + (long long)nbw * a.n + a_index((unsigned)lt << a.wshift, nk1, (unsigned)a.n1, a.wshift);
-                    // the destination register stays reserved to the end of the kernel (pf_sink below): the compiler does not know
-                    // that this asm is a load whose data arrives later, and would hand the register to another value at once
-                    asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pa) : "memory");
-                }
+            if constexpr (PERSIST) {
+                // the product pr[] was read for the last time when this phase's inputs were formed: its registers take the
+                // next row's A, in flight for the whole phase and issued BEFORE this phase's stores (loads and stores share
+                // vmcnt and return in order: the wait at the top of the next row does not include a store round trip)
+                if (has_next && rho == a.nphase - 1) load_row(vb + gridDim.x, min(lt, M - 1), pr);
             }
             if (lact) D::iA_store(lds, lq0, lqi, v);
             wave_sync_lds();
@@ -1243,18 +1302,27 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
             TWX_STAMP(9 + rho * 6);
             __syncthreads();
             TWX_STAMP(10 + rho * 6);
-            if (lt < M) {
-                D::iC(lds, lt, v);
+            if constexpr (PERSIST) {
+                // every wave is past stage B, the last reader of the folded table: back to the forward table for the next row
+                if (has_next && rho == a.nphase - 1 && lt < R0 * R) tabs[D::tab_c + lt] = s_tc[lt];
+            }
+            {
+                // In EVERY lane: the 48 idle lanes of the last wave repeat the work and the stores of lane M-1 (same values to the
+                // same addresses).  Inside a divergent branch the wait-count pass must assume the stores were skipped, and every
+                // later wait for a load issued before them (the next phase's ramp factor, the next row) becomes vmcnt(0): a store
+                // round trip per phase.  Unconditional, they are counted: vmcnt(20).
+                const int ltc = min(lt, M - 1);
+                D::iC(lds, ltc, v);
                 const C uu = cmul(ub, r1);
                 C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
-                const unsigned ltb = (unsigned)lt * (unsigned)sizeof(C);
+                const unsigned ltb = (unsigned)ltc * (unsigned)sizeof(C);
                 const unsigned long long ob = sgpr_u64(reinterpret_cast<unsigned long long>(out));
                 TWX_UNROLL
                 for (int c = 0; c < R0; ++c) {
                     C o;                                                                       // · W_N^{-k1 (t + c M)} · ramp1
                     if constexpr (FOLD) o = USGPR ? cmul_us(v[c], ld_uniform(vcrow, c)) : cmul(v[c], s_vc[c]);
                     else o = USGPR ? cmul3_us(v[c], uu, ld_uniform(vcrow, c)) : cmul3(v[c], uu, s_vc[c]);
-                    st_pin<C, TWX_NT_BZ != 0>(ob, (unsigned long long)c * M * sizeof(C), ltb, o);     // SGPR base + lane offset
+                    if (TWX_ABLR != 1) st_pin<C, TWX_NT_BZ != 0>(ob, (unsigned long long)c * M * sizeof(C), ltb, o);     // SGPR base + lane offset
                 }
             }
             TWX_STAMP(11 + rho * 6);
@@ -1274,8 +1342,9 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
             }
             TWX_STAMP(12 + rho * 6);
         }
-        asm volatile("" ::"v"(pf_sink));           // keeps the landing register allocated until here
     }
+    } while (PERSIST && (vb += gridDim.x) < total);        // rows of this workgroup
+    TWX_STAMP(31);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -20,11 +20,13 @@ df = np.full(B, 1780.75)
 for _ in range(3):
     L.check(lib.twx_process_windows_dev(cor._h, iq.data_ptr(), B, 1, 0, None, df.ctypes.data_as(C.c_void_p), res.data_ptr()), cor._h)
 L.check(lib.twx_synchronize(cor._h))
-nwg = B * 625
-st = np.zeros(nwg * 7 * 32, dtype=np.uint64)
+rows = B * 625
+nwg = int(os.environ.get("TWX_ROW_PF", "512"))       # resident workgroups (two per CU); the stamps of a workgroup's LAST row remain
+nwg = rows if nwg <= 0 else min(rows, nwg)
+st = np.zeros(rows * 7 * 32, dtype=np.uint64)
 L.check(lib.twx_debug_stamps(cor._h, st.ctypes.data_as(C.c_void_p), st.size))
-st = st.reshape(nwg, 7, 32).astype(np.int64)
-lab = ["prologue: loads issued, tables to LDS", "barrier 1", "wait row loads + fwd stage 0 (bfly, twiddle, LDS wr)", "barrier 2 (all-to-all)", "fwd stage 1 (table fold, rd, bfly, wr)",
+st = st.reshape(rows, 7, 32).astype(np.int64)[:nwg]
+lab = ["row top: take the row loaded ahead, first butterfly", "barrier 1", "wait row loads + fwd stage 0 (bfly, twiddle, LDS wr)", "barrier 2 (all-to-all)", "fwd stage 1 (table fold, rd, bfly, wr)",
        "wave sync + fwd stage 2 + product + iA_pre"]
 for r in range(3):
     lab += [f"rho{r}: barrier (top)", f"rho{r}: iA store + wave sync", f"rho{r}: stage B (rd, bfly, twiddle, wr)", f"rho{r}: barrier (all-to-all)",
@@ -37,7 +39,13 @@ tot = med.sum()
 for i in range(nseg):
     print(f"{lab[i]:56s} {med[i]:8.0f} cyc {100 * med[i] / tot:5.1f} %")
 life = st[:, :, nseg] - st[:, :, 0]
-print(f"sum of medians {tot:.0f} cycles; wave lifetime median {np.median(life[ok]):.0f} (s_memtime ticks at 100 MHz x ... = shader cycles per the guide)")
+print(f"sum of medians {tot:.0f} cycles; one row, median over waves {np.median(life[ok]):.0f} cycles (s_memtime tick = shader cycle)")
+whole = (st[:, :, 31] - st[:, :, 30])[ok]
+nrows = np.array([len(range(g, rows, nwg)) for g in range(nwg)])[:, None] * np.ones((1, 7), dtype=np.int64)
+print(f"workgroup lifetime (first to last stamp): median {np.median(whole):.0f}, max {whole.max():.0f} cycles; rows per workgroup {nrows.min()}..{nrows.max()}; "
+      f"lifetime / rows: median {np.median(whole / nrows[ok]):.0f} cycles per row")
+t0 = st[:, :, 30][ok].min(); t1 = st[:, :, 31][ok].max()
+print(f"first start to last end over all workgroups: {t1 - t0} cycles; start spread {st[:, :, 30][ok].max() - t0}, end spread {t1 - st[:, :, 31][ok].min()}")
 grp = {"forward (stage 0-2 + product)": range(0, 6), "barriers": [1, 3] + [6 + 6 * r for r in range(3)] + [9 + 6 * r for r in range(3)],
        "stage B": [8 + 6 * r for r in range(3)], "stage C + stores": [10 + 6 * r for r in range(3)], "ramp + stage A": [7 + 6 * r for r in range(3)] + [11 + 6 * r for r in range(3)]}
 for k, idx in grp.items():
