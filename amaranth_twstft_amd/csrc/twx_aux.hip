@@ -27,23 +27,27 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 constexpr int SD_NT = 256, SD_S = 64, SD_CH = SD_NT * SD_S;      // 16384 samples per workgroup
 constexpr int SD_T = 4;                                          // consecutive samples per lane and pass
+constexpr int SD_NPASS = SD_CH / (SD_T * SD_NT);                 // passes of a full piece
+struct SdRot { float2 r[SD_NPASS]; };                            // exp(-2 pi j ff 1024 k): rotation of pass k against pass 0 (host, fp64)
 
-// Register tile: a lane owns SD_T = 8 CONSECUTIVE samples per pass, so the replica values it needs for all NL lags are
-// the NL+7 consecutive entries c[8g-l+j] — every value read from LDS feeds eight packed FMAs (was: one read per FMA, which
-// left the VALU waiting for the LDS pipe).  The replica segment is stored transposed, entry u = SD_T*q+r at r*QS+q, so that
-// what the 64 lanes read together (same r, consecutive q) is contiguous: conflict-free ds_read_b32.  The NCO is evaluated
-// once per lane and pass (fp64 phase reduction + sincospi) and stepped over the other seven samples by the fp32 rotation
-// exp(-2 pi j ff) (seven steps: 5e-7 relative at most).
+// Register tile: a lane owns SD_T = 4 CONSECUTIVE samples per pass, so the replica values it needs for all NL lags are the
+// NL+3 consecutive entries c[4g-l+j] — every value read from LDS feeds four packed FMAs.  The segment lies in LDS as it
+// lies in memory, and a lane fetches its entries as ceil((NL+3)/4) aligned ds_read_b128 (consecutive lanes, consecutive
+// 16-byte words: conflict-free; 15 reads per pass at NLAG = 28, where the transposed layout of the first version needed 60
+// ds_read_b32).  The NCO is evaluated once per lane and PIECE (fp64 phase reduction + sincospi); a pass multiplies it by
+// the pass's rotation exp(-2 pi j ff 1024 k) from a 16-entry table in the kernel arguments (evaluated on the host in fp64), and the four samples of the pass
+// are stepped by the fp32 rotation exp(-2 pi j ff): three roundings on top of the table's (3e-7 relative at most).
 template <int NLAG>
-__global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict__ x, int nch, long long pt, long long nobs, int nlag, int chunk_len,
+__global__ __launch_bounds__(SD_NT, 2) void k_sliding_dot(const short2* __restrict__ x, int nch, long long pt, long long nobs, int nlag, int chunk_len,
                                                        const float* __restrict__ w, double ff, double phi, float scale, float rot_c, float rot_s,
-                                                       double* __restrict__ partial /*[ncodes][chunks][2*nlag+1][2]*/) {
+                                                       SdRot rot, double* __restrict__ partial /*[ncodes][chunks][2*nlag+1][2]*/) {
     constexpr int NL = 2 * NLAG + 1;
-    constexpr int NE = SD_CH + 2 * NLAG + SD_T;                    // replica entries of a full chunk (+ the tile's overhang)
-    constexpr int QS = ((NE + SD_T - 1) / SD_T) | 1;               // odd stride between the SD_T residue classes: they land in different banks
-    __shared__ float sw[SD_T * QS];                                // replica segment; reused by the final reduction
-    static_assert(NL * SD_NT <= SD_T * QS, "reduction buffer must fit the replica segment");
-    static_assert((SD_T & (SD_T - 1)) == 0, "SD_T must be a power of two");
+    constexpr int NQ = (NL + SD_T - 1 + 3) / 4;                    // 16-byte words a lane reads per pass
+    constexpr int NE4 = SD_CH / SD_T + NQ;                         // 16-byte words of a full chunk's segment
+    __shared__ float4 sw4[NE4];                                    // replica segment; reused by the final reduction
+    float* sw = reinterpret_cast<float*>(sw4);
+    static_assert(NL * SD_NT <= 4 * NE4, "reduction buffer must fit the replica segment");
+    static_assert(SD_T == 4, "one 16-byte word per group of samples");
     const int p = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const int tid = threadIdx.x;
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -51,23 +55,32 @@ __global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict_
 #pragma unroll
     for (int l = 0; l < NL; ++l) acc[l] = f2{0.f, 0.f};
     // a workgroup's chunk may be longer than the LDS segment: it is walked in pieces of SD_CH samples with ONE set of
-    // accumulators, so the block reduction below (as many LDS operations as 3/4 of a full piece) runs once per workgroup
+    // accumulators, so the block reduction below runs once per workgroup
     const long long c0 = (long long)chunk * chunk_len;
     const long long c1 = min(c0 + (long long)chunk_len, nobs);
     for (long long s0 = c0; s0 < c1; s0 += SD_CH) {
     const int cnt = (int)min((long long)SD_CH, c1 - s0);
+    const int ngrp = (cnt + SD_T - 1) / SD_T;
     if (s0 > c0) __syncthreads();                                  // the previous piece's replica segment is no longer read
-    // entry u <-> w[(s0 - NLAG + u) mod nobs]
+    // entry u <-> w[(s0 - NLAG + u) mod nobs]; every 16-byte word a lane will read is written (the overhang with whatever
+    // follows in the code: it meets samples that are masked to zero)
+    // straight into LDS (global_load_lds_dword: lane i of a wave writes base + 4 i, no register in between), every entry
+    // of the piece in flight at once: fetched through registers one or eight at a time, the 64-KB segment cost 8 of a full
+    // piece's 40 microseconds
     {
-        long long k = (s0 - NLAG + tid) % nobs; if (k < 0) k += nobs;          // one 64-bit division per thread, then steps
+        long long k = s0 - NLAG; if (k < 0) k += nobs;             // 0 <= s0 < nobs and NLAG < nobs: no division
+        k += tid; while (k >= nobs) k -= nobs;
         const long long step = SD_NT % nobs;
-        for (int u = tid; u < cnt + 2 * NLAG + SD_T - 1; u += SD_NT) {
-            sw[(u % SD_T) * QS + u / SD_T] = w[k];
+        const int nent = 4 * (ngrp + NQ);
+        float* wave_base = sw + (tid & ~63);
+        for (int u0 = 0; u0 < nent; u0 += SD_NT) {
+            if (u0 + tid < nent)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + k),
+                                                 (__attribute__((address_space(3))) void*)(wave_base + u0), 4, 0, 0);
+            __builtin_amdgcn_s_waitcnt(0x8F70);                    // vmcnt(32): the counter has six bits
             k += step; if (k >= nobs) k -= nobs;
         }
     }
-    __syncthreads();
-    const int ngrp = (cnt + SD_T - 1) / SD_T;
     // the samples of the NEXT pass are requested before this pass's arithmetic (two waves per SIMD do not hide a global
     // load round trip per pass by themselves); loads are unconditional with clamped indices, values masked below
     const long long ilast = (long long)p * nobs + s0 + cnt - 1;
@@ -77,21 +90,28 @@ __global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict_
 #pragma unroll
         for (int j = 0; j < SD_T; ++j) nx[j] = x[(pt + min(i0 + j, ilast)) * nch];
     }
-    for (int g = tid; g < ngrp; g += SD_NT) {
+    float bcs, bsn;                                                // the lane's NCO at its first sample of this piece
+    {
+        double ph = ff * (double)((long long)p * nobs + s0 + (long long)SD_T * tid) + phi;   // fp64 phase reduction, fp32 sincos
+        ph -= rint(ph);
+        sincospif(-2.0f * (float)ph, &bsn, &bcs);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): this thread's part of the segment has landed
+    __syncthreads();
+    int pass = 0;
+    for (int g = tid; g < ngrp; g += SD_NT, ++pass) {
         const int t0 = SD_T * g;
-        const long long i0 = (long long)p * nobs + s0 + t0;        // the NCO runs over the whole block of codes
         short2 sm[SD_T];
 #pragma unroll
-        for (int j = 0; j < SD_T; ++j) sm[j] = nx[j];
-        {
-            const long long i1 = (long long)p * nobs + s0 + (long long)SD_T * min(g + SD_NT, ngrp - 1);
-#pragma unroll
-            for (int j = 0; j < SD_T; ++j) nx[j] = x[(pt + min(i1 + j, ilast)) * nch];
+        for (int j = 0; j < SD_T; ++j) {
+            // opaque hand-over: otherwise the conversion to float moves up behind the load in the PREVIOUS pass (the loop then
+            // carries floats) and that pass waits for the samples it asked for a few hundred cycles earlier
+            unsigned t = *reinterpret_cast<const unsigned*>(&nx[j]);
+            asm volatile("" : "+v"(t));
+            sm[j] = *reinterpret_cast<const short2*>(&t);
         }
-        double ph = ff * (double)i0 + phi;                          // fp64 phase reduction, fp32 sincos
-        ph -= rint(ph);
-        float sn, cs;
-        sincospif(-2.0f * (float)ph, &sn, &cs);
+        const float2 pr = rot.r[pass];                             // kernel argument, uniform index: a scalar load
+        float cs = bcs * pr.x - bsn * pr.y, sn = bcs * pr.y + bsn * pr.x;
         f2 y[SD_T];
 #pragma unroll
         for (int j = 0; j < SD_T; ++j) {
@@ -102,21 +122,41 @@ __global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict_
             cs = c2; sn = s2;
         }
         // sample t0+j, lag index l  <->  replica entry SD_T*g + (j + 2*NLAG - l)
-        float cw[NL + SD_T - 1];
+        // The next pass's samples are asked for HERE, after the mixing: their landing registers are single dwords, and next to
+        // the mixing's temporaries they ended up as the unused halves of packed operands — the pass then waited for them a few
+        // hundred cycles after asking (the packed instruction reads the pair).  In the accumulation below every packed operand
+        // is a whole tuple (accumulator, y, the word read from LDS).
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const long long i1 = (long long)p * nobs + s0 + (long long)SD_T * min(g + SD_NT, ngrp - 1);
 #pragma unroll
-        for (int m = 0; m < NL + SD_T - 1; ++m) cw[m] = sw[(m % SD_T) * QS + g + m / SD_T];
+            for (int j = 0; j < SD_T; ++j) nx[j] = x[(pt + min(i1 + j, ilast)) * nch];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // word by word, two words ahead of the arithmetic: the four entries of a word meet their (sample, lag) pairs and are dead
+        // before the next word is needed.  The scheduling barriers keep that order — left alone, the scheduler asks for all
+        // NQ words first (60 registers on top of the 114 accumulators: spills at the 256-register limit of two waves per SIMD)
+        float4 q0 = sw4[g], q1 = sw4[g + 1];
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
+        for (int m = 0; m < NQ; ++m) {
+            float4 q2 = q1;
+            if (m + 2 < NQ) q2 = sw4[g + m + 2];
+            const float cw[4] = {q0.x, q0.y, q0.z, q0.w};
 #pragma unroll
-            for (int j = 0; j < SD_T; ++j) {
-                const float cv = cw[j + 2 * NLAG - l];
-                acc[l] = __builtin_elementwise_fma(y[j], f2{cv, cv}, acc[l]);
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int j = 0; j < SD_T; ++j) {
+                    const int l = j + 2 * NLAG - (4 * m + e);
+                    if (l >= 0 && l < NL) acc[l] = __builtin_elementwise_fma(y[j], f2{cw[e], cw[e]}, acc[l]);
+                }
             }
+            q0 = q1; q1 = q2;
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     }
-    // block reduction through LDS, one component at a time: buf[l][tid]; thread r = (l, quarter) sums 64 lanes,
-    // starting at a lane-dependent rotation so that the 64 lanes of a wave hit 64 different banks
+    // block reduction through LDS, one component at a time: buf[l][tid]; thread r = (l, quarter) sums 64 lanes as sixteen
+    // 16-byte words, starting at a lane-dependent rotation so that the eight lanes of a ds_read_b128 beat hit 32 different banks
     float* buf = sw;
     const int r = tid, rl = r >> 2, rq = r & 3;
     float part[2] = {0.f, 0.f};
@@ -127,10 +167,11 @@ __global__ __launch_bounds__(SD_NT) void k_sliding_dot(const short2* __restrict_
         for (int l = 0; l < NL; ++l) buf[l * SD_NT + tid] = comp ? acc[l].y : acc[l].x;
         __syncthreads();
         if (rl < NL) {
-            float a = 0.f;
-            const float* q = buf + rl * SD_NT + rq * 64;
-            for (int j = 0; j < 64; ++j) a += q[(j + r) & 63];
-            part[comp] = a;
+            const float4* q = reinterpret_cast<const float4*>(buf + rl * SD_NT + rq * 64);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const float4 t = q[(j + r) & 15]; a0 += t.x; a1 += t.y; a2 += t.z; a3 += t.w; }
+            part[comp] = (a0 + a1) + (a2 + a3);
         }
     }
     __syncthreads();
@@ -152,9 +193,13 @@ __global__ void k_sliding_reduce(const double* __restrict__ partial, int nchunks
     const int p = blockIdx.x, li = threadIdx.x;
     if (li >= nl) return;
     double sr = 0, si = 0;
-    for (int c = 0; c < nchunks; ++c) {   // fixed order: bit-reproducible
-        const double* q = partial + (((long long)p * nchunks + c) * nl + li) * 2;
-        sr += q[0]; si += q[1];
+    for (int c0 = 0; c0 < nchunks; c0 += 16) {   // sixteen loads in flight, added in the fixed order: bit-reproducible
+        double2 t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            t[k] = *reinterpret_cast<const double2*>(partial + (((long long)p * nchunks + min(c0 + k, nchunks - 1)) * nl + li) * 2);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { if (c0 + k < nchunks) { sr += t[k].x; si += t[k].y; } }
     }
     out[((long long)p * nl + li) * 2] = sr * inv_nobs;
     out[((long long)p * nl + li) * 2 + 1] = si * inv_nobs;
@@ -183,7 +228,13 @@ int launch_sliding(hipStream_t st, const short2* dx, int nch, long long pt, long
     const dim3 grid(nchunks, ncodes), block(SD_NT);
     const double two_pi = 6.283185307179586476925286766559;
     const float rot_c = (float)cos(two_pi * ff), rot_s = (float)(-sin(two_pi * ff));          // exp(-2 pi j ff)
-#define SD_GO(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, dpart)
+    SdRot rot;
+    for (int k = 0; k < SD_NPASS; ++k) {
+        double a = ff * (double)(SD_T * SD_NT * k);
+        a -= rint(a);
+        rot.r[k] = make_float2((float)cos(two_pi * a), (float)(-sin(two_pi * a)));
+    }
+#define SD_GO(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, rot, dpart)
     if (nlag <= 4) SD_GO(4); else if (nlag <= 8) SD_GO(8); else if (nlag <= 16) SD_GO(16); else if (nlag <= 28) SD_GO(28); else SD_GO(31);
 #undef SD_GO
     if (hipGetLastError() != hipSuccess) return TWX_E_HIP;
