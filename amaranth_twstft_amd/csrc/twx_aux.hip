@@ -253,51 +253,54 @@ size_t sliding_part_bytes(long long nobs, int ncodes, int nlag) {
 // Polyphase form  y[m] = sum_p sum_a h[a*D+p] * x_p[m+a],  x_p[q] = x[q*D+p]:  D stride-1 filters of A = ceil(ntaps/D) taps.
 // A workgroup of FIR_NT threads produces FIR_NT*4 consecutive outputs, thread t the four outputs 4t..4t+3:
 //   * its input span is staged in LDS as the raw int16 pairs (4 B per sample: 31 KB per workgroup, so five workgroups
-//     share a CU and cover each other's latencies; as floats it was one wave per SIMD), phase by phase and
-//     "transposed" so that what the 64 lanes of a wave read together is contiguous: slot(p, q) = p*PS + (q mod 4)*QS
-//     + q div 4  (lane t, step s reads q = 4t+s -> p*PS + (s mod 4)*QS + t + s div 4): conflict-free ds_read_b32,
-//     converted to float as it is read (two sign-extending converts per four packed FMAs);
+//     share a CU and cover each other's latencies; as floats it was one wave per SIMD), phase-major: slot(p, q) =
+//     p*PSQ + q.  Lane t, group sh reads x_p[4t + 4sh .. +3] as ONE ds_read_b128 (consecutive lanes, consecutive 16-byte
+//     words: conflict-free), converted to float as it is read (two sign-extending converts per four packed FMAs);
+//     PSQ/4 is odd, so the staging writes of consecutive phases spread over the banks;
 //   * each value read feeds the four outputs (8 FMAs) with four different taps; the taps are wave-uniform, read with
 //     scalar loads from a phase-major table hp[p][3 + a] that carries 3 zeros in front and zeros behind, so the
-//     loop has no edge cases;
+//     loop has no edge cases; the steps of the last group that meet only padding are skipped (uniform branch);
 //   * outputs leave as one 16-B (int16 IQ) or two 16-B (float) stores per lane.
-// grid = ceil(nout / (4*FIR_NT)), dynamic LDS = D*PS*8 bytes
+// The kernel is bound by vector issue slots (19 waves per SIMD x 21 k cycles of instructions = the measured time), so
+// what counts is the instruction count: per group of four steps 1 LDS read, 8 converts, 16 packed FMAs.
+// grid = ceil(nout / (4*FIR_NT)), dynamic LDS = D*PSQ*4 bytes
 // ---------------------------------------------------------------------------------------------
 constexpr int FIR_NT = 128, FIR_K = 4, FIR_OUT = FIR_NT * FIR_K;
-struct FirGeom { int A, SH, QS, PS, HROW; size_t lds; };
+struct FirGeom { int A, SH, PSQ, HROW, LASTN; size_t lds; };
 FirGeom fir_geom(int ntaps, int dec) {
     FirGeom g;
     g.A = (ntaps + dec - 1) / dec;
     g.SH = (g.A + FIR_K - 1 + 3) / 4;            // groups of four steps s = 0 .. A+K-2
-    if (g.SH <= 16) g.SH = std::max(4, g.SH);                 // counts 4..16 have unrolled kernels
-    g.QS = (FIR_NT + g.SH) | 1;                  // odd: staging writes of one phase spread over the banks
-    g.PS = FIR_K * g.QS + 1;
+    g.LASTN = g.A + FIR_K - 1 - 4 * (g.SH - 1);  // steps of the last group that can meet a tap (1..4)
+    if (g.SH < 4) { g.SH = 4; g.LASTN = 4; }                  // counts 4..16 have unrolled kernels
+    const int nq = FIR_K * (FIR_NT + g.SH);      // q values staged per phase
+    g.PSQ = ((nq / 4) & 1) ? nq : nq + 4;        // a multiple of 4 (16-byte reads) with PSQ/4 odd (staging writes)
     g.HROW = 4 * g.SH + 4;                       // taps per phase incl. padding (7 are read per group of steps)
-    g.lds = (size_t)dec * g.PS * sizeof(unsigned);
+    g.lds = (size_t)dec * g.PSQ * sizeof(unsigned);
     return g;
 }
 
 // SHT > 0: the number of 4-step groups is a compile-time constant, so a whole phase is one straight-line block: all
 // its taps are fetched with a few scalar loads up front (they then sit in SGPRs) and the LDS reads run ahead of the
-// FMAs; with the 60 KB a workgroup stages only one wave per SIMD is resident, so nothing else would hide those
-// latencies.  SHT == 0: generic loop for any tap count.
+// FMAs.  SHT == 0: generic loop for any tap count.
 template <int SHT>
 __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ x, int nch, long long nin, const float* __restrict__ hp,
-                                                     int D, int SH_rt, int QS, int PS, int HROW, long long nout,
+                                                     int D, int SH_rt, int PSQ, int HROW, int lastn, long long nout,
                                                      short2* __restrict__ y16, float2* __restrict__ yf) {
-    extern __shared__ unsigned X[];                                 // raw int16 IQ pairs: 4 B per sample, converted when read
+    extern __shared__ uint4 X4[];                                   // raw int16 IQ pairs: 4 B per sample, converted when read
+    unsigned* X = reinterpret_cast<unsigned*>(X4);
     const int SH = SHT > 0 ? SHT : SH_rt;
     const int tid = threadIdx.x;
     const long long m0 = (long long)blockIdx.x * FIR_OUT;
     const long long e0 = m0 * D;
     const int nq = FIR_K * (FIR_NT + SH);                          // q values staged per phase
-    const int span = nq * D;
-    // sample e = q*D + p of the span goes to slot(p, q); (q, p) of this thread's samples e = tid, tid+NT, ... advance by a
-    // fixed step, so no division runs per sample.
-    // Loads are UNCONDITIONAL (clamped indices, values masked afterwards): a load inside a divergent branch gets its own
-    // s_waitcnt vmcnt(0), which turns "eight loads in flight" into eight round trips — and with one wave per SIMD
-    // nothing else hides them (that was most of this kernel's time).
-    const int nvec = (span + 3) >> 2;
+    const int span = nq * D;                                       // a multiple of 4
+    // sample e = q*D + p of the span goes to slot(p, q) = p*PSQ + q: along e the slot advances by PSQ, and by 1 - (D-1)*PSQ
+    // where p wraps — no division and no multiplication per sample.
+    // Loads are UNCONDITIONAL (clamped indices): a load inside a divergent branch gets its own s_waitcnt vmcnt(0), which
+    // turns "eight loads in flight" into eight round trips.
+    const int nvec = span >> 2;
+    const int wrap = D * PSQ - 1;
     if (nch == 1 && ((reinterpret_cast<unsigned long long>(x + e0) & 15ull) == 0) && e0 + 4ll * nvec <= nin) {
         // interior workgroup, one channel, aligned: 16-B loads, four samples per lane
         const int4* xv = reinterpret_cast<const int4*>(x + e0);
@@ -311,11 +314,14 @@ __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ 
             for (int u = 0; u < 8; ++u) {
                 const int j = jb + u * FIR_NT + tid;
                 const int w4[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
-                int qq = q, pp = p;
+                int slot = p * PSQ + q, pp = p;
+                if (j < nvec) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (4 * j + i < span) X[pp * PS + (qq & 3) * QS + (qq >> 2)] = (unsigned)w4[i];
-                    if (++pp >= D) { pp = 0; ++qq; }
+                    for (int i = 0; i < 4; ++i) {
+                        X[slot] = (unsigned)w4[i];
+                        slot += PSQ;
+                        if (++pp >= D) { pp = 0; slot -= wrap; }
+                    }
                 }
                 q += dq4; p += dp4;
                 if (p >= D) { p -= D; ++q; }
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ 
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = eb + u * FIR_NT + tid;
-                if (e < span) X[p * PS + (q & 3) * QS + (q >> 2)] = raw[u];
+                if (e < span) X[p * PSQ + q] = raw[u];
                 q += dq; p += dp;
                 if (p >= D) { p -= D; ++q; }
             }
@@ -351,8 +357,9 @@ __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ 
     pk2 acc[FIR_K];
 #pragma unroll
     for (int k = 0; k < FIR_K; ++k) acc[k] = pk2{0.f, 0.f};
+    auto cvt = [](unsigned w) { return pk2{(float)(short)(w & 0xffffu), (float)(short)(w >> 16)}; };
     for (int p = 0; p < D; ++p) {
-        const unsigned* Xp = X + p * PS + tid;
+        const uint4* Xp = X4 + ((p * PSQ) >> 2) + tid;             // PSQ is a multiple of 4
         const float* h = hp + p * HROW;
         if constexpr (SHT > 0) {
             float t[4 * SHT + 4];
@@ -360,32 +367,35 @@ __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ 
             for (int j = 0; j < 4 * SHT + 4; ++j) t[j] = h[j];     // wave-uniform: scalar loads, once per phase
 #pragma unroll
             for (int sh = 0; sh < SHT; ++sh) {
-                pk2 v[4];
+                const uint4 w = Xp[sh];
+                const unsigned wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-                for (int sl = 0; sl < 4; ++sl) { const unsigned w = Xp[sl * QS + sh]; v[sl] = pk2{(float)(short)(w & 0xffffu), (float)(short)(w >> 16)}; }
-#pragma unroll
-                for (int sl = 0; sl < 4; ++sl)
+                for (int sl = 0; sl < 4; ++sl) {
+                    if (sh == SHT - 1 && sl >= lastn) break;        // only padding from here on (uniform)
+                    const pk2 v = cvt(wv[sl]);
 #pragma unroll
                     for (int k = 0; k < FIR_K; ++k) {              // step s = 4sh+sl feeds output k with tap a = s-k (table index a+3)
                         const float tv = t[4 * sh + sl - k + 3];
-                        acc[k] = __builtin_elementwise_fma(v[sl], pk2{tv, tv}, acc[k]);
+                        acc[k] = __builtin_elementwise_fma(v, pk2{tv, tv}, acc[k]);
                     }
+                }
             }
         } else {
             for (int sh = 0; sh < SH; ++sh) {
                 float t[7];
 #pragma unroll
                 for (int j = 0; j < 7; ++j) t[j] = h[4 * sh + j];
-                pk2 v[4];
+                const uint4 w = Xp[sh];
+                const unsigned wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-                for (int sl = 0; sl < 4; ++sl) { const unsigned w = Xp[sl * QS + sh]; v[sl] = pk2{(float)(short)(w & 0xffffu), (float)(short)(w >> 16)}; }
-#pragma unroll
-                for (int sl = 0; sl < 4; ++sl)
+                for (int sl = 0; sl < 4; ++sl) {
+                    const pk2 v = cvt(wv[sl]);
 #pragma unroll
                     for (int k = 0; k < FIR_K; ++k) {
                         const float tv = t[sl - k + 3];
-                        acc[k] = __builtin_elementwise_fma(v[sl], pk2{tv, tv}, acc[k]);
+                        acc[k] = __builtin_elementwise_fma(v, pk2{tv, tv}, acc[k]);
                     }
+                }
             }
         }
     }
@@ -436,7 +446,7 @@ int launch_fir(hipStream_t st, const short2* dx, int nch, long long nin, const f
         attr_set = true;
     }
     const unsigned grid = (unsigned)((nout + FIR_OUT - 1) / FIR_OUT);
-#define FIR_GO(SHT_) hipLaunchKernelGGL((k_fir_poly<SHT_>), dim3(grid), dim3(FIR_NT), g.lds, st, dx, nch, nin, hp_dev, dec, g.SH, g.QS, g.PS, g.HROW, nout, dy16, dyf)
+#define FIR_GO(SHT_) hipLaunchKernelGGL((k_fir_poly<SHT_>), dim3(grid), dim3(FIR_NT), g.lds, st, dx, nch, nin, hp_dev, dec, g.SH, g.PSQ, g.HROW, g.LASTN, nout, dy16, dyf)
     switch (g.SH) {                                       // unrolled instantiations for the usual tap counts, generic loop otherwise
         case 4: FIR_GO(4); break;   case 5: FIR_GO(5); break;   case 6: FIR_GO(6); break;   case 7: FIR_GO(7); break;
         case 8: FIR_GO(8); break;   case 9: FIR_GO(9); break;   case 10: FIR_GO(10); break; case 11: FIR_GO(11); break;
