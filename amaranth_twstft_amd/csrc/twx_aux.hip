@@ -375,6 +375,7 @@ __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ 
                     const pk2 v = cvt(wv[sl]);
 #pragma unroll
                     for (int k = 0; k < FIR_K; ++k) {              // step s = 4sh+sl feeds output k with tap a = s-k (table index a+3)
+                        if (4 * sh + sl - k < 0) continue;         // the table's leading zeros (compile-time: six FMAs per phase)
                         const float tv = t[4 * sh + sl - k + 3];
                         acc[k] = __builtin_elementwise_fma(v, pk2{tv, tv}, acc[k]);
                     }
