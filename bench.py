@@ -136,6 +136,52 @@ def run_cpu_baseline(n_win: int, workload: str, max_workers: int):
     return {"error": (r.stdout[-500:] + r.stderr[-1500:])}
 
 
+def measure_pmc_traffic(kernel_short: str):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured by THIS invocation: two child runs of a
+    one-step, 8-window bench under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace domains),
+    read = 2 x FETCH_SIZE (the gfx950 correction of MI355X_MICROARCH.md, section HBM), write = WRITE_SIZE; counters in KiB.
+    Runs before this process touches the GPU.  Returns (bytes or None, note)."""
+    import csv, glob, shutil, tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ):
+        return None, "this run is itself under a profiler"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from summarize_prof import short
+    except Exception as e:  # pragma: no cover
+        return None, "tools/summarize_prof.py: %r" % (e,)
+    tmp = tempfile.mkdtemp(prefix="twx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--windows", "8", "--no-cpu-baseline", "--no-roofline",
+                   "--no-caf"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+            files = glob.glob(os.path.join(tmp, counter, "**", "*_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %s): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-300:])
+            best = 0.0
+            for path in files:
+                for row in csv.DictReader(open(path)):
+                    if row["Counter_Name"] == counter and short(row["Kernel_Name"]).startswith(kernel_short):
+                        best = max(best, float(row["Counter_Value"]))            # per launch: the full 8-window batch
+            if best <= 0:
+                return None, "no %s rows for %s" % (counter, kernel_short)
+            vals[counter] = best
+    except Exception as e:
+        return None, repr(e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    byts = int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)
+    return byts, ("measured by this invocation: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate child runs "
+                  "(1 step, 8 windows = one launch of the kernel); read = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE: "
+                  "%d + %d bytes" % (int(2 * vals["FETCH_SIZE"] * 1024), int(vals["WRITE_SIZE"] * 1024)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +196,8 @@ def main():
     ap.add_argument("--cpu-max-workers", type=int, default=64)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes (roofline.traffic then comes "
+                    "from the committed profiles/pmc_traffic.json)")
     ap.add_argument("--no-caf", action="store_true", help="skip the BASELINE.json configs[2] leg (delay x Doppler CAF of one window)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                     "multi-rank path on a box with fewer GPUs than ranks)")
@@ -173,6 +221,10 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = run_cpu_baseline(a.cpu_windows, a.workload, a.cpu_max_workers)      # before the first GPU call
+    pmc_live = None
+    if rank == 0 and world == 1 and not a.no_roofline and not a.no_pmc and a.workload == "processing":
+        t_p = time.perf_counter()
+        pmc_live = measure_pmc_traffic("k_row_mid") + (round(time.perf_counter() - t_p, 1),)       # child processes, before the first GPU call
 
     import numpy as np
     import torch
@@ -342,7 +394,12 @@ def main():
         out["chain_GBs_algorithmic"] = round(tot / spl * value * 1e6 / 1e9 / world, 1)
         pc.close()
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if pmc_live and pmc_live[0] and dom == "k_row_mid":
+            out["roofline"]["traffic"] = pmc_live[0]
+            out["roofline"]["traffic_source"] = pmc_live[1] + " (%.0f s)" % pmc_live[2]
+        elif os.path.exists(pmc):
+            if pmc_live:
+                out["roofline"]["traffic_live_error"] = pmc_live[1]
             try:
                 t = json.load(open(pmc))
                 if t.get("kernel") == dom:

@@ -306,13 +306,32 @@ def test_bench_two_ranks_over_real_rccl():
     assert c["records"] == 48 and c["ranks_with_exact_lags"] == 2 and c["gathered_lag_exact"] and c["all_ranks_agree"]
 
 
+def test_bench_measures_the_pmc_traffic_itself():
+    """roofline.traffic of the driver-style line is measured by the invocation (two rocprofv3 --pmc child passes before the first
+    GPU call), not read from a committed file; it equals the dominant kernel's algorithmic bytes to 2 % (no wasted re-reads)."""
+    import shutil
+    if not shutil.which("rocprofv3"):
+        pytest.skip("rocprofv3 not on PATH")
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in list(env):
+        if k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")):
+            env.pop(k)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--windows", "24",
+                          "--no-cpu-baseline", "--no-caf"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    r = j["roofline"]
+    assert r["traffic_source"].startswith("measured by this invocation"), r
+    assert abs(r["traffic"] / r["algorithmic_bytes_per_launch"] - 1.0) < 0.02, r
+
+
 def test_bench_rccl_calls_with_a_world_of_one():
     """The N > 1 path of bench.py talks to RCCL (backend "nccl"): process group bound to the device, all_gather_into_tensor of
     the uint8 result records, all_reduce(MAX) of the step time, barrier.  Two ranks cannot share one GPU under RCCL, so the
     calls themselves run here with one rank (--force-dist); the two-rank logic runs above on gloo."""
     env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--windows", "9",
-                          "--force-dist", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+                          "--force-dist", "--no-cpu-baseline", "--no-pmc"], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 1 and j["integer_lag_exact"] and j["value"] > 0

@@ -6,7 +6,7 @@ i=0
 for envs in "$@"; do
   i=$((i+1))
   echo "=== variant $i: $envs" | tee -a $out/ab.txt
-  env $envs python bench.py --steps 10 --warmup 2 --windows 192 --no-cpu-baseline > $out/bench_$i.json 2> $out/bench_$i.err
+  env $envs python bench.py --steps 10 --warmup 2 --windows 192 --no-cpu-baseline --no-pmc > $out/bench_$i.json 2> $out/bench_$i.err
   python - "$out/bench_$i.json" <<'PY' | tee -a $out/ab.txt
 import json,sys
 try:

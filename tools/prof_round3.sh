@@ -6,9 +6,9 @@ O=gpurun_out/r03p
 rm -rf $O; mkdir -p $O
 timeout 600 python -m pytest tests -m gpu -q -x -k "sliding or fir or aux_kernels or tracking" > $O/pytest_aux.log 2>&1; echo "rc $?" >> $O/pytest_aux.log
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
-TWX_STREAMS=1 python3 bench.py --steps 5 --warmup 2 --windows 192 --no-cpu-baseline --no-caf > $O/bench_1slot.json 2>/dev/null
-TWX_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_1slot -- python3 bench.py --steps 5 --warmup 2 --windows 192 --no-cpu-baseline --no-caf > $O/stats_1slot.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_3slot -- python3 bench.py --steps 5 --warmup 2 --windows 192 --no-cpu-baseline --no-caf > $O/stats_3slot.log 2>&1
+TWX_STREAMS=1 python3 bench.py --steps 5 --warmup 2 --windows 192 --no-cpu-baseline --no-caf --no-pmc > $O/bench_1slot.json 2>/dev/null
+TWX_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_1slot -- python3 bench.py --steps 5 --warmup 2 --windows 192 --no-cpu-baseline --no-caf --no-pmc > $O/stats_1slot.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_3slot -- python3 bench.py --steps 5 --warmup 2 --windows 192 --no-cpu-baseline --no-caf --no-pmc > $O/stats_3slot.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --windows 8 --no-cpu-baseline --no-roofline > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 1 --warmup 0 --windows 8 --no-cpu-baseline --no-roofline > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU --output-format csv -d $O/pmc_sq_a -- python3 bench.py --steps 1 --warmup 0 --windows 8 --no-cpu-baseline --no-roofline > $O/pmc_sq_a.log 2>&1
