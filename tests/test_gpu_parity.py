@@ -226,7 +226,9 @@ def test_batched_device_api_linearity_and_determinism():
     assert np.array_equal(iq[1, :4096].cpu().numpy(), ref)
     band = L.twx_band(*band_godual(FS, n))
     outs = []
-    for batch in (1, 4, 0):
+    # 1: 625 rows per launch (one per workgroup of the row pass); 3: 1875 rows on 1280 row-walking workgroups (one or two rows
+    # each); 4: 2500; 0: the default batch
+    for batch in (1, 3, 4, 0):
         with Correlator(chips, fs=FS, Nint=1, max_batch=batch) as cor:
             res = torch.zeros((nwin, C.sizeof(L.twx_result)), dtype=torch.uint8, device=dev)
             for _ in range(2):
