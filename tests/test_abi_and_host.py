@@ -281,6 +281,31 @@ def test_hot_kernels_compile_without_register_spills(tmp_path):
     assert seen >= 3
 
 
+@pytest.mark.slow
+def test_row_walking_kernel_fits_two_workgroups_per_cu(tmp_path):
+    """k_rowd<MID> in fp32 walks the rows with the next row loaded ahead: it must stay inside 128 VGPRs WITHOUT spills (a spill
+    puts scratch traffic into the in-order memory counter its waits rely on) and inside half a CU's LDS (two resident workgroups)."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "r8000.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--offload-device-only",
+                    os.path.join(root, "amaranth_twstft_amd", "csrc", "twx_inst_row.hip"), "-DTWX_PLAN=Plan<8000,20,20,20>", "-DTWX_NT=448",
+                    "-DTWX_PADQ=20", "-DTWX_NO_F64", "-o", str(out)], check=True, capture_output=True)
+    txt = out.read_text()
+    seen = 0
+    for blk in txt.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if "k_rowdINS_4PlanILi8000" in name and "EEEfLi2ELi448" in name:        # float, MODE = ROW_MID
+            seen += 1
+            vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+            spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
+            lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk).group(1))
+            scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+            assert vgpr <= 128 and spill == 0 and scratch == 0 and lds <= 80 * 1024, (name, vgpr, spill, scratch, lds)
+    assert seen == 1
+
+
 def test_bluestein_length_search_is_fp64_aware_and_bounded():
     """cpp_twin._smooth_len: the context is opened in fp64, so only fp64-capable pairs count; lengths beyond every plan pair fail
     at once (a 10-minute capture used to spin for minutes in a pure-Python search before raising)."""
