@@ -160,7 +160,7 @@ def measure_pmc_traffic(kernel_short: str):
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--windows", "8", "--no-cpu-baseline", "--no-roofline",
                    "--no-caf"]
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
             files = glob.glob(os.path.join(tmp, counter, "**", "*_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, "rocprofv3 --pmc %s failed (rc %s): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-300:])
