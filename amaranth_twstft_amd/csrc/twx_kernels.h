@@ -104,7 +104,7 @@ __device__ __forceinline__ float tmax(float a, float b) { return __builtin_fmaxf
 __device__ __forceinline__ double tmax(double a, double b) { return __builtin_fmax(a, b); }
 // block-wide arg-max; result valid in thread 0. scratch: >= 2*nwaves words of T/uint
 template <typename T, int NT> __device__ __forceinline__ Best<T> block_best(Best<T> b, void* scratch) {
-    constexpr int NW = NT / 64;
+    constexpr int NW = (NT + 63) / 64;                   // a partial last wave counts
     T* sv = reinterpret_cast<T*>(scratch);
     unsigned int* si = reinterpret_cast<unsigned int*>(sv + NW);
     b = wave_best(b);
