@@ -457,6 +457,36 @@ def test_fir_decimating_front_end():
     assert np.abs(y16[:, 0] - np.rint(ref.real)).max() <= 1 and np.abs(y16[:, 1] - np.rint(ref.imag)).max() <= 1
 
 
+@pytest.mark.parametrize("ntaps,dec,nch,ch", [
+    (421, 14, 1, 0),      # configs[4]: 31 taps per phase, 9 step groups, two live steps in the last group
+    (577, 14, 1, 0),      # the longer design of the SURVEY (42 taps per phase)
+    (64, 16, 1, 0),       # 4 taps per phase: fewer step groups than the smallest unrolled kernel
+    (33, 3, 1, 0),        # 11 taps per phase, three live steps in the last group
+    (100, 5, 1, 0),       # 20 taps per phase, a full last group
+    (97, 4, 1, 0),        # 25 taps per phase, one live step in the last group
+    (330, 5, 1, 0),       # 66 taps per phase: the generic (not unrolled) kernel
+    (421, 14, 2, 1),      # second channel of a two-channel capture: the 4-byte staging path
+    (57, 7, 2, 0),
+])
+def test_fir_decimator_shapes(ntaps, dec, nch, ch):
+    """Every step-group count of k_fir_poly (unrolled 4..16, the generic loop), every count of live steps in the last group, both
+    staging paths (16-byte loads of one aligned channel, 4-byte loads of a channel of two) and a ragged last workgroup, against
+    the fp64 direct sum (orc.fir_decimate, the oracle's definition; unpinned by nature: the reference has no such filter)."""
+    from amaranth_twstft_amd import frontend
+    rng = np.random.default_rng(1000 * ntaps + dec)
+    taps = (rng.normal(0, 1, ntaps) * np.hamming(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n_in = 14 * 2048 + 3 * ntaps + 11                                   # several workgroups and a ragged tail
+    raw = np.clip(rng.normal(0, 4000, (n_in, 2 * nch)), -32768, 32767).astype(np.int16)
+    y = frontend.fir_decimate(raw, taps, dec, n_channels=nch, channel=ch, out="f32")
+    x = raw[:, 2 * ch].astype(np.float64) + 1j * raw[:, 2 * ch + 1]
+    ref = orc.fir_decimate(x, taps.astype(np.float64), dec)
+    assert y.shape == ref.shape and y.shape[0] == (n_in - ntaps) // dec + 1
+    assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-3
+    y16 = frontend.fir_decimate(raw, taps, dec, n_channels=nch, channel=ch, out="int16")
+    assert np.abs(y16[:, 0] - np.clip(np.rint(ref.real), -32768, 32767)).max() <= 1
+    assert np.abs(y16[:, 1] - np.clip(np.rint(ref.imag), -32768, 32767)).max() <= 1
+
+
 def test_wideband_chain_70msps():
     """configs[4] in miniature: chips held 28 samples at 70 Msps → FIR ↓14 → standard chain at 5 Msps;
     the lag found equals the lag the oracle finds on the same decimated int16 samples, fp32 vs fp64
