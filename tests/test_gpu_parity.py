@@ -438,6 +438,34 @@ def test_sliding_dot_short_code():
     assert (lag == delay).all() and np.all(np.abs(hrc - delay) < 0.5)
 
 
+@pytest.mark.parametrize("nobs,ncodes,nlag,nch,ch,pt", [
+    (20000, 5, 28, 1, 0, 0),          # one chunk per workgroup, a ragged last pass
+    (400000, 3, 28, 1, 0, 3),         # sdr.param size: chunks of several LDS pieces, odd start
+    (40001, 2, 31, 1, 0, 1),          # odd period: the replica segment wraps at an odd index
+    (17000, 4, 16, 2, 1, 5),          # second channel of a two-channel capture
+    (9000, 7, 8, 1, 0, 0),
+    (5000, 3, 4, 1, 0, 2),
+    (700, 2, 28, 1, 0, 0),            # a period shorter than one pass of the workgroup
+])
+def test_sliding_dot_shapes(nobs, ncodes, nlag, nch, ch, pt):
+    """k_sliding_dot over its lag-count instantiations (4, 8, 16, 28, 31), chunk / piece / pass boundaries, odd periods (the wrap
+    of the replica segment), a channel of two and a start offset, against the definition in fp64 (out[p][l] = scale/nobs *
+    sum_i x[pt + p nobs + i] e^{-2 pi j (ff (p nobs + i) + phi)} w[(i - lag) mod nobs], = downconv_trk + the replica dgemm of
+    rxcomplex.cpp:605,1051-1061)."""
+    from amaranth_twstft_amd import tracking
+    rng = np.random.default_rng(nobs + 7 * nlag)
+    w = rng.choice([-1.0, 1.0], nobs).astype(np.float32)
+    raw = np.clip(rng.normal(0, 3000, (pt + nobs * ncodes + 8, 2 * nch)), -32768, 32767).astype(np.int16)
+    ff, phi, scale = 3.1e-5, 0.37, 1.0 / 32768.0
+    got = tracking.sliding_dot(raw, w, nobs, ncodes, nlag, pt=pt, ff=ff, phi=phi, scale=scale, n_channels=nch, channel=ch)
+    x = raw[:, 2 * ch].astype(np.float64) + 1j * raw[:, 2 * ch + 1]
+    for p in range(ncodes):
+        i = np.arange(p * nobs, (p + 1) * nobs)
+        y = scale * x[pt + i] * np.exp(-2j * np.pi * (ff * i + phi))
+        ref = orc.sliding_dot(y, w.astype(np.float64), nlag)
+        assert np.abs(got[p] - ref).max() <= 3e-6 * np.abs(ref).max() + 1e-9, (p, np.abs(got[p] - ref).max(), np.abs(ref).max())
+
+
 def test_fir_decimating_front_end():
     """70 Msps → 5 Msps front end (configs[4]); oracle = fp64 direct convolution (unpinned)."""
     from amaranth_twstft_amd import frontend
