@@ -68,8 +68,10 @@ __global__ __launch_bounds__(SD_NT, 2) void k_sliding_dot(const short2* __restri
     // of the piece in flight at once: fetched through registers one or eight at a time, the 64-KB segment cost 8 of a full
     // piece's 40 microseconds
     {
-        long long k = s0 - NLAG; if (k < 0) k += nobs;             // 0 <= s0 < nobs and NLAG < nobs: no division
-        k += tid; while (k >= nobs) k -= nobs;
+        long long k = s0 - NLAG;                                   // 0 <= s0 < nobs
+        if (k < 0) { k += nobs; if (k < 0) { k %= nobs; if (k < 0) k += nobs; } }      // the division only for periods shorter than the lag window
+        k += tid;
+        if (k >= nobs) { k -= nobs; if (k >= nobs) k %= nobs; }
         const long long step = SD_NT % nobs;
         const int nent = 4 * (ngrp + NQ);
         float* wave_base = sw + (tid & ~63);

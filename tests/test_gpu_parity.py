@@ -446,6 +446,8 @@ def test_sliding_dot_short_code():
     (9000, 7, 8, 1, 0, 0),
     (5000, 3, 4, 1, 0, 2),
     (700, 2, 28, 1, 0, 0),            # a period shorter than one pass of the workgroup
+    (10, 3, 28, 1, 0, 0),             # a period shorter than the lag window
+    (1, 2, 4, 1, 0, 0),
 ])
 def test_sliding_dot_shapes(nobs, ncodes, nlag, nch, ch, pt):
     """k_sliding_dot over its lag-count instantiations (4, 8, 16, 28, 31), chunk / piece / pass boundaries, odd periods (the wrap
