@@ -515,6 +515,10 @@ def test_fir_decimator_shapes(ntaps, dec, nch, ch):
     y16 = frontend.fir_decimate(raw, taps, dec, n_channels=nch, channel=ch, out="int16")
     assert np.abs(y16[:, 0] - np.clip(np.rint(ref.real), -32768, 32767)).max() <= 1
     assert np.abs(y16[:, 1] - np.clip(np.rint(ref.imag), -32768, 32767)).max() <= 1
+    # the shortest inputs: one and two outputs
+    for extra in (0, dec):
+        ys = frontend.fir_decimate(raw[: ntaps + extra], taps, dec, n_channels=nch, channel=ch, out="f32")
+        assert ys.shape[0] == 1 + extra // dec and np.abs(ys - ref[: ys.shape[0]]).max() <= 2e-6 * np.abs(ref).max() + 1e-3
 
 
 def test_wideband_chain_70msps():
