@@ -24,7 +24,8 @@ TWX_CODE_BIPOLAR, TWX_CODE_UNIPOLAR = 0, 1
 TWX_PROF_MAX = 16
 TWX_TRK_RANGING, TWX_TRK_RE, TWX_TRK_LO = 0, 1, 2
 TWX_CARRIER_SEARCH_DF, TWX_CARRIER_CHUNK_BAND = 0, 1
-TWX_ABI_VERSION = 2
+TWX_ABI_VERSION = 3
+TWX_MULTI_NO_RCCL, TWX_MULTI_RCCL_ONE = 1, 2
 TWX_ACQ_IZAMAX = 1
 
 
@@ -101,6 +102,11 @@ class twx_track_result(C.Structure):
                 ("pk", C.c_double), ("cnt", C.c_int32), ("updated", C.c_int32)]
 
 
+class twx_multi_info(C.Structure):
+    _fields_ = [("n_contexts", C.c_int32), ("n_devices_distinct", C.c_int32), ("rccl", C.c_int32), ("rccl_version", C.c_int32),
+                ("records_gathered", C.c_int64), ("bytes_per_rank", C.c_int64), ("gather_ms", C.c_double)]
+
+
 class twx_prof_entry(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("ms_total", C.c_double), ("launches", C.c_int64), ("units", C.c_int64)]
 
@@ -153,6 +159,15 @@ SYMBOLS = {
     "twx_tracked_host": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.POINTER(twx_tracked_summary)]),
     "twx_tracked_fetch": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "twx_tracked_search_df": (C.c_int, [_VP, _VP, C.c_int64, C.POINTER(C.c_int64)]),
+    "twx_multi_create": (C.c_int, [C.POINTER(twx_config), _VP, C.c_int32, C.c_int32, C.POINTER(_VP)]),
+    "twx_multi_destroy": (None, [_VP]),
+    "twx_multi_last_error": (C.c_char_p, [_VP]),
+    "twx_multi_get_info": (C.c_int, [_VP, C.POINTER(twx_multi_info)]),
+    "twx_multi_context": (_VP, [_VP, C.c_int32]),
+    "twx_multi_process_file": (C.c_int, [_VP, C.c_char_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(twx_band), C.c_double, _VP, C.c_int64, C.POINTER(C.c_int64)]),
+    "twx_multi_process_windows": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
+    "twx_multi_process_windows_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
+    "twx_multi_fetch_gathered": (C.c_int, [_VP, C.c_int32, _VP, C.c_int64]),
     "twx_debug_stamps": (C.c_int, [_VP, _VP, C.c_longlong]),
     "twx_profile_reset": (C.c_int, [_VP]),
     "twx_profile_get": (C.c_int, [_VP, C.POINTER(twx_prof_entry), C.c_int32, C.POINTER(C.c_int32)]),

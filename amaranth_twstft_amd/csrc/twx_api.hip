@@ -482,6 +482,7 @@ template <typename T> struct Ctx : CtxBase {
     unsigned char* chips_dev = nullptr;
     // batch buffers
     WinSums* sums = nullptr; double* dfv = nullptr; long long* dfidx = nullptr;
+    SumPart* sum_parts = nullptr; unsigned* sum_tickets = nullptr;
     C *e1 = nullptr, *e2 = nullptr, *A = nullptr, *Bz = nullptr, *dc = nullptr;
     ArgPart<T>*part_band = nullptr, *part_peak = nullptr;
     twx_result* res_dev = nullptr;
@@ -491,6 +492,7 @@ template <typename T> struct Ctx : CtxBase {
         hipStream_t stream; WinSums* sums; double* dfv; long long* dfidx; C *e1, *e2, *A, *Bz, *dc;
         ArgPart<T>*part_band, *part_peak; twx_result* res_dev; double* fine_u; double* csum_part;
         short2* planar; WinSums* sums2;      // two-channel captures in all-channel mode: planar copies + both channels' sums (lazy)
+        SumPart* sum_parts; unsigned* sum_tickets;   // k_sums: [2][B][TWX_SUMS_MAXCHUNKS] partials, [B] tickets (zero between launches)
     };
     Slot slots[4] = {}; int nslots = 1;
     bool sums_ready = false;                 // run_batch_in: `sums` already holds this batch's statistics (k_sums_deint2)
@@ -501,6 +503,14 @@ template <typename T> struct Ctx : CtxBase {
         const Slot& q = slots[k];
         stream = q.stream; sums = q.sums; dfv = q.dfv; dfidx = q.dfidx; e1 = q.e1; e2 = q.e2; A = q.A; Bz = q.Bz; dc = q.dc;
         part_band = q.part_band; part_peak = q.part_peak; res_dev = q.res_dev; fine_u = q.fine_u; csum_part = q.csum_part;
+        sum_parts = q.sum_parts; sum_tickets = q.sum_tickets;
+    }
+    // k_sums grid: enough workgroups for the chip whatever the batch (8 per CU over the launch; 64 per window starved a
+    // one-window launch: 90 us for 20 MB, profiles/r03_aux_kernel_stats.md), at least 16 KB of samples each
+    int sums_chunks(int nb) const {
+        static const int per_cu = [] { const char* e = getenv("TWX_SUMS_WGS"); return e ? std::max(1, atoi(e)) : 8; }();
+        const long long want = ((long long)per_cu * ncu + nb - 1) / nb, cap = std::max<long long>(1, N / 4096);
+        return (int)std::max<long long>(1, std::min<long long>(std::min(want, cap), TWX_SUMS_MAXCHUNKS));
     }
     int pipeline_depth() const override { return nslots; }
     int sync_all() override {
@@ -783,6 +793,9 @@ template <typename T> struct Ctx : CtxBase {
             if (int rc = dalloc(&q.res_dev, (size_t)B * TWX_MAX_CHANNELS)) return rc;   // all-channel mode: B windows x channels
             if (fine_M) { if (int rc = dalloc(&q.fine_u, (size_t)B * fine_M)) return rc; }
             if (int rc = dalloc(&q.csum_part, (size_t)B * 64)) return rc;
+            if (int rc = dalloc(&q.sum_parts, (size_t)2 * B * TWX_SUMS_MAXCHUNKS)) return rc;
+            if (int rc = dalloc(&q.sum_tickets, (size_t)B)) return rc;
+            HIPCHK(hipMemsetAsync(q.sum_tickets, 0, sizeof(unsigned) * B, stream));
         }
         use_slot(0);
         {
@@ -833,8 +846,8 @@ template <typename T> struct Ctx : CtxBase {
 
     // one batch of nb windows starting at `in` (short2 units: window stride N*nch, channel offset applied)
     int run_batch(const short2* in, int nb, int nch, const twx_band* band, const double* df_host, twx_result* out_dev,
-                  C* zout /*optional full map, nb must be 1*/, bool same_window = false, int res_stride = 1) {
-        return run_batch_in(IN_I16, in, nullptr, nch, same_window ? 0 : (long long)N * nch, remove_mean, nb, band, df_host, out_dev, zout, res_stride);
+                  C* zout /*optional full map, nb must be 1*/, bool same_window = false, int res_stride = 1, double zscale = 0.0) {
+        return run_batch_in(IN_I16, in, nullptr, nch, same_window ? 0 : (long long)N * nch, remove_mean, nb, band, df_host, out_dev, zout, res_stride, zscale);
     }
     // Both channels of nb windows of a two-channel capture ([I1 Q1 I2 Q2] frames, 16-byte aligned) on the CURRENT slot: one
     // pass over the frames takes both channels' statistics and writes planar copies (k_sums_deint2), then the chain runs
@@ -849,12 +862,11 @@ template <typename T> struct Ctx : CtxBase {
             if (int rc = dalloc(&q.planar, (size_t)2 * B * N)) return rc;
             if (int rc = dalloc(&q.sums2, (size_t)2 * B)) return rc;
         }
-        HIPCHK(hipMemsetAsync(q.sums2, 0, sizeof(WinSums) * 2 * B, stream));
         {
             ProfScope ps(this, PC_SUMS, 2ll * nb * N);
-            const int chunks = (int)std::min<long long>(64, std::max<long long>(1, N / 16384));
+            const int chunks = sums_chunks(nb);
             TWX_LAUNCH((k_sums_deint2<0>), dim3(chunks, nb), dim3(256), stream, reinterpret_cast<const int4*>(frames), (long long)N, (long long)N,
-                       q.planar, q.planar + (size_t)B * N, q.sums2, q.sums2 + B);
+                       q.planar, q.planar + (size_t)B * N, q.sums2, q.sums2 + B, q.sum_parts, q.sum_parts + (size_t)B * TWX_SUMS_MAXCHUNKS, q.sum_tickets);
             HIPCHK(hipGetLastError());
         }
         int rc = TWX_OK;
@@ -892,21 +904,25 @@ template <typename T> struct Ctx : CtxBase {
     }
     // intype IN_I16: p0 = short2 samples, aux = channels per sample, wstride in short2;  IN_C64S: p0/p1 = real/imaginary
     // doubles, aux = element stride, wstride in doubles (the mean-removed complex `d` of processing(d,k), godual_ranging.m:12)
+    // zscale != 0 (with zout): MAP-ONLY call — the values of the map are written times zscale, no peak record is formed
+    // (k_peak skipped) and, without mean removal, no window statistics are taken (k_sums skipped): the x2 interpolation of
+    // short2double (rxcomplex.cpp:914-963) is such a call once per second and channel.
     int run_batch_in(int intype, const void* p0, const void* p1, int aux, long long wstride, int rm_mean, int nb, const twx_band* band,
-                     const double* df_host, twx_result* out_dev, C* zout, int res_stride) {
+                     const double* df_host, twx_result* out_dev, C* zout, int res_stride, double zscale = 0.0) {
+        const bool map_only = zout && zscale != 0.0;
         const short2* in = reinterpret_cast<const short2*>(p0);
         const int nch = aux;
         SplitPtr sp{reinterpret_cast<const double*>(p0), reinterpret_cast<const double*>(p1)};
         const void* colin = intype == IN_C64S ? static_cast<const void*>(&sp) : p0;
         if (intype == IN_I16 && sums_ready) {
             // statistics taken by the de-interleaving pre-pass (run_batch_2ch)
+        } else if (map_only && !rm_mean) {
+            // nothing reads the window statistics
         } else if (intype == IN_I16) {
-            HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums) * nb, stream));
             ProfScope ps(this, PC_SUMS, (long long)nb * N);
-            // few, fat chunks: the three 64-bit atomics per workgroup land on the same words of a window
-            const int chunks = (int)std::min<long long>(64, std::max<long long>(1, N / 16384));
+            const int chunks = sums_chunks(nb);
             for (int it = 0, ne = reps(PC_SUMS); it < ne; ++it)
-            TWX_LAUNCH((k_sums<0>), dim3(chunks, nb), dim3(256), stream, in, wstride, nch, N, sums);
+            TWX_LAUNCH((k_sums<0>), dim3(chunks, nb), dim3(256), stream, in, wstride, nch, N, sums, sum_parts, sum_tickets);
             HIPCHK(hipGetLastError());
         } else if (intype == IN_C32) {
             if (rm_mean) return fail(TWX_E_ARG, "complex input is taken as it is");
@@ -985,7 +1001,7 @@ template <typename T> struct Ctx : CtxBase {
             } else if (row->run(ROW_MID, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(mid) launch failed");
         }
         ColInvArgs<T> ia{};
-        ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = R; ia.nwin = nb; ia.Bz = Bz; ia.tw1 = tw1; ia.part = part_peak; ia.zout = zout; ia.norm1 = argmax_norm1;
+        ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = R; ia.nwin = nb; ia.Bz = Bz; ia.tw1 = tw1; ia.part = part_peak; ia.zout = zout; ia.norm1 = argmax_norm1; ia.zscale = (T)(map_only ? zscale : 1.0);
         {
             ProfScope ps(this, PC_COL_INV, (long long)nb * N);
             for (int it = 0, ne = reps(PC_COL_INV); it < ne; ++it)
@@ -995,7 +1011,7 @@ template <typename T> struct Ctx : CtxBase {
         pa.n = N; pa.n1 = N1; pa.n2 = N2; pa.nphase = R; pa.nparts = R * ntiles; pa.part = part_peak; pa.Bz = Bz; pa.tw1d = tw1d;
         pa.sums = sums; pa.remove_mean = rm_mean; pa.dc = dc; pa.dfv = dfv; pa.dfidx = dfidx; pa.inv_scale = 1.0 / scale_pow2;
         pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.convention = cfg.convention; pa.snr_valid = snr_valid; pa.res = out_dev; pa.res_stride = res_stride;
-        {
+        if (!map_only) {
             ProfScope ps(this, PC_PEAK, nb);
             for (int it = 0, ne = reps(PC_PEAK); it < ne; ++it)
             TWX_LAUNCH((k_peak<T>), dim3(nb), dim3(1024), stream, pa);
@@ -1385,11 +1401,8 @@ template <typename T> struct Ctx : CtxBase {
         if (int rc = sync_all()) return rc;
         use_slot(0);
         C* z = reinterpret_cast<C*>(out_dev);
-        if (int rc = run_batch(reinterpret_cast<const short2*>(iq_dev) + ch, 1, nch, nullptr, &df, res_dev, z)) return rc;
-        // ifft normalisation and the range scale undone in place (the product path never forms the whole map)
-        TWX_LAUNCH((k_convert<T, T>), dim3(1024), dim3(256), stream, (const C*)z, z, (long long)N * R, 1.0 / scale_pow2 / ((double)N * R));
-        HIPCHK(hipGetLastError());
-        return TWX_OK;
+        // ifft normalisation and the range scale are undone by the last pass as it writes the map (no separate pass)
+        return run_batch(reinterpret_cast<const short2*>(iq_dev) + ch, 1, nch, nullptr, &df, res_dev, z, false, 1, 1.0 / scale_pow2 / ((double)N * R));
     }
     int caf_freqs_cdev(const void* d_dev, const double* freqs, long long nf, int flags, twx_result* out) override {
         if (int rc = sync_all()) return rc;
@@ -1490,8 +1503,7 @@ template <typename T> struct Ctx : CtxBase {
         if (int rc = sc.get(&pk_d, (size_t)nbins)) return rc;       // every bin's record stays on the device until the end:
         if (int rc = sc.get(&lag_d, (size_t)nbins)) return rc;      // one D2H copy and one synchronisation per call
         const short2* in = reinterpret_cast<const short2*>(iq_dev) + ch;
-        HIPCHK(hipMemsetAsync(sums, 0, sizeof(WinSums), stream));
-        TWX_LAUNCH((k_sums<0>), dim3((unsigned)std::min<long long>(64, std::max<long long>(1, N / 16384)), 1), dim3(256), stream, in, 0ll, nch, N, sums);
+        TWX_LAUNCH((k_sums<0>), dim3((unsigned)sums_chunks(1), 1), dim3(256), stream, in, 0ll, nch, N, sums, sum_parts, sum_tickets);
         HIPCHK(hipGetLastError());
         ColFwdArgs<T> ca{};
         ca.in_win_stride = 0; ca.sums = sums; ca.remove_mean = 1; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = 1;
@@ -1509,14 +1521,19 @@ template <typename T> struct Ctx : CtxBase {
         const bool dform = cspec_perm && row->rowd && row->S == 3 && !caf_stockham;
         C* Yperm = nullptr; C* Bzc = Bz; ArgPart<T>* partc = part_peak;
         int nbpl = nbmax, bpw = 1;
+        // Two bin buffers on two streams: launch g+1's row pass (VALU / LDS bound) runs beside launch g's column pass (read
+        // bound), as the pipeline slots of the main chain do (TWX_CAF_SERIAL=1: one stream, profiles/r04_caf_overlap.txt)
+        static const bool caf_serial = [] { const char* e = getenv("TWX_CAF_SERIAL"); return e && atoi(e) != 0; }();
+        int nstr = 1;
         if (dform) {
             if (!(Yperm = static_cast<C*>(scratch_slot(3, (size_t)N * sizeof(C))))) return TWX_E_NOMEM;
             TWX_LAUNCH((k_cspec_perm<T>), dim3(N1), dim3(256), stream, Ysp, Yperm, N1, N2, row->R[0], row->R[2]);
             HIPCHK(hipGetLastError());
             const long long want = std::min<long long>(std::min<long long>(caf_bpl, nbins), std::max<long long>(1, (caf_maxmb << 20) / (N * (long long)sizeof(C))));
-            if (want > nbmax) {
-                if (!(Bzc = static_cast<C*>(scratch_slot(4, (size_t)N * want * sizeof(C))))) return TWX_E_NOMEM;
-                if (!(partc = static_cast<ArgPart<T>*>(scratch_slot(5, (size_t)ntiles * want * sizeof(ArgPart<T>))))) return TWX_E_NOMEM;
+            nstr = (nslots >= 2 && !caf_serial && nbins > want) ? 2 : 1;
+            if (want * nstr > nbmax) {
+                if (!(Bzc = static_cast<C*>(scratch_slot(4, (size_t)N * want * nstr * sizeof(C))))) return TWX_E_NOMEM;
+                if (!(partc = static_cast<ArgPart<T>*>(scratch_slot(5, (size_t)ntiles * want * nstr * sizeof(ArgPart<T>))))) return TWX_E_NOMEM;
             }
             nbpl = (int)want;                        // <= nbmax: the batch buffers of the chain serve as the bin buffer
             static const int bpw_env = [] { const char* e = getenv("TWX_CAF_BPW"); return e ? std::max(1, atoi(e)) : 32; }();
@@ -1525,8 +1542,17 @@ template <typename T> struct Ctx : CtxBase {
         // non-temporal bin-buffer stores only when the launch's bins cannot stay cached (TWX_CAF_NT=0/1 forces)
         static const int nt_env = [] { const char* e = getenv("TWX_CAF_NT"); return e ? atoi(e) : -1; }();
         const int nt = nt_env >= 0 ? nt_env : ((long long)nbpl * N * (long long)sizeof(C) > (192ll << 20) ? 1 : 0);
-        for (long long k0 = k_lo; k0 <= k_hi; k0 += nbpl) {
+        if (nstr > 1) {                                          // the second stream starts after Y / Yperm are complete
+            HIPCHK(hipEventRecord(ev_fork, slots[0].stream));
+            HIPCHK(hipStreamWaitEvent(slots[1].stream, ev_fork, 0));
+        }
+        C* const Bzc0 = Bzc; ArgPart<T>* const partc0 = partc;
+        long long grp = 0;
+        for (long long k0 = k_lo; k0 <= k_hi; k0 += nbpl, ++grp) {
             const int nb = (int)std::min<long long>(nbpl, k_hi - k0 + 1);
+            const int sidx = (int)(grp % nstr);
+            hipStream_t stream = slots[sidx].stream;              // shadows the context's current stream inside the loop
+            Bzc = Bzc0 + (size_t)sidx * nbpl * N; partc = partc0 + (size_t)sidx * nbpl * ntiles;
             CafArgs<T> fa{};
             fa.n = N; fa.n1 = N1; fa.nbins = nb; fa.kappa0 = k0; fa.Y = Ysp; fa.cspec = cspec; fa.stab_i = stab_i;
             fa.ta = ta; fa.tb = tb; fa.tshift = tshift; fa.scale = (T)scale_pow2; fa.Bz = Bzc;
@@ -1547,6 +1573,10 @@ template <typename T> struct Ctx : CtxBase {
                 TWX_LAUNCH((k_caf_reduce<T>), dim3(nb), dim3(256), stream, partc, ntiles, 1.0 / scale_pow2 / (double)N, pk_d + (k0 - k_lo), lag_d + (k0 - k_lo));
                 HIPCHK(hipGetLastError());
             }
+        }
+        if (nstr > 1) {
+            HIPCHK(hipEventRecord(ev_join[1], slots[1].stream));
+            HIPCHK(hipStreamWaitEvent(slots[0].stream, ev_join[1], 0));
         }
         HIPCHK(hipMemcpyAsync(pk, pk_d, sizeof(double) * (size_t)nbins, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(lag, lag_d, sizeof(long long) * (size_t)nbins, hipMemcpyDeviceToHost, stream));

@@ -64,6 +64,10 @@ struct WinSums {            // exact integer sums over the raw int16 window
     double fP;              // complex-double input (twx_process_complex): sum |d|^2 in fp64, valid when is_f != 0
     int is_f, pad;
 };
+// k_sums / k_sums_deint2: one partial per workgroup, reduced by the workgroup that arrives last (a ticket per window); no
+// atomics on the sums themselves and nothing to clear beforehand, so the grid can be sized for the chip whatever the batch
+struct SumPart { long long sI, sQ; unsigned long long sP; long long pad; };
+#define TWX_SUMS_MAXCHUNKS 1024
 template <typename T> struct ArgPart { T val; unsigned int idx; };
 template <> struct ArgPart<double> { double val; unsigned int idx; unsigned int pad; };
 
@@ -255,13 +259,80 @@ __global__ void k_sums_c64_final(const double* __restrict__ partial, int nparts,
     sums[b] = s;
 }
 
+// Block-wide finish of NC (channels) x {sum I, sum Q, sum I^2+Q^2}: every thread brings its own partial sums.  The block's
+// totals go to parts[c][blockIdx.x]; the block that draws the last ticket of its window adds up all the partials and
+// writes the window's WinSums (integer sums: the order of arrival cannot change the result).  Release / acquire at device
+// scope around the ticket (the eight XCDs have separate L2s: the partials are read with device-scope atomic loads).
+template <int NC>
+__device__ __forceinline__ void sums_finish(long long (&v)[NC][3], SumPart* const (&parts)[NC], unsigned* ticket, WinSums* const (&out)[NC]) {
+    __shared__ long long sh[NC * 3][4];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    auto block_sum = [&]() {                                   // totals valid in thread 0
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                for (int d = 32; d >= 1; d >>= 1) v[c][k] += shfl_down_ll(v[c][k], d);
+                if (lane == 0) sh[c * 3 + k][wv] = v[c][k];
+            }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v[c][k] = (sh[c * 3 + k][0] + sh[c * 3 + k][1]) + (sh[c * 3 + k][2] + sh[c * 3 + k][3]);
+        }
+    };
+    block_sum();
+    if (threadIdx.x == 0) {
+        int last = 1;
+        if (gridDim.x > 1) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                SumPart p; p.sI = v[c][0]; p.sQ = v[c][1]; p.sP = (unsigned long long)v[c][2]; p.pad = 0;
+                parts[c][blockIdx.x] = p;
+            }
+            __threadfence();
+            last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (gridDim.x > 1) {
+        __threadfence();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { v[c][0] = 0; v[c][1] = 0; v[c][2] = 0; }
+        for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                v[c][0] += __hip_atomic_load(&parts[c][i].sI, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[c][1] += __hip_atomic_load(&parts[c][i].sQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[c][2] += (long long)__hip_atomic_load(&parts[c][i].sP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();                                       // sh[] of the first block_sum has been read
+        block_sum();
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            WinSums s; s.sI = v[c][0]; s.sQ = v[c][1]; s.sP = (unsigned long long)v[c][2]; s.fP = 0.0; s.is_f = 0; s.pad = 0;
+            *out[c] = s;
+        }
+        if (gridDim.x > 1) *ticket = 0;                        // ready for the next launch on this stream
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_sums: exact integer statistics of a raw int16 window (mean removal godual_ranging.m:80,
 // power terms of :46).  grid = (chunks, windows)
 // ------------------------------------------------------------------------------------------
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void k_sums(const short2* __restrict__ in, long long win_stride /*short2 units*/,
-                                              int nch, long long n, WinSums* __restrict__ sums) {
+                                              int nch, long long n, WinSums* __restrict__ sums, SumPart* __restrict__ parts /*[windows][chunks]*/,
+                                              unsigned* __restrict__ tickets /*[windows], zero between launches*/) {
     const int b = blockIdx.y;
     const short2* p = in + (long long)b * win_stride;
     long long sI = 0, sQ = 0;
@@ -308,23 +379,10 @@ __global__ __launch_bounds__(256) void k_sums(const short2* __restrict__ in, lon
     } else {
         for (long long i = lo + threadIdx.x; i < hi; i += 256) acc(p[i * nch]);
     }
-    for (int d = 32; d >= 1; d >>= 1) {
-        sI += shfl_down_ll(sI, d);
-        sQ += shfl_down_ll(sQ, d);
-        sP += (unsigned long long)shfl_down_ll((long long)sP, d);
-    }
-    __shared__ long long sh[3][4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { sh[0][wv] = sI; sh[1][wv] = sQ; sh[2][wv] = (long long)sP; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        sI = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-        sQ = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
-        sP = (unsigned long long)(sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3]);
-        atomicAdd((unsigned long long*)&sums[b].sI, (unsigned long long)sI);
-        atomicAdd((unsigned long long*)&sums[b].sQ, (unsigned long long)sQ);
-        atomicAdd(&sums[b].sP, sP);
-    }
+    long long blk[1][3] = {{sI, sQ, (long long)sP}};
+    SumPart* pp[1] = {parts + (long long)b * gridDim.x};
+    WinSums* oo[1] = {sums + b};
+    sums_finish<1>(blk, pp, tickets + b, oo);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -337,7 +395,8 @@ __global__ __launch_bounds__(256) void k_sums(const short2* __restrict__ in, lon
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void k_sums_deint2(const int4* __restrict__ in /*two frames per element*/, long long win_stride /*frames*/,
                                                      long long n, short2* __restrict__ p0, short2* __restrict__ p1,
-                                                     WinSums* __restrict__ sums0, WinSums* __restrict__ sums1) {
+                                                     WinSums* __restrict__ sums0, WinSums* __restrict__ sums1,
+                                                     SumPart* __restrict__ parts0, SumPart* __restrict__ parts1, unsigned* __restrict__ tickets) {
     const int b = blockIdx.y;
     const int4* p = in + ((long long)b * win_stride >> 1);
     int2* o0 = reinterpret_cast<int2*>(p0 + (long long)b * n);
@@ -377,25 +436,10 @@ __global__ __launch_bounds__(256) void k_sums_deint2(const int4* __restrict__ in
         o1[k] = make_int2(q.y, q.w);
         sI[0] += aI[0]; sQ[0] += aQ[0]; sI[1] += aI[1]; sQ[1] += aQ[1];
     }
-    __shared__ long long sh[6][4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        for (int d = 32; d >= 1; d >>= 1) {
-            sI[c] += shfl_down_ll(sI[c], d);
-            sQ[c] += shfl_down_ll(sQ[c], d);
-            sP[c] += (unsigned long long)shfl_down_ll((long long)sP[c], d);
-        }
-        if (lane == 0) { sh[3 * c][wv] = sI[c]; sh[3 * c + 1][wv] = sQ[c]; sh[3 * c + 2][wv] = (long long)sP[c]; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        const int c = threadIdx.x;
-        WinSums* s = (c == 0 ? sums0 : sums1) + b;
-        atomicAdd((unsigned long long*)&s->sI, (unsigned long long)(sh[3 * c][0] + sh[3 * c][1] + sh[3 * c][2] + sh[3 * c][3]));
-        atomicAdd((unsigned long long*)&s->sQ, (unsigned long long)(sh[3 * c + 1][0] + sh[3 * c + 1][1] + sh[3 * c + 1][2] + sh[3 * c + 1][3]));
-        atomicAdd(&s->sP, (unsigned long long)(sh[3 * c + 2][0] + sh[3 * c + 2][1] + sh[3 * c + 2][2] + sh[3 * c + 2][3]));
-    }
+    long long blk[2][3] = {{sI[0], sQ[0], (long long)sP[0]}, {sI[1], sQ[1], (long long)sP[1]}};
+    SumPart* pp[2] = {parts0 + (long long)b * gridDim.x, parts1 + (long long)b * gridDim.x};
+    WinSums* oo[2] = {sums0 + b, sums1 + b};
+    sums_finish<2>(blk, pp, tickets + b, oo);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1744,6 +1788,7 @@ template <typename T> struct ColInvArgs {
     ArgPart<T>* part;        // [b][rho*ntiles + tile]
     cpx<T>* zout;            // optional full output [b][R*N] (natural interleaved order), or nullptr
     int norm1;               // arg-max of (|re|+|im|)^2 instead of |z|^2: cblas_izamax (rxcomplex.cpp:553) — selects the NORM1 instantiation
+    T zscale;                // factor on the values written to zout (the ifft normalisation of twx_xcorr_map_dev: no separate pass)
 };
 
 template <class P1R, typename T, int W, int NT, int NORM1 = 0>
@@ -1825,7 +1870,7 @@ __global__ __launch_bounds__(NT) void k_col_inv(ColInvArgs<T> a) {
                 TWX_UNROLL
                 for (int q = 0; q < R; ++q) {
                     const unsigned int m = (unsigned int)TL::template out_pos<s>(j, q) * mstep + mbase;
-                    a.zout[(long long)b * a.n * a.nphase + m] = v[q];
+                    a.zout[(long long)b * a.n * a.nphase + m] = cscale(v[q], a.zscale);
                 }
             }
         }
@@ -1924,7 +1969,7 @@ __global__ __launch_bounds__(NT, 6) void k_col_inv3(ColInvArgs<T> a) {
             TWX_UNROLL
             for (int q = 0; q < R1; ++q) {
                 const unsigned int m = (unsigned int)TL::template out_pos<1>(j, q) * mstep + mbase;
-                a.zout[(long long)b * a.n * a.nphase + m] = u[q];
+                a.zout[(long long)b * a.n * a.nphase + m] = cscale(u[q], a.zscale);
             }
         }
     }

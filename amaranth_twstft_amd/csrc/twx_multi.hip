@@ -1,0 +1,412 @@
+// twx_multi.hip — ONE host process, N devices: the multi-GPU driver behind the C ABI (twx_multi_* in include/twstft_hip.h).
+//
+// The reference's own shape for more than one correlation at a time is threads inside one process (one GoRanging worker per
+// channel with a reader hand-off, processing/CPP/main.cpp:180-187,488-497) and side-by-side jobs (acquisition/goprocess.sh:9-11).
+// Here: one correlator context and one persistent host thread per device; the windows of a capture are cut into contiguous
+// blocks (one contiguous file extent per device, sizes differing by at most one — the rule of amaranth_twstft_amd/dist.py),
+// every context runs twx_process_file / twx_process_windows[_dev] on its block, and the fixed-size result records are
+// exchanged with ONE ncclAllGather over xGMI (RCCL, communicators from ncclCommInitAll — the single-process form) issued
+// for all devices inside one ncclGroupStart/End.  A device list that names a device twice cannot form an RCCL communicator
+// (one rank per device): the blocks are then concatenated on the host, which is also what lets a one-GPU box test the
+// threading and the ordering.  RCCL is bound at run time (dlopen of librccl.so.1 on the first twx_multi_create that needs
+// it): a 570-MB library that no single-GPU MEX call should have to map.  No process is ever re-executed; threads only.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+#include "twx_internal.h"
+
+namespace {
+
+thread_local std::string g_multi_create_err;
+
+// ---- RCCL, bound at run time --------------------------------------------------------------------------------------
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    const char* (*GetLastError)(ncclComm_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    std::string err;
+    bool load() {
+        if (h) return true;
+        const char* names[] = {getenv("TWX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* nm : names) {
+            if (!nm || !*nm) continue;
+            h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+            err = dlerror();
+        }
+        if (!h) { err = "cannot load RCCL (librccl.so.1): " + err; return false; }
+        auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) err = std::string("RCCL symbol missing: ") + n; return p; };
+        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        AllGather = (decltype(AllGather))sym("ncclAllGather");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        GetLastError = (decltype(GetLastError))sym("ncclGetLastError");
+        GetVersion = (decltype(GetVersion))sym("ncclGetVersion");
+        if (!CommInitAll || !CommDestroy || !AllGather || !GroupStart || !GroupEnd || !GetErrorString) { dlclose(h); h = nullptr; return false; }
+        return true;
+    }
+};
+Rccl& rccl() { static Rccl r; return r; }
+std::mutex& rccl_mu() { static std::mutex m; return m; }
+
+// ---- one persistent host thread per context -----------------------------------------------------------------------
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = true, quit = false;
+    int rc = 0;
+    int dev = 0;
+    void start(int device) {
+        dev = device;
+        th = std::thread([this]() {
+            (void)hipSetDevice(dev);
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                cv.wait(lk, [this]() { return has_job || quit; });
+                if (quit) return;
+                std::function<int()> f = std::move(job);
+                has_job = false;
+                lk.unlock();
+                int r;
+                try { r = f(); } catch (const std::bad_alloc&) { r = TWX_E_NOMEM; } catch (...) { r = TWX_E_STATE; }
+                lk.lock();
+                rc = r; done = true;
+                cv.notify_all();
+            }
+        });
+    }
+    void submit(std::function<int()> f) {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(f); has_job = true; done = false;
+        cv.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this]() { return done; });
+        return rc;
+    }
+    void stop() {
+        if (!th.joinable()) return;
+        { std::lock_guard<std::mutex> lk(mu); quit = true; cv.notify_all(); }
+        th.join();
+    }
+};
+
+}  // namespace
+
+struct twx_multi {
+    int n = 0;
+    std::vector<int> devices;
+    std::vector<twx_ctx*> ctx;
+    std::vector<Worker*> workers;
+    bool distinct = true, use_rccl = false;
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> gstream;              // the gather's own stream on every device
+    std::vector<void*> send_dev, recv_dev; size_t cap_records = 0;      // per device: one block / all blocks of the gather
+    std::vector<std::vector<twx_result>> local;    // per context: the records of its block (host paths)
+    std::string err;
+    twx_multi_info info{};
+    twx_info cinfo{};
+
+    int fail(int code, const std::string& m) { err = m; return code; }
+    int nccl_fail(ncclResult_t r, const char* what, ncclComm_t c) {
+        Rccl& R = rccl();
+        std::string m = std::string(what) + " failed: " + (R.GetErrorString ? R.GetErrorString(r) : "?");
+        if (R.GetLastError && c) { const char* le = R.GetLastError(c); if (le && *le) m += std::string(" — ") + le; }
+        return fail(TWX_E_HIP, m);
+    }
+    ~twx_multi() {
+        for (auto w : workers) if (w) { w->stop(); delete w; }
+        if (use_rccl) for (int r = 0; r < (int)comms.size(); ++r) if (comms[r]) { (void)hipSetDevice(devices[r]); (void)rccl().CommDestroy(comms[r]); }
+        for (int r = 0; r < n; ++r) {
+            (void)hipSetDevice(devices[r]);
+            if (r < (int)send_dev.size() && send_dev[r]) (void)hipFree(send_dev[r]);
+            if (r < (int)recv_dev.size() && recv_dev[r]) (void)hipFree(recv_dev[r]);
+            if (r < (int)gstream.size() && gstream[r]) (void)hipStreamDestroy(gstream[r]);
+            if (r < (int)ctx.size() && ctx[r]) twx_destroy(ctx[r]);
+        }
+    }
+    // every context runs f(rank) on its own thread; first failure wins (its context's message is kept)
+    int run_all(const std::function<int(int)>& f) {
+        for (int r = 0; r < n; ++r) workers[r]->submit([&f, r]() { return f(r); });
+        int rc = TWX_OK;
+        for (int r = 0; r < n; ++r) {
+            const int rr = workers[r]->wait();
+            if (rr && !rc) {
+                rc = rr;
+                const char* m = twx_last_error(ctx[r]);
+                err = "context " + std::to_string(r) + " (device " + std::to_string(devices[r]) + "): " + (m && *m ? m : twx_strerror(rr));
+            }
+        }
+        return rc;
+    }
+    static void shard(long long total, int r, int world, long long* start, long long* count) {      // dist.shard_windows
+        const long long base = total / world, rem = total % world;
+        *start = r * base + std::min<long long>(r, rem);
+        *count = base + (r < rem ? 1 : 0);
+    }
+    int ensure_gather(size_t records) {
+        if (records <= cap_records) return TWX_OK;
+        const size_t cap = records + records / 4 + 16;
+        for (int r = 0; r < n; ++r) {
+            if (hipSetDevice(devices[r]) != hipSuccess) return fail(TWX_E_HIP, "hipSetDevice failed");
+            if (send_dev[r]) { (void)hipFree(send_dev[r]); send_dev[r] = nullptr; }
+            if (recv_dev[r]) { (void)hipFree(recv_dev[r]); recv_dev[r] = nullptr; }
+            if (hipMalloc(&send_dev[r], cap * sizeof(twx_result)) != hipSuccess || hipMalloc(&recv_dev[r], cap * sizeof(twx_result) * n) != hipSuccess)
+                return fail(TWX_E_NOMEM, "gather buffer allocation failed");
+        }
+        cap_records = cap;
+        return TWX_OK;
+    }
+    // send_dev[r] holds `block` records on every device -> recv_dev[r] holds n*block on every device (one collective)
+    int all_gather(size_t block) {
+        Rccl& R = rccl();
+        const auto t0 = std::chrono::steady_clock::now();
+        ncclResult_t g = R.GroupStart();
+        if (g != ncclSuccess) return nccl_fail(g, "ncclGroupStart", nullptr);
+        for (int r = 0; r < n; ++r) {
+            (void)hipSetDevice(devices[r]);
+            ncclResult_t e = R.AllGather(send_dev[r], recv_dev[r], block * sizeof(twx_result), ncclChar, comms[r], gstream[r]);
+            if (e != ncclSuccess) { (void)R.GroupEnd(); return nccl_fail(e, "ncclAllGather", comms[r]); }
+        }
+        g = R.GroupEnd();
+        if (g != ncclSuccess) return nccl_fail(g, "ncclGroupEnd", comms[0]);
+        for (int r = 0; r < n; ++r) {
+            (void)hipSetDevice(devices[r]);
+            if (hipStreamSynchronize(gstream[r]) != hipSuccess) return fail(TWX_E_HIP, "gather stream synchronize failed");
+        }
+        info.gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        info.records_gathered = (int64_t)(block * n); info.bytes_per_rank = (int64_t)(block * sizeof(twx_result));
+        return TWX_OK;
+    }
+    // the blocks local[r][0 .. counts[r]*per) -> out (blocks in rank order, no padding); through the devices when RCCL is on
+    int gather_host_blocks(const std::vector<long long>& counts, int per, twx_result* out) {
+        long long mx = 0;
+        for (long long c : counts) mx = std::max(mx, c);
+        const size_t block = (size_t)mx * per;
+        if (use_rccl && block > 0) {
+            if (int rc = ensure_gather(block)) return rc;
+            for (int r = 0; r < n; ++r) {
+                (void)hipSetDevice(devices[r]);
+                if (hipMemsetAsync(send_dev[r], 0, block * sizeof(twx_result), gstream[r]) != hipSuccess ||
+                    hipMemcpyAsync(send_dev[r], local[r].data(), (size_t)counts[r] * per * sizeof(twx_result), hipMemcpyHostToDevice, gstream[r]) != hipSuccess)
+                    return fail(TWX_E_HIP, "record upload failed");
+            }
+            if (int rc = all_gather(block)) return rc;
+            std::vector<twx_result> all(block * n);
+            (void)hipSetDevice(devices[0]);
+            if (hipMemcpy(all.data(), recv_dev[0], all.size() * sizeof(twx_result), hipMemcpyDeviceToHost) != hipSuccess) return fail(TWX_E_HIP, "gathered records D2H failed");
+            size_t o = 0;
+            for (int r = 0; r < n; ++r) { memcpy(out + o, all.data() + (size_t)r * block, (size_t)counts[r] * per * sizeof(twx_result)); o += (size_t)counts[r] * per; }
+        } else {
+            size_t o = 0;
+            for (int r = 0; r < n; ++r) { memcpy(out + o, local[r].data(), (size_t)counts[r] * per * sizeof(twx_result)); o += (size_t)counts[r] * per; }
+            info.gather_ms = 0; info.records_gathered = (int64_t)o; info.bytes_per_rank = (int64_t)(block * sizeof(twx_result));
+        }
+        return TWX_OK;
+    }
+};
+
+template <class F> static int multi_guard(twx_multi* m, F f) noexcept {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return m ? m->fail(TWX_E_NOMEM, "out of host memory") : TWX_E_NOMEM; }
+    catch (const std::exception& e) { return m ? m->fail(TWX_E_STATE, std::string("internal error: ") + e.what()) : TWX_E_STATE; }
+    catch (...) { return m ? m->fail(TWX_E_STATE, "internal error") : TWX_E_STATE; }
+}
+
+extern "C" {
+
+const char* twx_multi_last_error(const twx_multi* m) { return m ? m->err.c_str() : g_multi_create_err.c_str(); }
+
+static int multi_create_impl(const twx_config* cfg, const int32_t* devices, int32_t n, int32_t flags, twx_multi** out) {
+    if (!cfg || !out || n < 1 || n > 64) { g_multi_create_err = "bad argument (1..64 contexts)"; return TWX_E_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_multi_create_err = "no HIP device available (the HIP path has no CPU fallback)"; return TWX_E_HIP; }
+    std::unique_ptr<twx_multi> m(new twx_multi());
+    m->n = n;
+    for (int r = 0; r < n; ++r) {
+        const int d = devices ? devices[r] : r % ndev;
+        if (d < 0 || d >= ndev) { g_multi_create_err = "device " + std::to_string(d) + " of the list does not exist (" + std::to_string(ndev) + " visible)"; return TWX_E_ARG; }
+        for (int q = 0; q < r; ++q) if (m->devices[q] == d) m->distinct = false;
+        m->devices.push_back(d);
+    }
+    m->ctx.assign(n, nullptr); m->send_dev.assign(n, nullptr); m->recv_dev.assign(n, nullptr); m->gstream.assign(n, nullptr);
+    m->local.resize(n);
+    for (int r = 0; r < n; ++r) { Worker* w = new Worker(); m->workers.push_back(w); w->start(m->devices[r]); }
+    // contexts are created side by side (tables, code spectrum, 3 pipeline slots each): one thread per device
+    std::vector<std::string> cerr(n);
+    int rc = TWX_OK;
+    {
+        twx_multi* mp = m.get();
+        for (int r = 0; r < n; ++r) m->workers[r]->submit([mp, cfg, r, &cerr]() {
+            twx_config c = *cfg;
+            c.device = mp->devices[r];
+            const int e = twx_create(&c, &mp->ctx[r]);
+            if (e) cerr[r] = twx_last_error(nullptr);
+            return e;
+        });
+        for (int r = 0; r < n; ++r) { const int e = m->workers[r]->wait(); if (e && !rc) { rc = e; g_multi_create_err = "context " + std::to_string(r) + ": " + cerr[r]; } }
+    }
+    if (rc) return rc;
+    twx_get_info(m->ctx[0], &m->cinfo);
+    for (int r = 0; r < n; ++r) {
+        if (hipSetDevice(m->devices[r]) != hipSuccess || hipStreamCreateWithFlags(&m->gstream[r], hipStreamNonBlocking) != hipSuccess) {
+            g_multi_create_err = "gather stream creation failed"; return TWX_E_HIP;
+        }
+    }
+    // RCCL: one rank per device — only a list of distinct devices can form a communicator.  n = 1 needs no exchange at all;
+    // TWX_MULTI_RCCL_ONE (flag or env TWX_MULTI_FORCE_RCCL=1) builds the world of one anyway, so that a one-GPU box runs the same calls.
+    const char* fe = getenv("TWX_MULTI_FORCE_RCCL");
+    const bool force_one = (flags & TWX_MULTI_RCCL_ONE) || (fe && atoi(fe) != 0);
+    const bool no_rccl = (flags & TWX_MULTI_NO_RCCL) != 0;
+    if (m->distinct && !no_rccl && (n > 1 || force_one)) {
+        std::lock_guard<std::mutex> g(rccl_mu());
+        Rccl& R = rccl();
+        if (!R.load()) { g_multi_create_err = R.err; return TWX_E_HIP; }
+        m->comms.assign(n, nullptr);
+        const ncclResult_t e = R.CommInitAll(m->comms.data(), n, m->devices.data());
+        if (e != ncclSuccess) {
+            g_multi_create_err = std::string("ncclCommInitAll failed: ") + R.GetErrorString(e);
+            if (R.GetLastError) { const char* le = R.GetLastError(nullptr); if (le && *le) g_multi_create_err += std::string(" — ") + le; }
+            m->comms.clear();
+            return TWX_E_HIP;
+        }
+        m->use_rccl = true;
+        int v = 0;
+        if (R.GetVersion && R.GetVersion(&v) == ncclSuccess) m->info.rccl_version = v;
+    }
+    m->info.n_contexts = n; m->info.rccl = m->use_rccl ? 1 : 0;
+    {
+        std::vector<int> u = m->devices; std::sort(u.begin(), u.end());
+        m->info.n_devices_distinct = (int32_t)(std::unique(u.begin(), u.end()) - u.begin());
+    }
+    *out = m.release();
+    return TWX_OK;
+}
+int twx_multi_create(const twx_config* cfg, const int32_t* devices, int32_t n_devices, int32_t flags, twx_multi** out) {
+    try { return multi_create_impl(cfg, devices, n_devices, flags, out); }
+    catch (const std::bad_alloc&) { if (out) *out = nullptr; g_multi_create_err = "out of host memory"; return TWX_E_NOMEM; }
+    catch (...) { if (out) *out = nullptr; g_multi_create_err = "internal error"; return TWX_E_STATE; }
+}
+void twx_multi_destroy(twx_multi* m) { delete m; }
+int twx_multi_get_info(const twx_multi* m, twx_multi_info* info) { if (!m || !info) return TWX_E_ARG; *info = m->info; return TWX_OK; }
+twx_ctx* twx_multi_context(twx_multi* m, int32_t i) { return (m && i >= 0 && i < m->n) ? m->ctx[i] : nullptr; }
+
+int twx_multi_process_file(twx_multi* m, const char* path, int32_t n_channels, int32_t channel, int64_t skip_samples, const twx_band* band,
+                           double df_const, twx_result* out, int64_t max_windows, int64_t* n_done) {
+    if (!m) return TWX_E_ARG;
+    if (!path || !out || !n_done || max_windows < 0 || n_channels < 1 || channel < TWX_ALL_CHANNELS || channel >= n_channels || skip_samples < 0) return m->fail(TWX_E_ARG, "bad argument");
+    *n_done = 0;
+    return multi_guard(m, [&]() -> int {
+        struct stat sb;
+        if (stat(path, &sb) != 0) return m->fail(TWX_E_ARG, std::string("cannot open ") + path);
+        const long long N = m->cinfo.n, per = channel < 0 ? n_channels : 1;
+        const long long have = (long long)sb.st_size / (4ll * n_channels) - skip_samples;
+        const long long total = std::max<long long>(0, std::min<long long>(max_windows, have / N));     // a short final window ends the loop
+        std::vector<long long> start(m->n), count(m->n), done(m->n, 0);
+        for (int r = 0; r < m->n; ++r) { twx_multi::shard(total, r, m->n, &start[r], &count[r]); m->local[r].resize((size_t)std::max<long long>(1, count[r] * per)); }
+        int rc = m->run_all([&](int r) -> int {
+            if (count[r] == 0) return TWX_OK;
+            int64_t nd = 0;
+            const int e = twx_process_file(m->ctx[r], path, n_channels, channel, skip_samples + start[r] * N, band, df_const, m->local[r].data(), count[r], &nd);
+            done[r] = nd;
+            return e;
+        });
+        if (rc) return rc;
+        for (int r = 0; r < m->n; ++r)
+            if (done[r] != count[r]) return m->fail(TWX_E_STATE, "context " + std::to_string(r) + " read fewer windows than the file held when the job was cut (capture truncated meanwhile?)");
+        rc = m->gather_host_blocks(count, (int)per, out);
+        if (rc == TWX_OK) *n_done = total;
+        return rc;
+    });
+}
+
+int twx_multi_process_windows(twx_multi* m, const int16_t* iq, int64_t n_windows, int32_t n_channels, int32_t channel, const twx_band* band,
+                              const double* df, twx_result* out) {
+    if (!m) return TWX_E_ARG;
+    if (!iq || !out || n_windows < 0 || n_channels < 1 || channel < TWX_ALL_CHANNELS || channel >= n_channels || (!band && !df)) return m->fail(TWX_E_ARG, "bad argument");
+    if (n_windows == 0) return TWX_OK;
+    return multi_guard(m, [&]() -> int {
+        const long long N = m->cinfo.n, per = channel < 0 ? n_channels : 1;
+        std::vector<long long> start(m->n), count(m->n);
+        for (int r = 0; r < m->n; ++r) { twx_multi::shard(n_windows, r, m->n, &start[r], &count[r]); m->local[r].resize((size_t)std::max<long long>(1, count[r] * per)); }
+        int rc = m->run_all([&](int r) -> int {
+            if (count[r] == 0) return TWX_OK;
+            return twx_process_windows(m->ctx[r], iq + (size_t)start[r] * (size_t)N * n_channels * 2, count[r], n_channels, channel, band,
+                                       df ? df + start[r] * per : nullptr, m->local[r].data());
+        });
+        if (rc) return rc;
+        return m->gather_host_blocks(count, (int)per, out);
+    });
+}
+
+// Device-resident form (what bench.py --single-process times): context r processes n_windows windows of ITS OWN recording
+// iq_dev[r] (on its device); the records stay on the devices, are exchanged device to device (RCCL) or — repeated devices —
+// fetched block by block, and out (host, n*n_windows*per records, rank order) may be NULL when only the devices' copies
+// are wanted (twx_multi_fetch_gathered).
+int twx_multi_process_windows_dev(twx_multi* m, const void* const* iq_dev, int64_t n_windows, int32_t n_channels, int32_t channel,
+                                  const twx_band* band, const double* df, twx_result* out) {
+    if (!m) return TWX_E_ARG;
+    if (!iq_dev || n_windows < 1 || n_channels < 1 || channel < TWX_ALL_CHANNELS || channel >= n_channels || (!band && !df)) return m->fail(TWX_E_ARG, "bad argument");
+    return multi_guard(m, [&]() -> int {
+        const size_t per = channel < 0 ? n_channels : 1, block = (size_t)n_windows * per;
+        if (int rc = m->ensure_gather(block)) return rc;
+        int rc = m->run_all([&](int r) -> int {
+            const int e = twx_process_windows_dev(m->ctx[r], iq_dev[r], n_windows, n_channels, channel, band, df, static_cast<twx_result*>(m->send_dev[r]));
+            return e ? e : twx_synchronize(m->ctx[r]);                 // records complete before the collective reads them
+        });
+        if (rc) return rc;
+        if (m->use_rccl) {
+            if ((rc = m->all_gather(block))) return rc;
+            if (out) {
+                (void)hipSetDevice(m->devices[0]);
+                if (hipMemcpy(out, m->recv_dev[0], block * m->n * sizeof(twx_result), hipMemcpyDeviceToHost) != hipSuccess) return m->fail(TWX_E_HIP, "gathered records D2H failed");
+            }
+        } else {
+            // host-side concatenation; every context's "gathered" buffer is filled from it so that both modes leave the same state
+            std::vector<twx_result> all(block * m->n);
+            for (int r = 0; r < m->n; ++r) {
+                (void)hipSetDevice(m->devices[r]);
+                if (hipMemcpy(all.data() + (size_t)r * block, m->send_dev[r], block * sizeof(twx_result), hipMemcpyDeviceToHost) != hipSuccess) return m->fail(TWX_E_HIP, "record D2H failed");
+            }
+            for (int r = 0; r < m->n; ++r) {
+                (void)hipSetDevice(m->devices[r]);
+                if (hipMemcpy(m->recv_dev[r], all.data(), all.size() * sizeof(twx_result), hipMemcpyHostToDevice) != hipSuccess) return m->fail(TWX_E_HIP, "record H2D failed");
+            }
+            if (out) memcpy(out, all.data(), all.size() * sizeof(twx_result));
+            m->info.gather_ms = 0; m->info.records_gathered = (int64_t)all.size(); m->info.bytes_per_rank = (int64_t)(block * sizeof(twx_result));
+        }
+        return TWX_OK;
+    });
+}
+
+int twx_multi_fetch_gathered(twx_multi* m, int32_t i, twx_result* out, int64_t n_records) {
+    if (!m) return TWX_E_ARG;
+    if (!out || i < 0 || i >= m->n || n_records < 0 || (size_t)n_records > m->cap_records * (size_t)m->n) return m->fail(TWX_E_ARG, "bad argument");
+    (void)hipSetDevice(m->devices[i]);
+    return hipMemcpy(out, m->recv_dev[i], (size_t)n_records * sizeof(twx_result), hipMemcpyDeviceToHost) == hipSuccess ? TWX_OK : m->fail(TWX_E_HIP, "D2H failed");
+}
+
+}  // extern "C"

@@ -32,6 +32,10 @@ def _process_capture(cor, cap, band, all_channels, rank, world, backend):
     """Records of every window of ``cap`` (all ranks return the full list; one collective)."""
     from . import dist as D
     nch = 2
+    if hasattr(cor, "n_contexts"):            # --single-process: the library's own multi-GPU driver (twx_multi_*)
+        allb = cor.process_file(cap, n_channels=nch, channel=-1 if all_channels else 0, band=band, raw_records=True)
+        res = D.results_from_bytes(allb)
+        return (res[0::2], res[1::2]) if all_channels else (res, None)
     nwin = os.path.getsize(cap) // (cor.n * 4 * nch)
     start, stop = D.shard_windows(nwin, rank, world)
     recs = cor.process_file(cap, n_channels=nch, channel=-1 if all_channels else 0, band=band,
@@ -54,8 +58,10 @@ def _process_capture(cor, cap, band, all_channels, rank, world, backend):
 
 
 def run(datalocation="./", codelocation="./codes/", remote=0, OP=0, fs=5e6, Nint=1, out=sys.stdout, device=-1,
-        backend="nccl"):
+        backend="nccl", single_process_gpus=0):
     rank, local_rank, world = launch.rank_world()
+    if single_process_gpus:
+        rank, local_rank, world = 0, 0, 1
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -75,7 +81,19 @@ def run(datalocation="./", codelocation="./codes/", remote=0, OP=0, fs=5e6, Nint
     chips = prn.read_code_file(codefile)
     done = []
     say = out.write if rank == 0 else (lambda s: None)
-    with Correlator(chips, fs=fs, Nint=Nint, var_ddof=1, device=device) as cor:     # Octave var (N-1)
+    if single_process_gpus:
+        # one host process, N devices (threads + RCCL inside the library); a box with fewer GPUs repeats them, as the
+        # multi-rank gloo tests do
+        from .multi import MultiCorrelator
+        try:
+            import torch
+            nvis = max(1, torch.cuda.device_count())
+        except Exception:
+            nvis = 1
+        make = lambda: MultiCorrelator(chips, [i % nvis for i in range(single_process_gpus)], fs=fs, Nint=Nint, var_ddof=1)
+    else:
+        make = lambda: Correlator(chips, fs=fs, Nint=Nint, var_ddof=1, device=device)     # Octave var (N-1)
+    with make() as cor:
         band = band_godual(fs, cor.n, remote=remote, OP=OP)
         for cap in caps:
             base = os.path.basename(cap)
@@ -112,7 +130,12 @@ def main(argv=None):
     ap.add_argument("--Nint", type=int, default=1)
     ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU) sharing every capture's windows")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) or gloo (several ranks on one GPU, tests)")
+    ap.add_argument("--single-process", action="store_true", help="--gpus N inside THIS process: the library's twx_multi driver "
+                    "(one context + host thread per device, RCCL gather) instead of N ranks under torch.distributed.run")
     a = ap.parse_args(argv)
+    if a.single_process:
+        run(a.datalocation, a.codelocation, a.remote, a.OP, a.fs, a.Nint, single_process_gpus=max(1, a.gpus))
+        return
     if a.gpus > 1 and not launch.is_rank():
         args = list(sys.argv[1:] if argv is None else argv)
         sys.exit(launch.spawn_ranks(a.gpus, "", args, module="amaranth_twstft_amd.godual_ranging"))

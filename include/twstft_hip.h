@@ -21,8 +21,9 @@ extern "C" {
 #endif
 
 /* 2: twx_config.reserved became the live field nphase (the struct must be zero-initialised), the tracked-ranging,
- *    acquisition and *_dev entry points were added.  twx_abi_version() of an older library answers 1. */
-#define TWX_ABI_VERSION 2
+ *    acquisition and *_dev entry points were added.  twx_abi_version() of an older library answers 1.
+ * 3: twx_multi_* (several GPUs from one host process) and twx_rx_* (the DLL/PLL receiver) added; nothing changed. */
+#define TWX_ABI_VERSION 3
 
 typedef struct twx_ctx twx_ctx;
 
@@ -360,6 +361,48 @@ int twx_tracked_host(twx_tracked* trk, const int16_t* iq, int64_t n_samples, int
 int twx_tracked_fetch(twx_tracked* trk, twx_tracked_code* codes, double* df, int64_t* moved, double* movedval);
 /* search_df alone (:27-47) on the first chunk_samples of a host buffer: *kbon as in the summary. */
 int twx_tracked_search_df(twx_tracked* trk, const int16_t* iq, int64_t n_samples, int64_t* kbon);
+
+/* Several GPUs from ONE host process ----------------------------------------------------------------------------
+ * A MATLAB / Octave / C host is one process; the reference's own shape for concurrent correlations is threads inside the
+ * program (one GoRanging worker per channel with a reader hand-off, processing/CPP/main.cpp:180-187,488-497) and jobs side
+ * by side (acquisition/goprocess.sh:9-11).  A twx_multi owns one correlator context and one persistent host thread per
+ * entry of `devices` (NULL: 0, 1, ... modulo the visible devices).  The windows of a capture are cut into contiguous blocks,
+ * sizes differing by at most one (one contiguous file extent per device — independent windows, godual_ranging.m:75-102);
+ * every context works through its block with twx_process_file / twx_process_windows[_dev], and the fixed-size records are
+ * exchanged with ONE ncclAllGather over xGMI (RCCL communicators from ncclCommInitAll, every device's call inside one
+ * ncclGroupStart/End).  RCCL needs one rank per device: when the list names a device twice the blocks are concatenated on
+ * the host instead (a one-GPU box then exercises the threading and the ordering with e.g. {0,0,0,0}).  RCCL is bound at run
+ * time (librccl.so.1, TWX_RCCL_LIB overrides), so single-GPU hosts never map it.  Results are those of one context, record
+ * for record.  Not thread-safe: one caller at a time per twx_multi. */
+typedef struct twx_multi twx_multi;
+enum { TWX_MULTI_NO_RCCL = 1,      /* host-side concatenation even for distinct devices */
+       TWX_MULTI_RCCL_ONE = 2 };   /* a list of ONE device still builds its RCCL world of one (same calls as N > 1) */
+typedef struct twx_multi_info {
+    int32_t n_contexts, n_devices_distinct;
+    int32_t rccl;                  /* 1: the record exchange is ncclAllGather; 0: host-side concatenation */
+    int32_t rccl_version;          /* ncclGetVersion, 0 when RCCL is not in use */
+    int64_t records_gathered;      /* last call: records in the gathered buffer (blocks padded to the longest) */
+    int64_t bytes_per_rank;        /* last call: bytes each context contributed */
+    double gather_ms;              /* last call: wall time of the collective incl. its synchronisation */
+} twx_multi_info;
+int twx_multi_create(const twx_config* cfg, const int32_t* devices, int32_t n_devices, int32_t flags, twx_multi** out);
+void twx_multi_destroy(twx_multi* m);
+const char* twx_multi_last_error(const twx_multi* m);          /* m may be NULL: last create error */
+int twx_multi_get_info(const twx_multi* m, twx_multi_info* info);
+twx_ctx* twx_multi_context(twx_multi* m, int32_t i);           /* context i (inspection, twx_get_info, options) */
+/* twx_process_file over all devices: same arguments, same records in `out`, *n_done = windows processed. */
+int twx_multi_process_file(twx_multi* m, const char* path, int32_t n_channels, int32_t channel, int64_t skip_samples,
+                           const twx_band* band, double df_const, twx_result* out, int64_t max_windows, int64_t* n_done);
+/* twx_process_windows over all devices (capture in HOST memory, e.g. the MEX argument). */
+int twx_multi_process_windows(twx_multi* m, const int16_t* iq, int64_t n_windows, int32_t n_channels, int32_t channel,
+                              const twx_band* band, const double* df, twx_result* out);
+/* Device-resident form: context i processes n_windows windows of ITS OWN recording iq_dev[i] (memory of its device) —
+ * BASELINE.json configs[3]'s weak-scaling step.  The records are exchanged device to device; out (host, n_contexts *
+ * n_windows [* n_channels] records in context order) may be NULL.  df as in twx_process_windows_dev, shared by all. */
+int twx_multi_process_windows_dev(twx_multi* m, const void* const* iq_dev, int64_t n_windows, int32_t n_channels,
+                                  int32_t channel, const twx_band* band, const double* df, twx_result* out);
+/* Context i's copy of the gathered records of the last *_dev call (what the collective delivered to that device). */
+int twx_multi_fetch_gathered(twx_multi* m, int32_t i, twx_result* out, int64_t n_records);
 
 /* Profiling (TWX_FLAG_PROFILE): per kernel class, HIP-event time on the context's stream. */
 #define TWX_PROF_MAX 16

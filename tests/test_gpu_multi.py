@@ -1,0 +1,154 @@
+"""GPU (-m gpu): several GPUs from ONE host process — ``twx_multi_*`` (include/twstft_hip.h), the route a MATLAB / Octave / C
+host has to more than one device (one context + one host thread per device, contiguous window blocks, one ncclAllGather).
+
+A one-GPU box runs the threading and the ordering with a device list that repeats device 0 (blocks concatenated on the host)
+and the RCCL calls with a world of one; wherever two GPUs are visible the same tests run the real collective.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from amaranth_twstft_amd import _lib as L
+from amaranth_twstft_amd.correlator import ALL_CHANNELS, Correlator, band_godual
+from amaranth_twstft_amd.multi import MultiCorrelator
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FS = 5e6
+REC = C.sizeof(L.twx_result)
+
+
+def _two_channel_capture(tmp_path, nwin, nchips=10000, seed=31):
+    from tests.test_gpu_parity import _capture
+    chips, raw = _capture(14, 43, nchips, nwin, seed=seed)
+    path = tmp_path / "cap.bin"
+    raw.tofile(path)
+    return chips, raw, str(path)
+
+
+@pytest.mark.parametrize("devices,nwin", [([0, 0, 0, 0], 13), ([0, 0, 0], 2), ([0] * 8, 600)])
+def test_repeated_device_list_is_byte_identical_to_one_context(tmp_path, devices, nwin):
+    """{0,0,0,0}: four contexts on four host threads share GPU 0, every one reads its own contiguous extent of the capture file;
+    records byte-identical to one context's twx_process_file, in window order — ragged blocks (13 = 4+3+3+3), fewer windows
+    than contexts (2 over 3), configs[3]'s 600 windows over 8.  File path and host-buffer path, one channel and all channels."""
+    chips, raw, path = _two_channel_capture(tmp_path, nwin)
+    n = 2 * len(chips)
+    band = band_godual(FS, n)
+    with Correlator(chips, fs=FS, Nint=1, var_ddof=1) as one:
+        ref_all = one.process_file(path, n_channels=2, channel=ALL_CHANNELS, band=band, raw_records=True)
+        ref_ch1 = one.process_file(path, n_channels=2, channel=1, band=band, skip_samples=n, raw_records=True)
+    assert ref_all.shape == (2 * nwin, REC)
+    with MultiCorrelator(chips, devices, fs=FS, Nint=1, var_ddof=1) as m:
+        info = m.info
+        assert info.n_contexts == len(devices) and info.n_devices_distinct == 1 and info.rccl == 0
+        got_all = m.process_file(path, n_channels=2, channel=ALL_CHANNELS, band=band, raw_records=True)
+        assert got_all.tobytes() == ref_all.tobytes()
+        got_ch1 = m.process_file(path, n_channels=2, channel=1, band=band, skip_samples=n, raw_records=True)     # skip + short job
+        assert got_ch1.shape == (nwin - 1, REC) and got_ch1.tobytes() == ref_ch1.tobytes()
+        if nwin <= 16:
+            got_host = m.process(raw, n_channels=2, channel=ALL_CHANNELS, band=band, raw_records=True)          # capture in host memory
+            assert got_host.tobytes() == ref_all.tobytes()
+            dfs = np.linspace(-300.0, 300.0, nwin)
+            with Correlator(chips, fs=FS, Nint=1, var_ddof=1) as one:
+                want = one.process(raw, n_channels=2, channel=0, df=dfs)
+            got = m.process(raw, n_channels=2, channel=0, df=dfs)                                                # per-window df follows its window
+            assert [g.indice for g in got] == [w.indice for w in want] and [g.df for g in got] == list(dfs)
+        assert m.info.records_gathered >= 1
+
+
+def test_device_resident_step_and_every_contexts_gathered_copy():
+    """twx_multi_process_windows_dev: every context processes its OWN device-resident recording (the weak-scaling step of
+    bench.py --single-process); all contexts end up with the same gathered buffer, block r holding recording r's records."""
+    import torch
+    from amaranth_twstft_amd import prn, synth
+    chips = prn.lfsr_chips(14, 43, 10000)
+    n, nwin, nctx = 20000, 5, 3
+    dev = torch.device("cuda", 0)
+    recs, delays = [], []
+    for r in range(nctx):
+        ps = [synth.SynthParams(delay_q8=(1000 * (r + 1) + 7 * w) * 256, fstep=synth.fstep_for_df(200.0 * r, FS), phi0=w, amp=300,
+                                noise_gain=synth.noise_gain_for_sigma(300.0), seed=100 * r + w) for w in range(nwin)]
+        raw = np.concatenate([synth.synth_channel(n, chips, 2, p) for p in ps])
+        recs.append(torch.from_numpy(raw).to(dev))
+        delays.append([1000 * (r + 1) + 7 * w for w in range(nwin)])
+    band = band_godual(FS, n)
+    with MultiCorrelator(chips, [0] * nctx, fs=FS, Nint=1) as m:
+        got = m.process_dev([t.data_ptr() for t in recs], nwin, band=band)
+        arr = (L.twx_result * (nctx * nwin)).from_buffer_copy(got.tobytes())
+        for r in range(nctx):
+            assert [int(arr[r * nwin + w].indice0) for w in range(nwin)] == [3 * d for d in delays[r]]
+            assert m.fetch_gathered(r, nctx * nwin).tobytes() == got.tobytes()
+    with Correlator(chips, fs=FS, Nint=1) as one:
+        for r in range(nctx):
+            want = one.process_dev(recs[r].data_ptr(), nwin, band=band)
+            assert [w.indice for w in want] == [int(arr[r * nwin + w].indice0) for w in range(nwin)]
+            assert [w.xval.real for w in want] == [arr[r * nwin + w].xval[0] for w in range(nwin)]
+
+
+def test_rccl_world_of_one_runs_the_collective_calls(tmp_path):
+    """One device, RCCL forced on: ncclCommInitAll + ncclGroupStart / ncclAllGather / ncclGroupEnd of a world of one — the calls
+    of the N > 1 path, bound from librccl.so.1 at run time, on a box with a single GPU.  Same records as without."""
+    chips, raw, path = _two_channel_capture(tmp_path, 7)
+    band = band_godual(FS, 2 * len(chips))
+    with MultiCorrelator(chips, [0], fs=FS, Nint=1, rccl=False) as a:
+        ref = a.process_file(path, n_channels=2, channel=0, band=band, raw_records=True)
+        assert a.info.rccl == 0
+    with MultiCorrelator(chips, [0], fs=FS, Nint=1, rccl=True) as b:
+        got = b.process_file(path, n_channels=2, channel=0, band=band, raw_records=True)
+        i = b.info
+        assert i.rccl == 1 and i.rccl_version > 0 and i.records_gathered == 7 and i.bytes_per_rank == 7 * REC
+    assert got.tobytes() == ref.tobytes()
+
+
+def test_two_real_devices_gather_over_rccl(tmp_path):
+    """Two distinct devices: the record exchange is one ncclAllGather over xGMI (skipped on a one-GPU box)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL has one rank per device")
+    chips, raw, path = _two_channel_capture(tmp_path, 13)
+    band = band_godual(FS, 2 * len(chips))
+    with Correlator(chips, fs=FS, Nint=1) as one:
+        ref = one.process_file(path, n_channels=2, channel=ALL_CHANNELS, band=band, raw_records=True)
+    with MultiCorrelator(chips, [0, 1], fs=FS, Nint=1) as m:
+        got = m.process_file(path, n_channels=2, channel=ALL_CHANNELS, band=band, raw_records=True)
+        assert m.info.rccl == 1 and m.info.n_devices_distinct == 2
+    assert got.tobytes() == ref.tobytes()
+
+
+def test_errors_come_back_as_status_codes(tmp_path):
+    chips, raw, path = _two_channel_capture(tmp_path, 3)
+    lib = L.load()
+    h = C.c_void_p()
+    cfg = L.twx_config()
+    cfg.fs, cfg.sps, cfg.nint, cfg.lfsr_bitlen, cfg.lfsr_taps, cfg.n_chips = FS, 2, 1, 14, 43, 10000
+    devs = (C.c_int32 * 2)(0, 99)
+    assert lib.twx_multi_create(C.byref(cfg), C.cast(devs, C.c_void_p), 2, 0, C.byref(h)) == -1 and not h.value
+    assert b"does not exist" in lib.twx_multi_last_error(None)
+    with MultiCorrelator(chips, [0, 0], fs=FS, Nint=1) as m:
+        with pytest.raises(L.TwxError, match="cannot open"):
+            m.process_file(str(tmp_path / "nope.bin"), n_channels=2, channel=0, band=(0, 10), max_windows=1)
+        out = m.process_file(path, n_channels=2, channel=0, band=band_godual(FS, 20000), max_windows=0)
+        assert out == []
+
+
+def test_script_level_job_single_process(tmp_path):
+    """python -m amaranth_twstft_amd.godual_ranging --gpus 4 --single-process: the file-in / delay-out job of configs[3] through
+    twx_multi (no torch.distributed, no child ranks) writes the .mat / TSV a one-GPU run writes, byte for byte."""
+    from tests.test_gpu_configs import _write_capture
+    _write_capture(tmp_path, 10000, 13, seed=77)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    base = [sys.executable, "-m", "amaranth_twstft_amd.godual_ranging", "--datalocation", str(tmp_path), "--codelocation", str(tmp_path / "codes")]
+    one = subprocess.run(base, capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    mat = tmp_path / "1670074501.mat"
+    ref_bytes = mat.read_bytes()[128:]
+    mat.unlink()
+    many = subprocess.run(base + ["--gpus", "4", "--single-process"], capture_output=True, text=True, env=env, timeout=900)
+    assert many.returncode == 0, many.stdout[-2000:] + many.stderr[-3000:]
+    assert mat.read_bytes()[128:] == ref_bytes
+    rows = lambda s: [l for l in s.splitlines() if l[:1].isdigit() and "\t" in l]
+    assert rows(many.stdout) == rows(one.stdout) and len(rows(one.stdout)) == 13
