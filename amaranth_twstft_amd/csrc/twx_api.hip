@@ -482,7 +482,7 @@ template <typename T> struct Ctx : CtxBase {
     unsigned char* chips_dev = nullptr;
     // batch buffers
     WinSums* sums = nullptr; double* dfv = nullptr; long long* dfidx = nullptr;
-    SumPart* sum_parts = nullptr; unsigned* sum_tickets = nullptr;
+    SumPart* sum_parts = nullptr;
     C *e1 = nullptr, *e2 = nullptr, *A = nullptr, *Bz = nullptr, *dc = nullptr;
     ArgPart<T>*part_band = nullptr, *part_peak = nullptr;
     twx_result* res_dev = nullptr;
@@ -492,7 +492,7 @@ template <typename T> struct Ctx : CtxBase {
         hipStream_t stream; WinSums* sums; double* dfv; long long* dfidx; C *e1, *e2, *A, *Bz, *dc;
         ArgPart<T>*part_band, *part_peak; twx_result* res_dev; double* fine_u; double* csum_part;
         short2* planar; WinSums* sums2;      // two-channel captures in all-channel mode: planar copies + both channels' sums (lazy)
-        SumPart* sum_parts; unsigned* sum_tickets;   // k_sums: [2][B][TWX_SUMS_MAXCHUNKS] partials, [B] tickets (zero between launches)
+        SumPart* sum_parts;                  // k_sums: [2][B][TWX_SUMS_MAXCHUNKS] per-workgroup partials
     };
     Slot slots[4] = {}; int nslots = 1;
     bool sums_ready = false;                 // run_batch_in: `sums` already holds this batch's statistics (k_sums_deint2)
@@ -503,7 +503,7 @@ template <typename T> struct Ctx : CtxBase {
         const Slot& q = slots[k];
         stream = q.stream; sums = q.sums; dfv = q.dfv; dfidx = q.dfidx; e1 = q.e1; e2 = q.e2; A = q.A; Bz = q.Bz; dc = q.dc;
         part_band = q.part_band; part_peak = q.part_peak; res_dev = q.res_dev; fine_u = q.fine_u; csum_part = q.csum_part;
-        sum_parts = q.sum_parts; sum_tickets = q.sum_tickets;
+        sum_parts = q.sum_parts;
     }
     // k_sums grid: enough workgroups for the chip whatever the batch (8 per CU over the launch; 64 per window starved a
     // one-window launch: 90 us for 20 MB, profiles/r03_aux_kernel_stats.md), at least 16 KB of samples each
@@ -794,8 +794,6 @@ template <typename T> struct Ctx : CtxBase {
             if (fine_M) { if (int rc = dalloc(&q.fine_u, (size_t)B * fine_M)) return rc; }
             if (int rc = dalloc(&q.csum_part, (size_t)B * 64)) return rc;
             if (int rc = dalloc(&q.sum_parts, (size_t)2 * B * TWX_SUMS_MAXCHUNKS)) return rc;
-            if (int rc = dalloc(&q.sum_tickets, (size_t)B)) return rc;
-            HIPCHK(hipMemsetAsync(q.sum_tickets, 0, sizeof(unsigned) * B, stream));
         }
         use_slot(0);
         {
@@ -866,7 +864,9 @@ template <typename T> struct Ctx : CtxBase {
             ProfScope ps(this, PC_SUMS, 2ll * nb * N);
             const int chunks = sums_chunks(nb);
             TWX_LAUNCH((k_sums_deint2<0>), dim3(chunks, nb), dim3(256), stream, reinterpret_cast<const int4*>(frames), (long long)N, (long long)N,
-                       q.planar, q.planar + (size_t)B * N, q.sums2, q.sums2 + B, q.sum_parts, q.sum_parts + (size_t)B * TWX_SUMS_MAXCHUNKS, q.sum_tickets);
+                       q.planar, q.planar + (size_t)B * N, q.sum_parts, q.sum_parts + (size_t)B * TWX_SUMS_MAXCHUNKS);
+            HIPCHK(hipGetLastError());
+            TWX_LAUNCH((k_sums_final<0>), dim3(nb, 2), dim3(256), stream, q.sum_parts, chunks, (long long)B * TWX_SUMS_MAXCHUNKS, q.sums2, q.sums2 + B);
             HIPCHK(hipGetLastError());
         }
         int rc = TWX_OK;
@@ -922,7 +922,9 @@ template <typename T> struct Ctx : CtxBase {
             ProfScope ps(this, PC_SUMS, (long long)nb * N);
             const int chunks = sums_chunks(nb);
             for (int it = 0, ne = reps(PC_SUMS); it < ne; ++it)
-            TWX_LAUNCH((k_sums<0>), dim3(chunks, nb), dim3(256), stream, in, wstride, nch, N, sums, sum_parts, sum_tickets);
+            TWX_LAUNCH((k_sums<0>), dim3(chunks, nb), dim3(256), stream, in, wstride, nch, N, sum_parts);
+            HIPCHK(hipGetLastError());
+            TWX_LAUNCH((k_sums_final<0>), dim3(nb, 1), dim3(256), stream, sum_parts, chunks, 0ll, sums, sums);
             HIPCHK(hipGetLastError());
         } else if (intype == IN_C32) {
             if (rm_mean) return fail(TWX_E_ARG, "complex input is taken as it is");
@@ -1450,7 +1452,10 @@ template <typename T> struct Ctx : CtxBase {
         }
         int later = 0;
         for (double st = fstep / 2.0; !(st < 1.0); st /= 2.0) ++later;              // rounds after the coarse one (:565-567)
-        const int cap = std::min(B, 4);                                              // fc-step, fc, fc+step (+1 for rounding slack)
+        // every later round evaluates fc-step, fc, fc+step (+1 slot for rounding slack) in ONE launch: a context whose batch
+        // is shorter would silently drop the fc+step trial and sweep differently from rxcomplex.cpp:534-567
+        if (B < 3) return fail(TWX_E_ARG, "acquire: the context's max_batch must be at least 3 (three trial carriers per refinement round)");
+        const int cap = std::min(B, 4);
         twx_result* rec = nullptr; AcqState* st_dev = nullptr;
         if (int rc = sc.get(&rec, trial.size() + (size_t)later * cap + 1)) return rc;
         if (int rc = sc.get(&st_dev, 1)) return rc;
@@ -1503,7 +1508,8 @@ template <typename T> struct Ctx : CtxBase {
         if (int rc = sc.get(&pk_d, (size_t)nbins)) return rc;       // every bin's record stays on the device until the end:
         if (int rc = sc.get(&lag_d, (size_t)nbins)) return rc;      // one D2H copy and one synchronisation per call
         const short2* in = reinterpret_cast<const short2*>(iq_dev) + ch;
-        TWX_LAUNCH((k_sums<0>), dim3((unsigned)sums_chunks(1), 1), dim3(256), stream, in, 0ll, nch, N, sums, sum_parts, sum_tickets);
+        TWX_LAUNCH((k_sums<0>), dim3((unsigned)sums_chunks(1), 1), dim3(256), stream, in, 0ll, nch, N, sum_parts);
+        TWX_LAUNCH((k_sums_final<0>), dim3(1, 1), dim3(256), stream, sum_parts, sums_chunks(1), 0ll, sums, sums);
         HIPCHK(hipGetLastError());
         ColFwdArgs<T> ca{};
         ca.in_win_stride = 0; ca.sums = sums; ca.remove_mean = 1; ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = 1;

@@ -605,7 +605,9 @@ int track_update_impl(const double* cor, const double* phi, int bps, int nlag, t
             last_phi = res_phi[(size_t)p];
         } else w[(size_t)p] = 0.0;
     }
-    if (cnt == 0) return TWX_OK;                                           // every period filtered out (the program would divide by zero)
+    // fewer than two periods left (or all at one time tag): the weighted line through them has no slope — the program would
+    // write NaN into fc / df / pt; here the epoch counts as unusable and the state stays as it was
+    if (cnt < 2) return TWX_OK;
     st->last_phi = last_phi;
     double c0, c1, chi;
     fit_wlinear(ttag_phi, w, res_phi, &c0, &c1, &chi);                                   // :728

@@ -64,8 +64,8 @@ struct WinSums {            // exact integer sums over the raw int16 window
     double fP;              // complex-double input (twx_process_complex): sum |d|^2 in fp64, valid when is_f != 0
     int is_f, pad;
 };
-// k_sums / k_sums_deint2: one partial per workgroup, reduced by the workgroup that arrives last (a ticket per window); no
-// atomics on the sums themselves and nothing to clear beforehand, so the grid can be sized for the chip whatever the batch
+// k_sums / k_sums_deint2: one partial per workgroup, added up by k_sums_final; no atomics and nothing to clear beforehand, so
+// the grid can be sized for the chip whatever the batch
 struct SumPart { long long sI, sQ; unsigned long long sP; long long pad; };
 #define TWX_SUMS_MAXCHUNKS 1024
 template <typename T> struct ArgPart { T val; unsigned int idx; };
@@ -259,69 +259,42 @@ __global__ void k_sums_c64_final(const double* __restrict__ partial, int nparts,
     sums[b] = s;
 }
 
-// Block-wide finish of NC (channels) x {sum I, sum Q, sum I^2+Q^2}: every thread brings its own partial sums.  The block's
-// totals go to parts[c][blockIdx.x]; the block that draws the last ticket of its window adds up all the partials and
-// writes the window's WinSums (integer sums: the order of arrival cannot change the result).  Release / acquire at device
-// scope around the ticket (the eight XCDs have separate L2s: the partials are read with device-scope atomic loads).
+// Block-wide finish of NC (channels) x {sum I, sum Q, sum I^2+Q^2}: every thread brings its own partial sums; thread 0 ends up
+// with the block's totals.
 template <int NC>
-__device__ __forceinline__ void sums_finish(long long (&v)[NC][3], SumPart* const (&parts)[NC], unsigned* ticket, WinSums* const (&out)[NC]) {
+__device__ __forceinline__ void sums_block_total(long long (&v)[NC][3]) {
     __shared__ long long sh[NC * 3][4];
-    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    auto block_sum = [&]() {                                   // totals valid in thread 0
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            for (int d = 32; d >= 1; d >>= 1) v[c][k] += shfl_down_ll(v[c][k], d);
+            if (lane == 0) sh[c * 3 + k][wv] = v[c][k];
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                for (int d = 32; d >= 1; d >>= 1) v[c][k] += shfl_down_ll(v[c][k], d);
-                if (lane == 0) sh[c * 3 + k][wv] = v[c][k];
-            }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) v[c][k] = (sh[c * 3 + k][0] + sh[c * 3 + k][1]) + (sh[c * 3 + k][2] + sh[c * 3 + k][3]);
-        }
-    };
-    block_sum();
-    if (threadIdx.x == 0) {
-        int last = 1;
-        if (gridDim.x > 1) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                SumPart p; p.sI = v[c][0]; p.sQ = v[c][1]; p.sP = (unsigned long long)v[c][2]; p.pad = 0;
-                parts[c][blockIdx.x] = p;
-            }
-            __threadfence();
-            last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-        }
-        s_last = last;
+            for (int k = 0; k < 3; ++k) v[c][k] = (sh[c * 3 + k][0] + sh[c * 3 + k][1]) + (sh[c * 3 + k][2] + sh[c * 3 + k][3]);
     }
-    __syncthreads();
-    if (!s_last) return;
-    if (gridDim.x > 1) {
-        __threadfence();
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { v[c][0] = 0; v[c][1] = 0; v[c][2] = 0; }
-        for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                v[c][0] += __hip_atomic_load(&parts[c][i].sI, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v[c][1] += __hip_atomic_load(&parts[c][i].sQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v[c][2] += (long long)__hip_atomic_load(&parts[c][i].sP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();                                       // sh[] of the first block_sum has been read
-        block_sum();
-    }
+}
+// Second step of k_sums / k_sums_deint2: the per-workgroup partials of a window -> its WinSums (integer sums: the order cannot
+// change the result).  A launch of its own instead of atomics on the window's three words: same-address device-scope atomics
+// cost ~0.4 us each on this chip (256 workgroups per window on one ticket word: 0.127 ms for what reads in 0.03,
+// profiles/r04_ksums.txt), and a grid sized for the chip means hundreds of them.   grid = (windows, NC), block = 256
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_sums_final(const SumPart* __restrict__ parts, int nparts, long long chan_stride /*SumPart units*/,
+                                                    WinSums* __restrict__ sums0, WinSums* __restrict__ sums1) {
+    const int b = blockIdx.x, c = blockIdx.y;
+    const SumPart* p = parts + (long long)c * chan_stride + (long long)b * nparts;
+    long long v[1][3] = {{0, 0, 0}};
+    for (int i = threadIdx.x; i < nparts; i += 256) { const SumPart q = p[i]; v[0][0] += q.sI; v[0][1] += q.sQ; v[0][2] += (long long)q.sP; }
+    sums_block_total<1>(v);
     if (threadIdx.x == 0) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            WinSums s; s.sI = v[c][0]; s.sQ = v[c][1]; s.sP = (unsigned long long)v[c][2]; s.fP = 0.0; s.is_f = 0; s.pad = 0;
-            *out[c] = s;
-        }
-        if (gridDim.x > 1) *ticket = 0;                        // ready for the next launch on this stream
+        WinSums s; s.sI = v[0][0]; s.sQ = v[0][1]; s.sP = (unsigned long long)v[0][2]; s.fP = 0.0; s.is_f = 0; s.pad = 0;
+        (c == 0 ? sums0 : sums1)[b] = s;
     }
 }
 
@@ -331,8 +304,7 @@ __device__ __forceinline__ void sums_finish(long long (&v)[NC][3], SumPart* cons
 // ------------------------------------------------------------------------------------------
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void k_sums(const short2* __restrict__ in, long long win_stride /*short2 units*/,
-                                              int nch, long long n, WinSums* __restrict__ sums, SumPart* __restrict__ parts /*[windows][chunks]*/,
-                                              unsigned* __restrict__ tickets /*[windows], zero between launches*/) {
+                                              int nch, long long n, SumPart* __restrict__ parts /*[windows][chunks]*/) {
     const int b = blockIdx.y;
     const short2* p = in + (long long)b * win_stride;
     long long sI = 0, sQ = 0;
@@ -380,9 +352,8 @@ __global__ __launch_bounds__(256) void k_sums(const short2* __restrict__ in, lon
         for (long long i = lo + threadIdx.x; i < hi; i += 256) acc(p[i * nch]);
     }
     long long blk[1][3] = {{sI, sQ, (long long)sP}};
-    SumPart* pp[1] = {parts + (long long)b * gridDim.x};
-    WinSums* oo[1] = {sums + b};
-    sums_finish<1>(blk, pp, tickets + b, oo);
+    sums_block_total<1>(blk);
+    if (threadIdx.x == 0) { SumPart q; q.sI = blk[0][0]; q.sQ = blk[0][1]; q.sP = (unsigned long long)blk[0][2]; q.pad = 0; parts[(long long)b * gridDim.x + blockIdx.x] = q; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -395,8 +366,7 @@ __global__ __launch_bounds__(256) void k_sums(const short2* __restrict__ in, lon
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void k_sums_deint2(const int4* __restrict__ in /*two frames per element*/, long long win_stride /*frames*/,
                                                      long long n, short2* __restrict__ p0, short2* __restrict__ p1,
-                                                     WinSums* __restrict__ sums0, WinSums* __restrict__ sums1,
-                                                     SumPart* __restrict__ parts0, SumPart* __restrict__ parts1, unsigned* __restrict__ tickets) {
+                                                     SumPart* __restrict__ parts0, SumPart* __restrict__ parts1) {
     const int b = blockIdx.y;
     const int4* p = in + ((long long)b * win_stride >> 1);
     int2* o0 = reinterpret_cast<int2*>(p0 + (long long)b * n);
@@ -437,9 +407,14 @@ __global__ __launch_bounds__(256) void k_sums_deint2(const int4* __restrict__ in
         sI[0] += aI[0]; sQ[0] += aQ[0]; sI[1] += aI[1]; sQ[1] += aQ[1];
     }
     long long blk[2][3] = {{sI[0], sQ[0], (long long)sP[0]}, {sI[1], sQ[1], (long long)sP[1]}};
-    SumPart* pp[2] = {parts0 + (long long)b * gridDim.x, parts1 + (long long)b * gridDim.x};
-    WinSums* oo[2] = {sums0 + b, sums1 + b};
-    sums_finish<2>(blk, pp, tickets + b, oo);
+    sums_block_total<2>(blk);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            SumPart q; q.sI = blk[c][0]; q.sQ = blk[c][1]; q.sP = (unsigned long long)blk[c][2]; q.pad = 0;
+            (c == 0 ? parts0 : parts1)[(long long)b * gridDim.x + blockIdx.x] = q;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------

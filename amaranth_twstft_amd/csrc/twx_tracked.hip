@@ -294,14 +294,16 @@ twx_ctx* twx_tracked_context(twx_tracked* t) { return t ? t->ctx : nullptr; }
 int twx_tracked_file(twx_tracked* t, const char* path, int64_t skip_samples, int64_t kbon_hint, twx_tracked_summary* summary) {
     if (!t) return TWX_E_ARG;
     if (!path) return t->fail(TWX_E_ARG, "null path");
+    // the descriptor is closed on EVERY exit path, an exception out of run() (bad_alloc from the record vectors or from
+    // std::async) included: a long-running MEX / Octave host must not leak one per failed capture
+    struct Fd {
+        twx_tracked* t; int fd;
+        ~Fd() { t->drop_ahead(); if (fd >= 0) close(fd); t->fd = -1; }
+    } guard{t, open(path, O_RDONLY)};
+    if (guard.fd < 0) return t->fail(TWX_E_ARG, std::string("cannot open ") + path);
     return trk_guard(t, [&]() {
-        const int fd = open(path, O_RDONLY);
-        if (fd < 0) return t->fail(TWX_E_ARG, std::string("cannot open ") + path);
-        t->fd = fd; t->host_src = nullptr; t->src_i16 = 0;
-        const int rc = t->run(skip_samples, kbon_hint, summary);
-        t->drop_ahead();
-        close(fd); t->fd = -1;
-        return rc;
+        t->fd = guard.fd; t->host_src = nullptr; t->src_i16 = 0;
+        return t->run(skip_samples, kbon_hint, summary);
     });
 }
 int twx_tracked_host(twx_tracked* t, const int16_t* iq, int64_t n_samples, int64_t skip_samples, int64_t kbon_hint, twx_tracked_summary* summary) {

@@ -98,7 +98,10 @@ class MultiCorrelator:
                      max_windows: int | None = None, raw_records: bool = False):
         """``Correlator.process_file`` over all devices (same records, same order)."""
         per = self.n * 4 * n_channels
-        avail = max(0, (os.path.getsize(path) - skip_samples * 4 * n_channels)) // per
+        try:
+            avail = max(0, (os.path.getsize(path) - skip_samples * 4 * n_channels)) // per
+        except OSError:
+            avail = 0 if max_windows is None else max_windows            # the library reports the missing file
         nmax = avail if max_windows is None else min(avail, max_windows)
         nch_out = n_channels if channel < 0 else 1
         out = (L.twx_result * max(nmax * nch_out, 1))()

@@ -170,7 +170,7 @@ def _clean_stale():
         return
     tail = "_%s.so" % source_hash()
     for f in os.listdir(PLAN_DIR):
-        if f.endswith(".so") and not f.endswith(tail):
+        if (f.endswith(".so") and not f.endswith(tail)) or (f.endswith(".so.nof64") and not f[:-6].endswith(tail)):
             try:
                 os.unlink(os.path.join(PLAN_DIR, f))
             except OSError:
@@ -182,8 +182,9 @@ def _plan_macro(L, radices):
 
 
 def _compile(src, out, defs):
-    """hipcc one plug-in.  Returns (path, f64_built): a plan whose complex-double instantiation does not fit the 160 KB of
-    LDS is rebuilt for fp32 only, and the caller names the file after what it really holds."""
+    """hipcc one plug-in; returns the path of the file written.  A plan whose complex-double instantiation does not fit the
+    160 KB of LDS is rebuilt for fp32 only and written under the ``_f32_`` name (the name says what the object holds); a
+    ``.nof64`` marker beside it records the failed attempt so that :func:`_build` does not repeat it on every call."""
     os.makedirs(PLAN_DIR, exist_ok=True)
     if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
         raise RuntimeError(f"{HIPCC} not found: plan plug-ins are compiled with hipcc (set HIPCC=...)")
@@ -194,7 +195,10 @@ def _compile(src, out, defs):
     if r.returncode and "local memory" in r.stderr and "double" in r.stderr and "-DTWX_NO_F64" not in defs:
         # the complex-double instantiation of a long plan does not fit the 160 KB of LDS: fp32 contexts only
         # (the code spectrum is then computed in fp32 as well, Ctx::make_code_spectrum)
-        return _compile(src, out.replace("_f64_", "_f32_"), defs + ["-DTWX_NO_F64"])
+        got = _compile(src, out.replace("_f64_", "_f32_"), defs + ["-DTWX_NO_F64"])
+        with open(got + ".nof64", "w") as fd:
+            fd.write("the complex-double instantiation of this plan exceeds the LDS; fp32 only\n")
+        return got
     if r.returncode:
         raise RuntimeError("plan build failed:\n" + " ".join(cmd) + "\n" + r.stderr[-3000:])
     os.replace(tmp, out)
@@ -215,8 +219,8 @@ def _build(kind: str, src: str, plan: dict, defs) -> str:
     out64, out32 = _plan_file(kind, plan, True), _plan_file(kind, plan, False)
     if os.path.exists(out64):
         return out64                                   # holds the fp32 kernels as well
-    if not want64 and os.path.exists(out32):
-        return out32
+    if os.path.exists(out32) and (not want64 or os.path.exists(out32 + ".nof64")):
+        return out32                                   # asked for, or the fp64 attempt is known not to fit (marker of _compile)
     _clean_stale()
     return _compile(src, out64 if want64 else out32, defs + ([] if want64 else ["-DTWX_NO_F64"]))
 

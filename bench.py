@@ -72,7 +72,7 @@ def _cpu_one(p):
     d = orc.deinterleave(_CPU["raw"][p % len(_CPU["raw"])], 1, 0)
     d = d - d.mean()
     r = orc.processing(d, _CPU["k"], _CPU["freq"], _CPU["temps"], _CPU["fcode"], _CPU["code"], Nint=1, fs=FS, df=_CPU["df"])
-    return int(r["indice"])
+    return int(r["indice"]), float(r["correction"]), float(abs(r["xval"]))
 
 
 def cpu_baseline_child(n_win: int, workload: str, max_workers: int):
@@ -98,17 +98,19 @@ def cpu_baseline_child(n_win: int, workload: str, max_workers: int):
     freq = orc.freq_axis(FS, N)
     _CPU.update(code=code, fcode=fcode, freq=freq, k=orc.band_godual(freq), temps=np.arange(N) / FS)
     t2 = time.perf_counter()
-    indices = [_cpu_one(p) for p in range(n_win)]                # (i) one core, comparable with the README timings
+    full = [_cpu_one(p) for p in range(n_win)]                   # (i) one core, comparable with the README timings
     t3 = time.perf_counter()
+    indices = [f[0] for f in full]
     out = {"single_core": {"value": round(n_win * N / (t3 - t2) / 1e6, 4), "cores": 1, "windows": n_win, "seconds": round(t3 - t2, 2)},
-           "setup_seconds": round(t2 - t1, 2), "indices": indices, "host_cores": cores}
+           "setup_seconds": round(t2 - t1, 2), "indices": indices, "corrections": [f[1] for f in full], "peak_mags": [f[2] for f in full],
+           "host_cores": cores}
     if workers > 1:                                              # (ii) one window per core over all cores
         with ctx.Pool(workers) as pool:
             pool.map(_cpu_one, range(workers))                   # warm-up: page in the inherited arrays
             t4 = time.perf_counter()
             got = pool.map(_cpu_one, range(2 * workers), chunksize=1)
             t5 = time.perf_counter()
-        ok = all(got[i] == indices[i % n_win] for i in range(len(got)))
+        ok = all(got[i][0] == indices[i % n_win] for i in range(len(got)))
         out["all_cores"] = {"value": round(2 * workers * N / (t5 - t4) / 1e6, 4), "cores": workers, "windows": 2 * workers,
                             "seconds": round(t5 - t4, 2), "consistent": bool(ok)}
     try:                                                         # (iii) multi-threaded FFT (scipy.fft workers=-1)
@@ -118,7 +120,7 @@ def cpu_baseline_child(n_win: int, workload: str, max_workers: int):
         got = [_cpu_one(p) for p in range(n_win)]
         t7 = time.perf_counter()
         out["scipy_fft_workers_all"] = {"value": round(n_win * N / (t7 - t6) / 1e6, 4), "cores": cores, "windows": n_win,
-                                        "seconds": round(t7 - t6, 2), "consistent": got == indices}
+                                        "seconds": round(t7 - t6, 2), "consistent": [g[0] for g in got] == indices}
     except Exception as e:  # pragma: no cover
         out["scipy_fft_workers_all"] = {"error": repr(e)}
     finally:
@@ -160,7 +162,20 @@ def measure_pmc_traffic(kernel_short: str):
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--windows", "8", "--no-cpu-baseline", "--no-roofline",
                    "--no-caf"]
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+            # its own process group: on a timeout the whole group goes (rocprofv3 AND the bench process under it, which would
+            # otherwise keep running on the GPU through the parent's timed region), and is waited for before the next GPU user
+            proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+            try:
+                so, se = proc.communicate(timeout=240)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                proc.communicate()
+                return None, "rocprofv3 --pmc %s timed out after 240 s (its process group was killed and waited for)" % counter
+            r = subprocess.CompletedProcess(cmd, proc.returncode, so, se)
             files = glob.glob(os.path.join(tmp, counter, "**", "*_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, "rocprofv3 --pmc %s failed (rc %s): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-300:])
@@ -182,6 +197,89 @@ def measure_pmc_traffic(kernel_short: str):
                   "%d + %d bytes" % (int(2 * vals["FETCH_SIZE"] * 1024), int(vals["WRITE_SIZE"] * 1024)))
 
 
+def single_process(a, t_start):
+    """``--gpus N --single-process``: the N-GPU step driven from ONE host process through the library's own multi-GPU driver
+    (``twx_multi_*``: one context + host thread per device, one ncclAllGather of the records, RCCL bound by the library) — the
+    route a MATLAB / Octave / C host has.  Same workload, same timing rules and the same ``collective`` object as the
+    one-process-per-GPU form; a box with fewer GPUs than N repeats its devices (records then concatenated on the host)."""
+    import numpy as np
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    from amaranth_twstft_amd import _lib as L, prn
+    from amaranth_twstft_amd.correlator import band_godual
+    from amaranth_twstft_amd.multi import MultiCorrelator
+    lib = L.load()
+    world, nwin = a.gpus, a.windows
+    devices = [i % ndev for i in range(world)]
+    chips = prn.lfsr_chips(BITLEN, TAPS, NCHIPS)
+    m = MultiCorrelator(chips, devices, fs=FS, Nint=1, max_batch=a.batch)
+    recs, delays = [], []
+    for r in range(world):
+        dev = torch.device("cuda", devices[r])
+        torch.cuda.set_device(dev)
+        chips_dev = torch.from_numpy(chips).to(dev)
+        iq = torch.empty((nwin, N, 2), dtype=torch.int16, device=dev)
+        dl = []
+        for p in range(nwin):
+            sp, delay = window_params(p, r)
+            dl.append(delay)
+            params = np.array([sp.delay_q8, sp.fstep, sp.phi0, sp.amp, sp.noise_gain, sp.seed, sp.stream, 0], dtype=np.int64)
+            L.check(lib.twx_synth_capture_dev(iq[p].data_ptr(), N, 0, chips_dev.data_ptr(), NCHIPS, 2, 1, params.ctypes.data_as(C.c_void_p), None))
+        torch.cuda.synchronize(dev)
+        recs.append(iq); delays.append(dl)
+    ptrs = [t.data_ptr() for t in recs]
+    band = band_godual(FS, N)
+    df_true = np.full(nwin, 1780.75)
+
+    def step(workload, fetch=False):
+        return m.process_dev(ptrs, nwin, band=band if workload == "processing" else None, df=None if workload == "processing" else df_true, fetch=fetch)
+
+    def timed(workload):
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step(workload)                               # returns after the gather: every device's stream is idle
+        return time.perf_counter() - t0
+
+    t_ready = time.perf_counter()
+    for _ in range(a.warmup):
+        step(a.workload)
+    dt = timed(a.workload)
+    other = "xcorr" if a.workload == "processing" else "processing"
+    step(other)
+    dt_other = timed(other)
+    got = step(a.workload, fetch=True)
+    info = m.info
+    arr = (L.twx_result * (world * nwin)).from_buffer_copy(got.tobytes())
+    per_rank = [all(int(arr[r * nwin + p].indice0) == 3 * delays[r][p] for p in range(nwin)) for r in range(world)]
+    copies = [m.fetch_gathered(r, world * nwin).tobytes() == got.tobytes() for r in range(world)]
+    value = world * nwin * N * a.steps / dt / 1e6
+    out = {"metric": "Msamples/s correlated (1 s integrations, 2.5 Mchip PRN)", "value": round(value, 2), "unit": "Msamples/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": ("processing(d,k) full chain" if a.workload == "processing" else "xcorr, df supplied")
+                      + ": the window of BASELINE.json configs[1] (1 s, 5 Msps int16 IQ, 2.5 Mchip LFSR(22,3) code, fp32), Nint=1, "
+                      + f"one {nwin}-window recording per GPU per step, HBM-resident; ONE host process driving {world} contexts "
+                      + f"on devices {devices} through twx_multi_* (one host thread per context)",
+                      "windows_per_gpu_per_step": nwin, "samples_per_window": N, "sharding": f"windows/{world}", "launch": "single process",
+                      "devices": devices, "timed_region_s": round(dt, 3)},
+           "integer_lag_exact": bool(all(per_rank)),
+           "startup_s": {"to_first_step": round(t_ready - t_start, 2)},
+           "other_workload": {"workload": "xcorr, df supplied (code-phase only)" if other == "xcorr" else "processing(d,k) full chain",
+                              "value": round(world * nwin * N * a.steps / dt_other / 1e6, 2), "unit": "Msamples/s",
+                              "ms_per_step": round(dt_other / a.steps * 1e3, 3)},
+           "collective": {"op": "ncclAllGather (RCCL %d, ncclCommInitAll, one group call from the host process)" % info.rccl_version if info.rccl
+                                else "host-side concatenation (the device list repeats a device: RCCL has one rank per device)",
+                          "backend": "rccl" if info.rccl else "host", "world": world, "records": int(info.records_gathered),
+                          "bytes_per_rank": int(info.bytes_per_rank), "gather_ms_last": round(info.gather_ms, 3),
+                          "ranks_with_exact_lags": int(sum(per_rank)), "gathered_lag_exact": bool(all(per_rank)),
+                          "own_block_identical": bool(all(copies)), "all_ranks_agree": bool(all(copies) and all(per_rank)),
+                          "note": "every context's device copy of the gathered buffer was fetched and compared"}}
+    print(json.dumps(out))
+    m.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +299,8 @@ def main():
     ap.add_argument("--no-caf", action="store_true", help="skip the BASELINE.json configs[2] leg (delay x Doppler CAF of one window)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                     "multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--single-process", action="store_true", help="drive the --gpus N devices from THIS process through the library's "
+                    "twx_multi driver (host threads + RCCL inside the library) instead of one rank per GPU under torch.distributed.run")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the collectives even with one "
                     "rank (exercises the RCCL calls of the N > 1 path on a one-GPU box)")
     a = ap.parse_args()
@@ -208,6 +308,10 @@ def main():
 
     if a.cpu_baseline_child:
         cpu_baseline_child(a.cpu_windows, a.workload, a.cpu_max_workers)
+        return
+
+    if a.single_process:
+        single_process(a, t_start)
         return
 
     from amaranth_twstft_amd import launch
@@ -460,6 +564,18 @@ def main():
                                              f"{cpu['host_cores']} cores; one-off code-spectrum setup {cpu['setup_seconds']} s excluded)",
                                    "indice_matches_gpu": all(cpu["indices"][p] == int(arr[p].indice0) for p in range(min(n_cpu, nwin))),
                                    "variants": {k: cpu[k] for k in ("single_core", "all_cores", "scipy_fft_workers_all") if k in cpu}}
+            if "corrections" in cpu and a.workload == "processing":
+                # BASELINE.json's "delay err vs ref": the delay each window reports, (indice + correction) / ((2 Nint + 1) fs)
+                # (godual_ranging.m:96), GPU against the fp64 oracle on the windows the CPU leg processed
+                m = min(n_cpu, nwin)
+                derr = [abs((int(arr[p].indice0) + arr[p].correction) - (cpu["indices"][p] + cpu["corrections"][p])) / (3.0 * FS) for p in range(m)]
+                mrel = [abs(math.hypot(arr[p].xval[0], arr[p].xval[1]) - cpu["peak_mags"][p]) / cpu["peak_mags"][p] for p in range(m)]
+                out["delay_err_ps"] = round(max(derr) * 1e12, 4)
+                out["delay_err_vs_ref"] = {"max_ps": round(max(derr) * 1e12, 4), "mean_ps": round(sum(derr) / m * 1e12, 4), "windows": m,
+                                           "integer_lag_differences": int(sum(1 for p in range(m) if cpu["indices"][p] != int(arr[p].indice0))),
+                                           "peak_magnitude_max_rel_err": float("%.3g" % max(mrel)),
+                                           "ref": "oracle/twstft_oracle.py processing() in fp64 (the reference's numpy path), same windows",
+                                           "note": "one sample of the x3 grid = 66 667 ps; the gates are integer lag exact and |peak| within 1e-6"}
         else:
             out["cpu_baseline"] = cpu
     if rank == 0:

@@ -21,6 +21,15 @@
 //     [...] = twstft_processing_mex(raw_int16, nchan, chan, k_or_df, codeb, fs, Nint [, convention])
 //   chan  : 1-based channel, or 0 = every channel from one upload (outputs become nchan x n_windows)
 //
+// (C) a whole capture FILE (the file-in / delay-out contract of godual_ranging.m:70-103: every device reads its own extent):
+//     [...] = twstft_processing_mex('file', path, nchan, chan, k_or_df, codeb, fs, Nint [, convention] [, ngpu [, skip_samples [, max_windows]]])
+//   k_or_df: band ends, or ONE carrier offset for the whole file;  outputs nchan(or 1) x n_windows_processed
+//
+// ngpu (forms B and C, a trailing numeric argument after the optional convention string; default 1): the windows are cut
+// into ngpu contiguous blocks, one per device (devices 0..ngpu-1, wrapping where the box has fewer), each on its own host
+// thread inside the library, and the records come back through one RCCL all-gather (twx_multi_*, include/twstft_hip.h) —
+// the same outputs as with one GPU, record for record.
+//
 // indice is 1-based like Octave's max(); variances use Octave's N-1 normalisation.
 #if __has_include("mex.h")
 #include <string.h>
@@ -28,14 +37,19 @@
 #include "mex.h"
 #include "twstft_hip.h"
 
-static twx_ctx* g_ctx = nullptr;
+static twx_ctx* g_ctx = nullptr;          // ngpu == 1
+static twx_multi* g_multi = nullptr;      // ngpu > 1: one context + host thread per device
 static std::vector<uint8_t> g_chips;
 static double g_fs = 0;
-static int g_nint = -1, g_conv = -1;
+static int g_nint = -1, g_conv = -1, g_ngpu = 0;
 
 static void cleanup(void) {
     if (g_ctx) { twx_destroy(g_ctx); g_ctx = nullptr; }
+    if (g_multi) { twx_multi_destroy(g_multi); g_multi = nullptr; }
+    g_ngpu = 0;
 }
+static twx_ctx* any_ctx(void) { return g_multi ? twx_multi_context(g_multi, 0) : g_ctx; }
+static const char* last_error(void) { return g_multi ? twx_multi_last_error(g_multi) : twx_last_error(g_ctx); }
 
 static int parse_convention(const mxArray* a) {
     char b[32] = {0};
@@ -46,21 +60,23 @@ static int parse_convention(const mxArray* a) {
     return TWX_CONV_GODUAL;
 }
 
-static void ensure_context(const mxArray* codeb, double fs, int nint, int conv) {
+static void ensure_context(const mxArray* codeb, double fs, int nint, int conv, int ngpu = 1) {
     const size_t nchips = mxGetNumberOfElements(codeb);
     if (nchips == 0) mexErrMsgIdAndTxt("twstft:args", "empty code");
     std::vector<uint8_t> chips(nchips);
     const double* cd = mxIsDouble(codeb) ? mxGetPr(codeb) : nullptr;
     const uint8_t* cb = cd ? nullptr : (const uint8_t*)mxGetData(codeb);
     for (size_t i = 0; i < nchips; ++i) chips[i] = cd ? (uint8_t)cd[i] : cb[i];
-    if (g_ctx && chips == g_chips && fs == g_fs && nint == g_nint && conv == g_conv) return;   // cached across calls
+    if ((g_ctx || g_multi) && chips == g_chips && fs == g_fs && nint == g_nint && conv == g_conv && ngpu == g_ngpu) return;   // cached across calls
     cleanup();
     twx_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.fs = fs; cfg.sps = 2; cfg.nint = nint; cfg.chips = chips.data(); cfg.n_chips = (int64_t)nchips;
     cfg.convention = conv; cfg.precision = TWX_F32; cfg.var_ddof = 1 /* Octave var */; cfg.snr_rot = -1; cfg.device = -1;
-    if (twx_create(&cfg, &g_ctx)) mexErrMsgIdAndTxt("twstft:create", "%s", twx_last_error(nullptr));
-    g_chips = chips; g_fs = fs; g_nint = nint; g_conv = conv;
+    if (ngpu > 1) {
+        if (twx_multi_create(&cfg, nullptr, ngpu, 0, &g_multi)) mexErrMsgIdAndTxt("twstft:create", "%s", twx_multi_last_error(nullptr));
+    } else if (twx_create(&cfg, &g_ctx)) mexErrMsgIdAndTxt("twstft:create", "%s", twx_last_error(nullptr));
+    g_chips = chips; g_fs = fs; g_nint = nint; g_conv = conv; g_ngpu = ngpu;
     mexAtExit(cleanup);
     if (!mexIsLocked()) mexLock();             // once: `clear mex` can unload after the exit handler has run
 }
@@ -101,18 +117,53 @@ static void emit(int nlhs, mxArray* plhs[], const std::vector<twx_result>& res, 
 }
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
-    if (nrhs < 5) mexErrMsgIdAndTxt("twstft:args", "usage: (d, k_or_df, codeb, fs, Nint [, convention]) or (raw_int16, nchan, chan, k_or_df, codeb, fs, Nint [, convention])");
+    if (nrhs < 5) mexErrMsgIdAndTxt("twstft:args", "usage: (d, k_or_df, codeb, fs, Nint [, convention]) or (raw_int16, nchan, chan, k_or_df, codeb, fs, Nint [, convention] [, ngpu]) "
+                                                   "or ('file', path, nchan, chan, k_or_df, codeb, fs, Nint [, convention] [, ngpu [, skip_samples [, max_windows]]])");
+    const bool file_form = mxIsChar(prhs[0]);
     const bool raw_form = mxIsInt16(prhs[0]);
-    if (raw_form ? (nrhs != 7 && nrhs != 8) : (nrhs != 5 && nrhs != 6)) mexErrMsgIdAndTxt("twstft:args", "wrong number of inputs");
-    const int base = raw_form ? 3 : 1;                   // position of k_or_df
+    const int base = file_form ? 4 : raw_form ? 3 : 1;   // position of k_or_df
+    if (nrhs < base + 4) mexErrMsgIdAndTxt("twstft:args", "wrong number of inputs");
     const double fs = mxGetScalar(prhs[base + 2]);
     const int nint = (int)mxGetScalar(prhs[base + 3]);
-    const int conv = nrhs == base + 5 ? parse_convention(prhs[base + 4]) : TWX_CONV_GODUAL;
-    ensure_context(prhs[base + 1], fs, nint, conv);
+    int opt = base + 4;                                  // optional tail: convention string, then numbers
+    int conv = TWX_CONV_GODUAL;
+    if (opt < nrhs && mxIsChar(prhs[opt])) conv = parse_convention(prhs[opt++]);
+    double tail[3] = {1, -1, -1};                        // ngpu, skip_samples, max_windows
+    const int ntail = nrhs - opt;
+    if (ntail < 0 || ntail > (file_form ? 3 : raw_form ? 1 : 0)) mexErrMsgIdAndTxt("twstft:args", "wrong number of inputs");
+    for (int i = 0; i < ntail; ++i) {
+        if (mxIsChar(prhs[opt + i])) mexErrMsgIdAndTxt("twstft:args", "the convention string comes before ngpu");
+        tail[i] = mxGetScalar(prhs[opt + i]);
+    }
+    const int ngpu = (int)tail[0];
+    if (ngpu < 1 || ngpu > 64) mexErrMsgIdAndTxt("twstft:args", "ngpu must be 1..64");
+    ensure_context(prhs[base + 1], fs, nint, conv, ngpu);
     twx_info info;
-    twx_get_info(g_ctx, &info);
+    twx_get_info(any_ctx(), &info);
     twx_band band; std::vector<double> dfv;
-    if (raw_form) {
+    if (file_form) {
+        char what[16] = {0}, path[4096] = {0};
+        if (mxGetString(prhs[0], what, sizeof what) || strcmp(what, "file")) mexErrMsgIdAndTxt("twstft:args", "a string first argument must be 'file'");
+        if (!mxIsChar(prhs[1]) || mxGetString(prhs[1], path, sizeof path)) mexErrMsgIdAndTxt("twstft:args", "bad path");
+        const int nch = (int)mxGetScalar(prhs[2]);
+        const int ch = (int)mxGetScalar(prhs[3]) - 1;
+        if (nch < 1 || ch < -1 || ch >= nch) mexErrMsgIdAndTxt("twstft:args", "bad channel");
+        const int64_t skip = tail[1] > 0 ? (int64_t)tail[1] : 0;
+        FILE* f = fopen(path, "rb");
+        if (!f) mexErrMsgIdAndTxt("twstft:process", "cannot open %s", path);
+        fseek(f, 0, SEEK_END);
+        const int64_t have = ((int64_t)ftell(f) / (4 * nch) - skip) / info.n;
+        fclose(f);
+        const int64_t cap = have < 0 ? 0 : (tail[2] >= 0 && (int64_t)tail[2] < have ? (int64_t)tail[2] : have);
+        const size_t nco = ch < 0 ? (size_t)nch : 1;
+        std::vector<twx_result> res((size_t)(cap > 0 ? cap * nco : 1));
+        const bool est = parse_band_or_df(prhs[4], 1, &band, &dfv);
+        int64_t done = 0;
+        const int rc = g_multi ? twx_multi_process_file(g_multi, path, nch, ch, skip, est ? &band : nullptr, est ? 0.0 : dfv[0], res.data(), cap, &done)
+                               : twx_process_file(g_ctx, path, nch, ch, skip, est ? &band : nullptr, est ? 0.0 : dfv[0], res.data(), cap, &done);
+        if (rc) mexErrMsgIdAndTxt("twstft:process", "%s", last_error());
+        emit(nlhs, plhs, res, nco, (size_t)done, conv);
+    } else if (raw_form) {
         const int16_t* raw = (const int16_t*)mxGetData(prhs[0]);
         const int nch = (int)mxGetScalar(prhs[1]);
         const int ch = (int)mxGetScalar(prhs[2]) - 1;
@@ -121,8 +172,9 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         const size_t nco = ch < 0 ? (size_t)nch : 1;     // chan = 0: all channels, results [window][channel]
         std::vector<twx_result> res((size_t)(nwin > 0 ? nwin * nco : 1));
         const bool est = parse_band_or_df(prhs[3], (size_t)nwin * nco, &band, &dfv);
-        if (twx_process_windows(g_ctx, raw, nwin, nch, ch, est ? &band : nullptr, est ? nullptr : dfv.data(), res.data()))
-            mexErrMsgIdAndTxt("twstft:process", "%s", twx_last_error(g_ctx));
+        if (g_multi ? twx_multi_process_windows(g_multi, raw, nwin, nch, ch, est ? &band : nullptr, est ? nullptr : dfv.data(), res.data())
+                    : twx_process_windows(g_ctx, raw, nwin, nch, ch, est ? &band : nullptr, est ? nullptr : dfv.data(), res.data()))
+            mexErrMsgIdAndTxt("twstft:process", "%s", last_error());
         emit(nlhs, plhs, res, nco, (size_t)nwin, conv);
     } else {
         if (!mxIsDouble(prhs[0])) mexErrMsgIdAndTxt("twstft:args", "d must be a (complex) double vector or int16 raw samples");

@@ -1,6 +1,8 @@
 // mex_harness.cpp — runs the MEX gateway's mexFunction() for real, on top of tests/cpu/mex_fake/mex.h (no MATLAB/Octave):
 //   mex_harness raw     capture.bin chips.bin out.bin nchan chan  klo khi|df  fs Nint [convention]
 //   mex_harness complex capture.bin chips.bin out.bin nchan chan  klo khi|df  fs Nint [convention]
+//   mex_harness file    capture.bin chips.bin out.bin nchan chan  klo khi|df  fs Nint [convention] [ngpu=N] [skip=S] [max=M]
+// `raw` also takes a trailing ngpu=N (several devices from the one process, twx_multi_*); `file` hands over the PATH (call form C).
 // `raw` hands the int16 capture over as fread(...,'int16=>int16') would; `complex` does what the reference scripts do
 // before calling processing(): de-interleave one channel into a complex double column and remove each window's mean
 // (godual_ranging.m:77-80).  klo/khi are 1-based (find() output); "df <value>" passes a scalar carrier offset instead.
@@ -36,13 +38,24 @@ int main(int argc, char** argv) {
     else { kdf = mxCreateDoubleMatrix(1, 2, mxREAL); kdf->re[0] = atof(argv[ai]); kdf->re[1] = atof(argv[ai + 1]); ai += 2; }
     const double fs = atof(argv[ai]); const int nint = atoi(argv[ai + 1]); ai += 2;
     mxArray* conv = nullptr;
-    if (ai < argc) { conv = new mxArray; conv->cls = mxCHAR_CLASS; conv->str = argv[ai]; }
+    if (ai < argc && !strchr(argv[ai], '=')) { conv = new mxArray; conv->cls = mxCHAR_CLASS; conv->str = argv[ai]; ++ai; }
+    double ngpu = 0, skip = -1, maxw = -1;
+    for (; ai < argc; ++ai) {
+        if (!strncmp(argv[ai], "ngpu=", 5)) ngpu = atof(argv[ai] + 5);
+        else if (!strncmp(argv[ai], "skip=", 5)) skip = atof(argv[ai] + 5);
+        else if (!strncmp(argv[ai], "max=", 4)) maxw = atof(argv[ai] + 4);
+        else { fprintf(stderr, "unknown argument %s\n", argv[ai]); return 2; }
+    }
     mxArray* code = new mxArray; code->cls = mxUINT8_CLASS; code->m = chipb.size(); code->n = 1; code->u8 = chipb;
     const size_t nshort = cap.size() / 2;
     const int16_t* raw = reinterpret_cast<const int16_t*>(cap.data());
     std::vector<const mxArray*> in;
     mxArray* a0 = new mxArray;
-    if (mode == "raw") {
+    if (mode == "file") {
+        a0->cls = mxCHAR_CLASS; a0->str = "file";
+        mxArray* pa = new mxArray; pa->cls = mxCHAR_CLASS; pa->str = argv[2];
+        in = {a0, pa, scalar(nch), scalar(ch), kdf, code, scalar(fs), scalar(nint)};
+    } else if (mode == "raw") {
         a0->cls = mxINT16_CLASS; a0->m = nshort; a0->n = 1; a0->i16.assign(raw, raw + nshort);
         in = {a0, scalar(nch), scalar(ch), kdf, code, scalar(fs), scalar(nint)};
     } else {
@@ -61,6 +74,11 @@ int main(int argc, char** argv) {
         in = {a0, kdf, code, scalar(fs), scalar(nint)};
     }
     if (conv) in.push_back(conv);
+    if (ngpu > 0 || skip >= 0 || maxw >= 0) {
+        in.push_back(scalar(ngpu > 0 ? ngpu : 1));
+        if (skip >= 0 || maxw >= 0) in.push_back(scalar(skip >= 0 ? skip : 0));
+        if (maxw >= 0) in.push_back(scalar(maxw));
+    }
     mxArray* out[9] = {0};
     int nlhs = 9;
     try {

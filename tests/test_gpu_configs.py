@@ -194,6 +194,7 @@ def test_config4_two_station_wideband_chain_at_size():
             torch.cuda.synchronize()
             wide = (wide.to(torch.int32) + tmp.to(torch.int32)).clamp_(-32768, 32767).to(torch.int16).contiguous()
             del tmp
+            torch.cuda.synchronize()            # torch's stream wrote `wide`; the library's streams do not wait for it by themselves
             nar = torch.empty((N, 2), dtype=torch.int16, device=dev)
             narf = torch.empty((N, 2), dtype=torch.float32, device=dev)
             c32 = ctx[st][0]

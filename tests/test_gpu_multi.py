@@ -152,3 +152,46 @@ def test_script_level_job_single_process(tmp_path):
     assert mat.read_bytes()[128:] == ref_bytes
     rows = lambda s: [l for l in s.splitlines() if l[:1].isdigit() and "\t" in l]
     assert rows(many.stdout) == rows(one.stdout) and len(rows(one.stdout)) == 13
+
+
+def test_mex_gateway_ngpu_argument_and_file_form(tmp_path):
+    """twstft_processing_mex executed on the GPU (functional fake mex.h): call form B with a trailing ngpu = 3 and call form C
+    ('file', path, ...) with ngpu 1 and 4, skip and max_windows — every output equal to the one-GPU raw form, value for value."""
+    from tests.test_abi_and_host import build_mex_harness
+    from tests.test_gpu_configs import _read_mex_outputs
+    from tests.test_gpu_parity import _capture
+    exe = build_mex_harness(ROOT, tmp_path)
+    nchips, n, nwin = 10000, 20000, 7
+    chips, raw = _capture(14, 43, nchips, nwin, seed=64)
+    raw.tofile(tmp_path / "cap.bin")
+    chips.tofile(tmp_path / "chips.bin")
+    band = band_godual(FS, n)
+    common = [str(tmp_path / "cap.bin"), str(tmp_path / "chips.bin"), str(tmp_path / "out.bin"), "2"]
+    kk = [str(band[0] + 1), str(band[1] + 1)]
+
+    def run(mode, chan, *tail):
+        r = subprocess.run([str(exe), mode, *common, str(chan), *kk, "5e6", "1", *tail], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return _read_mex_outputs(tmp_path / "out.bin")
+
+    ref = run("raw", 0)
+    assert all(x.shape == (2, nwin) for x in ref)
+    for got in (run("raw", 0, "ngpu=3"), run("file", 0), run("file", 0, "ngpu=4"), run("file", 0, "godual", "ngpu=2")):
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+    part = run("file", 2, "ngpu=3", "skip=%d" % (2 * n), "max=4")              # channel 2, windows 2..5
+    assert all(x.shape == (1, 4) for x in part)
+    assert all(np.array_equal(a[0], b[1, 2:6]) for a, b in zip(part, ref))
+
+
+def test_bench_single_process_line():
+    """`python bench.py --gpus 4 --single-process`: four contexts driven from the one process (sharing GPU 0 on a one-GPU box),
+    the line carries the same `collective` object as the one-rank-per-GPU form and every context's gathered copy was checked."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--single-process", "--steps", "2", "--warmup", "1",
+                          "--windows", "9"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    c = j["collective"]
+    assert j["n_gpus"] == 4 and j["integer_lag_exact"] and j["value"] > 0 and j["config"]["launch"] == "single process"
+    assert c["world"] == 4 and c["records"] == 36 and c["ranks_with_exact_lags"] == 4 and c["gathered_lag_exact"] and c["all_ranks_agree"]
