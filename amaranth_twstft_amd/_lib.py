@@ -107,6 +107,32 @@ class twx_multi_info(C.Structure):
                 ("records_gathered", C.c_int64), ("bytes_per_rank", C.c_int64), ("gather_ms", C.c_double)]
 
 
+class twx_rx_row(C.Structure):
+    _fields_ = [("ch", C.c_char), ("mode", C.c_char), ("reserved", C.c_int16), ("pn", C.c_int32), ("fc_init", C.c_double), ("kcps", C.c_int32),
+                ("reserved2", C.c_int32), ("fltkhz", C.c_double), ("frange", C.c_double), ("fstep", C.c_double), ("snr_min_db", C.c_double),
+                ("code", C.POINTER(C.c_uint8)), ("code_len", C.c_int64)]
+
+
+class twx_rx_config(C.Structure):
+    _fields_ = [("fs_in", C.c_double), ("ninterp", C.c_int32), ("dec_a", C.c_int32), ("code_dir", C.c_char_p), ("out_dir", C.c_char_p),
+                ("seed", C.c_uint64), ("acq_block", C.c_int32), ("device", C.c_int32)]
+
+
+class twx_rx_report(C.Structure):
+    _fields_ = [("status", C.c_int32), ("cnt", C.c_int32), ("fc", C.c_double), ("df", C.c_double), ("phi", C.c_double), ("gd", C.c_double),
+                ("dg", C.c_double), ("sdgd", C.c_double), ("pk", C.c_double), ("px", C.c_double), ("pt", C.c_int64), ("acq_idx", C.c_int64),
+                ("n_trials", C.c_int64), ("dat_row", C.c_char * 128)]
+
+
+class twx_rx_channel_info(C.Structure):
+    _fields_ = [("pn", C.c_int32), ("is_chA", C.c_int32), ("clen", C.c_int32), ("nlag", C.c_int32), ("bps", C.c_int32), ("reserved", C.c_int32),
+                ("nobs", C.c_int64), ("nfft", C.c_int64), ("duration", C.c_double), ("range", C.c_double), ("step", C.c_double),
+                ("snr_min", C.c_double), ("psbb", C.c_double), ("dat_name", C.c_char * 64)]
+
+
+TWX_RX_NO_SIGNAL, TWX_RX_ACQUIRED, TWX_RX_CODE_LOCK, TWX_RX_TRACKED, TWX_RX_ACQ_FAILED, TWX_RX_LOCK_LOST = range(6)
+
+
 class twx_prof_entry(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("ms_total", C.c_double), ("launches", C.c_int64), ("units", C.c_int64)]
 
@@ -168,6 +194,19 @@ SYMBOLS = {
     "twx_multi_process_windows": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
     "twx_multi_process_windows_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
     "twx_multi_fetch_gathered": (C.c_int, [_VP, C.c_int32, _VP, C.c_int64]),
+    "twx_set_code_spectrum_dev": (C.c_int, [_VP, _VP]),
+    "twx_fft_forward_dev": (C.c_int, [_VP, _VP, _VP]),
+    "twx_sliding_dot_cdev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_double, C.c_double, C.c_double, _VP]),
+    "twx_track_epoch_cdev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_double, C.POINTER(twx_track_state), C.POINTER(twx_track_result)]),
+    "twx_rx_parse_param": (C.c_int, [C.c_char_p, C.POINTER(twx_rx_row), C.c_int32]),
+    "twx_rx_create": (C.c_int, [C.POINTER(twx_rx_config), C.POINTER(twx_rx_row), C.c_int32, C.POINTER(_VP)]),
+    "twx_rx_destroy": (None, [_VP]),
+    "twx_rx_last_error": (C.c_char_p, [_VP]),
+    "twx_rx_channel": (C.c_int, [_VP, C.c_int32, C.POINTER(twx_rx_channel_info)]),
+    "twx_rx_second": (C.c_int, [_VP, _VP, C.POINTER(twx_rx_report)]),
+    "twx_rx_second_dev": (C.c_int, [_VP, _VP, C.POINTER(twx_rx_report)]),
+    "twx_rx_file": (C.c_int, [_VP, C.c_char_p, C.c_int64, C.POINTER(twx_rx_report), C.c_int64, C.POINTER(C.c_int64)]),
+    "twx_rx_stream_dev": (_VP, [_VP, C.c_int32]),
     "twx_debug_stamps": (C.c_int, [_VP, _VP, C.c_longlong]),
     "twx_profile_reset": (C.c_int, [_VP]),
     "twx_profile_get": (C.c_int, [_VP, C.POINTER(twx_prof_entry), C.c_int32, C.POINTER(C.c_int32)]),

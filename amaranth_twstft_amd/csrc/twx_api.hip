@@ -166,6 +166,27 @@ __global__ void k_convert(const cpx<S>* __restrict__ in, cpx<D>* __restrict__ ou
         out[i] = mk<D>((D)(in[i].x * scale), (D)(in[i].y * scale));
 }
 
+// spectrum layouts: the row pass leaves bin k = k1 + N1*k2 at [k1][k2]; hosts and the replica set-up of the DLL/PLL receiver
+// (twx_rx.hip) speak natural order.  k_spec_to_natural: [k1][k2] (context precision) -> natural complex double;
+// k_spec_from_natural: natural complex double x scale -> [k1][k2] (context precision).
+template <typename T>
+__global__ void k_spec_to_natural(const cpx<T>* __restrict__ in, cpx<double>* __restrict__ out, int n1, int n2) {
+    const long long n = (long long)n1 * n2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long k1 = i / n2, k2 = i % n2;                    // coalesced reads, strided writes (set-up path)
+        out[k1 + (long long)n1 * k2] = mk<double>((double)in[i].x, (double)in[i].y);
+    }
+}
+template <typename T>
+__global__ void k_spec_from_natural(const cpx<double>* __restrict__ in, cpx<T>* __restrict__ out, int n1, int n2, double scale) {
+    const long long n = (long long)n1 * n2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long k1 = i / n2, k2 = i % n2;
+        const cpx<double> v = in[k1 + (long long)n1 * k2];
+        out[i] = mk<T>((T)(v.x * scale), (T)(v.y * scale));
+    }
+}
+
 // every dec-th sample of a complex-float stream -> contiguous (downconv_acq reads smp[i*dec], rxcomplex.cpp:1039-1049)
 __global__ void k_stride_copy(const cpx<float>* __restrict__ in, cpx<float>* __restrict__ out, long long n, int dec) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -434,6 +455,8 @@ struct CtxBase {
     virtual int process_complex(const double* re, const double* im, long long stride, long long nwin, const twx_band* band,
                                 const double* df, twx_result* out) = 0;
     virtual int set_code_spectrum(const double* spec) = 0;
+    virtual int set_code_spectrum_dev(const void* spec_dev) = 0;
+    virtual int fft_forward_dev(const void* in_dev, void* out_dev) = 0;
     virtual int xcorr_map_dev(const void* iq_dev, int nch, int ch, double df, void* out_dev) = 0;
     virtual int caf_freqs_cdev(const void* d_dev, const double* freqs, long long nf, int flags, twx_result* out) = 0;
     virtual int acquire_cdev(const void* d_dev, double fc0, double frange, double fstep, long long ptmod, int flags, twx_acq_result* out) = 0;
@@ -1399,6 +1422,37 @@ template <typename T> struct Ctx : CtxBase {
         snr_valid = 0;
         return TWX_OK;
     }
+    // the same from DEVICE memory (natural order, complex doubles): no host pass over the spectrum
+    int set_code_spectrum_dev(const void* spec_dev) override {
+        if (int rc = sync_all()) return rc;
+        use_slot(0);
+        TWX_LAUNCH((k_spec_from_natural<T>), dim3(2048), dim3(256), stream, reinterpret_cast<const cpx<double>*>(spec_dev), cspec, N1, N2, scale_pow2);
+        HIPCHK(hipGetLastError());
+        if (use_rowd) {
+            const int Rr = row->R[row->S - 1], R0 = row->S == 3 ? row->R[0] : 1;
+            TWX_LAUNCH((k_cspec_perm<T>), dim3(N1), dim3(256), stream, cspec, cspec_perm, N1, N2, R0, Rr);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        snr_valid = 0;
+        return TWX_OK;
+    }
+    // forward transform of N complex doubles, device to device, natural order out (asynchronous on the context's stream;
+    // in_dev and out_dev may be the same buffer)
+    int fft_forward_dev(const void* in_dev, void* out_dev) override {
+        if (int rc = sync_all()) return rc;
+        use_slot(0);
+        C* tmp = A; C* spec = Bz;                                   // the batch buffers of slot 0 hold at least one window each
+        ColFwdArgs<T> ca{};
+        ca.n = N; ca.n2 = N2; ca.ntiles = ntiles; ca.nwin = 1; ca.tw1 = tw1; ca.ta = ta; ca.tb = tb; ca.tshift = tshift; ca.tc = tcw; ca.out = tmp;
+        if (col->fwd(COL_PLAIN, IN_C64, in_dev, 0, &ca, (unsigned)ntiles, stream)) return fail(TWX_E_HIP, "col pass launch failed");
+        RowArgs<T> ra{};
+        ra.n = N; ra.n1 = N1; ra.nwin = 1; ra.A = tmp; ra.wshift = wshift_of(col->W); ra.stab_f = stab_f; ra.stab_i = stab_i; ra.spec_out = spec;
+        if (row->run(ROW_STORE, &ra, (unsigned)N1, stream)) return fail(TWX_E_HIP, "row pass launch failed");
+        TWX_LAUNCH((k_spec_to_natural<T>), dim3(2048), dim3(256), stream, (const C*)spec, reinterpret_cast<cpx<double>*>(out_dev), N1, N2);
+        HIPCHK(hipGetLastError());
+        return TWX_OK;
+    }
     int xcorr_map_dev(const void* iq_dev, int nch, int ch, double df, void* out_dev) override {
         if (int rc = sync_all()) return rc;
         use_slot(0);
@@ -1759,6 +1813,16 @@ int twx_set_code_spectrum(twx_ctx* ctx, const double* spec) {
     if (!ctx || !spec) return TWX_E_ARG;
     (void)hipSetDevice(ctx->impl->dev);
     return guarded(ctx->impl, [&]() { return ctx->impl->set_code_spectrum(spec); });
+}
+int twx_set_code_spectrum_dev(twx_ctx* ctx, const void* spec_dev) {
+    if (!ctx || !spec_dev) return TWX_E_ARG;
+    (void)hipSetDevice(ctx->impl->dev);
+    return guarded(ctx->impl, [&]() { return ctx->impl->set_code_spectrum_dev(spec_dev); });
+}
+int twx_fft_forward_dev(twx_ctx* ctx, const void* in_dev, void* out_dev) {
+    if (!ctx || !in_dev || !out_dev) return TWX_E_ARG;
+    (void)hipSetDevice(ctx->impl->dev);
+    return guarded(ctx->impl, [&]() { return ctx->impl->fft_forward_dev(in_dev, out_dev); });
 }
 int twx_xcorr_map_dev(twx_ctx* ctx, const void* iq_dev, int32_t n_channels, int32_t channel, double df, void* out_dev) {
     if (!ctx || !iq_dev || !out_dev || n_channels < 1 || channel < 0 || channel >= n_channels) return TWX_E_ARG;

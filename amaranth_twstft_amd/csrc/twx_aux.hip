@@ -37,8 +37,12 @@ struct SdRot { float2 r[SD_NPASS]; };                            // exp(-2 pi j 
 // ds_read_b32).  The NCO is evaluated once per lane and PIECE (fp64 phase reduction + sincospi); a pass multiplies it by
 // the pass's rotation exp(-2 pi j ff 1024 k) from a 16-entry table in the kernel arguments (evaluated on the host in fp64), and the four samples of the pass
 // are stepped by the fp32 rotation exp(-2 pi j ff): three roundings on top of the table's (3e-7 relative at most).
-template <int NLAG>
-__global__ __launch_bounds__(SD_NT, 2) void k_sliding_dot(const short2* __restrict__ x, int nch, long long pt, long long nobs, int nlag, int chunk_len,
+// XT = short2: interleaved int16 IQ of a capture; XT = float2: complex-float samples (the x2-interpolated stream the DLL/PLL
+// receiver tracks on, rxcomplex.cpp:477,602: dev_smp)
+__device__ __forceinline__ void sd_opaque(short2& v) { unsigned t = *reinterpret_cast<const unsigned*>(&v); asm volatile("" : "+v"(t)); v = *reinterpret_cast<const short2*>(&t); }
+__device__ __forceinline__ void sd_opaque(float2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+template <int NLAG, typename XT>
+__global__ __launch_bounds__(SD_NT, 2) void k_sliding_dot(const XT* __restrict__ x, int nch, long long pt, long long nobs, int nlag, int chunk_len,
                                                        const float* __restrict__ w, double ff, double phi, float scale, float rot_c, float rot_s,
                                                        SdRot rot, double* __restrict__ partial /*[ncodes][chunks][2*nlag+1][2]*/) {
     constexpr int NL = 2 * NLAG + 1;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(SD_NT, 2) void k_sliding_dot(const short2* __restri
     // the samples of the NEXT pass are requested before this pass's arithmetic (two waves per SIMD do not hide a global
     // load round trip per pass by themselves); loads are unconditional with clamped indices, values masked below
     const long long ilast = (long long)p * nobs + s0 + cnt - 1;
-    short2 nx[SD_T];
+    XT nx[SD_T];
     {
         const long long i0 = (long long)p * nobs + s0 + (long long)SD_T * min(tid, ngrp - 1);
 #pragma unroll
@@ -103,14 +107,13 @@ __global__ __launch_bounds__(SD_NT, 2) void k_sliding_dot(const short2* __restri
     int pass = 0;
     for (int g = tid; g < ngrp; g += SD_NT, ++pass) {
         const int t0 = SD_T * g;
-        short2 sm[SD_T];
+        XT sm[SD_T];
 #pragma unroll
         for (int j = 0; j < SD_T; ++j) {
             // opaque hand-over: otherwise the conversion to float moves up behind the load in the PREVIOUS pass (the loop then
             // carries floats) and that pass waits for the samples it asked for a few hundred cycles earlier
-            unsigned t = *reinterpret_cast<const unsigned*>(&nx[j]);
-            asm volatile("" : "+v"(t));
-            sm[j] = *reinterpret_cast<const short2*>(&t);
+            sm[j] = nx[j];
+            sd_opaque(sm[j]);
         }
         const float2 pr = rot.r[pass];                             // kernel argument, uniform index: a scalar load
         float cs = bcs * pr.x - bsn * pr.y, sn = bcs * pr.y + bsn * pr.x;
@@ -223,7 +226,8 @@ int sliding_chunk(long long nobs, int ncodes) {
     len = std::max<long long>(4096, ((len + SD_NT * SD_T - 1) / (SD_NT * SD_T)) * (SD_NT * SD_T));
     return (int)std::min<long long>(len, 1ll << 24);
 }
-int launch_sliding(hipStream_t st, const short2* dx, int nch, long long pt, long long nobs, int ncodes, int nlag, const float* dw,
+template <typename XT>
+int launch_sliding(hipStream_t st, const XT* dx, int nch, long long pt, long long nobs, int ncodes, int nlag, const float* dw,
                    double ff, double phi, double scale, double* dpart, double* dout) {
     const int clen = sliding_chunk(nobs, ncodes);
     const int nchunks = (int)((nobs + clen - 1) / clen);
@@ -236,7 +240,7 @@ int launch_sliding(hipStream_t st, const short2* dx, int nch, long long pt, long
         a -= rint(a);
         rot.r[k] = make_float2((float)cos(two_pi * a), (float)(-sin(two_pi * a)));
     }
-#define SD_GO(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, rot, dpart)
+#define SD_GO(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_, XT>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, rot, dpart)
     if (nlag <= 4) SD_GO(4); else if (nlag <= 8) SD_GO(8); else if (nlag <= 16) SD_GO(16); else if (nlag <= 28) SD_GO(28); else SD_GO(31);
 #undef SD_GO
     if (hipGetLastError() != hipSuccess) return TWX_E_HIP;
@@ -490,6 +494,17 @@ static int twx_sliding_dot_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n_
     return rc ? twx::ctx_fail(ctx, rc, "twx_sliding_dot_dev: launch failed") : TWX_OK;
 }
 
+static int twx_sliding_dot_cdev_impl(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, int64_t pt, int64_t nobs, int32_t ncodes, int32_t nlag,
+                                     const float* replica_dev, double ff, double phi, double scale, double* out_dev) {
+    if (!ctx) return TWX_E_ARG;
+    if (!sliding_args_ok(smp_dev, replica_dev, out_dev, 1, 0, nobs, ncodes, nlag, pt, n_samples)) return twx::ctx_fail(ctx, TWX_E_ARG, "twx_sliding_dot_cdev: bad argument");
+    if (int rc = twx::ctx_set_device(ctx)) return rc;
+    double* dpart = static_cast<double*>(twx::ctx_scratch(ctx, 0, sliding_part_bytes(nobs, ncodes, nlag)));
+    if (!dpart) return TWX_E_NOMEM;
+    const int rc = launch_sliding(twx::ctx_stream(ctx), reinterpret_cast<const float2*>(smp_dev), 1, pt, nobs, ncodes, nlag, replica_dev, ff, phi, scale, dpart, out_dev);
+    return rc ? twx::ctx_fail(ctx, rc, "twx_sliding_dot_cdev: launch failed") : TWX_OK;
+}
+
 static int twx_fir_decimate_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps, int32_t ntaps,
                          int32_t dec, void* out_i16_dev, void* out_f32_dev, int64_t* n_out) {
     if (!ctx) return TWX_E_ARG;
@@ -586,6 +601,7 @@ int track_update_impl(const double* cor, const double* phi, int bps, int nlag, t
             ++cnt;
         }
     }
+    out->cnt = cnt;                                                                      // what the "lock lost" line prints (:787)
     if (!(cnt * 2 > bps)) return TWX_OK;                                                 // :667: not enough usable periods
     std::vector<double> sel;
     for (int p = 0; p < bps; ++p) if (w[(size_t)p] > 0.0) sel.push_back(res_gd[(size_t)p]);          // :692-698
@@ -607,7 +623,7 @@ int track_update_impl(const double* cor, const double* phi, int bps, int nlag, t
     }
     // fewer than two periods left (or all at one time tag): the weighted line through them has no slope — the program would
     // write NaN into fc / df / pt; here the epoch counts as unusable and the state stays as it was
-    if (cnt < 2) return TWX_OK;
+    if (cnt < 2) { out->cnt = cnt; return TWX_OK; }
     st->last_phi = last_phi;
     double c0, c1, chi;
     fit_wlinear(ttag_phi, w, res_phi, &c0, &c1, &chi);                                   // :728
@@ -632,7 +648,8 @@ int track_update_impl(const double* cor, const double* phi, int bps, int nlag, t
 }  // namespace
 
 static int twx_track_epoch_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t nobs,
-                                    int32_t bps, int32_t nlag, const float* replica_dev, double scale, twx_track_state* st, twx_track_result* out) {
+                                    int32_t bps, int32_t nlag, const float* replica_dev, double scale, twx_track_state* st, twx_track_result* out,
+                                    bool complex_float = false) {
     if (!ctx) return TWX_E_ARG;
     if (!st || !out || bps < 2 || nlag < 2 || nlag > 31 || !(st->fs > 0)) return twx::ctx_fail(ctx, TWX_E_ARG, "twx_track_epoch_dev: bad argument");
     const int ncodes = bps - 1, nl = 2 * nlag + 1;
@@ -640,7 +657,8 @@ static int twx_track_epoch_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n_
     double* res_dev = static_cast<double*>(twx::ctx_scratch(ctx, 6, (size_t)ncodes * nl * 16));
     if (!res_dev) return TWX_E_NOMEM;
     const double ph0 = fmod((double)st->pt * st->fc / st->fs, 1.0);                      // :594
-    if (int rc = twx_sliding_dot_dev_impl(ctx, iq_dev, n_samples, n_channels, channel, st->pt, nobs, ncodes, nlag, replica_dev, st->fc / st->fs, ph0, scale, res_dev)) return rc;
+    if (int rc = complex_float ? twx_sliding_dot_cdev_impl(ctx, iq_dev, n_samples, st->pt, nobs, ncodes, nlag, replica_dev, st->fc / st->fs, ph0, scale, res_dev)
+                               : twx_sliding_dot_dev_impl(ctx, iq_dev, n_samples, n_channels, channel, st->pt, nobs, ncodes, nlag, replica_dev, st->fc / st->fs, ph0, scale, res_dev)) return rc;
     std::vector<double> res((size_t)ncodes * nl * 2), cor((size_t)ncodes * nl), ph((size_t)ncodes * nl);
     hipStream_t s = twx::ctx_stream(ctx);
     if (hipMemcpyAsync(res.data(), res_dev, res.size() * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
@@ -666,6 +684,14 @@ extern "C" {
 int twx_sliding_dot_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t pt, int64_t nobs,
                         int32_t ncodes, int32_t nlag, const float* replica_dev, double ff, double phi, double scale, double* out_dev) {
     return aux_guard([&]() { return twx_sliding_dot_dev_impl(ctx, iq_dev, n_samples, n_channels, channel, pt, nobs, ncodes, nlag, replica_dev, ff, phi, scale, out_dev); });
+}
+int twx_sliding_dot_cdev(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, int64_t pt, int64_t nobs, int32_t ncodes, int32_t nlag,
+                         const float* replica_dev, double ff, double phi, double scale, double* out_dev) {
+    return aux_guard([&]() { return twx_sliding_dot_cdev_impl(ctx, smp_dev, n_samples, pt, nobs, ncodes, nlag, replica_dev, ff, phi, scale, out_dev); });
+}
+int twx_track_epoch_cdev(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, int64_t nobs, int32_t bps, int32_t nlag, const float* replica_dev,
+                         double scale, twx_track_state* state, twx_track_result* out) {
+    return aux_guard([&]() { return twx_track_epoch_dev_impl(ctx, smp_dev, n_samples, 1, 0, nobs, bps, nlag, replica_dev, scale, state, out, true); });
 }
 int twx_fir_decimate_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps, int32_t ntaps,
                          int32_t dec, void* out_i16_dev, void* out_f32_dev, int64_t* n_out) {

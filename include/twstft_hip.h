@@ -198,6 +198,11 @@ int twx_xcorr_map(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t c
  * pass-band mask and 1/n^2 of cross_spectrum (:1001-1018) — and how the x2 interpolation of short2double (:914-963)
  * becomes a 2-phase "correlation" with a weight vector.  The wipe-off statistics are undefined afterwards (NaN). */
 int twx_set_code_spectrum(twx_ctx* ctx, const double* spec);
+/* The same with spec in DEVICE memory (N complex doubles, natural order), and the context's forward transform device to
+ * device: N complex doubles in, N complex doubles out in natural order (in_dev == out_dev allowed; asynchronous on the
+ * context's stream).  The replica set-up of the DLL/PLL receiver (twx_rx_*, rxcomplex.cpp:414-437) is made of these. */
+int twx_set_code_spectrum_dev(twx_ctx* ctx, const void* spec_dev);
+int twx_fft_forward_dev(twx_ctx* ctx, const void* in_dev, void* out_dev);
 /* prnmap of ONE window of a DEVICE-resident int16 capture into DEVICE memory: nphase*N complex floats (re, im),
  * normalised like ifft (1/(nphase*N)), natural order.  No mean removal when TWX_OPT_REMOVE_MEAN is 0. */
 int twx_xcorr_map_dev(twx_ctx* ctx, const void* iq_dev, int32_t n_channels, int32_t channel, double df, void* out_dev);
@@ -302,6 +307,84 @@ int twx_sliding_dot_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int
                         double* out_dev);
 int twx_fir_decimate_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps,
                          int32_t ntaps, int32_t dec, void* out_i16_dev, void* out_f32_dev, int64_t* n_out);
+
+/* twx_sliding_dot_dev / twx_track_epoch_dev on complex FLOAT samples resident in DEVICE memory (smp_dev: n_samples x (re, im)
+ * float32) — the x2-interpolated stream ci.dev_smp that rxcomplex.cpp tracks on (:477,602). */
+int twx_sliding_dot_cdev(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, int64_t pt, int64_t nobs, int32_t ncodes, int32_t nlag,
+                         const float* replica_dev, double ff, double phi, double scale, double* out_dev);
+int twx_track_epoch_cdev(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, int64_t nobs, int32_t bps, int32_t nlag,
+                         const float* replica_dev, double scale, twx_track_state* state, twx_track_result* out);
+
+/* The DLL/PLL receiver as a program: sdr.param in, ch?.pn??.????kcps.dat rows out -------------------------------------
+ * Replaces experiments/231001_DLL_PLL/rxcomplex.cpp as a whole (everything between reading the parameter file and the
+ * rows it appends): the parameter parser and per-channel set-up (:263-460 — PRN_sampling :965-978, memcpy_acq :980-987,
+ * lowpass :1020-1037, the replica FFT :434-437, psbb :431-432, all on the device), and the per-second loop (:463-835):
+ * short2double x2 interpolation of both physical channels (:914-963), received power (:481-489), per channel either the
+ * acquisition sweep with its SNR gate (:521-586) or one tracking epoch (:589-790) with the is_trk / is_first hand-over,
+ * the .dat rows (:724-754) and the rxcomplex.log lines (:439-443,580-584,757-781).
+ * Differences, all stated: the program draws the acquisition offset with rand() seeded by time(NULL) (:240,529) — here a
+ * generator seeded by cfg.seed (or a fixed block), reported per second; 'S' (SIC) rows are refused: their code is commented
+ * out in rxcomplex.cpp:508-519,539-541,596-598; codes come from <code_dir>/<pn-100>.bin as SDRcode does (:866-884) or from
+ * the row's own pointer.  A twx_rx is not thread-safe. */
+typedef struct twx_rx twx_rx;
+typedef struct twx_rx_row {        /* one row of sdr.param: chA_or_B Sic_or_Normal PRN_no. center_freq chip_rate LPF_cutoff range step least_SNR */
+    char ch, mode;                 /* 'A' | 'B',  'N' (| 'S': refused) */
+    int16_t reserved;
+    int32_t pn;                    /* 100.. : 100 000-chip SDR codes, 40 ms (:305-311); < 100: 10 000 chips, 4 ms (:299-304) */
+    double fc_init;                /* Hz */
+    int32_t kcps;                  /* 2500 */
+    int32_t reserved2;
+    double fltkhz, frange, fstep, snr_min_db;
+    const uint8_t* code;           /* NULL: read <code_dir>/<pn-100>.bin (pn >= 100); else code_len bytes 0/1 */
+    int64_t code_len;
+} twx_rx_row;
+typedef struct twx_rx_config {
+    double fs_in;                  /* sample rate of the capture, 5e6 (sps / Ninterp, :33) */
+    int32_t ninterp;               /* 2 (:29) */
+    int32_t dec_a;                 /* 1: X310 build, 2: N210/B210 build (:226-231) */
+    const char* code_dir;          /* where 0.bin, 1.bin live (NULL: current directory) */
+    const char* out_dir;           /* where the .dat files and rxcomplex.log are appended (NULL: no files, reports only) */
+    uint64_t seed;                 /* generator of the acquisition offset */
+    int32_t acq_block;             /* >= 0: the offset is always this many code periods (idx = acq_block * nobs) */
+    int32_t device;                /* -1 = current */
+} twx_rx_config;
+enum { TWX_RX_NO_SIGNAL = 0,       /* searched, gate not passed (:573) */
+       TWX_RX_ACQUIRED = 1,        /* gate passed this second: "analyzing" (:574-585) */
+       TWX_RX_CODE_LOCK = 2,       /* first tracking epoch after acquisition: state updated, no row yet (:757-767) */
+       TWX_RX_TRACKED = 3,         /* tracking epoch with a .dat row (:724-754) */
+       TWX_RX_ACQ_FAILED = 4,      /* first epoch had too few usable periods (:777-781) */
+       TWX_RX_LOCK_LOST = 5 };     /* a later epoch had too few usable periods (:783-789) */
+typedef struct twx_rx_report {     /* one channel, one second */
+    int32_t status, cnt;           /* TWX_RX_*; usable code periods of the epoch */
+    double fc, df, phi;            /* carrier (Hz, integer part), its fraction, phase (cycles) */
+    double gd, dg, sdgd;           /* code phase (ns), its rate (ns/s), scatter (ns) */
+    double pk, px;                 /* signal power, received power (V^2) */
+    int64_t pt;                    /* code phase in samples of the interpolated stream */
+    int64_t acq_idx, n_trials;     /* acquisition: sample offset used, trial carriers evaluated (else 0) */
+    char dat_row[128];             /* TWX_RX_TRACKED: the row appended to ch<A|B>.pn<id>.<kcps>kcps.dat, newline included */
+} twx_rx_report;
+typedef struct twx_rx_channel_info {
+    int32_t pn, is_chA, clen, nlag, bps, reserved;
+    int64_t nobs, nfft;
+    double duration, range, step, snr_min, psbb;
+    char dat_name[64];
+} twx_rx_channel_info;
+/* Parses a parameter file with the program's own rules (:263-296: '#' comments, 9 tokens, the value ranges of :288;
+ * rows that fail them are skipped as the program skips them); returns the number of rows stored (<= max_rows) or < 0. */
+int twx_rx_parse_param(const char* path, twx_rx_row* rows, int32_t max_rows);
+int twx_rx_create(const twx_rx_config* cfg, const twx_rx_row* rows, int32_t n_rows, twx_rx** out);
+void twx_rx_destroy(twx_rx* rx);
+const char* twx_rx_last_error(const twx_rx* rx);               /* rx may be NULL: last create error */
+int twx_rx_channel(const twx_rx* rx, int32_t i, twx_rx_channel_info* info);
+/* One pass of the loop body :468-832 on one second of capture: fs_in frames [IA QA IB QB] of int16 in HOST (iq) or DEVICE
+ * (iq_dev) memory; reports[n_rows]. */
+int twx_rx_second(twx_rx* rx, const int16_t* iq, twx_rx_report* reports);
+int twx_rx_second_dev(twx_rx* rx, const void* iq_dev, twx_rx_report* reports);
+/* The program's main loop over a capture file (`./rxcomplex data.bin sdr.param`): whole seconds until the file ends or
+ * max_seconds; reports (may be NULL) receives n_rows records per second, capacity report_seconds seconds. */
+int twx_rx_file(twx_rx* rx, const char* path, int64_t max_seconds, twx_rx_report* reports, int64_t report_seconds, int64_t* n_seconds);
+/* Device pointer to the interpolated stream of physical channel 0 (A) / 1 (B) of the last second (fs_in*ninterp complex floats). */
+const void* twx_rx_stream_dev(const twx_rx* rx, int32_t physical_channel);
 
 /* Tracked multi-code ranging: a whole capture in, per-code delay records out ---------------------------------
  * Replaces the capture loops of the three production scripts, everything between fopen and `save`:

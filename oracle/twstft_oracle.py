@@ -22,7 +22,7 @@ Parity pinning (see tests/golden/README.md, tools/make_golden.py):
   * The reference holds NO test vectors of its own for the correlator, and the
     Octave-only variants (``processing_claudio``, ``search_df``, ``ranging_tracked``, ``go_1s_session``, the QPSK form of ``make_code_variant``,
     ``peak_refine_polyfit``), the C++-only Hamming window
-    and the 231001_DLL_PLL acquisition/tracking restatements have no runnable twin here:
+    and the 231001_DLL_PLL acquisition/tracking restatements (incl. the receiver program ``rx_second``) have no runnable twin here:
     for those functions parity is UNPINNED (hand restatement, cross-checked by identities).
 """
 from __future__ import annotations
@@ -874,6 +874,7 @@ def rx_track_epoch(smp, wav_t, st: dict, nobs: int, bps: int, nlag: int, fs: flo
                          + float(pt + k - nlag)) * 1.0e+9 / fs                        # :649-659
             w[p] = 1.0
             cnt += 1
+    st["cnt_last"] = cnt                                                              # what the "lock lost" line prints (:787)
     if not cnt * 2 > bps:                                                             # :667
         return None
     sel = [res_gd[p] for p in range(bps) if w[p] > 0.0]                               # :692-698
@@ -904,6 +905,130 @@ def rx_track_epoch(smp, wav_t, st: dict, nobs: int, bps: int, nlag: int, fs: flo
                gd=g0 + 0.5 * g1, dg=g1, pk=float(np.mean(ps[w > 0.0])))              # :740-742, average() :887-901
     st["pt_prev"] = pt
     st["pt"] = int(np.floor((g0 + g1) * fs / 1.0e+9 + 0.5)) if (g0 + g1) >= 0 else -int(np.floor(-(g0 + g1) * fs / 1.0e+9 + 0.5))   # round() :744
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# The receiver as a program, experiments/231001_DLL_PLL/rxcomplex.cpp:263-835 — UNPINNED (same reason as above): parameter
+# parser, per-channel set-up, the per-second loop with the acquisition -> tracking hand-over, the text of the .dat rows and of
+# the rxcomplex.log lines.  Checker of twx_rx_* (tests/test_gpu_rx.py, tests/test_rx_host.py).
+# --------------------------------------------------------------------------------------------
+
+def rx_v2todbm(v2: float) -> float:
+    """``v2todBm`` :1236-1240."""
+    return 10.0 * np.log10(v2 * 1000.0 / 25.0) if v2 > 0.0 else 0.0
+
+
+def rx_parse_param(lines):
+    """The parameter-file loop :263-296: '#' lines skipped (:267), 9 tokens split on " ;\r\n" (:270-273), ``str[0]`` in A/B and
+    ``str[2]`` in N/S (:274), the ``sscanf`` of :280 and the value ranges of :288 (rows outside them are skipped).  Returns dicts
+    ``ch mode pn fc_init kcps fltkhz frange fstep snr_min_db``."""
+    import re
+    rows = []
+    for line in lines:
+        if line[:1] == "#":
+            continue
+        toks = [t for t in re.split(r"[ ;\r\n]+", line) if t]
+        if len(line) < 3 or line[0] not in "AB" or line[2] not in "NS" or len(toks) != 9:
+            continue
+        # sscanf(str, "%s %s %d %lf %d %lf %lf %lf %lf") :280 splits on white space only: a row written with ';' passes the token
+        # count but not the scan (the program then goes on with the previous row's values — not restated: such rows are skipped)
+        ws = line.split()
+        try:
+            pn, fc_init, kcps = int(ws[2]), float(ws[3]), int(ws[4])
+            fltkhz, frange, fstep, snr = float(ws[5]), float(ws[6]), float(ws[7]), float(ws[8])
+        except (ValueError, IndexError):
+            continue
+        if not (0 <= pn <= 131 and kcps == 2500 and -200000.0 <= fc_init < 200000.0 and 0.0 <= frange < 200000.0 and frange > fstep and snr > -100.0):
+            continue
+        rows.append(dict(ch=line[0], mode=line[2], pn=pn, fc_init=fc_init, kcps=kcps, fltkhz=fltkhz, frange=frange, fstep=fstep, snr_min_db=snr))
+    return rows
+
+
+def rx_channel_setup(row: dict, code_bytes, sps: int, dec_a: int = 1) -> dict:
+    """``channel_info`` after :290-437 for one accepted row; ``code_bytes`` = the file SDRcode reads (:866-884), 0/1 per chip."""
+    ci = dict(is_chA=row["ch"] == "A", cid=row["pn"], rc=row["kcps"] * 1000, fc_init=row["fc_init"])
+    if row["pn"] < 100:
+        ci.update(clen=10000, duration=0.004, nlag=14)                                # :299-304
+    else:
+        ci.update(clen=100000, duration=0.04, nlag=28)                                # :305-311
+    fs = float(sps)
+    ci["bps"] = ci["rc"] // ci["clen"]                                               # :363
+    ci["nobs"] = sps // ci["bps"]                                                     # :364
+    ci["fltmax"], ci["fltmin"] = float(ci["rc"]), -float(ci["rc"])                    # :367-368
+    nfft = 1
+    while True:                                                                        # :369-374
+        nfft *= 2
+        if nfft > ci["nobs"] * 2 // dec_a:
+            break
+    ci["nfft"] = nfft
+    rng = 1.0
+    while rng < row["frange"]:
+        rng *= 2.0                                                                     # :375-376
+    stp = 1.0
+    while stp < row["fstep"]:
+        stp *= 2.0                                                                     # :377-378
+    ci.update(range=rng, step=stp, snr_min=10.0 ** (row["snr_min_db"] / 10.0))         # :379
+    ci.update(is_trk=False, is_first=False, df=0.0, last_phi=0.0, fc=0.0, pt=0, pk=0.0, gd=0.0, dg=0.0, sdgd=0.0, cnt=0)
+    code = 1 - 2 * np.asarray(code_bytes[:ci["clen"]], dtype=np.int64)                 # host_code :879
+    wav_acq_f, psbb, filt = rx_replica(code, ci["nobs"], nfft, float(ci["rc"]), fs, ci["clen"], ci["fltmax"], ci["fltmin"], dec_a)
+    ci.update(wav_acq_f=wav_acq_f, psbb=psbb, wav_t=filt)
+    ci["dat_name"] = "ch%s.pn%02d.%dkcps.dat" % ("A" if ci["is_chA"] else "B", ci["cid"], ci["rc"] // 1000)     # :720
+    ci["log_set"] = "set param   : Ch. %s, PRN#%2d, %8.0f %4d %5.0f %5.0f %5.0f %3.0f\n" % (
+        "A" if ci["is_chA"] else "B", ci["cid"], ci["fc_init"], ci["rc"] // 1000, ci["fltmax"] * 1.0e-3, ci["range"], ci["step"], ci["snr_min"])   # :441
+    return ci
+
+
+def rx_second(cis, raw_second, sps: int, dec_a: int, acq_idx):
+    """One pass of the loop body :468-832.  ``raw_second``: ``sps/Ninterp`` frames ``[IA QA IB QB]`` of int16; ``acq_idx(i, ci)``
+    returns the sample offset the program draws with rand() (:529).  Returns one dict per channel: ``status`` (the names of the
+    TWX_RX_* states), the ``channel_info`` values after the pass, ``dat_row`` / ``log`` texts where the program writes them."""
+    fs = float(sps)
+    smp_a, smp_b = rx_short2double(np.asarray(raw_second).reshape(-1), sps)                 # :477
+    pwr = {True: rx_power(smp_a, fs, dec_a), False: rx_power(smp_b, fs, dec_a)}               # :481-489
+    out = []
+    for i, ci in enumerate(cis):
+        smp = smp_a if ci["is_chA"] else smp_b
+        ci["px"] = pwr[ci["is_chA"]]
+        chs = "A" if ci["is_chA"] else "B"
+        ev = dict(status=None, dat_row="", log="", acq_idx=0)
+        if not ci["is_trk"]:                                                                  # :521-586
+            idx = int(acq_idx(i, ci))
+            fc, pk, pt = rx_acquire(smp, idx, ci["wav_acq_f"], ci["nobs"], ci["nfft"], fs, ci["fc_init"], ci["range"], ci["step"],
+                                    ci["fltmax"], ci["fltmin"], dec_a)
+            ci["fc"], ci["pt"] = fc, pt
+            ci["pk"], locked = rx_gate(pk, ci["psbb"], ci["px"], ci["snr_min"])                 # :570-573
+            ev["acq_idx"] = idx
+            if locked:
+                ci["pt"] = ci["pt"] * dec_a                                                   # :575
+                ci["gd"] = float(ci["pt"]) * 1.0e+9 / fs
+                ci["is_trk"], ci["is_first"] = True, True
+                ev["log"] = "acquisition : Ch. %s, PRN#%2d, %3d %8.0f %7.0f %6d %8.3f %8.3f\n" % (
+                    chs, ci["cid"], idx // 2 // ci["nobs"], ci["fc"], ci["gd"], ci["pt"], rx_v2todbm(ci["pk"]), rx_v2todbm(ci["px"]))   # :582
+                ev["status"] = "acquired"
+            else:
+                ev["status"] = "no signal"
+        else:                                                                                 # :589-790
+            res = rx_track_epoch(smp, ci["wav_t"], ci, ci["nobs"], ci["bps"], ci["nlag"], fs)
+            if res is not None:
+                ci.update(gd=res["gd"], dg=res["dg"], sdgd=res["sdgd"], pk=res["pk"], cnt=res["cnt"])
+                if not ci["is_first"]:
+                    ev["dat_row"] = "%14.6f %11.8f %3d %5.3f %14.6f %11.6f %8.4f %7.3f %7.3f\n" % (
+                        ci["fc"] + ci["df"], ci["phi"], ci["cnt"], 0.0, ci["gd"], ci["dg"], ci["sdgd"], rx_v2todbm(ci["pk"]),
+                        rx_v2todbm(ci["px"] - ci["pk"]))                                        # :735,747,752
+                    ev["status"] = "tracked"
+                else:
+                    ev["log"] = "code lock   : Ch. %s, PRN#%2d, count = %d / %d\n" % (chs, ci["cid"], ci["cnt"], ci["bps"])      # :761
+                    ci["is_first"] = False                                                    # :766
+                    ev["status"] = "code lock"
+            else:
+                ev["log"] = "%s : Ch. %s, PRN#%2d, count = %d / %d\n" % ("acq failed " if ci["is_first"] else "lock lost  ", chs, ci["cid"],
+                                                                          ci.get("cnt_last", 0), ci["bps"])                      # :779,787
+                ev["status"] = "acq failed" if ci["is_first"] else "lock lost"
+                ci["is_trk"], ci["last_phi"] = False, 0.0                                      # :792-793
+        ev.update(fc=ci["fc"], df=ci["df"], phi=ci.get("phi", 0.0), gd=ci["gd"], dg=ci["dg"], sdgd=ci["sdgd"], pk=ci["pk"], px=ci["px"],
+                  pt=ci["pt"], cnt=ci["cnt"])
+        out.append(ev)
     return out
 
 

@@ -1,0 +1,147 @@
+"""GPU (-m gpu): the DLL/PLL receiver as a program (twx_rx_*, experiments/231001_DLL_PLL/rxcomplex.cpp:263-835): parameter rows in,
+acquisition in the first second, code lock in the second, .dat rows after — every second against the oracle's restatement of the
+loop body (oracle.rx_second: UNPINNED, the C++ program needs fftw3 / gsl / cblas).  sdr.param sizes: 5 Msps two-channel capture,
+x2 interpolation to 10 Msps, 100 000-chip codes at 2.5 Mchip/s (nobs = 400 000, nfft = 2^20), +-28 lags x 24 code periods."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from amaranth_twstft_amd import _lib as L
+from amaranth_twstft_amd import receiver, synth
+from oracle import twstft_oracle as orc
+from tests.helpers import chips_for
+from tests.test_gpu_configs import _synth_dev
+
+pytestmark = pytest.mark.gpu
+N_IN, SPS, CLEN = 5_000_000, 10_000_000, 100_000
+
+
+def _capture(seconds, jump_after=None, jump=0):
+    """Two physical channels, continuous over `seconds` seconds: A carries code 0 (LFSR 17 taps 9 = 0.bin), B code 1 (taps 15).
+    From second `jump_after` on, channel A arrives `jump` samples (5 Msps) later."""
+    import torch
+    dev = torch.device("cuda", 0)
+    chips = {"A": chips_for(17, 9, CLEN), "B": chips_for(17, 15, CLEN)}
+    chans = {"A": synth.SynthParams(delay_q8=123_457 * 256, fstep=synth.fstep_for_df(1307.25, 5e6), phi0=11, amp=400,
+                                    noise_gain=synth.noise_gain_for_sigma(900.0), seed=31, stream=0),
+             "B": synth.SynthParams(delay_q8=77_001 * 256, fstep=synth.fstep_for_df(-260.5, 5e6), phi0=5, amp=500,
+                                    noise_gain=synth.noise_gain_for_sigma(700.0), seed=31, stream=1)}
+    out = np.empty((seconds, N_IN, 4), dtype=np.int16)
+    tmp = torch.empty((N_IN, 2), dtype=torch.int16, device=dev)
+    for s in range(seconds):
+        for c, key in enumerate(("A", "B")):
+            p = chans[key]
+            if key == "A" and jump_after is not None and s >= jump_after:
+                p = synth.SynthParams(**{**p.__dict__, "delay_q8": p.delay_q8 + jump * 256})
+            _synth_dev(tmp, N_IN, torch.from_numpy(chips[key]).to(dev), CLEN, 2, [p], n0=s * N_IN)
+            torch.cuda.synchronize()
+            out[s, :, 2 * c:2 * c + 2] = tmp.cpu().numpy()
+    return chips, out
+
+
+def test_receiver_program_against_the_oracle_loop(tmp_path):
+    seconds = 5
+    chips, cap = _capture(seconds)
+    chips["A"].tofile(tmp_path / "0.bin")                       # SDRcode reads <pn-100>.bin (:875)
+    chips["B"].tofile(tmp_path / "1.bin")
+    param = tmp_path / "sdr.param"
+    param.write_text("# ch mode pn fc kcps lpf range step snr\n"
+                     "A N 100 0001186 2500 1250 2000 256 -18\n"        # code 0 on channel A: present
+                     "B N 101 -000186 2500 1250 2000 256 -18\n"        # code 1 on channel B: present
+                     "A N 101 0000186 2500 1250 1000 256 -18\n")       # code 1 on channel A: absent, re-acquires every second
+    rows = receiver.parse_param(str(param))
+    assert len(rows) == 3
+    outdir = tmp_path / "out"
+    outdir.mkdir()
+    block = 3
+    with receiver.Receiver(rows, code_dir=str(tmp_path), out_dir=str(outdir), acq_block=block) as rx:
+        infos = [rx.channel(i) for i in range(3)]
+        got = [rx.second(cap[s]) for s in range(seconds)]
+    # ---- oracle: the same rows, the same offsets
+    orows = orc.rx_parse_param(param.read_text().splitlines(True))
+    cis = [orc.rx_channel_setup(r, chips["A"] if r["pn"] == 100 else chips["B"], SPS) for r in orows]
+    for info, ci in zip(infos, cis):
+        assert (info.nobs, info.nfft, info.bps, info.nlag, info.clen) == (ci["nobs"], ci["nfft"], ci["bps"], ci["nlag"], ci["clen"])
+        assert (info.range, info.step) == (ci["range"], ci["step"]) and abs(info.snr_min - ci["snr_min"]) < 1e-15
+        assert abs(info.psbb - ci["psbb"]) <= 1e-9 * ci["psbb"] and info.dat_name.decode() == ci["dat_name"]
+    want = [orc.rx_second(cis, cap[s].reshape(-1), SPS, 1, lambda i, ci: block * ci["nobs"]) for s in range(seconds)]
+    names = {L.TWX_RX_NO_SIGNAL: "no signal", L.TWX_RX_ACQUIRED: "acquired", L.TWX_RX_CODE_LOCK: "code lock", L.TWX_RX_TRACKED: "tracked",
+             L.TWX_RX_ACQ_FAILED: "acq failed", L.TWX_RX_LOCK_LOST: "lock lost"}
+    status = [[names[r.status] for r in sec] for sec in got]
+    assert status == [[e["status"] for e in sec] for sec in want]
+    assert status[0] == ["acquired", "acquired", "no signal"] and status[1] == ["code lock", "code lock", "no signal"]
+    assert all(st == ["tracked", "tracked", "no signal"] for st in status[2:])
+    for s in range(seconds):
+        for i in range(3):
+            g, w = got[s][i], want[s][i]
+            assert abs(g.px - w["px"]) <= 1e-5 * w["px"]                                  # received power :481-489
+            if w["status"] in ("acquired", "no signal"):
+                assert (g.fc, g.pt, g.acq_idx) == (w["fc"], w["pt"], w["acq_idx"])      # carrier of the sweep and cblas_izamax lag: exact
+                assert abs(g.pk - w["pk"]) <= 1e-5 * w["pk"]
+                if w["status"] == "acquired":
+                    assert g.gd == w["gd"]
+            else:
+                assert (g.fc, g.pt, g.cnt) == (w["fc"], w["pt"], w["cnt"])                # integer carrier, code phase, usable periods
+                assert abs(g.fc + g.df - (w["fc"] + w["df"])) <= 5e-4 and abs(g.phi - w["phi"]) <= 2e-4
+                assert abs(g.gd - w["gd"]) <= 0.05 and abs(g.dg - w["dg"]) <= 0.1 and abs(g.sdgd - w["sdgd"]) <= 0.1
+                assert abs(g.pk - w["pk"]) <= 1e-5 * w["pk"]
+            if w["status"] == "tracked":
+                gr, wr = g.dat_row.decode(), w["dat_row"]
+                assert gr.endswith("\n") and len(gr.split()) == len(wr.split()) == 9
+                gv, wv = [float(x) for x in gr.split()], [float(x) for x in wr.split()]
+                assert gv[2] == wv[2] and gv[3] == wv[3] == 0.0                           # cnt, ib*duration
+                assert abs(gv[0] - wv[0]) <= 1e-3 and abs(gv[4] - wv[4]) <= 0.05 and abs(gv[7] - wv[7]) <= 2e-3 and abs(gv[8] - wv[8]) <= 2e-3
+            else:
+                assert g.dat_row == b""
+    # the truth of the generator: carrier offsets and code phases (delay in 5-Msps samples -> x2)
+    assert abs(got[-1][0].fc + got[-1][0].df - 1307.25) < 0.2 and abs(got[-1][1].fc + got[-1][1].df + 260.5) < 0.2
+    assert abs(got[-1][0].gd - 2 * 123_457 * 100.0) < 100.0 and abs(got[-1][1].gd - 2 * 77_001 * 100.0) < 100.0      # ns at 10 Msps
+    # ---- files: rows appended to ch?.pn???.2500kcps.dat, the log lines of the program
+    for i in (0, 1):
+        text = (outdir / infos[i].dat_name.decode()).read_text()
+        assert text == "".join(got[s][i].dat_row.decode() for s in range(2, seconds))
+    assert not (outdir / infos[2].dat_name.decode()).exists()
+    log = (outdir / "rxcomplex.log").read_text().splitlines(True)
+    assert log[:3] == [ci["log_set"] for ci in cis]
+    assert [l[:11] for l in log[3:]] == ["acquisition", "acquisition", "code lock  ", "code lock  "]
+    wl = [e["log"] for sec in want for e in sec if e["log"]]
+    assert [l.split(",")[:2] for l in log[3:]] == [l.split(",")[:2] for l in wl] and log[5:] == wl[2:]      # code-lock lines equal to the character
+    acq_g, acq_w = log[3].split(), wl[0].split()
+    assert acq_g[:8] == acq_w[:8]                                                        # Ch, PRN, block, carrier, gd, pt
+
+
+def test_receiver_file_loop_and_lock_lost(tmp_path):
+    """twx_rx_file = `./rxcomplex data.bin sdr.param`: whole seconds of a capture FILE.  After three seconds the signal arrives 28
+    samples of the 10-Msps stream later: every code period then peaks on the edge of the +-28-lag window, no period is usable
+    (:634) -> 'lock lost' (:783-793), and the channel acquires again in the next second.  (Noise alone does not unlock the
+    program: its tracking branch has no SNR test, the one at :634 is commented out.)"""
+    seconds = 5
+    chips, cap = _capture(seconds, jump_after=3, jump=14)
+    path = tmp_path / "data.bin"
+    with open(path, "wb") as f:
+        cap.tofile(f)
+        np.zeros(1000, dtype=np.int16).tofile(f)                  # a short tail: not a whole second, not processed
+    row = receiver.make_row("A", 100, 1186.0, 2000.0, 256.0, -18.0, code=chips["A"])
+    with receiver.Receiver([row], out_dir=str(tmp_path), seed=7) as rx:
+        reps = rx.run_file(str(path))
+        assert len(reps) == seconds
+        st = [r[0].status for r in reps]
+        assert st == [L.TWX_RX_ACQUIRED, L.TWX_RX_CODE_LOCK, L.TWX_RX_TRACKED, L.TWX_RX_LOCK_LOST, L.TWX_RX_ACQUIRED]
+        assert 0 <= reps[0][0].acq_idx < SPS and reps[0][0].acq_idx % 400_000 == 0 and reps[0][0].n_trials == 17 + 3 * 8
+        assert reps[3][0].cnt == 0 and reps[4][0].pt == (reps[0][0].pt + 28) % 400_000
+    log = (tmp_path / "rxcomplex.log").read_text()
+    assert "lock lost   : Ch. A, PRN#100, count =" in log and len((tmp_path / "chA.pn100.2500kcps.dat").read_text().splitlines()) == 1
+
+
+def test_receiver_refuses_what_the_program_cannot_do(tmp_path):
+    chips = chips_for(17, 9, CLEN)
+    with pytest.raises(L.TwxError, match="SIC rows are not supported"):
+        receiver.Receiver([receiver.make_row("A", 100, 186.0, 2000.0, 256.0, -18.0, mode="S", code=chips)])
+    with pytest.raises(L.TwxError, match="Code filename error"):
+        receiver.Receiver([receiver.make_row("A", 100, 186.0, 2000.0, 256.0, -18.0)], code_dir=str(tmp_path))
+    with pytest.raises(L.TwxError, match="no code source"):
+        receiver.Receiver([receiver.make_row("B", 7, 186.0, 2000.0, 256.0, -18.0)])
+    with pytest.raises(L.TwxError, match="ranges of rxcomplex.cpp:288"):
+        receiver.Receiver([receiver.make_row("A", 100, 186.0, 100.0, 256.0, -18.0, code=chips)])

@@ -1,0 +1,64 @@
+"""CPU: the parameter-file parser of the DLL/PLL receiver (twx_rx_parse_param, experiments/231001_DLL_PLL/rxcomplex.cpp:263-296)
+against the oracle's restatement, and the receiver failing loudly without a GPU."""
+import ctypes as C
+
+import pytest
+
+from amaranth_twstft_amd import _lib as L
+from amaranth_twstft_amd import receiver
+from oracle import twstft_oracle as orc
+
+PARAM = """# chA_or_B Sic_or_Normal PRN_no. center_freq(Hz) chip_rate(kcps) LPF_cutoff(kHz) freq_search_range(Hz) freq_search_step(Hz) least_required_SNR(dB)
+A N 100 0000186 2500 1250 64096 256 -18
+B N 101 0000056 2500 1250 64096 256 -18
+# commented A N 100 1 2500 1250 64096 256 -18
+A S 105 -150000 2500 1250 1000;10;-30
+B N 131 199999.5 2500 1250 199999 1 -99.9
+C N 100 0000186 2500 1250 64096 256 -18
+A X 100 0000186 2500 1250 64096 256 -18
+A N 100 0000186 2500 1250 64096 256
+A N 100 0000186 2500 1250 64096 256 -18 extra
+A N 132 0000186 2500 1250 64096 256 -18
+A N 100 0000186 1000 1250 64096 256 -18
+A N 100 200000 2500 1250 64096 256 -18
+A N 100 0000186 2500 1250 256 256 -18
+A N 100 0000186 2500 1250 64096 256 -100
+A N 7 -5.5 2500 1250 512 2 3
+"""
+
+
+def test_parameter_file_parser_matches_the_oracle(tmp_path):
+    p = tmp_path / "sdr.param"
+    p.write_text(PARAM)
+    got = receiver.parse_param(str(p))
+    want = orc.rx_parse_param(PARAM.splitlines(True))
+    assert len(got) == len(want) == 4                      # rows 1, 2, the limits row, the short-code row (the ';' row passes the token count, not the scan)
+    for g, w in zip(got, want):
+        assert (g.ch.decode(), g.mode.decode(), g.pn, g.fc_init, g.kcps, g.fltkhz, g.frange, g.fstep, g.snr_min_db) == \
+               (w["ch"], w["mode"], w["pn"], w["fc_init"], w["kcps"], w["fltkhz"], w["frange"], w["fstep"], w["snr_min_db"])
+    lib = L.load()
+    rows = (L.twx_rx_row * 2)()
+    assert lib.twx_rx_parse_param(str(p).encode(), rows, 2) == 2            # capacity respected
+    assert lib.twx_rx_parse_param(str(tmp_path / "missing").encode(), rows, 2) == -1
+    assert b"no such parameter file" in lib.twx_rx_last_error(None)
+
+
+def test_oracle_channel_setup_follows_the_program():
+    import numpy as np
+    row = orc.rx_parse_param(["A N 100 0000186 2500 1250 64096 256 -18\n"])[0]
+    rng = np.random.default_rng(1)
+    ci = orc.rx_channel_setup(row, rng.integers(0, 2, 100000), 10_000_000)
+    assert (ci["clen"], ci["nlag"], ci["bps"], ci["nobs"], ci["nfft"]) == (100000, 28, 25, 400000, 1 << 20)
+    assert (ci["range"], ci["step"]) == (65536.0, 256.0) and abs(ci["snr_min"] - 10 ** -1.8) < 1e-15
+    assert ci["dat_name"] == "chA.pn100.2500kcps.dat"
+    assert ci["log_set"] == "set param   : Ch. A, PRN#100,      186 2500  2500 65536   256   0\n"
+    short = orc.rx_channel_setup(orc.rx_parse_param(["B N 7 -5.5 2500 1250 512 2 3\n"])[0], rng.integers(0, 2, 10000), 10_000_000)
+    assert (short["clen"], short["nlag"], short["bps"], short["nobs"], short["nfft"]) == (10000, 14, 250, 40000, 1 << 17)
+
+
+def test_receiver_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(L.TwxError, match="no HIP device|HIP"):
+        receiver.Receiver([receiver.make_row("A", 100, 186.0, 2000.0, 256.0, -18.0, code=[0, 1] * 50000)])
