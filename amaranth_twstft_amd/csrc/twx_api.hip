@@ -21,6 +21,7 @@
 #include "twx_kernels.h"
 #include "twx_plans.h"
 #include "twx_internal.h"
+#include "twx_workers.h"
 
 namespace twx {
 
@@ -1253,23 +1254,7 @@ template <typename T> struct Ctx : CtxBase {
             char* dst = (char*)st[k].host;
             const int nthr = io_threads;
             return std::async(std::launch::async, [=]() -> long long {
-                const size_t need = win_bytes * (size_t)want;
-                const size_t off0 = (size_t)first * win_bytes;
-                const int P = (int)std::max<size_t>(1, std::min<size_t>((size_t)nthr, need >> 22));
-                const size_t piece = ((need + P - 1) / P + 4095) & ~(size_t)4095;
-                std::vector<std::future<size_t>> parts;
-                for (int i = 1; i < P; ++i) {
-                    const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));
-                    parts.push_back(std::async(std::launch::async, [=]() { return read_at(dst + lo, off0 + lo, hi - lo); }));
-                }
-                const size_t first_len = std::min(need, piece);
-                size_t total = read_at(dst, off0, first_len);
-                bool contiguous = total == first_len;
-                for (int i = 1; i < P; ++i) {
-                    const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));
-                    const size_t got = parts[i - 1].get();
-                    if (contiguous) { total += got; contiguous = got == hi - lo; }
-                }
+                const size_t total = read_in_pieces(read_at, dst, (size_t)first * win_bytes, win_bytes * (size_t)want, nthr);    // twx_workers.h
                 return (long long)(total / win_bytes);              // whole windows only
             });
         };

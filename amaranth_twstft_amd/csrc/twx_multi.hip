@@ -25,6 +25,7 @@
 #include <thread>
 #include <vector>
 #include "twx_internal.h"
+#include "twx_workers.h"
 
 namespace {
 
@@ -68,50 +69,7 @@ struct Rccl {
 Rccl& rccl() { static Rccl r; return r; }
 std::mutex& rccl_mu() { static std::mutex m; return m; }
 
-// ---- one persistent host thread per context -----------------------------------------------------------------------
-struct Worker {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::function<int()> job;
-    bool has_job = false, done = true, quit = false;
-    int rc = 0;
-    int dev = 0;
-    void start(int device) {
-        dev = device;
-        th = std::thread([this]() {
-            (void)hipSetDevice(dev);
-            std::unique_lock<std::mutex> lk(mu);
-            for (;;) {
-                cv.wait(lk, [this]() { return has_job || quit; });
-                if (quit) return;
-                std::function<int()> f = std::move(job);
-                has_job = false;
-                lk.unlock();
-                int r;
-                try { r = f(); } catch (const std::bad_alloc&) { r = TWX_E_NOMEM; } catch (...) { r = TWX_E_STATE; }
-                lk.lock();
-                rc = r; done = true;
-                cv.notify_all();
-            }
-        });
-    }
-    void submit(std::function<int()> f) {
-        std::lock_guard<std::mutex> lk(mu);
-        job = std::move(f); has_job = true; done = false;
-        cv.notify_all();
-    }
-    int wait() {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [this]() { return done; });
-        return rc;
-    }
-    void stop() {
-        if (!th.joinable()) return;
-        { std::lock_guard<std::mutex> lk(mu); quit = true; cv.notify_all(); }
-        th.join();
-    }
-};
+using twx::Worker;               // one persistent host thread per context (twx_workers.h: plain C++, run under -fsanitize=thread on the CPU)
 
 }  // namespace
 
@@ -254,7 +212,11 @@ static int multi_create_impl(const twx_config* cfg, const int32_t* devices, int3
     }
     m->ctx.assign(n, nullptr); m->send_dev.assign(n, nullptr); m->recv_dev.assign(n, nullptr); m->gstream.assign(n, nullptr);
     m->local.resize(n);
-    for (int r = 0; r < n; ++r) { Worker* w = new Worker(); m->workers.push_back(w); w->start(m->devices[r]); }
+    for (int r = 0; r < n; ++r) {
+        Worker* w = new Worker(); m->workers.push_back(w);
+        const int d = m->devices[r];
+        w->start([d]() { (void)hipSetDevice(d); }, TWX_E_NOMEM, TWX_E_STATE);
+    }
     // contexts are created side by side (tables, code spectrum, 3 pipeline slots each): one thread per device
     std::vector<std::string> cerr(n);
     int rc = TWX_OK;

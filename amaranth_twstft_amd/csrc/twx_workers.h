@@ -1,0 +1,86 @@
+// twx_workers.h — host threads of the library, plain C++ (no HIP in this file, so the CPU test suite can run it under
+// -fsanitize=thread: tests/cpu/threads_tsan.cpp):
+//   Worker            one persistent thread with a one-deep job slot (twx_multi: one per device context)
+//   read_in_pieces    one chunk of a capture fetched as several concurrent pieces (the ingest of twx_process_file /
+//                     twx_process_windows: one pread / memcpy runs at ~5 GB/s, the PCIe copy behind it at ten times that)
+#pragma once
+#include <stddef.h>
+#include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <future>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+namespace twx {
+
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = true, quit = false;
+    int rc = 0;
+    // `prologue` runs once on the new thread before the first job (hipSetDevice of the worker's device)
+    void start(std::function<void()> prologue, int fail_nomem, int fail_other) {
+        th = std::thread([this, prologue, fail_nomem, fail_other]() {
+            if (prologue) prologue();
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                cv.wait(lk, [this]() { return has_job || quit; });
+                if (quit) return;
+                std::function<int()> f = std::move(job);
+                has_job = false;
+                lk.unlock();
+                int r;
+                try { r = f(); } catch (const std::bad_alloc&) { r = fail_nomem; } catch (...) { r = fail_other; }
+                lk.lock();
+                rc = r; done = true;
+                cv.notify_all();
+            }
+        });
+    }
+    void submit(std::function<int()> f) {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(f); has_job = true; done = false;
+        cv.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this]() { return done; });
+        return rc;
+    }
+    void stop() {
+        if (!th.joinable()) return;
+        { std::lock_guard<std::mutex> lk(mu); quit = true; cv.notify_all(); }
+        th.join();
+    }
+    ~Worker() { stop(); }
+};
+
+// [off0, off0 + need) of a source into dst as up to `nthreads` concurrent pieces (4096-byte aligned cuts, pieces of at least
+// 4 MB).  read_at(dst, offset, len) -> bytes delivered (short only at the end of the source).  Returns the bytes delivered
+// CONTIGUOUSLY from off0 (a short piece ends the count: what follows it is not part of the capture).
+template <class ReadAt>
+size_t read_in_pieces(ReadAt read_at, char* dst, size_t off0, size_t need, int nthreads) {
+    const int P = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, nthreads), need >> 22));
+    const size_t piece = ((need + P - 1) / P + 4095) & ~(size_t)4095;
+    std::vector<std::future<size_t>> parts;
+    for (int i = 1; i < P; ++i) {
+        const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));
+        parts.push_back(std::async(std::launch::async, [=]() { return read_at(dst + lo, off0 + lo, hi - lo); }));
+    }
+    const size_t first_len = std::min(need, piece);
+    size_t total = read_at(dst, off0, first_len);
+    bool contiguous = total == first_len;
+    for (int i = 1; i < P; ++i) {
+        const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));
+        const size_t got = parts[i - 1].get();
+        if (contiguous) { total += got; contiguous = got == hi - lo; }
+    }
+    return total;
+}
+
+}  // namespace twx

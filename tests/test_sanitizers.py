@@ -1,0 +1,82 @@
+"""CPU: sanitizer builds of the host-side C++ (SURVEY.md §5 "race detection / sanitizers"; sanitizers run on the CPU build only).
+
+* ``-fsanitize=address,undefined``: the device FFT templates under the thread-loop emulation (fft_emul, rowd_emul), the tracked
+  control flow (twx_tracked_core.h, driven by the oracle through the same test functions as tests/test_tracked_host.py, in a
+  child interpreter with libasan preloaded), both MEX gateways on their error paths (no GPU here: mexFunction must fail with
+  a MEX error, not with a sanitizer report).
+* ``-fsanitize=thread``: the library's host threads (twx_workers.h: the worker pool of twx_multi, the piece-wise chunk reader and
+  the slot rotation of the ingest pipeline).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "amaranth_twstft_amd", "csrc")
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"]
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+
+
+def _no_report(r):
+    text = r.stdout + r.stderr
+    assert "ERROR: AddressSanitizer" not in text and "runtime error:" not in text and "LeakSanitizer" not in text and "ThreadSanitizer" not in text, text[-4000:]
+
+
+@pytest.mark.parametrize("src", ["fft_emul", "rowd_emul"])
+def test_fft_templates_under_asan_ubsan(tmp_path, src):
+    exe = tmp_path / src
+    subprocess.run(["g++", "-O1", "-std=c++17", *SAN, "-o", str(exe), os.path.join(ROOT, "tests", "cpu", src + ".cpp")], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=ENV, timeout=900)
+    _no_report(r)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_host_threads_under_tsan(tmp_path):
+    exe = tmp_path / "threads_tsan"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I" + CSRC, os.path.join(ROOT, "tests", "cpu", "threads_tsan.cpp"),
+                    "-o", str(exe), "-lpthread"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"), timeout=900)
+    _no_report(r)
+    assert r.returncode == 0 and "threads ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_tracked_control_flow_under_asan_ubsan():
+    """The SAME tests as tests/test_tracked_host.py (the oracle answers the backend calls) with the control flow compiled with
+    ASan + UBSan: a child interpreter with libasan preloaded loads the instrumented tracked_emul.so."""
+    libasan = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan.so not found")
+    env = dict(ENV, LD_PRELOAD=libasan, TWX_EMUL_SANITIZE="1", PYTHONPATH=ROOT, ASAN_OPTIONS="detect_leaks=0")   # CPython itself is not leak-clean
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_tracked_host.py"), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "helpers or control_flow or skip_and_known or no_carrier or edge_paths"],
+                       capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+    _no_report(r)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.parametrize("harness,gateway,args", [
+    ("mex_harness", "twstft_processing_mex", ["raw", "{cap}", "{chips}", "{out}", "2", "0", "1", "100", "5e6", "1"]),
+    ("mex_harness", "twstft_processing_mex", ["file", "{cap}", "{chips}", "{out}", "2", "1", "df", "12.5", "5e6", "1", "claudio", "ngpu=3", "skip=5", "max=1"]),
+    ("mex_tracked_harness", "twstft_tracked_mex", ["{cap}", "{chips}", "{out}", "lo", "0", "5e6", "1"]),
+])
+def test_mex_gateways_error_paths_under_asan_ubsan(tmp_path, harness, gateway, args):
+    """Both mexFunction()s instrumented (the library itself is not): on a box without a GPU every call must end in a MEX error
+    raised by the gateway — argument marshalling, context creation failure, clean-up — with no sanitizer report."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the error path under test is the no-GPU one (GPU runs of sanitizer builds are not made)")
+    libdir = os.path.join(ROOT, "amaranth_twstft_amd")
+    exe = tmp_path / harness
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", *SAN, "-I" + os.path.join(ROOT, "tests", "cpu", "mex_fake"), "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpu", harness + ".cpp"), os.path.join(ROOT, "mex", gateway + ".cpp"), "-L" + libdir, "-ltwstft_hip",
+                    "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
+    np.zeros(40000 * 4, dtype=np.int16).tofile(tmp_path / "cap.bin")
+    np.zeros(10000, dtype=np.uint8).tofile(tmp_path / "chips.bin")
+    fill = dict(cap=str(tmp_path / "cap.bin"), chips=str(tmp_path / "chips.bin"), out=str(tmp_path / "out.bin"))
+    r = subprocess.run([str(exe)] + [a.format(**fill) for a in args], capture_output=True, text=True, env=dict(ENV, ASAN_OPTIONS="detect_leaks=0"), timeout=600)
+    _no_report(r)
+    assert r.returncode == 3 and "twstft:create" in r.stderr and "no CPU fallback" in r.stderr, r.stderr[-2000:]

@@ -50,7 +50,9 @@ class Summary(C.Structure):
 @pytest.fixture(scope="module")
 def emul(tmp_path_factory):
     so = tmp_path_factory.mktemp("trk") / "tracked_emul.so"
-    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "amaranth_twstft_amd", "csrc"),
+    # TWX_EMUL_SANITIZE=1 (tests/test_sanitizers.py, in an interpreter with libasan preloaded): the same control flow with ASan + UBSan
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"] if os.environ.get("TWX_EMUL_SANITIZE") else ["-O2"]
+    subprocess.run(["g++", *san, "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "amaranth_twstft_amd", "csrc"),
                     os.path.join(ROOT, "tests", "cpu", "tracked_emul.cpp"), "-o", str(so)], check=True)
     lib = C.CDLL(str(so))
     lib.trk_emul_run.restype = C.c_int
