@@ -49,6 +49,9 @@
 #ifndef TWX_MID_SGPR
 #define TWX_MID_SGPR 1   // k_rowd<MID>: wave-uniform factors (stage C's W_N^{-k1 c M}, the ramp's q2 part) through scalar loads, not LDS reads
 #endif
+#ifndef TWX_NT_INV
+#define TWX_NT_INV 1    // k_col_inv3: non-temporal loads of Bz (read exactly once)
+#endif
 #ifndef TWX_NT_BZ
 #define TWX_NT_BZ 1     // k_rowd<MID>: non-temporal stores of Bz (written once, read once by k_col_inv 1 GB later)
 #endif
@@ -1892,7 +1895,7 @@ __global__ __launch_bounds__(NT, 6) void k_col_inv3(ColInvArgs<T> a) {
         // base and row stride pinned in SGPRs, the lane part a 32-bit offset: no 64-bit VALU address per load
         const unsigned long long cb = sgpr_u64(reinterpret_cast<unsigned long long>(cbase)), rs = sgpr_u64(rstride);
         TWX_UNROLL
-        for (int r = 0; r < R0; ++r) v[r] = (TWX_ABLC == 2) ? mk<T>((T)(tid + r), (T)(r - tid)) : ld_pin<C, true>(cb, r * rs, loff);
+        for (int r = 0; r < R0; ++r) v[r] = (TWX_ABLC == 2) ? mk<T>((T)(tid + r), (T)(r - tid)) : ld_pin<C, TWX_NT_INV != 0>(cb, r * rs, loff);
         if (TWX_ABLC == 1) {                 // timing-only build: loads, no arithmetic, no exchange
             TWX_UNROLL
             for (int r = 0; r < R0; ++r) asm volatile("" ::"v"(v[r]));

@@ -138,11 +138,14 @@ def run_cpu_baseline(n_win: int, workload: str, max_workers: int):
     return {"error": (r.stdout[-500:] + r.stderr[-1500:])}
 
 
-def measure_pmc_traffic(kernel_short: str):
-    """HBM bytes per launch of the dominant kernel from the PMC counters, measured by THIS invocation: two child runs of a
-    one-step, 8-window bench under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace domains),
-    read = 2 x FETCH_SIZE (the gfx950 correction of MI355X_MICROARCH.md, section HBM), write = WRITE_SIZE; counters in KiB.
-    Runs before this process touches the GPU.  Returns (bytes or None, note)."""
+def measure_pmc_traffic(kernel_short, child_args=("--steps", "1", "--warmup", "0", "--windows", "8", "--no-cpu-baseline", "--no-roofline", "--no-caf"),
+                        what="1 step, 8 windows = one launch of the kernel"):
+    """HBM bytes per launch of a kernel (or, for a tuple of names, of each of them) from the PMC counters, measured by THIS
+    invocation: two child runs of a small bench under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no
+    trace domains), read = 2 x FETCH_SIZE (the gfx950 correction of MI355X_MICROARCH.md, section HBM), write = WRITE_SIZE;
+    counters in KiB.  Runs before this process touches the GPU.  Returns (bytes or None, note) — bytes a dict for a tuple."""
+    many = not isinstance(kernel_short, str)
+    names = tuple(kernel_short) if many else (kernel_short,)
     import csv, glob, shutil, tempfile
     exe = shutil.which("rocprofv3")
     if not exe:
@@ -160,8 +163,7 @@ def measure_pmc_traffic(kernel_short: str):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "--", sys.executable,
-                   os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--windows", "8", "--no-cpu-baseline", "--no-roofline",
-                   "--no-caf"]
+                   os.path.abspath(__file__)] + list(child_args)
             # its own process group: on a timeout the whole group goes (rocprofv3 AND the bench process under it, which would
             # otherwise keep running on the GPU through the parent's timed region), and is waited for before the next GPU user
             proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
@@ -179,22 +181,30 @@ def measure_pmc_traffic(kernel_short: str):
             files = glob.glob(os.path.join(tmp, counter, "**", "*_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, "rocprofv3 --pmc %s failed (rc %s): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-300:])
-            best = 0.0
+            best = {n: 0.0 for n in names}
             for path in files:
                 for row in csv.DictReader(open(path)):
-                    if row["Counter_Name"] == counter and short(row["Kernel_Name"]).startswith(kernel_short):
-                        best = max(best, float(row["Counter_Value"]))            # per launch: the full 8-window batch
-            if best <= 0:
-                return None, "no %s rows for %s" % (counter, kernel_short)
+                    if row["Counter_Name"] != counter:
+                        continue
+                    sn = short(row["Kernel_Name"])
+                    for n in names:
+                        if sn.startswith(n):
+                            best[n] = max(best[n], float(row["Counter_Value"]))  # per launch: the fullest launch of the run
+            if min(best.values()) <= 0:
+                return None, "no %s rows for %s" % (counter, [n for n in names if best[n] <= 0])
             vals[counter] = best
     except Exception as e:
         return None, repr(e)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    byts = int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)
-    return byts, ("measured by this invocation: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate child runs "
-                  "(1 step, 8 windows = one launch of the kernel); read = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE: "
-                  "%d + %d bytes" % (int(2 * vals["FETCH_SIZE"] * 1024), int(vals["WRITE_SIZE"] * 1024)))
+    byts = {n: int(2 * vals["FETCH_SIZE"][n] * 1024 + vals["WRITE_SIZE"][n] * 1024) for n in names}
+    note = ("measured by this invocation: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate child runs (" + what + "); "
+            "read = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE: "
+            + "; ".join("%s %d + %d bytes" % (n, int(2 * vals["FETCH_SIZE"][n] * 1024), int(vals["WRITE_SIZE"][n] * 1024)) for n in names))
+    if not many:
+        note = note.replace(names[0] + " ", "")
+        return byts[names[0]], note
+    return byts, note
 
 
 def single_process(a, t_start):
@@ -280,6 +290,25 @@ def single_process(a, t_start):
     m.close()
 
 
+def caf_only():
+    """Child of the CAF's `rocprofv3 --pmc` passes: one synthetic window, 128 Doppler bins = two full 64-bin launches of k_rowd_caf
+    and of the last pass; nothing else of the bench runs."""
+    import numpy as np
+    import torch
+    from amaranth_twstft_amd import _lib as L, prn
+    from amaranth_twstft_amd.correlator import Correlator
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    chips = prn.lfsr_chips(BITLEN, TAPS, NCHIPS)
+    sp, _ = window_params(0, 0)
+    iq = torch.empty((N, 2), dtype=torch.int16, device=dev)
+    params = np.array([sp.delay_q8, sp.fstep, sp.phi0, sp.amp, sp.noise_gain, sp.seed, sp.stream, 0], dtype=np.int64)
+    L.check(lib.twx_synth_capture_dev(iq.data_ptr(), N, 0, torch.from_numpy(chips).to(dev).data_ptr(), NCHIPS, 2, 1, params.ctypes.data_as(C.c_void_p), None))
+    torch.cuda.synchronize()
+    with Correlator(chips, fs=FS, Nint=0, device=0) as cc:
+        cc.caf_bins_dev(iq.data_ptr(), 1717, 1717 + 127)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,6 +326,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes (roofline.traffic then comes "
                     "from the committed profiles/pmc_traffic.json)")
     ap.add_argument("--no-caf", action="store_true", help="skip the BASELINE.json configs[2] leg (delay x Doppler CAF of one window)")
+    ap.add_argument("--caf-only", action="store_true", help=argparse.SUPPRESS)      # the child of the CAF's --pmc passes: two full launches of the surface
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                     "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--single-process", action="store_true", help="drive the --gpus N devices from THIS process through the library's "
@@ -313,6 +343,9 @@ def main():
     if a.single_process:
         single_process(a, t_start)
         return
+    if a.caf_only:
+        caf_only()
+        return
 
     from amaranth_twstft_amd import launch
     if a.gpus > 1 and not launch.is_rank():
@@ -325,10 +358,14 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = run_cpu_baseline(a.cpu_windows, a.workload, a.cpu_max_workers)      # before the first GPU call
-    pmc_live = None
+    pmc_live = pmc_caf = None
     if rank == 0 and world == 1 and not a.no_roofline and not a.no_pmc and a.workload == "processing":
         t_p = time.perf_counter()
         pmc_live = measure_pmc_traffic("k_row_mid") + (round(time.perf_counter() - t_p, 1),)       # child processes, before the first GPU call
+        if not a.no_caf:
+            t_p = time.perf_counter()
+            pmc_caf = measure_pmc_traffic(("k_rowd_caf", "k_col_inv"), ("--caf-only",), "128 Doppler bins = two full launches of each kernel") \
+                + (round(time.perf_counter() - t_p, 1),)
 
     import numpy as np
     import torch
@@ -550,6 +587,23 @@ def main():
                                             "algorithmic_bytes_per_launch": int(cbytes[cdom](bpl)), "avg_ms": round(ck[cdom], 4),
                                             "note": "algorithmic bytes of the kernel's own interface; the Y rows and the bin buffer of a launch "
                                                     "are mostly served by L2 / Infinity Cache, so HBM traffic is below this figure"}}
+        if pmc_caf and pmc_caf[0]:
+            # HBM-true figures: the PMC bytes of one full launch of each kernel over the HIP-event duration of that launch
+            tr = {"k_row_caf": pmc_caf[0]["k_rowd_caf"], "k_col_inv_caf": pmc_caf[0]["k_col_inv"]}
+            rf = out["caf_workload"]["roofline"]
+            for k in ck:
+                out["caf_workload"]["kernels"][k]["hbm_traffic_bytes"] = int(tr[k])
+                out["caf_workload"]["kernels"][k]["hbm_GB/s"] = round(tr[k] / (ck[k] * 1e-3) / 1e9, 1)
+            pair_b, pair_ms = sum(tr[k] for k in ck), sum(ck.values())
+            rf.update(traffic=int(tr[cdom]), achieved=round(tr[cdom] / (ck[cdom] * 1e-3) / 1e9, 1),
+                      frac=round(tr[cdom] / (ck[cdom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), interface_GBs=round(cach, 1),
+                      pair={"kernels": sorted(ck), "traffic": int(pair_b), "ms": round(pair_ms, 4), "GB/s": round(pair_b / (pair_ms * 1e-3) / 1e9, 1),
+                            "frac": round(pair_b / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                      traffic_source=pmc_caf[1] + " (%.0f s)" % pmc_caf[2],
+                      note="achieved / frac are HBM-true: PMC bytes of a full launch (read = 2 x FETCH_SIZE, write = WRITE_SIZE) over its duration; "
+                           "interface_GBs prices the kernel's own interface bytes, most of which L2 / Infinity Cache serve")
+        elif pmc_caf:
+            out["caf_workload"]["roofline"]["traffic_live_error"] = pmc_caf[1]
     if collective is not None:
         out["collective"] = collective
     if cpu is not None:
