@@ -184,6 +184,7 @@ SYMBOLS = {
     "twx_tracked_file": (C.c_int, [_VP, C.c_char_p, C.c_int64, C.c_int64, C.POINTER(twx_tracked_summary)]),
     "twx_tracked_host": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.POINTER(twx_tracked_summary)]),
     "twx_tracked_fetch": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "twx_tracked_timing": (C.c_int, [_VP, _VP, _VP]),
     "twx_tracked_search_df": (C.c_int, [_VP, _VP, C.c_int64, C.POINTER(C.c_int64)]),
     "twx_multi_create": (C.c_int, [C.POINTER(twx_config), _VP, C.c_int32, C.c_int32, C.POINTER(_VP)]),
     "twx_multi_destroy": (None, [_VP]),

@@ -1602,6 +1602,8 @@ template <typename T> struct Ctx : CtxBase {
             fa.n = N; fa.n1 = N1; fa.nbins = nb; fa.kappa0 = k0; fa.Y = Ysp; fa.cspec = cspec; fa.stab_i = stab_i;
             fa.ta = ta; fa.tb = tb; fa.tshift = tshift; fa.scale = (T)scale_pow2; fa.Bz = Bzc;
             fa.Yperm = Yperm; fa.cspec_perm = cspec_perm; fa.dtabs = dtabs; fa.vc = vc_d; fa.bpw = bpw; fa.nt = nt;
+            static const int caf_rot = [] { const char* e = getenv("TWX_CAF_ROTATE"); return e ? atoi(e) : 1; }();      // 0: plain bin order (A/B, profiles/r04_caf_rotate.txt)
+            fa.rotate = caf_rot;
             const unsigned grid = dform ? (unsigned)(N1 * ((nb + bpw - 1) / bpw)) : (unsigned)(N1 * nb);
             {
                 ProfScope ps(this, PC_ROW_CAF, (long long)nb * N);
@@ -1648,6 +1650,9 @@ void* ctx_scratch(twx_ctx* ctx, int slot, size_t bytes) { return ctx->impl->scra
 
 // No exception may cross the C boundary (std::async, std::vector and std::string can throw).
 template <class F> static int guarded(CtxBase* c, F f) noexcept {
+    // the launches of this library are checked with hipGetLastError(): an error another library left behind on this thread
+    // (RCCL and PyTorch probe pointers and peers and do not clear what those probes set) must not be taken for ours
+    (void)hipGetLastError();
     try { return f(); }
     catch (const std::bad_alloc&) { return c ? c->fail(TWX_E_NOMEM, "out of host memory") : TWX_E_NOMEM; }
     catch (const std::exception& e) { return c ? c->fail(TWX_E_STATE, std::string("internal error: ") + e.what()) : TWX_E_STATE; }
@@ -1685,6 +1690,7 @@ static int create_impl(const twx_config* cfg, twx_ctx** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "no HIP device available (the HIP path has no CPU fallback)"; return TWX_E_HIP; }
     if (cfg->device >= 0) { if (hipSetDevice(cfg->device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return TWX_E_HIP; } }
+    (void)hipGetLastError();      // a stale error of another library on this thread is not ours (see guarded())
     const ColOps* col; const RowOps* row;
     const int f64 = cfg->precision == TWX_F64;
     if (!choose_split(N, f64, &col, &row)) {

@@ -675,6 +675,9 @@ static int twx_track_epoch_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n_
 
 // No exception may cross the C boundary.
 template <class F> static int aux_guard(F f) noexcept {
+    // the launches of this library are checked with hipGetLastError(): an error another library left behind on this thread
+    // (RCCL and PyTorch probe pointers and peers and do not clear what those probes set) must not be taken for ours
+    (void)hipGetLastError();
     try { return f(); }
     catch (const std::bad_alloc&) { return TWX_E_NOMEM; }
     catch (...) { return TWX_E_STATE; }

@@ -1534,6 +1534,7 @@ template <typename T> struct CafArgs {
     int bpw;
     int nt;                 // 1: non-temporal bin-buffer stores (a buffer far larger than the caches); 0: the few bins of a launch
                             // are meant to stay in L2 / Infinity Cache until the last pass reads them
+    int rotate;             // k_rowd_caf: walk the workgroup's bins in the order rotated by k1 (L2 reuse of the Y rows, see the kernel)
 };
 
 template <class P2, typename T, int PADQ, int NT>
@@ -1643,7 +1644,16 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 4 ? 4 : 1)) void k_rowd_caf(CafAr
     }
     __syncthreads();
     const int bin_end = min(a.nbins, (grp + 1) * a.bpw);
-    for (int bin = grp * a.bpw; bin < bin_end; ++bin) {
+    // The workgroup walks its bins in an order ROTATED by k1: bin = bin0 + (s - k1) mod nbg at step s.  Row k1 + kappa of Y is what
+    // it reads for bin kappa, so the nbg workgroups of consecutive k1 that run side by side on an XCD (k1 is the fast index of the
+    // launch) ask for the SAME one or two rows of Y at the same step — walked in plain order they ask for nbg different rows per
+    // step, 64 rows = 4 MB = the whole L2 of the XCD for its 64 resident workgroups, and every row is evicted between its uses
+    // (PMC: 1.5 GB of Y fetched per 64-bin launch for the 40 MB that Y holds, profiles/r04_caf_*).
+    const int bin0 = grp * a.bpw, nbg = bin_end - bin0;
+    const int rot = a.rotate ? k1 % max(nbg, 1) : 0;
+    for (int s = 0; s < nbg; ++s) {
+        int bo = s - rot; if (bo < 0) bo += nbg;
+        const int bin = bin0 + bo;
         const long long sft = (long long)k1 + a.kappa0 + bin;
         long long k1s = sft % a.n1; if (k1s < 0) k1s += a.n1;
         long long cr = ((sft - k1s) / a.n1) % N2; if (cr < 0) cr += N2;
@@ -1665,7 +1675,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 4 ? 4 : 1)) void k_rowd_caf(CafAr
             }
             D::iA_pre(tabs, qi, v);
         }
-        if (bin > grp * a.bpw) __syncthreads();            // the previous bin's stage C has read every block
+        if (s > 0) __syncthreads();                        // the previous bin's stage C has read every block
         if (act) D::iA_store(lds, q0, qi, v);
         wave_sync_lds();
         if constexpr (FOLD) { if (act) D::iB_folded(lds, tabs, q0, qi, wa0, v); }

@@ -374,6 +374,9 @@ struct twx_rx {
 };
 
 template <class F> static int rx_guard(twx_rx* rx, F f) noexcept {
+    // the launches of this library are checked with hipGetLastError(): an error another library left behind on this thread
+    // (RCCL and PyTorch probe pointers and peers and do not clear what those probes set) must not be taken for ours
+    (void)hipGetLastError();
     try { return f(); }
     catch (const std::bad_alloc&) { return rx ? rx->fail(TWX_E_NOMEM, "out of host memory") : TWX_E_NOMEM; }
     catch (const std::exception& e) { return rx ? rx->fail(TWX_E_STATE, std::string("internal error: ") + e.what()) : TWX_E_STATE; }

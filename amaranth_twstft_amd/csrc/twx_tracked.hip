@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <unistd.h>
+#include <chrono>
 #include <future>
 #include <new>
 #include <string>
@@ -79,6 +80,18 @@ struct twx_tracked : twx_trk::Backend {
     void* map_dev = nullptr; double* stat_dev = nullptr;
     // pinned staging of capture chunks: slot `cur` holds the chunk being uploaded, the other one the read-ahead
     void* pin[2] = {nullptr, nullptr};
+    // the read-ahead goes all the way to the device: the helper thread that fills pin[s] also copies it to stage_dev[s] on a
+    // stream of its own, so the PCIe transfer of chunk c+1 runs beside the measurements of chunk c; load_chunk then places it
+    // behind the carried tail with a device-to-device copy (where the tail ends is only known once chunk c is through)
+    short2* stage_dev[2] = {nullptr, nullptr};
+    hipStream_t cst = nullptr; hipEvent_t h2d_ev[2] = {nullptr, nullptr};
+    // wall time the control flow spent inside each backend call of the last run (twx_tracked_timing)
+    double t_stage[TWX_TRK_NSTAGES] = {0}; long long n_stage[TWX_TRK_NSTAGES] = {0};
+    struct Tick {
+        twx_tracked* t; int k; std::chrono::steady_clock::time_point t0;
+        Tick(twx_tracked* t_, int k_) : t(t_), k(k_), t0(std::chrono::steady_clock::now()) {}
+        ~Tick() { t->t_stage[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); ++t->n_stage[k]; }
+    };
     std::vector<twx_result> rec_host;
     // capture source of the current run
     int fd = -1; const int16_t* host_src = nullptr; long long src_i16 = 0;
@@ -92,8 +105,10 @@ struct twx_tracked : twx_trk::Backend {
     ~twx_tracked() override {
         drop_ahead();
         if (ctx) { (void)hipSetDevice(dev); (void)twx_synchronize(ctx); }
-        for (void* p : {(void*)buf, (void*)tail, (void*)rec_dev, map_dev, (void*)stat_dev}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)buf, (void*)tail, (void*)rec_dev, map_dev, (void*)stat_dev, (void*)stage_dev[0], (void*)stage_dev[1]}) if (p) (void)hipFree(p);
         for (void* p : pin) if (p) (void)hipHostFree(p);
+        for (auto e : h2d_ev) if (e) (void)hipEventDestroy(e);
+        if (cst) (void)hipStreamDestroy(cst);
         if (ctx) twx_destroy(ctx);
     }
     void drop_ahead() { if (ahead.valid()) { try { (void)ahead.get(); } catch (...) {} } ahead_pos = -1; }
@@ -125,6 +140,9 @@ struct twx_tracked : twx_trk::Backend {
             hipMalloc(&map_dev, (size_t)P.n * (size_t)P.r * esz) != hipSuccess || hipMalloc((void**)&stat_dev, 4 * sizeof(double)) != hipSuccess)
             return fail(TWX_E_NOMEM, "device allocation failed");
         for (auto& p : pin) if (hipHostMalloc(&p, (size_t)P.L * 4, hipHostMallocDefault) != hipSuccess) return fail(TWX_E_NOMEM, "pinned staging allocation failed");
+        for (auto& p : stage_dev) if (hipMalloc((void**)&p, (size_t)P.L * 4) != hipSuccess) return fail(TWX_E_NOMEM, "device staging allocation failed");
+        if (hipStreamCreateWithFlags(&cst, hipStreamNonBlocking) != hipSuccess) return fail(TWX_E_HIP, "copy stream creation failed");
+        for (auto& e : h2d_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(TWX_E_HIP, "event creation failed");
         rec_host.resize(rec_cap);
         return TWX_OK;
     }
@@ -170,22 +188,42 @@ struct twx_tracked : twx_trk::Backend {
     }
 
     int load_chunk(long long pos, long long carry, int* full) override {
+        Tick tk(this, TWX_TRK_T_LOAD);
         if ((size_t)(carry + P.L) > buf_samples) return fail(TWX_E_STATE, "carry exceeds the sample buffer");
         long long got;
-        if (ahead.valid() && ahead_pos == pos) { got = ahead.get(); cur = ahead_slot; ahead_pos = -1; }
+        bool staged = false;
+        if (ahead.valid() && ahead_pos == pos) { got = ahead.get(); cur = ahead_slot; ahead_pos = -1; staged = got == 2 * P.L; }
         else { drop_ahead(); cur ^= 1; got = read_at(pos, pin[cur]); }
+        if (got < 0) return fail(TWX_E_HIP, "read-ahead: copy of the chunk to the device failed");
         *full = got == 2 * P.L;
         if (!*full) return TWX_OK;
-        if (hipMemcpyAsync(buf + carry, pin[cur], (size_t)P.L * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail(TWX_E_HIP, "H2D copy failed");
-        if (hipStreamSynchronize(st) != hipSuccess) return fail(TWX_E_HIP, "stream synchronize failed");
-        // read ahead: the chunk that follows, into the other pinned buffer, while this one is measured
+        if (staged) {
+            // the helper thread has already sent the chunk to stage_dev[cur]: the context's stream waits for that copy, then moves
+            // the chunk behind the tail (40 MB device to device: microseconds); nothing here waits on the host
+            if (hipStreamWaitEvent(st, h2d_ev[cur], 0) != hipSuccess ||
+                hipMemcpyAsync(buf + carry, stage_dev[cur], (size_t)P.L * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(TWX_E_HIP, "staged chunk copy failed");
+        } else {
+            if (hipMemcpyAsync(buf + carry, pin[cur], (size_t)P.L * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail(TWX_E_HIP, "H2D copy failed");
+            if (hipStreamSynchronize(st) != hipSuccess) return fail(TWX_E_HIP, "stream synchronize failed");
+        }
+        // read ahead: the chunk that follows, into the other pinned buffer and on to the device, while this one is measured.
+        // pin[cur ^ 1] / stage_dev[cur ^ 1] held the chunk before this one: its measurements ended with a host synchronisation.
         ahead_slot = cur ^ 1; ahead_pos = pos + 2 * P.L;
-        void* dst = pin[ahead_slot]; const long long np = ahead_pos;
-        ahead = std::async(std::launch::async, [this, np, dst]() { return read_at(np, dst); });
+        const int as = ahead_slot; const long long np = ahead_pos;
+        ahead = std::async(std::launch::async, [this, np, as]() {
+            const long long g = read_at(np, pin[as]);
+            if (g == 2 * P.L) {
+                (void)hipSetDevice(dev);
+                if (hipMemcpyAsync(stage_dev[as], pin[as], (size_t)P.L * 4, hipMemcpyHostToDevice, cst) != hipSuccess ||
+                    hipEventRecord(h2d_ev[as], cst) != hipSuccess) return (long long)-1;           // reported as a short chunk by the caller's test
+            }
+            return g;
+        });
         return TWX_OK;
     }
 
     int measure(long long start, int count, double df, twx_trk::Meas* m) override {
+        Tick tk(this, TWX_TRK_T_MEASURE);
         if (start < 0 || (size_t)(start + (long long)count * P.n) > buf_samples || (size_t)count > rec_cap) return fail(TWX_E_STATE, "measure outside the sample buffer");
         std::vector<double> dfv((size_t)count, df);
         if (int rc = lib(twx_process_windows_dev(ctx, buf + start, count, 1, 0, nullptr, dfv.data(), rec_dev))) return rc;
@@ -198,12 +236,15 @@ struct twx_tracked : twx_trk::Backend {
         return TWX_OK;
     }
     int sq_bins(long long ns, const long long* bins, int nb, double* o) override {
+        Tick tk(this, TWX_TRK_T_SQBINS);
         return lib(twx_sqspec_bins_dev(ctx, buf, ns, 1, 0, (const int64_t*)bins, nb, o));
     }
     int sq_band(long long off, long long k_lo, long long nk, double* mag) override {
+        Tick tk(this, TWX_TRK_T_SQBAND);
         return lib(twx_sqspec_band_dev(ctx, buf + off, P.L, 1, 0, k_lo, nk, mag));
     }
     int candidate_snr(long long off, double dftmp, double* snr) override {
+        Tick tk(this, TWX_TRK_T_CANDIDATE);
         // y=d(1:length(fcode)).*lo on the RAW chunk (:36): no mean removal for this call
         if (!search_mode) { if (int rc = lib(twx_set_option(ctx, TWX_OPT_REMOVE_MEAN, 0))) return rc; search_mode = true; }
         if (int rc = lib(twx_xcorr_map_dev(ctx, buf + off, 1, 0, dftmp, map_dev))) return rc;
@@ -222,6 +263,7 @@ struct twx_tracked : twx_trk::Backend {
         return lib(twx_set_option(ctx, TWX_OPT_REMOVE_MEAN, 1));
     }
     int slide_tail(long long from, long long count) override {
+        Tick tk(this, TWX_TRK_T_SLIDE);
         if (count < 0 || count > P.n + 64 || (size_t)(from + count) > buf_samples) return fail(TWX_E_STATE, "tail longer than a code period");
         if (!count) return TWX_OK;
         if (hipMemcpyAsync(tail, buf + from, (size_t)count * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
@@ -232,7 +274,10 @@ struct twx_tracked : twx_trk::Backend {
     int run(long long skip, long long kbon_hint, twx_tracked_summary* s) {
         (void)hipSetDevice(dev);
         cur = 0; ahead_pos = -1;
+        for (int k = 0; k < TWX_TRK_NSTAGES; ++k) { t_stage[k] = 0; n_stage[k] = 0; }
+        const auto t_run = std::chrono::steady_clock::now();
         int rc = twx_trk::run(P, *this, skip < 0 ? cfg.skip_samples : skip, kbon_hint, out);
+        t_stage[TWX_TRK_T_TOTAL] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run).count(); n_stage[TWX_TRK_T_TOTAL] = 1;
         drop_ahead();
         const int rc2 = end_search();
         if (rc == -1 && err.empty()) rc = fail(TWX_E_ARG, "the search band holds no bin of the chunk axis");
@@ -246,6 +291,9 @@ struct twx_tracked : twx_trk::Backend {
 };
 
 template <class F> static int trk_guard(twx_tracked* t, F f) noexcept {
+    // the launches of this library are checked with hipGetLastError(): an error another library left behind on this thread
+    // (RCCL and PyTorch probe pointers and peers and do not clear what those probes set) must not be taken for ours
+    (void)hipGetLastError();
     try { return f(); }
     catch (const std::bad_alloc&) { if (t) t->err = "out of host memory"; return TWX_E_NOMEM; }
     catch (const std::exception& e) { if (t) t->err = std::string("internal error: ") + e.what(); return TWX_E_STATE; }
@@ -316,6 +364,11 @@ int twx_tracked_host(twx_tracked* t, const int16_t* iq, int64_t n_samples, int64
         t->host_src = nullptr;
         return rc;
     });
+}
+int twx_tracked_timing(const twx_tracked* t, double* seconds, int64_t* calls) {
+    if (!t || !seconds) return TWX_E_ARG;
+    for (int k = 0; k < TWX_TRK_NSTAGES; ++k) { seconds[k] = t->t_stage[k]; if (calls) calls[k] = t->n_stage[k]; }
+    return TWX_OK;
 }
 int twx_tracked_fetch(twx_tracked* t, twx_tracked_code* codes, double* df, int64_t* moved, double* movedval) {
     if (!t) return TWX_E_ARG;

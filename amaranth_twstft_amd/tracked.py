@@ -139,3 +139,12 @@ class TrackedRanging:
         skip = -1 if skip_seconds is None else int(skip_seconds * self.fs)
         self._check(self._lib.twx_tracked_file(self._h, os.fsencode(path), skip, -1 if kbon is None else int(kbon), C.byref(s)))
         return self._collect(s)
+
+    STAGES = ("chunk wait", "carrier bins", "band spectrum", "code measurements", "search_df candidates", "tail carry", "whole run")
+
+    def timing(self) -> dict:
+        """Wall time of the last run inside each device operation of the control flow (``twx_tracked_timing``): name -> (s, calls)."""
+        sec = (C.c_double * len(self.STAGES))()
+        calls = (C.c_int64 * len(self.STAGES))()
+        self._check(self._lib.twx_tracked_timing(self._h, sec, calls))
+        return {n: (float(sec[i]), int(calls[i])) for i, n in enumerate(self.STAGES)}

@@ -442,6 +442,11 @@ int twx_tracked_host(twx_tracked* trk, const int16_t* iq, int64_t n_samples, int
 /* Copies the records of the last run: codes[n_codes], df[n_chunks] (Hz, one per chunk), moved[n_moved] (the 1-based p
  * of every re-alignment) and movedval[n_moved]; any pointer may be NULL. */
 int twx_tracked_fetch(twx_tracked* trk, twx_tracked_code* codes, double* df, int64_t* moved, double* movedval);
+/* Where the last run's wall time went: seconds[TWX_TRK_NSTAGES] spent inside each device operation of the control flow (the
+ * chunk wait = file read + PCIe copy not hidden behind the previous chunk's measurements; carrier bins; band spectrum; the
+ * batched code measurements incl. their result copy; search_df's candidates; the tail carry) and the whole run; calls may be NULL. */
+enum { TWX_TRK_T_LOAD = 0, TWX_TRK_T_SQBINS, TWX_TRK_T_SQBAND, TWX_TRK_T_MEASURE, TWX_TRK_T_CANDIDATE, TWX_TRK_T_SLIDE, TWX_TRK_T_TOTAL, TWX_TRK_NSTAGES };
+int twx_tracked_timing(const twx_tracked* trk, double* seconds, int64_t* calls);
 /* search_df alone (:27-47) on the first chunk_samples of a host buffer: *kbon as in the summary. */
 int twx_tracked_search_df(twx_tracked* trk, const int16_t* iq, int64_t n_samples, int64_t* kbon);
 
