@@ -529,6 +529,8 @@ template <typename T> struct Ctx : CtxBase {
         part_band = q.part_band; part_peak = q.part_peak; res_dev = q.res_dev; fine_u = q.fine_u; csum_part = q.csum_part;
         sum_parts = q.sum_parts;
     }
+    // k_df_tables: slices per window, so that a launch of few windows still spreads its fp64 sincospi over ~64 workgroups
+    int df_slices(int nb) const { return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(16, (N1 + N2 + 511) / 512), (64 + nb - 1) / nb)); }
     // k_sums grid: enough workgroups for the chip whatever the batch (8 per CU over the launch; 64 per window starved a
     // one-window launch: 90 us for 20 MB, profiles/r03_aux_kernel_stats.md), at least 16 KB of samples each
     int sums_chunks(int nb) const {
@@ -998,7 +1000,7 @@ template <typename T> struct Ctx : CtxBase {
         {
             ProfScope ps(this, PC_DFT, nb);
             for (int it = 0, ne = reps(PC_DFT); it < ne; ++it)
-            TWX_LAUNCH((k_df_tables<T>), dim3(nb), dim3(256), stream, band ? 1 : 0, part_band, N1, dfv, dfidx, cfg.fs,
+            TWX_LAUNCH((k_df_tables<T>), dim3(nb, df_slices(nb)), dim3(256), stream, band ? 1 : 0, part_band, N1, dfv, dfidx, cfg.fs,
                                (long long)N, N1, N2, e1, e2);
             HIPCHK(hipGetLastError());
         }
@@ -1009,7 +1011,7 @@ template <typename T> struct Ctx : CtxBase {
             HIPCHK(hipGetLastError());
             TWX_LAUNCH((k_fine_fit<0>), dim3(nb), dim3(1024), stream, fine_u, fine_M, cfg.fs, dfv);
             HIPCHK(hipGetLastError());
-            TWX_LAUNCH((k_df_tables<T>), dim3(nb), dim3(256), stream, 2, part_band, N1, dfv, dfidx, cfg.fs,
+            TWX_LAUNCH((k_df_tables<T>), dim3(nb, df_slices(nb)), dim3(256), stream, 2, part_band, N1, dfv, dfidx, cfg.fs,
                                (long long)N, N1, N2, e1, e2);       // rebuild the NCO tables for df + dfleftover
             HIPCHK(hipGetLastError());
         }
@@ -1168,14 +1170,16 @@ template <typename T> struct Ctx : CtxBase {
         if (L < 1 || nb < 1 || nb > 64) return fail(TWX_E_ARG, "sqspec_bins: need L >= 1 and 1..64 bins");
         long long hb[64];
         for (int i = 0; i < nb; ++i) { hb[i] = bins[i] % L; if (hb[i] < 0) hb[i] += L; }
-        long long* bd = nullptr; double* acc = nullptr;
-        Scratch sc(this);
-        if (int rc = sc.get(&bd, (size_t)nb)) return rc;
-        if (int rc = sc.get(&acc, (size_t)2 * nb)) return rc;
+        if (L >= (1ll << 32)) return fail(TWX_E_ARG, "sqspec_bins: chunk too long");
+        // context-owned work area (slot 7): bins | sums | per-workgroup partials — no allocation per chunk of the tracked flow
+        const unsigned grid = (unsigned)std::min<long long>(4ll * ncu, (L + 255) / 256);
+        char* work = static_cast<char*>(scratch_slot(7, 512 + 1024 + (size_t)grid * nb * 16));
+        if (!work) return TWX_E_NOMEM;
+        long long* bd = reinterpret_cast<long long*>(work); double* acc = reinterpret_cast<double*>(work + 512); double* part = reinterpret_cast<double*>(work + 1536);
         HIPCHK(hipMemcpyAsync(bd, hb, sizeof(long long) * nb, hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemsetAsync(acc, 0, sizeof(double) * 2 * nb, stream));
-        const unsigned grid = (unsigned)std::min<long long>(2048, (L + 255) / 256);
-        TWX_LAUNCH((k_sq_dft_bins<0>), dim3(grid), dim3(256), stream, reinterpret_cast<const short2*>(iq_dev) + ch, nch, L, bd, nb, acc);
+        TWX_LAUNCH((k_sq_dft_bins<0>), dim3(grid), dim3(256), stream, reinterpret_cast<const short2*>(iq_dev) + ch, nch, L, bd, nb, part);
+        HIPCHK(hipGetLastError());
+        TWX_LAUNCH((k_sq_dft_final<0>), dim3(1), dim3(256), stream, part, (int)grid, 2 * nb, acc);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(out, acc, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -1188,10 +1192,11 @@ template <typename T> struct Ctx : CtxBase {
         if (nk < 1 || nk > L) return fail(TWX_E_ARG, "sqspec_band: bad bin count");
         const long long M = L / N;
         if (M > 4096 || nch * M > 0x7fffffffll) return fail(TWX_E_ARG, "sqspec_band: chunk too long for this window length");
-        C* spec = nullptr; double* mag = nullptr;
-        Scratch sc(this);
-        if (int rc = sc.get(&spec, (size_t)(M * N))) return rc;
-        if (int rc = sc.get(&mag, (size_t)nk)) return rc;
+        // work buffers kept by the context (the `lo` flavour of the tracked flow calls this once per 2-s chunk: an 80-MB
+        // allocation and release per call cost more than the transforms)
+        C* spec = static_cast<C*>(scratch_slot(8, (size_t)(M * N) * sizeof(C)));
+        double* mag = static_cast<double*>(scratch_slot(9, (size_t)nk * sizeof(double)));
+        if (!spec || !mag) return TWX_E_NOMEM;
         if (int rc = sync_all()) return rc;
         use_slot(0);
         const short2* base = reinterpret_cast<const short2*>(iq_dev) + ch;

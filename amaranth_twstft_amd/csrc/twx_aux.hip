@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <new>
@@ -41,17 +42,25 @@ struct SdRot { float2 r[SD_NPASS]; };                            // exp(-2 pi j 
 // receiver tracks on, rxcomplex.cpp:477,602: dev_smp)
 __device__ __forceinline__ void sd_opaque(short2& v) { unsigned t = *reinterpret_cast<const unsigned*>(&v); asm volatile("" : "+v"(t)); v = *reinterpret_cast<const short2*>(&t); }
 __device__ __forceinline__ void sd_opaque(float2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
-template <int NLAG, typename XT>
-__global__ __launch_bounds__(SD_NT, 2) void k_sliding_dot(const XT* __restrict__ x, int nch, long long pt, long long nobs, int nlag, int chunk_len,
+// T = consecutive samples per lane and pass, CH = samples per LDS piece, WPC = workgroups per CU the register budget allows.
+// (4, 16384, 2): the wide windows (114 accumulator registers at NLAG = 28).  (8, 8192, 4): windows of up to +-8 lags, where the
+// accumulators are few and the kernel is a stream over the samples: eight samples per lane fetched as 16-byte loads, half the
+// LDS per workgroup, twice the workgroups per CU — four times the bytes in flight (nch = 1 and nobs a multiple of 8 only: every
+// group of eight is whole, the launcher falls back to the general form otherwise).
+template <int NLAG, typename XT, int T = SD_T, int CH = SD_CH, int WPC = 2>
+__global__ __launch_bounds__(SD_NT, WPC) void k_sliding_dot(const XT* __restrict__ x, int nch, long long pt, long long nobs, int nlag, int chunk_len,
                                                        const float* __restrict__ w, double ff, double phi, float scale, float rot_c, float rot_s,
                                                        SdRot rot, double* __restrict__ partial /*[ncodes][chunks][2*nlag+1][2]*/) {
     constexpr int NL = 2 * NLAG + 1;
-    constexpr int NQ = (NL + SD_T - 1 + 3) / 4;                    // 16-byte words a lane reads per pass
-    constexpr int NE4 = SD_CH / SD_T + NQ;                         // 16-byte words of a full chunk's segment
+    constexpr int NQ = (NL + T - 1 + 3) / 4;                    // 16-byte words a lane reads per pass
+    constexpr int NE4 = CH / 4 + NQ;                               // 16-byte words of a full chunk's segment
+    constexpr int WG = T / 4;                                      // 16-byte words per group of samples
+    constexpr bool VEC = T == 8;                                   // whole groups, one channel: the samples of a group as 16-byte loads
     __shared__ float4 sw4[NE4];                                    // replica segment; reused by the final reduction
     float* sw = reinterpret_cast<float*>(sw4);
     static_assert(NL * SD_NT <= 4 * NE4, "reduction buffer must fit the replica segment");
-    static_assert(SD_T == 4, "one 16-byte word per group of samples");
+    static_assert(T == 4 || T == 8, "whole 16-byte words per group of samples");
+    static_assert(CH / (T * SD_NT) <= SD_NPASS, "pass rotation table too short");
     const int p = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const int tid = threadIdx.x;
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -62,9 +71,9 @@ __global__ __launch_bounds__(SD_NT, 2) void k_sliding_dot(const XT* __restrict__
     // accumulators, so the block reduction below runs once per workgroup
     const long long c0 = (long long)chunk * chunk_len;
     const long long c1 = min(c0 + (long long)chunk_len, nobs);
-    for (long long s0 = c0; s0 < c1; s0 += SD_CH) {
-    const int cnt = (int)min((long long)SD_CH, c1 - s0);
-    const int ngrp = (cnt + SD_T - 1) / SD_T;
+    for (long long s0 = c0; s0 < c1; s0 += CH) {
+    const int cnt = (int)min((long long)CH, c1 - s0);
+    const int ngrp = (cnt + T - 1) / T;
     if (s0 > c0) __syncthreads();                                  // the previous piece's replica segment is no longer read
     // entry u <-> w[(s0 - NLAG + u) mod nobs]; every 16-byte word a lane will read is written (the overhang with whatever
     // follows in the code: it meets samples that are masked to zero)
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(SD_NT, 2) void k_sliding_dot(const XT* __restrict__
         k += tid;
         if (k >= nobs) { k -= nobs; if (k >= nobs) k %= nobs; }
         const long long step = SD_NT % nobs;
-        const int nent = 4 * (ngrp + NQ);
+        const int nent = 4 * (WG * ngrp + NQ);
         float* wave_base = sw + (tid & ~63);
         for (int u0 = 0; u0 < nent; u0 += SD_NT) {
             if (u0 + tid < nent)
@@ -90,15 +99,27 @@ __global__ __launch_bounds__(SD_NT, 2) void k_sliding_dot(const XT* __restrict__
     // the samples of the NEXT pass are requested before this pass's arithmetic (two waves per SIMD do not hide a global
     // load round trip per pass by themselves); loads are unconditional with clamped indices, values masked below
     const long long ilast = (long long)p * nobs + s0 + cnt - 1;
-    XT nx[SD_T];
-    {
-        const long long i0 = (long long)p * nobs + s0 + (long long)SD_T * min(tid, ngrp - 1);
+    XT nx[T];
+    auto load_group = [&](int g) {
+        const long long i0 = (long long)p * nobs + s0 + (long long)T * min(g, ngrp - 1);
+        if constexpr (VEC) {
+            // 16-byte loads at the samples' own alignment (4 or 8 bytes: pt is any sample)
+            typedef unsigned uvec4 __attribute__((ext_vector_type(4), aligned(4)));
+            constexpr int NV = (int)(T * sizeof(XT) / 16);
+            const uvec4* src = reinterpret_cast<const uvec4*>(x + pt + i0);
+            unsigned raw[NV * 4];
 #pragma unroll
-        for (int j = 0; j < SD_T; ++j) nx[j] = x[(pt + min(i0 + j, ilast)) * nch];
-    }
+            for (int v = 0; v < NV; ++v) { const uvec4 q = src[v]; raw[4 * v] = q.x; raw[4 * v + 1] = q.y; raw[4 * v + 2] = q.z; raw[4 * v + 3] = q.w; }
+            __builtin_memcpy(nx, raw, sizeof raw);
+        } else {
+#pragma unroll
+            for (int j = 0; j < T; ++j) nx[j] = x[(pt + min(i0 + j, ilast)) * nch];
+        }
+    };
+    load_group(tid);
     float bcs, bsn;                                                // the lane's NCO at its first sample of this piece
     {
-        double ph = ff * (double)((long long)p * nobs + s0 + (long long)SD_T * tid) + phi;   // fp64 phase reduction, fp32 sincos
+        double ph = ff * (double)((long long)p * nobs + s0 + (long long)T * tid) + phi;   // fp64 phase reduction, fp32 sincos
         ph -= rint(ph);
         sincospif(-2.0f * (float)ph, &bsn, &bcs);
     }
@@ -106,10 +127,10 @@ __global__ __launch_bounds__(SD_NT, 2) void k_sliding_dot(const XT* __restrict__
     __syncthreads();
     int pass = 0;
     for (int g = tid; g < ngrp; g += SD_NT, ++pass) {
-        const int t0 = SD_T * g;
-        XT sm[SD_T];
+        const int t0 = T * g;
+        XT sm[T];
 #pragma unroll
-        for (int j = 0; j < SD_T; ++j) {
+        for (int j = 0; j < T; ++j) {
             // opaque hand-over: otherwise the conversion to float moves up behind the load in the PREVIOUS pass (the loop then
             // carries floats) and that pass waits for the samples it asked for a few hundred cycles earlier
             sm[j] = nx[j];
@@ -117,40 +138,36 @@ __global__ __launch_bounds__(SD_NT, 2) void k_sliding_dot(const XT* __restrict__
         }
         const float2 pr = rot.r[pass];                             // kernel argument, uniform index: a scalar load
         float cs = bcs * pr.x - bsn * pr.y, sn = bcs * pr.y + bsn * pr.x;
-        f2 y[SD_T];
+        f2 y[T];
 #pragma unroll
-        for (int j = 0; j < SD_T; ++j) {
+        for (int j = 0; j < T; ++j) {
             const float re = (float)sm[j].x, im = (float)sm[j].y;
             const float m = (t0 + j < cnt) ? scale : 0.f;
             y[j] = f2{m * (re * cs - im * sn), m * (re * sn + im * cs)};
             const float c2 = cs * rot_c - sn * rot_s, s2 = cs * rot_s + sn * rot_c;
             cs = c2; sn = s2;
         }
-        // sample t0+j, lag index l  <->  replica entry SD_T*g + (j + 2*NLAG - l)
+        // sample t0+j, lag index l  <->  replica entry T*g + (j + 2*NLAG - l)
         // The next pass's samples are asked for HERE, after the mixing: their landing registers are single dwords, and next to
         // the mixing's temporaries they ended up as the unused halves of packed operands — the pass then waited for them a few
         // hundred cycles after asking (the packed instruction reads the pair).  In the accumulation below every packed operand
         // is a whole tuple (accumulator, y, the word read from LDS).
         __builtin_amdgcn_sched_barrier(0);
-        {
-            const long long i1 = (long long)p * nobs + s0 + (long long)SD_T * min(g + SD_NT, ngrp - 1);
-#pragma unroll
-            for (int j = 0; j < SD_T; ++j) nx[j] = x[(pt + min(i1 + j, ilast)) * nch];
-        }
+        load_group(g + SD_NT);
         __builtin_amdgcn_sched_barrier(0);
         // word by word, two words ahead of the arithmetic: the four entries of a word meet their (sample, lag) pairs and are dead
         // before the next word is needed.  The scheduling barriers keep that order — left alone, the scheduler asks for all
         // NQ words first (60 registers on top of the 114 accumulators: spills at the 256-register limit of two waves per SIMD)
-        float4 q0 = sw4[g], q1 = sw4[g + 1];
+        float4 q0 = sw4[WG * g], q1 = sw4[WG * g + 1];
 #pragma unroll
         for (int m = 0; m < NQ; ++m) {
             float4 q2 = q1;
-            if (m + 2 < NQ) q2 = sw4[g + m + 2];
+            if (m + 2 < NQ) q2 = sw4[WG * g + m + 2];
             const float cw[4] = {q0.x, q0.y, q0.z, q0.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                for (int j = 0; j < SD_T; ++j) {
+                for (int j = 0; j < T; ++j) {
                     const int l = j + 2 * NLAG - (4 * m + e);
                     if (l >= 0 && l < NL) acc[l] = __builtin_elementwise_fma(y[j], f2{cw[e], cw[e]}, acc[l]);
                 }
@@ -212,7 +229,12 @@ __global__ void k_sliding_reduce(const double* __restrict__ partial, int nchunks
 
 // samples per workgroup: at most SD_CH (the LDS segment), chosen so that the grid is a whole number of "rounds" of two
 // workgroups per CU (a 600-workgroup grid on 512 slots runs a second, mostly empty round)
-int sliding_chunk(long long nobs, int ncodes) {
+// the streaming form for narrow lag windows (see the kernel): whole groups of eight samples, one channel
+bool sliding_narrow(long long nobs, int nlag, int nch) {
+    static const bool off = getenv("TWX_SLIDING_NARROW") && atoi(getenv("TWX_SLIDING_NARROW")) == 0;      // A/B (profiles/r04_sliding_scan.txt)
+    return !off && nlag <= 8 && nch == 1 && nobs % 8 == 0;
+}
+int sliding_chunk(long long nobs, int ncodes, bool narrow) {
     static const int ncu = [] {                                    // one process drives one GPU (or GPUs of one kind)
         int n = 256, dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) return n;
@@ -220,35 +242,41 @@ int sliding_chunk(long long nobs, int ncodes) {
     }();
     // one workgroup per slot (two per CU) where the work allows it: chunks of a code of nobs/ceil(...) samples, any length (the
     // kernel walks a chunk in LDS-sized pieces), at least 4096 samples so that the block reduction stays a small part
-    const long long slots = 2ll * ncu;
+    const long long slots = (narrow ? 4ll : 2ll) * ncu;
     const long long per_code = std::max<long long>(1, slots / ncodes);                    // chunks per code in one round
     long long len = (nobs + per_code - 1) / per_code;
-    len = std::max<long long>(4096, ((len + SD_NT * SD_T - 1) / (SD_NT * SD_T)) * (SD_NT * SD_T));
+    const long long gran = SD_NT * (narrow ? 8 : SD_T);
+    len = std::max<long long>(4096, ((len + gran - 1) / gran) * gran);
     return (int)std::min<long long>(len, 1ll << 24);
 }
 template <typename XT>
 int launch_sliding(hipStream_t st, const XT* dx, int nch, long long pt, long long nobs, int ncodes, int nlag, const float* dw,
                    double ff, double phi, double scale, double* dpart, double* dout) {
-    const int clen = sliding_chunk(nobs, ncodes);
+    const bool narrow = sliding_narrow(nobs, nlag, nch);
+    const int clen = sliding_chunk(nobs, ncodes, narrow);
     const int nchunks = (int)((nobs + clen - 1) / clen);
     const dim3 grid(nchunks, ncodes), block(SD_NT);
+    const int T = narrow ? 8 : SD_T;
     const double two_pi = 6.283185307179586476925286766559;
     const float rot_c = (float)cos(two_pi * ff), rot_s = (float)(-sin(two_pi * ff));          // exp(-2 pi j ff)
     SdRot rot;
     for (int k = 0; k < SD_NPASS; ++k) {
-        double a = ff * (double)(SD_T * SD_NT * k);
+        double a = ff * (double)(T * SD_NT * k);
         a -= rint(a);
         rot.r[k] = make_float2((float)cos(two_pi * a), (float)(-sin(two_pi * a)));
     }
 #define SD_GO(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_, XT>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, rot, dpart)
-    if (nlag <= 4) SD_GO(4); else if (nlag <= 8) SD_GO(8); else if (nlag <= 16) SD_GO(16); else if (nlag <= 28) SD_GO(28); else SD_GO(31);
+#define SD_GO8(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_, XT, 8, 8192, 4>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, rot, dpart)
+    if (narrow) { if (nlag <= 4) SD_GO8(4); else SD_GO8(8); }
+    else if (nlag <= 4) SD_GO(4); else if (nlag <= 8) SD_GO(8); else if (nlag <= 16) SD_GO(16); else if (nlag <= 28) SD_GO(28); else SD_GO(31);
 #undef SD_GO
+#undef SD_GO8
     if (hipGetLastError() != hipSuccess) return TWX_E_HIP;
     hipLaunchKernelGGL(k_sliding_reduce, dim3(ncodes), dim3(64), 0, st, dpart, nchunks, 2 * nlag + 1, 1.0 / (double)nobs, dout);
     return hipGetLastError() == hipSuccess ? TWX_OK : TWX_E_HIP;
 }
 size_t sliding_part_bytes(long long nobs, int ncodes, int nlag) {
-    const int clen = sliding_chunk(nobs, ncodes);
+    const int clen = std::min(sliding_chunk(nobs, ncodes, false), sliding_chunk(nobs, ncodes, true));      // the form is chosen at launch (channel count)
     return (size_t)ncodes * (size_t)((nobs + clen - 1) / clen) * (2 * nlag + 1) * 16;
 }
 

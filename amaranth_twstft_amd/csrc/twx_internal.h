@@ -9,7 +9,7 @@
 #define TWX_HIDDEN __attribute__((visibility("hidden")))
 
 namespace twx {
-enum { AUX_SCRATCH_SLOTS = 8 };
+enum { AUX_SCRATCH_SLOTS = 12 };      // 0-1, 6: twx_aux.hip; 2-5: the CAF surface; 7-9: the long squared spectra
 TWX_HIDDEN hipStream_t ctx_stream(twx_ctx* ctx);                        // = twx_stream(ctx)
 // Context-owned device buffer number `slot`, at least `bytes` long: kept across calls, re-allocated only when it has
 // to grow (after synchronising the context), released by twx_destroy.  nullptr on failure (error text set).

@@ -423,7 +423,9 @@ __global__ __launch_bounds__(256) void k_sums_deint2(const int4* __restrict__ in
 // ------------------------------------------------------------------------------------------
 // k_df_tables: (optionally) finish the coarse carrier estimate, then build the per-window NCO
 // tables  E1[n1] = exp(-2*pi*i*df*n1*N2/fs),  E2[n2] = exp(-2*pi*i*df*n2/fs)
-// (lo=exp(-j*2*pi*df*temps), godual_ranging.m:17 with temps=[0:N-1]/fs :72).  grid = windows
+// (lo=exp(-j*2*pi*df*temps), godual_ranging.m:17 with temps=[0:N-1]/fs :72).  grid = (windows, slices): every slice finishes the
+// estimate for itself (a few hundred records) and fills its share of the tables — one workgroup per window spent 9 us on the
+// 8 625 fp64 sincospi of a 1-s window, which a one-window call (the per-second loops, MEX form A) waits for in full
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_df_tables(int estimate, const ArgPart<T>* __restrict__ part, int nparts,
@@ -431,6 +433,7 @@ __global__ __launch_bounds__(256) void k_df_tables(int estimate, const ArgPart<T
                                                    double fs, long long n, int n1, int n2,
                                                    cpx<T>* __restrict__ e1, cpx<T>* __restrict__ e2) {
     const int b = blockIdx.x;
+    const bool lead = blockIdx.y == 0;
     __shared__ double s_df;
     __shared__ char scratch[64];
     if (estimate == 1) {
@@ -444,16 +447,15 @@ __global__ __launch_bounds__(256) void k_df_tables(int estimate, const ArgPart<T
             const double step = fs / (double)(n - 1);
             double f = (i == n - 1) ? fs / 2 : __dadd_rn(__dmul_rn((double)i, step), -fs / 2);
             s_df = f / 2;
-            dfv[b] = s_df;
-            dfidx[b] = i;
+            if (lead) { dfv[b] = s_df; dfidx[b] = i; }
         }
     } else if (threadIdx.x == 0) {
         s_df = dfv[b];
-        if (estimate == 0) dfidx[b] = -1;     // 2: tables only (after the fine-frequency step)
+        if (estimate == 0 && lead) dfidx[b] = -1;     // 2: tables only (after the fine-frequency step)
     }
     __syncthreads();
     const double fn = s_df / fs;   // cycles per sample
-    for (int i = threadIdx.x; i < n1 + n2; i += 256) {
+    for (int i = threadIdx.x + 256 * blockIdx.y; i < n1 + n2; i += 256 * gridDim.y) {
         double ph;
         if (i < n1) ph = fn * ((double)i * (double)n2); else ph = fn * (double)(i - n1);
         ph -= rint(ph);
@@ -1715,35 +1717,81 @@ __global__ __launch_bounds__(256) void k_caf_reduce(const ArgPart<T>* __restrict
 //   k_sqspec_combine: a band of bins of an L = M*N point transform from the M decimated N-point
 //                     spectra F_r (r = n mod M): X[k] = sum_r W_L^{r k} F_r[k mod N].
 // ------------------------------------------------------------------------------------------
+// One pass over the samples for up to SQ_NB bins at a time.  A thread walks the samples n0, n0 + stride, ...: its twiddle
+// exp(-2 pi i k n / L) starts from an exact integer phase reduction (one 64-bit modulo and one fp64 sincospi per bin and thread) and
+// advances by the constant factor exp(-2 pi i k stride / L) — a complex multiply per sample and bin where the first version paid
+// a modulo and a sincospi; re-seeded exactly every 32 steps.  Per-workgroup partials, added up in a fixed order by
+// k_sq_dft_final: the first version's atomicAdd on the bins' 14 words (2 048 workgroups on each) was most of its 1.15 ms per
+// 10^7-sample chunk (same-address device atomics: ~0.4 us each, profiles/r04_tracked_rate.txt) and made the sums order-dependent.
+// grid = workgroups (any), partial[gridDim.x][nb][2]
+#define TWX_SQ_NB 8
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void k_sq_dft_bins(const short2* __restrict__ in, int nch, long long L,
-                                                     const long long* __restrict__ bins, int nb, double* __restrict__ acc /*[nb][2]*/) {
-    __shared__ double red[4][2];
+                                                     const long long* __restrict__ bins, int nb, double* __restrict__ partial) {
+    __shared__ double red[4][2 * TWX_SQ_NB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int bi = 0; bi < nb; ++bi) {
-        const long long kk = bins[bi];            // already reduced to 0..L-1
-        double sx = 0, sy = 0;
-        for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < L; n += (long long)gridDim.x * 256) {
+    const long long n0 = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+    for (int b0 = 0; b0 < nb; b0 += TWX_SQ_NB) {
+        const int cnt = min(TWX_SQ_NB, nb - b0);
+        double zc[TWX_SQ_NB], zs[TWX_SQ_NB], wc[TWX_SQ_NB], ws[TWX_SQ_NB], sx[TWX_SQ_NB], sy[TWX_SQ_NB];
+        unsigned long long kk[TWX_SQ_NB];
+#pragma unroll
+        for (int j = 0; j < TWX_SQ_NB; ++j) {
+            kk[j] = (unsigned long long)bins[b0 + min(j, cnt - 1)];          // already reduced to 0..L-1
+            const unsigned long long ts = ((unsigned long long)stride % (unsigned long long)L * kk[j]) % (unsigned long long)L;
+            sincospi(2.0 * (double)ts / (double)L, &ws[j], &wc[j]);
+            sx[j] = 0; sy[j] = 0; zc[j] = 1; zs[j] = 0;
+        }
+        int step = 0;
+        for (long long n = n0; n < L; n += stride, ++step) {
+            if ((step & 31) == 0) {
+#pragma unroll
+                for (int j = 0; j < TWX_SQ_NB; ++j) {
+                    const unsigned long long t = ((unsigned long long)n * kk[j]) % (unsigned long long)L;     // n < L < 2^32 in every use: no overflow
+                    sincospi(2.0 * (double)t / (double)L, &zs[j], &zc[j]);
+                }
+            }
             const short2 s = in[n * nch];
             const double I = (double)s.x, Q = (double)s.y;
-            const double re = I * I - Q * Q, im = 2.0 * I * Q;          // d^2, exact
-            const unsigned long long t = ((unsigned long long)n * (unsigned long long)kk) % (unsigned long long)L;
-            double sn, cs;
-            sincospi(2.0 * (double)t / (double)L, &sn, &cs);
-            sx += re * cs + im * sn;                                     // d^2 * exp(-i phi)
-            sy += im * cs - re * sn;
+            const double re = I * I - Q * Q, im = 2.0 * I * Q;               // d^2, exact
+#pragma unroll
+            for (int j = 0; j < TWX_SQ_NB; ++j) {
+                sx[j] += re * zc[j] + im * zs[j];                            // d^2 * exp(-i phi)
+                sy[j] += im * zc[j] - re * zs[j];
+                const double c2 = zc[j] * wc[j] - zs[j] * ws[j], s2 = zc[j] * ws[j] + zs[j] * wc[j];
+                zc[j] = c2; zs[j] = s2;
+            }
         }
-        for (int d = 32; d >= 1; d >>= 1) { sx += __shfl_down(sx, d, 64); sy += __shfl_down(sy, d, 64); }
-        if (lane == 0) { red[wave][0] = sx; red[wave][1] = sy; }
+#pragma unroll
+        for (int j = 0; j < TWX_SQ_NB; ++j) {
+            for (int d = 32; d >= 1; d >>= 1) { sx[j] += __shfl_down(sx[j], d, 64); sy[j] += __shfl_down(sy[j], d, 64); }
+            if (lane == 0) { red[wave][2 * j] = sx[j]; red[wave][2 * j + 1] = sy[j]; }
+        }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            atomicAdd(&acc[2 * bi], red[0][0] + red[1][0] + red[2][0] + red[3][0]);
-            atomicAdd(&acc[2 * bi + 1], red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+        if (threadIdx.x < 2 * cnt) {
+            const int q = threadIdx.x;
+            partial[((long long)blockIdx.x * nb + b0) * 2 + q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
         }
         __syncthreads();
     }
 }
+// acc[q] = sum over the workgroups' partials, fixed order.  grid = 1, block = 256
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_sq_dft_final(const double* __restrict__ partial, int nparts, int nvals, double* __restrict__ acc) {
+    __shared__ double sh[256];
+    for (int q = 0; q < nvals; ++q) {
+        double a = 0;
+        for (int i = threadIdx.x; i < nparts; i += 256) a += partial[(long long)i * nvals + q];
+        sh[threadIdx.x] = a;
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) { if (threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h]; __syncthreads(); }
+        if (threadIdx.x == 0) acc[q] = sh[0];
+        __syncthreads();
+    }
+}
 
+// the twiddle W_L^{r k} advances by the constant factor exp(-2 pi i k / L) from r to r + 1 (one fp64 sincospi per bin instead of
+// one per term; M <= 4096 steps of fp64 rounding)
 template <typename T>
 __global__ __launch_bounds__(256) void k_sqspec_combine(const cpx<T>* __restrict__ spec /*[M][k1][k2]*/, int M, long long N, int N1, int N2,
                                                         long long k_lo, long long nk, double* __restrict__ mag) {
@@ -1753,14 +1801,19 @@ __global__ __launch_bounds__(256) void k_sqspec_combine(const cpx<T>* __restrict
     long long kk = (k_lo + i) % L; if (kk < 0) kk += L;
     const long long j = kk % N;
     const int k1 = (int)(j % N1), k2 = (int)(j / N1);
-    double sx = 0, sy = 0;
+    double ws, wc;
+    sincospi(2.0 * (double)kk / (double)L, &ws, &wc);
+    double zc = 1, zs = 0, sx = 0, sy = 0;
     for (int r = 0; r < M; ++r) {
+        if ((r & 63) == 0 && r) {                                            // exact re-seed
+            const unsigned long long t = ((unsigned long long)r * (unsigned long long)kk) % (unsigned long long)L;
+            sincospi(2.0 * (double)t / (double)L, &zs, &zc);
+        }
         const cpx<T> f = spec[(long long)r * N + (long long)k1 * N2 + k2];
-        const unsigned long long t = ((unsigned long long)r * (unsigned long long)kk) % (unsigned long long)L;
-        double sn, cs;
-        sincospi(2.0 * (double)t / (double)L, &sn, &cs);
-        sx += (double)f.x * cs + (double)f.y * sn;
-        sy += (double)f.y * cs - (double)f.x * sn;
+        sx += (double)f.x * zc + (double)f.y * zs;
+        sy += (double)f.y * zc - (double)f.x * zs;
+        const double c2 = zc * wc - zs * ws, s2 = zc * ws + zs * wc;
+        zc = c2; zs = s2;
     }
     mag[i] = sqrt(sx * sx + sy * sy);
 }

@@ -448,6 +448,13 @@ def test_sliding_dot_short_code():
     (700, 2, 28, 1, 0, 0),            # a period shorter than one pass of the workgroup
     (10, 3, 28, 1, 0, 0),             # a period shorter than the lag window
     (1, 2, 4, 1, 0, 0),
+    # the streaming form of narrow windows (nlag <= 8, one channel, nobs a multiple of 8: eight samples per lane, 16-byte loads)
+    (400000, 24, 8, 1, 0, 3),         # sdr.param size at the program's default +-8 lags (rxcomplex.cpp:295), unaligned start
+    (40000, 30, 4, 1, 0, 1),          # 4-ms codes
+    (8200, 2, 8, 1, 0, 5),            # a chunk one group longer than the 8192-sample LDS piece
+    (8, 3, 4, 1, 0, 0),               # a period of one group
+    (40000, 5, 8, 2, 1, 0),           # two channels: the general form
+    (9004, 3, 8, 1, 0, 0),            # period not a multiple of 8: the general form
 ])
 def test_sliding_dot_shapes(nobs, ncodes, nlag, nch, ch, pt):
     """k_sliding_dot over its lag-count instantiations (4, 8, 16, 28, 31), chunk / piece / pass boundaries, odd periods (the wrap
@@ -1012,3 +1019,31 @@ def test_all_channels_from_one_copy(tmp_path):
         for a, b_ in zip(sep_df[c], both_df[c]):
             assert (a.indice, a.xval, a.df) == (b_.indice, b_.xval, b_.df)
     assert len(both[0]) == len(both[1]) == 9
+
+
+@pytest.mark.parametrize("nobs,ncodes,nlag,pt", [(400000, 24, 28, 5), (40000, 9, 8, 3), (40000, 9, 14, 0), (9004, 3, 8, 1)])
+def test_sliding_dot_on_complex_float_samples(nobs, ncodes, nlag, pt):
+    """twx_sliding_dot_cdev: the same correlator on complex-float samples resident on the device (the x2-interpolated stream the
+    DLL/PLL receiver tracks on, rxcomplex.cpp:477,602), both kernel forms, against the definition in fp64."""
+    import ctypes as C2
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(nobs + nlag)
+    w = rng.choice([-1.0, 1.0], nobs).astype(np.float32)
+    n = pt + nobs * ncodes + 8
+    x = (rng.normal(0, 0.1, n) + 1j * rng.normal(0, 0.1, n)).astype(np.complex64)
+    xd = torch.from_numpy(np.ascontiguousarray(x).view(np.float32).reshape(-1, 2)).to(dev)
+    wd = torch.from_numpy(w).to(dev)
+    out = torch.zeros((ncodes, 2 * nlag + 1, 2), dtype=torch.float64, device=dev)
+    ff, phi, scale = 3.1e-5, 0.37, 1.4142135624
+    with Correlator(lfsr=(14, 43, 10000), fs=FS) as cor:
+        L.check(cor._lib.twx_sliding_dot_cdev(cor._h, xd.data_ptr(), n, pt, nobs, ncodes, nlag, wd.data_ptr(), ff, phi, scale, out.data_ptr()), cor._h)
+        cor.synchronize()
+    got = out.cpu().numpy()
+    got = got[..., 0] + 1j * got[..., 1]
+    xx = x.astype(np.complex128)
+    for p in range(ncodes):
+        i = np.arange(p * nobs, (p + 1) * nobs)
+        y = scale * xx[pt + i] * np.exp(-2j * np.pi * (ff * i + phi))
+        ref = orc.sliding_dot(y, w.astype(np.float64), nlag)
+        assert np.abs(got[p] - ref).max() <= 3e-6 * np.abs(ref).max() + 1e-12

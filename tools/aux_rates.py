@@ -80,7 +80,7 @@ def sliding():
 def sliding_scan():
     """time against the lag count and the code count: which part of k_sliding_dot's time is the FMA stream?"""
     nobs = 400_000
-    for ncodes, nlag in ((24, 4), (24, 8), (24, 16), (24, 28), (6, 28), (96, 28)):
+    for ncodes, nlag in ((24, 4), (24, 8), (96, 4), (96, 8), (24, 16), (24, 28), (6, 28), (96, 28)):
         n = nobs * ncodes + 64
         x = torch.randint(-3000, 3000, (n, 2), dtype=torch.int16, device=dev)
         rep = (torch.randint(0, 2, (nobs,), device=dev).float() * 2 - 1).contiguous()
@@ -89,7 +89,9 @@ def sliding_scan():
             dt = timed(lambda: cor.sliding_dot_dev(x.data_ptr(), n, rep.data_ptr(), nobs, ncodes, nlag, out.data_ptr(), ff=1.234e-5, scale=1.0 / 32768),
                        cor.synchronize, 50)
         flops = nobs * ncodes * (2 * nlag + 1) * 4
+        byts = nobs * ncodes * 4 + nobs * 4
         print(json.dumps({"kernel": "k_sliding_dot scan", "ncodes": ncodes, "nlag": nlag, "ms": round(dt * 1e3, 4), "Gsample_s": round(nobs * ncodes / dt / 1e9, 1),
+                          "GB_s": round(byts / dt / 1e9, 1), "frac_hbm": round(byts / dt / 1e9 / HBM, 4),
                           "TFLOP_s": round(flops / dt / 1e12, 2), "frac_fp32_vector": round(flops / dt / 1e12 / VEC, 4)}))
 
 
