@@ -49,6 +49,9 @@
 #ifndef TWX_MID_SGPR
 #define TWX_MID_SGPR 1   // k_rowd<MID>: wave-uniform factors (stage C's W_N^{-k1 c M}, the ramp's q2 part) through scalar loads, not LDS reads
 #endif
+#ifndef TWX_MID_ST16
+#define TWX_MID_ST16 0  // k_rowd<MID>: Bz stores as 16-byte stores (lane pairs swap half of their outputs through DPP); A/B: profiles/r04_rowd_st16.txt
+#endif
 #ifndef TWX_NT_INV
 #define TWX_NT_INV 1    // k_col_inv3: non-temporal loads of Bz (read exactly once)
 #endif
@@ -1335,12 +1338,37 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                 // same addresses).  Inside a divergent branch the wait-count pass must assume the stores were skipped, and every
                 // later wait for a load issued before them (the next phase's ramp factor, the next row) becomes vmcnt(0): a store
                 // round trip per phase.  Unconditional, they are counted: vmcnt(20).
-                const int ltc = min(lt, M - 1);
+                constexpr bool ST16 = TWX_MID_ST16 && FOLD && sizeof(T) == 4 && R0 % 2 == 0 && M % 2 == 0;
+                // ST16: the idle lanes repeat the PAIR (M-2, M-1), so that every lane pair exchanges like a live one
+                const int ltc = ST16 ? (lt < M ? lt : M - 2 + (lt & 1)) : min(lt, M - 1);
                 D::iC(lds, ltc, v);
                 const C uu = cmul(ub, r1);
                 C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
                 const unsigned ltb = (unsigned)ltc * (unsigned)sizeof(C);
                 const unsigned long long ob = sgpr_u64(reinterpret_cast<unsigned long long>(out));
+                if constexpr (ST16) {
+                    // Lane t (even) and t+1 hold z[t + M c], z[t+1 + M c] for every c.  For the row pair (c, c+1) the even lane takes
+                    // its neighbour's value of row c and stores {z[t], z[t+1]} of row c as ONE 16-byte store, the odd lane the same
+                    // for row c+1: half the store instructions, each a full 128-byte line per eight lanes.  The exchange is a DPP
+                    // quad_perm [1,0,3,2] move (full-rate VALU, no LDS): each lane sends what its neighbour stores.
+                    const bool odd = (ltc & 1) != 0;
+                    const unsigned ltb16 = (unsigned)(ltc & ~1) * (unsigned)sizeof(C);
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    TWX_UNROLL
+                    for (int c = 0; c < R0; c += 2) {
+                        const C oe = USGPR ? cmul_us(v[c], ld_uniform(vcrow, c)) : cmul(v[c], s_vc[c]);
+                        const C oo = USGPR ? cmul_us(v[c + 1], ld_uniform(vcrow, c + 1)) : cmul(v[c + 1], s_vc[c + 1]);
+                        const float sx = odd ? (float)oe.x : (float)oo.x, sy = odd ? (float)oe.y : (float)oo.y;
+                        const float rx = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sx), 0xB1, 0xF, 0xF, true));
+                        const float ry = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sy), 0xB1, 0xF, 0xF, true));
+                        f4 w;
+                        w.x = odd ? rx : (float)oe.x; w.y = odd ? ry : (float)oe.y;
+                        w.z = odd ? (float)oo.x : rx; w.w = odd ? (float)oo.y : ry;
+                        // even lane: row c; odd lane: row c + 1 (the row offset is a per-lane quantity here: one VALU add)
+                        const unsigned rowoff = (unsigned)((c + (odd ? 1 : 0)) * M) * (unsigned)sizeof(C);
+                        if (TWX_ABLR != 1) st_pin<f4, TWX_NT_BZ != 0>(ob, 0ull, ltb16 + rowoff, w);
+                    }
+                } else
                 TWX_UNROLL
                 for (int c = 0; c < R0; ++c) {
                     C o;                                                                       // · W_N^{-k1 (t + c M)} · ramp1
