@@ -1179,7 +1179,7 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipMemcpyAsync(bd, hb, sizeof(long long) * nb, hipMemcpyHostToDevice, stream));
         TWX_LAUNCH((k_sq_dft_bins<0>), dim3(grid), dim3(256), stream, reinterpret_cast<const short2*>(iq_dev) + ch, nch, L, bd, nb, part);
         HIPCHK(hipGetLastError());
-        TWX_LAUNCH((k_sq_dft_final<0>), dim3(1), dim3(256), stream, part, (int)grid, 2 * nb, acc);
+        TWX_LAUNCH((k_sq_dft_final<0>), dim3(2 * nb), dim3(256), stream, part, (int)grid, 2 * nb, acc);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(out, acc, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));

@@ -1803,19 +1803,17 @@ __global__ __launch_bounds__(256) void k_sq_dft_bins(const short2* __restrict__ 
         __syncthreads();
     }
 }
-// acc[q] = sum over the workgroups' partials, fixed order.  grid = 1, block = 256
+// acc[q] = sum over the workgroups' partials, fixed order.  grid = nvals (one workgroup per value), block = 256
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void k_sq_dft_final(const double* __restrict__ partial, int nparts, int nvals, double* __restrict__ acc) {
     __shared__ double sh[256];
-    for (int q = 0; q < nvals; ++q) {
-        double a = 0;
-        for (int i = threadIdx.x; i < nparts; i += 256) a += partial[(long long)i * nvals + q];
-        sh[threadIdx.x] = a;
-        __syncthreads();
-        for (int h = 128; h > 0; h >>= 1) { if (threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h]; __syncthreads(); }
-        if (threadIdx.x == 0) acc[q] = sh[0];
-        __syncthreads();
-    }
+    const int q = blockIdx.x;
+    double a = 0;
+    for (int i = threadIdx.x; i < nparts; i += 256) a += partial[(long long)i * nvals + q];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) { if (threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h]; __syncthreads(); }
+    if (threadIdx.x == 0) acc[q] = sh[0];
 }
 
 // the twiddle W_L^{r k} advances by the constant factor exp(-2 pi i k / L) from r to r + 1 (one fp64 sincospi per bin instead of

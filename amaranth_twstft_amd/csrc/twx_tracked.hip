@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <unistd.h>
+#include <atomic>
 #include <chrono>
 #include <future>
 #include <new>
@@ -151,7 +152,9 @@ struct twx_tracked : twx_trk::Backend {
     // int16 positions [pos, pos + 2L) into dst; returns the int16 count delivered.  The chunk (40 MB for the scripts' 2-s
     // chunks) is fetched as IO_PIECES concurrent pieces: one pread / memcpy runs at ~5 GB/s, the PCIe copy behind it at ten
     // times that (same finding as twx_process_file's ingest)
-    enum { IO_PIECES = 4 };
+    // (TWX_IO_THREADS pieces, default 8: with 4 the 180-s record ran at the speed of the page-cache copy, 25 GB/s — profiles/r04_tracked_rate.txt)
+    enum { IO_PIECES_MAX = 32 };
+    int io_pieces = [] { const char* e = getenv("TWX_IO_THREADS"); return e ? std::max(1, std::min((int)IO_PIECES_MAX, atoi(e))) : 8; }();
     size_t read_bytes(size_t off, char* dst, size_t len) const {           // [off, off+len) of the capture, in bytes
         if (host_src) {
             const size_t total = (size_t)src_i16 * 2;
@@ -168,22 +171,35 @@ struct twx_tracked : twx_trk::Backend {
         }
         return done;
     }
-    long long read_at(long long pos, void* dst) const {
+    // stage >= 0: every piece that arrives whole goes on to stage_dev[stage] at once, on the copy stream, from the thread that read
+    // it — the PCIe transfer of the first pieces runs beside the reads of the later ones; *staged_ok = every piece went out
+    long long read_at(long long pos, void* dst, int stage = -1, bool* staged_ok = nullptr) const {
         const size_t need = (size_t)P.L * 4, off0 = (size_t)pos * 2;
-        const size_t piece = ((need + IO_PIECES - 1) / IO_PIECES + 4095) & ~(size_t)4095;
-        std::future<size_t> parts[IO_PIECES];
-        for (int i = 1; i < IO_PIECES; ++i) {
+        const int NP = io_pieces;
+        const size_t piece = ((need + NP - 1) / NP + 4095) & ~(size_t)4095;
+        std::future<size_t> parts[IO_PIECES_MAX];
+        std::atomic<int> copy_failed{0};
+        auto one = [this, off0, dst, stage, &copy_failed](size_t lo, size_t hi) -> size_t {
+            const size_t got = read_bytes(off0 + lo, (char*)dst + lo, hi - lo);
+            if (stage >= 0 && got == hi - lo && got) {
+                (void)hipSetDevice(dev);
+                if (hipMemcpyAsync(reinterpret_cast<char*>(stage_dev[stage]) + lo, (const char*)dst + lo, got, hipMemcpyHostToDevice, cst) != hipSuccess) copy_failed = 1;
+            }
+            return got;
+        };
+        for (int i = 1; i < NP; ++i) {
             const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));
-            if (hi > lo) parts[i] = std::async(std::launch::async, [this, off0, lo, hi, dst]() { return read_bytes(off0 + lo, (char*)dst + lo, hi - lo); });
+            if (hi > lo) parts[i] = std::async(std::launch::async, one, lo, hi);
         }
-        size_t total = read_bytes(off0, (char*)dst, std::min(need, piece));
+        size_t total = one(0, std::min(need, piece));
         bool contiguous = total == std::min(need, piece);
-        for (int i = 1; i < IO_PIECES; ++i) {
+        for (int i = 1; i < NP; ++i) {
             if (!parts[i].valid()) continue;
             const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));
             const size_t got = parts[i].get();
             if (contiguous) { total += got; contiguous = got == hi - lo; }
         }
+        if (staged_ok) *staged_ok = copy_failed.load() == 0;
         return (long long)(total / 2);
     }
 
@@ -211,11 +227,11 @@ struct twx_tracked : twx_trk::Backend {
         ahead_slot = cur ^ 1; ahead_pos = pos + 2 * P.L;
         const int as = ahead_slot; const long long np = ahead_pos;
         ahead = std::async(std::launch::async, [this, np, as]() {
-            const long long g = read_at(np, pin[as]);
+            bool ok = true;
+            const long long g = read_at(np, pin[as], as, &ok);
             if (g == 2 * P.L) {
                 (void)hipSetDevice(dev);
-                if (hipMemcpyAsync(stage_dev[as], pin[as], (size_t)P.L * 4, hipMemcpyHostToDevice, cst) != hipSuccess ||
-                    hipEventRecord(h2d_ev[as], cst) != hipSuccess) return (long long)-1;           // reported as a short chunk by the caller's test
+                if (!ok || hipEventRecord(h2d_ev[as], cst) != hipSuccess) return (long long)-1;    // load_chunk reports it
             }
             return g;
         });

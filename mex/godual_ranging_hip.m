@@ -22,6 +22,8 @@ codelocation=getenv('codelocation');
 if (isempty(datalocation)) datalocation='./'; end
 if (isempty(codelocation)) codelocation='./codes/'; end
 if (!isempty(getenv('OP'))) OP=str2num(getenv('OP')); end
+ngpu=1;                      % TWX_NGPU=N: every capture as ONE call over N GPUs (call form C of the gateway: each device reads its own extent)
+if (!isempty(getenv('TWX_NGPU'))) ngpu=str2num(getenv('TWX_NGPU')); end
 
 % processing(d,k) of godual_ranging.m:12 — d: complex column, mean removed by the caller, one or several code lengths
 function [indice,correction,SNRr,SNRi,df,puissance,puissancecode,puissancenoise,xval]=processing(d,k)
@@ -59,14 +61,24 @@ for c=1:length(captures)
   printf("n\tdt1\tdf1\tP1\tSNR1\tdt2\tdf2\tP2\tSNR2\r\n");
   p=0;
   do
-    [raw,got]=fread(f,n*4*WIN,'int16=>int16');
-    nw=floor(got/(n*4));
+    if (ngpu>1)
+      % the whole capture in one call: the library cuts it into ngpu contiguous extents, one per device, and gathers the records
+      chan=0; if (remote==1) chan=1; end
+      [ii,cc,sr,si,dd,pu,pc,pn,xv]=twstft_processing_mex('file',[datalocation,'/',captures(c).name],2,chan,[k(1) k(end)],codeb,fs,Nint,ngpu);
+      nw=columns(ii); got=0;
+    else
+      [raw,got]=fread(f,n*4*WIN,'int16=>int16');
+      nw=floor(got/(n*4));
+    end
     if (nw>0)
-      raw=raw(1:nw*n*4);
-      if (remote!=1)
+      if (ngpu>1)
+        % outputs already there
+      elseif (remote!=1)
+        raw=raw(1:nw*n*4);
         % rows of every output: channel 1 (measurement), channel 2 (reference); columns: windows
         [ii,cc,sr,si,dd,pu,pc,pn,xv]=twstft_processing_mex(raw,2,0,[k(1) k(end)],codeb,fs,Nint);
       else
+        raw=raw(1:nw*n*4);
         [ii,cc,sr,si,dd,pu,pc,pn,xv]=twstft_processing_mex(raw,2,1,[k(1) k(end)],codeb,fs,Nint);
       end
       for w=1:nw
