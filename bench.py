@@ -382,10 +382,19 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(a.backend, rank=rank, world_size=world)
+        try:
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(a.backend, rank=rank, world_size=world)
+            probe = torch.zeros(1, device=dev if a.backend == "nccl" else "cpu")
+            dist.all_reduce(probe)                      # the first collective builds the communicator: fail HERE, with the library's text
+            if a.backend == "nccl":
+                torch.cuda.synchronize()
+        except Exception as e:                          # no retry, no re-exec: a rank that cannot join ends the job with a non-zero status
+            sys.stderr.write("bench.py rank %d/%d: %s initialisation failed: %s: %s\n(HSA_ENABLE_IPC_MODE_LEGACY=%s, visible GPUs %d)\n"
+                             % (rank, world, a.backend, type(e).__name__, e, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), ndev))
+            sys.exit(3)
 
     from amaranth_twstft_amd import _lib as L, prn
     from amaranth_twstft_amd.correlator import Correlator, band_godual

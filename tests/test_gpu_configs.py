@@ -291,6 +291,19 @@ def test_bench_self_launches_its_ranks():
     assert c["own_block_identical"] and c["all_ranks_agree"] and c["backend"] == "gloo"
 
 
+def test_bench_eight_ranks_collective_path():
+    """`python bench.py --gpus 8 --backend gloo --windows 8`: the 8-rank form of the line (configs[3]'s world size), ranks sharing the
+    GPUs the box has; the gathered buffer of EVERY rank is checked against what each of the eight ranks was given."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--windows", "8",
+                          "--backend", "gloo", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, env=env, timeout=1500)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    c = j["collective"]
+    assert j["n_gpus"] == 8 and j["integer_lag_exact"] and c["world"] == 8 and c["records"] == 64
+    assert c["ranks_with_exact_lags"] == 8 and c["gathered_lag_exact"] and c["own_block_identical"] and c["all_ranks_agree"]
+
+
 def test_bench_two_ranks_over_real_rccl():
     """`python bench.py --gpus 2` with the nccl (= RCCL) backend, one GPU per rank: runs wherever the box has two GPUs
     (the driver's 8-GPU node), skipped on a one-GPU box.  The gathered records of BOTH ranks must carry their own lags."""

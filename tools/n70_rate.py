@@ -22,3 +22,21 @@ with Correlator(chips, fs=fs, sps=sps, Nint=1, profile=True) as cor:
         print(cor.profile())
     except Exception as e:
         print("no profile", e)
+import json
+with Correlator(chips, fs=fs, sps=sps, Nint=1, profile=True) as cor:
+    cor.process_dev(wide.data_ptr(), nw, band=band)
+    cor.profile(reset=True)
+    cor.process_dev(wide.data_ptr(), nw, band=band)
+    prof = cor.profile()
+    tot = sum(v["ms_total"] for v in prof.values())
+    algo = {"k_sums": 4, "k_col_fwd_square": 12, "k_row_band": 8, "k_df_tables": 0, "k_col_fwd_mix": 12, "k_row_mid": 32, "k_col_inv": 24, "k_peak": 0}
+    dom = max(prof, key=lambda k: prof[k]["ms_total"])
+    ms = prof[dom]["ms_total"] / prof[dom]["launches"]
+    spl = prof[dom]["units"] / prof[dom]["launches"]
+    byts = algo[dom] * spl + (8 * n if dom == "k_row_mid" else 0)
+    ach = byts / (ms * 1e-3) / 1e9
+    print(json.dumps({"workload": "native 70 Msps x 1 s window (N = 7e7 = 7000 x 10000, W = 2), fp32, one pipeline slot (profiled context)", "value": round(nw * n / tot / 1e3, 1),
+                      "unit": "Msamples/s", "kernels_ms": {k: round(v["ms_total"] / v["launches"], 4) for k, v in prof.items()},
+                      "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "avg_ms": round(ms, 4),
+                                   "algorithmic_bytes_per_launch": int(byts)},
+                      "chain_GBs_algorithmic": round(92 * nw * n / tot / 1e6, 1)}))

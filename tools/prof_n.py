@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Per-kernel times of processing(d,k) at another window length (python tools/prof_n.py bitlen taps nchips)."""
+"""Per-kernel times of processing(d,k) at another window length or precision (python tools/prof_n.py bitlen taps nchips [f32|f64]), with a
+roofline object for the dominant kernel (algorithmic bytes as in DESIGN.md section 4, complex element = 8 B fp32 / 16 B fp64)."""
+import json
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
@@ -28,3 +30,16 @@ with Correlator(chips, fs=FS, Nint=1, profile=True, precision=precision) as cor:
     print(f"{precision} N={n} N1={cor.info.n1} N2={cor.info.n2} B={cor.info.batch}: {2 * nwin * n / tot / 1e6:.1f} Gsample/s (one slot)")
     for k, v in prof.items():
         print(f"  {k:18s} {v['ms_total'] / v['launches'] * 1e3:8.1f} us/launch  {v['ms_total'] / tot * 100:5.1f} %  {v['units'] / v['launches'] / 1e6:.2f} M samples/launch")
+    E = 16 if precision == "f64" else 8                    # bytes per complex element of the intermediates
+    R = 3
+    algo = {"k_sums": lambda S: 4 * S, "k_col_fwd_square": lambda S: (4 + E) * S, "k_row_band": lambda S: E * S, "k_df_tables": lambda S: 0,
+            "k_col_fwd_mix": lambda S: (4 + E) * S, "k_row_mid": lambda S: (1 + R) * E * S + E * n, "k_col_inv": lambda S: R * E * S, "k_peak": lambda S: 0}
+    kern = {k: (v["ms_total"] / v["launches"], v["units"] / v["launches"]) for k, v in prof.items()}
+    dom = max(kern, key=lambda k: prof[k]["ms_total"])
+    ach = algo[dom](kern[dom][1]) / (kern[dom][0] * 1e-3) / 1e9
+    chain = sum(algo[k](kern[k][1]) for k in kern) / kern[dom][1] * (2 * nwin * n / tot / 1e3) / 1e9
+    print(json.dumps({"workload": f"processing(d,k), {precision}, N = {n}, one pipeline slot, HBM-resident", "value": round(2 * nwin * n / tot / 1e3, 1), "unit": "Msamples/s",
+                      "bytes_per_sample": sum(algo[k](1e6) for k in kern) / 1e6,
+                      "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                                   "avg_ms": round(kern[dom][0], 4), "algorithmic_bytes_per_launch": int(algo[dom](kern[dom][1]))},
+                      "chain_GBs_algorithmic": round(chain, 1), "chain_frac": round(chain / 8000.0, 4)}))
