@@ -2096,26 +2096,11 @@ __global__ __launch_bounds__(1024) void k_peak(PeakArgs<T> a) {
         const int q1 = (int)(q / a.n2), q2 = (int)(q % a.n2);
         const cpx<T>* src = a.Bz + ((long long)b * a.nphase + rho) * a.n + q2;
         double sx = 0, sy = 0;
-        // five terms per lane in flight at a time (the loads are a cache line apart each: one HBM round trip per group instead of
-        // one per term), the twiddle index (k1 q1) mod n1 advanced by addition
-        const int tstep = (int)((64ll * q1) % a.n1);
-        int ti = (int)(((long long)lane * q1) % a.n1);
-        for (int k0 = lane; k0 < a.n1; k0 += 64 * 5) {
-            cpx<T> v[5]; cpx<double> w[5];
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const int k1 = min(k0 + 64 * u, a.n1 - 1);
-                v[u] = src[(long long)k1 * a.n2];
-                w[u] = a.tw1d[ti];                                            // conj → inverse
-                ti += tstep; if (ti >= a.n1) ti -= a.n1;
-            }
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                if (k0 + 64 * u < a.n1) {
-                    sx += (double)v[u].x * w[u].x + (double)v[u].y * w[u].y;
-                    sy += (double)v[u].y * w[u].x - (double)v[u].x * w[u].y;
-                }
-            }
+        for (int k1 = lane; k1 < a.n1; k1 += 64) {
+            cpx<T> v = src[(long long)k1 * a.n2];
+            cpx<double> w = a.tw1d[(int)(((long long)k1 * q1) % a.n1)];   // conj → inverse
+            sx += (double)v.x * w.x + (double)v.y * w.y;
+            sy += (double)v.y * w.x - (double)v.x * w.y;
         }
         for (int d = 32; d >= 1; d >>= 1) { sx += __shfl_down(sx, d, 64); sy += __shfl_down(sy, d, 64); }
         if (lane == 0) { s_z[pt][0] = sx * a.inv_scale / (double)M; s_z[pt][1] = sy * a.inv_scale / (double)M; }

@@ -42,4 +42,4 @@ with Correlator(chips, fs=FS, Nint=1, profile=True, precision=precision) as cor:
                       "bytes_per_sample": sum(algo[k](1e6) for k in kern) / 1e6,
                       "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                                    "avg_ms": round(kern[dom][0], 4), "algorithmic_bytes_per_launch": int(algo[dom](kern[dom][1]))},
-                      "chain_GBs_algorithmic": round(chain, 1), "chain_frac": round(chain / 8000.0, 4)}))
+                      "chain_GBs_algorithmic": round(chain * 1e6, 1), "chain_frac": round(chain * 1e6 / 8000.0, 4)}))
