@@ -690,6 +690,13 @@ def test_rxcomplex_acquisition_pipeline_at_sdr_param_sizes():
     assert (fcd, ptd) == (fod, ptod) and abs(pkd - pod) <= 3e-6 * pod
     assert abs(fcd - fc_true) <= 1.0 and abs(ptd * 2 - (2 * d0) % nobs) <= 2          # pt = pt*dec_a once locked (:575)
     a2.close(); interp.close()
+    # a context whose batch cannot hold the three trial carriers of a refinement round refuses the sweep (it used to drop fc + step silently)
+    a1 = acq.Acquisition(code_pm1, rc, fs, nobs, max_batch=2)
+    with pytest.raises(L.TwxError, match="max_batch must be at least 3"):
+        a1.acquire(smp_dev.data_ptr(), idx, 1186.0, 2048.0, 256.0)
+    a3 = acq.Acquisition(code_pm1, rc, fs, nobs, max_batch=3)
+    assert a3.acquire(smp_dev.data_ptr(), idx, 1186.0, 2048.0, 256.0) == (fc, pkb, pt)
+    a1.close(); a3.close()
 
 
 def test_track_epoch_on_the_device_vs_oracle_epoch():

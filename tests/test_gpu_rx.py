@@ -145,3 +145,31 @@ def test_receiver_refuses_what_the_program_cannot_do(tmp_path):
         receiver.Receiver([receiver.make_row("B", 7, 186.0, 2000.0, 256.0, -18.0)])
     with pytest.raises(L.TwxError, match="ranges of rxcomplex.cpp:288"):
         receiver.Receiver([receiver.make_row("A", 100, 186.0, 100.0, 256.0, -18.0, code=chips)])
+
+
+def test_receiver_b210_build_and_device_resident_seconds():
+    """dec_a = 2 (the N210 / B210 build, rxcomplex.cpp:226-231: every second sample of the stream in the acquisition, nfft = 2^19, pt * dec_a
+    at the hand-over :575) and seconds that already sit in device memory (twx_rx_second_dev), against the oracle loop with the same dec_a."""
+    import torch
+    seconds = 3
+    chips, cap = _capture(seconds)
+    row = receiver.make_row("B", 101, -186.0, 2000.0, 256.0, -18.0, code=chips["B"])
+    with receiver.Receiver([row], dec_a=2, acq_block=5) as rx:
+        info = rx.channel(0)
+        assert info.nfft == 1 << 19 and info.nobs == 400_000
+        dev = torch.device("cuda", 0)
+        got = []
+        for s in range(seconds):
+            d = torch.from_numpy(cap[s]).to(dev)
+            got.append(rx.second_dev(d.data_ptr())[0])
+            assert rx.stream_dev(1) != 0 and rx.stream_dev(0) == 0          # only physical channel B is interpolated
+    orow = dict(ch="B", mode="N", pn=101, fc_init=-186.0, kcps=2500, fltkhz=1250.0, frange=2000.0, fstep=256.0, snr_min_db=-18.0)
+    cis = [orc.rx_channel_setup(orow, chips["B"], SPS, dec_a=2)]
+    assert abs(info.psbb - cis[0]["psbb"]) <= 1e-9 * cis[0]["psbb"]
+    want = [orc.rx_second(cis, cap[s].reshape(-1), SPS, 2, lambda i, ci: 5 * ci["nobs"])[0] for s in range(seconds)]
+    assert [g.status for g in got] == [L.TWX_RX_ACQUIRED, L.TWX_RX_CODE_LOCK, L.TWX_RX_TRACKED]
+    assert [w["status"] for w in want] == ["acquired", "code lock", "tracked"]
+    assert (got[0].fc, got[0].pt, got[0].gd) == (want[0]["fc"], want[0]["pt"], want[0]["gd"]) and got[0].pt % 2 == 0
+    for g, w in zip(got[1:], want[1:]):
+        assert (g.fc, g.pt, g.cnt) == (w["fc"], w["pt"], w["cnt"]) and abs(g.gd - w["gd"]) <= 0.05 and abs(g.fc + g.df - (w["fc"] + w["df"])) <= 5e-4
+    assert abs(got[-1].gd - 2 * 77_001 * 100.0) < 100.0
