@@ -517,6 +517,7 @@ template <typename T> struct Ctx : CtxBase {
         ArgPart<T>*part_band, *part_peak; twx_result* res_dev; double* fine_u; double* csum_part;
         short2* planar; WinSums* sums2;      // two-channel captures in all-channel mode: planar copies + both channels' sums (lazy)
         SumPart* sum_parts;                  // k_sums: [2][B][TWX_SUMS_MAXCHUNKS] per-workgroup partials
+        double tables_df; int tables_nb;     // the NCO tables e1/e2 of windows [0, tables_nb) hold this carrier (tables_nb = 0: unknown)
     };
     Slot slots[4] = {}; int nslots = 1;
     bool sums_ready = false;                 // run_batch_in: `sums` already holds this batch's statistics (k_sums_deint2)
@@ -997,12 +998,23 @@ template <typename T> struct Ctx : CtxBase {
         } else if (df_host) {
             HIPCHK(hipMemcpyAsync(dfv, df_host, sizeof(double) * nb, hipMemcpyHostToDevice, stream));
         }                                            // else: the batch's df vector was written on the device (acquire_cdev)
-        {
+        // A map-only call with the carrier the slot's tables already hold (the x2 interpolation of the receiver: df = 0, every
+        // second, both channels) skips the table kernel: 8 625 fp64 sincospi to write the same ones again
+        Slot* cur_slot = nullptr;
+        for (int k = 0; k < nslots; ++k) if (slots[k].e1 == e1) cur_slot = &slots[k];
+        const bool same_tables = map_only && df_host && cur_slot && cur_slot->tables_nb >= nb && cur_slot->tables_df == df_host[0] && !(cfg.flags & TWX_FLAG_FINE_FREQ);
+        if (!same_tables) {
             ProfScope ps(this, PC_DFT, nb);
             for (int it = 0, ne = reps(PC_DFT); it < ne; ++it)
             TWX_LAUNCH((k_df_tables<T>), dim3(nb, df_slices(nb)), dim3(256), stream, band ? 1 : 0, part_band, N1, dfv, dfidx, cfg.fs,
                                (long long)N, N1, N2, e1, e2);
             HIPCHK(hipGetLastError());
+            if (cur_slot) {
+                bool uniform = df_host && !band;
+                for (int i = 1; uniform && i < nb; ++i) uniform = df_host[i] == df_host[0];
+                cur_slot->tables_nb = uniform ? nb : 0;
+                cur_slot->tables_df = uniform ? df_host[0] : 0.0;
+            }
         }
         if (cfg.flags & TWX_FLAG_FINE_FREQ) {
             if (intype == IN_C32) return fail(TWX_E_ARG, "TWX_FLAG_FINE_FREQ is not available on complex-float input");
