@@ -7,6 +7,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
 #include <deque>
 #include <future>
 #include <unistd.h>
@@ -548,7 +549,8 @@ template <typename T> struct Ctx : CtxBase {
     double* fine_u = nullptr; int fine_M = 0;   // TWX_FLAG_FINE_FREQ
     double* csum_part = nullptr;                // per-window partial sums of |d|^2 (complex-double input)
     int argmax_norm1 = 0;                       // cblas_izamax arg-max for the current call (twx_caf_freqs_cdev)
-    int io_threads = 4;                         // TWX_IO_THREADS: concurrent preads per chunk in twx_process_file
+    int io_threads = 8;                         // TWX_IO_THREADS: concurrent preads per chunk in twx_process_file
+    std::atomic<int> h2d_failed{0};             // set by a reader thread whose copy to the device was refused
     int ncu = 256;
     int ntiles = 0;
 
@@ -1269,12 +1271,23 @@ template <typename T> struct Ctx : CtxBase {
             const long long first = chunk * B;
             const long long want = std::max<long long>(0, std::min<long long>(B, max_windows - first));
             char* dst = (char*)st[k].host;
-            const int nthr = io_threads;
+            char* ddst = reinterpret_cast<char*>(st[k].dev);
+            hipStream_t sk = slots[k].stream;
+            const int nthr = io_threads, device = dev;
+            std::atomic<int>* bad = &h2d_failed;
             return std::async(std::launch::async, [=]() -> long long {
-                const size_t total = read_in_pieces(read_at, dst, (size_t)first * win_bytes, win_bytes * (size_t)want, nthr);    // twx_workers.h
+                // every piece goes on to the device from the thread that read it (the link measured 56.6 GB/s for pinned copies, the
+                // read-then-copy form of round 3 reached 35-41: profiles/r04_io_rate.txt); the chunk's kernels are enqueued on the
+                // same stream after the last piece has been handed over (rd[k].get() in the loop below)
+                auto to_device = [=](size_t lo, size_t got) {
+                    (void)hipSetDevice(device);
+                    if (hipMemcpyAsync(ddst + lo, dst + lo, got, hipMemcpyHostToDevice, sk) != hipSuccess) bad->store(1);
+                };
+                const size_t total = read_in_pieces(read_at, dst, (size_t)first * win_bytes, win_bytes * (size_t)want, nthr, to_device);    // twx_workers.h
                 return (long long)(total / win_bytes);              // whole windows only
             });
         };
+        h2d_failed.store(0);
         std::future<long long> rd[4];
         struct Events {                          // destroyed on every exit path, exceptions included
             hipEvent_t e[4] = {}; bool used[4] = {};
@@ -1302,9 +1315,10 @@ template <typename T> struct Ctx : CtxBase {
             if ((long long)nb < want || want == 0) eof = true;
             rc = drain(k);                       // results of the batch that used this slot nslots chunks ago
             if (rc) break;
+            if (h2d_failed.load()) { rc = fail(TWX_E_HIP, "H2D copy failed"); break; }
             if (nb > 0) {
                 use_slot(k);
-                if (hipMemcpyAsync(st[k].dev, st[k].host, win_bytes * nb, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = fail(TWX_E_HIP, "H2D copy failed"); break; }
+                // the chunk is already on its way: the readers enqueued its pieces on this slot's stream
                 (void)hipEventRecord(h2d_done[k], stream); h2d.used[k] = true;
                 if (all && nch == 2 && frames_ok_2ch(st[k].dev)) {         // one pass over the frames serves both channels
                     const double* d2[2] = {nullptr, nullptr};

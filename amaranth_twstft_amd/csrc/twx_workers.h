@@ -63,17 +63,21 @@ struct Worker {
 // [off0, off0 + need) of a source into dst as up to `nthreads` concurrent pieces (4096-byte aligned cuts, pieces of at least
 // 4 MB).  read_at(dst, offset, len) -> bytes delivered (short only at the end of the source).  Returns the bytes delivered
 // CONTIGUOUSLY from off0 (a short piece ends the count: what follows it is not part of the capture).
-template <class ReadAt>
-size_t read_in_pieces(ReadAt read_at, char* dst, size_t off0, size_t need, int nthreads) {
+// on_piece(lo, got) runs in the thread that read a piece, as soon as its `got` bytes (at dst + lo) are there: the ingest hands every
+// piece on to the device at once, so the PCIe copy of a chunk runs beside the reads of its later pieces.
+struct NoPieceHook { void operator()(size_t, size_t) const {} };
+template <class ReadAt, class OnPiece = NoPieceHook>
+size_t read_in_pieces(ReadAt read_at, char* dst, size_t off0, size_t need, int nthreads, OnPiece on_piece = OnPiece()) {
     const int P = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, nthreads), need >> 22));
     const size_t piece = ((need + P - 1) / P + 4095) & ~(size_t)4095;
     std::vector<std::future<size_t>> parts;
     for (int i = 1; i < P; ++i) {
         const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));
-        parts.push_back(std::async(std::launch::async, [=]() { return read_at(dst + lo, off0 + lo, hi - lo); }));
+        parts.push_back(std::async(std::launch::async, [=]() { const size_t g = read_at(dst + lo, off0 + lo, hi - lo); if (g) on_piece(lo, g); return g; }));
     }
     const size_t first_len = std::min(need, piece);
     size_t total = read_at(dst, off0, first_len);
+    if (total) on_piece((size_t)0, total);
     bool contiguous = total == first_len;
     for (int i = 1; i < P; ++i) {
         const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));

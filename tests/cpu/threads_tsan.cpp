@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <memory>
 #include <numeric>
 #include "twx_workers.h"
@@ -52,11 +53,21 @@ static void ingest_rotation(size_t total_bytes, size_t chunk_bytes, int nslots, 
     std::vector<std::vector<char>> slot((size_t)nslots, std::vector<char>(chunk_bytes));
     std::vector<std::future<size_t>> rd((size_t)nslots);
     std::vector<std::future<unsigned long long>> consumer((size_t)nslots);      // stands for the slot's H2D copy + kernels
+    std::vector<unsigned long long> hooked((size_t)nslots, 0);
+    unsigned long long hook_sum = 0;
     size_t next_chunk = 0;
     auto start_read = [&](int k) {
         const size_t off = next_chunk++ * chunk_bytes;
         char* dst = slot[(size_t)k].data();
-        rd[(size_t)k] = std::async(std::launch::async, [=, &read_at]() { return twx::read_in_pieces(read_at, dst, off, chunk_bytes, nthreads); });
+        // the piece hook stands for the per-piece copy to the device: it reads what the piece's thread has just written
+        unsigned long long* hk = &hooked[(size_t)k];
+        rd[(size_t)k] = std::async(std::launch::async, [=, &read_at]() {
+            std::atomic<unsigned long long> seen{0};
+            auto hook = [dst, &seen](size_t lo, size_t got) { unsigned long long a = 0; for (size_t i = 0; i < got; ++i) a += (unsigned char)dst[lo + i]; seen += a; };
+            const size_t g = twx::read_in_pieces(read_at, dst, off, chunk_bytes, nthreads, hook);
+            *hk = seen.load();
+            return g;
+        });
     };
     for (int k = 0; k < nslots; ++k) start_read(k);
     unsigned long long sum = 0, want = 0;
@@ -68,6 +79,7 @@ static void ingest_rotation(size_t total_bytes, size_t chunk_bytes, int nslots, 
         if (!rd[(size_t)k].valid()) { if (consumer[(size_t)k].valid()) sum += consumer[(size_t)k].get(); start_read(k); }
         const size_t got = rd[(size_t)k].get();
         if (got < chunk_bytes) eof = true;
+        hook_sum += hooked[(size_t)k];
         if (consumer[(size_t)k].valid()) sum += consumer[(size_t)k].get();       // drain: the batch that used this slot before
         if (got) {
             const char* p = slot[(size_t)k].data();
@@ -81,6 +93,7 @@ static void ingest_rotation(size_t total_bytes, size_t chunk_bytes, int nslots, 
     for (int k = 0; k < nslots; ++k) { if (rd[(size_t)k].valid()) (void)rd[(size_t)k].get(); if (consumer[(size_t)k].valid()) sum += consumer[(size_t)k].get(); }
     CHECK(consumed == total_bytes);
     CHECK(sum == want);
+    CHECK(hook_sum == want);
 }
 
 int main() {
