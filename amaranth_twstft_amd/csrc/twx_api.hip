@@ -1635,6 +1635,8 @@ template <typename T> struct Ctx : CtxBase {
             fa.Yperm = Yperm; fa.cspec_perm = cspec_perm; fa.dtabs = dtabs; fa.vc = vc_d; fa.bpw = bpw; fa.nt = nt;
             static const int caf_rot = [] { const char* e = getenv("TWX_CAF_ROTATE"); return e ? atoi(e) : 1; }();      // 0: plain bin order (A/B, profiles/r04_caf_rotate.txt)
             fa.rotate = caf_rot;
+            static const int caf_pad = [] { const char* e = getenv("TWX_CAF_PAD"); return e ? std::max(0, atoi(e)) : 0; }();
+            fa.lds_pad = (nstr > 1 && !profile) ? caf_pad : 0;
             const unsigned grid = dform ? (unsigned)(N1 * ((nb + bpw - 1) / bpw)) : (unsigned)(N1 * nb);
             {
                 ProfScope ps(this, PC_ROW_CAF, (long long)nb * N);

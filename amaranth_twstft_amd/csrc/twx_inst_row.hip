@@ -30,7 +30,8 @@ template <typename T> int caf(const void* args, unsigned nblk, hipStream_t s) {
     if constexpr (HasRowD<P>::value && P::S == 3) {
         if (a.Yperm) {                                     // DIF/DIT form: the caller passes nblk = N1 * ceil(nbins / bpw)
             constexpr int NTD = RowD<P, T>::NT_MIN;
-            TWX_LAUNCH((k_rowd_caf<P, T, NTD>), dim3(nblk), dim3(NTD), s, a);
+            if (a.lds_pad > 0) hipLaunchKernelGGL((k_rowd_caf<P, T, NTD>), dim3(nblk), dim3(NTD), (size_t)a.lds_pad, s, a);
+            else TWX_LAUNCH((k_rowd_caf<P, T, NTD>), dim3(nblk), dim3(NTD), s, a);
             return (int)hipGetLastError();
         }
     }

@@ -1565,6 +1565,8 @@ template <typename T> struct CafArgs {
     int nt;                 // 1: non-temporal bin-buffer stores (a buffer far larger than the caches); 0: the few bins of a launch
                             // are meant to stay in L2 / Infinity Cache until the last pass reads them
     int rotate;             // k_rowd_caf: walk the workgroup's bins in the order rotated by k1 (L2 reuse of the Y rows, see the kernel)
+    int lds_pad;            // k_rowd_caf: bytes of dynamic LDS the launch reserves without using them (experiment: one row-pass workgroup
+                            // per CU, so that the column pass of the other stream's launch can share the CU; profiles/r04_caf_overlap_rotate.txt)
 };
 
 template <class P2, typename T, int PADQ, int NT>

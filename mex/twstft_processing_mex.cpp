@@ -4,7 +4,7 @@
 //     mkoctfile --mex -I../include twstft_processing_mex.cpp -L../amaranth_twstft_amd -ltwstft_hip
 //     mex -I../include twstft_processing_mex.cpp -L../amaranth_twstft_amd -ltwstft_hip
 //
-// Two call forms, told apart by the class of the first argument.
+// Three call forms, told apart by the class of the first argument.
 //
 // (A) the reference's own signatures — `d` is the complex double column the scripts build, mean already removed:
 //     [indice,correction,SNRr,SNRi,df,puissance,puissancecode,puissancenoise,xval] = ...
