@@ -24,7 +24,7 @@ TWX_CODE_BIPOLAR, TWX_CODE_UNIPOLAR = 0, 1
 TWX_PROF_MAX = 16
 TWX_TRK_RANGING, TWX_TRK_RE, TWX_TRK_LO = 0, 1, 2
 TWX_CARRIER_SEARCH_DF, TWX_CARRIER_CHUNK_BAND = 0, 1
-TWX_ABI_VERSION = 3
+TWX_ABI_VERSION = 4
 TWX_MULTI_NO_RCCL, TWX_MULTI_RCCL_ONE = 1, 2
 TWX_ACQ_IZAMAX = 1
 
@@ -107,6 +107,10 @@ class twx_multi_info(C.Structure):
                 ("records_gathered", C.c_int64), ("bytes_per_rank", C.c_int64), ("gather_ms", C.c_double)]
 
 
+class twx_track_mai(C.Structure):
+    _fields_ = [("pk_idx", C.POINTER(C.c_int32)), ("amp", C.POINTER(C.c_double)), ("phase", C.POINTER(C.c_double))]
+
+
 class twx_rx_row(C.Structure):
     _fields_ = [("ch", C.c_char), ("mode", C.c_char), ("reserved", C.c_int16), ("pn", C.c_int32), ("fc_init", C.c_double), ("kcps", C.c_int32),
                 ("reserved2", C.c_int32), ("fltkhz", C.c_double), ("frange", C.c_double), ("fstep", C.c_double), ("snr_min_db", C.c_double),
@@ -125,7 +129,7 @@ class twx_rx_report(C.Structure):
 
 
 class twx_rx_channel_info(C.Structure):
-    _fields_ = [("pn", C.c_int32), ("is_chA", C.c_int32), ("clen", C.c_int32), ("nlag", C.c_int32), ("bps", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("pn", C.c_int32), ("is_chA", C.c_int32), ("clen", C.c_int32), ("nlag", C.c_int32), ("bps", C.c_int32), ("is_sic", C.c_int32),
                 ("nobs", C.c_int64), ("nfft", C.c_int64), ("duration", C.c_double), ("range", C.c_double), ("step", C.c_double),
                 ("snr_min", C.c_double), ("psbb", C.c_double), ("dat_name", C.c_char * 64)]
 
@@ -199,6 +203,9 @@ SYMBOLS = {
     "twx_fft_forward_dev": (C.c_int, [_VP, _VP, _VP]),
     "twx_sliding_dot_cdev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_double, C.c_double, C.c_double, _VP]),
     "twx_track_epoch_cdev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_double, C.POINTER(twx_track_state), C.POINTER(twx_track_result)]),
+    "twx_track_epoch_cdev_mai": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_double, C.POINTER(twx_track_state), C.POINTER(twx_track_result),
+                                          C.POINTER(twx_track_mai)]),
+    "twx_track_update_mai": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int64, C.POINTER(twx_track_state), C.POINTER(twx_track_result), C.POINTER(twx_track_mai)]),
     "twx_rx_parse_param": (C.c_int, [C.c_char_p, C.POINTER(twx_rx_row), C.c_int32]),
     "twx_rx_create": (C.c_int, [C.POINTER(twx_rx_config), C.POINTER(twx_rx_row), C.c_int32, C.POINTER(_VP)]),
     "twx_rx_destroy": (None, [_VP]),

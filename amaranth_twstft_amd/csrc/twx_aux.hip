@@ -607,11 +607,15 @@ void fit_wlinear(const std::vector<double>& x, const std::vector<double>& w, con
     for (size_t i = 0; i < x.size(); ++i) if (w[i] > 0) { const double d = y[i] - (*c0 + *c1 * x[i]); chi += w[i] * d * d; }
     *chisq = chi;
 }
-int track_update_impl(const double* cor, const double* phi, int bps, int nlag, twx_track_state* st, twx_track_result* out) {
+int track_update_impl(const double* cor, const double* phi, int bps, int nlag, twx_track_state* st, twx_track_result* out,
+                      long long nobs = 0, const twx_track_mai* mai = nullptr) {
     if (!cor || !phi || !st || !out || bps < 2 || nlag < 2 || !(st->fs > 0) || !(st->duration > 0)) return TWX_E_ARG;
+    if (mai && (!mai->pk_idx || !mai->amp || !mai->phase || nobs < 1)) return TWX_E_ARG;
     const int nl = 2 * nlag + 1;
     const double psbb = st->psbb != 0.0 ? st->psbb : 1.0;
     std::vector<double> res_gd((size_t)bps, 0.0), res_phi((size_t)bps, 0.0), ps((size_t)bps, 0.0), w((size_t)bps, 0.0), ttag_phi((size_t)bps, 0.0), ttag_gd((size_t)bps);
+    std::vector<double> amp(mai ? (size_t)bps : 0, 0.0);
+    std::vector<int> pki(mai ? (size_t)bps : 0, 0);
     memset(out, 0, sizeof *out);
     int cnt = 0;
     for (int p = 0; p < bps - 1; ++p) {
@@ -622,6 +626,7 @@ int track_update_impl(const double* cor, const double* phi, int bps, int nlag, t
         ps[(size_t)p] = c[k] / psbb;                                                     // :633
         if (k - 2 >= 0 && k + 2 < nl) {                                                  // :634
             res_phi[(size_t)p] = phi[(size_t)p * nl + k];
+            if (mai) { pki[(size_t)p] = k - nlag; amp[(size_t)p] = sqrt(2.0 * c[k]) / psbb; }              // rx.cpp:638,640
             res_gd[(size_t)p] = ((c[k - 1] - c[k + 1]) / (c[k - 1] - 2.0 * c[k] + c[k + 1])          // high-resolution correlator (:649-659)
                                  - (c[k - 2] - c[k + 2]) / (c[k - 2] - 2.0 * c[k] + c[k + 2])
                                  + (double)(st->pt + k - nlag)) * 1.0e+9 / st->fs;
@@ -638,6 +643,7 @@ int track_update_impl(const double* cor, const double* phi, int bps, int nlag, t
     const double med = sel[(size_t)(ii / 2)];
     const double stddev = (sel[(size_t)(ii * 3 / 4)] - sel[(size_t)(ii / 4)]) / 1.349;   // :699-700
     double last_phi = st->last_phi;
+    const std::vector<double> raw_phi = mai ? res_phi : std::vector<double>();           // rx.cpp:664, before the BPSK adjustment
     cnt = 0;
     for (int p = 0; p < bps - 1; ++p) {                                                  // :703-716
         if (w[(size_t)p] == 0.0) continue;
@@ -671,13 +677,19 @@ int track_update_impl(const double* cor, const double* phi, int bps, int nlag, t
     for (int p = 0; p < bps; ++p) if (w[(size_t)p] > 0.0) { acc += ps[(size_t)p]; ++na; }            // average() :887-901
     out->pk = na ? acc / (double)na : 0.0;
     out->updated = 1;
+    if (mai) {                                                                           // rx.cpp:664-666,752-757
+        for (int p = 0; p < bps; ++p) { mai->pk_idx[p] = pki[(size_t)p]; mai->amp[p] = amp[(size_t)p]; }
+        for (int p = 0; p < bps - 1; ++p)
+            mai->phase[p] = raw_phi[(size_t)p] - (st->fc + st->df - st->fc_prev) * (double)((long long)(p + 1) * nobs + st->pt_prev) / st->fs;
+        mai->phase[bps - 1] = 0.0;
+    }
     return TWX_OK;
 }
 }  // namespace
 
 static int twx_track_epoch_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t nobs,
                                     int32_t bps, int32_t nlag, const float* replica_dev, double scale, twx_track_state* st, twx_track_result* out,
-                                    bool complex_float = false) {
+                                    bool complex_float = false, const twx_track_mai* mai = nullptr) {
     if (!ctx) return TWX_E_ARG;
     if (!st || !out || bps < 2 || nlag < 2 || nlag > 31 || !(st->fs > 0)) return twx::ctx_fail(ctx, TWX_E_ARG, "twx_track_epoch_dev: bad argument");
     const int ncodes = bps - 1, nl = 2 * nlag + 1;
@@ -697,7 +709,7 @@ static int twx_track_epoch_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n_
         cor[i] = re * re + im * im;
         ph[i] = atan2(im, re) / two_pi;
     }
-    const int rc = track_update_impl(cor.data(), ph.data(), bps, nlag, st, out);
+    const int rc = track_update_impl(cor.data(), ph.data(), bps, nlag, st, out, nobs, mai);
     return rc ? twx::ctx_fail(ctx, rc, "twx_track_epoch_dev: bad state") : TWX_OK;
 }
 
@@ -723,6 +735,14 @@ int twx_sliding_dot_cdev(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, i
 int twx_track_epoch_cdev(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, int64_t nobs, int32_t bps, int32_t nlag, const float* replica_dev,
                          double scale, twx_track_state* state, twx_track_result* out) {
     return aux_guard([&]() { return twx_track_epoch_dev_impl(ctx, smp_dev, n_samples, 1, 0, nobs, bps, nlag, replica_dev, scale, state, out, true); });
+}
+int twx_track_epoch_cdev_mai(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, int64_t nobs, int32_t bps, int32_t nlag, const float* replica_dev,
+                             double scale, twx_track_state* state, twx_track_result* out, const twx_track_mai* mai) {
+    return aux_guard([&]() { return twx_track_epoch_dev_impl(ctx, smp_dev, n_samples, 1, 0, nobs, bps, nlag, replica_dev, scale, state, out, true, mai); });
+}
+int twx_track_update_mai(const double* cor, const double* phi, int32_t bps, int32_t nlag, int64_t nobs, twx_track_state* state, twx_track_result* out,
+                         const twx_track_mai* mai) {
+    return aux_guard([&]() { return track_update_impl(cor, phi, bps, nlag, state, out, nobs, mai); });
 }
 int twx_fir_decimate_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps, int32_t ntaps,
                          int32_t dec, void* out_i16_dev, void* out_f32_dev, int64_t* n_out) {

@@ -1,5 +1,7 @@
 // twx_rx.hip — the DLL/PLL receiver of experiments/231001_DLL_PLL/rxcomplex.cpp behind the C ABI (twx_rx_* in
-// include/twstft_hip.h): parameter file in, .dat rows out.
+// include/twstft_hip.h): parameter file in, .dat rows out.  With cfg.ninterp = 1 it is the other program of that directory,
+// rx.cpp: real samples, no interpolation, successive interference cancellation for the 'S' rows (see "real-sample program"
+// below); line numbers without a file name are rxcomplex.cpp's.
 //
 // What runs where.  Everything that touches samples is a kernel of this library: the x2 FFT-domain interpolation of both
 // physical channels (short2double :914-963 = the fused chain with two output phases and a weight vector as "code spectrum"),
@@ -97,11 +99,37 @@ __global__ __launch_bounds__(256) void k_rx_power(long long n, int dec, const fl
     if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// ---- real-sample program (rx.cpp) ----
+// short2double rx.cpp:892-900: the I sample of physical channel A (frame offset 0) / B (offset 2), /32768; kept as a complex
+// float with a zero imaginary part so that the acquisition and tracking kernels of the complex program run on it unchanged
+// (downconv_acq rx.cpp:976-986 and downconv_trk rx.cpp:988-998 are the complex ones with imag(smp) = 0)
+__global__ void k_rx_real_in(long long n, const short2* __restrict__ frames, int chan, float2* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = make_float2((float)frames[2 * i + chan].x * (1.0f / 32768.0f), 0.0f);
+}
+// MAI_up rx.cpp:1011-1020: the signal of one tracked channel rebuilt from its per-period records, added to acc[].x
+__global__ void k_rx_mai_up(long long n, long long ld, long long pt, const double* __restrict__ amp, const float* __restrict__ wav,
+                            const int* __restrict__ pidx, double ff, const double* __restrict__ pmod, int bps, float2* __restrict__ acc) {
+    for (long long i = pt + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = (i - pt) / ld;
+        if (p >= bps) continue;                                  // the program's arrays end there (pt >= 0: never taken)
+        const long long k = (i - pidx[p] - pt + ld) % ld;
+        double t = ff * (double)i + pmod[p];
+        t -= floor(t);
+        acc[i].x += (float)(0.5 * amp[p] * (double)wav[k] * cospi(2.0 * t));
+    }
+}
+// MAI_out rx.cpp:1022-1027: out = in - out
+__global__ void k_rx_mai_out(long long n, const float2* __restrict__ in, float2* __restrict__ acc) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        acc[i] = make_float2(in[i].x - acc[i].x, 0.0f);
+}
+
 double v2todBm(double v2) { return v2 > 0.0 ? 10.0 * log10(v2 * 1000.0 / 25.0) : 0.0; }      // :1236-1240
 
 struct Channel {
     twx_rx_row row{};
-    bool is_chA = true;
+    bool is_chA = true, is_sic = false;
     int cid = 0, rc = 0, clen = 0, nlag = 0, bps = 0;
     long long nobs = 0, nfft = 0;
     double duration = 0, fc_init = 0, fltmax = 0, fltmin = 0, range = 0, step = 0, snr_min = 0, psbb = 0;
@@ -112,6 +140,11 @@ struct Channel {
     twx_ctx* acq = nullptr;
     float* replica_dev = nullptr;
     std::string dat_name;
+    // the records MAI_up reads (rx.cpp:664-666,757), host and device: amp[bps], phase[bps] (double), pk_idx[bps] (int)
+    std::vector<double> mai_amp, mai_phase;
+    std::vector<int32_t> mai_pk;
+    void* mai_dev = nullptr;
+    int shown() const { return is_sic ? cid + 50 : cid; }      // the PRN the program prints (rx.cpp:708,745)
 };
 
 constexpr int RX_PARTS = 1024;
@@ -127,6 +160,9 @@ struct twx_rx {
     twx_ctx* interp = nullptr;
     short2* iq_dev = nullptr;      // one second of [IA QA IB QB] frames
     float2* smp[2] = {nullptr, nullptr};
+    float2* mai_free = nullptr;    // dev_smp_MAI_free (rx.cpp:251), allocated when the list has an 'S' row
+    hipStream_t own_stream = nullptr;
+    bool real = false, any_sic = false;
     double* part_dev = nullptr;
     std::vector<Channel> ch;
     std::mt19937_64 rng;
@@ -136,13 +172,15 @@ struct twx_rx {
     int lib(twx_ctx* c, int rc) { if (rc) { const char* m = twx_last_error(c); err = m && *m ? m : twx_strerror(rc); } return rc; }
     ~twx_rx() {
         (void)hipSetDevice(dev);
-        for (auto& c : ch) { if (c.acq) twx_destroy(c.acq); if (c.replica_dev) (void)hipFree(c.replica_dev); }
+        for (auto& c : ch) { if (c.acq) twx_destroy(c.acq); if (c.replica_dev) (void)hipFree(c.replica_dev); if (c.mai_dev) (void)hipFree(c.mai_dev); }
         if (interp) twx_destroy(interp);
-        for (void* p : {(void*)iq_dev, (void*)smp[0], (void*)smp[1], (void*)part_dev}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)iq_dev, (void*)smp[0], (void*)smp[1], (void*)part_dev, (void*)mai_free}) if (p) (void)hipFree(p);
+        if (own_stream) (void)hipStreamDestroy(own_stream);
     }
+    hipStream_t stream() const { return interp ? (hipStream_t)twx_stream(interp) : own_stream; }
     void log_line(const char* text) const {
         if (out_dir.empty()) return;
-        FILE* f = fopen((out_dir + "/rxcomplex.log").c_str(), "a");
+        FILE* f = fopen((out_dir + (real ? "/rxreal.log" : "/rxcomplex.log")).c_str(), "a");     // rx.cpp:440 / rxcomplex.cpp:439
         if (f) { fputs(text, f); fclose(f); }
     }
     static twx_config plain_cfg(long long n, double fs, int precision, int nphase, int max_batch, int device) {
@@ -207,7 +245,9 @@ struct twx_rx {
     }
 
     int init(const twx_rx_row* rows, int n_rows) {
-        if (!(cfg.fs_in >= 1000.0) || cfg.ninterp != 2 || (cfg.dec_a != 1 && cfg.dec_a != 2)) return fail(TWX_E_ARG, "need fs_in >= 1000, ninterp = 2 (rxcomplex.cpp:29), dec_a 1 or 2");
+        if (!(cfg.fs_in >= 1000.0) || (cfg.ninterp != 1 && cfg.ninterp != 2) || (cfg.dec_a != 1 && cfg.dec_a != 2))
+            return fail(TWX_E_ARG, "need fs_in >= 1000, ninterp = 2 (rxcomplex.cpp:29) or 1 (rx.cpp), dec_a 1 or 2");
+        real = cfg.ninterp == 1;
         if (n_rows < 1 || n_rows > 120) return fail(TWX_E_ARG, "1..120 channels (nch_max, rxcomplex.cpp:34)");
         if (cfg.device >= 0 && hipSetDevice(cfg.device) != hipSuccess) return fail(TWX_E_HIP, "hipSetDevice failed");
         if (hipGetDevice(&dev) != hipSuccess) return fail(TWX_E_HIP, "no HIP device available (the HIP path has no CPU fallback)");
@@ -221,8 +261,10 @@ struct twx_rx {
             Channel c;
             c.row = r; c.row.code = nullptr;
             if (r.ch != 'A' && r.ch != 'B') return fail(TWX_E_ARG, "row " + std::to_string(i) + ": channel must be A or B");
-            if (r.mode == 'S') return fail(TWX_E_ARG, "row " + std::to_string(i) + ": SIC rows are not supported (the code is commented out in rxcomplex.cpp:508-519)");
-            if (r.mode != 'N') return fail(TWX_E_ARG, "row " + std::to_string(i) + ": mode must be N");
+            if (r.mode == 'S' && !real) return fail(TWX_E_ARG, "row " + std::to_string(i) + ": SIC rows need ninterp = 1 (rx.cpp); the code is commented out in rxcomplex.cpp:508-519");
+            if (r.mode != 'N' && r.mode != 'S') return fail(TWX_E_ARG, "row " + std::to_string(i) + ": mode must be N or S");
+            c.is_sic = r.mode == 'S';
+            any_sic = any_sic || c.is_sic;
             // the acceptance test of :288
             if (!(r.pn >= 0 && r.pn <= 131 && r.kcps == 2500 && r.fc_init >= -200000. && r.fc_init < 200000. && r.frange >= 0.0 && r.frange < 200000. &&
                   r.frange > r.fstep && r.snr_min_db > -100.0)) return fail(TWX_E_ARG, "row " + std::to_string(i) + ": values outside the ranges of rxcomplex.cpp:288");
@@ -241,7 +283,7 @@ struct twx_rx {
             c.snr_min = pow(10.0, r.snr_min_db / 10.0);                                            // :379
             if ((sps - c.nfft * cfg.dec_a) / c.nobs < 1) return fail(TWX_E_ARG, "row " + std::to_string(i) + ": the one-second buffer is shorter than the acquisition window");
             char nm[64];
-            snprintf(nm, sizeof nm, "ch%s.pn%02d.%dkcps.dat", c.is_chA ? "A" : "B", c.cid, c.rc / 1000);   // :720
+            snprintf(nm, sizeof nm, "ch%s.pn%02d.%dkcps.dat", c.is_chA ? "A" : "B", c.shown(), c.rc / 1000);   // :720, rx.cpp:708
             c.dat_name = nm;
             std::vector<uint8_t> code;
             if (r.code) {
@@ -265,10 +307,18 @@ struct twx_rx {
             memset(&k.st, 0, sizeof k.st);
             k.st.fs = fs; k.st.duration = k.duration; k.st.psbb = k.psbb;
             char line[256];
-            snprintf(line, sizeof line, "set param   : Ch. %s, PRN#%2d, %8.0lf %4d %5.0lf %5.0lf %5.0lf %3.0lf\n", k.is_chA ? "A" : "B", k.cid, k.fc_init,
+            if (real) {
+                k.mai_amp.assign((size_t)k.bps, 0.0); k.mai_phase.assign((size_t)k.bps, 0.0); k.mai_pk.assign((size_t)k.bps, 0);
+                if (hipMalloc(&k.mai_dev, (size_t)k.bps * 20) != hipSuccess) return fail(TWX_E_NOMEM, "device allocation failed (interference records)");
+            }
+            snprintf(line, sizeof line, "set param   : Ch. %s, PRN#%2d, %8.0lf %4d %5.0lf %5.0lf %5.0lf %3.0lf\n", k.is_chA ? "A" : "B", k.shown(), k.fc_init,
                      k.rc / 1000, k.fltmax * 1.0e-3, k.range, k.step, k.snr_min);                  // :441
             log_line(line);
         }
+        if (real) {                                                                   // rx.cpp: no interpolation, the samples as they come
+            if (hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking) != hipSuccess) return fail(TWX_E_HIP, "stream creation failed");
+            if (any_sic && hipMalloc((void**)&mai_free, (size_t)sps * 8) != hipSuccess) return fail(TWX_E_NOMEM, "device allocation failed (interference-free stream)");
+        } else {
         // interpolator: the fused chain with two output phases and short2double's weights as replica spectrum
         const twx_config ic = plain_cfg(n_in, 1.0, TWX_F32, cfg.ninterp, 1, dev);
         if (int rc = twx_create(&ic, &interp)) { err = std::string("interpolation context of ") + std::to_string(n_in) + " points: " + twx_last_error(nullptr); return rc; }
@@ -282,15 +332,16 @@ struct twx_rx {
             if (rc) return lib(interp, rc);
         }
         if (int rc = lib(interp, twx_set_option(interp, TWX_OPT_REMOVE_MEAN, 0))) return rc;
+        }
         if (hipMalloc((void**)&iq_dev, (size_t)n_in * 8) != hipSuccess || hipMalloc((void**)&part_dev, RX_PARTS * 8) != hipSuccess) return fail(TWX_E_NOMEM, "device allocation failed");
         for (int p = 0; p < 2; ++p)
             if (need[p] && hipMalloc((void**)&smp[p], (size_t)sps * 8) != hipSuccess) return fail(TWX_E_NOMEM, "device allocation failed (stream)");
         return TWX_OK;
     }
 
-    int power(int p, double* out) {
-        hipStream_t s = (hipStream_t)twx_stream(interp);
-        hipLaunchKernelGGL(k_rx_power, dim3(RX_PARTS), dim3(256), 0, s, sps / cfg.dec_a, cfg.dec_a, smp[p], part_dev);
+    int power(const float2* buf, double* out) {
+        hipStream_t s = stream();
+        hipLaunchKernelGGL(k_rx_power, dim3(RX_PARTS), dim3(256), 0, s, sps / cfg.dec_a, cfg.dec_a, buf, part_dev);
         std::vector<double> hp(RX_PARTS);
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hp.data(), part_dev, RX_PARTS * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) return fail(TWX_E_HIP, "power reduction failed");
@@ -305,8 +356,9 @@ struct twx_rx {
         double pwr[2] = {0, 0};
         for (int p = 0; p < 2; ++p) {
             if (!need[p]) continue;
-            if (int rc = lib(interp, twx_xcorr_map_dev(interp, src, 2, p, 0.0, smp[p]))) return rc;       // short2double :477
-            if (int rc = power(p, &pwr[p])) return rc;                                                     // synchronises the stream: smp[p] is complete
+            if (real) hipLaunchKernelGGL(k_rx_real_in, dim3(2048), dim3(256), 0, stream(), sps, static_cast<const short2*>(src), p, smp[p]);   // rx.cpp:478
+            else if (int rc = lib(interp, twx_xcorr_map_dev(interp, src, 2, p, 0.0, smp[p]))) return rc;  // short2double :477
+            if (int rc = power(smp[p], &pwr[p])) return rc;                                                // synchronises the stream: smp[p] is complete
         }
         for (size_t i = 0; i < ch.size(); ++i) {
             Channel& c = ch[i];
@@ -314,6 +366,22 @@ struct twx_rx {
             memset(&r, 0, sizeof r);
             const int p = c.is_chA ? 0 : 1;
             c.px = pwr[p];                                                                                  // :493-503
+            const float2* obs = smp[p];
+            if (c.is_sic) {                                                                                 // rx.cpp:505-518
+                hipStream_t s = stream();
+                if (hipMemsetAsync(mai_free, 0, (size_t)sps * 8, s) != hipSuccess) return fail(TWX_E_HIP, "memset failed");
+                for (size_t k = 0; k < i; ++k) {
+                    const Channel& o = ch[k];
+                    if (o.is_chA != c.is_chA || o.cid == c.cid || o.is_sic || !o.is_trk || o.is_first) continue;      // rx.cpp:511
+                    const double* amp = static_cast<const double*>(o.mai_dev);
+                    hipLaunchKernelGGL(k_rx_mai_up, dim3(2048), dim3(256), 0, s, sps, o.nobs, std::max<long long>(o.st.pt_prev, 0), amp, o.replica_dev,
+                                       reinterpret_cast<const int*>(amp + 2 * o.bps), (o.st.fc + o.st.df) / fs, amp + o.bps, o.bps, mai_free);
+                }
+                hipLaunchKernelGGL(k_rx_mai_out, dim3(2048), dim3(256), 0, s, sps, smp[p], mai_free);
+                if (hipGetLastError() != hipSuccess) return fail(TWX_E_HIP, "interference cancellation launch failed");
+                if (int rc = power(mai_free, &c.px)) return rc;                                            // rx.cpp:515-516; synchronises
+                obs = mai_free;
+            }
             char line[320];
             const char* chs = c.is_chA ? "A" : "B";
             if (!c.is_trk) {                                                                                // acquisition :521-586
@@ -322,7 +390,7 @@ struct twx_rx {
                 const long long idx = blk * c.nobs;                                                         // :529
                 twx_acq_result a{};
                 const int flags = TWX_ACQ_IZAMAX | (cfg.dec_a > 1 ? TWX_ACQ_DEC(cfg.dec_a) : 0);
-                if (int rc = lib(c.acq, twx_acquire_cdev(c.acq, smp[p] + idx, c.fc_init, c.range, c.step, c.nobs / cfg.dec_a, flags, &a))) return rc;
+                if (int rc = lib(c.acq, twx_acquire_cdev(c.acq, obs + idx, c.fc_init, c.range, c.step, c.nobs / cfg.dec_a, flags, &a))) return rc;
                 c.st.fc = a.fc; c.st.pt = a.pt;
                 c.pk = 8.0 * a.pk * a.pk / c.psbb;                                                          // :570
                 r.acq_idx = idx; r.n_trials = a.n_trials;
@@ -330,7 +398,7 @@ struct twx_rx {
                     c.st.pt = c.st.pt * cfg.dec_a;                                                          // :575
                     c.gd = (double)c.st.pt * 1.0e+9 / fs;
                     c.is_trk = true; c.is_first = true;
-                    snprintf(line, sizeof line, "acquisition : Ch. %s, PRN#%2d, %3d %8.0lf %7.0lf %6d %8.3lf %8.3lf\n", chs, c.cid, (int)(idx / 2 / c.nobs),
+                    snprintf(line, sizeof line, "acquisition : Ch. %s, PRN#%2d, %3d %8.0lf %7.0lf %6d %8.3lf %8.3lf\n", chs, c.shown(), (int)(idx / 2 / c.nobs),
                              c.st.fc, c.gd, (int)c.st.pt, v2todBm(c.pk), v2todBm(c.px));                    // :582
                     log_line(line);
                     r.status = TWX_RX_ACQUIRED;
@@ -339,9 +407,17 @@ struct twx_rx {
                 twx_track_result t{};
                 const bool in_buf = c.st.pt >= 0 && c.st.pt + c.nobs * (c.bps - 1) <= sps;                   // the program would read past its buffer
                 if (in_buf) {
-                    if (int rc = lib(c.acq, twx_track_epoch_cdev(c.acq, smp[p], sps, c.nobs, c.bps, c.nlag, c.replica_dev, 1.4142135624, &c.st, &t))) return rc;
+                    const twx_track_mai rec{c.mai_pk.data(), c.mai_amp.data(), c.mai_phase.data()};
+                    if (int rc = lib(c.acq, twx_track_epoch_cdev_mai(c.acq, obs, sps, c.nobs, c.bps, c.nlag, c.replica_dev, 1.4142135624, &c.st, &t,
+                                                                     real && any_sic && !c.is_sic ? &rec : nullptr))) return rc;
                 }
                 c.cnt = t.cnt;
+                if (t.updated && real && any_sic && !c.is_sic) {                                            // rx.cpp:664-666,757: the records MAI_up reads
+                    char* d = static_cast<char*>(c.mai_dev);
+                    const size_t nb = (size_t)c.bps;
+                    if (hipMemcpy(d, c.mai_amp.data(), nb * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d + nb * 8, c.mai_phase.data(), nb * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(d + nb * 16, c.mai_pk.data(), nb * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(TWX_E_HIP, "H2D copy failed (interference records)");
+                }
                 if (t.updated) {
                     c.gd = t.gd; c.dg = t.dg; c.sdgd = t.sdgd; c.pk = t.pk;
                     if (!c.is_first) {                                                                      // :718-754
@@ -354,13 +430,13 @@ struct twx_rx {
                         }
                         r.status = TWX_RX_TRACKED;
                     } else {
-                        snprintf(line, sizeof line, "code lock   : Ch. %s, PRN#%2d, count = %d / %d\n", chs, c.cid, t.cnt, c.bps);     // :761
+                        snprintf(line, sizeof line, "code lock   : Ch. %s, PRN#%2d, count = %d / %d\n", chs, c.shown(), t.cnt, c.bps);     // :761
                         log_line(line);
                         c.is_first = false;                                                                 // :766
                         r.status = TWX_RX_CODE_LOCK;
                     }
                 } else {
-                    snprintf(line, sizeof line, "%s : Ch. %s, PRN#%2d, count = %d / %d\n", c.is_first ? "acq failed " : "lock lost  ", chs, c.cid, t.cnt, c.bps);   // :779,787
+                    snprintf(line, sizeof line, "%s : Ch. %s, PRN#%2d, count = %d / %d\n", c.is_first ? "acq failed " : "lock lost  ", chs, c.shown(), t.cnt, c.bps);   // :779,787
                     log_line(line);
                     r.status = c.is_first ? TWX_RX_ACQ_FAILED : TWX_RX_LOCK_LOST;
                     c.is_trk = false; c.st.last_phi = 0.0;                                                  // :792-793
@@ -434,12 +510,12 @@ int twx_rx_channel(const twx_rx* rx, int32_t i, twx_rx_channel_info* info) {
     if (!rx || !info || i < 0 || i >= (int)rx->ch.size()) return TWX_E_ARG;
     const Channel& c = rx->ch[(size_t)i];
     memset(info, 0, sizeof *info);
-    info->pn = c.cid; info->is_chA = c.is_chA; info->clen = c.clen; info->nlag = c.nlag; info->bps = c.bps; info->nobs = c.nobs; info->nfft = c.nfft;
+    info->pn = c.cid; info->is_chA = c.is_chA; info->clen = c.clen; info->nlag = c.nlag; info->bps = c.bps; info->is_sic = c.is_sic; info->nobs = c.nobs; info->nfft = c.nfft;
     info->duration = c.duration; info->range = c.range; info->step = c.step; info->snr_min = c.snr_min; info->psbb = c.psbb;
     snprintf(info->dat_name, sizeof info->dat_name, "%s", c.dat_name.c_str());
     return TWX_OK;
 }
-const void* twx_rx_stream_dev(const twx_rx* rx, int32_t p) { return (rx && (p == 0 || p == 1)) ? rx->smp[p] : nullptr; }
+const void* twx_rx_stream_dev(const twx_rx* rx, int32_t p) { return !rx ? nullptr : (p == 0 || p == 1) ? (const void*)rx->smp[p] : p == 2 ? (const void*)rx->mai_free : nullptr; }
 
 int twx_rx_second_dev(twx_rx* rx, const void* iq_dev, twx_rx_report* reports) {
     if (!rx) return TWX_E_ARG;

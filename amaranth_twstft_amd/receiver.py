@@ -3,7 +3,10 @@ rows out — binding of ``twx_rx_*`` (include/twstft_hip.h).  Everything (parame
 x2 interpolation, acquisition-or-tracking per channel and second, the rows and the log lines) is in libtwstft_hip.so; this
 module marshals arguments and is the ``./rxcomplex data.bin sdr.param`` command line:
 
-    python -m amaranth_twstft_amd.receiver data.bin sdr.param [--codes DIR] [--out DIR] [--seed N] [--seconds N]
+    python -m amaranth_twstft_amd.receiver data.bin sdr.param [--codes DIR] [--out DIR] [--seed N] [--seconds N] [--real]
+
+``--real`` / ``Receiver(..., real=True)`` is the other program of that directory, ``rx.cpp``: the I samples only, no
+interpolation, ``S`` rows of the parameter file with successive interference cancellation (rx.cpp:505-518), ``rxreal.log``.
 """
 from __future__ import annotations
 
@@ -44,10 +47,11 @@ def make_row(ch: str, pn: int, fc_init: float, frange: float, fstep: float, snr_
 
 class Receiver:
     def __init__(self, rows, fs_in: float = 5e6, code_dir: str | None = None, out_dir: str | None = None, seed: int = 1, acq_block: int = -1,
-                 dec_a: int = 1, device: int = -1):
+                 dec_a: int = 1, device: int = -1, real: bool = False):
         self._lib = L.load()
         cfg = L.twx_rx_config()
-        cfg.fs_in, cfg.ninterp, cfg.dec_a = fs_in, 2, dec_a
+        ninterp = 1 if real else 2
+        cfg.fs_in, cfg.ninterp, cfg.dec_a = fs_in, ninterp, dec_a
         cfg.code_dir = os.fsencode(code_dir) if code_dir else None
         cfg.out_dir = os.fsencode(out_dir) if out_dir else None
         cfg.seed, cfg.acq_block, cfg.device = seed, acq_block, device
@@ -60,7 +64,7 @@ class Receiver:
             n_in = int(round(fs_in))
             for r in rows:
                 bps = 2500000 // (10000 if r.pn < 100 else 100000)
-                nobs = 2 * n_in // bps
+                nobs = ninterp * n_in // bps
                 nfft = 1
                 while True:
                     nfft *= 2
@@ -68,7 +72,8 @@ class Receiver:
                         break
                 for n, prec in ((nobs, 1), (nfft, 1), (nfft, 0)):
                     plans.ensure(n, prec, self._lib)
-            plans.ensure(n_in, 0, self._lib)
+            if not real:
+                plans.ensure(n_in, 0, self._lib)
             rc = self._lib.twx_rx_create(C.byref(cfg), arr, len(rows), C.byref(h))
         if rc:
             raise L.TwxError(rc, (self._lib.twx_rx_last_error(None) or b"?").decode())
@@ -134,14 +139,15 @@ def main(argv=None):
     ap.add_argument("--out", default=".", help="where the .dat files and rxcomplex.log are appended")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=int, default=1 << 40)
+    ap.add_argument("--real", action="store_true", help="rx.cpp instead of rxcomplex.cpp: real samples, S rows (SIC), rxreal.log")
     a = ap.parse_args(argv)
     print(a.data)
     rows = parse_param(a.param)
-    with Receiver(rows, code_dir=a.codes, out_dir=a.out, seed=a.seed) as rx:
+    with Receiver(rows, code_dir=a.codes, out_dir=a.out, seed=a.seed, real=a.real) as rx:
         for s, reps in enumerate(rx.run_file(a.data, a.seconds)):
             for i, r in enumerate(reps):
                 info = rx.channel(i)
-                tag = "%s: #%02d" % ("A" if info.is_chA else "B", info.pn)
+                tag = "%s: #%02d" % ("A" if info.is_chA else "B", info.pn + (50 if info.is_sic else 0))
                 if r.status == L.TWX_RX_TRACKED:
                     print("%s %12.3f Hz %13.3f ns SNR %6.2f dB" % (tag, r.fc + r.df, r.gd, 10 * np.log10(r.pk / (r.px - r.pk)) if r.px > r.pk > 0 else 0.0))
                 else:

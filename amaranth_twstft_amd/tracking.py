@@ -80,7 +80,7 @@ def _state_out(st: L.twx_track_state, state: dict, r: L.twx_track_result):
     return dict(freq=r.freq, phi=r.phi, cnt=int(r.cnt), gd=r.gd, dg=r.dg, sdgd=r.sdgd, pk=r.pk)
 
 
-def tracking_update(cor: np.ndarray, phi: np.ndarray, nlag: int, state: dict) -> dict | None:
+def tracking_update(cor: np.ndarray, phi: np.ndarray, nlag: int, state: dict, nobs: int | None = None) -> dict | None:
     """One tracking epoch of experiments/231001_DLL_PLL/rxcomplex.cpp:620-745 on the ``bps-1`` code periods whose power/phase
     matrices ``cor``/``phi`` ([bps-1, 2·nlag+1]) came from :func:`sliding_dot` + :func:`get_cor_and_phi` — binding of the
     library's ``twx_track_update`` (host arithmetic in C++, no GPU needed): per-code peak and high-resolution-correlator delay
@@ -89,13 +89,26 @@ def tracking_update(cor: np.ndarray, phi: np.ndarray, nlag: int, state: dict) ->
 
     ``state`` holds ``fc pt last_phi fs duration psbb`` (the ``ci[i]`` fields) and is updated in place; the returned dict has
     the printed quantities (``freq phi cnt gd dg sdgd pk``).  ``None`` when no more than half of the periods produced a usable
-    peak (:667), in which case ``state`` is left alone.  UNPINNED (GSL/CBLAS program, cannot be built here)."""
+    peak (:667), in which case ``state`` is left alone.  UNPINNED (GSL/CBLAS program, cannot be built here).
+
+    With ``nobs`` (samples per code period) the result also carries ``mai``: the per-period records the real-sample program
+    keeps for its interference cancellation (``twx_track_update_mai``; rx.cpp:664-666,752-757: ``pk_idx amp phase``)."""
     cor = np.ascontiguousarray(cor, dtype=np.float64)
     phi = np.ascontiguousarray(phi, dtype=np.float64)
     st, r = _state_in(state), L.twx_track_result()
-    L.check(L.load().twx_track_update(cor.ctypes.data_as(C.c_void_p), phi.ctypes.data_as(C.c_void_p), cor.shape[0] + 1, int(nlag),
-                                      C.byref(st), C.byref(r)))
-    return _state_out(st, state, r)
+    if nobs is None:
+        L.check(L.load().twx_track_update(cor.ctypes.data_as(C.c_void_p), phi.ctypes.data_as(C.c_void_p), cor.shape[0] + 1, int(nlag),
+                                          C.byref(st), C.byref(r)))
+        return _state_out(st, state, r)
+    bps = cor.shape[0] + 1
+    pk, amp, ph = np.zeros(bps, dtype=np.int32), np.zeros(bps), np.zeros(bps)
+    mai = L.twx_track_mai(pk.ctypes.data_as(C.POINTER(C.c_int32)), amp.ctypes.data_as(C.POINTER(C.c_double)), ph.ctypes.data_as(C.POINTER(C.c_double)))
+    L.check(L.load().twx_track_update_mai(cor.ctypes.data_as(C.c_void_p), phi.ctypes.data_as(C.c_void_p), bps, int(nlag), int(nobs),
+                                          C.byref(st), C.byref(r), C.byref(mai)))
+    out = _state_out(st, state, r)
+    if out is not None:
+        out["mai"] = dict(pk_idx=pk, amp=amp, phase=ph)
+    return out
 
 
 def track_epoch_dev(cor_ctx, iq_dev: int, n_samples: int, replica_dev: int, nobs: int, bps: int, nlag: int, state: dict,

@@ -23,7 +23,7 @@ extern "C" {
 /* 2: twx_config.reserved became the live field nphase (the struct must be zero-initialised), the tracked-ranging,
  *    acquisition and *_dev entry points were added.  twx_abi_version() of an older library answers 1.
  * 3: twx_multi_* (several GPUs from one host process) and twx_rx_* (the DLL/PLL receiver) added; nothing changed. */
-#define TWX_ABI_VERSION 3
+#define TWX_ABI_VERSION 4
 
 typedef struct twx_ctx twx_ctx;
 
@@ -315,7 +315,31 @@ int twx_sliding_dot_cdev(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, i
 int twx_track_epoch_cdev(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, int64_t nobs, int32_t bps, int32_t nlag,
                          const float* replica_dev, double scale, twx_track_state* state, twx_track_result* out);
 
+/* The per-period records the real-sample program keeps for its successive interference cancellation
+ * (experiments/231001_DLL_PLL/rx.cpp:664-666,752-757: dev_pk_idx, dev_res_amp, dev_raw_phi; consumed by MAI_up :1011-1020).
+ * Arrays of bps entries each, owned by the caller; written only when the epoch updates the state (out->updated = 1):
+ *   pk_idx[p]  lag of the period's peak, -nlag..nlag (:638); 0 where the period had no usable peak
+ *   amp[p]     sqrt(2 cor)/psbb (:640)
+ *   phase[p]   carrier phase at the peak BEFORE the BPSK adjustment (raw_phi :664) minus
+ *              (fc + df - fc_prev) * ((p+1)*nobs + pt_prev) / fs with the UPDATED fc, df (:754); entry bps-1 is 0.
+ * The _mai variants are twx_track_update / twx_track_epoch_cdev with these arrays filled in (mai may be NULL). */
+typedef struct twx_track_mai { int32_t* pk_idx; double* amp; double* phase; } twx_track_mai;
+int twx_track_update_mai(const double* cor, const double* phi, int32_t bps, int32_t nlag, int64_t nobs, twx_track_state* state,
+                         twx_track_result* out, const twx_track_mai* mai);
+int twx_track_epoch_cdev_mai(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, int64_t nobs, int32_t bps, int32_t nlag,
+                             const float* replica_dev, double scale, twx_track_state* state, twx_track_result* out,
+                             const twx_track_mai* mai);
+
 /* The DLL/PLL receiver as a program: sdr.param in, ch?.pn??.????kcps.dat rows out -------------------------------------
+ * cfg.ninterp selects which of the two programs of experiments/231001_DLL_PLL runs:
+ *   2  rxcomplex.cpp — complex samples, x2 interpolation, 'N' rows only (described below);
+ *   1  rx.cpp — the REAL-sample program: no interpolation (short2double :892-900 keeps the I sample of each physical channel,
+ *      sps = fs_in), the same set-up / acquisition / tracking on those samples (downconv_acq :976-986, downconv_trk :988-998),
+ *      log lines in rxreal.log, and successive interference cancellation for 'S' rows (:505-518): before such a row is
+ *      searched or tracked, the signals of the 'N' rows EARLIER in the list that sit on the same physical channel with another
+ *      code, are tracking and past their code-lock second, are rebuilt from this second's tracking records (MAI_up
+ *      :1011-1020) and subtracted (MAI_out :1022-1027); the row's received power is that of the cleaned stream (:515-516), its
+ *      PRN is printed + 50 (:708,745).
  * Replaces experiments/231001_DLL_PLL/rxcomplex.cpp as a whole (everything between reading the parameter file and the
  * rows it appends): the parameter parser and per-channel set-up (:263-460 — PRN_sampling :965-978, memcpy_acq :980-987,
  * lowpass :1020-1037, the replica FFT :434-437, psbb :431-432, all on the device), and the per-second loop (:463-835):
@@ -323,12 +347,12 @@ int twx_track_epoch_cdev(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, i
  * acquisition sweep with its SNR gate (:521-586) or one tracking epoch (:589-790) with the is_trk / is_first hand-over,
  * the .dat rows (:724-754) and the rxcomplex.log lines (:439-443,580-584,757-781).
  * Differences, all stated: the program draws the acquisition offset with rand() seeded by time(NULL) (:240,529) — here a
- * generator seeded by cfg.seed (or a fixed block), reported per second; 'S' (SIC) rows are refused: their code is commented
+ * generator seeded by cfg.seed (or a fixed block), reported per second; 'S' (SIC) rows are refused when ninterp = 2: their code is commented
  * out in rxcomplex.cpp:508-519,539-541,596-598; codes come from <code_dir>/<pn-100>.bin as SDRcode does (:866-884) or from
  * the row's own pointer.  A twx_rx is not thread-safe. */
 typedef struct twx_rx twx_rx;
 typedef struct twx_rx_row {        /* one row of sdr.param: chA_or_B Sic_or_Normal PRN_no. center_freq chip_rate LPF_cutoff range step least_SNR */
-    char ch, mode;                 /* 'A' | 'B',  'N' (| 'S': refused) */
+    char ch, mode;                 /* 'A' | 'B',  'N' | 'S' (SIC: ninterp = 1 only) */
     int16_t reserved;
     int32_t pn;                    /* 100.. : 100 000-chip SDR codes, 40 ms (:305-311); < 100: 10 000 chips, 4 ms (:299-304) */
     double fc_init;                /* Hz */
@@ -340,7 +364,7 @@ typedef struct twx_rx_row {        /* one row of sdr.param: chA_or_B Sic_or_Norm
 } twx_rx_row;
 typedef struct twx_rx_config {
     double fs_in;                  /* sample rate of the capture, 5e6 (sps / Ninterp, :33) */
-    int32_t ninterp;               /* 2 (:29) */
+    int32_t ninterp;               /* 2: rxcomplex.cpp (:29);  1: rx.cpp, real samples, SIC rows allowed */
     int32_t dec_a;                 /* 1: X310 build, 2: N210/B210 build (:226-231) */
     const char* code_dir;          /* where 0.bin, 1.bin live (NULL: current directory) */
     const char* out_dir;           /* where the .dat files and rxcomplex.log are appended (NULL: no files, reports only) */
@@ -364,7 +388,7 @@ typedef struct twx_rx_report {     /* one channel, one second */
     char dat_row[128];             /* TWX_RX_TRACKED: the row appended to ch<A|B>.pn<id>.<kcps>kcps.dat, newline included */
 } twx_rx_report;
 typedef struct twx_rx_channel_info {
-    int32_t pn, is_chA, clen, nlag, bps, reserved;
+    int32_t pn, is_chA, clen, nlag, bps, is_sic;
     int64_t nobs, nfft;
     double duration, range, step, snr_min, psbb;
     char dat_name[64];
@@ -383,7 +407,9 @@ int twx_rx_second_dev(twx_rx* rx, const void* iq_dev, twx_rx_report* reports);
 /* The program's main loop over a capture file (`./rxcomplex data.bin sdr.param`): whole seconds until the file ends or
  * max_seconds; reports (may be NULL) receives n_rows records per second, capacity report_seconds seconds. */
 int twx_rx_file(twx_rx* rx, const char* path, int64_t max_seconds, twx_rx_report* reports, int64_t report_seconds, int64_t* n_seconds);
-/* Device pointer to the interpolated stream of physical channel 0 (A) / 1 (B) of the last second (fs_in*ninterp complex floats). */
+/* Device pointer to the interpolated stream of physical channel 0 (A) / 1 (B) of the last second (fs_in*ninterp complex floats;
+ * ninterp = 1: the real samples with a zero imaginary part); physical_channel 2: the interference-free stream of the LAST 'S' row
+ * processed (NULL when there is none). */
 const void* twx_rx_stream_dev(const twx_rx* rx, int32_t physical_channel);
 
 /* Tracked multi-code ranging: a whole capture in, per-code delay records out ---------------------------------

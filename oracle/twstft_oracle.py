@@ -702,6 +702,29 @@ def rx_short2double(smp, nobs: int, dec: int = 1):
     return out[0], out[1]
 
 
+def rx_short2double_real(smp, nobs: int, dec: int = 1):
+    """``short2double`` of the REAL-sample program, experiments/231001_DLL_PLL/rx.cpp:892-900: the I sample of physical
+    channel A (offset 0) and B (offset 2) of every frame, /32768; no interpolation."""
+    smp = np.asarray(smp).reshape(-1)
+    i = np.arange(nobs)
+    return smp[4 * i * dec] / 32768.0, smp[4 * i * dec + 2] / 32768.0
+
+
+def rx_mai_up(nobs: int, ld: int, pt: int, amp, c_wav, pidx, ff: float, pmod, wav):
+    """``MAI_up`` rx.cpp:1011-1020: for ``i >= pt``, period ``p=(i-pt)/ld``, code sample ``k=(i-pidx[p]-pt+ld)%ld``:
+    ``wav[i] += 0.5*amp[p]*real(c_wav[k])*cos(2 pi (ff*i + pmod[p]))`` (in place)."""
+    i = np.arange(pt, nobs)
+    p = (i - pt) // ld
+    k = (i - np.asarray(pidx)[p] - pt + ld) % ld
+    wav[pt:] += 0.5 * np.asarray(amp)[p] * np.asarray(c_wav).real[k] * np.cos(2.0 * 3.141592653589793 * (ff * i.astype(np.float64) + np.asarray(pmod)[p]))
+    return wav
+
+
+def rx_mai_out(inp, out):
+    """``MAI_out`` rx.cpp:1022-1027: ``out = in - out``."""
+    return np.asarray(inp) - out
+
+
 def rx_prn_sampling(nobs: int, code, rc: float, fs: float, clen: int, delay_ns: float = 0.0):
     """``PRN_sampling`` :965-978: ``idx=floor(fmod((i/fs-delay*1e-9)*rc, clen))`` (wrapped), value ``code[idx]``."""
     i = np.arange(nobs, dtype=np.float64)
@@ -860,7 +883,8 @@ def rx_track_epoch(smp, wav_t, st: dict, nobs: int, bps: int, nlag: int, fs: flo
     res = alpha * (obs @ wav.T)                                                       # cblas_dgemm :605: [bps-1, nl], re and im columns
     cor = res.real ** 2 + res.imag ** 2                                               # get_cor_and_phi :1063-1072
     ph = np.arctan2(res.imag, res.real) / 2.0 / 3.141592653589793
-    res_gd, res_phi, ps, w, ttag_phi = (np.zeros(bps) for _ in range(5))
+    res_gd, res_phi, ps, w, ttag_phi, res_amp = (np.zeros(bps) for _ in range(6))
+    pk_idx = np.zeros(bps, dtype=np.int64)
     cnt = 0
     for p in range(bps - 1):
         k = int(np.argmax(np.abs(cor[p])))                                            # cblas_idamax :630
@@ -868,6 +892,8 @@ def rx_track_epoch(smp, wav_t, st: dict, nobs: int, bps: int, nlag: int, fs: flo
         ps[p] = cor[p, k] / st["psbb"]                                                # :633
         if k - 2 >= 0 and k + 2 < nl:                                                 # :634
             res_phi[p] = ph[p, k]
+            pk_idx[p] = k - nlag                                                      # rx.cpp:638
+            res_amp[p] = np.sqrt(2.0 * cor[p, k]) / st["psbb"]                        # rx.cpp:640
             c = cor[p]
             res_gd[p] = ((c[k - 1] - c[k + 1]) / (c[k - 1] - 2.0 * c[k] + c[k + 1])
                          - (c[k - 2] - c[k + 2]) / (c[k - 2] - 2.0 * c[k] + c[k + 2])
@@ -877,6 +903,7 @@ def rx_track_epoch(smp, wav_t, st: dict, nobs: int, bps: int, nlag: int, fs: flo
     st["cnt_last"] = cnt                                                              # what the "lock lost" line prints (:787)
     if not cnt * 2 > bps:                                                             # :667
         return None
+    raw_phi = res_phi.copy()                                                          # rx.cpp:664 (the real-sample program's SIC records)
     sel = [res_gd[p] for p in range(bps) if w[p] > 0.0]                               # :692-698
     ii = len(sel)
     c0 = rx_kth_smallest(sel, ii // 2)                                                # :699
@@ -905,11 +932,17 @@ def rx_track_epoch(smp, wav_t, st: dict, nobs: int, bps: int, nlag: int, fs: flo
                gd=g0 + 0.5 * g1, dg=g1, pk=float(np.mean(ps[w > 0.0])))              # :740-742, average() :887-901
     st["pt_prev"] = pt
     st["pt"] = int(np.floor((g0 + g1) * fs / 1.0e+9 + 0.5)) if (g0 + g1) >= 0 else -int(np.floor(-(g0 + g1) * fs / 1.0e+9 + 0.5))   # round() :744
+    # rx.cpp:664-666,752-757: what MAI_up reads — peak lags, amplitudes, and the raw phases with the carrier update taken out
+    rec = np.zeros(bps)
+    pp = np.arange(bps - 1)
+    rec[:bps - 1] = raw_phi[:bps - 1] - (st["fc"] + st["df"] - st["fc_prev"]) * ((pp + 1) * nobs + st["pt_prev"]).astype(np.float64) / fs
+    st["mai"] = dict(pk_idx=pk_idx, amp=res_amp, phase=rec)
     return out
 
 
 # --------------------------------------------------------------------------------------------
-# The receiver as a program, experiments/231001_DLL_PLL/rxcomplex.cpp:263-835 — UNPINNED (same reason as above): parameter
+# The receiver as a program, experiments/231001_DLL_PLL/rxcomplex.cpp:263-835, and (real=True) its real-sample sibling rx.cpp with
+# the successive interference cancellation of rx.cpp:505-518 — UNPINNED (same reason as above): parameter
 # parser, per-channel set-up, the per-second loop with the acquisition -> tracking hand-over, the text of the .dat rows and of
 # the rxcomplex.log lines.  Checker of twx_rx_* (tests/test_gpu_rx.py, tests/test_rx_host.py).
 # --------------------------------------------------------------------------------------------
@@ -947,7 +980,9 @@ def rx_parse_param(lines):
 
 def rx_channel_setup(row: dict, code_bytes, sps: int, dec_a: int = 1) -> dict:
     """``channel_info`` after :290-437 for one accepted row; ``code_bytes`` = the file SDRcode reads (:866-884), 0/1 per chip."""
-    ci = dict(is_chA=row["ch"] == "A", cid=row["pn"], rc=row["kcps"] * 1000, fc_init=row["fc_init"])
+    ci = dict(is_chA=row["ch"] == "A", cid=row["pn"], rc=row["kcps"] * 1000, fc_init=row["fc_init"], is_sic=row.get("mode", "N") == "S")
+    shown = ci["cid"] + 50 if ci["is_sic"] else ci["cid"]                             # rx.cpp:442,708: SIC rows print PRN + 50
+    ci["shown"] = shown
     if row["pn"] < 100:
         ci.update(clen=10000, duration=0.004, nlag=14)                                # :299-304
     else:
@@ -973,23 +1008,35 @@ def rx_channel_setup(row: dict, code_bytes, sps: int, dec_a: int = 1) -> dict:
     code = 1 - 2 * np.asarray(code_bytes[:ci["clen"]], dtype=np.int64)                 # host_code :879
     wav_acq_f, psbb, filt = rx_replica(code, ci["nobs"], nfft, float(ci["rc"]), fs, ci["clen"], ci["fltmax"], ci["fltmin"], dec_a)
     ci.update(wav_acq_f=wav_acq_f, psbb=psbb, wav_t=filt)
-    ci["dat_name"] = "ch%s.pn%02d.%dkcps.dat" % ("A" if ci["is_chA"] else "B", ci["cid"], ci["rc"] // 1000)     # :720
+    ci["dat_name"] = "ch%s.pn%02d.%dkcps.dat" % ("A" if ci["is_chA"] else "B", shown, ci["rc"] // 1000)     # :720
     ci["log_set"] = "set param   : Ch. %s, PRN#%2d, %8.0f %4d %5.0f %5.0f %5.0f %3.0f\n" % (
-        "A" if ci["is_chA"] else "B", ci["cid"], ci["fc_init"], ci["rc"] // 1000, ci["fltmax"] * 1.0e-3, ci["range"], ci["step"], ci["snr_min"])   # :441
+        "A" if ci["is_chA"] else "B", shown, ci["fc_init"], ci["rc"] // 1000, ci["fltmax"] * 1.0e-3, ci["range"], ci["step"], ci["snr_min"])   # :441
     return ci
 
 
-def rx_second(cis, raw_second, sps: int, dec_a: int, acq_idx):
+def rx_second(cis, raw_second, sps: int, dec_a: int, acq_idx, real: bool = False):
     """One pass of the loop body :468-832.  ``raw_second``: ``sps/Ninterp`` frames ``[IA QA IB QB]`` of int16; ``acq_idx(i, ci)``
     returns the sample offset the program draws with rand() (:529).  Returns one dict per channel: ``status`` (the names of the
     TWX_RX_* states), the ``channel_info`` values after the pass, ``dat_row`` / ``log`` texts where the program writes them."""
     fs = float(sps)
-    smp_a, smp_b = rx_short2double(np.asarray(raw_second).reshape(-1), sps)                 # :477
+    if real:                                                                                  # rx.cpp:478 — and, below, its SIC block :505-518
+        smp_a, smp_b = rx_short2double_real(np.asarray(raw_second).reshape(-1), sps)
+    else:
+        smp_a, smp_b = rx_short2double(np.asarray(raw_second).reshape(-1), sps)             # :477
     pwr = {True: rx_power(smp_a, fs, dec_a), False: rx_power(smp_b, fs, dec_a)}               # :481-489
     out = []
     for i, ci in enumerate(cis):
         smp = smp_a if ci["is_chA"] else smp_b
         ci["px"] = pwr[ci["is_chA"]]
+        if real and ci["is_sic"]:                                                             # rx.cpp:505-518
+            mai = np.zeros(sps)
+            for k in range(i):
+                o = cis[k]
+                if o["is_chA"] == ci["is_chA"] and o["cid"] != ci["cid"] and not o["is_sic"] and o["is_trk"] and not o["is_first"]:
+                    m = o["mai"]
+                    rx_mai_up(sps, o["nobs"], o["pt_prev"], m["amp"], o["wav_t"], m["pk_idx"], (o["fc"] + o["df"]) / fs, m["phase"], mai)
+            smp = rx_mai_out(smp, mai)
+            ci["px"] = rx_power(smp, fs, dec_a)                                               # rx.cpp:515-516
         chs = "A" if ci["is_chA"] else "B"
         ev = dict(status=None, dat_row="", log="", acq_idx=0)
         if not ci["is_trk"]:                                                                  # :521-586
@@ -1004,7 +1051,7 @@ def rx_second(cis, raw_second, sps: int, dec_a: int, acq_idx):
                 ci["gd"] = float(ci["pt"]) * 1.0e+9 / fs
                 ci["is_trk"], ci["is_first"] = True, True
                 ev["log"] = "acquisition : Ch. %s, PRN#%2d, %3d %8.0f %7.0f %6d %8.3f %8.3f\n" % (
-                    chs, ci["cid"], idx // 2 // ci["nobs"], ci["fc"], ci["gd"], ci["pt"], rx_v2todbm(ci["pk"]), rx_v2todbm(ci["px"]))   # :582
+                    chs, ci["shown"], idx // 2 // ci["nobs"], ci["fc"], ci["gd"], ci["pt"], rx_v2todbm(ci["pk"]), rx_v2todbm(ci["px"]))   # :582
                 ev["status"] = "acquired"
             else:
                 ev["status"] = "no signal"
@@ -1018,11 +1065,11 @@ def rx_second(cis, raw_second, sps: int, dec_a: int, acq_idx):
                         rx_v2todbm(ci["px"] - ci["pk"]))                                        # :735,747,752
                     ev["status"] = "tracked"
                 else:
-                    ev["log"] = "code lock   : Ch. %s, PRN#%2d, count = %d / %d\n" % (chs, ci["cid"], ci["cnt"], ci["bps"])      # :761
+                    ev["log"] = "code lock   : Ch. %s, PRN#%2d, count = %d / %d\n" % (chs, ci["shown"], ci["cnt"], ci["bps"])      # :761
                     ci["is_first"] = False                                                    # :766
                     ev["status"] = "code lock"
             else:
-                ev["log"] = "%s : Ch. %s, PRN#%2d, count = %d / %d\n" % ("acq failed " if ci["is_first"] else "lock lost  ", chs, ci["cid"],
+                ev["log"] = "%s : Ch. %s, PRN#%2d, count = %d / %d\n" % ("acq failed " if ci["is_first"] else "lock lost  ", chs, ci["shown"],
                                                                           ci.get("cnt_last", 0), ci["bps"])                      # :779,787
                 ev["status"] = "acq failed" if ci["is_first"] else "lock lost"
                 ci["is_trk"], ci["last_phi"] = False, 0.0                                      # :792-793

@@ -137,7 +137,7 @@ def test_receiver_file_loop_and_lock_lost(tmp_path):
 
 def test_receiver_refuses_what_the_program_cannot_do(tmp_path):
     chips = chips_for(17, 9, CLEN)
-    with pytest.raises(L.TwxError, match="SIC rows are not supported"):
+    with pytest.raises(L.TwxError, match="SIC rows need ninterp = 1"):
         receiver.Receiver([receiver.make_row("A", 100, 186.0, 2000.0, 256.0, -18.0, mode="S", code=chips)])
     with pytest.raises(L.TwxError, match="Code filename error"):
         receiver.Receiver([receiver.make_row("A", 100, 186.0, 2000.0, 256.0, -18.0)], code_dir=str(tmp_path))
@@ -173,3 +173,81 @@ def test_receiver_b210_build_and_device_resident_seconds():
     for g, w in zip(got[1:], want[1:]):
         assert (g.fc, g.pt, g.cnt) == (w["fc"], w["pt"], w["cnt"]) and abs(g.gd - w["gd"]) <= 0.05 and abs(g.fc + g.df - (w["fc"] + w["df"])) <= 5e-4
     assert abs(got[-1].gd - 2 * 77_001 * 100.0) < 100.0
+
+
+def test_real_sample_program_with_interference_cancellation(tmp_path):
+    """cfg.ninterp = 1: the real-sample program experiments/231001_DLL_PLL/rx.cpp — the I samples only, no interpolation (nobs = 200 000,
+    nfft = 2^19), rxreal.log — and its successive interference cancellation (rx.cpp:505-518, MAI_up :1011-1020, MAI_out :1022-1027).
+    Physical channel A carries code 0 strongly and code 1 weakly.  The 'N' row for code 1 never passes the -14 dB gate (the strong code
+    is its noise); the 'S' row for the same code does, from the second in which code 0 is past its code lock: the received power of
+    the cleaned stream drops, the weak code is acquired, locked and tracked.  Every second against oracle.rx_second(real=True)."""
+    import torch
+    seconds = 4
+    dev = torch.device("cuda", 0)
+    chips = {0: chips_for(17, 9, CLEN), 1: chips_for(17, 15, CLEN)}
+    par = {0: synth.SynthParams(delay_q8=123_457 * 256, fstep=synth.fstep_for_df(1307.25, 5e6), phi0=11, amp=1500,
+                                noise_gain=synth.noise_gain_for_sigma(600.0), seed=31, stream=0),
+           1: synth.SynthParams(delay_q8=77_001 * 256, fstep=synth.fstep_for_df(-260.5, 5e6), phi0=5, amp=300, noise_gain=0, seed=31, stream=1)}
+    cap = np.zeros((seconds, N_IN, 4), dtype=np.int16)
+    tmp = torch.empty((N_IN, 2), dtype=torch.int16, device=dev)
+    for s in range(seconds):
+        acc = np.zeros((N_IN, 2), dtype=np.int32)
+        for c in (0, 1):
+            _synth_dev(tmp, N_IN, torch.from_numpy(chips[c]).to(dev), CLEN, 2, [par[c]], n0=s * N_IN)
+            torch.cuda.synchronize()
+            acc += tmp.cpu().numpy()
+        cap[s, :, 0:2] = acc                                    # physical channel B stays silent
+    chips[0].tofile(tmp_path / "0.bin")
+    chips[1].tofile(tmp_path / "1.bin")
+    param = tmp_path / "sdr.param"
+    param.write_text("A N 100 0001186 2500 1250 2000 256 -18\n"         # the strong code
+                     "A S 101 -000186 2500 1250 2000 256 -14\n"         # the weak code behind the cancellation: printed as PRN 151
+                     "A N 101 -000186 2500 1250 2000 256 -14\n")        # the weak code without it
+    rows = receiver.parse_param(str(param))
+    assert [r.mode for r in rows] == [b"N", b"S", b"N"]
+    outdir = tmp_path / "out"
+    outdir.mkdir()
+    block = 3
+    with receiver.Receiver(rows, code_dir=str(tmp_path), out_dir=str(outdir), acq_block=block, real=True) as rx:
+        infos = [rx.channel(i) for i in range(3)]
+        got = []
+        for s in range(seconds):
+            got.append(rx.second(cap[s]))
+            assert rx.stream_dev(0) != 0 and rx.stream_dev(1) == 0 and rx.stream_dev(2) != 0
+    assert [(i.nobs, i.nfft, i.bps, i.nlag, i.is_sic) for i in infos] == [(200_000, 1 << 19, 25, 28, 0), (200_000, 1 << 19, 25, 28, 1), (200_000, 1 << 19, 25, 28, 0)]
+    assert [i.dat_name.decode() for i in infos] == ["chA.pn100.2500kcps.dat", "chA.pn151.2500kcps.dat", "chA.pn101.2500kcps.dat"]
+    # ---- oracle
+    orows = orc.rx_parse_param(param.read_text().splitlines(True))
+    cis = [orc.rx_channel_setup(r, chips[0] if r["pn"] == 100 else chips[1], N_IN) for r in orows]
+    for info, ci in zip(infos, cis):
+        assert abs(info.psbb - ci["psbb"]) <= 1e-9 * ci["psbb"] and info.dat_name.decode() == ci["dat_name"]
+    want = [orc.rx_second(cis, cap[s].reshape(-1), N_IN, 1, lambda i, ci: block * ci["nobs"], real=True) for s in range(seconds)]
+    status = [[receiver.STATUS[r.status] for r in sec] for sec in got]
+    assert status == [[e["status"] for e in sec] for sec in want]
+    assert status == [["acquired", "no signal", "no signal"], ["code lock", "acquired", "no signal"], ["tracked", "code lock", "no signal"],
+                      ["tracked", "tracked", "no signal"]]
+    for s in range(seconds):
+        for i in range(3):
+            g, w = got[s][i], want[s][i]
+            assert abs(g.px - w["px"]) <= (1e-4 if i == 1 else 1e-5) * w["px"], (s, i)      # row 1: power of the CLEANED stream (rx.cpp:515-516)
+            if w["status"] in ("acquired", "no signal"):
+                assert (g.fc, g.pt, g.acq_idx) == (w["fc"], w["pt"], w["acq_idx"]), (s, i)
+                assert abs(g.pk - w["pk"]) <= 1e-4 * w["pk"]
+            else:
+                assert (g.fc, g.pt, g.cnt) == (w["fc"], w["pt"], w["cnt"]), (s, i)
+                assert abs(g.fc + g.df - (w["fc"] + w["df"])) <= 2e-3 and abs(g.gd - w["gd"]) <= 0.2 and abs(g.pk - w["pk"]) <= 1e-4 * w["pk"]
+    # what the cancellation buys: the cleaned stream's power is less than half of channel A's from the second after code 0's code lock
+    assert got[0][1].px == got[0][0].px and all(got[s][1].px < 0.55 * got[s][0].px for s in (1, 2, 3))
+    assert all(got[s][2].px == got[s][0].px for s in range(seconds))
+    # the truth of the generator (real samples: the carrier's sign is not observable, the sweep settles on +260.5)
+    assert abs(got[-1][0].fc + got[-1][0].df - 1307.25) < 0.2 and abs(abs(got[-1][1].fc + got[-1][1].df) - 260.5) < 0.2
+    assert abs(got[-1][0].gd - 123_457 * 200.0) < 100.0 and abs(got[-1][1].gd - 77_001 * 200.0) < 100.0            # ns at 5 Msps
+    # ---- files: rxreal.log, PRN + 50 for the SIC row
+    log = (outdir / "rxreal.log").read_text().splitlines(True)
+    assert not (outdir / "rxcomplex.log").exists()
+    assert log[:3] == [ci["log_set"] for ci in cis] and "PRN#151" in log[1]
+    wl = [e["log"] for sec in want for e in sec if e["log"]]
+    assert [l[:11] for l in log[3:]] == ["acquisition", "code lock  ", "acquisition", "code lock  "] == [l[:11] for l in wl]
+    assert [l.split(",")[:2] for l in log[3:]] == [l.split(",")[:2] for l in wl]
+    assert (outdir / "chA.pn151.2500kcps.dat").read_text() == got[3][1].dat_row.decode()
+    assert len((outdir / "chA.pn100.2500kcps.dat").read_text().splitlines()) == 2 and not (outdir / "chA.pn101.2500kcps.dat").exists()

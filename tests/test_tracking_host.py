@@ -97,8 +97,12 @@ def test_track_update_equals_the_oracle_restatement_of_the_epoch():
         pt = st2["pt"]
         obs = orc.rx_downconv_trk(nobs * (bps - 1), nobs, st2["fc"] / fs, float(np.fmod(pt * st2["fc"] / fs, 1.0)), x[pt:])
         res = (obs @ orc.rx_prn_mapping(nobs, nlag, wav.astype(complex)).T) / nobs
-        got = tracking.tracking_update(res.real ** 2 + res.imag ** 2, np.arctan2(res.imag, res.real) / 2 / np.pi, nlag, st2)
+        got = tracking.tracking_update(res.real ** 2 + res.imag ** 2, np.arctan2(res.imag, res.real) / 2 / np.pi, nlag, st2, nobs=nobs)
         assert want is not None and got is not None and got["cnt"] == want["cnt"] >= bps - 3
+        # the records rx.cpp keeps for MAI_up (:664-666,752-757): peak lags exact, amplitudes and recovered phases to rounding
+        assert np.array_equal(got["mai"]["pk_idx"], st["mai"]["pk_idx"]) and np.count_nonzero(got["mai"]["amp"]) >= bps - 3
+        assert np.allclose(got["mai"]["amp"], st["mai"]["amp"], rtol=1e-12, atol=0) and np.allclose(got["mai"]["phase"], st["mai"]["phase"], rtol=0, atol=1e-9)
+        assert got["mai"]["phase"][-1] == 0.0 and got["mai"]["amp"][-1] == 0.0
         for k in ("freq", "phi", "gd", "dg", "sdgd", "pk"):
             assert abs(got[k] - want[k]) <= 1e-9 * max(1.0, abs(want[k])), k
         assert (st2["pt"], st2["fc"], st2["pt_prev"]) == (st["pt"], st["fc"], st["pt_prev"]) and abs(st2["last_phi"] - st["last_phi"]) < 1e-12
