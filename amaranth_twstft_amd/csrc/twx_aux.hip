@@ -234,7 +234,7 @@ bool sliding_narrow(long long nobs, int nlag, int nch) {
     static const bool off = getenv("TWX_SLIDING_NARROW") && atoi(getenv("TWX_SLIDING_NARROW")) == 0;      // A/B (profiles/r04_sliding_scan.txt)
     return !off && nlag <= 8 && nch == 1 && nobs % 8 == 0;
 }
-int sliding_chunk(long long nobs, int ncodes, bool narrow) {
+int sliding_chunk(long long nobs, int ncodes, bool narrow, bool wide8 = false) {
     static const int ncu = [] {                                    // one process drives one GPU (or GPUs of one kind)
         int n = 256, dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) return n;
@@ -245,7 +245,7 @@ int sliding_chunk(long long nobs, int ncodes, bool narrow) {
     const long long slots = (narrow ? 4ll : 2ll) * ncu;
     const long long per_code = std::max<long long>(1, slots / ncodes);                    // chunks per code in one round
     long long len = (nobs + per_code - 1) / per_code;
-    const long long gran = SD_NT * (narrow ? 8 : SD_T);
+    const long long gran = SD_NT * ((narrow || wide8) ? 8 : SD_T);
     len = std::max<long long>(4096, ((len + gran - 1) / gran) * gran);
     return (int)std::min<long long>(len, 1ll << 24);
 }
@@ -253,10 +253,14 @@ template <typename XT>
 int launch_sliding(hipStream_t st, const XT* dx, int nch, long long pt, long long nobs, int ncodes, int nlag, const float* dw,
                    double ff, double phi, double scale, double* dpart, double* dout) {
     const bool narrow = sliding_narrow(nobs, nlag, nch);
-    const int clen = sliding_chunk(nobs, ncodes, narrow);
+    // wide windows, eight samples per lane (whole groups of eight, one channel): the per-pass overhead (mixing, addresses, the
+    // LDS words) is shared by twice the FMAs
+    static const bool wide8_off = getenv("TWX_SLIDING_WIDE8") && atoi(getenv("TWX_SLIDING_WIDE8")) == 0;
+    const bool wide8 = !narrow && !wide8_off && nlag > 8 && nch == 1 && nobs % 8 == 0;
+    const int clen = sliding_chunk(nobs, ncodes, narrow, wide8);
     const int nchunks = (int)((nobs + clen - 1) / clen);
     const dim3 grid(nchunks, ncodes), block(SD_NT);
-    const int T = narrow ? 8 : SD_T;
+    const int T = (narrow || wide8) ? 8 : SD_T;
     const double two_pi = 6.283185307179586476925286766559;
     const float rot_c = (float)cos(two_pi * ff), rot_s = (float)(-sin(two_pi * ff));          // exp(-2 pi j ff)
     SdRot rot;
@@ -267,16 +271,19 @@ int launch_sliding(hipStream_t st, const XT* dx, int nch, long long pt, long lon
     }
 #define SD_GO(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_, XT>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, rot, dpart)
 #define SD_GO8(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_, XT, 8, 8192, 4>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, rot, dpart)
+#define SD_GOW(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_, XT, 8, 16384, 2>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, rot, dpart)
     if (narrow) { if (nlag <= 4) SD_GO8(4); else SD_GO8(8); }
+    else if (wide8) { if (nlag <= 16) SD_GOW(16); else if (nlag <= 28) SD_GOW(28); else SD_GOW(31); }
     else if (nlag <= 4) SD_GO(4); else if (nlag <= 8) SD_GO(8); else if (nlag <= 16) SD_GO(16); else if (nlag <= 28) SD_GO(28); else SD_GO(31);
 #undef SD_GO
 #undef SD_GO8
+#undef SD_GOW
     if (hipGetLastError() != hipSuccess) return TWX_E_HIP;
     hipLaunchKernelGGL(k_sliding_reduce, dim3(ncodes), dim3(64), 0, st, dpart, nchunks, 2 * nlag + 1, 1.0 / (double)nobs, dout);
     return hipGetLastError() == hipSuccess ? TWX_OK : TWX_E_HIP;
 }
 size_t sliding_part_bytes(long long nobs, int ncodes, int nlag) {
-    const int clen = std::min(sliding_chunk(nobs, ncodes, false), sliding_chunk(nobs, ncodes, true));      // the form is chosen at launch (channel count)
+    const int clen = std::min(sliding_chunk(nobs, ncodes, false), sliding_chunk(nobs, ncodes, true));      // the form is chosen at launch (channel count); the wide8 chunks are no shorter
     return (size_t)ncodes * (size_t)((nobs + clen - 1) / clen) * (2 * nlag + 1) * 16;
 }
 
@@ -300,18 +307,87 @@ size_t sliding_part_bytes(long long nobs, int ncodes, int nlag) {
 // grid = ceil(nout / (4*FIR_NT)), dynamic LDS = D*PSQ*4 bytes
 // ---------------------------------------------------------------------------------------------
 constexpr int FIR_NT = 128, FIR_K = 4, FIR_OUT = FIR_NT * FIR_K;
-struct FirGeom { int A, SH, PSQ, HROW, LASTN; size_t lds; };
+// The EIGHT-output form (k_fir_poly8, round 4): thread t of a half-workgroup of FIR8_T threads owns the eight outputs 8t..8t+7, so a
+// value read (and converted) feeds eight packed FMAs instead of four: per group of four steps 1 LDS read, 8 converts, 32 packed
+// FMAs — 12 % fewer vector instructions per output.  Eight outputs per thread double the span a workgroup stages (60 KB for
+// 1024 outputs: two workgroups per CU); to keep eight waves on the CU the workgroup has TWO halves of FIR8_T threads that share
+// the staged span and split the D phases between them (half 0: phases 0..ceil(D/2)-1), and half 1 hands its partial sums to half
+// 0 through LDS at the end.  Used when D >= 2 and the step count fits the unrolled instantiations; TWX_FIR_K=4 forces the old form.
+constexpr int FIR8_T = 128, FIR8_K = 8, FIR8_NT = 2 * FIR8_T, FIR8_OUT = FIR8_T * FIR8_K;
+struct FirGeom { int K, A, SH, PSQ, HROW, LASTN; size_t lds; };
 FirGeom fir_geom(int ntaps, int dec) {
     FirGeom g;
     g.A = (ntaps + dec - 1) / dec;
-    g.SH = (g.A + FIR_K - 1 + 3) / 4;            // groups of four steps s = 0 .. A+K-2
-    g.LASTN = g.A + FIR_K - 1 - 4 * (g.SH - 1);  // steps of the last group that can meet a tap (1..4)
+    static const int force_k = [] { const char* e = getenv("TWX_FIR_K"); return e ? atoi(e) : 0; }();
+    const int sh8 = std::max(4, (g.A + FIR8_K - 1 + 3) / 4);
+    g.K = (dec >= 2 && sh8 <= 16 && force_k != 4) ? FIR8_K : FIR_K;
+    g.SH = (g.A + g.K - 1 + 3) / 4;              // groups of four steps s = 0 .. A+K-2
+    g.LASTN = g.A + g.K - 1 - 4 * (g.SH - 1);    // steps of the last group that can meet a tap (1..4)
     if (g.SH < 4) { g.SH = 4; g.LASTN = 4; }                  // counts 4..16 have unrolled kernels
-    const int nq = FIR_K * (FIR_NT + g.SH);      // q values staged per phase
+    const int nq = g.K * (g.K == FIR8_K ? FIR8_T : FIR_NT) + 4 * g.SH;   // q values staged per phase
     g.PSQ = ((nq / 4) & 1) ? nq : nq + 4;        // a multiple of 4 (16-byte reads) with PSQ/4 odd (staging writes)
-    g.HROW = 4 * g.SH + 4;                       // taps per phase incl. padding (7 are read per group of steps)
+    g.HROW = 4 * g.SH + g.K;                     // taps per phase incl. padding (K-1 zeros in front; K+3 are read per group of steps)
     g.lds = (size_t)dec * g.PSQ * sizeof(unsigned);
     return g;
+}
+
+// Staging of a workgroup's input span into LDS, phase-major (NTH threads).
+template <int NTH>
+__device__ __forceinline__ void fir_stage(unsigned* __restrict__ X, const short2* __restrict__ x, int nch, long long nin, long long e0, int span, int D,
+                                          int PSQ, int tid) {
+    // sample e = q*D + p of the span goes to slot(p, q) = p*PSQ + q: along e the slot advances by PSQ, and by 1 - (D-1)*PSQ
+    // where p wraps — no division and no multiplication per sample.
+    // Loads are UNCONDITIONAL (clamped indices): a load inside a divergent branch gets its own s_waitcnt vmcnt(0), which
+    // turns "eight loads in flight" into eight round trips.
+    const int nvec = span >> 2;
+    const int wrap = D * PSQ - 1;
+    if (nch == 1 && ((reinterpret_cast<unsigned long long>(x + e0) & 15ull) == 0) && e0 + 4ll * nvec <= nin) {
+        // interior workgroup, one channel, aligned: 16-B loads, four samples per lane
+        const int4* xv = reinterpret_cast<const int4*>(x + e0);
+        const int dq4 = (4 * NTH) / D, dp4 = 4 * NTH - dq4 * D;
+        int q = (4 * tid) / D, p = 4 * tid - q * D;
+        for (int jb = 0; jb < nvec; jb += 8 * NTH) {
+            int4 raw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) raw[u] = xv[min(jb + u * NTH + tid, nvec - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = jb + u * NTH + tid;
+                const int w4[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+                int slot = p * PSQ + q, pp = p;
+                if (j < nvec) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        X[slot] = (unsigned)w4[i];
+                        slot += PSQ;
+                        if (++pp >= D) { pp = 0; slot -= wrap; }
+                    }
+                }
+                q += dq4; p += dp4;
+                if (p >= D) { p -= D; ++q; }
+            }
+        }
+    } else {
+        const int dq = NTH / D, dp = NTH - dq * D;
+        int q = tid / D, p = tid - q * D;
+        const unsigned* xs = reinterpret_cast<const unsigned*>(x);
+        for (int eb = 0; eb < span; eb += 8 * NTH) {
+            unsigned raw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long g = e0 + eb + u * NTH + tid;
+                const unsigned v = xs[min(g, nin - 1) * nch];
+                raw[u] = g < nin ? v : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = eb + u * NTH + tid;
+                if (e < span) X[p * PSQ + q] = raw[u];
+                q += dq; p += dp;
+                if (p >= D) { p -= D; ++q; }
+            }
+        }
+    }
 }
 
 // SHT > 0: the number of 4-step groups is a compile-time constant, so a whole phase is one straight-line block: all
@@ -329,59 +405,7 @@ __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ 
     const long long e0 = m0 * D;
     const int nq = FIR_K * (FIR_NT + SH);                          // q values staged per phase
     const int span = nq * D;                                       // a multiple of 4
-    // sample e = q*D + p of the span goes to slot(p, q) = p*PSQ + q: along e the slot advances by PSQ, and by 1 - (D-1)*PSQ
-    // where p wraps — no division and no multiplication per sample.
-    // Loads are UNCONDITIONAL (clamped indices): a load inside a divergent branch gets its own s_waitcnt vmcnt(0), which
-    // turns "eight loads in flight" into eight round trips.
-    const int nvec = span >> 2;
-    const int wrap = D * PSQ - 1;
-    if (nch == 1 && ((reinterpret_cast<unsigned long long>(x + e0) & 15ull) == 0) && e0 + 4ll * nvec <= nin) {
-        // interior workgroup, one channel, aligned: 16-B loads, four samples per lane
-        const int4* xv = reinterpret_cast<const int4*>(x + e0);
-        const int dq4 = (4 * FIR_NT) / D, dp4 = 4 * FIR_NT - dq4 * D;
-        int q = (4 * tid) / D, p = 4 * tid - q * D;
-        for (int jb = 0; jb < nvec; jb += 8 * FIR_NT) {
-            int4 raw[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) raw[u] = xv[min(jb + u * FIR_NT + tid, nvec - 1)];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = jb + u * FIR_NT + tid;
-                const int w4[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
-                int slot = p * PSQ + q, pp = p;
-                if (j < nvec) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        X[slot] = (unsigned)w4[i];
-                        slot += PSQ;
-                        if (++pp >= D) { pp = 0; slot -= wrap; }
-                    }
-                }
-                q += dq4; p += dp4;
-                if (p >= D) { p -= D; ++q; }
-            }
-        }
-    } else {
-        const int dq = FIR_NT / D, dp = FIR_NT - dq * D;
-        int q = tid / D, p = tid - q * D;
-        const unsigned* xs = reinterpret_cast<const unsigned*>(x);
-        for (int eb = 0; eb < span; eb += 8 * FIR_NT) {
-            unsigned raw[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const long long g = e0 + eb + u * FIR_NT + tid;
-                const unsigned v = xs[min(g, nin - 1) * nch];
-                raw[u] = g < nin ? v : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = eb + u * FIR_NT + tid;
-                if (e < span) X[p * PSQ + q] = raw[u];
-                q += dq; p += dp;
-                if (p >= D) { p -= D; ++q; }
-            }
-        }
-    }
+    fir_stage<FIR_NT>(X, x, nch, nin, e0, span, D, PSQ, tid);
     __syncthreads();
     // (I, Q) of an output as one 2-vector: one v_pk_fma_f32 per tap and output with the wave-uniform tap broadcast from its
     // scalar register.  Measured equal to the two v_fmac_f32 with a scalar operand it replaces (0.187 ms both: a packed fp32
@@ -461,10 +485,107 @@ __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ 
     }
 }
 
-// phase-major tap table: hp[p][3 + a] = taps[a*D + p], zeros elsewhere
+// The eight-output form (see FIR8_* above).  Same staging, same table (7 zeros in front), same arithmetic per output except that
+// the phases are summed as (0..D0-1) + (D0..D-1) instead of one after the other.  The step count AND the count of live steps of
+// the last group are compile-time here, i.e. the taps per phase A = 4*SHT + LASTN - 11 are: the FMAs that would meet the table's
+// zeros behind the taps (28 of 304 per phase at K = 8) are not emitted, and the phases that hold one tap less (p >= nfull: ntaps
+// is rarely a multiple of D) run a body of their own with A-1 taps.
+template <int SHT, int LASTN>
+__global__ __launch_bounds__(FIR8_NT) void k_fir_poly8(const short2* __restrict__ x, int nch, long long nin, const float* __restrict__ hp,
+                                                       int D, int PSQ, int HROW, int nfull, long long nout,
+                                                       short2* __restrict__ y16, float2* __restrict__ yf) {
+    extern __shared__ uint4 X4[];
+    unsigned* X = reinterpret_cast<unsigned*>(X4);
+    constexpr int K = FIR8_K, A = 4 * SHT + LASTN - (K + 3);
+    static_assert(A >= 2, "at least two taps per phase");
+    const int tid = threadIdx.x, t = tid & (FIR8_T - 1);
+    const int half = __builtin_amdgcn_readfirstlane(tid / FIR8_T);  // wave-uniform: the tap loads below stay scalar
+    const long long m0 = (long long)blockIdx.x * FIR8_OUT;
+    const long long e0 = m0 * D;
+    const int span = (FIR8_OUT + 4 * SHT) * D;                      // a multiple of 4
+    fir_stage<FIR8_NT>(X, x, nch, nin, e0, span, D, PSQ, tid);
+    __syncthreads();
+    typedef float pk2 __attribute__((ext_vector_type(2)));
+    pk2 acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = pk2{0.f, 0.f};
+    auto cvt = [](unsigned w) { return pk2{(float)(short)(w & 0xffffu), (float)(short)(w >> 16)}; };
+    auto phase = [&](auto at, int p) {
+        constexpr int AT = decltype(at)::value;                     // taps of this phase
+        const uint4* Xp = X4 + ((p * PSQ) >> 2) + 2 * t;            // lane t: x_p[8t + 4sh .. +3]
+        const float* h = hp + p * HROW + (K - 1);
+        float tp[AT];
+#pragma unroll
+        for (int j = 0; j < AT; ++j) tp[j] = h[j];                  // wave-uniform: scalar loads, once per phase
+#pragma unroll
+        for (int sh = 0; sh < SHT; ++sh) {
+            if (4 * sh > AT + K - 2) break;
+            const uint4 w = Xp[sh];
+            const unsigned wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int s = 4 * sh + sl;                          // step s feeds output k with tap a = s-k
+                if (s > AT + K - 2) break;
+                const pk2 v = cvt(wv[sl]);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (s - k < 0 || s - k > AT - 1) continue;
+                    const float tv = tp[s - k];
+                    acc[k] = __builtin_elementwise_fma(v, pk2{tv, tv}, acc[k]);
+                }
+            }
+        }
+    };
+    const int D0 = (D + 1) >> 1;
+    const int p_lo = half ? D0 : 0, p_hi = half ? D : D0;
+    for (int p = p_lo; p < p_hi; ++p) {
+        if (p < nfull) phase(std::integral_constant<int, A>{}, p);
+        else phase(std::integral_constant<int, A - 1>{}, p);
+    }
+    __syncthreads();                                                // every read of the staged span is done: its first 8 KB carry half 1's sums
+    float4* S = reinterpret_cast<float4*>(X4);
+    if (half) {
+#pragma unroll
+        for (int k = 0; k < K; k += 2) S[(k >> 1) * FIR8_T + t] = make_float4(acc[k].x, acc[k].y, acc[k + 1].x, acc[k + 1].y);
+    }
+    __syncthreads();
+    if (half) return;
+#pragma unroll
+    for (int k = 0; k < K; k += 2) {
+        const float4 o = S[(k >> 1) * FIR8_T + t];
+        acc[k] += pk2{o.x, o.y};
+        acc[k + 1] += pk2{o.z, o.w};
+    }
+    const long long m = m0 + (long long)K * t;
+    auto pack = [](pk2 a) {
+        const float r = fminf(fmaxf(rintf(a.x), -32768.f), 32767.f), q = fminf(fmaxf(rintf(a.y), -32768.f), 32767.f);
+        return ((unsigned)(unsigned short)(short)r) | ((unsigned)(unsigned short)(short)q << 16);
+    };
+    if (m + K <= nout) {
+        if (yf) {
+            float4* o = reinterpret_cast<float4*>(yf + m);
+#pragma unroll
+            for (int k = 0; k < K; k += 2) o[k >> 1] = make_float4(acc[k].x, acc[k].y, acc[k + 1].x, acc[k + 1].y);
+        }
+        if (y16) {
+            uint4* o = reinterpret_cast<uint4*>(y16 + m);
+            o[0] = make_uint4(pack(acc[0]), pack(acc[1]), pack(acc[2]), pack(acc[3]));
+            o[1] = make_uint4(pack(acc[4]), pack(acc[5]), pack(acc[6]), pack(acc[7]));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (m + k >= nout) break;
+            if (yf) yf[m + k] = make_float2(acc[k].x, acc[k].y);
+            if (y16) { const unsigned w = pack(acc[k]); y16[m + k] = make_short2((short)(w & 0xffffu), (short)(w >> 16)); }
+        }
+    }
+}
+
+// phase-major tap table: hp[p][K-1 + a] = taps[a*D + p], zeros elsewhere
 std::vector<float> fir_phase_table(const float* taps, int ntaps, int dec, const FirGeom& g) {
     std::vector<float> hp((size_t)dec * g.HROW, 0.f);
-    for (int j = 0; j < ntaps; ++j) hp[(size_t)(j % dec) * g.HROW + 3 + j / dec] = taps[j];
+    for (int j = 0; j < ntaps; ++j) hp[(size_t)(j % dec) * g.HROW + (g.K - 1) + j / dec] = taps[j];
     return hp;
 }
 int launch_fir(hipStream_t st, const short2* dx, int nch, long long nin, const float* hp_dev, int ntaps, int dec, long long nout,
@@ -479,6 +600,29 @@ int launch_fir(hipStream_t st, const short2* dx, int nch, long long nin, const f
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return TWX_E_HIP;
         attr_set = true;
+    }
+    if (g.K == FIR8_K) {
+        const unsigned grid8 = (unsigned)((nout + FIR8_OUT - 1) / FIR8_OUT);
+        const size_t lds8 = std::max<size_t>(g.lds, (size_t)FIR8_OUT * 8);
+        // phases that hold all A taps: ntaps = (A-1)*D + nfull; a geometry padded up to the smallest instantiation has no short phases
+        const int a_t = 4 * g.SH + (g.SH == 4 ? 4 : g.LASTN) - (FIR8_K + 3);      // taps per phase of the instantiation chosen below
+        const int nfull = a_t == g.A ? ntaps - (g.A - 1) * dec : dec;
+        hipError_t attr = hipSuccess;
+#define FIR8_GO(SHT_, LN_) do { static bool set = false; auto* fn = &k_fir_poly8<SHT_, LN_>; \
+            if (!set) { attr = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = attr == hipSuccess; } \
+            if (set) hipLaunchKernelGGL(fn, dim3(grid8), dim3(FIR8_NT), lds8, st, dx, nch, nin, hp_dev, dec, g.PSQ, g.HROW, nfull, nout, dy16, dyf); } while (0)
+#define FIR8_LN(SHT_) switch (g.LASTN) { case 1: FIR8_GO(SHT_, 1); break; case 2: FIR8_GO(SHT_, 2); break; case 3: FIR8_GO(SHT_, 3); break; default: FIR8_GO(SHT_, 4); break; }
+        switch (g.SH) {
+            case 4: FIR8_GO(4, 4); break;                            // A <= 9 (padded up): one instantiation
+            case 5: FIR8_LN(5); break;   case 6: FIR8_LN(6); break;   case 7: FIR8_LN(7); break;   case 8: FIR8_LN(8); break;
+            case 9: FIR8_LN(9); break;   case 10: FIR8_LN(10); break; case 11: FIR8_LN(11); break; case 12: FIR8_LN(12); break;
+            case 13: FIR8_LN(13); break; case 14: FIR8_LN(14); break; case 15: FIR8_LN(15); break; case 16: FIR8_LN(16); break;
+            default: return TWX_E_STATE;
+        }
+#undef FIR8_LN
+#undef FIR8_GO
+        if (attr != hipSuccess) return TWX_E_HIP;
+        return hipGetLastError() == hipSuccess ? TWX_OK : TWX_E_HIP;
     }
     const unsigned grid = (unsigned)((nout + FIR_OUT - 1) / FIR_OUT);
 #define FIR_GO(SHT_) hipLaunchKernelGGL((k_fir_poly<SHT_>), dim3(grid), dim3(FIR_NT), g.lds, st, dx, nch, nin, hp_dev, dec, g.SH, g.PSQ, g.HROW, g.LASTN, nout, dy16, dyf)

@@ -455,6 +455,12 @@ def test_sliding_dot_short_code():
     (8, 3, 4, 1, 0, 0),               # a period of one group
     (40000, 5, 8, 2, 1, 0),           # two channels: the general form
     (9004, 3, 8, 1, 0, 0),            # period not a multiple of 8: the general form
+    # wide windows: eight samples per lane where the period is a multiple of 8 and the capture has one channel (the shapes above
+    # with nobs % 8 == 0 and nlag > 8 take it too), four otherwise
+    (6152, 2, 31, 1, 0, 1),           # three passes of 2048 and one group
+    (40008, 3, 16, 1, 0, 7),
+    (16, 2, 28, 1, 0, 0),             # a period of two groups, shorter than the lag window
+    (20004, 5, 28, 1, 0, 0),          # not a multiple of 8: four samples per lane
 ])
 def test_sliding_dot_shapes(nobs, ncodes, nlag, nch, ch, pt):
     """k_sliding_dot over its lag-count instantiations (4, 8, 16, 28, 31), chunk / piece / pass boundaries, odd periods (the wrap
@@ -504,9 +510,13 @@ def test_fir_decimating_front_end():
     (330, 5, 1, 0),       # 66 taps per phase: the generic (not unrolled) kernel
     (421, 14, 2, 1),      # second channel of a two-channel capture: the 4-byte staging path
     (57, 7, 2, 0),
+    (171, 3, 1, 0),       # 57 taps per phase: the longest the eight-output form takes (16 step groups), odd phase count (2 + 1)
+    (232, 4, 1, 0),       # 58 taps per phase: back to the four-output form
+    (31, 1, 1, 0),        # no decimation: one phase, four-output form
 ])
 def test_fir_decimator_shapes(ntaps, dec, nch, ch):
-    """Every step-group count of k_fir_poly (unrolled 4..16, the generic loop), every count of live steps in the last group, both
+    """Both forms of the kernel (k_fir_poly8: eight outputs per thread, phases split between the halves of a workgroup; k_fir_poly:
+    four outputs), every step-group count (unrolled 4..16, the generic loop), every count of live steps in the last group, both
     staging paths (16-byte loads of one aligned channel, 4-byte loads of a channel of two) and a ragged last workgroup, against
     the fp64 direct sum (orc.fir_decimate, the oracle's definition; unpinned by nature: the reference has no such filter)."""
     from amaranth_twstft_amd import frontend
@@ -1021,7 +1031,7 @@ def test_all_channels_from_one_copy(tmp_path):
     assert len(both[0]) == len(both[1]) == 9
 
 
-@pytest.mark.parametrize("nobs,ncodes,nlag,pt", [(400000, 24, 28, 5), (40000, 9, 8, 3), (40000, 9, 14, 0), (9004, 3, 8, 1)])
+@pytest.mark.parametrize("nobs,ncodes,nlag,pt", [(400000, 24, 28, 5), (40000, 9, 8, 3), (40000, 9, 14, 0), (9004, 3, 8, 1), (40004, 5, 14, 2)])
 def test_sliding_dot_on_complex_float_samples(nobs, ncodes, nlag, pt):
     """twx_sliding_dot_cdev: the same correlator on complex-float samples resident on the device (the x2-interpolated stream the
     DLL/PLL receiver tracks on, rxcomplex.cpp:477,602), both kernel forms, against the definition in fp64."""
