@@ -2,7 +2,7 @@
 
 * ``-fsanitize=address,undefined``: the device FFT templates under the thread-loop emulation (fft_emul, rowd_emul), the tracked
   control flow (twx_tracked_core.h, driven by the oracle through the same test functions as tests/test_tracked_host.py, in a
-  child interpreter with libasan preloaded), both MEX gateways on their error paths (no GPU here: mexFunction must fail with
+  child interpreter with libasan preloaded), the tracking epoch's host arithmetic (twx_track_core.h, fuzzed), both MEX gateways on their error paths (no GPU here: mexFunction must fail with
   a MEX error, not with a sanitizer report).
 * ``-fsanitize=thread``: the library's host threads (twx_workers.h: the worker pool of twx_multi, the piece-wise chunk reader and
   the slot rotation of the ingest pipeline).
@@ -32,6 +32,17 @@ def test_fft_templates_under_asan_ubsan(tmp_path, src):
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=ENV, timeout=900)
     _no_report(r)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_tracking_epoch_arithmetic_under_asan_ubsan(tmp_path):
+    """csrc/twx_track_core.h (twx_track_update[_mai]: peak pick, high-resolution correlator, order statistics, phase unwrap, the two
+    weighted fits, the interference-cancellation records) on 20 000 random correlation matrices incl. edge peaks, flat tops, zeros,
+    NaN / infinity entries: no report, invariants hold (tests/cpu/track_fuzz.cpp)."""
+    exe = tmp_path / "track_fuzz"
+    subprocess.run(["g++", "-O1", "-std=c++17", *SAN, "-I" + CSRC, "-o", str(exe), os.path.join(ROOT, "tests", "cpu", "track_fuzz.cpp")], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=ENV, timeout=900)
+    _no_report(r)
+    assert r.returncode == 0 and "track ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_host_threads_under_tsan(tmp_path):
