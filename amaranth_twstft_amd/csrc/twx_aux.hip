@@ -51,7 +51,7 @@ __device__ __forceinline__ void sd_opaque(float2& v) { asm volatile("" : "+v"(v.
 template <int NLAG, typename XT, int T = SD_T, int CH = SD_CH, int WPC = 2>
 __global__ __launch_bounds__(SD_NT, WPC) void k_sliding_dot(const XT* __restrict__ x, int nch, long long pt, long long nobs, int nlag, int chunk_len,
                                                        const float* __restrict__ w, double ff, double phi, float scale, float rot_c, float rot_s,
-                                                       SdRot rot, double* __restrict__ partial /*[ncodes][chunks][2*nlag+1][2]*/) {
+                                                       SdRot rot, double* __restrict__ partial /*[ncodes][chunks][2*nlag+1][2]*/, int ch) {
     constexpr int NL = 2 * NLAG + 1;
     constexpr int NQ = (NL + T - 1 + 3) / 4;                    // 16-byte words a lane reads per pass
     constexpr int NE4 = CH / 4 + NQ;                               // 16-byte words of a full chunk's segment
@@ -107,11 +107,29 @@ __global__ __launch_bounds__(SD_NT, WPC) void k_sliding_dot(const XT* __restrict
             // 16-byte loads at the samples' own alignment (4 or 8 bytes: pt is any sample)
             typedef unsigned uvec4 __attribute__((ext_vector_type(4), aligned(4)));
             constexpr int NV = (int)(T * sizeof(XT) / 16);
-            const uvec4* src = reinterpret_cast<const uvec4*>(x + pt + i0);
-            unsigned raw[NV * 4];
+            if (nch == 1) {
+                const uvec4* src = reinterpret_cast<const uvec4*>(x + pt + i0);
+                unsigned raw[NV * 4];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) { const uvec4 q = src[v]; raw[4 * v] = q.x; raw[4 * v + 1] = q.y; raw[4 * v + 2] = q.z; raw[4 * v + 3] = q.w; }
-            __builtin_memcpy(nx, raw, sizeof raw);
+                for (int v = 0; v < NV; ++v) { const uvec4 q = src[v]; raw[4 * v] = q.x; raw[4 * v + 1] = q.y; raw[4 * v + 2] = q.z; raw[4 * v + 3] = q.w; }
+                __builtin_memcpy(nx, raw, sizeof raw);
+            } else {
+                // a channel of a two-channel capture ([a0 b0 a1 b1 ...], the reference's file format): the eight frames of the group
+                // as 16-byte loads from the FRAME base (x points at this channel's sample of frame 0: x - ch is the frame), the
+                // channel's words picked out — twice the bytes, which this kernel has to spare, and whole sectors either way
+                constexpr int WPS = (int)(sizeof(XT) / 4);                 // 32-bit words per sample
+                const uvec4* src = reinterpret_cast<const uvec4*>(x - ch + (pt + i0) * 2);
+                unsigned raw[NV * 8];
+#pragma unroll
+                for (int v = 0; v < 2 * NV; ++v) { const uvec4 q = src[v]; raw[4 * v] = q.x; raw[4 * v + 1] = q.y; raw[4 * v + 2] = q.z; raw[4 * v + 3] = q.w; }
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    unsigned wv[WPS];
+#pragma unroll
+                    for (int e = 0; e < WPS; ++e) wv[e] = ch ? raw[(2 * j + 1) * WPS + e] : raw[2 * j * WPS + e];
+                    __builtin_memcpy(&nx[j], wv, sizeof(XT));
+                }
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < T; ++j) nx[j] = x[(pt + min(i0 + j, ilast)) * nch];
@@ -233,7 +251,7 @@ __global__ void k_sliding_reduce(const double* __restrict__ partial, int nchunks
 // the streaming form for narrow lag windows (see the kernel): whole groups of eight samples, one channel
 bool sliding_narrow(long long nobs, int nlag, int nch) {
     static const bool off = getenv("TWX_SLIDING_NARROW") && atoi(getenv("TWX_SLIDING_NARROW")) == 0;      // A/B (profiles/r04_sliding_scan.txt)
-    return !off && nlag <= 8 && nch == 1 && nobs % 8 == 0;
+    return !off && nlag <= 8 && (nch == 1 || nch == 2) && nobs % 8 == 0;
 }
 int sliding_chunk(long long nobs, int ncodes, bool narrow, bool wide8 = false) {
     static const int ncu = [] {                                    // one process drives one GPU (or GPUs of one kind)
@@ -252,12 +270,12 @@ int sliding_chunk(long long nobs, int ncodes, bool narrow, bool wide8 = false) {
 }
 template <typename XT>
 int launch_sliding(hipStream_t st, const XT* dx, int nch, long long pt, long long nobs, int ncodes, int nlag, const float* dw,
-                   double ff, double phi, double scale, double* dpart, double* dout) {
+                   double ff, double phi, double scale, double* dpart, double* dout, int ch = 0) {       // dx: the channel's sample of frame 0; ch: its place in the frame
     const bool narrow = sliding_narrow(nobs, nlag, nch);
     // wide windows, eight samples per lane (whole groups of eight, one channel): the per-pass overhead (mixing, addresses, the
     // LDS words) is shared by twice the FMAs
     static const bool wide8_off = getenv("TWX_SLIDING_WIDE8") && atoi(getenv("TWX_SLIDING_WIDE8")) == 0;
-    const bool wide8 = !narrow && !wide8_off && nlag > 8 && nch == 1 && nobs % 8 == 0;
+    const bool wide8 = !narrow && !wide8_off && nlag > 8 && (nch == 1 || nch == 2) && nobs % 8 == 0;
     const int clen = sliding_chunk(nobs, ncodes, narrow, wide8);
     const int nchunks = (int)((nobs + clen - 1) / clen);
     const dim3 grid(nchunks, ncodes), block(SD_NT);
@@ -270,9 +288,9 @@ int launch_sliding(hipStream_t st, const XT* dx, int nch, long long pt, long lon
         a -= rint(a);
         rot.r[k] = make_float2((float)cos(two_pi * a), (float)(-sin(two_pi * a)));
     }
-#define SD_GO(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_, XT>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, rot, dpart)
-#define SD_GO8(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_, XT, 8, 8192, 4>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, rot, dpart)
-#define SD_GOW(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_, XT, 8, 16384, 2>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, rot, dpart)
+#define SD_GO(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_, XT>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, rot, dpart, ch)
+#define SD_GO8(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_, XT, 8, 8192, 4>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, rot, dpart, ch)
+#define SD_GOW(NL_) hipLaunchKernelGGL((k_sliding_dot<NL_, XT, 8, 16384, 2>), grid, block, 0, st, dx, nch, pt, nobs, nlag, clen, dw, ff, phi, (float)scale, rot_c, rot_s, rot, dpart, ch)
     if (narrow) { if (nlag <= 4) SD_GO8(4); else SD_GO8(8); }
     else if (wide8) { if (nlag <= 16) SD_GOW(16); else if (nlag <= 28) SD_GOW(28); else SD_GOW(31); }
     else if (nlag <= 4) SD_GO(4); else if (nlag <= 8) SD_GO(8); else if (nlag <= 16) SD_GO(16); else if (nlag <= 28) SD_GO(28); else SD_GO(31);
@@ -663,7 +681,7 @@ static int twx_sliding_dot_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n_
     double* dpart = static_cast<double*>(twx::ctx_scratch(ctx, 0, sliding_part_bytes(nobs, ncodes, nlag)));
     if (!dpart) return TWX_E_NOMEM;
     const int rc = launch_sliding(twx::ctx_stream(ctx), reinterpret_cast<const short2*>(iq_dev) + channel, n_channels, pt, nobs, ncodes, nlag,
-                                  replica_dev, ff, phi, scale, dpart, out_dev);
+                                  replica_dev, ff, phi, scale, dpart, out_dev, channel);
     return rc ? twx::ctx_fail(ctx, rc, "twx_sliding_dot_dev: launch failed") : TWX_OK;
 }
 
@@ -715,7 +733,7 @@ static int twx_sliding_dot_impl(const int16_t* iq, int64_t n_samples, int32_t n_
     if (hipMemcpy(dx.p, iq, (size_t)n_samples * n_channels * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(dw.p, replica, (size_t)nobs * 4, hipMemcpyHostToDevice) != hipSuccess) return TWX_E_HIP;
     if (int rc = launch_sliding(nullptr, static_cast<const short2*>(dx.p) + channel, n_channels, pt, nobs, ncodes, nlag, static_cast<const float*>(dw.p),
-                                ff, phi, scale, static_cast<double*>(dpart.p), static_cast<double*>(dout.p))) return rc;
+                                ff, phi, scale, static_cast<double*>(dpart.p), static_cast<double*>(dout.p), channel)) return rc;
     return hipMemcpy(out, dout.p, out_bytes, hipMemcpyDeviceToHost) == hipSuccess ? TWX_OK : TWX_E_HIP;
 }
 

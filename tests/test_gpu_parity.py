@@ -453,7 +453,7 @@ def test_sliding_dot_short_code():
     (40000, 30, 4, 1, 0, 1),          # 4-ms codes
     (8200, 2, 8, 1, 0, 5),            # a chunk one group longer than the 8192-sample LDS piece
     (8, 3, 4, 1, 0, 0),               # a period of one group
-    (40000, 5, 8, 2, 1, 0),           # two channels: the general form
+    (40000, 5, 8, 2, 1, 0),           # two channels
     (9004, 3, 8, 1, 0, 0),            # period not a multiple of 8: the general form
     # wide windows: eight samples per lane where the period is a multiple of 8 and the capture has one channel (the shapes above
     # with nobs % 8 == 0 and nlag > 8 take it too), four otherwise
@@ -461,6 +461,11 @@ def test_sliding_dot_short_code():
     (40008, 3, 16, 1, 0, 7),
     (16, 2, 28, 1, 0, 0),             # a period of two groups, shorter than the lag window
     (20004, 5, 28, 1, 0, 0),          # not a multiple of 8: four samples per lane
+    # a channel of a two-channel capture (the reference's file format) in the eight-samples-per-lane forms: whole frames loaded,
+    # the channel's words picked out ((40000, 5, 8, 2, 1) and (17000, 4, 16, 2, 1) above take them too)
+    (40000, 3, 4, 2, 0, 3),
+    (16392, 2, 28, 2, 0, 0),          # one group more than the LDS piece
+    (16392, 2, 28, 2, 1, 1),
 ])
 def test_sliding_dot_shapes(nobs, ncodes, nlag, nch, ch, pt):
     """k_sliding_dot over its lag-count instantiations (4, 8, 16, 28, 31), chunk / piece / pass boundaries, odd periods (the wrap
