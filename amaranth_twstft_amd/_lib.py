@@ -215,6 +215,8 @@ SYMBOLS = {
     "twx_rx_second_dev": (C.c_int, [_VP, _VP, C.POINTER(twx_rx_report)]),
     "twx_rx_file": (C.c_int, [_VP, C.c_char_p, C.c_int64, C.POINTER(twx_rx_report), C.c_int64, C.POINTER(C.c_int64)]),
     "twx_rx_stream_dev": (_VP, [_VP, C.c_int32]),
+    "twx_rx_powers": (C.c_int, [_VP, C.POINTER(C.c_double)]),
+    "twx_rx_console_line": (C.c_int, [_VP, C.c_int32, C.POINTER(twx_rx_report), C.c_char_p, C.c_int32]),
     "twx_debug_stamps": (C.c_int, [_VP, _VP, C.c_longlong]),
     "twx_profile_reset": (C.c_int, [_VP]),
     "twx_profile_get": (C.c_int, [_VP, C.POINTER(twx_prof_entry), C.c_int32, C.POINTER(C.c_int32)]),

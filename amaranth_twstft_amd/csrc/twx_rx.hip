@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <new>
@@ -167,6 +168,7 @@ struct twx_rx {
     std::vector<Channel> ch;
     std::mt19937_64 rng;
     bool need[2] = {false, false};
+    double last_pwr[2] = {0, 0};
 
     int fail(int code, const std::string& m) { err = m; return code; }
     int lib(twx_ctx* c, int rc) { if (rc) { const char* m = twx_last_error(c); err = m && *m ? m : twx_strerror(rc); } return rc; }
@@ -360,6 +362,7 @@ struct twx_rx {
             else if (int rc = lib(interp, twx_xcorr_map_dev(interp, src, 2, p, 0.0, smp[p]))) return rc;  // short2double :477
             if (int rc = power(smp[p], &pwr[p])) return rc;                                                // synchronises the stream: smp[p] is complete
         }
+        last_pwr[0] = pwr[0]; last_pwr[1] = pwr[1];
         for (size_t i = 0; i < ch.size(); ++i) {
             Channel& c = ch[i];
             twx_rx_report& r = rep[i];
@@ -514,6 +517,30 @@ int twx_rx_channel(const twx_rx* rx, int32_t i, twx_rx_channel_info* info) {
     info->duration = c.duration; info->range = c.range; info->step = c.step; info->snr_min = c.snr_min; info->psbb = c.psbb;
     snprintf(info->dat_name, sizeof info->dat_name, "%s", c.dat_name.c_str());
     return TWX_OK;
+}
+int twx_rx_powers(const twx_rx* rx, double pwr_v2[2]) {
+    if (!rx || !pwr_v2) return TWX_E_ARG;
+    pwr_v2[0] = rx->last_pwr[0]; pwr_v2[1] = rx->last_pwr[1];
+    return TWX_OK;
+}
+int twx_rx_console_line(const twx_rx* rx, int32_t i, const twx_rx_report* r, char* buf, int32_t cap) {
+    if (!rx || !r || !buf || cap < 2 || i < 0 || i >= (int)rx->ch.size()) return TWX_E_ARG;
+    const Channel& c = rx->ch[(size_t)i];
+    const char* chs = c.is_chA ? "A" : "B";
+    const double mcps = (double)c.rc * 1.0e-6;
+    int n;
+    if (r->status == TWX_RX_NO_SIGNAL || r->status == TWX_RX_ACQ_FAILED || r->status == TWX_RX_LOCK_LOST) {                 // is_trk == 0 (:808-817)
+        if (r->px <= r->pk) n = snprintf(buf, (size_t)cap, "%s: #%02d %4.1lf Mcps SNR       Low      , no signal\n", chs, c.shown(), mcps);
+        else n = snprintf(buf, (size_t)cap, "%s: %lf %lf %s: #%02d %4.1lf Mcps SNR %6.2lf < %6.2lf, no signal\n", chs, r->pk, r->px, chs, c.shown(), mcps,
+                          10.0 * log10(r->pk / (r->px - r->pk)), 10.0 * log10(c.snr_min));
+    } else if (r->status == TWX_RX_ACQUIRED) {                                                                             // is_first == 1 (:820-824)
+        n = snprintf(buf, (size_t)cap, "%s: %lf %lf %s: #%02d %4.1lf Mcps SNR %6.2lf > %6.2lf, analyzing\n", chs, r->pk, r->px, chs, c.shown(), mcps,
+                     10.0 * log10(r->pk / (r->px - r->pk)), 10.0 * log10(c.snr_min));
+    } else {                                                                                                               // :826-830 (ib = 0)
+        n = snprintf(buf, (size_t)cap, "%s: #%02d %4.1lf Mcps %12.3lf Hz %13.3lf (%6.3lf) ns SNR %6.2lf dB\n", chs, c.shown(), mcps, r->fc + r->df, r->gd,
+                     r->sdgd / sqrt((double)r->cnt), v2todBm(r->pk) - v2todBm(r->px - r->pk));
+    }
+    return n < 0 ? TWX_E_STATE : std::min(n, cap - 1);
 }
 const void* twx_rx_stream_dev(const twx_rx* rx, int32_t p) { return !rx ? nullptr : (p == 0 || p == 1) ? (const void*)rx->smp[p] : p == 2 ? (const void*)rx->mai_free : nullptr; }
 

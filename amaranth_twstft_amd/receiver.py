@@ -127,6 +127,20 @@ class Receiver:
         self._check(self._lib.twx_rx_file(self._h, os.fsencode(path), max_seconds, rep, nsec, C.byref(done)))
         return [[rep[s * self.n_rows + i] for i in range(self.n_rows)] for s in range(done.value)]
 
+    def powers(self):
+        """Received power of physical channels A and B in the last second (V^2; 0 for a channel no row listens to)."""
+        p = (C.c_double * 2)()
+        self._check(self._lib.twx_rx_powers(self._h, p))
+        return p[0], p[1]
+
+    def console_line(self, i: int, report) -> str:
+        """The line the program prints for channel ``i`` after a second (rxcomplex.cpp:806-831)."""
+        buf = C.create_string_buffer(512)
+        n = self._lib.twx_rx_console_line(self._h, i, C.byref(report), buf, len(buf))
+        if n < 0:
+            raise L.TwxError(n, "twx_rx_console_line")
+        return buf.value.decode()
+
     def stream_dev(self, physical_channel: int) -> int:
         return int(self._lib.twx_rx_stream_dev(self._h, physical_channel) or 0)
 
@@ -146,12 +160,7 @@ def main(argv=None):
     with Receiver(rows, code_dir=a.codes, out_dir=a.out, seed=a.seed, real=a.real) as rx:
         for s, reps in enumerate(rx.run_file(a.data, a.seconds)):
             for i, r in enumerate(reps):
-                info = rx.channel(i)
-                tag = "%s: #%02d" % ("A" if info.is_chA else "B", info.pn + (50 if info.is_sic else 0))
-                if r.status == L.TWX_RX_TRACKED:
-                    print("%s %12.3f Hz %13.3f ns SNR %6.2f dB" % (tag, r.fc + r.df, r.gd, 10 * np.log10(r.pk / (r.px - r.pk)) if r.px > r.pk > 0 else 0.0))
-                else:
-                    print("%s %s" % (tag, STATUS[r.status]))
+                sys.stdout.write(rx.console_line(i, r))                  # the program's own lines (:806-831)
 
 
 if __name__ == "__main__":

@@ -407,6 +407,12 @@ int twx_rx_second_dev(twx_rx* rx, const void* iq_dev, twx_rx_report* reports);
 /* The program's main loop over a capture file (`./rxcomplex data.bin sdr.param`): whole seconds until the file ends or
  * max_seconds; reports (may be NULL) receives n_rows records per second, capacity report_seconds seconds. */
 int twx_rx_file(twx_rx* rx, const char* path, int64_t max_seconds, twx_rx_report* reports, int64_t report_seconds, int64_t* n_seconds);
+/* What the program prints on stdout after a second (:804-831): twx_rx_powers gives the two received powers of the "PWR A / PWR B"
+ * line in V^2 (a physical channel no row listens to is not converted: 0), twx_rx_console_line the line of channel i — "no signal"
+ * (SNR Low, or SNR x < y), "analyzing", or carrier / code phase / SNR — from the report of that second, newline included;
+ * returns the length or < 0.  apps/rxcomplex_hip.cpp is the program built on these: `./rxcomplex_hip [data.bin [sdr.param]]`. */
+int twx_rx_powers(const twx_rx* rx, double pwr_v2[2]);
+int twx_rx_console_line(const twx_rx* rx, int32_t i, const twx_rx_report* report, char* buf, int32_t cap);
 /* Device pointer to the interpolated stream of physical channel 0 (A) / 1 (B) of the last second (fs_in*ninterp complex floats;
  * ninterp = 1: the real samples with a zero imaginary part); physical_channel 2: the interference-free stream of the LAST 'S' row
  * processed (NULL when there is none). */

@@ -251,3 +251,42 @@ def test_real_sample_program_with_interference_cancellation(tmp_path):
     assert [l.split(",")[:2] for l in log[3:]] == [l.split(",")[:2] for l in wl]
     assert (outdir / "chA.pn151.2500kcps.dat").read_text() == got[3][1].dat_row.decode()
     assert len((outdir / "chA.pn100.2500kcps.dat").read_text().splitlines()) == 2 and not (outdir / "chA.pn101.2500kcps.dat").exists()
+
+
+def test_command_line_programs_equal_the_library_calls(tmp_path):
+    """apps/bin/rxcomplex_hip and rx_hip (`./rxcomplex data.bin sdr.param`, `./rx …`): child processes on a capture file; the .dat
+    rows and log files they append are byte-identical to what the same seed gives through the library calls, and stdout carries the
+    programs' lines (rxcomplex.cpp:804-831): the PWR line and one line per parameter row and second."""
+    import re
+    import subprocess
+    seconds = 3
+    chips, cap = _capture(seconds)
+    chips["A"].tofile(tmp_path / "0.bin")
+    chips["B"].tofile(tmp_path / "1.bin")
+    cap.tofile(tmp_path / "data.bin")
+    (tmp_path / "sdr.param").write_text("A N 100 0001186 2500 1250 2000 256 -18\nB N 101 -000186 2500 1250 2000 256 -18\nA N 101 0000186 2500 1250 1000 256 -18\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for prog, real, logname in (("rxcomplex_hip", False, "rxcomplex.log"), ("rx_hip", True, "rxreal.log")):
+        out_cli, out_lib = tmp_path / (prog + "_cli"), tmp_path / (prog + "_lib")
+        out_cli.mkdir(); out_lib.mkdir()
+        env = dict(os.environ, TWX_RX_SEED="11", TWX_RX_CODES=str(tmp_path), TWX_RX_OUT=str(out_cli))
+        r = subprocess.run([os.path.join(root, "apps", "bin", prog)], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        rows = receiver.parse_param(str(tmp_path / "sdr.param"))
+        with receiver.Receiver(rows, code_dir=str(tmp_path), out_dir=str(out_lib), seed=11, real=real) as rx:
+            reps = rx.run_file(str(tmp_path / "data.bin"))
+            last_lines = [rx.console_line(i, reps[-1][i]) for i in range(3)]
+        assert len(reps) == seconds and [x.status for x in reps[-1]][:2] == [L.TWX_RX_TRACKED, L.TWX_RX_TRACKED]
+        names = sorted(p.name for p in out_lib.iterdir())
+        assert names == sorted(p.name for p in out_cli.iterdir()) and logname in names and len(names) == 3
+        for n in names:
+            assert (out_cli / n).read_bytes() == (out_lib / n).read_bytes(), n
+        lines = r.stdout.splitlines()
+        assert lines[0] == "./data.bin" and sum(l.startswith("PWR A:") for l in lines) == seconds
+        body = [l for l in lines[1:] if l and not l.startswith("PWR A:")]
+        assert len(body) == 3 * seconds and body[-3:] == [l.rstrip("\n") for l in last_lines]
+        assert re.fullmatch(r"A: \d\.\d+ \d\.\d+ A: #100  2\.5 Mcps SNR +-?\d+\.\d\d > -18\.00, analyzing", body[0])
+        assert re.fullmatch(r"A: #100  2\.5 Mcps +1307\.\d{3} Hz +\d+\.\d{3} \( ?\d+\.\d{3}\) ns SNR +-?\d+\.\d\d dB", body[-3])
+        assert body[-1].endswith(", no signal") and "#101" in body[-1]
+        pw = [l for l in lines if l.startswith("PWR A:")][-1]
+        assert re.fullmatch(r"PWR A: +-?\d+\.\d\d dBm , PWR B: +-?\d+\.\d\d dBm", pw)

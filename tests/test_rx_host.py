@@ -62,3 +62,29 @@ def test_receiver_fails_loudly_without_a_gpu():
         pytest.skip("GPU present")
     with pytest.raises(L.TwxError, match="no HIP device|HIP"):
         receiver.Receiver([receiver.make_row("A", 100, 186.0, 2000.0, 256.0, -18.0, code=[0, 1] * 50000)])
+
+
+@pytest.mark.parametrize("prog", ["rxcomplex_hip", "rx_hip"])
+def test_receiver_programs_argument_and_error_paths(tmp_path, prog):
+    """apps/rxcomplex_hip.cpp, the command-line drop-ins for ./rxcomplex and ./rx: the usage text (rxcomplex.cpp:175-180), the
+    parameter-file and data-file errors (:213-217,254-255) with the programs' own words and exit code, and — here, without a GPU, or
+    with one but without the code file — a loud failure from the library, never a silent run."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "apps", "bin", prog)
+    assert os.path.exists(exe), "build with make -C amaranth_twstft_amd/csrc (target apps)"
+    run = lambda *a: subprocess.run([exe, *a], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    r = run("a", "b", "c")
+    assert r.returncode == 1 and r.stdout.splitlines()[0] == "usage:" and "out_path param_file" in r.stdout
+    r = run("nodata.bin", "noparam")
+    assert r.returncode == 1 and r.stdout.splitlines() == ["nodata.bin", "no such parameter file : noparam"]
+    (tmp_path / "sdr.param").write_text("A N 100 0001186 2500 1250 2000 256 -18\n")
+    r = run("nodata.bin")
+    assert r.returncode == 1 and r.stdout.splitlines() == ["nodata.bin", "Data filename error"]
+    (tmp_path / "data.bin").write_bytes(b"\0" * 1000)
+    r = run()                                                   # defaults ./data.bin and sdr.param (:185,208)
+    assert r.returncode == 1 and r.stdout.splitlines()[0] == "./data.bin"
+    assert "no HIP device" in r.stdout or "Code filename error" in r.stdout
+    (tmp_path / "sdr.param").write_text("# nothing usable\nA N 100 0001186 1000 1250 2000 256 -18\n")
+    r = run()
+    assert r.returncode == 1 and "no usable row" in r.stdout
