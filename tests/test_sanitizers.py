@@ -91,3 +91,26 @@ def test_mex_gateways_error_paths_under_asan_ubsan(tmp_path, harness, gateway, a
     r = subprocess.run([str(exe)] + [a.format(**fill) for a in args], capture_output=True, text=True, env=dict(ENV, ASAN_OPTIONS="detect_leaks=0"), timeout=600)
     _no_report(r)
     assert r.returncode == 3 and "twstft:create" in r.stderr and "no CPU fallback" in r.stderr, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("real", [False, True])
+def test_receiver_program_main_under_asan_ubsan(tmp_path, real):
+    """apps/rxcomplex_hip.cpp (main() of the receiver programs) instrumented, on its argument / file error paths and — without a
+    GPU — the library's refusal: exit code 1 and the program's message each time, no sanitizer report."""
+    import torch
+    libdir = os.path.join(ROOT, "amaranth_twstft_amd")
+    exe = tmp_path / "rx_main"
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", *SAN, *(["-DTWX_RX_REAL"] if real else []), "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "apps", "rxcomplex_hip.cpp"), "-L" + libdir, "-ltwstft_hip", "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
+    env = dict(ENV, ASAN_OPTIONS="detect_leaks=0")
+    run = lambda *a: subprocess.run([str(exe), *a], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=600)
+    (tmp_path / "sdr.param").write_text("# c\nA N 100 0001186 2500 1250 2000 256 -18\nB S 101 0001186 2500 1250 2000 256 -18\n" + "A N 100 1 2500 1250 2000 256 -18\n" * 130)
+    (tmp_path / "data.bin").write_bytes(b"\0" * 4096)
+    for args, want in ((("a", "b", "c"), "usage:"), (("x.bin", "nope"), "no such parameter file"), (("x.bin",), "Data filename error")):
+        r = run(*args)
+        _no_report(r)
+        assert r.returncode == 1 and want in r.stdout, r.stdout + r.stderr
+    if not torch.cuda.is_available():
+        r = run()                                               # 120 rows kept of 132 (nch_max), then twx_rx_create refuses: no device
+        _no_report(r)
+        assert r.returncode == 1 and "no HIP device" in r.stdout, r.stdout + r.stderr
