@@ -500,6 +500,7 @@ template <typename T> struct Ctx : CtxBase {
     cpx<double>* tw1d = nullptr;
     C* cspec = nullptr;
     C *cspec_perm = nullptr, *dtabs = nullptr, *ea_d = nullptr, *eb_d = nullptr;   // DIF/DIT row pass (k_rowd)
+    C *cspec_plain = nullptr, *cspec_perm_plain = nullptr;   // Hamming-window contexts: the UNWINDOWED code spectrum, for the wipe-off statistics
     C* wr_d = nullptr;            // exp(-2 pi i j/R), j < R: pruned last stage of k_rowd<BAND>
     C* vw_d = nullptr;            // [k1][2][R] exp(+2 pi i k1 a/N), exp(+2 pi i k1 R b/N): k_rowd<MID>'s folded output twiddle
     C* vc_d = nullptr;            // [k1][c] exp(+2 pi i k1 c M/N): stage C's per-row output twiddle of k_rowd<MID> (scalar loads)
@@ -671,6 +672,20 @@ template <typename T> struct Ctx : CtxBase {
     // conj(fft(code)) in [k1][k2] layout, computed in fp64 when the fp64 plans exist
     int make_code_spectrum() {
         if (int rc = dalloc(&cspec, (size_t)N)) return rc;
+        if (cfg.window == TWX_WIN_HAMMING) {
+            // The C++ twin, the only user of the window (processing/CPP/main.cpp:717-719), takes the peak from the correlation with
+            // the WINDOWED spectrum (:288-301) but wipes the code off yint = ifft(zero-padded FFT(y)) — no fcode in it (:319-332).
+            // The identity of DESIGN §SNR turns that into three samples of the correlation with the UNWINDOWED replica around the
+            // peak, so such a context keeps both spectra and runs the row pass a second time for the statistics (run_batch_in).
+            if (int rc = dalloc(&cspec_plain, (size_t)N)) return rc;
+            cfg.window = TWX_WIN_NONE;
+            const int rc = build_code_spectrum(cspec_plain);
+            cfg.window = TWX_WIN_HAMMING;
+            if (rc) return rc;
+        }
+        return build_code_spectrum(cspec);
+    }
+    int build_code_spectrum(C* cspec) {
         const ColOps* c64 = find_col(N1, 1, col->W); const RowOps* r64 = find_row(N2, 1);
         const bool use64 = !std::is_same<T, double>::value && c64 && r64 && c64->W == col->W;
         if (std::is_same<T, double>::value || !use64) return code_spectrum_T<T>(cspec, col, row, tw1, stab_f, ta, tb, tcw, scale_pow2 == 1.0 ? 0.0 : scale_pow2);
@@ -789,6 +804,11 @@ template <typename T> struct Ctx : CtxBase {
             const int Rr = row->R[row->S - 1], R0 = row->S == 3 ? row->R[0] : 1;
             TWX_LAUNCH((k_cspec_perm<T>), dim3(N1), dim3(256), stream, cspec, cspec_perm, N1, N2, R0, Rr);
             HIPCHK(hipGetLastError());
+            if (cspec_plain) {
+                if (int rc = dalloc(&cspec_perm_plain, (size_t)N)) return rc;
+                TWX_LAUNCH((k_cspec_perm<T>), dim3(N1), dim3(256), stream, cspec_plain, cspec_perm_plain, N1, N2, R0, Rr);
+                HIPCHK(hipGetLastError());
+            }
         }
         // batch buffers, one set per pipeline slot
         {
@@ -1056,6 +1076,18 @@ template <typename T> struct Ctx : CtxBase {
         if (!map_only) {
             ProfScope ps(this, PC_PEAK, nb);
             for (int it = 0, ne = reps(PC_PEAK); it < ne; ++it)
+            TWX_LAUNCH((k_peak<T>), dim3(nb), dim3(1024), stream, pa);
+            HIPCHK(hipGetLastError());
+        }
+        if (!map_only && cspec_plain && snr_valid) {
+            // Hamming-window context (make_code_spectrum): the row pass once more on the same column-pass output with the unwindowed
+            // spectrum, and the statistics from the twelve samples around the peak the first call found
+            ra.cspec = cspec_plain;
+            if (use_rowd) {
+                RowDArgs<T> rd{}; rd.r = ra; rd.dtabs = dtabs; rd.cspec_perm = cspec_perm_plain; rd.ea_d = ea_d; rd.eb_d = eb_d; rd.vc = vc_d; rd.vw = vw_d;
+                if (row->rowd(ROW_MID, &rd, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_rowd(mid, unwindowed) launch failed");
+            } else if (row->run(ROW_MID, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(mid, unwindowed) launch failed");
+            pa.snr_only = 1;
             TWX_LAUNCH((k_peak<T>), dim3(nb), dim3(1024), stream, pa);
             HIPCHK(hipGetLastError());
         }

@@ -1278,10 +1278,13 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
         constexpr bool USGPR = TWX_MID_SGPR != 0;
         C ub = mk<T>(1, 0);
         C wa0 = mk<T>(1, 0);
-        if constexpr (!FOLD) { if (tid < M) {
-            const unsigned m = (unsigned)k1 * (unsigned)tid;
+        if constexpr (!FOLD) {
+            // in EVERY lane, the idle ones of the last wave with lane M-1's factor: they repeat that lane's store in stage C (below),
+            // and with a factor of their own they raced it with a different value — element M-1 of every row was wrong in the one
+            // instantiation that takes this path (R0 = 1 in fp64, e.g. N2 = 400: found by test_randomised_option_sweep)
+            const unsigned m = (unsigned)k1 * (unsigned)min(tid, M - 1);
             ub = cconj(cmul(a.ta[m >> a.tshift], a.tb[m & mask]));
-        } }
+        }
         const C* vcrow = ad.vc + (long long)k1 * R0;                              // wave-uniform address: scalar loads
         if (act && k1 == 0 && u == 0) a.dc[b] = v[0];
         // in every lane (the idle ones of the last wave multiply leftovers): a conditional definition would keep the previous
@@ -2072,6 +2075,8 @@ template <typename T> struct PeakArgs {
     int snr_valid;               // 0: replica is not a +-1 code, the wipe-off statistics are undefined
     twx_result* res;             // record of window b at res[b * res_stride]
     int res_stride;              // 1, or the channel count when all channels of a window are interleaved in the output
+    int snr_only;                // 1: second call of a Hamming-window context — Bz now holds the correlation with the UNWINDOWED
+                                 // replica; the peak is the one already in the record, only the wipe-off statistics are written
 };
 
 template <typename T>
@@ -2086,9 +2091,15 @@ __global__ __launch_bounds__(1024) void k_peak(PeakArgs<T> a) {
         best.take(p.val, p.idx);
     }
     best = block_best<T, 1024>(best, scratch);
-    if (tid == 0) s_idx = best.idx;
-    __syncthreads();
     const long long M = a.n * a.nphase;
+    if (tid == 0) {
+        s_idx = best.idx;
+        if (a.snr_only) {
+            const long long i0 = a.res[(long long)b * a.res_stride].indice0;
+            s_idx = (unsigned int)(a.convention == TWX_CONV_CLAUDIO ? (M - i0) % M : i0);
+        }
+    }
+    __syncthreads();
     const long long mstar = s_idx;
     const int lane = tid & 63, wv = tid >> 6;
     for (int pt = wv; pt < TWX_PEAK_NP; pt += 16) {
@@ -2157,6 +2168,11 @@ __global__ __launch_bounds__(1024) void k_peak(PeakArgs<T> a) {
         r.puissancecode = ok ? mr * mr + mi * mi : nan("");
         r.puissancenoise = ok ? var : nan("");
         r.status = 0; r.reserved = 0;
+        if (a.snr_only) {                                                  // everything but the wipe-off statistics stays as the first call left it
+            twx_result o = a.res[(long long)b * a.res_stride];
+            o.SNRr = r.SNRr; o.SNRi = r.SNRi; o.puissancecode = r.puissancecode; o.puissancenoise = r.puissancenoise;
+            r = o;
+        }
         a.res[(long long)b * a.res_stride] = r;
     }
 }

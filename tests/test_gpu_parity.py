@@ -306,6 +306,10 @@ def test_hamming_windowed_code_spectrum():
     z = orc.xcorr_interp(np.fft.fft(d), fh, 1)
     ind, corr, xval, _, _ = orc.peak_refine(z)
     assert g.indice == ind and abs(abs(g.xval) - abs(xval)) <= MAG_TOL * abs(xval) and abs(g.correction - corr) < 2e-4
+    # the wipe-off statistics: the C++ twin takes them from yint = ifft(zero-padded FFT(y)) — no window in it (main.cpp:319-332) —
+    # rotated to the peak of the WINDOWED map; orc.processing does the same (its SNR never sees fcode)
+    o = orc.processing(d, None, None, np.arange(n) / FS, fh, code, Nint=1, fs=FS, df=0.0)
+    _check(g, o)
 
 
 def test_claudio_convention():
@@ -1009,6 +1013,91 @@ def test_randomised_parity_sweep():
             else:
                 assert abs(abs(g.xval) - abs(o["xval"])) <= MAG_TOL * abs(o["xval"])
     assert not mism, mism
+
+
+def test_randomised_option_sweep():
+    """Seeded sweep over the OPTIONS of processing(): interpolation factor, variance convention, the wipe-off rotation, the
+    Hamming-windowed replica, fp32 / fp64, carrier searched over one of the three bands or supplied, one- and two-channel frames,
+    strong to noise-dominated windows — the combinations the single-option tests above do not meet — against the oracle with the
+    same settings: integer lag and carrier exact, the rest within the tolerances of _check.  TWX_SWEEP_OPTIONS raises the count."""
+    rng = np.random.default_rng(424242)
+    ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "16"))
+    codes = [(13, 27, 5000), (14, 57, 10000)]
+    seen = set()
+    for it in range(ncomb):
+        bitlen, taps, nchips = codes[int(rng.integers(0, len(codes)))]
+        chips = chips_for(bitlen, taps, nchips)
+        n = 2 * nchips
+        Nint = int(rng.choice([0, 1, 1, 2]))
+        ddof = int(rng.integers(0, 2))
+        snr_rot = int(rng.choice([-1, -1, -2, 0]))
+        window = str(rng.choice(["none", "none", "hamming"]))
+        precision = str(rng.choice(["f32", "f32", "f64"]))
+        nch = int(rng.integers(1, 3))
+        ch = int(rng.integers(0, nch))
+        mode = str(rng.choice(["band_numpy", "band_godual", "band_remote", "df"]))
+        seen.add((Nint, ddof, snr_rot, window, precision, nch, mode))
+        df_true = float(rng.uniform(-6000, 6000)) if mode != "band_remote" else float(rng.uniform(41000, 59000))     # the bands search 2*df
+        nwin = 3
+        chans = [synth.SynthParams(delay_q8=int(rng.integers(0, n)) * 256 + int(rng.integers(0, 256)), fstep=synth.fstep_for_df(df_true + 3.0 * c, FS),
+                                   phi0=int(rng.integers(0, 2 ** 32)), amp=int(rng.choice([0, 40, 300, 2000])),
+                                   noise_gain=synth.noise_gain_for_sigma(float(rng.choice([60.0, 500.0, 2500.0]))), seed=int(rng.integers(1, 10 ** 6)), stream=c)
+                 for c in range(nch)]
+        raw = synth.synth_capture(n * nwin, chips, 2, chans)
+        code = orc.make_code(chips, 2)
+        fcode = orc.make_fcode(code, "hamming" if window == "hamming" else "godual")
+        freq = orc.freq_axis(FS, n)
+        temps = np.arange(n) / FS
+        if mode == "band_numpy":
+            k, band = orc.band_numpy(freq), band_numpy(FS, n)
+        elif mode == "band_godual":
+            k, band = orc.band_godual(freq), band_godual(FS, n)
+        elif mode == "band_remote":
+            k, band = orc.band_godual(freq, 1, 0), band_godual(FS, n, remote=1, OP=0)
+        else:
+            k = band = None
+        dfs = [df_true + 0.37 * w for w in range(nwin)]
+        with Correlator(chips, fs=FS, Nint=Nint, var_ddof=ddof, snr_rot=snr_rot, window=window, precision=precision, max_batch=int(rng.integers(1, 4))) as cor:
+            got = cor.process(raw, nch, ch, band=band) if band is not None else cor.process(raw, nch, ch, df=dfs)
+        assert len(got) == nwin
+        for w, g in enumerate(got):
+            d = orc.deinterleave(raw[w * n:(w + 1) * n], nch, ch)
+            d = d - d.mean()
+            o = orc.processing(d, k, freq, temps, fcode, code, Nint=Nint, fs=FS, snr_rot=snr_rot, ddof=ddof, df=None if band is not None else dfs[w])
+            try:
+                _check(g, o)
+            except AssertionError as e:
+                raise AssertionError(f"combination {it}: Nint={Nint} ddof={ddof} snr_rot={snr_rot} window={window} {precision} nch={nch} ch={ch} {mode} window {w}: {e}") from e
+    assert len(seen) >= min(ncomb, 12)
+
+
+@pytest.mark.parametrize("bitlen,taps,nchips", [(13, 27, 5000), (14, 57, 10000), (15, 17, 25000), (16, 45, 32768), (17, 9, 100000), (18, 39, 262144)])
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_whole_correlation_map_every_row_form(bitlen, taps, nchips, precision):
+    """EVERY lag of the interpolated correlation map (twx_xcorr_map), not only the peak and its neighbours, against the oracle's
+    ifft — over the row-pass forms the window lengths select: N2 = 400 = 20*20 (R0 = 1: k_rowd_small in fp32, the unfolded
+    k_rowd in fp64), 256 = 16*16 and 4096 = 16^3 (power-of-two plug-ins), 8000 = 20^3 (the folded, row-walking form) — in both
+    precisions.  (The unfolded fp64 form once wrote element N2-1 of every row wrong: idle lanes of the last wave raced the store of
+    lane M-1 with another twiddle; the peak-only tests met that column with probability 1/400.)"""
+    chips = chips_for(bitlen, taps, nchips)
+    n = 2 * nchips
+    code = orc.make_code(chips, 2)
+    fcode = orc.make_fcode(code)
+    p = synth.SynthParams(delay_q8=(n // 3 + 11) * 256 + 77, fstep=synth.fstep_for_df(0.0, FS), phi0=77, amp=900,
+                          noise_gain=synth.noise_gain_for_sigma(300.0), seed=nchips)
+    raw = synth.synth_channel(n, chips, 2, p)
+    x = orc.deinterleave(raw, 1, 0)
+    x = x - x.mean()
+    fx = np.fft.fft(x)
+    tol = 2e-6 if precision == "f32" else 1e-12
+    for Nint in (0, 1):
+        with Correlator(chips, fs=FS, Nint=Nint, precision=precision) as cor:
+            z = cor.xcorr_map(raw, 0.0, n_channels=1, channel=0)
+            n2 = int(cor.info.n2)
+        zr = orc.xcorr_interp(fx, fcode, Nint)
+        err = np.abs(z - zr)
+        bad = np.nonzero(err > tol * np.abs(zr).max())[0]
+        assert bad.size == 0, (n, n2, precision, Nint, bad.size, sorted(set(((bad // (2 * Nint + 1)) % n2).tolist()))[:8], float(err.max() / np.abs(zr).max()))
 
 
 def test_all_channels_from_one_copy(tmp_path):

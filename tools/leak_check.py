@@ -40,6 +40,10 @@ for it in range(24):
             m.process(raw, 1, 0, band=band_numpy(5e6, n))
         with receiver.Receiver([receiver.make_row("A", 100, 186.0, 1000.0, 256.0, -18.0, code=chips)], fs_in=2.5e6) as rx:   # 2.5 Msps: nobs = 200 000, nfft = 2^19 (plans that exist), half the work of a 5-Msps second
             rx.second(np.zeros((2_500_000, 4), dtype=np.int16))
+        # the real-sample program with an 'S' row (rx.cpp): own stream, interference records, the cleaned stream
+        with receiver.Receiver([receiver.make_row("A", 100, 186.0, 1000.0, 256.0, -18.0, code=chips),
+                                receiver.make_row("A", 101, 186.0, 1000.0, 256.0, -18.0, code=chips[::-1].copy(), mode="S")], fs_in=5e6, real=True) as rx:
+            rx.second(np.zeros((5_000_000, 4), dtype=np.int16))
     a = acquisition.Acquisition(1 - 2 * chips.astype(np.int64), 2.5e6, 10e6, 400000, dec_a=1 + it % 2, max_batch=16)
     a.acquire(smp.data_ptr(), 0, 100.0, 1024.0, 256.0)
     a.close()
