@@ -1071,6 +1071,77 @@ def test_randomised_option_sweep():
     assert len(seen) >= min(ncomb, 12)
 
 
+def test_randomised_option_sweep_conventions_and_replicas():
+    """The second option sweep: the claudio convention (fcode.*conj(ffty), Octave variances) against processing_claudio, the replica
+    variants of the experiment scripts (0/1 levels, zero mean, complex QPSK replica) against a direct ifft(fft(y).*fcode), and the
+    all-channel call (both channels of a two-channel capture from one copy) — each with random interpolation factor, precision, batch
+    size and signal level.  TWX_SWEEP_OPTIONS raises the count."""
+    rng = np.random.default_rng(777)
+    ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "16"))
+    codes = [(13, 27, 5000), (14, 57, 10000)]
+    for it in range(ncomb):
+        bitlen, taps, nchips = codes[int(rng.integers(0, len(codes)))]
+        chips = chips_for(bitlen, taps, nchips)
+        n = 2 * nchips
+        Nint = int(rng.choice([0, 1, 1, 2]))
+        R = 2 * Nint + 1
+        precision = str(rng.choice(["f32", "f32", "f64"]))
+        kind = str(rng.choice(["claudio", "claudio", "unipolar", "zero_mean", "qpsk", "all_channels"]))
+        nch = 2 if kind == "all_channels" else int(rng.integers(1, 3))
+        ch = int(rng.integers(0, nch))
+        nwin = 3
+        df0 = float(rng.uniform(-5000, 5000))
+        dfs = [df0 + 0.61 * w for w in range(nwin)]
+        chans = [synth.SynthParams(delay_q8=int(rng.integers(0, n)) * 256 + int(rng.integers(0, 256)), fstep=synth.fstep_for_df(df0, FS),
+                                   phi0=int(rng.integers(0, 2 ** 32)), amp=int(rng.choice([0, 60, 400, 2500])),
+                                   noise_gain=synth.noise_gain_for_sigma(float(rng.choice([60.0, 500.0, 2500.0]))), seed=int(rng.integers(1, 10 ** 6)), stream=c)
+                 for c in range(nch)]
+        raw = synth.synth_capture(n * nwin, chips, 2, chans)
+        temps = np.arange(n) / FS
+        mb = int(rng.integers(1, 4))
+        tag = f"combination {it}: {kind} Nint={Nint} {precision} nch={nch} ch={ch} max_batch={mb}"
+        win = lambda w, c: (lambda d: d - d.mean())(orc.deinterleave(raw[w * n:(w + 1) * n], nch, c))
+        try:
+            if kind == "claudio":
+                ddof = int(rng.integers(0, 2))
+                code = orc.make_code(chips, 2)
+                fc = orc.make_fcode(code, "claudio")
+                with Correlator(chips, fs=FS, Nint=Nint, convention="claudio", var_ddof=ddof, precision=precision, max_batch=mb) as cor:
+                    got = cor.process(raw, nch, ch, df=dfs)
+                for w, g in enumerate(got):
+                    _check(g, orc.processing_claudio(win(w, ch), dfs[w], temps, fc, code, Nint=Nint, ddof=ddof))
+            elif kind == "all_channels":
+                code = orc.make_code(chips, 2)
+                fcode = orc.make_fcode(code)
+                df2 = np.array([[d, d - 2.5] for d in dfs])
+                with Correlator(chips, fs=FS, Nint=Nint, precision=precision, max_batch=mb) as cor:
+                    got = cor.process(raw, 2, -1, df=df2)
+                for c in (0, 1):
+                    assert len(got[c]) == nwin
+                    for w, g in enumerate(got[c]):
+                        _check(g, orc.processing(win(w, c), None, None, temps, fcode, code, Nint=Nint, fs=FS, df=float(df2[w, c])))
+            else:
+                cq = chips_for(14, 57, nchips) if kind == "qpsk" else None
+                unipolar = kind in ("unipolar", "qpsk") or bool(rng.integers(0, 2))
+                zero_mean = kind in ("zero_mean", "qpsk") or bool(rng.integers(0, 2))
+                code = orc.make_code_variant(chips, cq, 2, unipolar=unipolar, zero_mean=zero_mean)
+                fcode = np.conj(np.fft.fft(code))
+                with Correlator(chips, fs=FS, Nint=Nint, chips_q=cq, code_levels="unipolar" if unipolar else "bipolar", code_zero_mean=zero_mean,
+                                precision=precision, max_batch=mb) as cor:
+                    got = cor.process(raw, nch, ch, df=dfs)
+                for w, g in enumerate(got):
+                    y = win(w, ch) * np.exp(-2j * np.pi * dfs[w] * temps)
+                    z = orc.xcorr_interp(np.fft.fft(y), fcode, Nint)
+                    ind, corr, xval, xm1, xp1 = orc.peak_refine(z)
+                    assert g.indice == ind
+                    assert abs(g.xval - xval) <= 2 * MAG_TOL * abs(xval) and abs(g.xvalm1 - xm1) <= 2 * MAG_TOL * abs(xval) and abs(g.xvalp1 - xp1) <= 2 * MAG_TOL * abs(xval)
+                    assert abs(g.correction - corr) <= 2e-4 and abs(g.puissance - np.var(y)) <= 1e-6 * np.var(y)
+                    if unipolar or zero_mean or cq is not None:
+                        assert np.isnan(g.SNRr) and np.isnan(g.puissancecode)
+        except AssertionError as e:
+            raise AssertionError(f"{tag}: {e}") from e
+
+
 @pytest.mark.parametrize("bitlen,taps,nchips", [(13, 27, 5000), (14, 57, 10000), (15, 17, 25000), (16, 45, 32768), (17, 9, 100000), (18, 39, 262144)])
 @pytest.mark.parametrize("precision", ["f32", "f64"])
 def test_whole_correlation_map_every_row_form(bitlen, taps, nchips, precision):
