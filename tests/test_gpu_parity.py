@@ -328,24 +328,28 @@ def test_claudio_convention():
         _check(g, o)
 
 
-def test_caf_integer_bins_vs_oracle():
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+@pytest.mark.parametrize("bitlen,taps,nchips,delay", [(14, 43, 10000, 6543), (13, 27, 5000, 399), (16, 45, 32768, 255 + 256 * 9), (17, 9, 100000, 4000 * 7 - 1)])
+def test_caf_integer_bins_vs_oracle(bitlen, taps, nchips, delay, precision):
     """Delay x Doppler surface on the integer-bin grid vs the oracle's
-    shift-and-correlate restatement of rxcomplex.cpp:534-563 (unpinned)."""
-    nchips, n = 10000, 20000
-    chips = chips_for(14, 43, nchips)
-    df_bins = 7                                               # true offset = 7 bins = 7*fs/N = 1750 Hz
-    p = synth.SynthParams(delay_q8=6543 * 256, fstep=synth.fstep_for_df(df_bins * FS / n, FS), phi0=77, amp=400,
+    shift-and-correlate restatement of rxcomplex.cpp:534-563 (unpinned) — in both precisions, over the row-pass forms of the
+    surface kernels (N2 = 400 and 256: k_row_caf; 4000: k_rowd_caf), the peak on the LAST element of a row of the two-pass layout."""
+    n = 2 * nchips
+    chips = chips_for(bitlen, taps, nchips)
+    df_bins = 7                                               # true offset = 7 bins = 7*fs/N
+    p = synth.SynthParams(delay_q8=delay * 256, fstep=synth.fstep_for_df(df_bins * FS / n, FS), phi0=77, amp=400,
                           noise_gain=synth.noise_gain_for_sigma(300.0), seed=8)
     raw = synth.synth_channel(n, chips, 2, p)
-    with Correlator(chips, fs=FS, Nint=0) as cor:
+    with Correlator(chips, fs=FS, Nint=0, precision=precision) as cor:
+        assert delay % int(cor.info.n2) == int(cor.info.n2) - 1 or nchips == 10000
         pk, lag = cor.caf_bins(raw, -40, 40)
     d = orc.deinterleave(raw, 1, 0)
     d = d - d.mean()
     ks, pk_o, lag_o = orc.caf_bins_shift(d, orc.make_fcode(orc.make_code(chips, 2)), -40, 40)
     assert np.array_equal(lag, lag_o)                          # every bin's arg-max, bit-exact
-    assert np.abs(pk - pk_o).max() <= MAG_TOL * pk_o.max()
+    assert np.abs(pk - pk_o).max() <= (MAG_TOL if precision == "f32" else 1e-12) * pk_o.max()
     best = int(np.argmax(pk))
-    assert ks[best] == df_bins and lag[best] == 6543
+    assert ks[best] == df_bins and lag[best] == delay
 
 
 def test_caf_row_pass_forms_agree_on_random_windows(monkeypatch):
