@@ -760,21 +760,25 @@ def test_tracked_loop_realigns_after_a_jump():
     assert np.abs(gx - wx).max() <= MAG_TOL * wx.max()
 
 
-def test_tracked_loop_reference_sizes():
-    """The script's own sizes: 100 kchip code (N = 200 000, 40 ms), 2-s chunks of 10^7 samples (:15,125-131)."""
+@pytest.mark.parametrize("precision,delay", [("f32", 123456), ("f64", 123456), ("f64", 400 * 77 - 1), ("f32", 400 * 77 - 1)])
+def test_tracked_loop_reference_sizes(precision, delay):
+    """The script's own sizes: 100 kchip code (N = 200 000 = 500 x 400, 40 ms), 2-s chunks of 10^7 samples (:15,125-131) — in fp32
+    and in fp64 (the context's precision: every kernel of the flow in complex double), the code phase also on the last element of
+    a row of the two-pass layout."""
     from amaranth_twstft_amd.tracked import TrackedRanging
     nchips, n = 100000, 200000
     chips = chips_for(17, 9, nchips)
-    p = synth.SynthParams(delay_q8=123456 * 256, fstep=synth.fstep_for_df(12.0, FS), phi0=9, amp=300,
+    p = synth.SynthParams(delay_q8=delay * 256, fstep=synth.fstep_for_df(12.0, FS), phi0=9, amp=300,
                           noise_gain=synth.noise_gain_for_sigma(500.0), seed=21)
     raw = synth.synth_channel(n * 101, chips, 2, p)
     want = orc.ranging_tracked(raw, chips, fs=FS)
-    with TrackedRanging(chips, fs=FS, Nint=1) as tr:
+    with TrackedRanging(chips, fs=FS, Nint=1, precision=precision) as tr:
         got = tr.run(raw)
     assert got["kbon"] == want["kbon"] and want["kbon"] > 0 and got["df"] == want["df"]
     assert got["moved"] == want["moved"] and got["indice1"] == want["indice1"] and len(want["indice1"]) >= 98
     gx, wx = np.abs(np.array(got["xval"])), np.abs(np.array(want["xval"]))
-    assert np.abs(gx - wx).max() <= MAG_TOL * wx.max()
+    assert np.abs(gx - wx).max() <= (MAG_TOL if precision == "f32" else 1e-11) * wx.max()
+    assert np.abs(np.array(got["correction1"]) - np.array(want["correction1"])).max() < (2e-4 if precision == "f32" else 1e-8)
 
 
 def _tracked_agrees(got, want, floor=False):
