@@ -1179,6 +1179,42 @@ def test_whole_correlation_map_every_row_form(bitlen, taps, nchips, precision):
         assert bad.size == 0, (n, n2, precision, Nint, bad.size, sorted(set(((bad // (2 * Nint + 1)) % n2).tolist()))[:8], float(err.max() / np.abs(zr).max()))
 
 
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+@pytest.mark.parametrize("bitlen,taps,nchips", [(13, 27, 5000), (14, 57, 10000), (16, 45, 32768), (17, 9, 100000)])
+def test_carrier_search_finds_a_tone_on_every_bin_of_the_band(bitlen, taps, nchips, precision):
+    """The coarse carrier estimate (arg-max of fftshift(abs(fft(d.^2))) over the band k, godual_ranging.m:14-15) bin by bin: one
+    window per bin of the search band, each a tone whose square lands exactly on that bin — every bin must be found, i.e. every
+    element of the band the pruned row pass (k_rowd<BAND> / k_row<BAND>) evaluates is right, in both precisions and over the row
+    forms (N2 = 400, 256, 4000).  The peak-only tests meet a given bin with the probability of the carrier they draw."""
+    chips = chips_for(bitlen, taps, nchips)
+    n = 2 * nchips
+    freq = orc.freq_axis(FS, n)
+    k = orc.band_godual(freq)
+    band = band_godual(FS, n)
+    bins = k if k.size <= 600 else k[:: k.size // 600 + 1]                       # 600 windows at most: every bin for the short codes, a comb over the long
+    if k.size > 600:
+        bins = np.unique(np.concatenate((bins, k[:40], k[-40:], k[k.size // 2 - 20:k.size // 2 + 20])))
+    bins = bins[bins != n // 2]                                                 # the tone on bin 0 is a constant: the mean removal takes it away
+    t = np.arange(n)
+    raw = np.empty((bins.size * n, 2), dtype=np.int16)
+    for i, kb in enumerate(bins):
+        kappa = int(kb) - n // 2                                                 # signed bin of the fft (fftshift: index n/2 is bin 0)
+        ph = (kappa * t % (2 * n)).astype(np.float64) * (np.pi / n)               # the tone at kappa/2 bins: its square sits on bin kappa
+        raw[i * n:(i + 1) * n, 0] = np.rint(8000 * np.cos(ph))
+        raw[i * n:(i + 1) * n, 1] = np.rint(8000 * np.sin(ph))
+    with Correlator(chips, fs=FS, Nint=0, precision=precision) as cor:
+        got = cor.process(raw, 1, 0, band=band)
+    assert len(got) == bins.size
+    wrong = []
+    for i, (g, kb) in enumerate(zip(got, bins)):
+        d = orc.deinterleave(raw[i * n:(i + 1) * n], 1, 0)
+        d = d - d.mean()
+        idx, df = orc.coarse_df(d, k, freq)
+        if abs(g.df - df) > 1e-9 or g.df_index != idx:
+            wrong.append((int(kb), g.df_index, idx, g.df, df))
+    assert not wrong, (len(wrong), wrong[:10])
+
+
 def test_all_channels_from_one_copy(tmp_path):
     """channel = -1: both channels of every window from one upload / one pass over the file equal the per-channel calls
     (host buffer with more chunks than slots, device-resident, file)."""
