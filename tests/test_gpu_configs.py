@@ -909,3 +909,51 @@ def test_two_way_end_to_end_from_four_captures(tmp_path):
     # every channel was re-aligned to sample 21 by the tracked loop (:183), so the four series sit at 21 samples = 4200 ns
     for series in (tw.oplo, tw.opre, tw.ltlo, tw.ltre):
         assert np.abs(series - 21 / FS * 1e9).max() < 70.0          # the remote series keep indice/3 = 21 1/3 (:174)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_full_size_carrier_search_and_map_at_row_boundaries(precision):
+    """N = 5e6 = 625 x 8000 (the folded, row-walking k_rowd in fp32; the folded k_rowd in fp64): (a) the coarse carrier estimate finds
+    a tone whose square lies on the first / last bins of the band, next to zero and on both sides of the k2 = 0 / 7999 row ends of the
+    two-pass layout; (b) the correlation peak placed on the last and the first element of a row (lag = 8000 m - 1, 8000 m) and on the
+    map's ends comes out with the oracle's lag, neighbours and correction."""
+    import torch
+    dev = torch.device("cuda", 0)
+    chips = chips_for(22, 3, NCHIPS)
+    freq = orc.freq_axis(FS, N)
+    k = orc.band_godual(freq)
+    band = band_godual(FS, N)
+    # (a) tones: the replica of the generator held at -1 (chips all zero) is a pure carrier
+    kappas = [int(k[0]) - N // 2, int(k[-1]) - N // 2, -1, 1, 624, 625, 626, -625, 7999, 8000, 8001, -8001, 15999, 16000, 19999, -19999]
+    zeros = torch.zeros(NCHIPS, dtype=torch.uint8, device=dev)
+    iq = torch.empty((N, 2), dtype=torch.int16, device=dev)
+    with Correlator(chips, fs=FS, Nint=1, precision=precision, max_batch=1) as cor:
+        for kappa in kappas:
+            p = synth.SynthParams(delay_q8=0, fstep=synth.fstep_for_df(kappa / 2.0 * FS / N, FS), phi0=12345, amp=6000, noise_gain=0, seed=1)
+            _synth_dev(iq, N, zeros, NCHIPS, 2, [p])
+            torch.cuda.synchronize()
+            g = cor.process_dev(iq.data_ptr(), 1, 1, 0, band=band)[0]
+            d = orc.deinterleave(iq.cpu().numpy(), 1, 0)
+            idx, df = orc.coarse_df(d - d.mean(), k, freq)                     # (the mean removal bends the tones next to zero: ask the oracle)
+            assert g.df_index == idx and abs(g.df - df) <= 1e-9, (kappa, g.df_index - N // 2, idx - N // 2)
+            assert abs(idx - N // 2 - kappa) <= 1
+        # (b) peaks across the row ends
+        code = orc.make_code(chips, 2)
+        fcode = orc.make_fcode(code)
+        temps = np.arange(N) / FS
+        cd = torch.from_numpy(chips).to(dev)
+        for delay in (8000 * 311 - 1, 8000 * 311, N - 1, 0):
+            p = synth.SynthParams(delay_q8=delay * 256 + 60, fstep=synth.fstep_for_df(333.0, FS), phi0=7, amp=300, noise_gain=synth.noise_gain_for_sigma(400.0), seed=delay + 5)
+            _synth_dev(iq, N, cd, NCHIPS, 2, [p])
+            torch.cuda.synchronize()
+            raw = iq.cpu().numpy()
+            g = cor.process(raw, 1, 0, df=333.0)[0]
+            d = orc.deinterleave(raw, 1, 0)
+            d = d - d.mean()
+            o = orc.processing(d, None, None, temps, fcode, code, Nint=1, fs=FS, df=333.0)
+            assert g.indice == o["indice"], (delay, g.indice, o["indice"])
+            off = (g.indice / 3.0 - delay) % N
+            assert min(off, N - off) <= 1.5, (delay, g.indice)                 # the generator's truth, circularly
+            tol = (2e-6 if precision == "f32" else 1e-11) * abs(o["xval"])
+            assert abs(g.xval - o["xval"]) <= tol and abs(g.xvalm1 - o["xvalm1"]) <= tol and abs(g.xvalp1 - o["xvalp1"]) <= tol, delay
+            assert abs(g.correction - o["correction"]) <= 2e-4 and abs(g.SNRr - o["SNRr"]) <= 3e-4 * max(o["SNRr"], o["SNRi"])
