@@ -40,6 +40,9 @@ typedef enum twx_status {
 enum { TWX_CONV_GODUAL = 0,   /* fft(y).*conj(fft(code))   godual_ranging.m:26,66            */
        TWX_CONV_CLAUDIO = 1 };/* fft(code).*conj(fft(y))   claudio_aligned_code_ranging_separate.m:59,124 */
 enum { TWX_WIN_NONE = 0, TWX_WIN_HAMMING = 1 };   /* Hamming on fcode: processing/CPP/main.cpp:717-719 */
+/* With the Hamming window the peak (indice, xval*, correction) comes from the correlation with the WINDOWED spectrum and the wipe-off
+ * statistics (SNRr, SNRi, puissancecode, puissancenoise) from the unwindowed yint, as in the C++ program (main.cpp:288-301 against
+ * :319-332): the context keeps both spectra and runs its row pass twice per batch. */
 enum { TWX_F32 = 0, TWX_F64 = 1 };
 enum { TWX_FLAG_PROFILE = 1,                      /* time every kernel launch with HIP events */
        TWX_FLAG_FINE_FREQ = 2,                    /* add the phase-drift fine carrier step of
