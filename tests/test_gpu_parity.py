@@ -1215,6 +1215,49 @@ def test_carrier_search_finds_a_tone_on_every_bin_of_the_band(bitlen, taps, nchi
     assert not wrong, (len(wrong), wrong[:10])
 
 
+def test_randomised_fir_and_sliding_shapes():
+    """Random shapes of the two kernels beside the FFT chain against their fp64 definitions: the FIR decimator over tap count 1..1024,
+    decimation 1..16, one / two channels, lengths from one output up to several workgroups with ragged tails (both kernel forms, every
+    step-group count, the generic loop); the sliding dot product over period, code count, lag window 0..31, channel layout, start
+    offset, carrier and phase (the three tiles and their fall-backs).  TWX_SWEEP_OPTIONS raises the count."""
+    from amaranth_twstft_amd import frontend, tracking
+    rng = np.random.default_rng(31337)
+    ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "16"))
+    for it in range(ncomb):
+        # ---- FIR
+        dec = int(rng.integers(1, 17))
+        ntaps = int(rng.choice([rng.integers(1, 40), rng.integers(40, 400), rng.integers(400, 1025)]))
+        nch = int(rng.integers(1, 3)); ch = int(rng.integers(0, nch))
+        nout = int(rng.choice([1, 2, rng.integers(3, 600), rng.integers(600, 5000)]))
+        n_in = (nout - 1) * dec + ntaps + int(rng.integers(0, dec))
+        taps = (rng.normal(0, 1, ntaps) / np.sqrt(ntaps)).astype(np.float32)
+        raw = np.clip(rng.normal(0, 5000, (n_in, 2 * nch)), -32768, 32767).astype(np.int16)
+        x = raw[:, 2 * ch].astype(np.float64) + 1j * raw[:, 2 * ch + 1]
+        ref = orc.fir_decimate(x, taps.astype(np.float64), dec)
+        tag = f"combination {it}: FIR ntaps={ntaps} dec={dec} nch={nch} ch={ch} nout={nout}"
+        y = frontend.fir_decimate(raw, taps, dec, n_channels=nch, channel=ch, out="f32")
+        assert y.shape == ref.shape == (nout,), tag
+        assert np.abs(y - ref).max() <= 3e-6 * np.abs(ref).max() + 2e-3, (tag, float(np.abs(y - ref).max()), float(np.abs(ref).max()))
+        y16 = frontend.fir_decimate(raw, taps, dec, n_channels=nch, channel=ch, out="int16")
+        assert np.abs(y16[:, 0] - np.clip(np.rint(ref.real), -32768, 32767)).max() <= 1 and np.abs(y16[:, 1] - np.clip(np.rint(ref.imag), -32768, 32767)).max() <= 1, tag
+        # ---- sliding dot product
+        nlag = int(rng.choice([0, 1, 4, 8, 9, 16, 28, 31, rng.integers(0, 32)]))
+        nobs = int(rng.choice([rng.integers(1, 64), 8 * rng.integers(1, 400), rng.integers(64, 3000), 8 * rng.integers(2000, 3000), 16384 + 8 * rng.integers(0, 4)]))
+        ncodes = int(rng.integers(1, 6))
+        nch = int(rng.integers(1, 3)); ch = int(rng.integers(0, nch)); pt = int(rng.integers(0, 9))
+        ff, phi = float(rng.uniform(-1e-3, 1e-3)), float(rng.uniform(0, 1))
+        w = rng.choice([-1.0, 1.0], nobs).astype(np.float32)
+        raw = np.clip(rng.normal(0, 3000, (pt + nobs * ncodes, 2 * nch)), -32768, 32767).astype(np.int16)      # not a frame more than needed
+        tag = f"combination {it}: sliding nobs={nobs} ncodes={ncodes} nlag={nlag} nch={nch} ch={ch} pt={pt}"
+        got = tracking.sliding_dot(raw, w, nobs, ncodes, nlag, pt=pt, ff=ff, phi=phi, scale=1.0 / 32768.0, n_channels=nch, channel=ch)
+        x = raw[:, 2 * ch].astype(np.float64) + 1j * raw[:, 2 * ch + 1]
+        for p in range(ncodes):
+            i = np.arange(p * nobs, (p + 1) * nobs)
+            yy = x[pt + i] / 32768.0 * np.exp(-2j * np.pi * (ff * i + phi))
+            ref = orc.sliding_dot(yy, w.astype(np.float64), nlag)
+            assert np.abs(got[p] - ref).max() <= 4e-6 * np.abs(ref).max() + 1e-9, (tag, p, float(np.abs(got[p] - ref).max()), float(np.abs(ref).max()))
+
+
 def test_all_channels_from_one_copy(tmp_path):
     """channel = -1: both channels of every window from one upload / one pass over the file equal the per-channel calls
     (host buffer with more chunks than slots, device-resident, file)."""
