@@ -195,3 +195,44 @@ def test_bench_single_process_line():
     c = j["collective"]
     assert j["n_gpus"] == 4 and j["integer_lag_exact"] and j["value"] > 0 and j["config"]["launch"] == "single process"
     assert c["world"] == 4 and c["records"] == 36 and c["ranks_with_exact_lags"] == 4 and c["gathered_lag_exact"] and c["all_ranks_agree"]
+
+
+def test_randomised_partitions_equal_one_context(tmp_path):
+    """Random jobs over random device lists (device 0 repeated 1..7 times): window count from 0 upward, one or two channels, one
+    channel / all channels, band or supplied carrier, file skip and window limit, host-buffer and file entry — the gathered records
+    byte-identical to ONE context's, whatever the partition (blocks of 0 windows, fewer windows than contexts, ragged blocks)."""
+    from tests.test_gpu_parity import _capture
+    rng = np.random.default_rng(99)
+    chips, raw_all = _capture(13, 27, 5000, 23, seed=5)
+    n = 2 * len(chips)
+    band = band_godual(FS, n)
+    ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "10"))
+    with Correlator(chips, fs=FS, Nint=1) as one:
+        for it in range(ncomb):
+            ndev = int(rng.integers(1, 8))
+            nwin = int(rng.choice([0, 1, 2, ndev - 1, ndev, ndev + 1, rng.integers(0, 24)]))
+            nwin = max(0, min(23, nwin))
+            channel = int(rng.integers(-1, 2))
+            use_band = bool(rng.integers(0, 2))
+            skip = int(rng.integers(0, 3)) * n if nwin > 2 else 0
+            maxw = int(rng.integers(1, nwin + 2)) if rng.integers(0, 2) else None
+            raw = raw_all[: nwin * n]
+            path = tmp_path / f"cap{it}.bin"
+            raw.tofile(path)
+            tag = f"combination {it}: {ndev} contexts, {nwin} windows, channel {channel}, {'band' if use_band else 'df'}, skip {skip // n}, max {maxw}"
+            kw = dict(band=band) if use_band else dict(df=123.5)
+            with MultiCorrelator(chips, [0] * ndev, fs=FS, Nint=1) as m:
+                ref = one.process_file(str(path), n_channels=2, channel=channel, skip_samples=skip, max_windows=maxw, raw_records=True, **kw)
+                got = m.process_file(str(path), n_channels=2, channel=channel, skip_samples=skip, max_windows=maxw, raw_records=True, **kw)
+                assert got.shape == ref.shape and got.tobytes() == ref.tobytes(), tag
+                if nwin:
+                    kw2 = dict(band=band) if use_band else dict(df=np.linspace(-50.0, 50.0, nwin * (2 if channel < 0 else 1)).reshape((nwin, 2) if channel < 0 else (nwin,)))
+                    refh = one.process(raw, n_channels=2, channel=channel, raw_records=True, **kw2) if "raw_records" in one.process.__code__.co_varnames else None
+                    goth = m.process(raw, n_channels=2, channel=channel, raw_records=True, **kw2)
+                    if refh is not None:
+                        assert goth.tobytes() == refh.tobytes(), tag + " (host buffer)"
+                    else:
+                        r2 = one.process(raw, n_channels=2, channel=channel, **kw2)
+                        g2 = m.process(raw, n_channels=2, channel=channel, **kw2)
+                        flat = lambda r: [x for c in sorted(r) for x in r[c]] if isinstance(r, dict) else r
+                        assert [(a.indice, a.xval, a.df, a.SNRr) for a in flat(g2)] == [(a.indice, a.xval, a.df, a.SNRr) for a in flat(r2)], tag + " (host buffer)"
