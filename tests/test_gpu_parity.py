@@ -1258,6 +1258,47 @@ def test_randomised_fir_and_sliding_shapes():
             assert np.abs(got[p] - ref).max() <= 4e-6 * np.abs(ref).max() + 1e-9, (tag, p, float(np.abs(got[p] - ref).max()), float(np.abs(ref).max()))
 
 
+def test_randomised_tracked_flows():
+    """Random captures through the tracked multi-code flow, all three scripts' flavours, against the oracle's restatement: random
+    chunk length (a whole number of codes), capture length (incl. a ragged tail of whole codes and of a code fraction), carrier,
+    delays that jump once or twice (sample loss: re-alignments, sometimes in the first chunk, sometimes across a chunk end), strong
+    to weak signals, fp32 and fp64.  The control flow decides on thresholds, so a window that is measured a hair differently shows
+    up as a different `moved` list: everything must agree.  TWX_SWEEP_OPTIONS raises the count."""
+    from amaranth_twstft_amd.tracked import TrackedRanging
+    rng = np.random.default_rng(2718)
+    ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "6"))
+    for it in range(ncomb):
+        mode, OP = [("ranging", 0), ("lo", 0), ("re", 0), ("re", 1)][int(rng.integers(0, 4))]
+        m = orc.tracked_mode(mode, OP)
+        car = float(rng.uniform(-3000, 3000)) if mode != "re" else (m["band"][0] + m["band"][1]) / 4 + float(rng.uniform(-500, 500))
+        per_chunk = int(rng.integers(8, 41))
+        nseg = int(rng.integers(1, 4))
+        parts, delay = [], int(rng.integers(100, 15000))
+        amp = int(rng.choice([150, 500, 2000])); sigma = float(rng.choice([100.0, 300.0, 800.0]))
+        for sgm in range(nseg):
+            chips, n, a = _tracked_capture(ncodes=int(rng.integers(per_chunk // 2 + 1, 2 * per_chunk + 5)), df=car, delay=delay, seed=int(rng.integers(1, 10 ** 6)), sigma=sigma, amp=amp)
+            parts.append(a)
+            delay = (delay + int(rng.choice([-1, 1])) * int(rng.integers(30, 3000))) % n
+        raw = np.concatenate(parts)
+        raw = raw[: raw.shape[0] - int(rng.choice([0, 0, n // 3, 7]))]                 # sometimes a code fraction at the end
+        Lc = per_chunk * n
+        precision = str(rng.choice(["f32", "f32", "f64"]))
+        tag = f"combination {it}: {mode}/{OP} {precision} chunk {per_chunk} codes, {raw.shape[0] / n:.2f} codes, carrier {car:.1f}, {nseg} segments, amp {amp} sigma {sigma}"
+        want = orc.ranging_tracked(raw, chips, fs=FS, ls_samples=Lc, band=m["band"], carrier=m["carrier"], indice_floor=m["indice_floor"])
+        with TrackedRanging(chips, fs=FS, Nint=1, ls_samples=Lc, mode=mode, OP=OP, precision=precision) as tr:
+            got = tr.run(raw)
+        try:
+            assert got["kbon"] == want["kbon"] and got["df"] == want["df"]
+            assert got["moved"] == want["moved"] and np.allclose(got["movedval"], want["movedval"])
+            assert got["indice1"] == want["indice1"]
+            if len(want["xval"]):
+                gx, wx = np.abs(np.array(got["xval"])), np.abs(np.array(want["xval"]))
+                assert np.abs(gx - wx).max() <= MAG_TOL * wx.max()
+                assert np.abs(np.array(got["correction1"]) - np.array(want["correction1"])).max() < 2e-4
+        except AssertionError as e:
+            raise AssertionError(f"{tag}: {e}") from e
+
+
 def test_all_channels_from_one_copy(tmp_path):
     """channel = -1: both channels of every window from one upload / one pass over the file equal the per-channel calls
     (host buffer with more chunks than slots, device-resident, file)."""
