@@ -290,3 +290,73 @@ def test_command_line_programs_equal_the_library_calls(tmp_path):
         assert body[-1].endswith(", no signal") and "#101" in body[-1]
         pw = [l for l in lines if l.startswith("PWR A:")][-1]
         assert re.fullmatch(r"PWR A: +-?\d+\.\d\d dBm , PWR B: +-?\d+\.\d\d dBm", pw)
+
+
+def test_randomised_receiver_scenarios():
+    """Random scenarios through both receiver programs at half the sample rate (fs_in = 2.5 Msps: one sample per chip in, nobs =
+    200 000 / 100 000, the same code paths at a quarter of the oracle's cost): which codes are on which physical channel and how
+    strong (well above the gate, or absent), carriers inside the search range, delays, a delay jump in some second (lock lost ->
+    re-acquisition), the X310 / B210 builds (dec_a), rxcomplex / rx with 'S' rows behind 'N' rows of the other code — the state of
+    every row after every second (status, integer carrier, code phase, usable periods) equal to oracle.rx_second, the measured
+    quantities within the fp32 tolerances.  TWX_SWEEP_OPTIONS raises the count."""
+    rng = np.random.default_rng(161803)
+    ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "3"))
+    fs_in, n_in = 2.5e6, 2_500_000
+    codes = {100: chips_for(17, 9, CLEN), 101: chips_for(17, 15, CLEN)}
+    names = {v: k for k, v in receiver.STATUS.items()}
+    for it in range(ncomb):
+        real = bool(rng.integers(0, 2))
+        dec_a = int(rng.integers(1, 3))
+        sps = n_in * (1 if real else 2)
+        seconds = int(rng.integers(3, 6))
+        # what is on the air: per physical channel a list of (pn, amp, carrier, delay)
+        air = {"A": [], "B": []}
+        for chn in ("A", "B"):
+            for pn in (100, 101):
+                if rng.integers(0, 3) == 0:
+                    continue
+                # real samples cannot tell +f from -f (the two sweep peaks are equal up to rounding): the real program's rows search
+                # a range that holds only one of them
+                car = float(rng.uniform(300, 450)) if real else float(rng.uniform(-400, 400))
+                air[chn].append([pn, int(rng.choice([900, 1500])), car, int(rng.integers(0, CLEN))])
+        jump_sec = int(rng.integers(2, seconds + 2))                     # beyond the capture: no jump
+        cap = np.zeros((seconds, n_in, 4), dtype=np.int16)
+        for s in range(seconds):
+            for c, chn in enumerate(("A", "B")):
+                acc = np.zeros((n_in, 2), dtype=np.int32)
+                for j, (pn, amp, car, dly) in enumerate(air[chn]):
+                    d = dly + (37 if s >= jump_sec else 0)
+                    p = synth.SynthParams(delay_q8=d * 256, fstep=synth.fstep_for_df(car, fs_in), phi0=3 + j, amp=amp,
+                                          noise_gain=synth.noise_gain_for_sigma(500.0) if j == 0 else 0, seed=1000 * it + 10 * c + j, stream=c)
+                    acc += synth.synth_channel(n_in, codes[pn], 1, p, n0=s * n_in).reshape(n_in, 2)
+                if not air[chn]:
+                    p = synth.SynthParams(delay_q8=0, fstep=0, phi0=0, amp=0, noise_gain=synth.noise_gain_for_sigma(500.0), seed=1000 * it + 10 * c, stream=c)
+                    acc += synth.synth_channel(n_in, codes[100], 1, p, n0=s * n_in).reshape(n_in, 2)
+                cap[s, :, 2 * c:2 * c + 2] = np.clip(acc, -32768, 32767)
+        # rows: every (channel, code) pair in random order, 'S' for some rows of the real program that follow an 'N' row of the other code
+        pairs = [(chn, pn) for chn in ("A", "B") for pn in (100, 101)]
+        rng.shuffle(pairs)
+        pairs = pairs[: int(rng.integers(1, 5))]
+        rows, orows = [], []
+        for chn, pn in pairs:
+            mode = "S" if real and rng.integers(0, 2) and any(o["ch"] == chn and o["pn"] != pn and o["mode"] == "N" for o in orows) else "N"
+            fc_init = float(rng.integers(340, 411)) if real else float(rng.integers(-100, 101))
+            frange, fstep = (200.0, 64.0) if real else (512.0, 128.0)
+            rows.append(receiver.make_row(chn, pn, fc_init, frange, fstep, -14.0, mode=mode, code=codes[pn]))
+            orows.append(dict(ch=chn, mode=mode, pn=pn, fc_init=fc_init, kcps=2500, fltkhz=1250.0, frange=frange, fstep=fstep, snr_min_db=-14.0))
+        block = int(rng.integers(0, 5))
+        tag = f"combination {it}: {'rx' if real else 'rxcomplex'} dec_a={dec_a} {seconds} s, air {air}, jump at {jump_sec}, rows {[(o['ch'], o['mode'], o['pn']) for o in orows]}"
+        with receiver.Receiver(rows, fs_in=fs_in, acq_block=block, dec_a=dec_a, real=real) as rx:
+            got = [rx.second(cap[s]) for s in range(seconds)]
+        cis = [orc.rx_channel_setup(o, codes[o["pn"]], sps, dec_a) for o in orows]
+        try:
+            for s in range(seconds):
+                want = orc.rx_second(cis, cap[s].reshape(-1), sps, dec_a, lambda i, ci: block * ci["nobs"], real=real)
+                for i, (g, w) in enumerate(zip(got[s], want)):
+                    assert g.status == names[w["status"]], (s, i, receiver.STATUS[g.status], w["status"])
+                    assert (g.fc, g.pt) == (w["fc"], w["pt"]), (s, i, g.fc, w["fc"], g.pt, w["pt"])
+                    assert abs(g.px - w["px"]) <= 2e-4 * w["px"] and abs(g.pk - w["pk"]) <= 2e-4 * abs(w["pk"]) + 1e-12, (s, i)
+                    if w["status"] in ("tracked", "code lock"):
+                        assert g.cnt == w["cnt"] and abs(g.fc + g.df - (w["fc"] + w["df"])) <= 5e-3 and abs(g.gd - w["gd"]) <= 0.5, (s, i)
+        except AssertionError as e:
+            raise AssertionError(f"{tag}: {e}") from e
