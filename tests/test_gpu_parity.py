@@ -1299,6 +1299,39 @@ def test_randomised_tracked_flows():
             raise AssertionError(f"{tag}: {e}") from e
 
 
+def test_randomised_caf_ranges():
+    """Random Doppler ranges of the delay x Doppler surface against the oracle's shift-and-correlate: window length (k_row_caf for
+    N2 = 400 / 256, k_rowd_caf with several bins per workgroup for N2 = 4000), precision, first bin anywhere in +-3 N1 and beyond
+    (the k1 rotation carries into k2, negative bins), 1 to ~150 bins (whole and ragged groups of bins per workgroup and per
+    launch), one / two channels, signal from strong to absent (the arg-max of every bin decided among noise peaks): every bin's lag
+    bit-exact, its peak within 1e-6.  TWX_SWEEP_OPTIONS raises the count."""
+    rng = np.random.default_rng(55555)
+    ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "8"))
+    shapes = [(13, 27, 5000), (14, 57, 10000), (16, 45, 32768), (17, 9, 100000)]
+    for it in range(ncomb):
+        bitlen, taps, nchips = shapes[int(rng.integers(0, len(shapes)))]
+        chips = chips_for(bitlen, taps, nchips)
+        n = 2 * nchips
+        precision = str(rng.choice(["f32", "f32", "f64"]))
+        nch = int(rng.integers(1, 3)); ch = int(rng.integers(0, nch))
+        nb = int(rng.choice([1, 2, rng.integers(3, 40), rng.integers(40, 150)])) if n <= 65536 else int(rng.choice([1, 7, rng.integers(8, 40)]))
+        amp = int(rng.choice([0, 80, 600]))
+        true_bin = int(rng.integers(-2000, 2000))
+        chans = [synth.SynthParams(delay_q8=int(rng.integers(0, n)) * 256, fstep=synth.fstep_for_df(true_bin * FS / n, FS), phi0=int(rng.integers(0, 2 ** 31)), amp=amp,
+                                   noise_gain=synth.noise_gain_for_sigma(400.0), seed=int(rng.integers(1, 10 ** 6)), stream=c) for c in range(nch)]
+        raw = synth.synth_capture(n, chips, 2, chans)
+        with Correlator(chips, fs=FS, Nint=0, precision=precision) as cor:
+            n1 = int(cor.info.n1)
+            k_lo = int(rng.choice([true_bin - nb // 2, rng.integers(-3 * n1, 3 * n1), -n1 - 1, n1 - nb + 1, rng.integers(-n // 2 + 1, n // 2 - nb)]))
+            pk, lag = cor.caf_bins(raw, k_lo, k_lo + nb - 1, n_channels=nch, channel=ch)
+        d = orc.deinterleave(raw, nch, ch)
+        d = d - d.mean()
+        ks, pk_o, lag_o = orc.caf_bins_shift(d, orc.make_fcode(orc.make_code(chips, 2)), k_lo, k_lo + nb - 1)
+        tag = f"combination {it}: N={n} (N1={n1}) {precision} nch={nch} ch={ch} bins {k_lo}..{k_lo + nb - 1} amp {amp} true bin {true_bin}"
+        assert np.array_equal(lag, lag_o), (tag, np.nonzero(lag != lag_o)[0][:5])
+        assert np.abs(pk - pk_o).max() <= (MAG_TOL if precision == "f32" else 1e-12) * pk_o.max(), tag
+
+
 def test_all_channels_from_one_copy(tmp_path):
     """channel = -1: both channels of every window from one upload / one pass over the file equal the per-channel calls
     (host buffer with more chunks than slots, device-resident, file)."""
