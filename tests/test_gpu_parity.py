@@ -1150,7 +1150,10 @@ def test_randomised_option_sweep_conventions_and_replicas():
             raise AssertionError(f"{tag}: {e}") from e
 
 
-@pytest.mark.parametrize("bitlen,taps,nchips", [(13, 27, 5000), (14, 57, 10000), (15, 17, 25000), (16, 45, 32768), (17, 9, 100000), (18, 39, 262144)])
+@pytest.mark.parametrize("bitlen,taps,nchips", [(13, 27, 5000), (14, 57, 10000), (15, 17, 25000), (16, 45, 32768), (17, 9, 100000), (18, 39, 262144),
+                                                # the plug-in lengths of __graft_entry__.PLUGIN_LENGTHS: N = 5000, 25000, 4000, 80000, 81000, 14000, 6000, 12000, 18000
+                                                (13, 27, 2500), (15, 3, 12500), (12, 83, 2000), (16, 45, 40000), (16, 45, 40500), (13, 27, 7000), (12, 83, 3000),
+                                                (13, 27, 6000), (14, 43, 9000)])
 @pytest.mark.parametrize("precision", ["f32", "f64"])
 def test_whole_correlation_map_every_row_form(bitlen, taps, nchips, precision):
     """EVERY lag of the interpolated correlation map (twx_xcorr_map), not only the peak and its neighbours, against the oracle's
