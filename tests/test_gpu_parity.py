@@ -1030,12 +1030,12 @@ def test_randomised_option_sweep():
     same settings: integer lag and carrier exact, the rest within the tolerances of _check.  TWX_SWEEP_OPTIONS raises the count."""
     rng = np.random.default_rng(424242)
     ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "16"))
-    codes = [(13, 27, 5000), (14, 57, 10000)]
+    codes = [(13, 27, 5000, 2), (14, 57, 10000, 2), (13, 27, 5000, 1), (13, 27, 5000, 4), (13, 27, 2500, 4), (14, 57, 10000, 1)]     # chips x samples per chip
     seen = set()
     for it in range(ncomb):
-        bitlen, taps, nchips = codes[int(rng.integers(0, len(codes)))]
+        bitlen, taps, nchips, sps = codes[int(rng.integers(0, len(codes)))]
         chips = chips_for(bitlen, taps, nchips)
-        n = 2 * nchips
+        n = sps * nchips
         Nint = int(rng.choice([0, 1, 1, 2]))
         ddof = int(rng.integers(0, 2))
         snr_rot = int(rng.choice([-1, -1, -2, 0]))
@@ -1044,15 +1044,15 @@ def test_randomised_option_sweep():
         nch = int(rng.integers(1, 3))
         ch = int(rng.integers(0, nch))
         mode = str(rng.choice(["band_numpy", "band_godual", "band_remote", "df"]))
-        seen.add((Nint, ddof, snr_rot, window, precision, nch, mode))
+        seen.add((Nint, ddof, snr_rot, window, precision, nch, mode, sps))
         df_true = float(rng.uniform(-6000, 6000)) if mode != "band_remote" else float(rng.uniform(41000, 59000))     # the bands search 2*df
         nwin = 3
         chans = [synth.SynthParams(delay_q8=int(rng.integers(0, n)) * 256 + int(rng.integers(0, 256)), fstep=synth.fstep_for_df(df_true + 3.0 * c, FS),
                                    phi0=int(rng.integers(0, 2 ** 32)), amp=int(rng.choice([0, 40, 300, 2000])),
                                    noise_gain=synth.noise_gain_for_sigma(float(rng.choice([60.0, 500.0, 2500.0]))), seed=int(rng.integers(1, 10 ** 6)), stream=c)
                  for c in range(nch)]
-        raw = synth.synth_capture(n * nwin, chips, 2, chans)
-        code = orc.make_code(chips, 2)
+        raw = synth.synth_capture(n * nwin, chips, sps, chans)
+        code = orc.make_code(chips, sps)
         fcode = orc.make_fcode(code, "hamming" if window == "hamming" else "godual")
         freq = orc.freq_axis(FS, n)
         temps = np.arange(n) / FS
@@ -1065,17 +1065,27 @@ def test_randomised_option_sweep():
         else:
             k = band = None
         dfs = [df_true + 0.37 * w for w in range(nwin)]
-        with Correlator(chips, fs=FS, Nint=Nint, var_ddof=ddof, snr_rot=snr_rot, window=window, precision=precision, max_batch=int(rng.integers(1, 4))) as cor:
-            got = cor.process(raw, nch, ch, band=band) if band is not None else cor.process(raw, nch, ch, df=dfs)
+        # a third of the combinations hand over what the reference's own call gets: the complex column d, mean already removed by the
+        # caller (godual_ranging.m:80), here with a gain and a rotation so that it is no longer integer-valued (twx_process_complex)
+        cplx = bool(rng.integers(0, 3) == 0)
+        gain = (0.37 + 0.11j) if cplx else 1.0
+        wins = []
+        for w in range(nwin):
+            d = orc.deinterleave(raw[w * n:(w + 1) * n], nch, ch)
+            wins.append((d - d.mean()) * gain)
+        with Correlator(chips, fs=FS, sps=sps, Nint=Nint, var_ddof=ddof, snr_rot=snr_rot, window=window, precision=precision, max_batch=int(rng.integers(1, 4))) as cor:
+            if cplx:
+                got = cor.processing_complex(np.concatenate(wins), k=band) if band is not None else cor.processing_complex(np.concatenate(wins), df=dfs)
+            else:
+                got = cor.process(raw, nch, ch, band=band) if band is not None else cor.process(raw, nch, ch, df=dfs)
         assert len(got) == nwin
         for w, g in enumerate(got):
-            d = orc.deinterleave(raw[w * n:(w + 1) * n], nch, ch)
-            d = d - d.mean()
+            d = wins[w]
             o = orc.processing(d, k, freq, temps, fcode, code, Nint=Nint, fs=FS, snr_rot=snr_rot, ddof=ddof, df=None if band is not None else dfs[w])
             try:
                 _check(g, o)
             except AssertionError as e:
-                raise AssertionError(f"combination {it}: Nint={Nint} ddof={ddof} snr_rot={snr_rot} window={window} {precision} nch={nch} ch={ch} {mode} window {w}: {e}") from e
+                raise AssertionError(f"combination {it}: {nchips} chips x {sps} Nint={Nint} ddof={ddof} snr_rot={snr_rot} window={window} {precision} nch={nch} ch={ch} {mode} complex_input={cplx} window {w}: {e}") from e
     assert len(seen) >= min(ncomb, 12)
 
 
