@@ -123,6 +123,15 @@ struct twx_tracked : twx_trk::Backend {
         c.var_ddof = 1;                         // Octave var
         c.snr_rot = -1;                         // codetmp(indice-1:end) (:91)
         c.precision = cfg.precision; c.device = cfg.device; c.max_batch = cfg.max_batch;
+        if (c.max_batch <= 0) {
+            // The flow measures the codes of ONE chunk and then looks at the records (does the window have to move?): nothing of the
+            // next chunk is in flight meanwhile, so the chunk should be one launch sequence, not four of 16 windows — batch = the codes
+            // of a chunk (the scripts' 2-s chunks of 40-ms codes: 50), at most 64 (A + Bz: 64 x 200 000 x 32 B = 0.4 GB per slot)
+            static const int forced = [] { const char* e = getenv("TWX_TRK_BATCH"); return e ? atoi(e) : 0; }();
+            const long long n_code = (long long)cfg.n_chips * std::max(cfg.sps, 1);
+            const long long per_chunk = n_code > 0 ? cfg.chunk_samples / n_code : 0;
+            c.max_batch = forced > 0 ? forced : (int)std::min<long long>(64, std::max<long long>(16, per_chunk));
+        }
         if (int rc = twx_create(&c, &ctx)) { err = twx_last_error(nullptr); return rc; }
         cfg.chips = nullptr;
         (void)hipGetDevice(&dev);
