@@ -1345,6 +1345,29 @@ def test_randomised_caf_ranges():
         assert np.abs(pk - pk_o).max() <= (MAG_TOL if precision == "f32" else 1e-12) * pk_o.max(), tag
 
 
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_records_do_not_depend_on_the_batch_size(precision):
+    """The same 37 two-channel windows through contexts of 1, 3, 8, 16, 37 and 64 windows per launch (whole and ragged last batches,
+    one to many batches on the three pipeline slots), carrier searched and supplied, one channel and all channels: the records are
+    byte-identical — no result depends on how the windows were grouped (the statistics are exact integer sums, every reduction has a
+    fixed order)."""
+    chips, raw = _capture(13, 27, 5000, 37, seed=77)
+    n = 2 * len(chips)
+    band = band_numpy(FS, n)
+    dfs = np.linspace(-900.0, 900.0, 37)
+    ref = None
+    for mb in (1, 3, 8, 16, 37, 64):
+        with Correlator(chips, fs=FS, Nint=1, precision=precision, max_batch=mb) as cor:
+            assert cor.info.batch == mb
+            got = (cor.process(raw, 2, 1, band=band, raw_records=True).tobytes() if "raw_records" in cor.process.__code__.co_varnames else None,
+                   [(r.indice, r.xval, r.correction, r.df, r.SNRr, r.SNRi, r.puissance, r.puissancecode, r.puissancenoise) for r in cor.process(raw, 2, 1, band=band)],
+                   [(r.indice, r.xval, r.correction, r.SNRr, r.puissancenoise) for r in cor.process(raw, 2, 0, df=dfs)],
+                   {c: [(r.indice, r.xval, r.df, r.SNRi) for r in v] for c, v in cor.process(raw, 2, -1, band=band).items()})
+        if ref is None:
+            ref = got
+        assert got == ref, mb
+
+
 def test_all_channels_from_one_copy(tmp_path):
     """channel = -1: both channels of every window from one upload / one pass over the file equal the per-channel calls
     (host buffer with more chunks than slots, device-resident, file)."""
