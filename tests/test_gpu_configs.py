@@ -957,3 +957,51 @@ def test_full_size_carrier_search_and_map_at_row_boundaries(precision):
             tol = (2e-6 if precision == "f32" else 1e-11) * abs(o["xval"])
             assert abs(g.xval - o["xval"]) <= tol and abs(g.xvalm1 - o["xvalm1"]) <= tol and abs(g.xvalp1 - o["xvalp1"]) <= tol, delay
             assert abs(g.correction - o["correction"]) <= 2e-4 and abs(g.SNRr - o["SNRr"]) <= 3e-4 * max(o["SNRr"], o["SNRi"])
+
+
+def test_randomised_acquisition_sweeps():
+    """The one-call acquisition (twx_acquire_cdev: coarse sweep, step halving until < 1 Hz, bookkeeping on the device) with random
+    centre, range and step — few and many trial carriers per round, the best carrier inside the range, on its edge or absent, the
+    B210 build's decimated sweep — against orc.rx_acquire on the same x2-interpolated stream (half rate: fs_in = 2.5 Msps, nobs =
+    200 000, nfft = 2^19 / 2^18): integer carrier and cblas_izamax lag exact, the peak within 3e-6.  TWX_SWEEP_OPTIONS raises the count."""
+    import torch
+    from amaranth_twstft_amd import acquisition as acq
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(8128)
+    ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "4"))
+    n_in, fs, rc, clen = 2_500_000, 5e6, 2.5e6, 100_000
+    nobs = int(fs) // 25
+    chips = chips_for(17, 9, clen)
+    code_pm1 = 1 - 2 * chips.astype(np.int64)
+    interp = acq.Interpolator(n_in)
+    smp_dev = torch.empty((2 * n_in, 2), dtype=torch.float32, device=dev)
+    accs = {d: acq.Acquisition(code_pm1, rc, fs, nobs, dec_a=d) for d in (1, 2)}
+    wavs = {d: orc.rx_replica(code_pm1, nobs, accs[d].nfft, rc, fs, clen, rc, -rc, dec_a=d)[0] for d in (1, 2)}
+    try:
+        for it in range(ncomb):
+            fc_true = float(rng.uniform(-3000, 3000))
+            amp = int(rng.choice([0, 500, 1500]))
+            p = synth.SynthParams(delay_q8=int(rng.integers(0, clen)) * 256, fstep=synth.fstep_for_df(fc_true, 2.5e6), phi0=int(rng.integers(0, 1 << 30)), amp=amp,
+                                  noise_gain=synth.noise_gain_for_sigma(700.0), seed=int(rng.integers(1, 10 ** 6)))
+            raw1 = synth.synth_channel(n_in, chips, 1, p)
+            raw = np.zeros((n_in, 4), dtype=np.int16)
+            raw[:, 0:2] = raw1
+            iq = torch.from_numpy(raw).to(dev)
+            interp(iq.data_ptr(), smp_dev.data_ptr(), n_channels=2, channel=0)
+            interp.cor.synchronize()
+            oA, _ = orc.rx_short2double(raw.reshape(-1), 2 * n_in)
+            dec_a = int(rng.integers(1, 3))
+            a = accs[dec_a]
+            fstep = float(rng.choice([16.0, 64.0, 256.0]))
+            frange = fstep * float(rng.choice([2, 4, 16]))
+            fc_init = float(np.round(fc_true + rng.choice([0.0, 0.4, -0.9, 1.0, 3.0]) * frange))      # inside, at the edge, outside the range
+            idx = int(rng.integers(0, (2 * n_in - a.nfft * dec_a) // nobs)) * nobs
+            tag = f"combination {it}: dec_a={dec_a} fc_true={fc_true:.1f} amp={amp} fc_init={fc_init} range={frange} step={fstep} idx={idx}"
+            fc, pk, pt = a.acquire(smp_dev.data_ptr(), idx, fc_init=fc_init, frange=frange, fstep=fstep)
+            fo, pko, pto = orc.rx_acquire(oA, idx, wavs[dec_a], nobs, a.nfft, fs, fc_init, frange, fstep, rc, -rc, dec_a=dec_a)
+            assert (fc, pt) == (fo, pto), (tag, fc, fo, pt, pto)
+            assert abs(pk - pko) <= 3e-6 * pko, tag
+    finally:
+        for a in accs.values():
+            a.close()
+        interp.close()
