@@ -1753,7 +1753,8 @@ __global__ __launch_bounds__(256) void k_caf_reduce(const ArgPart<T>* __restrict
 // One pass over the samples for up to SQ_NB bins at a time.  A thread walks the samples n0, n0 + stride, ...: its twiddle
 // exp(-2 pi i k n / L) starts from an exact integer phase reduction (one 64-bit modulo and one fp64 sincospi per bin and thread) and
 // advances by the constant factor exp(-2 pi i k stride / L) — a complex multiply per sample and bin where the first version paid
-// a modulo and a sincospi; re-seeded exactly every 32 steps.  Per-workgroup partials, added up in a fixed order by
+// a modulo and a sincospi; re-seeded exactly every 128 steps (fp64: 128 roundings of 1.1e-16; at 32 the re-seeding — eight 64-bit
+// modulos and fp64 sincospi per thread — was half of the kernel's instructions when a thread walks ~80 samples).  Per-workgroup partials, added up in a fixed order by
 // k_sq_dft_final: the first version's atomicAdd on the bins' 14 words (2 048 workgroups on each) was most of its 1.15 ms per
 // 10^7-sample chunk (same-address device atomics: ~0.4 us each, profiles/r04_tracked_rate.txt) and made the sums order-dependent.
 // grid = workgroups (any), partial[gridDim.x][nb][2]
@@ -1777,7 +1778,7 @@ __global__ __launch_bounds__(256) void k_sq_dft_bins(const short2* __restrict__ 
         }
         int step = 0;
         for (long long n = n0; n < L; n += stride, ++step) {
-            if ((step & 31) == 0) {
+            if ((step & 127) == 0) {
 #pragma unroll
                 for (int j = 0; j < TWX_SQ_NB; ++j) {
                     const unsigned long long t = ((unsigned long long)n * kk[j]) % (unsigned long long)L;     // n < L < 2^32 in every use: no overflow
