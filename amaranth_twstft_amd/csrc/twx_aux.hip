@@ -353,7 +353,7 @@ FirGeom fir_geom(int ntaps, int dec) {
 // Staging of a workgroup's input span into LDS, phase-major (NTH threads).
 template <int NTH>
 __device__ __forceinline__ void fir_stage(unsigned* __restrict__ X, const short2* __restrict__ x, int nch, long long nin, long long e0, int span, int D,
-                                          int PSQ, int tid) {
+                                          int PSQ, int tid, int ch) {
     // sample e = q*D + p of the span goes to slot(p, q) = p*PSQ + q: along e the slot advances by PSQ, and by 1 - (D-1)*PSQ
     // where p wraps — no division and no multiplication per sample.
     // Loads are UNCONDITIONAL (clamped indices): a load inside a divergent branch gets its own s_waitcnt vmcnt(0), which
@@ -386,6 +386,35 @@ __device__ __forceinline__ void fir_stage(unsigned* __restrict__ X, const short2
                 if (p >= D) { p -= D; ++q; }
             }
         }
+    } else if (nch == 2 && ((reinterpret_cast<unsigned long long>(x - ch + 2 * e0) & 15ull) == 0) && e0 + 4ll * nvec <= nin) {
+        // interior workgroup, a channel of a TWO-channel capture ([a0 b0 a1 b1 ...]; x points at this channel's sample of frame 0,
+        // x - ch at the frame): 16-B loads of two frames, the channel's two samples picked out — with 4-byte loads of every second
+        // word this path ran the kernel 60 % slower than the one-channel one (0.199 against 0.124 ms at 70 Msps, tools/fir_nch.py)
+        const int4* xv = reinterpret_cast<const int4*>(x - ch + 2 * e0);
+        const int nvec2 = span >> 1;
+        const int dq2 = (2 * NTH) / D, dp2 = 2 * NTH - dq2 * D;
+        int q = (2 * tid) / D, p = 2 * tid - q * D;
+        for (int jb = 0; jb < nvec2; jb += 8 * NTH) {
+            int4 raw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) raw[u] = xv[min(jb + u * NTH + tid, nvec2 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = jb + u * NTH + tid;
+                const int w2[2] = {ch ? raw[u].y : raw[u].x, ch ? raw[u].w : raw[u].z};
+                int slot = p * PSQ + q, pp = p;
+                if (j < nvec2) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        X[slot] = (unsigned)w2[i];
+                        slot += PSQ;
+                        if (++pp >= D) { pp = 0; slot -= wrap; }
+                    }
+                }
+                q += dq2; p += dp2;
+                if (p >= D) { p -= D; ++q; }
+            }
+        }
     } else {
         const int dq = NTH / D, dp = NTH - dq * D;
         int q = tid / D, p = tid - q * D;
@@ -415,7 +444,7 @@ __device__ __forceinline__ void fir_stage(unsigned* __restrict__ X, const short2
 template <int SHT>
 __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ x, int nch, long long nin, const float* __restrict__ hp,
                                                      int D, int SH_rt, int PSQ, int HROW, int lastn, long long nout,
-                                                     short2* __restrict__ y16, float2* __restrict__ yf) {
+                                                     short2* __restrict__ y16, float2* __restrict__ yf, int ch) {
     extern __shared__ uint4 X4[];                                   // raw int16 IQ pairs: 4 B per sample, converted when read
     unsigned* X = reinterpret_cast<unsigned*>(X4);
     const int SH = SHT > 0 ? SHT : SH_rt;
@@ -424,7 +453,7 @@ __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ 
     const long long e0 = m0 * D;
     const int nq = FIR_K * (FIR_NT + SH);                          // q values staged per phase
     const int span = nq * D;                                       // a multiple of 4
-    fir_stage<FIR_NT>(X, x, nch, nin, e0, span, D, PSQ, tid);
+    fir_stage<FIR_NT>(X, x, nch, nin, e0, span, D, PSQ, tid, ch);
     __syncthreads();
     // (I, Q) of an output as one 2-vector: one v_pk_fma_f32 per tap and output with the wave-uniform tap broadcast from its
     // scalar register.  Measured equal to the two v_fmac_f32 with a scalar operand it replaces (0.187 ms both: a packed fp32
@@ -512,7 +541,7 @@ __global__ __launch_bounds__(FIR_NT) void k_fir_poly(const short2* __restrict__ 
 template <int SHT, int LASTN>
 __global__ __launch_bounds__(FIR8_NT) void k_fir_poly8(const short2* __restrict__ x, int nch, long long nin, const float* __restrict__ hp,
                                                        int D, int PSQ, int HROW, int nfull, long long nout,
-                                                       short2* __restrict__ y16, float2* __restrict__ yf) {
+                                                       short2* __restrict__ y16, float2* __restrict__ yf, int ch) {
     extern __shared__ uint4 X4[];
     unsigned* X = reinterpret_cast<unsigned*>(X4);
     constexpr int K = FIR8_K, A = 4 * SHT + LASTN - (K + 3);
@@ -522,7 +551,7 @@ __global__ __launch_bounds__(FIR8_NT) void k_fir_poly8(const short2* __restrict_
     const long long m0 = (long long)blockIdx.x * FIR8_OUT;
     const long long e0 = m0 * D;
     const int span = (FIR8_OUT + 4 * SHT) * D;                      // a multiple of 4
-    fir_stage<FIR8_NT>(X, x, nch, nin, e0, span, D, PSQ, tid);
+    fir_stage<FIR8_NT>(X, x, nch, nin, e0, span, D, PSQ, tid, ch);
     __syncthreads();
     typedef float pk2 __attribute__((ext_vector_type(2)));
     pk2 acc[K];
@@ -608,7 +637,7 @@ std::vector<float> fir_phase_table(const float* taps, int ntaps, int dec, const 
     return hp;
 }
 int launch_fir(hipStream_t st, const short2* dx, int nch, long long nin, const float* hp_dev, int ntaps, int dec, long long nout,
-               short2* dy16, float2* dyf) {
+               short2* dy16, float2* dyf, int ch = 0) {            // dx: the channel's sample of frame 0; ch: its place in the frame
     const FirGeom g = fir_geom(ntaps, dec);
     static bool attr_set = false;
     if (!attr_set) {
@@ -629,7 +658,7 @@ int launch_fir(hipStream_t st, const short2* dx, int nch, long long nin, const f
         hipError_t attr = hipSuccess;
 #define FIR8_GO(SHT_, LN_) do { static bool set = false; auto* fn = &k_fir_poly8<SHT_, LN_>; \
             if (!set) { attr = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = attr == hipSuccess; } \
-            if (set) hipLaunchKernelGGL(fn, dim3(grid8), dim3(FIR8_NT), lds8, st, dx, nch, nin, hp_dev, dec, g.PSQ, g.HROW, nfull, nout, dy16, dyf); } while (0)
+            if (set) hipLaunchKernelGGL(fn, dim3(grid8), dim3(FIR8_NT), lds8, st, dx, nch, nin, hp_dev, dec, g.PSQ, g.HROW, nfull, nout, dy16, dyf, ch); } while (0)
 #define FIR8_LN(SHT_) switch (g.LASTN) { case 1: FIR8_GO(SHT_, 1); break; case 2: FIR8_GO(SHT_, 2); break; case 3: FIR8_GO(SHT_, 3); break; default: FIR8_GO(SHT_, 4); break; }
         switch (g.SH) {
             case 4: FIR8_GO(4, 4); break;                            // A <= 9 (padded up): one instantiation
@@ -644,7 +673,7 @@ int launch_fir(hipStream_t st, const short2* dx, int nch, long long nin, const f
         return hipGetLastError() == hipSuccess ? TWX_OK : TWX_E_HIP;
     }
     const unsigned grid = (unsigned)((nout + FIR_OUT - 1) / FIR_OUT);
-#define FIR_GO(SHT_) hipLaunchKernelGGL((k_fir_poly<SHT_>), dim3(grid), dim3(FIR_NT), g.lds, st, dx, nch, nin, hp_dev, dec, g.SH, g.PSQ, g.HROW, g.LASTN, nout, dy16, dyf)
+#define FIR_GO(SHT_) hipLaunchKernelGGL((k_fir_poly<SHT_>), dim3(grid), dim3(FIR_NT), g.lds, st, dx, nch, nin, hp_dev, dec, g.SH, g.PSQ, g.HROW, g.LASTN, nout, dy16, dyf, ch)
     switch (g.SH) {                                       // unrolled instantiations for the usual tap counts, generic loop otherwise
         case 4: FIR_GO(4); break;   case 5: FIR_GO(5); break;   case 6: FIR_GO(6); break;   case 7: FIR_GO(7); break;
         case 8: FIR_GO(8); break;   case 9: FIR_GO(9); break;   case 10: FIR_GO(10); break; case 11: FIR_GO(11); break;
@@ -718,7 +747,7 @@ static int twx_fir_decimate_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n
         shadow.assign(reinterpret_cast<const unsigned char*>(hp.data()), reinterpret_cast<const unsigned char*>(hp.data()) + hp_bytes);
     }
     const int rc = launch_fir(st, reinterpret_cast<const short2*>(iq_dev) + channel, n_channels, n_in, hp_dev, ntaps, dec, nout,
-                              reinterpret_cast<short2*>(out_i16_dev), reinterpret_cast<float2*>(out_f32_dev));
+                              reinterpret_cast<short2*>(out_i16_dev), reinterpret_cast<float2*>(out_f32_dev), channel);
     return rc ? twx::ctx_fail(ctx, rc, "twx_fir_decimate_dev: launch failed") : TWX_OK;
 }
 
@@ -750,7 +779,7 @@ static int twx_fir_decimate_impl(const int16_t* iq, int64_t n_in, int32_t n_chan
     if (hipMemcpy(dx.p, iq, (size_t)n_in * n_channels * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(dh.p, hp.data(), hp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return TWX_E_HIP;
     if (int rc = launch_fir(nullptr, static_cast<const short2*>(dx.p) + channel, n_channels, n_in, static_cast<const float*>(dh.p), ntaps, dec, nout,
-                            static_cast<short2*>(dy16.p), static_cast<float2*>(dyf.p))) return rc;
+                            static_cast<short2*>(dy16.p), static_cast<float2*>(dyf.p), channel)) return rc;
     if (out_i16 && hipMemcpy(out_i16, dy16.p, (size_t)nout * 4, hipMemcpyDeviceToHost) != hipSuccess) return TWX_E_HIP;
     if (out_f32 && hipMemcpy(out_f32, dyf.p, (size_t)nout * 8, hipMemcpyDeviceToHost) != hipSuccess) return TWX_E_HIP;
     return TWX_OK;
