@@ -22,7 +22,8 @@ Parity pinning (see tests/golden/README.md, tools/make_golden.py):
   * The reference holds NO test vectors of its own for the correlator, and the
     Octave-only variants (``processing_claudio``, ``search_df``, ``ranging_tracked``, ``go_1s_session``, the QPSK form of ``make_code_variant``,
     ``peak_refine_polyfit``), the C++-only Hamming window
-    and the 231001_DLL_PLL acquisition/tracking restatements (incl. the receiver program ``rx_second``) have no runnable twin here:
+    and the 231001_DLL_PLL acquisition/tracking restatements (incl. the receiver programs ``rx_second`` — rxcomplex.cpp and, with
+    ``real=True``, rx.cpp with its interference cancellation ``rx_mai_up`` / ``rx_mai_out``) have no runnable twin here:
     for those functions parity is UNPINNED (hand restatement, cross-checked by identities).
 """
 from __future__ import annotations
