@@ -346,3 +346,37 @@ def test_design_quotes_the_committed_profiles():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.check(verbose=False) == 0
+
+
+def test_every_ctypes_struct_has_the_layout_of_the_header(tmp_path):
+    """Each ``twx_*`` structure of amaranth_twstft_amd/_lib.py against include/twstft_hip.h as gcc lays it out: the size and the
+    offset and size of every field (a C program generated from the ctypes definitions prints them).  A field renamed, re-ordered
+    or re-typed on one side only would otherwise show up as garbage in some result far from here."""
+    import inspect
+    import subprocess
+    structs = [(n, c) for n, c in inspect.getmembers(L, inspect.isclass) if issubclass(c, C.Structure) and n.startswith("twx_") and hasattr(c, "_fields_")]
+    assert len(structs) >= 15
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "twstft_hip.h"', 'int main(void) {']
+    for n, c in structs:
+        lines.append(f'  printf("{n} %zu\\n", sizeof({n}));')
+        for f in c._fields_:
+            lines.append(f'  printf("{n}.{f[0]} %zu %zu\\n", offsetof({n}, {f[0]}), sizeof((({n}*)0)->{f[0]}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    want = {}
+    for ln in out:
+        p = ln.split()
+        if len(p) == 2:
+            want[p[0]] = (int(p[1]),)
+        elif len(p) == 3:
+            want[p[0]] = (int(p[1]), int(p[2]))
+    for n, c in structs:
+        assert want[n] == (C.sizeof(c),), (n, want[n], C.sizeof(c))
+        for f in c._fields_:
+            d = getattr(c, f[0])
+            assert want[f"{n}.{f[0]}"] == (d.offset, d.size), (n, f[0], want[f"{n}.{f[0]}"], (d.offset, d.size))
