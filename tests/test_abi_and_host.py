@@ -380,3 +380,48 @@ def test_every_ctypes_struct_has_the_layout_of_the_header(tmp_path):
         for f in c._fields_:
             d = getattr(c, f[0])
             assert want[f"{n}.{f[0]}"] == (d.offset, d.size), (n, f[0], want[f"{n}.{f[0]}"], (d.offset, d.size))
+
+
+def test_every_binding_has_the_argument_list_of_the_header():
+    """The ctypes prototypes of _lib.SYMBOLS against the declarations of include/twstft_hip.h: argument count, and for every argument
+    and the return value the class of its type (pointer / 32-bit integer / 64-bit integer / double / float / void).  The C ABI does
+    not check what a caller pushes: a binding one argument short, or an int where the header says int64_t, works until it does not."""
+    txt = open(os.path.join(ROOT, "include", "twstft_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"^\s*#.*$", "", txt, flags=re.M)
+    decls = dict()
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(twx_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", txt):
+        decls[m.group(2)] = (m.group(1).strip(), m.group(3).strip())
+    assert set(decls) == set(L.SYMBOLS), set(decls) ^ set(L.SYMBOLS)
+
+    def c_class(t):
+        t = t.strip()
+        if "*" in t:
+            return "ptr"
+        t = re.sub(r"\bconst\b", "", t).strip()
+        t = re.sub(r"\s+[A-Za-z_][A-Za-z0-9_]*(\[\d*\])?$", "", t).strip() if " " in t else t          # drop the parameter name
+        return {"void": "void", "int": "i32", "int32_t": "i32", "uint32_t": "i32", "int64_t": "i64", "uint64_t": "i64", "long long": "i64",
+                "size_t": "i64", "double": "f64", "float": "f32"}.get(t, "?" + t)
+
+    def py_class(t):
+        if t is None:
+            return "void"
+        if t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents") or (isinstance(t, type) and issubclass(t, C._Pointer)):
+            return "ptr"
+        return {C.c_int: "i32", C.c_int32: "i32", C.c_uint32: "i32", C.c_int64: "i64", C.c_uint64: "i64", C.c_longlong: "i64", C.c_size_t: "i64",
+                C.c_double: "f64", C.c_float: "f32"}.get(t, "?" + repr(t))
+
+    bad = []
+    for name, (ret, args) in sorted(decls.items()):
+        res, argtypes = L.SYMBOLS[name]
+        cargs = [] if args in ("", "void") else [a for a in args.split(",")]
+        cl = [c_class(a) for a in cargs]
+        if any("[" in a for a in cargs):                                   # array parameters decay to pointers
+            cl = ["ptr" if "[" in a else c for a, c in zip(cargs, cl)]
+        pl = [py_class(t) for t in argtypes]
+        if cl != pl:
+            bad.append((name, cl, pl))
+        rc = "ptr" if "*" in ret else c_class(ret + " x")
+        if rc != py_class(res):
+            bad.append((name, "return", rc, py_class(res)))
+    assert not bad, bad
