@@ -191,7 +191,9 @@ int twx_fft_forward(twx_ctx* ctx, const double* in, double* out);
 /* conj(fft(code)) (× window) as held by the context, natural order, interleaved re/im doubles. */
 int twx_get_code_spectrum(twx_ctx* ctx, double* out);
 /* Full interpolated correlation map prnmap (godual_ranging.m:28) of ONE window: (2*nint+1)*N
- * complex doubles (host).  Slow path for tests. */
+ * complex doubles (host).  Slow path for tests.  Always the godual form ifft(pad(fft(y).*fcode)), also in a TWX_CONV_CLAUDIO
+ * context, whose own map is the mirrored conjugate prnmap_c[m] = conj(prnmap[(M - m) mod M]) (the records carry that index
+ * and those samples; magnitudes, maxima and variances of the two maps are the same). */
 int twx_xcorr_map(twx_ctx* ctx, const int16_t* iq, int32_t n_channels, int32_t channel, double df,
                   double* out);
 

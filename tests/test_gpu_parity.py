@@ -1406,6 +1406,52 @@ def test_fine_frequency_step_with_other_options():
             assert abs(g.puissance - o["puissance"]) <= 1e-6 * o["puissance"], tag
 
 
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+@pytest.mark.parametrize("variant", ["claudio", "hamming", "unipolar_zero_mean", "qpsk"])
+@pytest.mark.parametrize("bitlen,taps,nchips", [(13, 27, 5000), (17, 9, 100000)])
+def test_whole_correlation_map_of_the_variants(bitlen, taps, nchips, variant, precision):
+    """Every lag of the map for the replica / convention variants too: the claudio convention (ifft of fcode.*conj(ffty), the mirrored
+    conjugate of the godual map), the Hamming-windowed spectrum, the 0/1 zero-mean and the complex QPSK replicas."""
+    chips = chips_for(bitlen, taps, nchips)
+    n = 2 * nchips
+    p = synth.SynthParams(delay_q8=(n // 7 + 3) * 256 + 200, fstep=synth.fstep_for_df(750.0, FS), phi0=7, amp=700,
+                          noise_gain=synth.noise_gain_for_sigma(300.0), seed=nchips + 1)
+    raw = synth.synth_channel(n, chips, 2, p)
+    x = orc.deinterleave(raw, 1, 0)
+    x = x - x.mean()
+    y = x * np.exp(-2j * np.pi * 750.0 * np.arange(n) / FS)
+    fy = np.fft.fft(y)
+    kw, cq = {}, None
+    if variant == "claudio":
+        fcode = orc.make_fcode(orc.make_code(chips, 2), "claudio")
+        kw = dict(convention="claudio")
+    elif variant == "hamming":
+        fcode = orc.make_fcode(orc.make_code(chips, 2), "hamming")
+        kw = dict(window="hamming")
+    else:
+        cq = chips_for(bitlen, taps + 2, nchips) if variant == "qpsk" else None
+        fcode = np.conj(np.fft.fft(orc.make_code_variant(chips, cq, 2, unipolar=True, zero_mean=True)))
+        kw = dict(chips_q=cq, code_levels="unipolar", code_zero_mean=True)
+    tol = 2e-6 if precision == "f32" else 1e-12
+    for Nint in (0, 1):
+        with Correlator(chips, fs=FS, Nint=Nint, precision=precision, **kw) as cor:
+            z = cor.xcorr_map(raw, 750.0, n_channels=1, channel=0)
+        if variant == "claudio":
+            r = 2 * Nint + 1
+            mul = fcode * np.conj(fy)                                           # claudio_aligned_code_ranging_separate.m:59-61
+            pad = np.zeros(r * n, dtype=complex)
+            pad[:n // 2] = mul[:n // 2]
+            pad[-(n // 2):] = mul[-(n // 2):]
+            zc = np.fft.ifft(pad)
+            # the map entry always returns the godual form (header); the claudio map is its mirrored conjugate:
+            # prnmap_c[m] = conj(prnmap_g[(M - m) mod M]) — which is what k_peak applies to the index and the samples
+            zr = np.conj(zc[(-np.arange(r * n)) % (r * n)])
+        else:
+            zr = orc.xcorr_interp(fy, fcode, Nint)
+        err = np.abs(z - zr)
+        assert err.max() <= tol * np.abs(zr).max(), (variant, precision, Nint, int(err.argmax()), float(err.max() / np.abs(zr).max()))
+
+
 def test_all_channels_from_one_copy(tmp_path):
     """channel = -1: both channels of every window from one upload / one pass over the file equal the per-channel calls
     (host buffer with more chunks than slots, device-resident, file)."""
