@@ -47,18 +47,24 @@ def _capture(bitlen, taps, nchips, nwin, seed, df=(1780.75, 0.0), amp=(300, 3000
     return chips, synth.synth_capture(n * nwin, chips, 2, chans)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f64"])
 @pytest.mark.parametrize("bitlen,taps,nchips", [(13, 27, 5000), (14, 43, 10000), (15, 3, 25000), (17, 9, 100000),
-                                                 (18, 39, 250000), (19, 39, 500000)])
-def test_fft_and_code_spectrum(bitlen, taps, nchips):
+                                                 (18, 39, 250000), (19, 39, 500000),
+                                                 # plug-in lengths: N = 5000, 25000, 4000, 80000, 81000, 14000, 6000, 12000, 18000, 2^16, 2^19, 2^20
+                                                 (13, 27, 2500), (15, 3, 12500), (12, 83, 2000), (16, 45, 40000), (16, 45, 40500), (13, 27, 7000),
+                                                 (12, 83, 3000), (13, 27, 6000), (14, 43, 9000), (16, 45, 32768), (18, 39, 262144), (19, 39, 524288)])
+def test_fft_and_code_spectrum(bitlen, taps, nchips, precision):
+    """The N-point transform of the context (twx_fft_forward: column pass + ROW_STORE row pass) and its code spectrum against numpy,
+    every output, for every window length the library or its plug-ins hold, in both precisions."""
     chips = chips_for(bitlen, taps, nchips)
     n = 2 * nchips
-    with Correlator(chips, fs=FS) as cor:
+    with Correlator(chips, fs=FS, precision=precision) as cor:
         rng = np.random.default_rng(n)
         x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
         ref = np.fft.fft(x)
-        assert np.abs(cor.fft(x) - ref).max() <= 1e-6 * np.abs(ref).max()
+        assert np.abs(cor.fft(x) - ref).max() <= (1e-6 if precision == "f32" else 1e-13) * np.abs(ref).max()
         cref = orc.make_fcode(orc.make_code(chips, 2))
-        assert np.abs(cor.code_spectrum() - cref).max() <= 2e-7 * np.abs(cref).max()
+        assert np.abs(cor.code_spectrum() - cref).max() <= (2e-7 if precision == "f32" else 1e-13) * np.abs(cref).max()
 
 
 @pytest.mark.parametrize("bitlen,taps,nchips,nwin", [(13, 27, 5000, 5), (14, 57, 10000, 4), (15, 17, 25000, 3),
