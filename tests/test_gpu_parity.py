@@ -1458,6 +1458,45 @@ def test_whole_correlation_map_of_the_variants(bitlen, taps, nchips, variant, pr
         assert err.max() <= tol * np.abs(zr).max(), (variant, precision, Nint, int(err.argmax()), float(err.max() / np.abs(zr).max()))
 
 
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_degenerate_windows(precision):
+    """Windows the formulas divide by zero on: all zeros, a constant (the mean removal leaves zeros), one impulse, a single
+    step, all in one call beside an ordinary window.  The library and the oracle (numpy, like the reference) agree on the lag
+    — ties resolve to the FIRST maximum in both — and on WHICH quantities are not numbers; an ordinary window in the same batch is
+    not disturbed."""
+    import warnings
+    chips = chips_for(13, 27, 5000)
+    n = 10000
+    code = orc.make_code(chips, 2)
+    fcode = orc.make_fcode(code)
+    temps = np.arange(n) / FS
+    p = synth.SynthParams(delay_q8=777 * 256, fstep=synth.fstep_for_df(0.0, FS), phi0=1, amp=400, noise_gain=synth.noise_gain_for_sigma(300.0), seed=2)
+    wins = [np.zeros((n, 2), np.int16), np.full((n, 2), 1234, np.int16), np.zeros((n, 2), np.int16), np.zeros((n, 2), np.int16), synth.synth_channel(n, chips, 2, p).reshape(n, 2)]
+    wins[2][4321, 0] = 20000                                           # one impulse
+    wins[3][:, 0] = np.where(np.arange(n) < n // 2, 3000, -3000)      # one step, zero mean (a periodic wave would tie its own periods)
+    raw = np.concatenate(wins)
+    with Correlator(chips, fs=FS, Nint=1, precision=precision) as cor:
+        got = cor.process(raw, 1, 0, df=0.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with np.errstate(all="ignore"):
+            for w, g in enumerate(got):
+                d = orc.deinterleave(wins[w], 1, 0)
+                d = d - d.mean()
+                o = orc.processing(d, None, None, temps, fcode, code, Nint=1, fs=FS, df=0.0)
+                assert g.indice == o["indice"], (w, g.indice, o["indice"])
+                for key in ("correction", "SNRr", "SNRi", "puissancenoise", "puissancecode", "puissance"):
+                    a, b = getattr(g, key), o[key]
+                    assert np.isnan(a) == np.isnan(b), (w, key, a, b)
+                    if not np.isnan(b) and w >= 2:
+                        tol = 2e-4 if key == "correction" else 3e-4 * max(abs(b), abs(o["SNRr"]), abs(o["SNRi"]), 1e-300) + 1e-30
+                        assert abs(a - b) <= tol, (w, key, a, b)
+                if w >= 2:
+                    assert abs(abs(g.xval) - abs(o["xval"])) <= 2e-6 * abs(o["xval"]), w
+                else:
+                    assert g.xval == 0 and g.puissance == 0
+
+
 def test_all_channels_from_one_copy(tmp_path):
     """channel = -1: both channels of every window from one upload / one pass over the file equal the per-channel calls
     (host buffer with more chunks than slots, device-resident, file)."""
