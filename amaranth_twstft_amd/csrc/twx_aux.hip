@@ -11,6 +11,7 @@
 #include <string.h>
 #include <algorithm>
 #include <new>
+#include <atomic>
 #include <vector>
 #include "twx_internal.h"
 #include "twx_track_core.h"
@@ -639,15 +640,20 @@ std::vector<float> fir_phase_table(const float* taps, int ntaps, int dec, const 
 int launch_fir(hipStream_t st, const short2* dx, int nch, long long nin, const float* hp_dev, int ntaps, int dec, long long nout,
                short2* dy16, float2* dyf, int ch = 0) {            // dx: the channel's sample of frame 0; ch: its place in the frame
     const FirGeom g = fir_geom(ntaps, dec);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // The dynamic-LDS limit is an attribute of the function ON A DEVICE: one bit per device (contexts on several devices and host
+    // threads — twx_multi — may get here together; the attribute call is idempotent)
+    static std::atomic<unsigned long long> attr_devs{0};
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    const unsigned long long dev_bit = 1ull << (cur_dev & 63);
+    if (!(attr_devs.load() & dev_bit)) {
         const void* fns[] = {(const void*)&k_fir_poly<0>, (const void*)&k_fir_poly<4>, (const void*)&k_fir_poly<5>, (const void*)&k_fir_poly<6>,
                              (const void*)&k_fir_poly<7>, (const void*)&k_fir_poly<8>, (const void*)&k_fir_poly<9>, (const void*)&k_fir_poly<10>,
                              (const void*)&k_fir_poly<11>, (const void*)&k_fir_poly<12>, (const void*)&k_fir_poly<13>, (const void*)&k_fir_poly<14>,
                              (const void*)&k_fir_poly<15>, (const void*)&k_fir_poly<16>};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return TWX_E_HIP;
-        attr_set = true;
+        attr_devs.fetch_or(dev_bit);
     }
     if (g.K == FIR8_K) {
         const unsigned grid8 = (unsigned)((nout + FIR8_OUT - 1) / FIR8_OUT);
@@ -656,9 +662,9 @@ int launch_fir(hipStream_t st, const short2* dx, int nch, long long nin, const f
         const int a_t = 4 * g.SH + (g.SH == 4 ? 4 : g.LASTN) - (FIR8_K + 3);      // taps per phase of the instantiation chosen below
         const int nfull = a_t == g.A ? ntaps - (g.A - 1) * dec : dec;
         hipError_t attr = hipSuccess;
-#define FIR8_GO(SHT_, LN_) do { static bool set = false; auto* fn = &k_fir_poly8<SHT_, LN_>; \
-            if (!set) { attr = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = attr == hipSuccess; } \
-            if (set) hipLaunchKernelGGL(fn, dim3(grid8), dim3(FIR8_NT), lds8, st, dx, nch, nin, hp_dev, dec, g.PSQ, g.HROW, nfull, nout, dy16, dyf, ch); } while (0)
+#define FIR8_GO(SHT_, LN_) do { static std::atomic<unsigned long long> set{0}; auto* fn = &k_fir_poly8<SHT_, LN_>; \
+            if (!(set.load() & dev_bit)) { attr = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr == hipSuccess) set.fetch_or(dev_bit); } \
+            if (set.load() & dev_bit) hipLaunchKernelGGL(fn, dim3(grid8), dim3(FIR8_NT), lds8, st, dx, nch, nin, hp_dev, dec, g.PSQ, g.HROW, nfull, nout, dy16, dyf, ch); } while (0)
 #define FIR8_LN(SHT_) switch (g.LASTN) { case 1: FIR8_GO(SHT_, 1); break; case 2: FIR8_GO(SHT_, 2); break; case 3: FIR8_GO(SHT_, 3); break; default: FIR8_GO(SHT_, 4); break; }
         switch (g.SH) {
             case 4: FIR8_GO(4, 4); break;                            // A <= 9 (padded up): one instantiation
