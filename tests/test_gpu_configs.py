@@ -967,7 +967,7 @@ def test_randomised_acquisition_sweeps():
     import torch
     from amaranth_twstft_amd import acquisition as acq
     dev = torch.device("cuda", 0)
-    rng = np.random.default_rng(8128)
+    rng = np.random.default_rng(8128 + int(os.environ.get("TWX_SWEEP_SEED", "0")))
     ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "4"))
     n_in, fs, rc, clen = 2_500_000, 5e6, 2.5e6, 100_000
     nobs = int(fs) // 25

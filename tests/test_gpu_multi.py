@@ -202,7 +202,7 @@ def test_randomised_partitions_equal_one_context(tmp_path):
     channel / all channels, band or supplied carrier, file skip and window limit, host-buffer and file entry — the gathered records
     byte-identical to ONE context's, whatever the partition (blocks of 0 windows, fewer windows than contexts, ragged blocks)."""
     from tests.test_gpu_parity import _capture
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(99 + int(os.environ.get("TWX_SWEEP_SEED", "0")))
     chips, raw_all = _capture(13, 27, 5000, 23, seed=5)
     n = 2 * len(chips)
     band = band_godual(FS, n)

@@ -1034,7 +1034,7 @@ def test_randomised_option_sweep():
     Hamming-windowed replica, fp32 / fp64, carrier searched over one of the three bands or supplied, one- and two-channel frames,
     strong to noise-dominated windows — the combinations the single-option tests above do not meet — against the oracle with the
     same settings: integer lag and carrier exact, the rest within the tolerances of _check.  TWX_SWEEP_OPTIONS raises the count."""
-    rng = np.random.default_rng(424242)
+    rng = np.random.default_rng(424242 + int(os.environ.get("TWX_SWEEP_SEED", "0")))
     ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "16"))
     codes = [(13, 27, 5000, 2), (14, 57, 10000, 2), (13, 27, 5000, 1), (13, 27, 5000, 4), (13, 27, 2500, 4), (14, 57, 10000, 1)]     # chips x samples per chip
     seen = set()
@@ -1100,7 +1100,7 @@ def test_randomised_option_sweep_conventions_and_replicas():
     variants of the experiment scripts (0/1 levels, zero mean, complex QPSK replica) against a direct ifft(fft(y).*fcode), and the
     all-channel call (both channels of a two-channel capture from one copy) — each with random interpolation factor, precision, batch
     size and signal level.  TWX_SWEEP_OPTIONS raises the count."""
-    rng = np.random.default_rng(777)
+    rng = np.random.default_rng(777 + int(os.environ.get("TWX_SWEEP_SEED", "0")))
     ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "16"))
     codes = [(13, 27, 5000), (14, 57, 10000)]
     for it in range(ncomb):
@@ -1240,7 +1240,7 @@ def test_randomised_fir_and_sliding_shapes():
     step-group count, the generic loop); the sliding dot product over period, code count, lag window 0..31, channel layout, start
     offset, carrier and phase (the three tiles and their fall-backs).  TWX_SWEEP_OPTIONS raises the count."""
     from amaranth_twstft_amd import frontend, tracking
-    rng = np.random.default_rng(31337)
+    rng = np.random.default_rng(31337 + int(os.environ.get("TWX_SWEEP_SEED", "0")))
     ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "16"))
     for it in range(ncomb):
         # ---- FIR
@@ -1285,7 +1285,7 @@ def test_randomised_tracked_flows():
     to weak signals, fp32 and fp64.  The control flow decides on thresholds, so a window that is measured a hair differently shows
     up as a different `moved` list: everything must agree.  TWX_SWEEP_OPTIONS raises the count."""
     from amaranth_twstft_amd.tracked import TrackedRanging
-    rng = np.random.default_rng(2718)
+    rng = np.random.default_rng(2718 + int(os.environ.get("TWX_SWEEP_SEED", "0")))
     ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "6"))
     for it in range(ncomb):
         mode, OP = [("ranging", 0), ("lo", 0), ("re", 0), ("re", 1)][int(rng.integers(0, 4))]
@@ -1325,7 +1325,7 @@ def test_randomised_caf_ranges():
     (the k1 rotation carries into k2, negative bins), 1 to ~150 bins (whole and ragged groups of bins per workgroup and per
     launch), one / two channels, signal from strong to absent (the arg-max of every bin decided among noise peaks): every bin's lag
     bit-exact, its peak within 1e-6.  TWX_SWEEP_OPTIONS raises the count."""
-    rng = np.random.default_rng(55555)
+    rng = np.random.default_rng(55555 + int(os.environ.get("TWX_SWEEP_SEED", "0")))
     ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "8"))
     shapes = [(13, 27, 5000), (14, 57, 10000), (16, 45, 32768), (17, 9, 100000)]
     for it in range(ncomb):
@@ -1380,7 +1380,7 @@ def test_fine_frequency_step_with_other_options():
     fs/3 samples, so N = 2e6) combined with the other options — interpolation factor, variance convention, precision, one- / two-channel
     frames, all-channel call — against orc.processing(fine_freq=True).  The golden test above pins the default combination to the
     reference's own return values; this one walks around it."""
-    rng = np.random.default_rng(1123)
+    rng = np.random.default_rng(1123 + int(os.environ.get("TWX_SWEEP_SEED", "0")))
     nchips, n = 1_000_000, 2_000_000
     chips = chips_for(21, 5, nchips)
     code = orc.make_code(chips, 2)

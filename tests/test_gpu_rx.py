@@ -299,7 +299,7 @@ def test_randomised_receiver_scenarios():
     re-acquisition), the X310 / B210 builds (dec_a), rxcomplex / rx with 'S' rows behind 'N' rows of the other code — the state of
     every row after every second (status, integer carrier, code phase, usable periods) equal to oracle.rx_second, the measured
     quantities within the fp32 tolerances.  TWX_SWEEP_OPTIONS raises the count."""
-    rng = np.random.default_rng(161803)
+    rng = np.random.default_rng(161803 + int(os.environ.get("TWX_SWEEP_SEED", "0")))
     ncomb = int(os.environ.get("TWX_SWEEP_OPTIONS", "3"))
     fs_in, n_in = 2.5e6, 2_500_000
     codes = {100: chips_for(17, 9, CLEN), 101: chips_for(17, 15, CLEN)}
