@@ -953,26 +953,65 @@ def rx_v2todbm(v2: float) -> float:
     return 10.0 * np.log10(v2 * 1000.0 / 25.0) if v2 > 0.0 else 0.0
 
 
+def _c_sscanf(line: str, fmt: str):
+    """``sscanf(line, fmt)`` for the conversions the program uses (``%s %d %lf`` separated by blanks): every directive skips white
+    space; ``%s`` takes the run of non-blank characters, ``%d`` the longest decimal-integer prefix (strtol), ``%lf`` the longest
+    floating-point prefix (strtod: digits, point, exponent, inf / nan) — and the NEXT directive goes on right behind it, inside the
+    same token if something is left of it ("100.5" read with ``%d %lf`` gives 100 and .5).  Returns the converted values; the scan
+    stops at the first directive that cannot convert."""
+    import re
+    out, pos = [], 0
+    num = re.compile(r"[+-]?(?:(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?|[iI][nN][fF](?:[iI][nN][iI][tT][yY])?|[nN][aA][nN])")
+    for d in fmt.split():
+        while pos < len(line) and line[pos] in " \t\n\r\v\f":
+            pos += 1
+        if pos >= len(line):
+            break
+        if d == "%s":
+            m = re.compile(r"\S+").match(line, pos)
+            out.append(m.group(0))
+        elif d == "%d":
+            m = re.compile(r"[+-]?\d+").match(line, pos)
+            if not m:
+                break
+            out.append(int(m.group(0)))
+        elif d == "%lf":
+            m = num.match(line, pos)
+            if not m:
+                break
+            out.append(float(m.group(0)))
+        else:
+            raise ValueError(d)
+        pos = m.end()
+    return out
+
+
 def rx_parse_param(lines):
     """The parameter-file loop :263-296: '#' lines skipped (:267), 9 tokens split on " ;\r\n" (:270-273), ``str[0]`` in A/B and
-    ``str[2]`` in N/S (:274), the ``sscanf`` of :280 and the value ranges of :288 (rows outside them are skipped).  Returns dicts
-    ``ch mode pn fc_init kcps fltkhz frange fstep snr_min_db``."""
+    ``str[2]`` in N/S (:274), the ``sscanf`` of :280 — restated with C's conversion rules (``_c_sscanf``: it splits on white space
+    only, and a numeric directive stops where its number stops, so a row written with ';', or an integer field written "100.5",
+    scans differently from how it tokenises) — and the value ranges of :288 (rows outside them are skipped).  A row whose scan does
+    not yield all nine values is skipped (the program goes on with the previous row's values there — not restated).  Lines are cut at
+    199 characters as ``fgets(str, 200, …)`` cuts them (:265).  Returns dicts ``ch mode pn fc_init kcps fltkhz frange fstep snr_min_db``."""
     import re
     rows = []
-    for line in lines:
+    pieces = []
+    for line in lines:                                                   # fgets(str, 200): a longer line comes in pieces of 199 characters
+        while len(line) > 199:
+            pieces.append(line[:199])
+            line = line[199:]
+        if line:
+            pieces.append(line)
+    for line in pieces:
         if line[:1] == "#":
             continue
         toks = [t for t in re.split(r"[ ;\r\n]+", line) if t]
         if len(line) < 3 or line[0] not in "AB" or line[2] not in "NS" or len(toks) != 9:
             continue
-        # sscanf(str, "%s %s %d %lf %d %lf %lf %lf %lf") :280 splits on white space only: a row written with ';' passes the token
-        # count but not the scan (the program then goes on with the previous row's values — not restated: such rows are skipped)
-        ws = line.split()
-        try:
-            pn, fc_init, kcps = int(ws[2]), float(ws[3]), int(ws[4])
-            fltkhz, frange, fstep, snr = float(ws[5]), float(ws[6]), float(ws[7]), float(ws[8])
-        except (ValueError, IndexError):
+        v = _c_sscanf(line, "%s %s %d %lf %d %lf %lf %lf %lf")
+        if len(v) != 9:
             continue
+        _, _, pn, fc_init, kcps, fltkhz, frange, fstep, snr = v
         if not (0 <= pn <= 131 and kcps == 2500 and -200000.0 <= fc_init < 200000.0 and 0.0 <= frange < 200000.0 and frange > fstep and snr > -100.0):
             continue
         rows.append(dict(ch=line[0], mode=line[2], pn=pn, fc_init=fc_init, kcps=kcps, fltkhz=fltkhz, frange=frange, fstep=fstep, snr_min_db=snr))

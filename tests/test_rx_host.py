@@ -88,3 +88,53 @@ def test_receiver_programs_argument_and_error_paths(tmp_path, prog):
     (tmp_path / "sdr.param").write_text("# nothing usable\nA N 100 0001186 1000 1250 2000 256 -18\n")
     r = run()
     assert r.returncode == 1 and "no usable row" in r.stdout
+
+
+def test_parameter_file_parser_fuzz(tmp_path):
+    """5000 generated parameter lines — well-formed rows with values around every limit of rxcomplex.cpp:288, and mutations of them
+    (tokens dropped / added, separators of the token rule vs the scan rule, comment marks, lower case, numbers written as floats,
+    with exponents, with junk behind them, empty and very long lines) — through twx_rx_parse_param and through the oracle's
+    restatement: the same rows, in the same order, with the same values."""
+    import numpy as np
+    rng = np.random.default_rng(4711)
+    lines = []
+    def num(lo, hi, edge):
+        v = float(rng.choice(edge)) if rng.integers(0, 3) == 0 else float(rng.uniform(lo, hi))
+        style = int(rng.integers(0, 5))
+        if style == 0: return "%d" % int(v)
+        if style == 1: return "%.3f" % v
+        if style == 2: return "%07d" % int(abs(v)) if v >= 0 else "-%06d" % int(abs(v))
+        if style == 3: return "%g" % v
+        return "%.2e" % v
+    for _ in range(5000):
+        wild = rng.integers(0, 4) == 0                                     # a quarter of the rows draw every field from the hostile sets
+        toks = [str(rng.choice(["A", "B", "A", "B", "C", "a", ""] if wild else ["A", "B"])), str(rng.choice(["N", "S", "N", "X", "n"] if wild else ["N", "N", "S"])),
+                num(-5, 140, [0, 99, 100, 131, 132, -1]) if wild else "%d" % int(rng.integers(0, 132)),
+                num(-250000, 250000, [-200000, 199999, 200000, -200001, 0]) if wild else num(-199000, 199000, [-200000, 199999, 0]),
+                str(rng.choice(["2500", "2500", "2500", "1000", "2500.0", "25e2"] if wild else ["2500"])), num(0, 3000, [1250]),
+                num(-10, 250000, [0, 199999, 200000, 256, 1]) if wild else num(300, 190000, [199999, 65536]), num(0, 70000, [256, 1, 0]) if wild else num(1, 290, [256, 1]),
+                num(-120, 30, [-100, -99.9, -18])]
+        m = int(rng.integers(0, 12)) if rng.integers(0, 3) == 0 else 11
+        if m == 0: toks = toks[:-1]
+        elif m == 1: toks.append("extra")
+        elif m == 2: toks[int(rng.integers(2, 9))] += "x"
+        elif m == 3: toks.insert(int(rng.integers(0, 9)), "")
+        sep = " " if m != 4 else str(rng.choice([";", "  ", " ;", "\t"]))
+        line = sep.join(toks)
+        if m == 5: line = "#" + line
+        elif m == 6: line = " " + line
+        elif m == 7: line = ""
+        elif m == 8: line = line + " " * int(rng.integers(1, 150))
+        lines.append(line + str(rng.choice(["\n", "\n", "\r\n"])))
+    text = "".join(lines)
+    p = tmp_path / "fuzz.param"
+    p.write_bytes(text.encode())
+    lib = L.load()
+    rows = (L.twx_rx_row * 6000)()
+    n = lib.twx_rx_parse_param(str(p).encode(), rows, 6000)
+    want = orc.rx_parse_param(text.splitlines(True))
+    assert n == len(want) and n > 300, (n, len(want))
+    for i, w in enumerate(want):
+        g = rows[i]
+        assert (g.ch.decode(), g.mode.decode(), g.pn, g.fc_init, g.kcps, g.fltkhz, g.frange, g.fstep, g.snr_min_db) == \
+               (w["ch"], w["mode"], w["pn"], w["fc_init"], w["kcps"], w["fltkhz"], w["frange"], w["fstep"], w["snr_min_db"]), (i, w)
