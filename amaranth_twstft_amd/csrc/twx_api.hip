@@ -998,7 +998,10 @@ template <typename T> struct Ctx : CtxBase {
             // k_rowd<MID>: workgroups in the launch.  Two are resident per CU (LDS); five per CU = 3.9 rows each balance the tail
             // better than two per CU with 9 or 10 rows each (profiles/r03_rowd_resident.txt: 0.326 against 0.334 ms).
             static const int pf = [] { const char* e = getenv("TWX_ROW_PF"); return e ? atoi(e) : -1; }();      // experiments: 0 = one workgroup per row
-            ra.pf_stride = pf >= 0 ? pf : 5 * ncu;
+            // a launch of no more rows than 1.5 x the resident slots (one window: 625 rows on 512 slots) runs as one resident workgroup
+            // per slot — the first 113 take a second row while the others' CUs drain — instead of one workgroup per row in two uneven
+            // waves: 28.3 -> 29.4 Gsample/s for the one-window chain (profiles/r04_b1_pf.txt)
+            ra.pf_stride = pf >= 0 ? pf : ((long long)N1 * nb <= 3ll * ncu ? 2 * ncu : 5 * ncu);
         }
         if (band) {
             if (band->k_lo < 0 || band->k_hi >= N || band->k_lo > band->k_hi) return fail(TWX_E_ARG, "band outside 0..N-1");
