@@ -24,7 +24,7 @@ TWX_CODE_BIPOLAR, TWX_CODE_UNIPOLAR = 0, 1
 TWX_PROF_MAX = 16
 TWX_TRK_RANGING, TWX_TRK_RE, TWX_TRK_LO = 0, 1, 2
 TWX_CARRIER_SEARCH_DF, TWX_CARRIER_CHUNK_BAND = 0, 1
-TWX_ABI_VERSION = 4
+TWX_ABI_VERSION = 5
 TWX_MULTI_NO_RCCL, TWX_MULTI_RCCL_ONE = 1, 2
 TWX_ACQ_IZAMAX = 1
 
@@ -104,7 +104,8 @@ class twx_track_result(C.Structure):
 
 class twx_multi_info(C.Structure):
     _fields_ = [("n_contexts", C.c_int32), ("n_devices_distinct", C.c_int32), ("rccl", C.c_int32), ("rccl_version", C.c_int32),
-                ("records_gathered", C.c_int64), ("bytes_per_rank", C.c_int64), ("gather_ms", C.c_double)]
+                ("records_gathered", C.c_int64), ("bytes_per_rank", C.c_int64), ("gather_ms", C.c_double),
+                ("rccl_fallback", C.c_int32), ("threads_pinned", C.c_int32), ("numa_node", C.c_int32 * 64), ("rccl_error", C.c_char * 256)]
 
 
 class twx_track_mai(C.Structure):
@@ -199,6 +200,8 @@ SYMBOLS = {
     "twx_multi_process_windows": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
     "twx_multi_process_windows_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
     "twx_multi_fetch_gathered": (C.c_int, [_VP, C.c_int32, _VP, C.c_int64]),
+    "twx_device_affinity": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.c_char_p, C.c_size_t]),
+    "twx_pin_thread_to_device": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "twx_set_code_spectrum_dev": (C.c_int, [_VP, _VP]),
     "twx_fft_forward_dev": (C.c_int, [_VP, _VP, _VP]),
     "twx_sliding_dot_cdev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _VP, C.c_double, C.c_double, C.c_double, _VP]),

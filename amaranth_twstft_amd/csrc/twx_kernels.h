@@ -319,7 +319,8 @@ __global__ __launch_bounds__(256) void k_sums(const short2* __restrict__ in, lon
     const long long lo = (long long)blockIdx.x * per, hi = min(n, lo + per);
     auto acc = [&](short2 s) {
         sI += s.x; sQ += s.y;
-        sP += (unsigned long long)((int)s.x * (int)s.x + (int)s.y * (int)s.y);
+        // through unsigned: (-32768)^2 * 2 = 2^31 does not fit an int (a clipped capture holds such samples), like acc4 below
+        sP += (unsigned long long)((unsigned int)((int)s.x * (int)s.x) + (unsigned int)((int)s.y * (int)s.y));
     };
     if (nch == 1 && ((reinterpret_cast<unsigned long long>(p) & 15) == 0)) {
         // 16 B per lane: four [I Q] samples per load (coalesced 1 KiB per wave-instruction)

@@ -10,8 +10,14 @@
 // (one rank per device): the blocks are then concatenated on the host, which is also what lets a one-GPU box test the
 // threading and the ordering.  RCCL is bound at run time (dlopen of librccl.so.1 on the first twx_multi_create that needs
 // it): a 570-MB library that no single-GPU MEX call should have to map.  No process is ever re-executed; threads only.
+//
+// The exchange is 240 bytes per window: it must never be what loses a job.  When RCCL cannot be loaded, ncclCommInitAll fails or
+// does not come back within TWX_RCCL_INIT_TIMEOUT_S (default 120 s), or a collective fails or does not complete within
+// TWX_RCCL_GATHER_TIMEOUT_S (default 60 s), the driver says so in twx_multi_info (rccl_fallback, rccl_error) and carries on with
+// the host-side concatenation — same records, same order.  Worker threads are bound to the CPUs of their device's NUMA node
+// (twx_affinity.h; TWX_NO_PIN=1 turns that off).  TWX_MULTI_INJECT={init,init_hang,gather,gather_timeout} makes the corresponding
+// RCCL step fail on purpose (tests/test_gpu_multi.py: a one-GPU box has no other way to reach these branches).
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <string.h>
 #include <sys/stat.h>
@@ -19,6 +25,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -26,16 +33,36 @@
 #include <vector>
 #include "twx_internal.h"
 #include "twx_workers.h"
+#include "twx_affinity.h"
+
+// The few RCCL declarations this file uses, restated from rccl/rccl.h (values of RCCL 2.x, unchanged since NCCL 2.0): the library
+// is bound at run time, and a build box for single-GPU users need not carry the RCCL development headers.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4,
+               ncclInvalidUsage = 5, ncclRemoteError = 6, ncclInProgress = 7 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
+}
 
 namespace {
 
 thread_local std::string g_multi_create_err;
+
+double env_seconds(const char* name, double dflt) {
+    const char* e = getenv(name);
+    if (!e || !*e) return dflt;
+    char* end = nullptr;
+    const double v = strtod(e, &end);
+    return (end != e && v > 0) ? v : dflt;
+}
+bool inject(const char* what) { const char* e = getenv("TWX_MULTI_INJECT"); return e && strcmp(e, what) == 0; }
 
 // ---- RCCL, bound at run time --------------------------------------------------------------------------------------
 struct Rccl {
     void* h = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -56,6 +83,7 @@ struct Rccl {
         auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) err = std::string("RCCL symbol missing: ") + n; return p; };
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        CommAbort = (decltype(CommAbort))dlsym(h, "ncclCommAbort");                 // optional: only the time-out path wants it
         AllGather = (decltype(AllGather))sym("ncclAllGather");
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
@@ -83,17 +111,12 @@ struct twx_multi {
     std::vector<hipStream_t> gstream;              // the gather's own stream on every device
     std::vector<void*> send_dev, recv_dev; size_t cap_records = 0;      // per device: one block / all blocks of the gather
     std::vector<std::vector<twx_result>> local;    // per context: the records of its block (host paths)
+    std::vector<int> pinned;                       // per worker: 1 = bound to its device's NUMA CPUs
     std::string err;
     twx_multi_info info{};
     twx_info cinfo{};
 
     int fail(int code, const std::string& m) { err = m; return code; }
-    int nccl_fail(ncclResult_t r, const char* what, ncclComm_t c) {
-        Rccl& R = rccl();
-        std::string m = std::string(what) + " failed: " + (R.GetErrorString ? R.GetErrorString(r) : "?");
-        if (R.GetLastError && c) { const char* le = R.GetLastError(c); if (le && *le) m += std::string(" — ") + le; }
-        return fail(TWX_E_HIP, m);
-    }
     ~twx_multi() {
         for (auto w : workers) if (w) { w->stop(); delete w; }
         if (use_rccl) for (int r = 0; r < (int)comms.size(); ++r) if (comms[r]) { (void)hipSetDevice(devices[r]); (void)rccl().CommDestroy(comms[r]); }
@@ -105,9 +128,17 @@ struct twx_multi {
             if (r < (int)ctx.size() && ctx[r]) twx_destroy(ctx[r]);
         }
     }
-    // every context runs f(rank) on its own thread; first failure wins (its context's message is kept)
+    // every context runs f(rank) on its own thread; first failure wins (its context's message is kept).  The jobs hold pointers
+    // into the caller's frame: whatever happens while they are being handed out (bad_alloc from a std::function copy), every job
+    // already submitted is waited for before this frame is left.
     int run_all(const std::function<int(int)>& f) {
-        for (int r = 0; r < n; ++r) workers[r]->submit([&f, r]() { return f(r); });
+        int submitted = 0;
+        try {
+            for (int r = 0; r < n; ++r) { workers[r]->submit([&f, r]() { return f(r); }); ++submitted; }
+        } catch (...) {
+            for (int r = 0; r < submitted; ++r) (void)workers[r]->wait();
+            throw;
+        }
         int rc = TWX_OK;
         for (int r = 0; r < n; ++r) {
             const int rr = workers[r]->wait();
@@ -137,32 +168,74 @@ struct twx_multi {
         cap_records = cap;
         return TWX_OK;
     }
-    // send_dev[r] holds `block` records on every device -> recv_dev[r] holds n*block on every device (one collective)
-    int all_gather(size_t block) {
+    // RCCL is given up for the rest of this object's life: the exchange continues as host-side concatenation (flagged, never silent)
+    void give_up_rccl(int why, const std::string& text, bool abort_comms) {
+        Rccl& R = rccl();
+        for (int r = 0; r < (int)comms.size(); ++r) {
+            if (!comms[r]) continue;
+            (void)hipSetDevice(devices[r]);
+            // a communicator with a collective still in flight is aborted, never destroyed (ncclCommDestroy would wait for it);
+            // without ncclCommAbort it is left alone
+            if (abort_comms) { if (R.CommAbort) (void)R.CommAbort(comms[r]); }
+            else (void)R.CommDestroy(comms[r]);
+            comms[r] = nullptr;
+        }
+        comms.clear();
+        use_rccl = false;
+        info.rccl = 0; info.rccl_fallback = why;
+        snprintf(info.rccl_error, sizeof(info.rccl_error), "%s", text.c_str());
+    }
+    // send_dev[r] holds `block` records on every device -> recv_dev[r] holds n*block on every device (one collective).
+    // false: RCCL failed or timed out and has been given up (give_up_rccl); the caller continues on the host path.
+    bool all_gather(size_t block) {
         Rccl& R = rccl();
         const auto t0 = std::chrono::steady_clock::now();
-        ncclResult_t g = R.GroupStart();
-        if (g != ncclSuccess) return nccl_fail(g, "ncclGroupStart", nullptr);
-        for (int r = 0; r < n; ++r) {
-            (void)hipSetDevice(devices[r]);
-            ncclResult_t e = R.AllGather(send_dev[r], recv_dev[r], block * sizeof(twx_result), ncclChar, comms[r], gstream[r]);
-            if (e != ncclSuccess) { (void)R.GroupEnd(); return nccl_fail(e, "ncclAllGather", comms[r]); }
+        auto text = [&](ncclResult_t r, const char* what, ncclComm_t c) {
+            std::string m = std::string(what) + " failed: " + (R.GetErrorString ? R.GetErrorString(r) : "?");
+            if (R.GetLastError && c) { const char* le = R.GetLastError(c); if (le && *le) m += std::string(" - ") + le; }
+            return m;
+        };
+        if (inject("gather")) { give_up_rccl(2, "ncclAllGather failed: injected failure (TWX_MULTI_INJECT=gather)", false); return false; }
+        const bool fake_hang = inject("gather_timeout");
+        if (!fake_hang) {
+            ncclResult_t g = R.GroupStart();
+            if (g != ncclSuccess) { give_up_rccl(2, text(g, "ncclGroupStart", nullptr), false); return false; }
+            for (int r = 0; r < n; ++r) {
+                (void)hipSetDevice(devices[r]);
+                ncclResult_t e = R.AllGather(send_dev[r], recv_dev[r], block * sizeof(twx_result), ncclChar, comms[r], gstream[r]);
+                if (e != ncclSuccess) { (void)R.GroupEnd(); give_up_rccl(2, text(e, "ncclAllGather", comms[r]), true); return false; }
+            }
+            g = R.GroupEnd();
+            if (g != ncclSuccess) { give_up_rccl(2, text(g, "ncclGroupEnd", comms[0]), true); return false; }
         }
-        g = R.GroupEnd();
-        if (g != ncclSuccess) return nccl_fail(g, "ncclGroupEnd", comms[0]);
+        // completion with a deadline: a peer that never arrives must not hang the host program
+        const double limit = fake_hang ? 0.2 : env_seconds("TWX_RCCL_GATHER_TIMEOUT_S", 60.0);
         for (int r = 0; r < n; ++r) {
             (void)hipSetDevice(devices[r]);
-            if (hipStreamSynchronize(gstream[r]) != hipSuccess) return fail(TWX_E_HIP, "gather stream synchronize failed");
+            for (;;) {
+                const hipError_t q = fake_hang ? hipErrorNotReady : hipStreamQuery(gstream[r]);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) { (void)hipGetLastError(); give_up_rccl(2, std::string("gather stream failed: ") + hipGetErrorString(q), true); return false; }
+                (void)hipGetLastError();
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+                    char b[160];
+                    snprintf(b, sizeof(b), "ncclAllGather did not complete on context %d within %.1f s%s", r, limit, fake_hang ? " (injected: TWX_MULTI_INJECT=gather_timeout)" : "");
+                    give_up_rccl(2, b, true);
+                    return false;
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
         }
         info.gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         info.records_gathered = (int64_t)(block * n); info.bytes_per_rank = (int64_t)(block * sizeof(twx_result));
-        return TWX_OK;
+        return true;
     }
     // the blocks local[r][0 .. counts[r]*per) -> out (blocks in rank order, no padding); through the devices when RCCL is on
     int gather_host_blocks(const std::vector<long long>& counts, int per, twx_result* out) {
         long long mx = 0;
         for (long long c : counts) mx = std::max(mx, c);
         const size_t block = (size_t)mx * per;
+        bool done = false;
         if (use_rccl && block > 0) {
             if (int rc = ensure_gather(block)) return rc;
             for (int r = 0; r < n; ++r) {
@@ -171,13 +244,16 @@ struct twx_multi {
                     hipMemcpyAsync(send_dev[r], local[r].data(), (size_t)counts[r] * per * sizeof(twx_result), hipMemcpyHostToDevice, gstream[r]) != hipSuccess)
                     return fail(TWX_E_HIP, "record upload failed");
             }
-            if (int rc = all_gather(block)) return rc;
-            std::vector<twx_result> all(block * n);
-            (void)hipSetDevice(devices[0]);
-            if (hipMemcpy(all.data(), recv_dev[0], all.size() * sizeof(twx_result), hipMemcpyDeviceToHost) != hipSuccess) return fail(TWX_E_HIP, "gathered records D2H failed");
-            size_t o = 0;
-            for (int r = 0; r < n; ++r) { memcpy(out + o, all.data() + (size_t)r * block, (size_t)counts[r] * per * sizeof(twx_result)); o += (size_t)counts[r] * per; }
-        } else {
+            if (all_gather(block)) {
+                std::vector<twx_result> all(block * n);
+                (void)hipSetDevice(devices[0]);
+                if (hipMemcpy(all.data(), recv_dev[0], all.size() * sizeof(twx_result), hipMemcpyDeviceToHost) != hipSuccess) return fail(TWX_E_HIP, "gathered records D2H failed");
+                size_t o = 0;
+                for (int r = 0; r < n; ++r) { memcpy(out + o, all.data() + (size_t)r * block, (size_t)counts[r] * per * sizeof(twx_result)); o += (size_t)counts[r] * per; }
+                done = true;
+            }
+        }
+        if (!done) {                       // host-side concatenation (repeated devices, TWX_MULTI_NO_RCCL, or RCCL given up just now)
             size_t o = 0;
             for (int r = 0; r < n; ++r) { memcpy(out + o, local[r].data(), (size_t)counts[r] * per * sizeof(twx_result)); o += (size_t)counts[r] * per; }
             info.gather_ms = 0; info.records_gathered = (int64_t)o; info.bytes_per_rank = (int64_t)(block * sizeof(twx_result));
@@ -215,11 +291,24 @@ static int multi_create_impl(const twx_config* cfg, const int32_t* devices, int3
     }
     m->ctx.assign(n, nullptr); m->send_dev.assign(n, nullptr); m->recv_dev.assign(n, nullptr); m->gstream.assign(n, nullptr);
     m->local.resize(n);
+    // one persistent thread per context, bound to the CPUs next to its device (pinned staging buffers are first touched, and the
+    // capture is read, by this thread): /sys/bus/pci/devices/<bus id>/{numa_node,local_cpulist}
+    const char* np_env = getenv("TWX_NO_PIN");
+    const bool pin = !(np_env && atoi(np_env) != 0);
+    m->pinned.assign(n, 0);               // written by the workers' prologues: lives in the object, which outlives its threads
     for (int r = 0; r < n; ++r) {
-        Worker* w = new Worker(); m->workers.push_back(w);
         const int d = m->devices[r];
-        w->start([d]() { (void)hipSetDevice(d); }, TWX_E_NOMEM, TWX_E_STATE);
+        char bus[64] = {0};
+        twx::DeviceAffinity aff;
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), d) == hipSuccess) aff = twx::affinity_of_pci(bus);
+        else (void)hipGetLastError();
+        if (r < 64) m->info.numa_node[r] = aff.numa_node;
+        Worker* w = new Worker(); m->workers.push_back(w);
+        int* flag = &m->pinned[r];
+        std::vector<int> cpus = (pin && aff.numa_node >= 0) ? aff.cpus : std::vector<int>();
+        w->start([d, cpus, flag]() { (void)hipSetDevice(d); *flag = twx::pin_current_thread(cpus) > 0 ? 1 : 0; }, TWX_E_NOMEM, TWX_E_STATE);
     }
+    for (int r = n; r < 64; ++r) m->info.numa_node[r] = -1;
     // contexts are created side by side (tables, code spectrum, 3 pipeline slots each): one thread per device
     std::vector<std::string> cerr(n);
     int rc = TWX_OK;
@@ -249,19 +338,51 @@ static int multi_create_impl(const twx_config* cfg, const int32_t* devices, int3
     if (m->distinct && !no_rccl && (n > 1 || force_one)) {
         std::lock_guard<std::mutex> g(rccl_mu());
         Rccl& R = rccl();
-        if (!R.load()) { g_multi_create_err = R.err; return TWX_E_HIP; }
-        m->comms.assign(n, nullptr);
-        const ncclResult_t e = R.CommInitAll(m->comms.data(), n, m->devices.data());
-        if (e != ncclSuccess) {
-            g_multi_create_err = std::string("ncclCommInitAll failed: ") + R.GetErrorString(e);
-            if (R.GetLastError) { const char* le = R.GetLastError(nullptr); if (le && *le) g_multi_create_err += std::string(" — ") + le; }
-            m->comms.clear();
-            return TWX_E_HIP;
+        std::string why;
+        if (!R.load()) why = R.err;
+        else if (inject("init")) why = "ncclCommInitAll failed: injected failure (TWX_MULTI_INJECT=init)";
+        else {
+            // ncclCommInitAll on its own thread with a deadline: a bootstrap that never returns (a peer's IPC handle that cannot be
+            // opened, a dead link) must not hang the host program.  The thread is abandoned on a time-out — it holds only the
+            // shared state below — and RCCL is not touched again by this object.
+            struct Init { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t rc = ncclSuccess; std::vector<ncclComm_t> comms; std::vector<int> devs; std::string last; };
+            auto st = std::make_shared<Init>();
+            st->comms.assign(n, nullptr); st->devs = m->devices;
+            const bool hang = inject("init_hang");
+            std::thread([st, &R, hang]() {
+                ncclResult_t rc = ncclSuccess;
+                if (hang) std::this_thread::sleep_for(std::chrono::seconds(3600));
+                else rc = R.CommInitAll(st->comms.data(), (int)st->devs.size(), st->devs.data());
+                std::string last;
+                if (rc != ncclSuccess && R.GetLastError) { const char* le = R.GetLastError(nullptr); if (le && *le) last = le; }
+                std::lock_guard<std::mutex> lk(st->mu);
+                st->rc = rc; st->last = last; st->done = true;
+                st->cv.notify_all();
+            }).detach();
+            const double limit = hang ? 0.3 : env_seconds("TWX_RCCL_INIT_TIMEOUT_S", 120.0);
+            std::unique_lock<std::mutex> lk(st->mu);
+            if (!st->cv.wait_for(lk, std::chrono::duration<double>(limit), [&]() { return st->done; })) {
+                char b[160];
+                snprintf(b, sizeof(b), "ncclCommInitAll did not return within %.1f s%s", limit, hang ? " (injected: TWX_MULTI_INJECT=init_hang)" : "");
+                why = b;
+            } else if (st->rc != ncclSuccess) {
+                why = std::string("ncclCommInitAll failed: ") + R.GetErrorString(st->rc);
+                if (!st->last.empty()) why += " - " + st->last;
+            } else {
+                m->comms = st->comms;
+                m->use_rccl = true;
+                int v = 0;
+                if (R.GetVersion && R.GetVersion(&v) == ncclSuccess) m->info.rccl_version = v;
+            }
         }
-        m->use_rccl = true;
-        int v = 0;
-        if (R.GetVersion && R.GetVersion(&v) == ncclSuccess) m->info.rccl_version = v;
+        (void)hipGetLastError();
+        if (!m->use_rccl) {                 // the job goes on without RCCL: host-side concatenation, flagged
+            m->info.rccl_fallback = 1;
+            snprintf(m->info.rccl_error, sizeof(m->info.rccl_error), "%s", why.c_str());
+        }
     }
+    m->info.threads_pinned = 0;
+    for (int r = 0; r < n; ++r) { (void)m->workers[r]->wait(); m->info.threads_pinned += m->pinned[r]; }     // (the prologues ran before the creation jobs)
     m->info.n_contexts = n; m->info.rccl = m->use_rccl ? 1 : 0;
     {
         std::vector<int> u = m->devices; std::sort(u.begin(), u.end());
@@ -343,14 +464,17 @@ int twx_multi_process_windows_dev(twx_multi* m, const void* const* iq_dev, int64
             return e ? e : twx_synchronize(m->ctx[r]);                 // records complete before the collective reads them
         });
         if (rc) return rc;
-        if (m->use_rccl) {
-            if ((rc = m->all_gather(block))) return rc;
+        bool done = false;
+        if (m->use_rccl && m->all_gather(block)) {
             if (out) {
                 (void)hipSetDevice(m->devices[0]);
                 if (hipMemcpy(out, m->recv_dev[0], block * m->n * sizeof(twx_result), hipMemcpyDeviceToHost) != hipSuccess) return m->fail(TWX_E_HIP, "gathered records D2H failed");
             }
-        } else {
-            // host-side concatenation; every context's "gathered" buffer is filled from it so that both modes leave the same state
+            done = true;
+        }
+        if (!done) {
+            // host-side concatenation (repeated devices, TWX_MULTI_NO_RCCL, or RCCL given up — possibly just now, by all_gather);
+            // every context's "gathered" buffer is filled from it so that both modes leave the same state
             std::vector<twx_result> all(block * m->n);
             for (int r = 0; r < m->n; ++r) {
                 (void)hipSetDevice(m->devices[r]);
@@ -365,6 +489,33 @@ int twx_multi_process_windows_dev(twx_multi* m, const void* const* iq_dev, int64
         }
         return TWX_OK;
     });
+}
+
+// NUMA placement of a device, and binding the calling thread next to it (what the twx_multi workers do for themselves; the
+// one-process-per-GPU ranks of dist.py / bench.py call it once after choosing their device)
+int twx_device_affinity(int32_t device, int32_t* numa_node, char* cpulist, size_t cap) {
+    (void)hipGetLastError();
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return TWX_E_ARG; }
+    const twx::DeviceAffinity a = twx::affinity_of_pci(bus);
+    if (numa_node) *numa_node = a.numa_node;
+    if (cpulist && cap) snprintf(cpulist, cap, "%s", a.cpulist.c_str());
+    return TWX_OK;
+}
+int twx_pin_thread_to_device(int32_t device, int32_t* numa_node, int32_t* n_cpus) {
+    (void)hipGetLastError();
+    if (numa_node) *numa_node = -1;
+    if (n_cpus) *n_cpus = 0;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return TWX_E_ARG; }
+    const twx::DeviceAffinity a = twx::affinity_of_pci(bus);
+    if (numa_node) *numa_node = a.numa_node;
+    const char* np_env = getenv("TWX_NO_PIN");
+    if ((np_env && atoi(np_env) != 0) || a.numa_node < 0) return TWX_OK;          // nothing to do is not an error
+    const int k = twx::pin_current_thread(a.cpus);
+    if (k < 0) return TWX_E_STATE;
+    if (n_cpus) *n_cpus = k;
+    return TWX_OK;
 }
 
 int twx_multi_fetch_gathered(twx_multi* m, int32_t i, twx_result* out, int64_t n_records) {

@@ -138,7 +138,8 @@ struct Channel {
     twx_track_state st{};
     double gd = 0, dg = 0, sdgd = 0, pk = 0, px = 0;
     int cnt = 0;
-    twx_ctx* acq = nullptr;
+    twx_ctx* acq = nullptr;         // the acquisition context of this row's transform length — SHARED by all rows of that length (twx_rx::acq_ctx)
+    void* acq_spec = nullptr;       // this row's acquisition operand (natural order, complex double), loaded into the shared context before a sweep
     float* replica_dev = nullptr;
     std::string dat_name;
     // the records MAI_up reads (rx.cpp:664-666,757), host and device: amp[bps], phase[bps] (double), pk_idx[bps] (int)
@@ -169,12 +170,25 @@ struct twx_rx {
     std::mt19937_64 rng;
     bool need[2] = {false, false};
     double last_pwr[2] = {0, 0};
+    // One fp32 acquisition context per distinct transform length (a context of 2^20 points with its three pipeline slots is
+    // about 3 GB: one per ROW would not fit the program's 120 rows, rxcomplex.cpp:34).  Rows of one length differ only in the
+    // operand conj(FFT(replica)), which each row keeps (16 bytes a point) and loads before its sweep when it is not the one in place.
+    std::map<long long, twx_ctx*> acq_ctx;
+    std::map<twx_ctx*, const Channel*> acq_loaded;
+    int load_acq_operand(const Channel& c) {
+        auto it = acq_loaded.find(c.acq);
+        if (it != acq_loaded.end() && it->second == &c) return TWX_OK;
+        if (int rc = lib(c.acq, twx_set_code_spectrum_dev(c.acq, c.acq_spec))) return rc;
+        acq_loaded[c.acq] = &c;
+        return TWX_OK;
+    }
 
     int fail(int code, const std::string& m) { err = m; return code; }
     int lib(twx_ctx* c, int rc) { if (rc) { const char* m = twx_last_error(c); err = m && *m ? m : twx_strerror(rc); } return rc; }
     ~twx_rx() {
         (void)hipSetDevice(dev);
-        for (auto& c : ch) { if (c.acq) twx_destroy(c.acq); if (c.replica_dev) (void)hipFree(c.replica_dev); if (c.mai_dev) (void)hipFree(c.mai_dev); }
+        for (auto& c : ch) { if (c.acq_spec) (void)hipFree(c.acq_spec); if (c.replica_dev) (void)hipFree(c.replica_dev); if (c.mai_dev) (void)hipFree(c.mai_dev); }
+        for (auto& kv : acq_ctx) twx_destroy(kv.second);
         if (interp) twx_destroy(interp);
         for (void* p : {(void*)iq_dev, (void*)smp[0], (void*)smp[1], (void*)part_dev, (void*)mai_free}) if (p) (void)hipFree(p);
         if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -212,8 +226,10 @@ struct twx_rx {
         unsigned char* code_dev = nullptr; cd *wav_t = nullptr, *wav_acq = nullptr; double* part = nullptr;
         struct Free { std::vector<void*> p; ~Free() { for (void* q : p) if (q) (void)hipFree(q); } } fr;
         auto alloc = [&](void** p, size_t bytes) { if (hipMalloc(p, bytes) != hipSuccess) return false; fr.p.push_back(*p); return true; };
-        if (!alloc((void**)&code_dev, code.size()) || !alloc((void**)&wav_t, (size_t)c.nobs * 16) || !alloc((void**)&wav_acq, (size_t)c.nfft * 16) ||
-            !alloc((void**)&part, RX_PARTS * 8)) return fail(TWX_E_NOMEM, "device allocation failed (channel set-up)");
+        if (!alloc((void**)&code_dev, code.size()) || !alloc((void**)&wav_t, (size_t)c.nobs * 16) || !alloc((void**)&part, RX_PARTS * 8))
+            return fail(TWX_E_NOMEM, "device allocation failed (channel set-up)");
+        if (hipMalloc((void**)&wav_acq, (size_t)c.nfft * 16) != hipSuccess) return fail(TWX_E_NOMEM, "device allocation failed (acquisition operand)");
+        c.acq_spec = wav_acq;                                                            // kept: released with the receiver
         if (hipMalloc((void**)&c.replica_dev, (size_t)c.nobs * 4) != hipSuccess) return fail(TWX_E_NOMEM, "device allocation failed (replica)");
         if (hipMemcpy(code_dev, code.data(), code.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(TWX_E_HIP, "code upload failed");
         twx_ctx *cn = nullptr, *cf = nullptr;
@@ -239,10 +255,15 @@ struct twx_rx {
         if (int rc = lib(cf, twx_fft_forward_dev(cf, wav_acq, wav_acq))) return rc;
         hipLaunchKernelGGL(k_rx_acq_spec, dim3(g), dim3(b), 0, sf, c.nfft, wav_acq, (fs / (double)cfg.dec_a) / (double)c.nfft, c.fltmax, c.fltmin);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sf) != hipSuccess) return fail(TWX_E_HIP, "acquisition operand failed");
-        const twx_config ac = plain_cfg(c.nfft, fs / (double)cfg.dec_a, TWX_F32, 0, 64, dev);
-        if (int rc = twx_create(&ac, &c.acq)) { err = std::string("acquisition context of ") + std::to_string(c.nfft) + " points: " + twx_last_error(nullptr); return rc; }
-        if (int rc = lib(c.acq, twx_set_code_spectrum_dev(c.acq, wav_acq))) return rc;
-        if (int rc = lib(c.acq, twx_set_option(c.acq, TWX_OPT_REMOVE_MEAN, 0))) return rc;
+        auto it = acq_ctx.find(c.nfft);
+        if (it == acq_ctx.end()) {
+            const twx_config ac = plain_cfg(c.nfft, fs / (double)cfg.dec_a, TWX_F32, 0, 64, dev);
+            twx_ctx* x = nullptr;
+            if (int rc = twx_create(&ac, &x)) { err = std::string("acquisition context of ") + std::to_string(c.nfft) + " points: " + twx_last_error(nullptr); return rc; }
+            it = acq_ctx.emplace(c.nfft, x).first;
+            if (int rc = lib(x, twx_set_option(x, TWX_OPT_REMOVE_MEAN, 0))) return rc;
+        }
+        c.acq = it->second;
         return TWX_OK;
     }
 
@@ -393,6 +414,7 @@ struct twx_rx {
                 const long long idx = blk * c.nobs;                                                         // :529
                 twx_acq_result a{};
                 const int flags = TWX_ACQ_IZAMAX | (cfg.dec_a > 1 ? TWX_ACQ_DEC(cfg.dec_a) : 0);
+                if (int rc = load_acq_operand(c)) return rc;
                 if (int rc = lib(c.acq, twx_acquire_cdev(c.acq, obs + idx, c.fc_init, c.range, c.step, c.nobs / cfg.dec_a, flags, &a))) return rc;
                 c.st.fc = a.fc; c.st.pt = a.pt;
                 c.pk = 8.0 * a.pk * a.pk / c.psbb;                                                          // :570

@@ -30,13 +30,14 @@ def max_shard(n_windows: int, world: int) -> int:
     return -(-n_windows // world)
 
 
-def gather_results(local, n_windows: int, rank: int, world: int, device=None, per_window: int = 1):
+def gather_results(local, n_windows: int, rank: int, world: int, device=None, per_window: int = 1, exchange=None):
     """all_gather the local result records → numpy structured bytes for all ``n_windows``.
 
     ``local``: torch uint8 tensor [n_local*per_window, RESULT_BYTES] (on the rank's GPU for RCCL, on CPU
     for gloo); ``per_window`` records belong to one window (the channels of the all-channel mode).
     Shards are padded to a common length so a single ``all_gather_into_tensor`` suffices
-    (≈ 240 B × windows: latency-bound, one collective per capture).
+    (≈ 240 B × windows: latency-bound, one collective per capture).  ``exchange``: a :class:`collective.RecordExchange`
+    (RCCL with its gloo fall-back) to carry it; without one the default process group is used as it is.
     """
     import torch
     import torch.distributed as dist
@@ -47,7 +48,10 @@ def gather_results(local, n_windows: int, rank: int, world: int, device=None, pe
         out = pad.unsqueeze(0)
     else:
         flat = torch.empty((world * cap, RESULT_BYTES), dtype=torch.uint8, device=local.device)
-        dist.all_gather_into_tensor(flat, pad)
+        if exchange is not None:
+            exchange.all_gather_records(flat, pad)
+        else:
+            dist.all_gather_into_tensor(flat, pad)
         out = flat.view(world, cap, RESULT_BYTES)
     out = out.cpu().numpy()
     pieces = []

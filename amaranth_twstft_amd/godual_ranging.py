@@ -28,7 +28,7 @@ from . import launch, prn, results_io
 from .correlator import Correlator, band_godual
 
 
-def _process_capture(cor, cap, band, all_channels, rank, world, backend):
+def _process_capture(cor, cap, band, all_channels, rank, world, exchange):
     """Records of every window of ``cap`` (all ranks return the full list; one collective)."""
     from . import dist as D
     nch = 2
@@ -46,9 +46,9 @@ def _process_capture(cor, cap, band, all_channels, rank, world, backend):
     if world > 1:
         import torch
         local = torch.from_numpy(recs)
-        if backend == "nccl":
+        if exchange.backend == "nccl":
             local = local.cuda()
-        allb = D.gather_results(local, nwin, rank, world, per_window=per)
+        allb = D.gather_results(local, nwin, rank, world, per_window=per, exchange=exchange)
     else:
         allb = recs
     res = D.results_from_bytes(allb)
@@ -62,17 +62,21 @@ def run(datalocation="./", codelocation="./codes/", remote=0, OP=0, fs=5e6, Nint
     rank, local_rank, world = launch.rank_world()
     if single_process_gpus:
         rank, local_rank, world = 0, 0, 1
+    ex = None
     if world > 1:
+        # the record exchange: gloo control plane + RCCL probe job BEFORE this rank touches its GPU, then the RCCL data plane with
+        # its fall-back to gloo (collective.py) — a communicator that cannot be formed costs a line on stderr, not the capture
+        from .collective import RecordExchange, pin_to_device
+        ex = RecordExchange(rank, world, want=backend, reason=os.environ.get("TWX_COLLECTIVE_FALLBACK_REASON") or None).prepare()
         import torch
-        import torch.distributed as dist
         if device < 0:
             device = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(device)
-        if not dist.is_initialized():
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
-            else:
-                dist.init_process_group(backend, rank=rank, world_size=world)
+        ex.bring_up(torch.device("cuda", device))
+        from . import _lib
+        pin_to_device(_lib.load(), device)
+        if rank == 0 and ex.fallback:
+            sys.stderr.write(f"[godual_ranging] record exchange: {ex.describe()}\n")
     caps = sorted(glob.glob(os.path.join(datalocation, "1*.bin")))
     codes = sorted(glob.glob(os.path.join(codelocation, "n*.bin")) + glob.glob(os.path.join(codelocation, "n*.bin.gz")))
     if not codes:
@@ -103,20 +107,18 @@ def run(datalocation="./", codelocation="./codes/", remote=0, OP=0, fs=5e6, Nint
                 continue
             say(base + "\n")
             # both channels of every window from one pass over the file (:91,95); remote: measurement channel only
-            r1, r2 = _process_capture(cor, cap, band, remote != 1, rank, world, backend)
+            r1, r2 = _process_capture(cor, cap, band, remote != 1, rank, world, ex)
             if rank == 0:
                 for row in results_io.tsv_rows(r1, r2, fs, Nint):
                     say(row)
                 for line in results_io.residual_report(r1, r2, fs, Nint):
                     say(line)
                 results_io.save_mat(nom, r1, r2, code=prn.chips_to_code(chips), remote=remote)
-            if world > 1:
-                import torch.distributed as dist
-                dist.barrier()            # the .mat exists before any rank looks at the next capture's "already done"
+            if ex is not None:
+                ex.barrier()              # the .mat exists before any rank looks at the next capture's "already done"
             done.append(nom)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    if ex is not None:
+        ex.close()
     return done
 
 
@@ -138,7 +140,7 @@ def main(argv=None):
         return
     if a.gpus > 1 and not launch.is_rank():
         args = list(sys.argv[1:] if argv is None else argv)
-        sys.exit(launch.spawn_ranks(a.gpus, "", args, module="amaranth_twstft_amd.godual_ranging"))
+        sys.exit(launch.spawn_with_fallback(a.gpus, "", args, module="amaranth_twstft_amd.godual_ranging", backend=a.backend))
     run(a.datalocation, a.codelocation, a.remote, a.OP, a.fs, a.Nint, backend=a.backend)
 
 

@@ -42,3 +42,27 @@ def spawn_ranks(n: int, script: str, argv: list[str], module: str | None = None,
            "--master-addr", "127.0.0.1", "--master-port", str(free_port())]
     cmd += (["-m", module] if module else [script]) + list(argv)
     return subprocess.run(cmd, env=env, timeout=timeout).returncode
+
+
+def spawn_with_fallback(n: int, script: str, argv: list[str], module: str | None = None, backend: str = "nccl", timeout: float | None = None) -> int:
+    """:func:`spawn_ranks`, and when that job ends with a non-zero status although its ranks already fall back by themselves
+    (amaranth_twstft_amd/collective.py) — a rank killed inside RCCL, a bootstrap that aborted the process — ONE more job, fresh, with
+    ``--backend gloo`` and the reason in ``TWX_COLLECTIVE_FALLBACK_REASON`` (the output then reads ``gloo (fallback: ...)``).
+    This launcher never touches the GPU; no rank is ever re-executed, the second job is all new processes."""
+    rc = spawn_ranks(n, script, argv, module=module, timeout=timeout)
+    if rc == 0 or backend != "nccl" or os.environ.get("TWX_NO_JOB_FALLBACK", "0") != "0":
+        return rc
+    sys.stderr.write(f"[launch] the {n}-rank job ended with status {rc}; starting it once more with the record exchange on gloo\n")
+    args, skip = [], False
+    for x in argv:                                  # drop a --backend the caller gave, in either spelling
+        if skip:
+            skip = False
+        elif x == "--backend":
+            skip = True
+        elif not x.startswith("--backend="):
+            args.append(x)
+    os.environ["TWX_COLLECTIVE_FALLBACK_REASON"] = f"the RCCL job ended with status {rc}; restarted by the launcher"
+    try:
+        return spawn_ranks(n, script, args + ["--backend", "gloo"], module=module, timeout=timeout)
+    finally:
+        os.environ.pop("TWX_COLLECTIVE_FALLBACK_REASON", None)

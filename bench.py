@@ -280,8 +280,11 @@ def single_process(a, t_start):
                               "value": round(world * nwin * N * a.steps / dt_other / 1e6, 2), "unit": "Msamples/s",
                               "ms_per_step": round(dt_other / a.steps * 1e3, 3)},
            "collective": {"op": "ncclAllGather (RCCL %d, ncclCommInitAll, one group call from the host process)" % info.rccl_version if info.rccl
-                                else "host-side concatenation (the device list repeats a device: RCCL has one rank per device)",
-                          "backend": "rccl" if info.rccl else "host", "world": world, "records": int(info.records_gathered),
+                                else ("host-side concatenation (RCCL given up, see backend)" if info.rccl_fallback else
+                                      "host-side concatenation (the device list repeats a device: RCCL has one rank per device)"),
+                          "backend": "rccl" if info.rccl else ("host (fallback: %s)" % info.rccl_error.decode(errors="replace") if info.rccl_fallback else "host"),
+                          "rccl_fallback": int(info.rccl_fallback), "world": world, "records": int(info.records_gathered),
+                          "threads_pinned": int(info.threads_pinned), "numa_nodes": [int(info.numa_node[i]) for i in range(world)],
                           "bytes_per_rank": int(info.bytes_per_rank), "gather_ms_last": round(info.gather_ms, 3),
                           "ranks_with_exact_lags": int(sum(per_rank)), "gathered_lag_exact": bool(all(per_rank)),
                           "own_block_identical": bool(all(copies)), "all_ranks_agree": bool(all(copies) and all(per_rank)),
@@ -347,13 +350,19 @@ def main():
         caf_only()
         return
 
-    from amaranth_twstft_amd import launch
+    from amaranth_twstft_amd import collective, launch
     if a.gpus > 1 and not launch.is_rank():
-        # not started by torchrun: start the N ranks as a child job (nothing here has touched the GPU yet)
-        sys.exit(launch.spawn_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:]))
+        # not started by torchrun: start the N ranks as a child job (nothing here has touched the GPU yet); a job that ends with
+        # a non-zero status is started once more, fresh, with the exchange on gloo — the line then says so
+        sys.exit(launch.spawn_with_fallback(a.gpus, os.path.abspath(__file__), sys.argv[1:], backend=a.backend))
     rank, local_rank, world = launch.rank_world()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE {world}: start with --nproc-per-node {a.gpus}, or without torchrun")
+    # control plane (gloo) and the RCCL probe job: before this process touches the GPU (amaranth_twstft_amd/collective.py)
+    use_dist = world > 1 or a.force_dist
+    ex = collective.RecordExchange(rank, world, want=a.backend, reason=os.environ.get("TWX_COLLECTIVE_FALLBACK_REASON") or None)
+    if use_dist:
+        ex.prepare(force=a.force_dist)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -372,33 +381,15 @@ def main():
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    if a.backend == "nccl" and local_rank >= ndev:
-        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPUs visible")
+    sharing = world > ndev                  # fewer GPUs than ranks (tests): ranks share devices, the exchange is then gloo by necessity
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or a.force_dist
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        try:
-            if a.backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            else:
-                dist.init_process_group(a.backend, rank=rank, world_size=world)
-            probe = torch.zeros(1, device=dev if a.backend == "nccl" else "cpu")
-            dist.all_reduce(probe)                      # the first collective builds the communicator: fail HERE, with the library's text
-            if a.backend == "nccl":
-                torch.cuda.synchronize()
-        except Exception as e:                          # no retry, no re-exec: a rank that cannot join ends the job with a non-zero status
-            sys.stderr.write("bench.py rank %d/%d: %s initialisation failed: %s: %s\n(HSA_ENABLE_IPC_MODE_LEGACY=%s, visible GPUs %d)\n"
-                             % (rank, world, a.backend, type(e).__name__, e, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), ndev))
-            sys.exit(3)
 
     from amaranth_twstft_amd import _lib as L, prn
     from amaranth_twstft_amd.correlator import Correlator, band_godual
     lib = L.load()
+    pin = collective.pin_to_device(lib, local_rank)         # this rank's threads next to its GPU (NUMA node of the device)
 
     chips = prn.lfsr_chips(BITLEN, TAPS, NCHIPS)
     cor = Correlator(chips, fs=FS, Nint=1, device=local_rank, max_batch=a.batch)
@@ -418,6 +409,10 @@ def main():
     gathered = torch.zeros((world * nwin, C.sizeof(L.twx_result)), dtype=torch.uint8, device=dev) if use_dist else None
     band = L.twx_band(*band_godual(FS, N))
     df_true = np.array([1780.75] * nwin, dtype=np.float64)
+    if use_dist:
+        # data plane: RCCL sub-group + a rehearsal of the real gather, each under a deadline and agreed on by all ranks; any
+        # failure leaves the exchange on gloo, flagged in the line
+        ex.bring_up(dev, rehearsal=(gathered, res))
 
     def step(c, workload=None):
         if (workload or a.workload) == "processing":
@@ -426,18 +421,12 @@ def main():
             L.check(lib.twx_process_windows_dev(c._h, iq.data_ptr(), nwin, 1, 0, None, df_true.ctypes.data_as(C.c_void_p),
                                                 res.data_ptr()), c._h)
         if use_dist:
-            L.check(lib.twx_synchronize(c._h), c._h)        # results complete before RCCL reads them
-            if a.backend == "nccl":
-                dist.all_gather_into_tensor(gathered, res)        # RCCL over xGMI, 240 B per window
-                torch.cuda.current_stream().synchronize()         # the next step rewrites `res` from the library's own streams
-            else:
-                host = gathered.cpu()
-                dist.all_gather_into_tensor(host, res.cpu())
-                gathered.copy_(host)
+            L.check(lib.twx_synchronize(c._h), c._h)        # results complete before the exchange reads them
+            ex.all_gather_records(gathered, res)            # RCCL over xGMI, 240 B per window (returns when `gathered` is complete:
+                                                            # the next step rewrites `res` from the library's own streams)
 
     def barrier():
-        if use_dist:
-            dist.barrier()
+        ex.barrier()
         L.check(lib.twx_synchronize(cor._h), cor._h)
         torch.cuda.synchronize()
 
@@ -447,12 +436,7 @@ def main():
         for _ in range(steps):
             step(cor, workload)
         barrier()
-        dt = time.perf_counter() - t0
-        if use_dist:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
-        return dt
+        return ex.max_float(time.perf_counter() - t0)      # the slowest rank's time
 
     t_ready = time.perf_counter()
     for _ in range(a.warmup):
@@ -482,13 +466,17 @@ def main():
             ok = all(int(garr[r * nwin + p].indice0) == 3 * window_params(p, r)[1] for p in range(nwin))
             per_rank.append(bool(ok))
         own = gh[rank * nwin:(rank + 1) * nwin].tobytes() == host
-        collective = {"op": "all_gather_into_tensor", "backend": a.backend + (" (RCCL)" if a.backend == "nccl" else ""), "world": world,
+        collective = {"op": "all_gather_into_tensor", "backend": ex.describe(), "requested": a.backend, "world": world,
                       "records": world * nwin, "bytes_per_rank": nwin * C.sizeof(L.twx_result), "ranks_with_exact_lags": int(sum(per_rank)),
-                      "gathered_lag_exact": bool(all(per_rank)), "own_block_identical": bool(own), "checked_on_rank": rank}
+                      "gathered_lag_exact": bool(all(per_rank)), "own_block_identical": bool(own), "checked_on_rank": rank,
+                      "control_plane": "gloo over 127.0.0.1 (barriers, max-over-ranks of the time, agreements)"}
+        if ex.probe is not None:
+            collective["rccl_probe"] = {k: ex.probe[k] for k in ("ok", "tried", "seconds") if k in ex.probe}
+        if sharing:
+            collective["ranks_sharing_devices"] = f"{world} ranks on {ndev} GPU(s)"
         # every rank checks its copy; rank 0 reports whether ALL copies were right
-        flag = torch.tensor([1 if (all(per_rank) and own) else 0], dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        collective["all_ranks_agree"] = bool(int(flag.item()) == 1)
+        collective["all_ranks_agree"] = ex.all_true(bool(all(per_rank) and own))
+        collective["numa"] = ex.all_objects(pin)            # per rank: NUMA node of its GPU and the CPUs it was bound to
 
     samples = world * nwin * N * a.steps
     value = samples / dt / 1e6
@@ -615,6 +603,12 @@ def main():
             out["caf_workload"]["roofline"]["traffic_live_error"] = pmc_caf[1]
     if collective is not None:
         out["collective"] = collective
+    else:
+        out["numa"] = pin
+    if world > 1:
+        out["omitted_at_n_gt_1"] = {"cpu_baseline": "N=1 only (the bench contract: rank 0 at N=1)",
+                                    "roofline.traffic": "the live rocprofv3 --pmc passes run at N=1 only; here from the committed profiles/pmc_traffic.json",
+                                    "caf_workload": "N=1 only"}
     if cpu is not None:
         if "single_core" in cpu:
             n_cpu = cpu["single_core"]["windows"]
@@ -644,9 +638,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     cor.close()
-    if use_dist:
-        dist.barrier()                   # rank 0 may still have been profiling; leave together
-        dist.destroy_process_group()
+    ex.close()                           # (barrier first: rank 0 may still have been profiling; leave together)
 
 
 if __name__ == "__main__":

@@ -22,8 +22,10 @@ extern "C" {
 
 /* 2: twx_config.reserved became the live field nphase (the struct must be zero-initialised), the tracked-ranging,
  *    acquisition and *_dev entry points were added.  twx_abi_version() of an older library answers 1.
- * 3: twx_multi_* (several GPUs from one host process) and twx_rx_* (the DLL/PLL receiver) added; nothing changed. */
-#define TWX_ABI_VERSION 4
+ * 3: twx_multi_* (several GPUs from one host process) and twx_rx_* (the DLL/PLL receiver) added; nothing changed.
+ * 5: twx_multi_info grew (rccl_fallback, threads_pinned, numa_node, rccl_error: the RCCL exchange falls back to host-side
+ *    concatenation instead of failing the job); twx_device_affinity / twx_pin_thread_to_device added. */
+#define TWX_ABI_VERSION 5
 
 typedef struct twx_ctx twx_ctx;
 
@@ -498,7 +500,10 @@ int twx_tracked_search_df(twx_tracked* trk, const int16_t* iq, int64_t n_samples
  * ncclGroupStart/End).  RCCL needs one rank per device: when the list names a device twice the blocks are concatenated on
  * the host instead (a one-GPU box then exercises the threading and the ordering with e.g. {0,0,0,0}).  RCCL is bound at run
  * time (librccl.so.1, TWX_RCCL_LIB overrides), so single-GPU hosts never map it.  Results are those of one context, record
- * for record.  Not thread-safe: one caller at a time per twx_multi. */
+ * for record.  Not thread-safe: one caller at a time per twx_multi.
+ * The exchange never loses the job: RCCL that cannot be loaded, an ncclCommInitAll that fails or does not return within
+ * TWX_RCCL_INIT_TIMEOUT_S (120), a collective that fails or does not complete within TWX_RCCL_GATHER_TIMEOUT_S (60) turn the
+ * object to host-side concatenation for good, reported in twx_multi_info.rccl_fallback / rccl_error. */
 typedef struct twx_multi twx_multi;
 enum { TWX_MULTI_NO_RCCL = 1,      /* host-side concatenation even for distinct devices */
        TWX_MULTI_RCCL_ONE = 2 };   /* a list of ONE device still builds its RCCL world of one (same calls as N > 1) */
@@ -509,6 +514,12 @@ typedef struct twx_multi_info {
     int64_t records_gathered;      /* last call: records in the gathered buffer (blocks padded to the longest) */
     int64_t bytes_per_rank;        /* last call: bytes each context contributed */
     double gather_ms;              /* last call: wall time of the collective incl. its synchronisation */
+    /* ABI 5 */
+    int32_t rccl_fallback;         /* 0: none.  1: RCCL could not be loaded / ncclCommInitAll failed or timed out at creation; 2: a collective
+                                    * failed or timed out later.  Either way the records are concatenated on the host since (rccl = 0) */
+    int32_t threads_pinned;        /* worker threads bound to the CPUs of their device's NUMA node */
+    int32_t numa_node[64];         /* per context: NUMA node of its device (-1: the platform does not say) */
+    char rccl_error[256];          /* the text behind rccl_fallback ("" when 0) */
 } twx_multi_info;
 int twx_multi_create(const twx_config* cfg, const int32_t* devices, int32_t n_devices, int32_t flags, twx_multi** out);
 void twx_multi_destroy(twx_multi* m);
@@ -528,6 +539,12 @@ int twx_multi_process_windows_dev(twx_multi* m, const void* const* iq_dev, int64
                                   int32_t channel, const twx_band* band, const double* df, twx_result* out);
 /* Context i's copy of the gathered records of the last *_dev call (what the collective delivered to that device). */
 int twx_multi_fetch_gathered(twx_multi* m, int32_t i, twx_result* out, int64_t n_records);
+/* NUMA placement of a device (/sys/bus/pci/devices/<bus id>/{numa_node,local_cpulist}): *numa_node = -1 where the platform does
+ * not say; cpulist (may be NULL) receives the kernel's list text.  twx_pin_thread_to_device binds the CALLING thread to those CPUs
+ * (intersected with the CPUs it may already use; TWX_NO_PIN=1 or an unknown node: nothing is changed, still TWX_OK) — what the
+ * twx_multi workers do for themselves, exported for hosts that run one process or thread per GPU of their own. */
+int twx_device_affinity(int32_t device, int32_t* numa_node, char* cpulist, size_t cap);
+int twx_pin_thread_to_device(int32_t device, int32_t* numa_node, int32_t* n_cpus);
 
 /* Profiling (TWX_FLAG_PROFILE): per kernel class, HIP-event time on the context's stream. */
 #define TWX_PROF_MAX 16

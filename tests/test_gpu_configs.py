@@ -320,6 +320,71 @@ def test_bench_two_ranks_over_real_rccl():
     assert c["records"] == 48 and c["ranks_with_exact_lags"] == 2 and c["gathered_lag_exact"] and c["all_ranks_agree"]
 
 
+def _bench_line(args, env_extra=None, torchrun=0, timeout=900):
+    env = dict(os.environ, PYTHONPATH=ROOT, **(env_extra or {}))
+    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={torchrun}", "--master-addr", "127.0.0.1",
+            "--master-port", "29541"] if torchrun else [sys.executable]
+    out = subprocess.run(head + [os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]), out
+
+
+@pytest.mark.parametrize("how", ["driver", "self", "real_rccl_error", "probe_child", "job"])
+def test_bench_asked_for_rccl_never_ends_empty(how):
+    """`bench.py --gpus 2` with the default backend (nccl = RCCL) where RCCL cannot come up must still print a valid line, exit 0,
+    with the exchange on gloo and the reason in `collective.backend`:
+    driver  — started the way the round-end driver starts it (torch.distributed.run ... bench.py --gpus 2); two ranks, one GPU here:
+              rank 0's probe refuses before anything touches the device;
+    self    — the self-launching form;
+    real_rccl_error — the probe's child job really runs, its ranks sharing the GPU: RCCL itself refuses (a genuine RCCL error text);
+    probe_child     — one rank of the probe job dies (wherever >= 2 GPUs exist this is the injected form of the same);
+    job     — a rank of the JOB dies while RCCL is asked for: the launcher, which never touched a GPU, starts ONE fresh job on gloo."""
+    import torch
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "9", "--no-cpu-baseline", "--no-roofline"]
+    two = torch.cuda.device_count() >= 2
+    env, torchrun = {}, 0
+    if how == "driver":
+        torchrun = 2
+        if two:
+            env = {"TWX_INJECT_RCCL_FAIL": "probe"}
+    elif how == "self":
+        if two:
+            env = {"TWX_INJECT_RCCL_FAIL": "probe"}
+    elif how == "real_rccl_error":
+        if two:
+            pytest.skip("two GPUs: RCCL works, nothing to refuse (the injected forms cover the branch)")
+        env = {"TWX_RCCL_PROBE_SHARE": "1", "TWX_RCCL_PROBE_TIMEOUT_S": "150"}
+    elif how == "probe_child":
+        env = {"TWX_RCCL_PROBE_SHARE": "1", "TWX_INJECT_RCCL_FAIL": "probe_child:1", "TWX_RCCL_PROBE_TIMEOUT_S": "150"}
+    else:
+        env = {"TWX_INJECT_RCCL_FAIL": "exit:1"}
+    j, out = _bench_line(args, env, torchrun, timeout=1500)
+    c = j["collective"]
+    assert j["n_gpus"] == 2 and j["integer_lag_exact"] and j["value"] > 0
+    assert c["backend"].startswith("gloo (fallback: "), c
+    assert c["requested"] == ("gloo" if how == "job" else "nccl")
+    assert c["world"] == 2 and c["records"] == 18 and c["ranks_with_exact_lags"] == 2 and c["gathered_lag_exact"] and c["all_ranks_agree"]
+    assert len(c["numa"]) == 2 and all(x["ok"] for x in c["numa"])
+    assert "cpu_baseline" in j["omitted_at_n_gt_1"]
+    if how == "job":
+        assert "restarted by the launcher" in c["backend"] and "starting it once more" in out.stderr
+    elif how in ("real_rccl_error", "probe_child"):
+        assert "RCCL probe job failed" in c["backend"] and c["rccl_probe"]["ok"] is False and len(c["rccl_probe"]["tried"]) == 2   # both environments tried
+    else:
+        assert "RCCL probe job failed" in c["backend"]
+
+
+@pytest.mark.parametrize("step", ["init:0", "rehearsal:0"])
+def test_bench_rccl_bring_up_failure_in_the_rank_falls_back(step):
+    """The in-rank stages after a good probe: the RCCL sub-group's first all_reduce, then the rehearsal of the real gather — a failure
+    in either (injected; world of one, --force-dist) is agreed on over the control plane and the exchange stays on gloo."""
+    j, _ = _bench_line(["--gpus", "1", "--steps", "2", "--warmup", "1", "--windows", "9", "--force-dist", "--no-cpu-baseline", "--no-roofline"],
+                       {"TWX_INJECT_RCCL_FAIL": step, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29534"})
+    c = j["collective"]
+    assert c["backend"].startswith("gloo (fallback: RCCL bring-up failed: rank 0: RuntimeError: injected failure"), c
+    assert j["integer_lag_exact"] and c["gathered_lag_exact"] and c["own_block_identical"] and c["all_ranks_agree"]
+
+
 def test_bench_measures_the_pmc_traffic_itself():
     """roofline.traffic of the driver-style line is measured by the invocation (two rocprofv3 --pmc child passes before the first
     GPU call), not read from a committed file; it equals the dominant kernel's algorithmic bytes to 2 % (no wasted re-reads)."""

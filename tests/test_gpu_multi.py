@@ -104,6 +104,71 @@ def test_rccl_world_of_one_runs_the_collective_calls(tmp_path):
     assert got.tobytes() == ref.tobytes()
 
 
+@pytest.mark.parametrize("inject,stage", [("init", 1), ("init_hang", 1), ("gather", 2), ("gather_timeout", 2)])
+def test_rccl_failures_fall_back_to_host_concatenation(tmp_path, monkeypatch, inject, stage):
+    """The exchange must never lose the job: ncclCommInitAll failing or not returning (stage 1), a collective failing or never
+    completing (stage 2) — injected, a one-GPU box has no other way in — leave the driver on host-side concatenation, flagged in
+    twx_multi_info with the reason; records byte-identical to the run without RCCL, file path and device-resident path."""
+    import torch
+    chips, raw, path = _two_channel_capture(tmp_path, 7)
+    n = 2 * len(chips)
+    band = band_godual(FS, n)
+    with MultiCorrelator(chips, [0], fs=FS, Nint=1, rccl=False) as a:
+        ref = a.process_file(path, n_channels=2, channel=0, band=band, raw_records=True)
+        assert a.info.rccl == 0 and a.info.rccl_fallback == 0 and a.info.rccl_error == b""
+    monkeypatch.setenv("TWX_MULTI_INJECT", inject)
+    with MultiCorrelator(chips, [0], fs=FS, Nint=1, rccl=True) as b:
+        i = b.info
+        if stage == 1:
+            assert i.rccl == 0 and i.rccl_fallback == 1 and b"ncclCommInitAll" in i.rccl_error and b"injected" in i.rccl_error
+        else:
+            assert i.rccl == 1 and i.rccl_fallback == 0
+        got = b.process_file(path, n_channels=2, channel=0, band=band, raw_records=True)
+        i = b.info
+        assert i.rccl == 0 and i.rccl_fallback == stage and i.records_gathered == 7
+        assert (b"ncclAllGather" in i.rccl_error) == (stage == 2), i.rccl_error
+        assert got.tobytes() == ref.tobytes()
+        again = b.process_file(path, n_channels=2, channel=0, band=band, raw_records=True)        # stays on the host path, quietly
+        assert again.tobytes() == ref.tobytes() and b.info.rccl_fallback == stage
+    # the device-resident step (bench.py --single-process): the fall-back happens inside the very call whose collective failed
+    dev_raw = torch.from_numpy(raw.reshape(-1, 4)[:, :2].copy().reshape(-1)).to("cuda:0")
+    with MultiCorrelator(chips, [0], fs=FS, Nint=1, rccl=True) as c:
+        got_dev = c.process_dev([dev_raw.data_ptr()], 7, band=band)
+        assert c.info.rccl == 0 and c.info.rccl_fallback == stage
+        assert c.fetch_gathered(0, 7).tobytes() == got_dev.tobytes()
+    monkeypatch.delenv("TWX_MULTI_INJECT")
+    with MultiCorrelator(chips, [0], fs=FS, Nint=1, rccl=True) as d:
+        want_dev = d.process_dev([dev_raw.data_ptr()], 7, band=band)
+        assert d.info.rccl == 1 and d.info.rccl_fallback == 0
+    assert got_dev.tobytes() == want_dev.tobytes()
+
+
+def test_workers_are_placed_next_to_their_device():
+    """NUMA placement: twx_device_affinity answers from /sys/bus/pci/devices/<bus id>/, the twx_multi workers bind themselves to those
+    CPUs where the platform names a node (threads_pinned), and a rank's own thread can do the same (twx_pin_thread_to_device)."""
+    from amaranth_twstft_amd import prn
+    lib = L.load()
+    node, buf = C.c_int32(-7), C.create_string_buffer(512)
+    assert lib.twx_device_affinity(0, C.byref(node), buf, 512) == 0 and node.value >= -1
+    assert lib.twx_device_affinity(99, C.byref(node), buf, 512) != 0
+    before = os.sched_getaffinity(0)
+    try:
+        n2, k = C.c_int32(-7), C.c_int32(-7)
+        assert lib.twx_pin_thread_to_device(0, C.byref(n2), C.byref(k)) == 0 and n2.value == node.value
+        if node.value >= 0 and buf.value:
+            assert k.value >= 1 and len(os.sched_getaffinity(0)) == k.value
+        else:
+            assert k.value == 0 and os.sched_getaffinity(0) == before              # the platform does not say: nothing changed
+    finally:
+        os.sched_setaffinity(0, before)
+    chips = prn.lfsr_chips(13, 27, 5000)
+    with MultiCorrelator(chips, [0, 0, 0], fs=FS, Nint=1) as m:
+        i = m.info
+        assert [i.numa_node[r] for r in range(3)] == [node.value] * 3 and i.numa_node[3] == -1
+        assert i.threads_pinned == (3 if node.value >= 0 and buf.value else 0)
+    assert os.sched_getaffinity(0) == before                                       # the caller's own thread is never touched by twx_multi
+
+
 def test_two_real_devices_gather_over_rccl(tmp_path):
     """Two distinct devices: the record exchange is one ncclAllGather over xGMI (skipped on a one-GPU box)."""
     import torch

@@ -13,7 +13,7 @@ import pytest
 
 from amaranth_twstft_amd import prn, synth
 from amaranth_twstft_amd import _lib as L
-from amaranth_twstft_amd.correlator import Correlator, band_numpy, band_godual, lfsr_chips_device
+from amaranth_twstft_amd.correlator import ALL_CHANNELS, Correlator, band_numpy, band_godual, lfsr_chips_device
 from oracle import twstft_oracle as orc
 from tests.helpers import load_golden, capture_from_desc, chips_for
 
@@ -1547,3 +1547,31 @@ def test_sliding_dot_on_complex_float_samples(nobs, ncodes, nlag, pt):
         y = scale * xx[pt + i] * np.exp(-2j * np.pi * (ff * i + phi))
         ref = orc.sliding_dot(y, w.astype(np.float64), nlag)
         assert np.abs(got[p] - ref).max() <= 3e-6 * np.abs(ref).max() + 1e-12
+
+
+def test_clipped_capture_power_is_the_same_on_every_loader_path():
+    """A capture that sits on the negative rail: (I, Q) = (-32768, -32768) gives I^2 + Q^2 = 2^31, one more than an int holds.  The
+    exact integer sums (k_sums: 16-byte path for an aligned single-channel window, scalar path otherwise, k_sums_deint2 for all
+    channels at once) must agree with each other and with the oracle — puissance / puissancenoise of godual_ranging.m:46-48."""
+    chips, raw2 = _capture(14, 43, 10000, 2, seed=91)
+    n = 2 * len(chips)
+    raw2 = raw2.reshape(-1, 4).copy()
+    rng = np.random.default_rng(4)
+    hit = rng.random(raw2.shape[0]) < 0.3
+    raw2[hit, 0] = raw2[hit, 1] = -32768                                        # channel 0 clipped on 30 % of its samples
+    raw2[:, 2:] = raw2[:, :2]                                                   # channel 1 = the same signal
+    one = raw2[:, :2].copy().reshape(-1)
+    band = band_numpy(FS, n)
+    ref = orc.ranging(one, chips, fs=FS, Nint=1, n_channels=1, channels=(0,), band="numpy")[0]
+    with Correlator(chips, fs=FS, Nint=1) as cor:
+        a = cor.process(one, n_channels=1, channel=0, band=band)                                   # 16-byte path
+        b = cor.process(raw2.reshape(-1), n_channels=2, channel=0, band=band)                      # scalar path (nch = 2)
+        c = cor.process(raw2.reshape(-1), n_channels=2, channel=1, band=band)
+        d = cor.process(raw2.reshape(-1), n_channels=2, channel=ALL_CHANNELS, band=band)           # k_sums_deint2
+    for w in range(2):
+        want = ref[w]
+        for got in (a[w], b[w], c[w], d[0][w], d[1][w]):
+            assert got.indice == want["indice"]
+            assert got.puissance == a[w].puissance and got.puissancenoise == a[w].puissancenoise  # bit-identical across the loader paths
+            assert abs(got.puissance - want["puissance"]) <= 1e-6 * want["puissance"]
+            assert abs(got.puissancenoise - want["puissancenoise"]) <= 1e-6 * want["puissancenoise"] + 5e-7 * want["puissancecode"]

@@ -45,6 +45,20 @@ def test_tracking_epoch_arithmetic_under_asan_ubsan(tmp_path):
     assert r.returncode == 0 and "track ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_device_affinity_helpers_under_asan_ubsan(tmp_path):
+    """csrc/twx_affinity.h (NUMA node / local CPUs of a GPU from sysfs, binding a worker thread) against a fake sysfs tree."""
+    for bus, node, cpus in (("0000:c1:00.0", "1", "0-1"), ("0000:05:00.0", "-1", "0"), ("0000:06:00.0", "0", "zero-three")):
+        d = tmp_path / "sys" / "bus" / "pci" / "devices" / bus
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(node + "\n")
+        (d / "local_cpulist").write_text(cpus + "\n")
+    exe = tmp_path / "affinity_test"
+    subprocess.run(["g++", "-O1", "-std=c++17", *SAN, "-I" + CSRC, "-o", str(exe), os.path.join(ROOT, "tests", "cpu", "affinity_test.cpp"), "-lpthread"], check=True)
+    r = subprocess.run([str(exe), str(tmp_path / "sys")], capture_output=True, text=True, env=ENV, timeout=300)
+    _no_report(r)
+    assert r.returncode == 0 and "affinity ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_host_threads_under_tsan(tmp_path):
     exe = tmp_path / "threads_tsan"
     subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I" + CSRC, os.path.join(ROOT, "tests", "cpu", "threads_tsan.cpp"),
