@@ -131,6 +131,14 @@ inline int search_df(const Params& P, Backend& be, const FreqAxis& freq, long lo
 
 // The capture loop.  skip_samples: complex samples skipped before the first chunk (fseek(f,30*fs*2*2), :128);
 // kbon_hint >= 0: a carrier bin known beforehand (no search).
+// The re-alignment test of the code loop (claudio_aligned_code_ranging_separate.m:175-176): a code measured above -30 dB whose peak
+// sits neither within the first 43 samples nor in the last two of the n-sample window makes the loop move its window.
+// `ind` = indice/(2Nint+1) on the 1-based sample grid, `snr` = SNR1r + SNR1i (linear).
+inline bool needs_realign(double ind, double snr, long long n) {
+    return snr > 0 && 10 * log10(snr) > -30 &&
+           ((ind > 43 && ind < (double)n / 2) || (ind < (double)n - 2 && ind > (double)n / 2));
+}
+
 inline int run(const Params& P, Backend& be, long long skip_samples, long long kbon_hint, Output& out) {
     out.clear();
     const long long n = P.n, Lc = P.L;
@@ -200,8 +208,7 @@ inline int run(const Params& P, Backend& be, long long skip_samples, long long k
                 if (P.indice_floor) ind = floor(ind);                       // lo :134
                 bool stop = false;
                 const double snr = g.snr_i + g.snr_r;
-                if (snr > 0 && 10 * log10(snr) > -30 &&
-                    ((ind > 43 && ind < (double)n / 2) || (ind < (double)n - 2 && ind > (double)n / 2))) {       // :175-176
+                if (needs_realign(ind, snr, n)) {                                                               // :175-176
                     out.moved.push_back(p);
                     out.movedval.push_back(ind + 1);
                     const double dcur = dindex + (double)j * (double)n;

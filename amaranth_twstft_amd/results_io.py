@@ -141,3 +141,41 @@ def save_cpp_mat(capture_path: str, res1, res2=None, remote: int = 0) -> str:
     path = cpp_mat_name(capture_path, remote)
     scipy.io.savemat(path, cpp_mat_dict(res1, res2), format="5", do_compression=False)
     return path
+
+
+def read_gofinal_table(path_or_lines) -> dict:
+    """A per-second table of gofinal_op.m / gofinal_ltfb.m (experiments/230111_twstft_2M5/gofinal_ltfb.m:86-89, the consumer of this
+    package's ``.mat`` output): a ``%`` header line, then rows ``Y m d H M S<TAB>delay<TAB>df1<TAB>SNR1<TAB>delay2<TAB>df2<TAB>SNR2
+    <TAB>delayrem<TAB>df1rem<TAB>SNR1rem`` (``%.12f  %.3f  %.1f`` three times); a row may stop after SNR2 (no remote solution): its
+    remote columns are NaN.  ``path_or_lines``: a file (``.gz`` allowed) or an iterable of text lines.  Returns arrays keyed
+    ``unix`` (seconds, the date taken as UTC), ``delay df1 SNR1 delay2 df2 SNR2 delayrem df1rem SNR1rem`` and ``date`` (n x 6 ints)."""
+    import calendar
+    import gzip
+    if isinstance(path_or_lines, (str, bytes)):
+        opener = gzip.open if str(path_or_lines).endswith(".gz") else open
+        with opener(path_or_lines, "rt") as f:
+            lines = f.read().splitlines()
+    else:
+        lines = list(path_or_lines)
+    names = ("delay", "df1", "SNR1", "delay2", "df2", "SNR2", "delayrem", "df1rem", "SNR1rem")
+    cols = {k: [] for k in names}
+    dates = []
+    for ln in lines:
+        ln = ln.rstrip("\r\n")
+        if not ln.strip() or ln.lstrip().startswith("%"):
+            continue
+        parts = ln.split("\t")
+        d = [int(x) for x in parts[0].split()]
+        if len(d) != 6:
+            raise ValueError(f"not a gofinal row: {ln[:60]!r}")
+        vals = [float(x) for x in parts[1:] if x.strip()]
+        if len(vals) not in (6, 9):
+            raise ValueError(f"{len(vals)} value columns in {ln[:60]!r} (6 or 9 expected)")
+        vals += [np.nan] * (9 - len(vals))
+        dates.append(d)
+        for k, v in zip(names, vals):
+            cols[k].append(v)
+    out = {k: np.asarray(v, dtype=np.float64) for k, v in cols.items()}
+    out["date"] = np.asarray(dates, dtype=np.int64).reshape(-1, 6)
+    out["unix"] = np.asarray([calendar.timegm(tuple(d) + (0, 0, 0)) for d in dates], dtype=np.float64)
+    return out

@@ -79,12 +79,14 @@ class TwoWay:
 
 
 def combine(oplo, opre, ltlo, ltre, N: int = 1, codes_per_s: int = 25, outlier_ns: float = 5.0,
-            unwrap: bool = False) -> TwoWay:
+            unwrap: bool = True) -> TwoWay:
     """go_1s.m:176-268 from the four delay series in ns (already restricted to their valid codes).
 
     ``unwrap`` applies the script's ±200/(2N+1) ns code-ambiguity shifts (:214-217) exactly as written —
-    including the second test ``res>median(res)-10`` that adds the step to almost every element — and is
-    off by default; everything else follows the script.
+    including the second test ``res>median(res)-10`` that adds the step to almost every element.  The script
+    runs these lines unconditionally, so they are ON by default (a drop-in must deliver the script's numbers:
+    on the reference's own 240527 records the mean moves by 200/3 ns, tests/test_ref_archives.py);
+    ``unwrap=False`` gives the plain ``0.5*((opre-oplo)-(ltre-ltlo))``.
     """
     oplo, opre, ltlo, ltre = (np.asarray(v, dtype=float) for v in (oplo, opre, ltlo, ltre))
     m = min(len(oplo), len(ltlo))                                    # :176-182

@@ -55,6 +55,7 @@ double trk_emul_freq(double fs, long long L, long long i) { return twx_trk::Freq
 void trk_emul_band(double fs, long long L, double lo, double hi, long long* k0, long long* nk) {
     twx_trk::band_indices(twx_trk::FreqAxis(fs, L), lo, hi, k0, nk);
 }
+int trk_emul_needs_realign(double ind, double snr, long long n) { return twx_trk::needs_realign(ind, snr, n) ? 1 : 0; }
 double trk_emul_median(const double* v, long long n) { return twx_trk::median_of(std::vector<double>(v, v + n)); }
 
 }  // extern "C"

@@ -969,7 +969,7 @@ def test_two_way_end_to_end_from_four_captures(tmp_path):
         ga, wb = [float(v) for v in a.split("\t")], [float(v) for v in b.split("\t")]
         assert ga[0] == wb[0] and max(abs(x - y) for x, y in zip(ga[1:], wb[1:])) <= 0.02, (a, b)
     # the two-way observable itself: res (ns), NaN pattern included
-    res_w = want["res"] - 200 / 3                                  # the oracle restates the shift of :210-211, the product leaves it off by default
+    res_w = want["res"]                                            # incl. the shift of :210-211: the product applies the script's lines by default (round 5)
     assert np.array_equal(np.isnan(tw.res), np.isnan(res_w)) and np.nanmax(np.abs(tw.res - res_w)) <= 0.03
     # every channel was re-aligned to sample 21 by the tracked loop (:183), so the four series sit at 21 samples = 4200 ns
     for series in (tw.oplo, tw.opre, tw.ltlo, tw.ltre):

@@ -37,7 +37,9 @@ def test_two_way_difference_and_one_second_rows():
     lt_re = sat + lt_lo - clock
     rec = dict(op_local=_record(n, op_lo, rng), op_remote=_record(n, op_re, rng),
                lt_local=_record(n, lt_lo, rng), lt_remote=_record(n, lt_re, rng))
-    tw = twoway.session(**rec)
+    as_script = twoway.session(**rec)                            # default = go_1s.m as written: the shift of :208-211 hits every code
+    tw = twoway.session(**rec, unwrap=False)                     # the plain two-way difference
+    assert abs((as_script.resmean - tw.resmean) - 200 / 3) < 1e-9 and abs(as_script.resstd - tw.resstd) < 1e-9
     assert len(tw.res) == n - 11                                 # 10 leading codes + the last one dropped
     assert abs(tw.resmean - clock) < 0.02 and tw.resstd < 0.2
     assert abs(tw.resmean25 - clock) < 0.02 and tw.resstd25 < tw.resstd
@@ -53,7 +55,7 @@ def test_outliers_become_nan():
     oplo = np.full(100, 700.0); ltlo = np.full(100, 900.0)
     opre = np.full(100, 1e6); ltre = np.full(100, 1e6 - 50)
     opre[40] += 30.0
-    tw = twoway.combine(oplo, opre, ltlo, ltre)
+    tw = twoway.combine(oplo, opre, ltlo, ltre, unwrap=False)
     assert np.isnan(tw.res[40]) and np.count_nonzero(np.isnan(tw.res)) == 1
     assert abs(tw.resmean - 125.0) < 1e-9
 
