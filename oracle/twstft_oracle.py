@@ -24,7 +24,14 @@ Parity pinning (see tests/golden/README.md, tools/make_golden.py):
     ``peak_refine_polyfit``), the C++-only Hamming window
     and the 231001_DLL_PLL acquisition/tracking restatements (incl. the receiver programs ``rx_second`` — rxcomplex.cpp and, with
     ``real=True``, rx.cpp with its interference cancellation ``rx_mai_up`` / ``rx_mai_out``) have no runnable twin here:
-    for those functions parity is UNPINNED (hand restatement, cross-checked by identities).
+    for those functions parity is UNPINNED (hand restatement, cross-checked by identities) — EXCEPT what the reference's own result
+    archives pin (round 5, tools/make_golden_archives.py -> tests/golden/ref_archives.*, tests/test_ref_archives.py): the parabola of
+    ``peak_refine`` / ``peak_refine_polyfit(.., 1)`` against 3 850 stored (xvalm1, xval, xvalp1, correction) sets of 220616_Besancon and the
+    ``freq_axis`` grid against its 101 distinct df values; ``make_code(lfsr_chips(17, 15 | 9, 100000))`` against the `code` variable of
+    230315_analysis_100k and SNR1r + SNR1i = puissancecode / puissancenoise; the re-alignment rule of ``ranging_tracked``
+    (claudio...separate.m:175-185: the limits 43 / n/2 / n-2, the -30 dB gate, movedval = indice1 + 1, the undivided re-measured
+    index) against all 2 087 production records of 2401_{OP,LTFB} and 240527 (16.9 M codes, 3 358 moves); ``go_1s_session`` runs on two
+    real sessions of 240527 (no stored output exists to compare with: the numbers are physically checked, not pinned).
 """
 from __future__ import annotations
 
