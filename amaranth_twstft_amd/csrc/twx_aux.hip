@@ -247,6 +247,127 @@ __global__ void k_sliding_reduce(const double* __restrict__ partial, int nchunks
     out[((long long)p * nl + li) * 2 + 1] = si * inv_nobs;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The sliding dot product on the MATRIX cores (round 5).  The reference evaluates this step as a GEMM — cblas_dgemm of the
+// (2 nlag + 1) x nobs replica matrix against the nobs x 2(bps-1) matrix of mixed samples (rxcomplex.cpp:605,989-999) — and so does
+// this kernel, on v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: bit-for-bit an fmaf chain, at the fp32 vector PEAK rate, which the
+// packed-FMA form above cannot reach: v_pk_fma_f32 issues at half of it):
+//     C[li][2p + c] = sum_i  W[li][i] * Y[i][2p + c],     W[li][i] = w[(i - (li - nlag)) mod nobs],   Y[i][2p + c] = Re/Im of the mixed sample
+// W is Toeplitz: it is never materialised, lane (i = l & 15, k = l >> 4) of an A operand reads w_seg[kk + k - li + 63] from the
+// replica segment in LDS (consecutive lanes, consecutive words).  Y is produced by the workgroup itself, 64 samples ("piece") of
+// up to 32 codes at a time: coalesced int16 / float loads, NCO per (sample, code) = exp(-2 pi j (ff i + phi)) [fp64 phase reduction,
+// one sincos per thread and piece] * exp(-2 pi j ff p nobs) [per code, once per workgroup], written column-major
+// (YT[col][sample], row stride 68 words: the writes of consecutive samples and the B-operand reads lane (j = l & 15, k = l >> 4)
+// -> YT[16 nt + j][kk + k] are both conflict-free).  Wave w owns the 16 lag rows of M tile (w mod MT) and every (4/MT)-th N
+// tile: no reduction across waves.  Pieces are dealt round-robin to the workgroups of a code group (grid.x), two buffers: the
+// loads and the mixing of the next piece are in flight while the matrix cores work on this one.
+//   grid = (workgroups per code group, ceil(ncodes / 32)), block = 256;   partial[p][part = blockIdx.x][li][2] as for k_sliding_dot
+// ---------------------------------------------------------------------------------------------
+constexpr int SM_P = 64, SM_LD = 68, SM_CG = 32;                 // samples per piece, words per YT row, codes per group
+template <typename XT, int MT>
+__global__ __launch_bounds__(256, 4) void k_sliding_mfma(const XT* __restrict__ x, int nch, long long pt, long long nobs, int ncodes, int nlag,
+                                                        const float* __restrict__ w, double ff, double phi, float scale, int npieces,
+                                                        double* __restrict__ partial /*[ncodes][gridDim.x][2*nlag+1][2]*/) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int NG = 4 / MT;                                     // N-tile groups (waves that share an M tile split the N tiles)
+    constexpr int NTW = 4 / NG;                                    // N tiles per wave at most (4 tiles = 64 columns = 32 codes per group)
+    __shared__ float yt[2][64 * SM_LD];
+    __shared__ float wseg[2][SM_P + 64];
+    __shared__ float2 ecode[SM_CG];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cg = blockIdx.y, p0 = cg * SM_CG, ncg = min(SM_CG, ncodes - p0);
+    const int ntile = (2 * ncg + 15) >> 4;
+    const int nl = 2 * nlag + 1;
+    const int mt = wv % MT, ng = wv / MT;
+    if (tid < ncg) {                                               // exp(-2 pi j ff p nobs): the code's place in the stream
+        double ph = ff * (double)((long long)(p0 + tid) * nobs);
+        ph -= rint(ph);
+        float sn, cs;
+        sincospif(-2.0f * (float)ph, &sn, &cs);
+        ecode[tid] = make_float2(cs * scale, sn * scale);          // the scale rides on the per-code factor
+    }
+    f4 acc[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    // mixing roles: thread (si = tid & 63, c0 = tid >> 6) takes sample si of the piece for the codes c0, c0 + 4, ... of the group
+    const int si = tid & 63, c0 = tid >> 6;
+    constexpr int NJ = SM_CG / 4;
+    XT nx[NJ];
+    auto load_piece = [&](int q) {
+        const long long i = (long long)q * SM_P + si;
+        const long long ic = min(i, nobs - 1);                     // clamped: the value is masked below
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int pl = min(c0 + 4 * j, ncg - 1);
+            nx[j] = x[(pt + (long long)(p0 + pl) * nobs + ic) * nch];
+        }
+    };
+    auto stage_w = [&](int q, int buf) {                           // entry u <-> w[(64 q + u - 63 + nlag) mod nobs], u < 128
+        if (tid < SM_P + 64) {
+            long long k = ((long long)q * SM_P + tid - 63 + nlag) % nobs;
+            if (k < 0) k += nobs;
+            wseg[buf][tid] = w[k];
+        }
+    };
+    auto mix_piece = [&](int q, int buf) {
+        const long long i = (long long)q * SM_P + si;
+        double ph = ff * (double)i + phi;                          // fp64 phase reduction, fp32 sincos
+        ph -= rint(ph);
+        float sn, cs;
+        sincospif(-2.0f * (float)ph, &sn, &cs);
+        const float m = i < nobs ? 1.f : 0.f;
+        cs *= m; sn *= m;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int pl = c0 + 4 * j;
+            if (pl < ncg) {
+                const float2 e = ecode[pl];
+                const float ec = cs * e.x - sn * e.y, es = cs * e.y + sn * e.x;
+                const float re = (float)nx[j].x, im = (float)nx[j].y;
+                yt[buf][(2 * pl) * SM_LD + si] = re * ec - im * es;
+                yt[buf][(2 * pl + 1) * SM_LD + si] = re * es + im * ec;
+            }
+        }
+    };
+    int q = blockIdx.x;
+    if (q < npieces) { load_piece(q); stage_w(q, 0); }
+    __syncthreads();                                               // ecode visible
+    if (q < npieces) mix_piece(q, 0);
+    int buf = 0;
+    for (; q < npieces; q += gridDim.x, buf ^= 1) {
+        const int qn = q + gridDim.x;
+        __syncthreads();                                           // piece q is in yt[buf] / wseg[buf]; the other buffer is free
+        if (qn < npieces) { load_piece(qn); stage_w(qn, buf ^ 1); }
+        // --- the matrix cores: 16 K steps of 4 samples
+        const float* ws = wseg[buf] + 63 - 16 * mt - (lane & 15) + (lane >> 4);
+        const float* yb = yt[buf] + (lane & 15) * SM_LD + (lane >> 4);
+#pragma unroll 4
+        for (int kk = 0; kk < SM_P; kk += 4) {
+            const float a = ws[kk];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                const int nt = ng + NG * i;
+                if (nt < ntile) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, yb[nt * 16 * SM_LD + kk], acc[i], 0, 0, 0);
+            }
+        }
+        if (qn < npieces) mix_piece(qn, buf ^ 1);
+    }
+    // D of 16x16x4: column = lane & 15, rows 4 (lane >> 4) + r
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = ng + NG * i;
+        const int col = nt * 16 + (lane & 15);
+        if (nt < ntile && col < 2 * ncg) {
+            const int p = p0 + (col >> 1), c = col & 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int li = 16 * mt + 4 * (lane >> 4) + r;
+                if (li < nl) partial[(((long long)p * gridDim.x + blockIdx.x) * nl + li) * 2 + c] = (double)acc[i][r];
+            }
+        }
+    }
+}
+
 // samples per workgroup: at most SD_CH (the LDS segment), chosen so that the grid is a whole number of "rounds" of two
 // workgroups per CU (a 600-workgroup grid on 512 slots runs a second, mostly empty round)
 // the streaming form for narrow lag windows (see the kernel): whole groups of eight samples, one channel
@@ -269,9 +390,43 @@ int sliding_chunk(long long nobs, int ncodes, bool narrow, bool wide8 = false) {
     len = std::max<long long>(4096, ((len + gran - 1) / gran) * gran);
     return (int)std::min<long long>(len, 1ll << 24);
 }
+// The matrix-core form: wide lag windows (the narrow ones are a stream over the samples, bound by HBM) and enough codes to fill
+// a 16-column tile to a useful degree.  TWX_SLIDING_MFMA=0 / 1 forces the choice (A/B runs, profiles/r05_sliding_mfma.txt).
+bool sliding_mfma(long long nobs, int ncodes, int nlag) {
+    static const int force = getenv("TWX_SLIDING_MFMA") ? atoi(getenv("TWX_SLIDING_MFMA")) : -1;
+    if (force == 0) return false;
+    if (force == 1) return true;
+    return nlag > 8 && ncodes >= 6 && nobs >= 4096;
+}
+// workgroups per code group: between 2 and 4 per CU, the count that wastes the least of the last round of 64-sample pieces
+int sliding_mfma_parts(long long nobs, int ncodes) {
+    int ncu = 256, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    const long long pieces = (nobs + SM_P - 1) / SM_P;
+    const int groups = (ncodes + SM_CG - 1) / SM_CG;
+    const long long lo = std::max<long long>(1, 2ll * ncu / groups), hi = std::max<long long>(lo, 4ll * ncu / groups);
+    if (pieces <= hi) return (int)pieces;
+    long long best = hi; double bw = 1e9;
+    for (long long n = hi; n >= lo; --n) {
+        const long long per = (pieces + n - 1) / n;
+        const double waste = (double)(per * n) / (double)pieces;
+        if (waste < bw - 1e-9) { bw = waste; best = n; }
+    }
+    return (int)best;
+}
 template <typename XT>
 int launch_sliding(hipStream_t st, const XT* dx, int nch, long long pt, long long nobs, int ncodes, int nlag, const float* dw,
                    double ff, double phi, double scale, double* dpart, double* dout, int ch = 0) {       // dx: the channel's sample of frame 0; ch: its place in the frame
+    if (sliding_mfma(nobs, ncodes, nlag)) {
+        const int npieces = (int)((nobs + SM_P - 1) / SM_P);
+        const int nparts = sliding_mfma_parts(nobs, ncodes);
+        const dim3 grid(nparts, (ncodes + SM_CG - 1) / SM_CG), block(256);
+        if (2 * nlag + 1 <= 32) hipLaunchKernelGGL((k_sliding_mfma<XT, 2>), grid, block, 0, st, dx, nch, pt, nobs, ncodes, nlag, dw, ff, phi, (float)scale, npieces, dpart);
+        else hipLaunchKernelGGL((k_sliding_mfma<XT, 4>), grid, block, 0, st, dx, nch, pt, nobs, ncodes, nlag, dw, ff, phi, (float)scale, npieces, dpart);
+        if (hipGetLastError() != hipSuccess) return TWX_E_HIP;
+        hipLaunchKernelGGL(k_sliding_reduce, dim3(ncodes), dim3(64), 0, st, dpart, nparts, 2 * nlag + 1, 1.0 / (double)nobs, dout);
+        return hipGetLastError() == hipSuccess ? TWX_OK : TWX_E_HIP;
+    }
     const bool narrow = sliding_narrow(nobs, nlag, nch);
     // wide windows, eight samples per lane (whole groups of eight, one channel): the per-pass overhead (mixing, addresses, the
     // LDS words) is shared by twice the FMAs
@@ -304,7 +459,8 @@ int launch_sliding(hipStream_t st, const XT* dx, int nch, long long pt, long lon
 }
 size_t sliding_part_bytes(long long nobs, int ncodes, int nlag) {
     const int clen = std::min(sliding_chunk(nobs, ncodes, false), sliding_chunk(nobs, ncodes, true));      // the form is chosen at launch (channel count); the wide8 chunks are no shorter
-    return (size_t)ncodes * (size_t)((nobs + clen - 1) / clen) * (2 * nlag + 1) * 16;
+    const size_t parts = std::max<size_t>((size_t)((nobs + clen - 1) / clen), (size_t)sliding_mfma_parts(nobs, ncodes));
+    return (size_t)ncodes * parts * (2 * nlag + 1) * 16;
 }
 
 // ---------------------------------------------------------------------------------------------

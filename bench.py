@@ -293,6 +293,168 @@ def single_process(a, t_start):
     m.close()
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: two stations x {local, remote} = four correlations on a 70-Msps wideband capture, fp32 and fp64
+# (acquisition/go_1s.m:88,120,147,171 consumes exactly these four series)
+# ------------------------------------------------------------------------------------------------------------------
+ALGO_BYTES_F64 = {"k_sums": lambda S: 4 * S, "k_col_fwd_square": lambda S: 20 * S, "k_row_band": lambda S: 16 * S, "k_df_tables": lambda S: 0,
+                  "k_col_fwd_mix": lambda S: 20 * S, "k_row_mid": lambda S: 64 * S + 16 * N, "k_col_inv": lambda S: 48 * S, "k_peak": lambda S: 0}
+
+
+def wideband_legs(local_rank: int, seconds: int = 4, steps: int = 5):
+    """Per step: for each of the two stations a `seconds`-long 70-Msps int16 capture (own code in the loop-back + the other station's
+    code 50 kHz off, chips held 28 samples) -> twx_fir_decimate_dev (577-tap Hamming low-pass, decimate by 14) -> 5-Msps int16 ->
+    FOUR correlations in flight together (four contexts, each with its own streams): OPlo, OPre, LTFBlo, LTFBre, every one the full
+    processing(d,k) over `seconds` 1-s windows with its own band.  Returns (wideband_workload, f64_workload): the fp32 chain with the
+    FIR's own roofline, and the same four correlations in fp64 with the roofline of their dominant kernel and the fp32-vs-fp64
+    peak-magnitude comparison configs[4] asks for."""
+    import numpy as np
+    import torch
+    from amaranth_twstft_amd import _lib as L, frontend, prn, synth
+    from amaranth_twstft_amd.correlator import Correlator, band_godual
+    lib = L.load()
+    dev = torch.device("cuda", local_rank)
+    fs_in, dec, sps_in = 70e6, 14, 28
+    taps = frontend.lowpass_taps(fs_in, 2.1e6, 0.4e6)
+    ntaps, W = int(taps.size), int(seconds)
+    n_out = W * N
+    n_in = (n_out - 1) * dec + ntaps
+    half = (ntaps - 1) // 2
+    codes = {"OP": prn.lfsr_chips(BITLEN, 57, NCHIPS), "LTFB": prn.lfsr_chips(BITLEN, 3, NCHIPS)}
+    cdev = {k: torch.from_numpy(v).to(dev) for k, v in codes.items()}
+    # (station, other, local delay [70-Msps samples], remote delay, remote carrier offset, OP flag of the remote band)
+    stations = [("OP", "LTFB", 18_364_717, 50_772_133, +50_000.0, 0), ("LTFB", "OP", 41_000_003, 9_123_457, -50_000.0, 1)]
+
+    def synth_into(out, chips_dev, p):
+        params = np.array([p.delay_q8, p.fstep, p.phi0, p.amp, p.noise_gain, p.seed, p.stream, 0], dtype=np.int64)
+        L.check(lib.twx_synth_capture_dev(out.data_ptr(), n_in, 0, chips_dev.data_ptr(), NCHIPS, sps_in, 1, params.ctypes.data_as(C.c_void_p), None))
+
+    wide, expect = {}, {}
+    for i, (st, other, d_loc, d_rem, f_rem, op_flag) in enumerate(stations):
+        a_ = torch.empty((n_in, 2), dtype=torch.int16, device=dev)
+        b_ = torch.empty((n_in, 2), dtype=torch.int16, device=dev)
+        synth_into(a_, cdev[st], synth.SynthParams(delay_q8=d_loc * 256, fstep=synth.fstep_for_df(3.25, fs_in), phi0=99, amp=2500,
+                                                   noise_gain=synth.noise_gain_for_sigma(2500.0), seed=401, stream=2 * i))
+        synth_into(b_, cdev[other], synth.SynthParams(delay_q8=d_rem * 256, fstep=synth.fstep_for_df(f_rem, fs_in), phi0=7, amp=1200,
+                                                      noise_gain=0, seed=402, stream=2 * i))
+        torch.cuda.synchronize(dev)
+        step_ = 1 << 26
+        for lo in range(0, n_in, step_):                      # a + b with saturation, in pieces (no 4-byte copy of the whole capture)
+            sl = slice(lo, min(n_in, lo + step_))
+            a_[sl] = (a_[sl].to(torch.int32) + b_[sl].to(torch.int32)).clamp_(-32768, 32767).to(torch.int16)
+        del b_
+        wide[st] = a_
+        expect[st + "lo"], expect[st + "re"] = (d_loc - half) / dec, (d_rem - half) / dec
+    torch.cuda.synchronize(dev)                                # torch's stream wrote the captures; the library's streams do not wait for it
+    nar = {st: torch.empty((n_out, 2), dtype=torch.int16, device=dev) for st in ("OP", "LTFB")}
+    # name -> (capture's station, code, band)
+    plan = {"OPlo": ("OP", "OP", band_godual(FS, N)), "OPre": ("OP", "LTFB", band_godual(FS, N, remote=1, OP=0)),
+            "LTFBlo": ("LTFB", "LTFB", band_godual(FS, N)), "LTFBre": ("LTFB", "OP", band_godual(FS, N, remote=1, OP=1))}
+    bands = {k: L.twx_band(*v[2]) for k, v in plan.items()}
+    res = {(k, pr): torch.zeros((W, C.sizeof(L.twx_result)), dtype=torch.uint8, device=dev) for k in plan for pr in ("f32", "f64")}
+
+    def make(precision, **kw):
+        return {k: Correlator(codes[v[1]], fs=FS, Nint=1, device=local_rank, precision=precision, **kw) for k, v in plan.items()}
+
+    def fir_all(ctx):
+        for st in ("OP", "LTFB"):
+            ctx[st + "lo"].fir_decimate_dev(wide[st].data_ptr(), n_in, taps, dec, out_i16_dev=nar[st].data_ptr())
+        for st in ("OP", "LTFB"):
+            ctx[st + "lo"].synchronize()                       # the remote correlations run on other contexts' streams
+
+    def corr_all(ctx, pr):
+        for k, (st, _, _) in plan.items():                     # four launches back to back: nothing waits in between
+            L.check(lib.twx_process_windows_dev(ctx[k]._h, nar[st].data_ptr(), W, 1, 0, C.byref(bands[k]), None, res[(k, pr)].data_ptr()), ctx[k]._h)
+        for k in plan:
+            ctx[k].synchronize()
+
+    def records(pr):
+        out = {}
+        for k in plan:
+            arr = (L.twx_result * W).from_buffer_copy(res[(k, pr)].cpu().numpy().tobytes())
+            out[k] = [(int(arr[w].indice0), math.hypot(arr[w].xval[0], arr[w].xval[1]), float(arr[w].df)) for w in range(W)]
+        return out
+
+    c32 = make("f32")
+    fir_all(c32); corr_all(c32, "f32")                          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fir_all(c32)
+    t_fir = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        corr_all(c32, "f32")
+    t_corr = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fir_all(c32); corr_all(c32, "f32")
+    t_step = (time.perf_counter() - t0) / steps
+    # the FIR kernel alone: HIP events on the stream it is launched on (the context's, not torch's)
+    es = torch.cuda.ExternalStream(int(lib.twx_stream(c32["OPlo"]._h)), device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c32["OPlo"].fir_decimate_dev(wide["OP"].data_ptr(), n_in, taps, dec, out_i16_dev=nar["OP"].data_ptr())
+    e0.record(es)
+    for _ in range(5):
+        c32["OPlo"].fir_decimate_dev(wide["OP"].data_ptr(), n_in, taps, dec, out_i16_dev=nar["OP"].data_ptr())
+    e1.record(es)
+    e1.synchronize()
+    fir_ms = e0.elapsed_time(e1) / 5
+    fir_flops = n_out * ntaps * 4                                # complex int16 sample x real tap: 2 FMAs
+    fir_bytes = n_in * 4 + n_out * 4
+    r32 = records("f32")
+    for c in c32.values():
+        c.close()
+
+    c64 = make("f64")
+    corr_all(c64, "f64")
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        corr_all(c64, "f64")
+    t_corr64 = (time.perf_counter() - t0) / steps
+    r64 = records("f64")
+    for c in c64.values():
+        c.close()
+    pc = Correlator(codes["OP"], fs=FS, Nint=1, device=local_rank, precision="f64", profile=True)
+    run1 = lambda: L.check(lib.twx_process_windows_dev(pc._h, nar["OP"].data_ptr(), W, 1, 0, C.byref(bands["OPlo"]), None, res[("OPlo", "f64")].data_ptr()), pc._h)
+    run1(); pc.profile(reset=True)
+    for _ in range(3):
+        run1()
+    prof = pc.profile()
+    pc.close()
+    kern = {k: (v["ms_total"] / v["launches"], v["units"] / v["launches"]) for k, v in prof.items() if v["launches"]}
+    dom = max(kern, key=lambda k: prof[k]["ms_total"])
+    dbytes = ALGO_BYTES_F64[dom](kern[dom][1])
+    dach = dbytes / (kern[dom][0] * 1e-3) / 1e9
+
+    lag_ok = all(abs(((r32[k][w][0] / 3.0 - expect[k] + N / 2) % N) - N / 2) < 1.0 for k in plan for w in range(W))
+    same = all(r32[k][w][0] == r64[k][w][0] for k in plan for w in range(W))
+    rel = max(abs(r32[k][w][1] - r64[k][w][1]) / r64[k][w][1] for k in plan for w in range(W))
+    corr_samples = 4 * W * N
+    wl = {"workload": f"BASELINE.json configs[4]: two stations x {{local, remote}} = 4 correlations (OPlo, OPre, LTFBlo, LTFBre: two LFSR(22) codes, taps 57 / 3, "
+                      f"remote signal +-50 kHz off), {W} s of 70-Msps int16 IQ per station, HBM-resident: FIR 577 taps decimate by 14 -> 5 Msps -> full "
+                      "processing(d,k) per 1-s window, the four correlations in flight together (four contexts), fp32",
+          "input_Msamples_per_s": round(2 * n_in / t_step / 1e6, 1), "correlated_Msamples_per_s": round(corr_samples / t_step / 1e6, 1),
+          "ms_per_step": round(t_step * 1e3, 3), "fir_ms_per_step": round(t_fir * 1e3, 3), "correlations_ms_per_step": round(t_corr * 1e3, 3),
+          "correlations_alone_Msamples_per_s": round(corr_samples / t_corr / 1e6, 1),
+          "chain_GBs_algorithmic": round(92 * corr_samples / t_corr / 1e9, 1), "chain_frac_hbm": round(92 * corr_samples / t_corr / 1e9 / HBM_PEAK_GBS, 4),
+          "expected_lags_within_one_sample": bool(lag_ok), "steps": steps,
+          "fir": {"kernel": "k_fir_poly8", "avg_ms": round(fir_ms, 4), "input_Msamples_per_s": round(n_in / fir_ms / 1e3, 1),
+                  "roofline": {"bound": "fp32 vector", "achieved": round(fir_flops / (fir_ms * 1e-3) / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
+                               "frac": round(fir_flops / (fir_ms * 1e-3) / 1e12 / 157.3, 4), "flops_per_launch": int(fir_flops)},
+                  "GB/s": round(fir_bytes / (fir_ms * 1e-3) / 1e9, 1), "frac_hbm": round(fir_bytes / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                  "timing": "HIP events on the context's stream around 5 launches"}}
+    f64 = {"workload": f"the same four correlations in fp64 (twx_config.precision = f64) on the decimated captures, {W} windows each, in flight together",
+           "dtype": "f64", "correlated_Msamples_per_s": round(corr_samples / t_corr64 / 1e6, 1), "ms_per_step": round(t_corr64 * 1e3, 3),
+           "chain_GBs_algorithmic": round(180 * corr_samples / t_corr64 / 1e9, 1), "chain_frac_hbm": round(180 * corr_samples / t_corr64 / 1e9 / HBM_PEAK_GBS, 4),
+           "roofline": {"bound": "hbm", "kernel": dom + " (fp64)", "achieved": round(dach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dach / HBM_PEAK_GBS, 4),
+                        "traffic": None, "algorithmic_bytes_per_launch": int(dbytes), "avg_ms": round(kern[dom][0], 4), "launches_timed": int(prof[dom]["launches"]),
+                        "note": "one correlation alone in a one-slot profiling context; complex double = 16 B"},
+           "kernels": {k: {"avg_ms": round(v[0], 4), "GB/s": round(ALGO_BYTES_F64[k](v[1]) / (v[0] * 1e-3) / 1e9, 1)} for k, v in kern.items() if k in ALGO_BYTES_F64},
+           "integer_lags_equal_fp32": bool(same), "fp32_vs_fp64_peak_rel": float("%.3g" % rel), "tolerance": 1e-6,
+           "within_tolerance": bool(rel <= 1e-6 and same)}
+    return wl, f64
+
+
 def caf_only():
     """Child of the CAF's `rocprofv3 --pmc` passes: one synthetic window, 128 Doppler bins = two full 64-bin launches of k_rowd_caf
     and of the last pass; nothing else of the bench runs."""
@@ -330,6 +492,9 @@ def main():
                     "from the committed profiles/pmc_traffic.json)")
     ap.add_argument("--no-caf", action="store_true", help="skip the BASELINE.json configs[2] leg (delay x Doppler CAF of one window)")
     ap.add_argument("--caf-only", action="store_true", help=argparse.SUPPRESS)      # the child of the CAF's --pmc passes: two full launches of the surface
+    ap.add_argument("--no-wideband", action="store_true", help="skip the BASELINE.json configs[4] legs (70-Msps front end + four correlations, fp32 and fp64)")
+    ap.add_argument("--wideband-only", action="store_true", help="run only the configs[4] legs and print their two objects (profiling runs)")
+    ap.add_argument("--wideband-seconds", type=int, default=4, help="seconds of 70-Msps capture per station in the configs[4] legs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                     "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--single-process", action="store_true", help="drive the --gpus N devices from THIS process through the library's "
@@ -348,6 +513,10 @@ def main():
         return
     if a.caf_only:
         caf_only()
+        return
+    if a.wideband_only:
+        wl, f64 = wideband_legs(0, a.wideband_seconds)
+        print(json.dumps({"wideband_workload": wl, "f64_workload": f64}))
         return
 
     from amaranth_twstft_amd import collective, launch
@@ -601,6 +770,14 @@ def main():
                            "interface_GBs prices the kernel's own interface bytes, most of which L2 / Infinity Cache serve")
         elif pmc_caf:
             out["caf_workload"]["roofline"]["traffic_live_error"] = pmc_caf[1]
+    # --- BASELINE.json configs[4]: the wideband front end + four concurrent correlations, and the same chain in fp64
+    if rank == 0 and world == 1 and not a.no_wideband and not a.no_roofline:
+        del iq, gathered
+        torch.cuda.empty_cache()
+        try:
+            out["wideband_workload"], out["f64_workload"] = wideband_legs(local_rank, a.wideband_seconds)
+        except Exception as e:                               # the headline line is never lost to a side leg
+            out["wideband_workload"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if collective is not None:
         out["collective"] = collective
     else:

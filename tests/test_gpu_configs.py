@@ -223,6 +223,21 @@ def test_config4_two_station_wideband_chain_at_size():
                 expect = (d70 - half) / dec
                 assert abs(results[name][0].indice / 3.0 - expect) < 1.0, name
         assert sorted(results) == ["LTFBlo", "LTFBre", "OPlo", "OPre"]
+        # ... and the four IN FLIGHT TOGETHER: four contexts (own streams each), four launches back to back, one wait at the end —
+        # record for record what the one-after-another calls above returned
+        lib = L.load()
+        with Correlator(codes["OP"], fs=FS, Nint=1) as x_op, Correlator(codes["LTFB"], fs=FS, Nint=1) as x_lt:
+            four = {"OPlo": c_op32, "OPre": c_lt32, "LTFBlo": x_lt, "LTFBre": x_op}          # a context per correlation
+            outs = {k: torch.zeros(C.sizeof(L.twx_result), dtype=torch.uint8, device=dev) for k in four}
+            for name, cx in four.items():
+                b = L.twx_band(*results[name][3])
+                L.check(lib.twx_process_windows_dev(cx._h, narrow[name[:-2]].data_ptr(), 1, 1, 0, C.byref(b), None, outs[name].data_ptr()), cx._h)
+            for cx in four.values():
+                cx.synchronize()
+            for name in four:
+                r = L.twx_result.from_buffer_copy(outs[name].cpu().numpy().tobytes())
+                g32 = results[name][0]
+                assert int(r.indice0) == g32.indice and complex(*r.xval) == g32.xval and r.df == g32.df and r.correction == g32.correction, name
     # oracle on the same decimated int16 samples, all four correlations
     for name, (g32, g64, code_key, band) in results.items():
         st = name[:-2]
@@ -383,6 +398,19 @@ def test_bench_rccl_bring_up_failure_in_the_rank_falls_back(step):
     c = j["collective"]
     assert c["backend"].startswith("gloo (fallback: RCCL bring-up failed: rank 0: RuntimeError: injected failure"), c
     assert j["integer_lag_exact"] and c["gathered_lag_exact"] and c["own_block_identical"] and c["all_ranks_agree"]
+
+
+def test_bench_wideband_and_fp64_legs():
+    """`bench.py --wideband-only`: the configs[4] objects of the driver's line — 70 Msps -> FIR -> four correlations in flight together
+    (fp32) with the FIR's fp32-vector roofline, and the same four in fp64 with the roofline of their dominant kernel; lags as expected,
+    fp32 = fp64 lag for lag, |peak| within 1e-6."""
+    j, _ = _bench_line(["--wideband-only", "--wideband-seconds", "1"])
+    w, f = j["wideband_workload"], j["f64_workload"]
+    assert w["expected_lags_within_one_sample"] and w["input_Msamples_per_s"] > 1000 and w["correlated_Msamples_per_s"] > 1000
+    assert w["fir"]["roofline"]["bound"] == "fp32 vector" and 0.05 < w["fir"]["roofline"]["frac"] < 1.0 and w["fir"]["avg_ms"] > 0
+    assert f["dtype"] == "f64" and f["integer_lags_equal_fp32"] and f["within_tolerance"] and f["fp32_vs_fp64_peak_rel"] <= 1e-6
+    r = f["roofline"]
+    assert r["bound"] == "hbm" and r["kernel"].startswith("k_row_mid") and 0.05 < r["frac"] < 1.0 and r["algorithmic_bytes_per_launch"] == 64 * 5_000_000 + 16 * 5_000_000
 
 
 def test_bench_measures_the_pmc_traffic_itself():
