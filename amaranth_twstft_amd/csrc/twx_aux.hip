@@ -259,26 +259,26 @@ __global__ void k_sliding_reduce(const double* __restrict__ partial, int nchunks
 // one sincos per thread and piece] * exp(-2 pi j ff p nobs) [per code, once per workgroup], written column-major
 // (YT[col][sample], row stride 68 words: the writes of consecutive samples and the B-operand reads lane (j = l & 15, k = l >> 4)
 // -> YT[16 nt + j][kk + k] are both conflict-free).  Wave w owns the 16 lag rows of M tile (w mod MT) and every (4/MT)-th N
-// tile: no reduction across waves.  Pieces are dealt round-robin to the workgroups of a code group (grid.x), two buffers: the
-// loads and the mixing of the next piece are in flight while the matrix cores work on this one.
-//   grid = (workgroups per code group, ceil(ncodes / 32)), block = 256;   partial[p][part = blockIdx.x][li][2] as for k_sliding_dot
+// tile: no reduction across waves.  Pieces are dealt round-robin to the workgroups of a code group (grid.x), two buffers.
+// Every wave does both jobs in turn (matrix-core phase on piece q, then the mixing of piece q + G; four workgroups = 16 waves per CU,
+// whose phases drift apart, keep both pipes busy).  Tried and measured slower: dedicated mixer / matrix-core waves in workgroups of
+// eight (two workgroups per CU: 121 us against 95 for 96 codes — profiles/r05_sliding_mfma.txt has the whole series).
+//   grid = (workgroups per code group, ceil(ncodes / 32)), block = 256;   partial: float [part = blockIdx.x][li][2 p + c]
 // ---------------------------------------------------------------------------------------------
 constexpr int SM_P = 64, SM_LD = 68, SM_CG = 32;                 // samples per piece, words per YT row, codes per group
-template <typename XT, int MT>
+template <typename XT, int MT, int NTW>
 __global__ __launch_bounds__(256, 4) void k_sliding_mfma(const XT* __restrict__ x, int nch, long long pt, long long nobs, int ncodes, int nlag,
                                                         const float* __restrict__ w, double ff, double phi, float scale, int npieces,
-                                                        double* __restrict__ partial /*[ncodes][gridDim.x][2*nlag+1][2]*/) {
+                                                        double* __restrict__ partial /*as float [gridDim.x][2*nlag+1][2*ncodes]*/, int ablate) {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    constexpr int NG = 4 / MT;                                     // N-tile groups (waves that share an M tile split the N tiles)
-    constexpr int NTW = 4 / NG;                                    // N tiles per wave at most (4 tiles = 64 columns = 32 codes per group)
+    // MT = M tiles (16 lag rows each: 2 for windows of up to 31 lags, 4 otherwise), NTW = N tiles of the group (16 columns = 8 codes
+    // each; the launcher instantiates the count of the fullest group, columns past a group's own are multiplied and never stored)
     __shared__ float yt[2][64 * SM_LD];
     __shared__ float wseg[2][SM_P + 64];
     __shared__ float2 ecode[SM_CG];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = blockIdx.y, p0 = cg * SM_CG, ncg = min(SM_CG, ncodes - p0);
-    const int ntile = (2 * ncg + 15) >> 4;
     const int nl = 2 * nlag + 1;
-    const int mt = wv % MT, ng = wv / MT;
     if (tid < ncg) {                                               // exp(-2 pi j ff p nobs): the code's place in the stream
         double ph = ff * (double)((long long)(p0 + tid) * nobs);
         ph -= rint(ph);
@@ -286,85 +286,163 @@ __global__ __launch_bounds__(256, 4) void k_sliding_mfma(const XT* __restrict__ 
         sincospif(-2.0f * (float)ph, &sn, &cs);
         ecode[tid] = make_float2(cs * scale, sn * scale);          // the scale rides on the per-code factor
     }
-    f4 acc[NTW];
+    // wave wv owns the 16 lag rows of M tile (wv mod MT) and every (4/MT)-th N tile: NTW accumulator tiles per wave, no sum across waves
+    // (all tiles in every wave with the samples split over the waves needs 64 accumulator registers next to the three sets of samples
+    // in flight: it spilled at the 128 registers of four workgroups per CU and ran 129 us where this form runs 95)
+    constexpr int NG = 4 / MT;
+    constexpr int NTL = (NTW + NG - 1) / NG;                       // N tiles per wave
+    const int mt = wv % MT, ng = wv / MT;
+    f4 acc[NTL];
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
-    // mixing roles: thread (si = tid & 63, c0 = tid >> 6) takes sample si of the piece for the codes c0, c0 + 4, ... of the group
-    const int si = tid & 63, c0 = tid >> 6;
+    for (int i = 0; i < NTL; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    // mixing roles: thread (si = tid & 63, c0 = its wave) takes sample si of the piece for the codes c0, c0 + 4, ... of the group.
+    // c0 is wave-uniform: the codes' stream bases are scalar (SGPR pair + 32-bit lane offset: no 64-bit vector address arithmetic
+    // per load — with it, the address code of a piece was as long as its mixing) and the per-code NCO factors are scalar operands
+    const int si = tid & 63, c0 = wv;
     constexpr int NJ = SM_CG / 4;
-    XT nx[NJ];
-    auto load_piece = [&](int q) {
+    // THREE pieces of samples on their way per mixer thread (three register sets, the loop below is unrolled by three): one piece
+    // ahead, the bytes in flight per CU (16 KB) against the load latency under load (~4 us) were 1 TB/s for the whole chip — the
+    // kernel waited for memory with idle matrix cores
+    XT nxr[3][NJ];
+    float wregr[3] = {0.f, 0.f, 0.f};
+    auto load_piece = [&](int q, XT (&nx)[NJ]) {
         const long long i = (long long)q * SM_P + si;
-        const long long ic = min(i, nobs - 1);                     // clamped: the value is masked below
+        const unsigned voff = (unsigned)(min(i, nobs - 1) * nch) * (unsigned)sizeof(XT);      // clamped: the value is masked below
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int pl = min(c0 + 4 * j, ncg - 1);
-            nx[j] = x[(pt + (long long)(p0 + pl) * nobs + ic) * nch];
+            const char* base = reinterpret_cast<const char*>(x + (pt + (long long)(p0 + pl) * nobs) * nch);      // uniform
+            nx[j] = *reinterpret_cast<const XT*>(base + voff);
         }
     };
-    auto stage_w = [&](int q, int buf) {                           // entry u <-> w[(64 q + u - 63 + nlag) mod nobs], u < 128
+    // replica segment of a piece: entry u <-> w[(64 q + u - 63 + nlag) mod nobs], u < 128.  Asked for with the samples.
+    auto load_w = [&](int q, float& wreg) {
         if (tid < SM_P + 64) {
-            long long k = ((long long)q * SM_P + tid - 63 + nlag) % nobs;
-            if (k < 0) k += nobs;
-            wseg[buf][tid] = w[k];
+            long long k = (long long)q * SM_P + tid - 63 + nlag;  // > -64, < nobs + 128
+            if (nobs >= 256) { if (k < 0) k += nobs; else if (k >= nobs) k -= nobs; }
+            else { k %= nobs; if (k < 0) k += nobs; }              // the division only for periods shorter than the segment
+            wreg = w[k];
         }
     };
-    auto mix_piece = [&](int q, int buf) {
-        const long long i = (long long)q * SM_P + si;
-        double ph = ff * (double)i + phi;                          // fp64 phase reduction, fp32 sincos
+    // NCO of the thread's sample: exact (fp64 phase reduction, fp32 sincos) on every fourth of the workgroup's pieces, stepped by the
+    // rotation between consecutive pieces of this workgroup exp(-2 pi j ff 64 gridDim.x) in between (three fp32 complex products at most)
+    float rgc, rgs;
+    {
+        double ph = ff * (double)((long long)SM_P * gridDim.x);
         ph -= rint(ph);
-        float sn, cs;
-        sincospif(-2.0f * (float)ph, &sn, &cs);
+        sincospif(-2.0f * (float)ph, &rgs, &rgc);
+    }
+    float ncs = 1.f, nsn = 0.f;
+    float ecx[NJ], ecy[NJ];                                        // this wave's codes: uniform values (scalar registers), set below
+    auto mix_piece = [&](int q, int buf, int it, const XT (&nx)[NJ], float wreg) {
+        const long long i = (long long)q * SM_P + si;
+        if ((it & 3) == 0) {
+            double ph = ff * (double)i + phi;
+            ph -= rint(ph);
+            sincospif(-2.0f * (float)ph, &nsn, &ncs);
+        } else {
+            const float c2 = ncs * rgc - nsn * rgs, s2 = ncs * rgs + nsn * rgc;
+            ncs = c2; nsn = s2;
+        }
         const float m = i < nobs ? 1.f : 0.f;
-        cs *= m; sn *= m;
+        const float cs = ncs * m, sn = nsn * m;
+        float* yrow = yt[buf] + (2 * c0) * SM_LD + si;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int pl = c0 + 4 * j;
-            if (pl < ncg) {
-                const float2 e = ecode[pl];
-                const float ec = cs * e.x - sn * e.y, es = cs * e.y + sn * e.x;
+            if (c0 + 4 * j < ncg) {                                 // uniform
+                const float ec = cs * ecx[j] - sn * ecy[j], es = cs * ecy[j] + sn * ecx[j];
                 const float re = (float)nx[j].x, im = (float)nx[j].y;
-                yt[buf][(2 * pl) * SM_LD + si] = re * ec - im * es;
-                yt[buf][(2 * pl + 1) * SM_LD + si] = re * es + im * ec;
+                yrow[(8 * j) * SM_LD] = re * ec - im * es;
+                yrow[(8 * j + 1) * SM_LD] = re * es + im * ec;
             }
         }
+        if (tid < SM_P + 64) wseg[buf][tid] = wreg;
     };
+    const int G = gridDim.x, qlast = npieces - 1;
     int q = blockIdx.x;
-    if (q < npieces) { load_piece(q); stage_w(q, 0); }
+    // loads are unconditional (a piece past the end is the last one again; its mixing lands in a buffer nobody reads): behind a
+    // branch the wait-count pass assumes the loads were skipped and every mixing waits with vmcnt(0) — for the set asked for one step
+    // ago, i.e. a full memory latency per piece
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { load_piece(min(q + k * G, qlast), nxr[k]); load_w(min(q + k * G, qlast), wregr[k]); }
     __syncthreads();                                               // ecode visible
-    if (q < npieces) mix_piece(q, 0);
-    int buf = 0;
-    for (; q < npieces; q += gridDim.x, buf ^= 1) {
-        const int qn = q + gridDim.x;
-        __syncthreads();                                           // piece q is in yt[buf] / wseg[buf]; the other buffer is free
-        if (qn < npieces) { load_piece(qn); stage_w(qn, buf ^ 1); }
-        // --- the matrix cores: 16 K steps of 4 samples
-        const float* ws = wseg[buf] + 63 - 16 * mt - (lane & 15) + (lane >> 4);
-        const float* yb = yt[buf] + (lane & 15) * SM_LD + (lane >> 4);
-#pragma unroll 4
-        for (int kk = 0; kk < SM_P; kk += 4) {
-            const float a = ws[kk];
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) {
-                const int nt = ng + NG * i;
-                if (nt < ntile) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, yb[nt * 16 * SM_LD + kk], acc[i], 0, 0, 0);
-            }
-        }
-        if (qn < npieces) mix_piece(qn, buf ^ 1);
+    for (int j = 0; j < NJ; ++j) {
+        const float2 e = ecode[min(c0 + 4 * j, ncg - 1)];
+        ecx[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, e.x)));
+        ecy[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, e.y)));
     }
-    // D of 16x16x4: column = lane & 15, rows 4 (lane >> 4) + r
+    mix_piece(min(q, qlast), 0, 0, nxr[0], wregr[0]);              // piece 0 of this workgroup into buffer 0
+    load_piece(min(q + 3 * G, qlast), nxr[0]); load_w(min(q + 3 * G, qlast), wregr[0]);
+    // matrix-core phase: 16 K steps of 4 samples on the wave's tiles
+    int buf = 0, it = 1;
+#define SM_STEP(K_)                                                                                                       \
+    {                                                                                                                     \
+        __syncthreads();                                          /* piece q is in yt[buf] / wseg[buf]; the other is free */ \
+        if (ablate != 1) {                                                                                                \
+            const float* ws = wseg[buf] + 63 - 16 * mt - (lane & 15) + (lane >> 4);                                       \
+            const float* yb = yt[buf] + ((lane & 15) + 16 * ng) * SM_LD + (lane >> 4);                                    \
+            _Pragma("unroll") for (int kk = 0; kk < SM_P; kk += 4) {                                                      \
+                const float a = ws[kk];                                                                                   \
+                _Pragma("unroll") for (int i = 0; i < NTL; ++i)                                                           \
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, yb[NG * i * 16 * SM_LD + kk], acc[i], 0, 0, 0);      \
+            }                                                                                                             \
+        }                                                                                                                 \
+        if (ablate != 2) {                                                                                                \
+            mix_piece(min(q + G, qlast), buf ^ 1, it, nxr[K_], wregr[K_]);                                                \
+            load_piece(min(q + 4 * G, qlast), nxr[K_]); load_w(min(q + 4 * G, qlast), wregr[K_]);                         \
+        }                                                                                                                 \
+        q += G; buf ^= 1; ++it;                                                                                           \
+    }
+    while (q < npieces) {
+        SM_STEP(1)
+        if (q >= npieces) break;
+        SM_STEP(2)
+        if (q >= npieces) break;
+        SM_STEP(0)
+    }
+#undef SM_STEP
+    // D of 16x16x4: column = lane & 15, rows 4 (lane >> 4) + r.  The workgroup's part leaves as floats (what the accumulators are),
+    // [part][li][2 p + c]: the sixteen lanes of a row write 64 contiguous bytes
+    float* po = reinterpret_cast<float*>(partial) + (long long)blockIdx.x * nl * 2 * ncodes;
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        const int nt = ng + NG * i;
-        const int col = nt * 16 + (lane & 15);
-        if (nt < ntile && col < 2 * ncg) {
-            const int p = p0 + (col >> 1), c = col & 1;
+    for (int i = 0; i < NTL; ++i) {
+        const int col = (ng + NG * i) * 16 + (lane & 15);
+        if (col < 2 * ncg) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int li = 16 * mt + 4 * (lane >> 4) + r;
-                if (li < nl) partial[(((long long)p * gridDim.x + blockIdx.x) * nl + li) * 2 + c] = (double)acc[i][r];
+                if (li < nl) po[(long long)li * 2 * ncodes + 2 * p0 + col] = acc[i][r];
             }
         }
+    }
+}
+
+// The sum over the parts of the matrix-core form, float [part][li][2 p + c] -> out[p][li][c] (double): block = 64 columns x 16 groups
+// of parts; a group adds every sixteenth part in order (fp64), the sixteen sums are added in a fixed order — bit-reproducible.
+// grid = (ceil(2 ncodes / 64), nl)
+__global__ __launch_bounds__(1024) void k_sliding_reduce_wide(const float* __restrict__ partial, int nparts, int nl, int ncols, double inv_nobs, double* __restrict__ out) {
+    __shared__ double sh[16][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), li = blockIdx.y, g = threadIdx.x >> 6;
+    double s = 0;
+    if (col < ncols) {
+        const float* src = partial + (long long)li * ncols + col;
+        const long long pstride = (long long)nl * ncols;
+        for (int c0 = g; c0 < nparts; c0 += 16 * 8) {
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = src[(long long)min(c0 + 16 * k, nparts - 1) * pstride];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (c0 + 16 * k < nparts) s += (double)t[k];
+        }
+    }
+    sh[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && col < ncols) {
+        double a = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += sh[k][threadIdx.x & 63];
+        out[((long long)(col >> 1) * nl + li) * 2 + (col & 1)] = a * inv_nobs;
     }
 }
 
@@ -396,7 +474,9 @@ bool sliding_mfma(long long nobs, int ncodes, int nlag) {
     static const int force = getenv("TWX_SLIDING_MFMA") ? atoi(getenv("TWX_SLIDING_MFMA")) : -1;
     if (force == 0) return false;
     if (force == 1) return true;
-    return nlag > 8 && ncodes >= 6 && nobs >= 4096;
+    // measured (profiles/r05_sliding_mfma.txt): +-28 lags x 96 codes 86.5 TFLOP/s against 68.3 of the packed-FMA form, x 24 codes
+    // 53.6 against 55.0 — three N tiles leave the matrix cores a quarter idle and the fixed cost of a launch (12 us) weighs more
+    return nlag > 8 && ncodes >= 40 && nobs >= 4096;
 }
 // workgroups per code group: between 2 and 4 per CU, the count that wastes the least of the last round of 64-sample pieces
 int sliding_mfma_parts(long long nobs, int ncodes) {
@@ -404,7 +484,7 @@ int sliding_mfma_parts(long long nobs, int ncodes) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
     const long long pieces = (nobs + SM_P - 1) / SM_P;
     const int groups = (ncodes + SM_CG - 1) / SM_CG;
-    const long long lo = std::max<long long>(1, 2ll * ncu / groups), hi = std::max<long long>(lo, 4ll * ncu / groups);
+    const long long lo = std::max<long long>(1, 3ll * ncu / groups), hi = std::max<long long>(lo, 4ll * ncu / groups);
     if (pieces <= hi) return (int)pieces;
     long long best = hi; double bw = 1e9;
     for (long long n = hi; n >= lo; --n) {
@@ -421,10 +501,16 @@ int launch_sliding(hipStream_t st, const XT* dx, int nch, long long pt, long lon
         const int npieces = (int)((nobs + SM_P - 1) / SM_P);
         const int nparts = sliding_mfma_parts(nobs, ncodes);
         const dim3 grid(nparts, (ncodes + SM_CG - 1) / SM_CG), block(256);
-        if (2 * nlag + 1 <= 32) hipLaunchKernelGGL((k_sliding_mfma<XT, 2>), grid, block, 0, st, dx, nch, pt, nobs, ncodes, nlag, dw, ff, phi, (float)scale, npieces, dpart);
-        else hipLaunchKernelGGL((k_sliding_mfma<XT, 4>), grid, block, 0, st, dx, nch, pt, nobs, ncodes, nlag, dw, ff, phi, (float)scale, npieces, dpart);
+        const int tiles = (2 * std::min(ncodes, SM_CG) + 15) / 16;                  // N tiles of the fullest code group
+        static const int ablate = getenv("TWX_SM_ABLATE") ? atoi(getenv("TWX_SM_ABLATE")) : 0;        // diagnostic: 1 = no MFMAs, 2 = no mixing
+#define SM_GO(MT_, NTW_) hipLaunchKernelGGL((k_sliding_mfma<XT, MT_, NTW_>), grid, block, 0, st, dx, nch, pt, nobs, ncodes, nlag, dw, ff, phi, (float)scale, npieces, dpart, ablate)
+#define SM_MT(MT_) switch (tiles) { case 1: SM_GO(MT_, 1); break; case 2: SM_GO(MT_, 2); break; case 3: SM_GO(MT_, 3); break; default: SM_GO(MT_, 4); break; }
+        if (2 * nlag + 1 <= 32) { SM_MT(2) } else { SM_MT(4) }
+#undef SM_MT
+#undef SM_GO
         if (hipGetLastError() != hipSuccess) return TWX_E_HIP;
-        hipLaunchKernelGGL(k_sliding_reduce, dim3(ncodes), dim3(64), 0, st, dpart, nparts, 2 * nlag + 1, 1.0 / (double)nobs, dout);
+        hipLaunchKernelGGL(k_sliding_reduce_wide, dim3((2 * ncodes + 63) / 64, 2 * nlag + 1), dim3(1024), 0, st, reinterpret_cast<const float*>(dpart), nparts,
+                           2 * nlag + 1, 2 * ncodes, 1.0 / (double)nobs, dout);
         return hipGetLastError() == hipSuccess ? TWX_OK : TWX_E_HIP;
     }
     const bool narrow = sliding_narrow(nobs, nlag, nch);
