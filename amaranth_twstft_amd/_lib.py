@@ -200,6 +200,9 @@ SYMBOLS = {
     "twx_multi_process_windows": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
     "twx_multi_process_windows_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
     "twx_multi_fetch_gathered": (C.c_int, [_VP, C.c_int32, _VP, C.c_int64]),
+    "twx_file_df": (C.c_int, [C.c_char_p, C.c_double, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "twx_write_cmat": (C.c_int, [C.c_char_p, _VP, _VP, C.c_int64]),
+    "twx_file_df_last_error": (C.c_char_p, []),
     "twx_device_affinity": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.c_char_p, C.c_size_t]),
     "twx_pin_thread_to_device": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "twx_set_code_spectrum_dev": (C.c_int, [_VP, _VP]),

@@ -24,7 +24,7 @@ extern "C" {
  *    acquisition and *_dev entry points were added.  twx_abi_version() of an older library answers 1.
  * 3: twx_multi_* (several GPUs from one host process) and twx_rx_* (the DLL/PLL receiver) added; nothing changed.
  * 5: twx_multi_info grew (rccl_fallback, threads_pinned, numa_node, rccl_error: the RCCL exchange falls back to host-side
- *    concatenation instead of failing the job); twx_device_affinity / twx_pin_thread_to_device added. */
+ *    concatenation instead of failing the job); twx_device_affinity / twx_pin_thread_to_device, twx_file_df / twx_write_cmat added. */
 #define TWX_ABI_VERSION 5
 
 typedef struct twx_ctx twx_ctx;
@@ -545,6 +545,20 @@ int twx_multi_fetch_gathered(twx_multi* m, int32_t i, twx_result* out, int64_t n
  * twx_multi workers do for themselves, exported for hosts that run one process or thread per GPU of their own. */
 int twx_device_affinity(int32_t device, int32_t* numa_node, char* cpulist, size_t cap);
 int twx_pin_thread_to_device(int32_t device, int32_t* numa_node, int32_t* n_cpus);
+
+/* The C++ program of the reference as a library (processing/CPP/main.cpp) --------------------------------------------
+ * twx_file_df = GoRanging::df (:363-450): ONE carrier estimate per capture FILE and channel of a 2-channel int16 capture
+ * [I1 Q1 I2 Q2]: every n_dec-th frame of the whole file (the program: n_dec = 25, :776), mixed by foffset, minus the mean of the raw
+ * samples, squared, DFT of that arbitrary length, halves swapped, arg-max of |.| — channel 1 inside +-2*8 kHz of the decimated axis,
+ * channel 2 (remote = 0 only; *df2 = NaN otherwise, df2 may be NULL) over the whole spectrum — and freq(pos)/2 + foffset.  The
+ * transform runs on the device (Bluestein in blocks on the library's fp64 FFT of 5e6 points): any file length, no plan plug-in.
+ * The two numbers are what the program passes on as the carrier of every window (twx_process_file's df_const).
+ * twx_write_cmat = GoRanging::save (:521-656): the `<capture>C.mat` container (MAT v5, uncompressed, n x 1 columns) from the
+ * records of channel 1 and — when not NULL — channel 2: correction<c> = indice0 + correction (:310), SNR<c> in dB (:355), df<c>,
+ * puissance<c>, puissance<c>code in dB (:343), complex xval<c>, xval<c>m1, xval<c>p1.  Errors: twx_file_df_last_error(). */
+int twx_file_df(const char* path, double fs, int32_t n_dec, int32_t remote, double foffset, int32_t device, double* df1, double* df2);
+int twx_write_cmat(const char* path, const twx_result* res1, const twx_result* res2, int64_t n_windows);
+const char* twx_file_df_last_error(void);
 
 /* Profiling (TWX_FLAG_PROFILE): per kernel class, HIP-event time on the context's stream. */
 #define TWX_PROF_MAX 16

@@ -885,6 +885,75 @@ def test_cpp_twin_file_level_carrier_estimate(tmp_path):
     eng.close()
 
 
+def test_file_df_behind_the_c_abi_and_the_goranging_program(tmp_path, monkeypatch):
+    """twx_file_df (GoRanging::df, processing/CPP/main.cpp:363-450, on the device: Bluestein in blocks on the fp64 FFT of 5e6 points)
+    against the oracle restatement and the Python twin, for series lengths that are odd / have large prime factors, with and without
+    foffset, remote = 0 / 1, and with the block length forced small so that the block machinery (27 x 27 blocks for a 330-s capture)
+    runs on a short one.  Then the program: apps/bin/goranging_hip writes the `<capture>C.mat` the Python twin writes (same variables,
+    same values) and prints the program's lines."""
+    from scipy.io import loadmat
+    from amaranth_twstft_amd import cpp_twin, results_io
+    from tests.test_gpu_parity import _capture
+    lib = L.load()
+    chips, raw = _capture(15, 3, 25000, 20, seed=5, df=(1780.75, -3.5))            # 1 000 000 samples x 2 channels
+    cases = [(999_975 + 24, 0.0, 0, 0), (1_000_000, 250.0, 0, 0), (40_003 * 25, -1000.0, 0, 0), (1_000_000, 0.0, 1, 0),
+             (1_000_000, 250.0, 0, 7001), (40_003 * 25, 0.0, 0, 12345), (999_999, 0.0, 0, 40000)]
+    for nsamp, foff, remote, block in cases:
+        r = np.concatenate([raw, raw])[:nsamp]
+        path = tmp_path / f"cap{nsamp}_{block}.bin"
+        r.tofile(path)
+        if block:
+            monkeypatch.setenv("TWX_FILEDF_BLOCK", str(block))
+        else:
+            monkeypatch.delenv("TWX_FILEDF_BLOCK", raising=False)
+        d1, d2 = C.c_double(), C.c_double()
+        rc = lib.twx_file_df(str(path).encode(), FS, 25, remote, foff, -1, C.byref(d1), C.byref(d2))
+        assert rc == 0, lib.twx_file_df_last_error()
+        ref = orc.cpp_file_df(r, FS, 25, remote, foff)
+        assert d1.value == ref[0] and (np.isnan(d2.value) if remote else d2.value == ref[1]), (nsamp, foff, remote, block, d1.value, d2.value, ref)
+    monkeypatch.delenv("TWX_FILEDF_BLOCK", raising=False)
+    assert lib.twx_file_df(str(tmp_path / "nope.bin").encode(), FS, 25, 0, 0.0, -1, C.byref(d1), C.byref(d2)) != 0
+    assert b"cannot open" in lib.twx_file_df_last_error()
+    # ---- the program against the Python twin
+    exe = os.path.join(ROOT, "apps", "bin", "goranging_hip")
+    if not os.path.exists(exe):
+        pytest.skip("apps/bin/goranging_hip not built")
+    nchips, nwin = 25000, 6
+    n = 2 * nchips
+    chips, raw = _capture(15, 3, nchips, nwin, seed=11, df=(812.25, -3.5))
+    (tmp_path / "run").mkdir()
+    cap = tmp_path / "run" / "1670074501.bin"
+    raw.tofile(cap)
+    chips.tofile(tmp_path / "run" / "code.bin")
+    out = subprocess.run([exe, str(cap), str(tmp_path / "run" / "code.bin")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert lines[0].endswith("data.bin code.bin [remote=0] [foffset=0.]") and f"{n} {3 * n}" in lines
+    df1, df2 = cpp_twin.file_level_df(str(cap), FS, 25, 0, 0.0)
+    assert "df1=%.3f" % df1 in lines and " df2=%.3f" % df2 in lines and "No more data" in lines and any(l.startswith("temps: ") for l in lines)
+    rows = [l for l in lines if l.startswith(tuple(f"{p}/0 " for p in range(nwin)))]
+    assert len(rows) == nwin and all(f"{p}/1 " in rows[p] for p in range(nwin))
+    got = loadmat(str(tmp_path / "run" / "1670074501C.mat"))
+    with Correlator(chips, fs=FS, Nint=1, window="hamming", var_ddof=0) as cor:
+        r1 = cor.process_file(str(cap), n_channels=2, channel=0, df=df1)
+        r2 = cor.process_file(str(cap), n_channels=2, channel=1, df=df2)
+    (tmp_path / "twin").mkdir()
+    want = loadmat(results_io.save_cpp_mat(str(tmp_path / "twin" / "1670074501.bin"), r1, r2))
+    keys = [k for k in want if not k.startswith("__")]
+    assert [k for k in got if not k.startswith("__")] == keys
+    for k in keys:
+        if k.startswith("SNR") or k.endswith("code"):              # 10*log10 in libm here, in numpy there: an ulp apart
+            assert np.abs(got[k] - want[k]).max() <= 1e-13 * np.abs(want[k]).max(), k
+        else:
+            assert np.array_equal(got[k], want[k]), k
+    d = float(rows[2].split()[1])
+    assert abs(d - (r1[2].indice + r1[2].correction) / FS / 3) < 1e-11
+    out = subprocess.run([exe, str(cap), str(tmp_path / "run" / "code.bin"), "1", "250"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and os.path.exists(tmp_path / "run" / "remote1670074501C.mat")
+    g2 = loadmat(str(tmp_path / "run" / "remote1670074501C.mat"))
+    assert "correction1" in g2 and "correction2" not in g2 and g2["df1"][0, 0] == cpp_twin.file_level_df(str(cap), FS, 25, 1, 250.0)[0]
+
+
 def test_stream_contract_of_the_device_entry_point():
     """include/twstft_hip.h: twx_process_windows_dev is ordered against twx_stream(ctx) on both sides although batches run
     on several internal streams — a producer enqueued on that stream before the call (here the synthetic generator) and a

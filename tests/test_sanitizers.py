@@ -128,3 +128,27 @@ def test_receiver_program_main_under_asan_ubsan(tmp_path, real):
         r = run()                                               # 120 rows kept of 132 (nch_max), then twx_rx_create refuses: no device
         _no_report(r)
         assert r.returncode == 1 and "no HIP device" in r.stdout, r.stdout + r.stderr
+
+
+def test_goranging_program_main_under_asan_ubsan(tmp_path):
+    """apps/goranging_hip.cpp (main() of GoRanging, processing/CPP/main.cpp:773-807) instrumented, on its argument / file error paths
+    and — without a GPU — the library's refusal: the program's messages, exit code 1, no sanitizer report."""
+    import torch
+    libdir = os.path.join(ROOT, "amaranth_twstft_amd")
+    exe = tmp_path / "goranging_main"
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", *SAN, "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "apps", "goranging_hip.cpp"), "-L" + libdir, "-ltwstft_hip", "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
+    env = dict(ENV, ASAN_OPTIONS="detect_leaks=0")
+    run = lambda *a: subprocess.run([str(exe), *a], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=600)
+    np.zeros(40000 * 4, dtype=np.int16).tofile(tmp_path / "1670074501.bin")
+    np.zeros(10000, dtype=np.uint8).tofile(tmp_path / "code.bin")
+    (tmp_path / "empty.bin").write_bytes(b"")
+    for args, want in (((), "data.bin code.bin [remote=0] [foffset=0.]"), (("1670074501.bin", "nope.bin"), "fcode read: FAIL"),
+                       (("1670074501.bin", "empty.bin"), "fcode read: FAIL")):
+        r = run(*args)
+        _no_report(r)
+        assert r.returncode == 1 and want in r.stdout, r.stdout + r.stderr
+    if not torch.cuda.is_available():
+        r = run("1670074501.bin", "code.bin", "1", "250.5")
+        _no_report(r)
+        assert r.returncode == 1 and "init error" in r.stdout and "20000 60000" in r.stdout, r.stdout + r.stderr

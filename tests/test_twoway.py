@@ -165,3 +165,43 @@ def test_cpp_twin_container(tmp_path):
     assert abs(m["SNR2"][0, 0] - 10 * np.log10(3e-7)) < 1e-12 and abs(m["puissance1code"][0, 0] - (-30.0)) < 1e-9
     assert m["xval1m1"][2, 0] == 0.5j and set(k for k in m if not k.startswith("__")) == {
         f"{v}{c}{s}" for c in "12" for v, s in (("correction", ""), ("SNR", ""), ("df", ""), ("puissance", ""), ("puissance", "code"), ("xval", ""), ("xval", "m1"), ("xval", "p1"))}
+
+
+def test_c_abi_cmat_writer_equals_the_python_container(tmp_path):
+    """twx_write_cmat (csrc/twx_filedf.hip: GoRanging::save, processing/CPP/main.cpp:521-656, as a C entry point — host only, no GPU
+    involved): a MAT-v5 file scipy reads back with the variable set, order, shapes and values of results_io.save_cpp_mat."""
+    import ctypes as C
+    from scipy.io import loadmat
+    from amaranth_twstft_amd import _lib as L, results_io
+    from amaranth_twstft_amd.correlator import WindowResult
+    lib = L.load()
+    rng = np.random.default_rng(3)
+    n = 7
+    recs = [(L.twx_result * n)(), (L.twx_result * n)()]
+    wres = [[], []]
+    for c in range(2):
+        for i in range(n):
+            r = recs[c][i]
+            r.indice0 = int(rng.integers(0, 15_000_000)); r.correction = float(rng.uniform(-0.5, 0.5)); r.df = float(rng.normal(0, 2000))
+            r.SNRr, r.SNRi = float(rng.uniform(1e-8, 1e-3)), float(rng.uniform(1e-8, 1e-3))
+            r.puissance, r.puissancecode, r.puissancenoise = float(rng.uniform(1, 1e6)), float(rng.uniform(1e-6, 10)), 1.0
+            for k, name in enumerate(("xval", "xvalm1", "xvalp1")):
+                z = getattr(r, name); z[0], z[1] = float(rng.normal()), float(rng.normal())
+            wres[c].append(WindowResult(int(r.indice0), r.correction, complex(*r.xval), complex(*r.xvalm1), complex(*r.xvalp1), np.zeros(7, complex), r.df, -1,
+                                        r.SNRr, r.SNRi, r.puissance, r.puissancecode, r.puissancenoise))
+    for two in (True, False):
+        path = tmp_path / ("both.mat" if two else "one.mat")
+        assert lib.twx_write_cmat(str(path).encode(), C.cast(recs[0], C.c_void_p), C.cast(recs[1], C.c_void_p) if two else None, n) == 0
+        got = loadmat(str(path))
+        ref_path = results_io.save_cpp_mat(str(tmp_path / ("r2.bin" if two else "r1.bin")), wres[0], wres[1] if two else None)
+        want = loadmat(ref_path)
+        keys = [k for k in want if not k.startswith("__")]
+        assert [k for k in got if not k.startswith("__")] == keys and len(keys) == (16 if two else 8)
+        for k in keys:
+            assert got[k].shape == want[k].shape == (n, 1) and got[k].dtype == want[k].dtype, k
+            if k.startswith("SNR") or k.endswith("code"):          # 10*log10 in libm here, in numpy there: an ulp apart
+                assert np.abs(got[k] - want[k]).max() <= 1e-13 * np.abs(want[k]).max(), k
+            else:
+                assert np.array_equal(got[k], want[k]), k
+    assert lib.twx_write_cmat(str(tmp_path / "nodir" / "x.mat").encode(), C.cast(recs[0], C.c_void_p), None, n) != 0
+    assert b"cannot create" in lib.twx_file_df_last_error()
