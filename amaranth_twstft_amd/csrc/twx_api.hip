@@ -1,6 +1,8 @@
 // twx_api.hip — C ABI (include/twstft_hip.h) of the TWSTFT correlator: context, plan choice,
 // twiddle tables, the per-batch kernel sequence and the inspection entry points.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <math.h>
 #include <stdio.h>
 #include <sys/types.h>
@@ -1398,6 +1400,28 @@ template <typename T> struct Ctx : CtxBase {
         if (!f) return fail(TWX_E_ARG, std::string("cannot open ") + path);
         const int fd = fileno(f);
         const off_t base_off = (off_t)skip * nch * 4;
+        // TWX_FILE_MMAP=1 (A/B, profiles/r05_io_rate.txt): the capture mapped, the reader threads memcpy from the mapping instead
+        // of pread — no copy_to_user, a minor fault per 4-KB page of a mapping this process touches for the first time
+        static const bool use_mmap = [] { const char* e = getenv("TWX_FILE_MMAP"); return e && atoi(e) != 0; }();
+        if (use_mmap) {
+            struct stat sb;
+            if (fstat(fd, &sb) == 0 && sb.st_size > base_off) {
+                struct Mapping { void* p; size_t len; ~Mapping() { if (p != MAP_FAILED) munmap(p, len); } } mp{MAP_FAILED, (size_t)sb.st_size};
+                mp.p = mmap(nullptr, mp.len, PROT_READ, MAP_SHARED, fd, 0);
+                if (mp.p != MAP_FAILED) {
+                    (void)madvise(mp.p, mp.len, MADV_SEQUENTIAL);
+                    const char* src = static_cast<const char*>(mp.p) + base_off;
+                    const size_t total = mp.len - (size_t)base_off;
+                    auto read_map = [src, total](char* dst, size_t off, size_t len) -> size_t {
+                        if (off >= total) return 0;
+                        const size_t n = std::min(len, total - off);
+                        memcpy(dst, src + off, n);
+                        return n;
+                    };
+                    return run_pipeline(read_map, nch, ch, band, nullptr, df_const, out, max_windows, n_done);
+                }
+            }
+        }
         auto read_at = [fd, base_off](char* dst, size_t off, size_t len) -> size_t {
             size_t done = 0;
             while (done < len) {

@@ -58,8 +58,25 @@
 #ifndef TWX_NT_BZ
 #define TWX_NT_BZ 1     // k_rowd<MID>: non-temporal stores of Bz (written once, read once by k_col_inv 1 GB later)
 #endif
+#ifndef TWX_BZ16
+#define TWX_BZ16 0      // EXPERIMENT (round 5, profiles/r05_bz16.txt): fp32 contexts keep Bz as fp16 pairs (4 instead of 8 bytes per element) in
+                        // k_rowd<MID> (store), k_col_inv3 (load) and k_peak (load) — the upper bound of what a compact Bz can buy; the
+                        // candidate / exact-mode machinery that would make the lag decision rigorous is NOT in this build
+#endif
 
 namespace twx {
+#if TWX_BZ16
+__device__ __forceinline__ unsigned bz16_pack(float x, float y) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 v = {(_Float16)x, (_Float16)y};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float2 bz16_unpack(unsigned u) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 v = __builtin_bit_cast(h2, u);
+    return make_float2((float)v.x, (float)v.y);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // device-side per-window records
@@ -1378,6 +1395,14 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                     C o;                                                                       // · W_N^{-k1 (t + c M)} · ramp1
                     if constexpr (FOLD) o = USGPR ? cmul_us(v[c], ld_uniform(vcrow, c)) : cmul(v[c], s_vc[c]);
                     else o = USGPR ? cmul3_us(v[c], uu, ld_uniform(vcrow, c)) : cmul3(v[c], uu, s_vc[c]);
+#if TWX_BZ16
+                    if constexpr (sizeof(T) == 4) {
+                        // the same element index in a buffer of 4-byte elements: base, row offset and lane offset all halve
+                        const unsigned long long ob16 = sgpr_u64(reinterpret_cast<unsigned long long>(a.Bz) +
+                                                                 (unsigned long long)((((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2) * 4));
+                        st_pin<unsigned, TWX_NT_BZ != 0>(ob16, (unsigned long long)c * M * 4, ltb / 2, bz16_pack((float)o.x, (float)o.y));
+                    } else
+#endif
                     if (TWX_ABLR != 1) st_pin<C, TWX_NT_BZ != 0>(ob, (unsigned long long)c * M * sizeof(C), ltb, o);     // SGPR base + lane offset
                 }
             }
@@ -1990,8 +2015,18 @@ __global__ __launch_bounds__(NT, 6) void k_col_inv3(ColInvArgs<T> a) {
         const unsigned long long rstride = (unsigned long long)(L / R0) * (unsigned long long)a.n2 * sizeof(C);
         // base and row stride pinned in SGPRs, the lane part a 32-bit offset: no 64-bit VALU address per load
         const unsigned long long cb = sgpr_u64(reinterpret_cast<unsigned long long>(cbase)), rs = sgpr_u64(rstride);
+        (void)cb; (void)rs;
+#if TWX_BZ16
+        {
+            const unsigned long long cb16 = sgpr_u64(reinterpret_cast<unsigned long long>(a.Bz) + (unsigned long long)((((long long)b * a.nphase + rho) * a.n) * 4));
+            const unsigned long long rs16 = sgpr_u64(rstride / 2);
+            TWX_UNROLL
+            for (int r = 0; r < R0; ++r) { const float2 f = bz16_unpack(ld_pin<unsigned, TWX_NT_INV != 0>(cb16, r * rs16, loff / 2)); v[r] = mk<T>((T)f.x, (T)f.y); }
+        }
+#else
         TWX_UNROLL
         for (int r = 0; r < R0; ++r) v[r] = (TWX_ABLC == 2) ? mk<T>((T)(tid + r), (T)(r - tid)) : ld_pin<C, TWX_NT_INV != 0>(cb, r * rs, loff);
+#endif
         if (TWX_ABLC == 1) {                 // timing-only build: loads, no arithmetic, no exchange
             TWX_UNROLL
             for (int r = 0; r < R0; ++r) asm volatile("" ::"v"(v[r]));
@@ -2112,7 +2147,16 @@ __global__ __launch_bounds__(1024) void k_peak(PeakArgs<T> a) {
         const cpx<T>* src = a.Bz + ((long long)b * a.nphase + rho) * a.n + q2;
         double sx = 0, sy = 0;
         for (int k1 = lane; k1 < a.n1; k1 += 64) {
+#if TWX_BZ16
+            cpx<T> v;
+            if constexpr (sizeof(T) == 4) {
+                const unsigned* s16 = reinterpret_cast<const unsigned*>(a.Bz) + ((long long)b * a.nphase + rho) * a.n + q2;
+                const float2 f = bz16_unpack(s16[(long long)k1 * a.n2]);
+                v = mk<T>((T)f.x, (T)f.y);
+            } else v = src[(long long)k1 * a.n2];
+#else
             cpx<T> v = src[(long long)k1 * a.n2];
+#endif
             cpx<double> w = a.tw1d[(int)(((long long)k1 * q1) % a.n1)];   // conj → inverse
             sx += (double)v.x * w.x + (double)v.y * w.y;
             sy += (double)v.y * w.x - (double)v.x * w.y;
