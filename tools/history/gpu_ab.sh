@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of kernel variants selected by environment variables: tools/gpu_ab.sh OUTDIR "ENV1=.. ENV2=.." "ENV..." ...
+# A/B of kernel variants selected by environment variables: tools/history/gpu_ab.sh OUTDIR "ENV1=.. ENV2=.." "ENV..." ...
 out=gpurun_out/$1; shift
 mkdir -p $out
 i=0

@@ -1,5 +1,5 @@
 #!/bin/bash
-# clocks / power while the bench runs (is the chain power-limited?): tools/gpu_power.sh OUTDIR
+# clocks / power while the bench runs (is the chain power-limited?): tools/history/gpu_power.sh OUTDIR
 out=gpurun_out/$1; mkdir -p $out
 ( for i in $(seq 1 40); do rocm-smi --showclocks --showpower --showuse 2>/dev/null | grep -E "sclk|mclk|fclk|Power|GPU use|Socket" | tr '\n' ' '; echo; sleep 0.5; done ) > $out/smi.txt 2>&1 &
 sleep 1

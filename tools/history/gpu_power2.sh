@@ -1,5 +1,5 @@
 #!/bin/bash
-# board power / shader clock under sustained synthetic loads (tools/power_probe.hip): tools/gpu_power2.sh OUTDIR
+# board power / shader clock under sustained synthetic loads (tools/power_probe.hip): tools/history/gpu_power2.sh OUTDIR
 out=gpurun_out/$1; mkdir -p $out
 smi() { rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power" | sed -e 's/.*sclk clock level: [0-9S]*: (\([0-9]*\)Mhz).*/sclk \1/' -e 's/.*Power (W): \([0-9.]*\).*/W \1/' | tr '\n' ' '; echo; }
 for m in read copy valu pkvalu lds "mix 5 1" "mix 5 4" "mix 5 16"; do

@@ -3,7 +3,7 @@ out=gpurun_out/r03e; mkdir -p $out
 timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --durations=5 > $out/pytest_parity.log 2>&1
 echo "pytest rc $?" >> $out/pytest_parity.log
 V=amaranth_twstft_amd/variants
-bash tools/gpu_ab.sh r03e/ab "TWX_LIB=$V/lib_base.so" "TWX_LIB=$V/lib_fold.so" "TWX_LIB=$V/lib_sgpr.so" "TWX_X=1" "TWX_LIB=$V/lib_base.so" "TWX_X=1" > /dev/null 2>&1
+bash tools/history/gpu_ab.sh r03e/ab "TWX_LIB=$V/lib_base.so" "TWX_LIB=$V/lib_fold.so" "TWX_LIB=$V/lib_sgpr.so" "TWX_X=1" "TWX_LIB=$V/lib_base.so" "TWX_X=1" > /dev/null 2>&1
 for k in k_row_mid; do
   for lib in $V/lib_base.so amaranth_twstft_amd/libtwstft_hip.so; do
     echo "$lib: $(TWX_LIB=$lib python tools/kernel_alone.py $k 4 2>/dev/null | tail -1)" >> $out/alone.txt

@@ -9,5 +9,5 @@ done
 echo "TWX_ROW_PF=0 (one workgroup per row): $(TWX_ROW_PF=0 python tools/kernel_alone.py k_row_mid 4 2>/dev/null | tail -1)" >> $out/alone.txt
 echo "TWX_ROW_PF=256: $(TWX_ROW_PF=256 python tools/kernel_alone.py k_row_mid 4 2>/dev/null | tail -1)" >> $out/alone.txt
 echo "TWX_ROW_PF=768: $(TWX_ROW_PF=768 python tools/kernel_alone.py k_row_mid 4 2>/dev/null | tail -1)" >> $out/alone.txt
-bash tools/gpu_ab.sh r03m/ab "TWX_LIB=$V/lib_head.so" "TWX_X=1" "TWX_LIB=$V/lib_head.so" "TWX_X=1" > /dev/null 2>&1
+bash tools/history/gpu_ab.sh r03m/ab "TWX_LIB=$V/lib_head.so" "TWX_X=1" "TWX_LIB=$V/lib_head.so" "TWX_X=1" > /dev/null 2>&1
 tail -3 $out/pytest.log; cat $out/alone.txt; cat $out/ab/ab.txt

@@ -4,7 +4,7 @@ out=gpurun_out/r04g; mkdir -p $out
 for lib in amaranth_twstft_amd/libtwstft_hip.so amaranth_twstft_amd/variants/lib_st16.so amaranth_twstft_amd/libtwstft_hip.so amaranth_twstft_amd/variants/lib_st16.so; do
   echo "$lib: $(TWX_LIB=$lib python tools/kernel_alone.py k_row_mid 3 | tail -1)" >> $out/st16_alone.txt
 done
-bash tools/gpu_ab.sh r04g_ab "TWX_X=0" "TWX_LIB=amaranth_twstft_amd/variants/lib_st16.so" "TWX_X=1" "TWX_LIB=amaranth_twstft_amd/variants/lib_st16.so" > /dev/null 2>&1
+bash tools/history/gpu_ab.sh r04g_ab "TWX_X=0" "TWX_LIB=amaranth_twstft_amd/variants/lib_st16.so" "TWX_X=1" "TWX_LIB=amaranth_twstft_amd/variants/lib_st16.so" > /dev/null 2>&1
 cp gpurun_out/r04g_ab/ab.txt $out/st16_ab.txt
 TWX_LIB=amaranth_twstft_amd/variants/lib_st16.so timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "full_size or randomised or processing_vs_oracle" > $out/pytest_st16.log 2>&1
 echo "pytest rc $?" >> $out/pytest_st16.log

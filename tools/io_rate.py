@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from amaranth_twstft_amd import prn
 from amaranth_twstft_amd.correlator import Correlator, band_godual
+if os.environ.get("TWX_IO_CPUS"):                      # e.g. "0-63": writer and readers on the CPUs of one NUMA node (profiles/r05_io_rate.txt)
+    lo, hi = os.environ["TWX_IO_CPUS"].split("-")
+    os.sched_setaffinity(0, range(int(lo), int(hi) + 1))
 NCH = 2500000; N = 2 * NCH; NW = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 threads = [int(a) for a in sys.argv[2:]] or [4]
 chips = prn.lfsr_chips(22, 3, NCH)

@@ -1,4 +1,4 @@
-// power_probe.hip — sustained synthetic loads for reading board power / clocks with rocm-smi (tools/gpu_power2.sh):
+// power_probe.hip — sustained synthetic loads for reading board power / clocks with rocm-smi (tools/history/gpu_power2.sh):
 //   power_probe read|copy|valu|pkvalu|lds|mix  [seconds]
 // read: 16-B streaming reads of a 4 GiB buffer; copy: read + write; valu: v_fma_f32 on registers, every CU, 4 waves per SIMD;
 // pkvalu: v_pk_fma_f32; lds: ds_read_b64 / ds_write_b64 round trips; mix: read stream and packed FMAs in the same waves.

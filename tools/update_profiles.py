@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copy the summaries of one tools/prof_round2.sh run (gpurun_out/<dir>) into profiles/ (newest CSV per pass).
+"""Copy the summaries of one tools/history/prof_round2.sh run (gpurun_out/<dir>) into profiles/ (newest CSV per pass).
 
     python tools/update_profiles.py gpurun_out/r02p r02
 """
@@ -22,7 +22,7 @@ per = {k: {"read_bytes": int(2 * v["FETCH_SIZE_KiB_max"] * 1024), "write_bytes":
 mid = per.get("k_row_mid(dif)") or per["k_row_mid"]
 doc = {"note": "per launch of 8 windows x 5e6 samples; read = 2 x FETCH_SIZE (gfx950 half-count correction, MI355X_MICROARCH.md §HBM, calibrated on "
                "k_sums/k_col_inv whose compulsory reads are exactly 160 MB / 960 MB), write = WRITE_SIZE; separate --pmc passes (rocprofv3 --pmc "
-               "FETCH_SIZE / --pmc WRITE_SIZE, tools/prof_round2.sh); k_row_mid is the DIF/DIT form k_rowd<MID> (the default)",
+               "FETCH_SIZE / --pmc WRITE_SIZE, tools/history/prof_round2.sh); k_row_mid is the DIF/DIT form k_rowd<MID> (the default)",
        "source_commit": head, "kernel": "k_row_mid", "bytes_per_launch": mid["read_bytes"] + mid["write_bytes"], "per_kernel": per}
 json.dump(doc, open("profiles/pmc_traffic.json", "w"), indent=1)
 json.dump(out, open(f"profiles/{tag}_pmc_raw.json", "w"), indent=1)
@@ -59,7 +59,7 @@ for k, c in sq.items():
     rows[k]["wait_inst_any_share"] = round(c.get("SQ_WAIT_INST_ANY", 0) / wc, 4)
     if c.get("SQ_LDS_IDX_ACTIVE"):
         rows[k]["lds_bank_conflict_share_of_lds_cycles"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"], 4)
-json.dump({"note": "rocprofv3 --pmc SQ_* (two passes, tools/prof_round2.sh), summed over the dispatches of one 8-window batch; shares are of SQ_WAVE_CYCLES "
+json.dump({"note": "rocprofv3 --pmc SQ_* (two passes, tools/history/prof_round2.sh), summed over the dispatches of one 8-window batch; shares are of SQ_WAVE_CYCLES "
                    "(quad-cycles), bank conflicts of SQ_LDS_IDX_ACTIVE", "source_commit": head, "kernels": rows}, open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
 d = json.loads(open(f"profiles/{tag}_bench_line.json").read().strip().splitlines()[-1])
 print(d["value"], d["roofline"], d.get("other_workload"))
