@@ -303,7 +303,7 @@ ALGO_BYTES_F64 = {"k_sums": lambda S: 4 * S, "k_col_fwd_square": lambda S: 20 * 
 
 def wideband_legs(local_rank: int, seconds: int = 4, steps: int = 5):
     """Per step: for each of the two stations a `seconds`-long 70-Msps int16 capture (own code in the loop-back + the other station's
-    code 50 kHz off, chips held 28 samples) -> twx_fir_decimate_dev (577-tap Hamming low-pass, decimate by 14) -> 5-Msps int16 ->
+    code 50 kHz off, chips held 28 samples) -> twx_fir_decimate_dev (Hamming low-pass of frontend.lowpass_taps: 421 taps, decimate by 14) -> 5-Msps int16 ->
     FOUR correlations in flight together (four contexts, each with its own streams): OPlo, OPre, LTFBlo, LTFBre, every one the full
     processing(d,k) over `seconds` 1-s windows with its own band.  Returns (wideband_workload, f64_workload): the fp32 chain with the
     FIR's own roofline, and the same four correlations in fp64 with the roofline of their dominant kernel and the fp32-vs-fp64
@@ -431,7 +431,7 @@ def wideband_legs(local_rank: int, seconds: int = 4, steps: int = 5):
     rel = max(abs(r32[k][w][1] - r64[k][w][1]) / r64[k][w][1] for k in plan for w in range(W))
     corr_samples = 4 * W * N
     wl = {"workload": f"BASELINE.json configs[4]: two stations x {{local, remote}} = 4 correlations (OPlo, OPre, LTFBlo, LTFBre: two LFSR(22) codes, taps 57 / 3, "
-                      f"remote signal +-50 kHz off), {W} s of 70-Msps int16 IQ per station, HBM-resident: FIR 577 taps decimate by 14 -> 5 Msps -> full "
+                      f"remote signal +-50 kHz off), {W} s of 70-Msps int16 IQ per station, HBM-resident: FIR {ntaps} taps decimate by 14 -> 5 Msps -> full "
                       "processing(d,k) per 1-s window, the four correlations in flight together (four contexts), fp32",
           "input_Msamples_per_s": round(2 * n_in / t_step / 1e6, 1), "correlated_Msamples_per_s": round(corr_samples / t_step / 1e6, 1),
           "ms_per_step": round(t_step * 1e3, 3), "fir_ms_per_step": round(t_fir * 1e3, 3), "correlations_ms_per_step": round(t_corr * 1e3, 3),

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Do the numbers DESIGN.md quotes still agree with the committed profiles?
 
-DESIGN.md carries one table between the markers ``<!-- key-numbers -->`` and ``<!-- /key-numbers -->``; every row is
+DESIGN.md (current numbers) and profiles/EXPERIMENTS.md (the log of rounds 1-4) each carry one table between the markers ``<!-- key-numbers -->`` and ``<!-- /key-numbers -->``; every row is
 
     | what | value unit | profiles/<file>:<selector> |
 
 with a selector of one of these forms
 
     <json key path with dots>                    bench-line style JSON (last line of the file), e.g. ``roofline.avg_ms``
-    jsonl[<field>=<substring>].<key>             first line of a .jsonl file whose <field> contains <substring>
+    jsonl[<field>=<substring>[,<field>=...]].<key>   first line of a .jsonl file whose fields contain the substrings (integer fields: equal)
     stats[<kernel-name substring>].<column>      row of a rocprofv3 ``*_kernel_stats.csv`` (columns as in the CSV, e.g. AverageNs)
 
 The quoted value may carry a scale suffix the tool understands (``ms`` vs ``AverageNs`` → x 1e-6, ``Gsample/s`` vs Msamples/s →
@@ -36,16 +36,17 @@ def _json_path(obj, path):
 def lookup(source: str) -> float:
     fname, sel = source.split(":", 1)
     path = os.path.join(ROOT, fname)
-    m = re.match(r"jsonl\[(\w+)=([^\]]+)\]\.(.+)$", sel)
+    m = re.match(r"jsonl\[([^\]]+)\]\.(.+)$", sel)
     if m:
-        field, sub, key = m.groups()
+        conds, key = m.groups()                              # field=substring[,field=substring ...]
+        pairs = [c.split("=", 1) for c in conds.split(",")]
         for line in open(path):
             line = line.strip()
             if line.startswith("{"):
                 j = json.loads(line)
-                if sub in str(j.get(field, "")):
+                if all((str(j.get(f, "")) == sub) if str(j.get(f, "")).lstrip("-").isdigit() else (sub in str(j.get(f, ""))) for f, sub in pairs):
                     return _json_path(j, key)
-        raise KeyError(f"{source}: no line with {field} ~ {sub}")
+        raise KeyError(f"{source}: no line with {conds}")
     m = re.match(r"stats\[([^\]]+)\]\.(\w+)$", sel)
     if m:
         sub, col = m.groups()
@@ -60,11 +61,14 @@ def lookup(source: str) -> float:
 SCALES = {("ms", "ns"): 1e-6, ("us", "ns"): 1e-3, ("Gsample/s", "M"): 1e-3, ("TB/s", "GB"): 1e-3}
 
 
-def check(verbose=True) -> int:
-    txt = open(os.path.join(ROOT, "DESIGN.md")).read()
+DOCS = ("DESIGN.md", os.path.join("profiles", "EXPERIMENTS.md"))      # current numbers; the log of rounds 1-4
+
+
+def check_one(doc: str, verbose=True) -> int:
+    txt = open(os.path.join(ROOT, doc)).read()
     m = re.search(r"<!-- key-numbers -->(.*?)<!-- /key-numbers -->", txt, re.S)
     if not m:
-        print("DESIGN.md has no key-numbers table")
+        print(f"{doc} has no key-numbers table")
         return 1
     bad = 0
     n = 0
@@ -91,12 +95,16 @@ def check(verbose=True) -> int:
         n += 1
         ok = abs(val - got) <= TOL * abs(got)
         if verbose or not ok:
-            print(f"{'ok ' if ok else 'BAD'} {what[:60]:60s} DESIGN {val:g} {unit:10s} profile {got:.6g}  ({source})")
+            print(f"{'ok ' if ok else 'BAD'} {what[:60]:60s} {doc} {val:g} {unit:10s} profile {got:.6g}  ({source})")
         bad += not ok
     if n < 8:
-        print(f"only {n} checkable rows found")
+        print(f"{doc}: only {n} checkable rows found")
         return 1
     return 1 if bad else 0
+
+
+def check(verbose=True) -> int:
+    return max(check_one(d, verbose) for d in DOCS)
 
 
 if __name__ == "__main__":
