@@ -210,3 +210,96 @@ def test_gofinal_tables_read_back(arch, tmp_path):
     assert len(tab["delay"]) == 1 and np.isnan(tab["delayrem"][0]) and np.isfinite(tab["SNR2"][0])
     with pytest.raises(ValueError):
         results_io.read_gofinal_table(["2023 01 11 13 06 09\t0.5\t1.0"])
+
+
+def test_code_loop_replays_production_records(arch, core):
+    """The product's code loop (twx_trk::run in csrc/twx_tracked_core.h — the loop that drives the device) REPLAYED on 70 production
+    records of the reference (all of 240527, every 35th of 2401_{OP,LTFB}): a backend answers every measurement request with the record's
+    own values in order (first measurement of a moved code: movedval - 1; its re-measurement: the stored raw index), one-second chunks of
+    5e6 samples, 200 000-sample codes.  The loop must then consume EXACTLY the record — the same number of codes per file (8149 / 8150 /
+    5400 ...: a re-alignment costs a chunk its last code), the same number of chunks, the same `moved` code numbers and `movedval` —
+    which pins the window arithmetic of claudio_aligned_code_*.m:166-200 (dindex, the +21, the + length(fcode) wrap, the dold carry,
+    1-based p) against reference-held data.  Records of script revisions with other limits (movedval - 1 <= 43) are skipped and counted."""
+    from tests.test_tracked_host import Callbacks, Code, Meas, Params, Summary, LOAD, MEASURE, SQBINS, SQBAND, CAND, SLIDE
+    lib = core
+    lib.trk_emul_run.restype = C.c_int
+    lib.trk_emul_run.argtypes = [C.POINTER(Params), C.POINTER(Callbacks), C.c_longlong, C.c_longlong, C.POINTER(Summary)]
+    lib.trk_emul_fetch.restype = None
+    lib.trk_emul_fetch.argtypes = [C.c_void_p] * 4
+    doc, bulk = arch
+    Lc, fs = 5_000_000, 5e6
+    done = skipped = moves = 0
+    for f in doc["replay"]["files"]:
+        key, n = f["key"], f["n"]
+        ind3 = bulk[key + "_ind3"].astype(np.int64)
+        gate = np.unpackbits(bulk[key + "_gate"])[: len(ind3)].astype(bool)
+        moved = bulk[key + "_moved"].astype(np.int64)
+        mval3 = bulk[key + "_movedval3"].astype(np.int64)
+        if np.any((mval3 - 3) <= 43 * 3) or len(set(moved.tolist())) != len(moved):         # another revision's limits / a code moved twice
+            skipped += 1
+            continue
+        first3 = ind3.copy()                                   # what the FIRST measurement of code p returned, x3 grid, 1-based
+        first3[moved - 1] = mval3 - 3
+        above = gate.copy()
+        above[moved - 1] = True                                # a moved code was above the gate when first measured
+        state = {"p": 0, "chunks": 0, "bad": ""}
+
+        def load_chunk(pos, carry, full):
+            full[0] = int(state["chunks"] < f["chunks"])
+            state["chunks"] += 1
+            return 0
+
+        def measure(start, count, df, out):
+            p = state["p"]
+            for j in range(count):
+                q = p + j
+                if q >= len(ind3):
+                    # the loop asks for more codes than the record holds: answer with a quiet code, the totals will differ
+                    out[j].indice0, out[j].snr_r, out[j].snr_i = 62, 1e-9, 0.0
+                    continue
+                if state.get("remeasure") == q:                # the re-measurement after a move: the stored RAW index (never divided, :184-185)
+                    out[j].indice0, out[j].snr_r, out[j].snr_i = int(ind3[q]) // 3 - 1, (1.0 if gate[q] else 1e-9), 0.0
+                else:
+                    out[j].indice0, out[j].snr_r, out[j].snr_i = int(first3[q]) - 1, (1.0 if above[q] else 1e-9), 0.0
+                out[j].correction = out[j].xre = out[j].xim = out[j].puissance = out[j].pcode = out[j].pnoise = 0.0
+            # what the loop will do with this batch: accept codes up to the first one that moves, then re-measure that one
+            state["remeasure"] = None
+            if count > 1 or state.get("last_was_batch", True):
+                for j in range(count):
+                    q = p + j
+                    if q < len(ind3) and (q + 1) in set_moved and above[q]:
+                        state["p"], state["remeasure"] = q, q
+                        state["last_was_batch"] = False
+                        return 0
+                state["p"] = p + count
+                state["last_was_batch"] = True
+            else:                                              # the single re-measurement: code q is done
+                state["p"] = p + 1
+                state["last_was_batch"] = True
+            return 0
+
+        def sq_band(offset, k_lo, nk, mag):
+            a = np.ctypeslib.as_array(mag, shape=(nk,))
+            a[:] = 0.0
+            a[nk // 2] = 1.0
+            return 0
+
+        set_moved = set(moved.tolist())
+        cb = Callbacks(LOAD(load_chunk), MEASURE(measure), SQBINS(lambda *a: 0), SQBAND(sq_band), CAND(lambda *a: 0), SLIDE(lambda *a: 0))
+        prm = Params(n, Lc, 3, 1, 0, 0, fs, -20000.0, 20000.0, 20.0)
+        s = Summary()
+        assert lib.trk_emul_run(C.byref(prm), C.byref(cb), 0, -1, C.byref(s)) == 0
+        codes = (Code * max(s.n_codes, 1))()
+        df = np.zeros(max(s.n_chunks, 1)); mv = np.zeros(max(s.n_moved, 1), dtype=np.int64); mvv = np.zeros(max(s.n_moved, 1))
+        lib.trk_emul_fetch(C.cast(codes, C.c_void_p), df.ctypes.data, mv.ctypes.data, mvv.ctypes.data)
+        tag = f["file"]
+        assert s.n_chunks == f["chunks"], (tag, s.n_chunks)
+        assert s.n_codes == f["codes"], (tag, s.n_codes, f["codes"])
+        assert list(mv[: s.n_moved]) == moved.tolist(), (tag, list(mv[: s.n_moved]), moved.tolist())
+        assert np.allclose(mvv[: s.n_moved] * 3, mval3, atol=1e-6), tag
+        got3 = np.rint(np.array([codes[i].indice1 for i in range(s.n_codes)]) * 3).astype(np.int64)
+        assert np.array_equal(got3, ind3), (tag, np.nonzero(got3 != ind3)[0][:5])
+        done += 1
+        moves += len(moved)
+    print(f"replayed {done} records with {moves} re-alignments, skipped {skipped}")
+    assert done >= 60 and moves >= 60 and skipped <= 8, (done, moves, skipped)

@@ -215,6 +215,31 @@ def gen_sessions(bulk):
     return {"source": "experiments/240527/{op,ltfb}/{local,remote}claudio*.mat.gz", "sessions": out}
 
 
+def gen_replay(bulk):
+    """Whole production records for a replay of the code loop (tests/test_ref_archives.py drives csrc/twx_tracked_core.h with them): per code
+    the measured index on the x3 grid (round(3 indice1): thirds for codes that stayed, the raw re-measured index for moved ones) and whether
+    it was above the -30 dB gate; per file `moved` (1-based code numbers), round(3 movedval) and the number of 1-s chunks (= length(df)).
+    All ten files of 240527 and every 35th of 2401_{OP,LTFB}."""
+    files = sorted(glob.glob(os.path.join(EXP, "240527", "*", "*.mat.gz"))) + sorted(glob.glob(os.path.join(EXP, "240102_1PPS_TXsync", "2401_*", "*.mat.gz")))[::35]
+    out = []
+    for f in files:
+        m = load(f)
+        if "moved" not in m or "xval1" not in m:
+            continue
+        i = len(out)
+        i3 = np.rint(m["indice1"] * 3)
+        assert np.abs(i3 - m["indice1"] * 3).max() < 1e-6
+        snr = m["SNR1r"] + m["SNR1i"]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            gate = 10 * np.log10(snr) > -30
+        bulk[f"rp{i}_ind3"] = i3.astype(np.int32)
+        bulk[f"rp{i}_gate"] = np.packbits(gate)
+        bulk[f"rp{i}_moved"] = m["moved"].astype(np.int32)
+        bulk[f"rp{i}_movedval3"] = np.rint(m["movedval"] * 3).astype(np.int32)
+        out.append({"key": f"rp{i}", "file": rel(f), "codes": int(len(i3)), "chunks": int(len(m["df"])), "moves": int(len(m["moved"])), "n": int(len(m["code"]))})
+    return {"source": "experiments/240527/{op,ltfb}/*.mat.gz (all) and every 35th file of experiments/240102_1PPS_TXsync/2401_{OP,LTFB}", "files": out}
+
+
 def gen_gofinal():
     """Per-second tables written by gofinal_op.m / gofinal_ltfb.m (experiments/230111_twstft_2M5/gofinal_ltfb.m:86-89): header line,
     then `Y m d H M S <tab> delay <tab> df1 <tab> SNR1 <tab> delay2 <tab> df2 <tab> SNR2 <tab> delayrem <tab> df1rem <tab> SNR1rem`; rows
@@ -246,7 +271,7 @@ def main():
     bulk = {}
     doc = {"generator": "tools/make_golden_archives.py (build container; reads the reference's result archives, writes numbers only)",
            "besancon": gen_besancon(bulk), "claudio100k": gen_claudio100k(bulk), "tracked": gen_tracked(bulk), "sessions": gen_sessions(bulk),
-           "gofinal": gen_gofinal()}
+           "replay": gen_replay(bulk), "gofinal": gen_gofinal()}
     np.savez_compressed(os.path.join(GOLD, "ref_archives.npz"), **bulk)
     json.dump(doc, open(os.path.join(GOLD, "ref_archives.json"), "w"), indent=1)
     print("wrote", os.path.getsize(os.path.join(GOLD, "ref_archives.npz")), "bytes npz,", os.path.getsize(os.path.join(GOLD, "ref_archives.json")), "bytes json")
@@ -255,6 +280,7 @@ def main():
     print("tracked:", {k: v for k, v in doc["tracked"].items() if k != "source"})
     for s in doc["sessions"]["sessions"]:
         print(s["key"], s["as_is"], s["oracle_on_cut"])
+    print("replay files:", len(doc["replay"]["files"]), "moves:", sum(f["moves"] for f in doc["replay"]["files"]))
     print(doc["gofinal"]["totals"])
 
 
