@@ -31,7 +31,7 @@ Parity pinning (see tests/golden/README.md, tools/make_golden.py):
     230315_analysis_100k and SNR1r + SNR1i = puissancecode / puissancenoise; the re-alignment rule of ``ranging_tracked``
     (claudio...separate.m:175-185: the limits 43 / n/2 / n-2, the -30 dB gate, movedval = indice1 + 1, the undivided re-measured
     index) against all 2 087 production records of 2401_{OP,LTFB} and 240527 (16.9 M codes, 3 358 moves), and the window arithmetic of the
-    code loop (:166-200: dindex, +21, the + length(fcode) wrap, the dold carry, codes per chunk) by replaying 67 whole records through the
+    code loop (:166-200: dindex, +21, the + length(fcode) wrap, the dold carry, codes per chunk) by replaying 70 whole records (109 moves) through the
     product's loop (twx_tracked_core.h — the same loop tests/test_tracked_host.py holds against ``ranging_tracked``); ``go_1s_session`` runs on two
     real sessions of 240527 (no stored output exists to compare with: the numbers are physically checked, not pinned).
 """
