@@ -1,0 +1,109 @@
+"""Early / prompt / late tracking loop of the Octave DLL/PLL experiment (host twin over the C ABI).
+
+``experiments/230503_100kchips_withcode/gotracking_inv2.m:149-235``: per code period the block is mixed by the NCO
+``exp(1j*2*pi*(-freq0+doppler_freq(l))*time)`` (:157-159), cross-correlated with the late / prompt / early replicas
+``zl=xcorr(al,xx,MAXLAG)`` ... (:161-163, ``MAXLAG = points_per_code``, :95: every lag of the LINEAR cross-correlation), the three
+peaks feed the early-minus-late DLL discriminator (:187) and the arctangent PLL discriminator (:201-203), and the 2nd-order loop
+filter updates the Doppler estimate (:209-235).
+
+The three correlations run on the GPU: a correlator context of 2N samples per replica (``twx_set_code_spectrum`` with the spectrum
+of the zero-padded replica, claudio convention = ``fft(a).*conj(fft(xx))``, no interpolation) evaluates the linear cross-correlation
+of two N-sample sequences as a circular one of length 2N and returns the arg-max and the complex peak — all the loop reads
+(``abs(zl(bbl))``, ``zp(bbp)``, ``abs(ze(bbe))``).  Lag k of ``xcorr`` sits at index k + N + 1 of Octave's vector (1-based) and at
+circular index k mod 2N of the map.  The loop arithmetic is host Python, as in the script.  UNPINNED (Octave only; oracle:
+``oracle.epl_step``).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .correlator import Correlator
+
+
+def replicas(chips, sps: int = 2):
+    """``ap`` = +-1 code held ``sps`` samples, ``al`` = one sample late, ``ae`` = one sample early (:36-41)."""
+    ap = np.repeat(2.0 * np.asarray(chips, dtype=np.float64) - 1.0, sps)
+    al = np.concatenate([ap[-1:], ap[:-1]])
+    ae = np.concatenate([ap[1:], ap[:1]])
+    return al, ap, ae
+
+
+class EplTracker:
+    """State of the loop between code periods: ``l`` (1-based block number), ``doppler_freq`` (list, Hz), ``time_end`` (s: the last
+    sample time of the previous block, :156), ``code_phase`` / ``carrier_phase`` (the filtered values, :227-228)."""
+
+    def __init__(self, chips, fs: float = 5e6, sps: int = 2, freq0: float = 0.0, T_blk: float = 80e-3, delay_spacing: float = 0.5,
+                 B_DLL: float = 2.0, B_PLL: float = 20.0, time_end: float | None = None, precision: str = "f64", device: int = -1):
+        self.fs, self.freq0, self.T_blk, self.delay_spacing, self.B_DLL, self.B_PLL = fs, freq0, T_blk, delay_spacing, B_DLL, B_PLL
+        self.al, self.ap, self.ae = replicas(chips, sps)
+        self.n = self.ap.size                                   # points_per_code
+        self.zeta = 1 / math.sqrt(2)                             # :146-147
+        self.omega_n = B_PLL / .53
+        self.l = 1
+        self.doppler_freq = [0.0]                                # doppler_freq=0 (:145)
+        self.code_phase = 0.0
+        self.carrier_phase = 0.0
+        self.time_end = (fs / 10 - 1) / fs if time_end is None else time_end      # time of the 0.1-s acquisition block (:22,53)
+        self.history: list[dict] = []
+        m = 2 * self.n
+        self._cor = []
+        for a in (self.al, self.ap, self.ae):
+            c = Correlator(lfsr=(20, 9, m), fs=fs, sps=1, Nint=0, convention="claudio", precision=precision, device=device, var_ddof=0)
+            pad = np.zeros(m)
+            pad[: self.n] = a
+            c.set_code_spectrum(np.conj(np.fft.fft(pad)))        # the context multiplies fft(y) by this; claudio: conj of the product
+            self._cor.append(c)
+
+    def close(self):
+        for c in self._cor:
+            c.close()
+        self._cor = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _peak(self, cor, xx_pad):
+        r = cor.processing_complex(xx_pad, df=0.0)[0]
+        i = r.indice                                             # 0-based index of the circular map of 2N lags
+        lag = i if i <= self.n else i - 2 * self.n
+        return lag + self.n + 1, r.xval * (2 * self.n)           # Octave's 1-based index into the 2N+1 vector; xcorr carries no 1/M
+
+    def step(self, x) -> dict:
+        """One code period: ``x`` = the N complex samples of the tracked channel (:151-155).  Returns the quantities of this block."""
+        x = np.asarray(x, dtype=np.complex128).reshape(-1)
+        if x.size != self.n:
+            raise ValueError("a block is one code period")
+        l = self.l
+        fd = self.doppler_freq[l - 1]
+        time = self.time_end + np.arange(1, x.size + 1) / self.fs                              # :156
+        xx = x * np.exp(1j * (2 * np.pi * (-self.freq0 + fd) * time))                         # :157-159
+        pad = np.zeros(2 * self.n, dtype=np.complex128)
+        pad[: self.n] = xx
+        (bbl, zl), (bbp, zp), (bbe, ze) = (self._peak(c, pad) for c in self._cor)              # :161-177
+        code_phase_error = self.delay_spacing * (abs(ze) - abs(zl)) / (abs(ze) + abs(zl) + 2 * abs(zp))      # :187
+        filtered_code_phase_error = self.T_blk * self.B_DLL / .25 * code_phase_error          # :193
+        measured_code_phase = self.code_phase + code_phase_error
+        filtered_code_phase = self.code_phase + filtered_code_phase_error
+        delta_theta = math.atan(zp.imag / zp.real) / (2 * math.pi)                             # :201
+        sortie = math.atan2(zp.imag, zp.real) / (2 * math.pi)                                   # :202
+        doppler_freq_error = self.T_blk / 2 * delta_theta                                       # :204
+        filtered_carrier_phase_error = (2 * self.zeta * self.omega_n * self.T_blk - 3 / 2 * self.omega_n ** 2 * self.T_blk ** 2) * delta_theta   # :210
+        filtered_doppler_freq_error = self.omega_n ** 2 * self.T_blk * delta_theta              # :211
+        measured_carrier_phase = self.carrier_phase + delta_theta
+        filtered_carrier_phase = self.carrier_phase + filtered_carrier_phase_error
+        measured_doppler_freq = fd + doppler_freq_error
+        filtered_doppler_freq = fd + filtered_doppler_freq_error
+        self.code_phase, self.carrier_phase = filtered_code_phase, filtered_carrier_phase       # :227-228
+        self.time_end = float(time[-1])
+        self.l = l + 1
+        self.doppler_freq.append(filtered_doppler_freq)                                         # :249
+        out = dict(l=l, bbl=bbl, bbp=bbp, bbe=bbe, zl=zl, zp=zp, ze=ze, code_phase_error=code_phase_error, delta_theta=delta_theta, sortie=sortie,
+                   measured_code_phase=measured_code_phase, filtered_code_phase=filtered_code_phase, measured_carrier_phase=measured_carrier_phase,
+                   filtered_carrier_phase=filtered_carrier_phase, measured_doppler_freq=measured_doppler_freq, doppler_freq=filtered_doppler_freq)
+        self.history.append(out)
+        return out

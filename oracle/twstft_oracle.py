@@ -21,7 +21,7 @@ Parity pinning (see tests/golden/README.md, tools/make_golden.py):
     godual_ranging_OP.py:ranging`` (printed lag, correction and complex peak sample).
   * The reference holds NO test vectors of its own for the correlator, and the
     Octave-only variants (``processing_claudio``, ``search_df``, ``ranging_tracked``, ``go_1s_session``, the QPSK form of ``make_code_variant``,
-    ``peak_refine_polyfit``), the C++-only Hamming window
+    ``peak_refine_polyfit``, ``epl_step`` / ``octave_xcorr``), the C++-only Hamming window
     and the 231001_DLL_PLL acquisition/tracking restatements (incl. the receiver programs ``rx_second`` — rxcomplex.cpp and, with
     ``real=True``, rx.cpp with its interference cancellation ``rx_mai_up`` / ``rx_mai_out``) have no runnable twin here:
     for those functions parity is UNPINNED (hand restatement, cross-checked by identities) — EXCEPT what the reference's own result
@@ -1170,3 +1170,52 @@ def cpp_file_df(raw, fs: float = 5e6, N: int = 25, remote: int = 0, foffset: flo
         pos = int(np.abs(out[kmin:kmax]).argmax()) + kmin if ch == 0 else int(np.abs(out).argmax())
         res[ch] = float(freq[pos] / 2.0 + float(np.float32(foffset)))
     return res[0], res[1]
+
+
+# --------------------------------------------------------------------------------------------
+# Early / prompt / late tracking loop of experiments/230503_100kchips_withcode/gotracking_inv2.m:149-235 — UNPINNED (Octave only)
+# --------------------------------------------------------------------------------------------
+
+def octave_xcorr(a, b):
+    """``xcorr(a,b)`` of two equal-length vectors (octave-signal): c[k + N] = sum_n a[n+k] conj(b[n]), k = -(N-1) ... N-1 — returned with
+    the 2N+1 entries of ``xcorr(a,b,N)`` (lags -N and +N are zero)."""
+    a = np.asarray(a, dtype=complex).reshape(-1)
+    b = np.asarray(b, dtype=complex).reshape(-1)
+    n = a.size
+    full = np.correlate(a, b, mode="full") if n <= 4096 else None
+    if full is None:                                             # FFT evaluation of the same sum
+        m = 2 * n
+        c = _ifft(_fft(np.concatenate([a, np.zeros(n)])) * np.conj(_fft(np.concatenate([b, np.zeros(n)]))))
+        full = np.concatenate([c[n + 1:], c[:n]])                # lags -(n-1) ... n-1
+    return np.concatenate([[0.0], full, [0.0]])
+
+
+def epl_step(state: dict, x, al, ap, ae, fs=5e6, freq0=0.0, T_blk=80e-3, delay_spacing=0.5, B_DLL=2.0, B_PLL=20.0):
+    """One pass of the main loop (:151-249).  ``state``: l (1-based), doppler_freq (list), time_end, code_phase, carrier_phase —
+    updated in place; returns the quantities of the block (1-based arg-max indices as Octave's ``max``)."""
+    zeta, omega_n = 1 / np.sqrt(2), B_PLL / .53                                            # :146-147
+    x = np.asarray(x, dtype=complex).reshape(-1)
+    l = state["l"]
+    fd = state["doppler_freq"][l - 1]
+    time = state["time_end"] + np.arange(1, x.size + 1) / fs                               # :156
+    xx = x * np.exp(1j * (2 * np.pi * (-freq0 + fd) * time))                              # :157-159
+    zl, zp, ze = (octave_xcorr(a, xx) for a in (al, ap, ae))                               # :161-163, MAXLAG = points_per_code
+    bbl, bbp, bbe = (int(np.abs(z).argmax()) + 1 for z in (zl, zp, ze))                    # :175-177
+    vl, vp, ve = zl[bbl - 1], zp[bbp - 1], ze[bbe - 1]
+    code_phase_error = delay_spacing * (abs(ve) - abs(vl)) / (abs(ve) + abs(vl) + 2 * abs(vp))   # :187
+    filtered_code_phase_error = T_blk * B_DLL / .25 * code_phase_error                    # :193
+    out = dict(l=l, bbl=bbl, bbp=bbp, bbe=bbe, zl=vl, zp=vp, ze=ve, code_phase_error=code_phase_error)
+    out["measured_code_phase"] = state["code_phase"] + code_phase_error
+    out["filtered_code_phase"] = state["code_phase"] + filtered_code_phase_error
+    delta_theta = np.arctan(vp.imag / vp.real) / (2 * np.pi)                               # :201
+    out["delta_theta"] = float(delta_theta)
+    out["sortie"] = float(np.arctan2(vp.imag, vp.real) / (2 * np.pi))                      # :202
+    out["measured_carrier_phase"] = state["carrier_phase"] + delta_theta
+    out["filtered_carrier_phase"] = state["carrier_phase"] + (2 * zeta * omega_n * T_blk - 3 / 2 * omega_n ** 2 * T_blk ** 2) * delta_theta   # :210
+    out["measured_doppler_freq"] = fd + T_blk / 2 * delta_theta                            # :204,216
+    out["doppler_freq"] = fd + omega_n ** 2 * T_blk * delta_theta                          # :211,217,249
+    state["code_phase"], state["carrier_phase"] = out["filtered_code_phase"], out["filtered_carrier_phase"]
+    state["time_end"] = float(time[-1])
+    state["l"] = l + 1
+    state["doppler_freq"].append(out["doppler_freq"])
+    return out

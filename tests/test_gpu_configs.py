@@ -1167,3 +1167,40 @@ def test_randomised_acquisition_sweeps():
         for a in accs.values():
             a.close()
         interp.close()
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_early_prompt_late_tracking_loop(precision):
+    """experiments/230503_100kchips_withcode/gotracking_inv2.m:149-235 — the Octave DLL/PLL experiment's main loop: NCO mix, three LINEAR
+    cross-correlations over every lag (xcorr(al|ap|ae, xx, MAXLAG = points_per_code)) on the GPU, early-minus-late and arctangent
+    discriminators, 2nd-order loop filter — 25 code periods of a 5000-chip code with a residual carrier, against oracle.epl_step block by
+    block (peak indices equal, peak values and every loop quantity to the precision of the context)."""
+    from amaranth_twstft_amd import epl
+    chips = chips_for(13, 27, 5000)
+    fs, n = FS, 10000
+    al, ap, ae = epl.replicas(chips, 2)
+    rng = np.random.default_rng(8)
+    nblk, delay, f_res, freq0 = 25, 3, 4.0, 1000.0
+    t = np.arange(nblk * n + n) / fs
+    sig = 800.0 * np.tile(ap, nblk + 1) * np.exp(2j * np.pi * ((freq0 + f_res) * t + 0.11))
+    sig = np.roll(sig, delay) + rng.normal(0, 300.0, sig.size) + 1j * rng.normal(0, 300.0, sig.size)
+    sig = np.rint(sig.real) + 1j * np.rint(sig.imag)                                    # what an int16 capture holds
+    state = dict(l=1, doppler_freq=[0.0], time_end=-1.0 / fs, code_phase=0.0, carrier_phase=0.0)
+    tol = 1e-9 if precision == "f64" else 2e-5
+    with epl.EplTracker(chips, fs=fs, freq0=freq0, time_end=-1.0 / fs, precision=precision) as trk:
+        for b in range(nblk):
+            x = sig[b * n:(b + 1) * n]
+            got = trk.step(x)
+            want = orc.epl_step(state, x, al, ap, ae, fs=fs, freq0=freq0)
+            assert (got["bbl"], got["bbp"], got["bbe"]) == (want["bbl"], want["bbp"], want["bbe"]), (b, got["bbp"], want["bbp"])
+            for k in ("zl", "zp", "ze"):
+                assert abs(got[k] - want[k]) <= tol * abs(want[k]), (b, k, got[k], want[k])
+            for k in ("code_phase_error", "delta_theta", "sortie", "filtered_code_phase", "filtered_carrier_phase", "measured_doppler_freq", "doppler_freq"):
+                assert abs(got[k] - want[k]) <= 50 * tol * max(1.0, abs(want[k])), (b, k, got[k], want[k])
+            if precision == "f32":                                                       # the loop feeds its own estimate back: keep the twins in step
+                trk.doppler_freq[-1], trk.code_phase, trk.carrier_phase = state["doppler_freq"][-1], state["code_phase"], state["carrier_phase"]
+        assert got["bbp"] == n + 1 - delay                                                      # xcorr(ap, xx) peaks at lag -delay (index lag + N + 1)
+        assert got["bbl"] - got["bbp"] == 1 and got["bbp"] - got["bbe"] == 1                  # late / early replicas: one sample either side
+        assert len(trk.doppler_freq) == nblk + 1 and trk.l == nblk + 1
+        # (with the script's constants — T_blk = 80 ms, B_PLL = 20 Hz, made for 40-ms codes — a 2-ms code period does not pull in; the
+        # test holds the twin against the restatement, not the loop design)

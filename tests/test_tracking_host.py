@@ -107,3 +107,28 @@ def test_track_update_equals_the_oracle_restatement_of_the_epoch():
             assert abs(got[k] - want[k]) <= 1e-9 * max(1.0, abs(want[k])), k
         assert (st2["pt"], st2["fc"], st2["pt_prev"]) == (st["pt"], st["fc"], st["pt_prev"]) and abs(st2["last_phi"] - st["last_phi"]) < 1e-12
         assert abs(want["freq"] - (1000.0 + fres)) < 0.5 and st["pt"] == delay
+
+
+def test_oracle_octave_xcorr_and_epl_step():
+    """oracle.octave_xcorr (the LINEAR cross-correlation of gotracking_inv2.m:161-163 with MAXLAG = N) against its definition, both
+    evaluation routes; oracle.epl_step: one block of a clean delayed code gives the prompt peak at lag -delay, late / early one sample
+    either side, a zero phase discriminator for a carrier-free block."""
+    from oracle import twstft_oracle as orc
+    from amaranth_twstft_amd import epl, prn
+    rng = np.random.default_rng(0)
+    for n in (50, 5000):
+        a = rng.choice([-1.0, 1.0], n)
+        b = rng.normal(size=n) + 1j * rng.normal(size=n)
+        z = orc.octave_xcorr(a, b)
+        assert z.size == 2 * n + 1 and z[0] == 0 and z[-1] == 0
+        for k in (-(n - 1), -7, 0, 3, n - 1):
+            ref = sum(a[i + k] * np.conj(b[i]) for i in range(n) if 0 <= i + k < n)
+            assert abs(z[k + n] - ref) <= 1e-10 * max(1.0, abs(ref))
+    chips = prn.lfsr_chips(13, 27, 2500)
+    al, ap, ae = epl.replicas(chips, 2)
+    assert np.array_equal(al[1:], ap[:-1]) and np.array_equal(ae[:-1], ap[1:]) and al[0] == ap[-1] and ae[-1] == ap[0]
+    x = 100.0 * np.roll(ap, 5)
+    st = dict(l=1, doppler_freq=[0.0], time_end=0.0, code_phase=0.0, carrier_phase=0.0)
+    o = orc.epl_step(st, x, al, ap, ae)
+    assert o["bbp"] == ap.size + 1 - 5 and o["bbl"] == o["bbp"] + 1 and o["bbe"] == o["bbp"] - 1
+    assert abs(o["delta_theta"]) < 1e-12 and st["l"] == 2 and len(st["doppler_freq"]) == 2 and abs(st["time_end"] - ap.size / 5e6) < 1e-15
