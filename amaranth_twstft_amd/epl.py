@@ -71,7 +71,7 @@ class EplTracker:
         r = cor.processing_complex(xx_pad, df=0.0)[0]
         i = r.indice                                             # 0-based index of the circular map of 2N lags
         lag = i if i <= self.n else i - 2 * self.n
-        return lag + self.n + 1, r.xval * (2 * self.n)           # Octave's 1-based index into the 2N+1 vector; xcorr carries no 1/M
+        return lag + self.n + 1, r.xval                          # Octave's 1-based index into the 2N+1 vector; ifft(fft.*conj(fft)) IS the sum
 
     def step(self, x) -> dict:
         """One code period: ``x`` = the N complex samples of the tracked channel (:151-155).  Returns the quantities of this block."""
