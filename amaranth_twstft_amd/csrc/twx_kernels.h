@@ -58,6 +58,10 @@
 #ifndef TWX_NT_BZ
 #define TWX_NT_BZ 1     // k_rowd<MID>: non-temporal stores of Bz (written once, read once by k_col_inv 1 GB later)
 #endif
+#ifndef TWX_MID_PERSIST64
+#define TWX_MID_PERSIST64 1  // k_rowd<MID> for complex double in the row-walking form as well (round 5: one 128-KB row per CU, so the wait for the
+                             // next row was fully exposed; 0.461 -> 0.392 ms per 4 windows, profiles/r05_f64_rowwalk.txt); 0 = one row per workgroup
+#endif
 #ifndef TWX_BZ16
 #define TWX_BZ16 0      // EXPERIMENT (round 5, profiles/r05_bz16.txt): fp32 contexts keep Bz as fp16 pairs (4 instead of 8 bytes per element) in
                         // k_rowd<MID> (store), k_col_inv3 (load) and k_peak (load) — the upper bound of what a compact Bz can buy; the
@@ -1084,7 +1088,9 @@ __device__ __forceinline__ void wave_sync_lds() {
 // k_rowd<MID> with resident workgroups (see the kernel): the launcher sizes the grid with the same predicate
 template <class P2, typename T> constexpr bool rowd_mid_resident() {
     using D = RowD<P2, T>;
-    return TWX_MID_PERSIST && TWX_MID_FOLD && D::R0 > 1 && sizeof(T) == 4 && D::M % 16 == 0;
+    // complex double: only where the row, the tables and the copy of the forward table tc still fit the 160 KB of one CU
+    constexpr bool fits64 = (size_t)(D::lds_elems + D::tab_total + D::R0 * D::R + 32) * sizeof(cpx<double>) + 1024 <= 160 * 1024;
+    return TWX_MID_PERSIST && TWX_MID_FOLD && D::R0 > 1 && (sizeof(T) == 4 || (TWX_MID_PERSIST64 && fits64)) && D::M % 16 == 0;
 }
 
 template <class P2, typename T, int MODE, int NT>
