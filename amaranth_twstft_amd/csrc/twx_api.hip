@@ -74,10 +74,16 @@ static bool choose_split_from(long long n, int f64, bool builtin_only, const Col
         const long long n1 = n / r.L;
         if (n1 > 100000) continue;
         const ColOps* c = nullptr;                        // widest column tile of that length whose width divides the row
+        static const int force_w = [] { const char* e = getenv("TWX_COL_W"); return e ? atoi(e) : 0; }();      // experiments: force the tile width
         for (auto& ce : col_reg()) {
             const ColOps& o = ce.o;
             if (builtin_only && ce.plugin) continue;
-            if (o.L == (int)n1 && o.f64 == f64 && r.L % o.W == 0 && (!c || o.W > c->W)) c = &o;
+            if (force_w && o.W != force_w) continue;
+            if (o.L != (int)n1 || o.f64 != f64 || r.L % o.W != 0) continue;
+            // complex double: a tile of L x W x 16 bytes; two workgroups per CU (<= 80 KB each) beat one with a wider tile — W = 8 still
+            // moves whole 128-byte pieces (k_col_inv 0.329 -> 0.232 ms at L = 625, profiles/r05_f64_rowwalk.txt); fp32: the widest tile
+            auto two_fit = [&](const ColOps& q) { return !f64 || (long long)q.L * q.W * 16 <= 80 * 1024; };
+            if (!c || (two_fit(o) && !two_fit(*c)) || (two_fit(o) == two_fit(*c) && o.W > c->W)) c = &o;
         }
         if (!c) continue;
         // widest column tile first (HBM piece size), then the row: 4000, then the longest row that still leaves room for
