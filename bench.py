@@ -312,6 +312,7 @@ def wideband_legs(local_rank: int, seconds: int = 4, steps: int = 5):
     import torch
     from amaranth_twstft_amd import _lib as L, frontend, prn, synth
     from amaranth_twstft_amd.correlator import Correlator, band_godual
+    from amaranth_twstft_amd.wideband import WidebandSession
     lib = L.load()
     dev = torch.device("cuda", local_rank)
     fs_in, dec, sps_in = 70e6, 14, 28
@@ -346,21 +347,73 @@ def wideband_legs(local_rank: int, seconds: int = 4, steps: int = 5):
         wide[st] = a_
         expect[st + "lo"], expect[st + "re"] = (d_loc - half) / dec, (d_rem - half) / dec
     torch.cuda.synchronize(dev)                                # torch's stream wrote the captures; the library's streams do not wait for it
-    nar = {st: torch.empty((n_out, 2), dtype=torch.int16, device=dev) for st in ("OP", "LTFB")}
     # name -> (capture's station, code, band)
     plan = {"OPlo": ("OP", "OP", band_godual(FS, N)), "OPre": ("OP", "LTFB", band_godual(FS, N, remote=1, OP=0)),
             "LTFBlo": ("LTFB", "LTFB", band_godual(FS, N)), "LTFBre": ("LTFB", "OP", band_godual(FS, N, remote=1, OP=1))}
     bands = {k: L.twx_band(*v[2]) for k, v in plan.items()}
-    res = {(k, pr): torch.zeros((W, C.sizeof(L.twx_result)), dtype=torch.uint8, device=dev) for k in plan for pr in ("f32", "f64")}
+    res = {(k, pr): torch.zeros((W, C.sizeof(L.twx_result)), dtype=torch.uint8, device=dev) for k in plan for pr in ("f64",)}
+    wptr = {st: t.data_ptr() for st, t in wide.items()}
+
+    def records_of(step_records):
+        return {k: [(int(r.indice0), math.hypot(r.xval[0], r.xval[1]), float(r.df)) for r in v] for k, v in step_records.items()}
+
+    # fp32: the product's session (amaranth_twstft_amd/wideband.py): front end + four correlations, double-buffered by step
+    sess = WidebandSession(codes, taps, dec, fs=FS, windows=W, device=local_rank, precision="f32", plan=plan)
+    c32 = sess.ctx
+
+    def fir_all():
+        for st in sess.stations:
+            c32[sess.front[st]].fir_decimate_dev(wptr[st], n_in, taps, dec, out_i16_dev=sess.nar[st][0].data_ptr())
+        for st in sess.stations:
+            c32[sess.front[st]].synchronize()
+
+    def corr_all32():
+        for k, (st, _, _) in plan.items():                     # four launches back to back: nothing waits in between
+            L.check(lib.twx_process_windows_dev(c32[k]._h, sess.nar[st][0].data_ptr(), W, 1, 0, C.byref(bands[k]), None, sess.res[k][0].data_ptr()), c32[k]._h)
+        for k in plan:
+            c32[k].synchronize()
+
+    sess.submit(wptr); sess.submit(wptr); sess.synchronize()    # warm-up (both buffer parities)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fir_all()
+    t_fir = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        corr_all32()
+    t_corr = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):                                      # one step at a time: submit, wait
+        sess.submit(wptr); sess.synchronize()
+    t_step_serial = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    last = -1
+    for _ in range(steps):                                      # the session as it is meant to run: step i+1 enqueued behind step i,
+        last = sess.submit(wptr)                                # its front end sharing the GPU with step i's correlations
+        if last >= 1:
+            sess.fetch(last - 1)                                # (and every step's records fetched, one step behind)
+    r32 = records_of(sess.fetch(last))
+    sess.synchronize()
+    t_step = (time.perf_counter() - t0) / steps
+    # the FIR kernel alone: HIP events on the stream it is launched on (the context's, not torch's)
+    es = sess.stream["OPlo"]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c32["OPlo"].fir_decimate_dev(wptr["OP"], n_in, taps, dec, out_i16_dev=sess.nar["OP"][0].data_ptr())
+    e0.record(es)
+    for _ in range(5):
+        c32["OPlo"].fir_decimate_dev(wptr["OP"], n_in, taps, dec, out_i16_dev=sess.nar["OP"][0].data_ptr())
+    e1.record(es)
+    e1.synchronize()
+    fir_ms = e0.elapsed_time(e1) / 5
+    fir_flops = n_out * ntaps * 4                                # complex int16 sample x real tap: 2 FMAs
+    fir_bytes = n_in * 4 + n_out * 4
+    sess.synchronize()
+    nar = {st: sess.nar[st][0].clone() for st in sess.stations}   # the decimated captures for the fp64 leg
+    torch.cuda.synchronize(dev)
+    sess.close()
 
     def make(precision, **kw):
         return {k: Correlator(codes[v[1]], fs=FS, Nint=1, device=local_rank, precision=precision, **kw) for k, v in plan.items()}
-
-    def fir_all(ctx):
-        for st in ("OP", "LTFB"):
-            ctx[st + "lo"].fir_decimate_dev(wide[st].data_ptr(), n_in, taps, dec, out_i16_dev=nar[st].data_ptr())
-        for st in ("OP", "LTFB"):
-            ctx[st + "lo"].synchronize()                       # the remote correlations run on other contexts' streams
 
     def corr_all(ctx, pr):
         for k, (st, _, _) in plan.items():                     # four launches back to back: nothing waits in between
@@ -374,36 +427,6 @@ def wideband_legs(local_rank: int, seconds: int = 4, steps: int = 5):
             arr = (L.twx_result * W).from_buffer_copy(res[(k, pr)].cpu().numpy().tobytes())
             out[k] = [(int(arr[w].indice0), math.hypot(arr[w].xval[0], arr[w].xval[1]), float(arr[w].df)) for w in range(W)]
         return out
-
-    c32 = make("f32")
-    fir_all(c32); corr_all(c32, "f32")                          # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fir_all(c32)
-    t_fir = (time.perf_counter() - t0) / steps
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        corr_all(c32, "f32")
-    t_corr = (time.perf_counter() - t0) / steps
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fir_all(c32); corr_all(c32, "f32")
-    t_step = (time.perf_counter() - t0) / steps
-    # the FIR kernel alone: HIP events on the stream it is launched on (the context's, not torch's)
-    es = torch.cuda.ExternalStream(int(lib.twx_stream(c32["OPlo"]._h)), device=dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    c32["OPlo"].fir_decimate_dev(wide["OP"].data_ptr(), n_in, taps, dec, out_i16_dev=nar["OP"].data_ptr())
-    e0.record(es)
-    for _ in range(5):
-        c32["OPlo"].fir_decimate_dev(wide["OP"].data_ptr(), n_in, taps, dec, out_i16_dev=nar["OP"].data_ptr())
-    e1.record(es)
-    e1.synchronize()
-    fir_ms = e0.elapsed_time(e1) / 5
-    fir_flops = n_out * ntaps * 4                                # complex int16 sample x real tap: 2 FMAs
-    fir_bytes = n_in * 4 + n_out * 4
-    r32 = records("f32")
-    for c in c32.values():
-        c.close()
 
     c64 = make("f64")
     corr_all(c64, "f64")
@@ -432,9 +455,12 @@ def wideband_legs(local_rank: int, seconds: int = 4, steps: int = 5):
     corr_samples = 4 * W * N
     wl = {"workload": f"BASELINE.json configs[4]: two stations x {{local, remote}} = 4 correlations (OPlo, OPre, LTFBlo, LTFBre: two LFSR(22) codes, taps 57 / 3, "
                       f"remote signal +-50 kHz off), {W} s of 70-Msps int16 IQ per station, HBM-resident: FIR {ntaps} taps decimate by 14 -> 5 Msps -> full "
-                      "processing(d,k) per 1-s window, the four correlations in flight together (four contexts), fp32",
+                      "processing(d,k) per 1-s window, the four correlations in flight together (four contexts), fp32; steps double-buffered "
+                      "(amaranth_twstft_amd/wideband.py: step i+1 is enqueued behind step i, every step's records fetched one step behind)",
           "input_Msamples_per_s": round(2 * n_in / t_step / 1e6, 1), "correlated_Msamples_per_s": round(corr_samples / t_step / 1e6, 1),
-          "ms_per_step": round(t_step * 1e3, 3), "fir_ms_per_step": round(t_fir * 1e3, 3), "correlations_ms_per_step": round(t_corr * 1e3, 3),
+          "ms_per_step": round(t_step * 1e3, 3), "ms_per_step_one_at_a_time": round(t_step_serial * 1e3, 3),
+          "input_Msamples_per_s_one_at_a_time": round(2 * n_in / t_step_serial / 1e6, 1),
+          "fir_ms_per_step": round(t_fir * 1e3, 3), "correlations_ms_per_step": round(t_corr * 1e3, 3),
           "correlations_alone_Msamples_per_s": round(corr_samples / t_corr / 1e6, 1),
           "chain_GBs_algorithmic": round(92 * corr_samples / t_corr / 1e9, 1), "chain_frac_hbm": round(92 * corr_samples / t_corr / 1e9 / HBM_PEAK_GBS, 4),
           "expected_lags_within_one_sample": bool(lag_ok), "steps": steps,

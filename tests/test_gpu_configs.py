@@ -258,6 +258,80 @@ def test_config4_two_station_wideband_chain_at_size():
             assert 40_000.0 < abs(o["df"]) < 60_000.0
 
 
+def test_config4_session_steps_enqueued_behind_each_other():
+    """amaranth_twstft_amd/wideband.py: five steps submitted back to back (double-buffered decimated captures and records, the
+    front end of step i+1 sharing the GPU with the correlations of step i), records fetched one step behind.  The captures of
+    consecutive steps DIFFER (other delays), so a record computed from a buffer that was overwritten too early, or read too
+    early, cannot equal the reference: the same step done alone on fresh contexts with a wait after every call."""
+    import torch
+    from amaranth_twstft_amd.wideband import WidebandSession, godual_plan
+    dev = torch.device("cuda", 0)
+    fs_in, dec, sps_in = 70e6, 14, 28
+    taps = frontend.lowpass_taps(fs_in, 2.1e6, 0.4e6)
+    codes = {"OP": chips_for(22, 57, NCHIPS), "LTFB": chips_for(22, 3, NCHIPS)}
+    cdev = {k: torch.from_numpy(v).to(dev) for k, v in codes.items()}
+    n_in = (N - 1) * dec + taps.size
+    half = (taps.size - 1) // 2
+
+    def capture(st, other, d_loc, d_rem, f_rem, stream):
+        wide = torch.empty((n_in, 2), dtype=torch.int16, device=dev)
+        tmp = torch.empty((n_in, 2), dtype=torch.int16, device=dev)
+        _synth_dev(wide, n_in, cdev[st], NCHIPS, sps_in, [synth.SynthParams(delay_q8=d_loc * 256, fstep=synth.fstep_for_df(3.25, fs_in), phi0=99, amp=2500,
+                                                                          noise_gain=synth.noise_gain_for_sigma(2500.0), seed=411, stream=stream)])
+        _synth_dev(tmp, n_in, cdev[other], NCHIPS, sps_in, [synth.SynthParams(delay_q8=d_rem * 256, fstep=synth.fstep_for_df(f_rem, fs_in), phi0=7, amp=1200,
+                                                                            noise_gain=0, seed=412, stream=stream)])
+        torch.cuda.synchronize()
+        wide = (wide.to(torch.int32) + tmp.to(torch.int32)).clamp_(-32768, 32767).to(torch.int16).contiguous()
+        torch.cuda.synchronize()
+        return wide
+
+    # two different capture sets, used alternately: A B A B A
+    delays = [{"OP": (18_364_717, 50_772_133), "LTFB": (41_000_003, 9_123_457)}, {"OP": (3_141_593, 27_182_818), "LTFB": (60_221_409, 16_180_339)}]
+    sets = [{"OP": capture("OP", "LTFB", *d["OP"], +50_000.0, 2 * i), "LTFB": capture("LTFB", "OP", *d["LTFB"], -50_000.0, 2 * i + 1)} for i, d in enumerate(delays)]
+    plan = godual_plan(("OP", "LTFB"), FS, N)
+    key = lambda r: (int(r.indice0), r.xval[0], r.xval[1], r.df, r.correction, r.xvalm1[0], r.xvalp1[0], r.SNRr, r.SNRi)
+    # reference: one call at a time, a wait after each
+    ref = []
+    for cs in sets:
+        out = {}
+        nar = torch.empty((N, 2), dtype=torch.int16, device=dev)
+        for st in ("OP", "LTFB"):
+            for name, (cst, code_st, band) in plan.items():
+                if cst != st:
+                    continue
+                with Correlator(codes[code_st], fs=FS, Nint=1) as c:
+                    assert c.fir_decimate_dev(cs[st].data_ptr(), n_in, taps, dec, out_i16_dev=nar.data_ptr()) == N
+                    c.synchronize()
+                    b = L.twx_band(*band)
+                    o = torch.zeros(C.sizeof(L.twx_result), dtype=torch.uint8, device=dev)
+                    L.check(c._lib.twx_process_windows_dev(c._h, nar.data_ptr(), 1, 1, 0, C.byref(b), None, o.data_ptr()), c._h)
+                    c.synchronize()
+                    out[name] = key(L.twx_result.from_buffer_copy(o.cpu().numpy().tobytes()))
+        ref.append(out)
+    for i, d in enumerate(delays):               # the reference itself sits where the generator put the codes
+        for st in ("OP", "LTFB"):
+            for suffix, d70 in zip(("lo", "re"), d[st]):
+                assert abs(ref[i][st + suffix][0] / 3.0 - (d70 - half) / dec) < 1.0
+    assert ref[0] != ref[1]
+    with WidebandSession(codes, taps, dec, fs=FS, windows=1, plan=plan) as sess:
+        got = {}
+        for i in range(5):
+            step = sess.submit({st: t.data_ptr() for st, t in sets[i % 2].items()})
+            assert step == i
+            if i:
+                got[i - 1] = sess.fetch(i - 1)
+        got[4] = sess.fetch(4)
+        with pytest.raises(ValueError):
+            sess.fetch(2)                           # overwritten two steps ago
+        for i in range(5):
+            for name in plan:
+                assert key(got[i][name][0]) == ref[i % 2][name], (i, name)
+        # a capture too short for the step's windows is refused before anything is enqueued
+        with pytest.raises(ValueError):
+            sess.submit({st: t.data_ptr() for st, t in sets[0].items()}, n_in=n_in - dec)
+        assert sess.step == 5
+
+
 # --------------------------------------------------------------------------------------------------------------
 # multi-rank path with the real correlator (ranks share GPU 0, records exchanged with gloo)
 # --------------------------------------------------------------------------------------------------------------
