@@ -80,10 +80,7 @@ static bool choose_split_from(long long n, int f64, bool builtin_only, const Col
             if (builtin_only && ce.plugin) continue;
             if (force_w && o.W != force_w) continue;
             if (o.L != (int)n1 || o.f64 != f64 || r.L % o.W != 0) continue;
-            // complex double: a tile of L x W x 16 bytes; two workgroups per CU (<= 80 KB each) beat one with a wider tile — W = 8 still
-            // moves whole 128-byte pieces (k_col_inv 0.329 -> 0.232 ms at L = 625, profiles/r05_f64_rowwalk.txt); fp32: the widest tile
-            auto two_fit = [&](const ColOps& q) { return !f64 || (long long)q.L * q.W * 16 <= 80 * 1024; };
-            if (!c || (two_fit(o) && !two_fit(*c)) || (two_fit(o) == two_fit(*c) && o.W > c->W)) c = &o;
+            if (!c || o.W > c->W) c = &o;
         }
         if (!c) continue;
         // widest column tile first (HBM piece size), then the row: 4000, then the longest row that still leaves room for
@@ -94,6 +91,21 @@ static bool choose_split_from(long long n, int f64, bool builtin_only, const Col
     if (!br) return false;
     *col = bc; *row = br;
     return true;
+}
+// The LAST pass may use another tile width than the forward passes: Bz is not tile-blocked, so nothing but this kernel sees its W.
+// Complex double: a tile of L x W x 16 bytes; two workgroups per CU (<= 80 KB each) beat one with a wider tile, and W = 8 still moves whole
+// 128-byte pieces (k_col_inv 0.322 -> 0.233 ms at L = 625, profiles/r05_f64_colw.txt) — while the forward passes keep W = 16, because the
+// row passes gather A in pieces of W elements and lose more with 128-byte pieces than the forward column passes gain.  fp32: the same plan.
+static const ColOps* choose_col_inv(const ColOps* col, int n2, int f64) {
+    if (!f64 || getenv("TWX_COL_W") || (long long)col->L * col->W * 16 <= 80 * 1024) return col;
+    std::lock_guard<std::recursive_mutex> g(reg_mu());
+    const ColOps* best = col;
+    for (auto& ce : col_reg()) {
+        const ColOps& o = ce.o;
+        if (o.L != col->L || o.f64 != f64 || n2 % o.W != 0 || (long long)o.L * o.W * 16 > 80 * 1024) continue;
+        if (best == col || o.W > best->W) best = &o;
+    }
+    return best;
 }
 bool choose_split(long long n, int f64, const ColOps** col, const RowOps** row) {
     std::lock_guard<std::recursive_mutex> g(reg_mu());
@@ -363,6 +375,7 @@ struct CtxBase {
     hipStream_t stream = nullptr;
     long long N = 0; int N1 = 0, N2 = 0, R = 1, B = 1;
     const ColOps* col = nullptr; const RowOps* row = nullptr;
+    const ColOps* colinv = nullptr;          // the last pass's plan (choose_col_inv): col unless complex double needs a narrower tile
     std::vector<std::pair<void*, size_t>> allocs;
     long long dev_bytes = 0;
     // profiling
@@ -561,7 +574,7 @@ template <typename T> struct Ctx : CtxBase {
     int io_threads = 8;                         // TWX_IO_THREADS: concurrent preads per chunk in twx_process_file
     std::atomic<int> h2d_failed{0};             // set by a reader thread whose copy to the device was refused
     int ncu = 256;
-    int ntiles = 0;
+    int ntiles = 0, ntiles_inv = 0;          // column tiles per row: forward passes / last pass
 
     template <typename U> int upload(U** dst, const std::vector<U>& src) {
         int rc = dalloc(dst, src.size());
@@ -755,7 +768,7 @@ template <typename T> struct Ctx : CtxBase {
         profile = (cfg.flags & TWX_FLAG_PROFILE) != 0;
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         R = cfg.nphase > 0 ? cfg.nphase : 2 * cfg.nint + 1;
-        ntiles = N2 / col->W;
+        ntiles = N2 / col->W; ntiles_inv = N2 / colinv->W;
         if (cfg.max_batch > 0) B = cfg.max_batch;
         else {   // largest power of two whose A+Bz buffers stay under ~1.5 GiB; at most 16 windows per launch, up to 256
                  // for windows under 64 k samples where a launch would otherwise be shorter than its own overhead
@@ -846,7 +859,7 @@ template <typename T> struct Ctx : CtxBase {
             if (int rc = dalloc(&q.Bz, (size_t)B * R * N)) return rc;
             if (int rc = dalloc(&q.dc, (size_t)B)) return rc;
             if (int rc = dalloc(&q.part_band, (size_t)B * N1)) return rc;
-            if (int rc = dalloc(&q.part_peak, (size_t)B * R * ntiles)) return rc;
+            if (int rc = dalloc(&q.part_peak, (size_t)B * R * ntiles_inv)) return rc;
             if (int rc = dalloc(&q.res_dev, (size_t)B * TWX_MAX_CHANNELS)) return rc;   // all-channel mode: B windows x channels
             if (fine_M) { if (int rc = dalloc(&q.fine_u, (size_t)B * fine_M)) return rc; }
             if (int rc = dalloc(&q.csum_part, (size_t)B * 64)) return rc;
@@ -1074,14 +1087,14 @@ template <typename T> struct Ctx : CtxBase {
             } else if (row->run(ROW_MID, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(mid) launch failed");
         }
         ColInvArgs<T> ia{};
-        ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = R; ia.nwin = nb; ia.Bz = Bz; ia.tw1 = tw1; ia.part = part_peak; ia.zout = zout; ia.norm1 = argmax_norm1; ia.zscale = (T)(map_only ? zscale : 1.0);
+        ia.n = N; ia.n2 = N2; ia.ntiles = ntiles_inv; ia.nphase = R; ia.nwin = nb; ia.Bz = Bz; ia.tw1 = tw1; ia.part = part_peak; ia.zout = zout; ia.norm1 = argmax_norm1; ia.zscale = (T)(map_only ? zscale : 1.0);
         {
             ProfScope ps(this, PC_COL_INV, (long long)nb * N);
             for (int it = 0, ne = reps(PC_COL_INV); it < ne; ++it)
-            if (col->inv(&ia, (unsigned)(ntiles * R * nb), stream)) return fail(TWX_E_HIP, "k_col_inv launch failed");
+            if (colinv->inv(&ia, (unsigned)(ntiles_inv * R * nb), stream)) return fail(TWX_E_HIP, "k_col_inv launch failed");
         }
         PeakArgs<T> pa{};
-        pa.n = N; pa.n1 = N1; pa.n2 = N2; pa.nphase = R; pa.nparts = R * ntiles; pa.part = part_peak; pa.Bz = Bz; pa.tw1d = tw1d;
+        pa.n = N; pa.n1 = N1; pa.n2 = N2; pa.nphase = R; pa.nparts = R * ntiles_inv; pa.part = part_peak; pa.Bz = Bz; pa.tw1d = tw1d;
         pa.sums = sums; pa.remove_mean = rm_mean; pa.dc = dc; pa.dfv = dfv; pa.dfidx = dfidx; pa.inv_scale = 1.0 / scale_pow2;
         pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.convention = cfg.convention; pa.snr_valid = snr_valid; pa.res = out_dev; pa.res_stride = res_stride;
         if (!map_only) {
@@ -1674,7 +1687,7 @@ template <typename T> struct Ctx : CtxBase {
             nstr = (nslots >= 2 && !caf_serial && nbins > want) ? 2 : 1;
             if (want * nstr > nbmax) {
                 if (!(Bzc = static_cast<C*>(scratch_slot(4, (size_t)N * want * nstr * sizeof(C))))) return TWX_E_NOMEM;
-                if (!(partc = static_cast<ArgPart<T>*>(scratch_slot(5, (size_t)ntiles * want * nstr * sizeof(ArgPart<T>))))) return TWX_E_NOMEM;
+                if (!(partc = static_cast<ArgPart<T>*>(scratch_slot(5, (size_t)ntiles_inv * want * nstr * sizeof(ArgPart<T>))))) return TWX_E_NOMEM;
             }
             nbpl = (int)want;                        // <= nbmax: the batch buffers of the chain serve as the bin buffer
             static const int bpw_env = [] { const char* e = getenv("TWX_CAF_BPW"); return e ? std::max(1, atoi(e)) : 32; }();
@@ -1693,7 +1706,7 @@ template <typename T> struct Ctx : CtxBase {
             const int nb = (int)std::min<long long>(nbpl, k_hi - k0 + 1);
             const int sidx = (int)(grp % nstr);
             hipStream_t stream = slots[sidx].stream;              // shadows the context's current stream inside the loop
-            Bzc = Bzc0 + (size_t)sidx * nbpl * N; partc = partc0 + (size_t)sidx * nbpl * ntiles;
+            Bzc = Bzc0 + (size_t)sidx * nbpl * N; partc = partc0 + (size_t)sidx * nbpl * ntiles_inv;
             CafArgs<T> fa{};
             fa.n = N; fa.n1 = N1; fa.nbins = nb; fa.kappa0 = k0; fa.Y = Ysp; fa.cspec = cspec; fa.stab_i = stab_i;
             fa.ta = ta; fa.tb = tb; fa.tshift = tshift; fa.scale = (T)scale_pow2; fa.Bz = Bzc;
@@ -1708,14 +1721,14 @@ template <typename T> struct Ctx : CtxBase {
                 if (row->caf(&fa, grid, stream)) return fail(TWX_E_HIP, "k_row_caf launch failed");
             }
             ColInvArgs<T> ia{};
-            ia.n = N; ia.n2 = N2; ia.ntiles = ntiles; ia.nphase = 1; ia.nwin = nb; ia.Bz = Bzc; ia.tw1 = tw1; ia.part = partc; ia.zout = nullptr;
+            ia.n = N; ia.n2 = N2; ia.ntiles = ntiles_inv; ia.nphase = 1; ia.nwin = nb; ia.Bz = Bzc; ia.tw1 = tw1; ia.part = partc; ia.zout = nullptr;
             {
                 ProfScope ps(this, PC_COL_INV_CAF, (long long)nb * N);
-                if (col->inv(&ia, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_inv launch failed");
+                if (colinv->inv(&ia, (unsigned)(ntiles_inv * nb), stream)) return fail(TWX_E_HIP, "k_col_inv launch failed");
             }
             {
                 ProfScope ps(this, PC_CAF_REDUCE, nb);
-                TWX_LAUNCH((k_caf_reduce<T>), dim3(nb), dim3(256), stream, partc, ntiles, 1.0 / scale_pow2 / (double)N, pk_d + (k0 - k_lo), lag_d + (k0 - k_lo));
+                TWX_LAUNCH((k_caf_reduce<T>), dim3(nb), dim3(256), stream, partc, ntiles_inv, 1.0 / scale_pow2 / (double)N, pk_d + (k0 - k_lo), lag_d + (k0 - k_lo));
                 HIPCHK(hipGetLastError());
             }
         }
@@ -1800,7 +1813,7 @@ static int create_impl(const twx_config* cfg, twx_ctx** out) {
     }
     if ((col->W & (col->W - 1)) != 0) { g_create_err = "column tile width must be a power of two (tile-blocked A layout)"; return TWX_E_SIZE; }
     CtxBase* c = f64 ? static_cast<CtxBase*>(new Ctx<double>()) : static_cast<CtxBase*>(new Ctx<float>());
-    c->cfg = *cfg; c->N = N; c->N1 = col->L; c->N2 = row->L; c->col = col; c->row = row;
+    c->cfg = *cfg; c->N = N; c->N1 = col->L; c->N2 = row->L; c->col = col; c->row = row; c->colinv = choose_col_inv(col, row->L, f64);
     (void)hipGetDevice(&c->dev);
     int rc = guarded(c, [&]() { return c->init(); });
     if (rc) { g_create_err = c->err; delete c; return rc; }
