@@ -35,12 +35,14 @@ torch.cuda.synchronize()
 band = band_godual(FS, N)
 with Correlator(chips, fs=FS, Nint=1) as cor:
     got = cor.process_dev(iq.data_ptr(), nwin, band=band)
+with Correlator(chips, fs=FS, Nint=1, precision="f64") as cor64:      # round 5: the complex-double chain on the same windows
+    got64 = cor64.process_dev(iq.data_ptr(), nwin, band=band)
 code = orc.make_code(chips, 2)
 fcode = orc.make_fcode(code)
 freq = orc.freq_axis(FS, N)
 k = np.arange(band[0], band[1] + 1)
 temps = np.arange(N) / FS
-mism, relmax = [], 0.0
+mism, relmax, mism64, relmax64 = [], 0.0, [], 0.0
 t0 = time.time()
 for w in range(nwin):
     d = orc.deinterleave(iq[w].cpu().numpy(), 1, 0)
@@ -51,5 +53,10 @@ for w in range(nwin):
         mism.append((w, params[w], g.indice, o["indice"], g.df, o["df"]))
     else:
         relmax = max(relmax, abs(abs(g.xval) - abs(o["xval"])) / abs(o["xval"]))
-print(json.dumps({"windows": nwin, "n": N, "mismatches": mism, "max_rel_peak_error": relmax, "noise_only_windows": sum(1 for p in params if p[0] == 0),
+    g = got64[w]
+    if g.indice != o["indice"] or abs(g.df - o["df"]) > 1e-9:
+        mism64.append((w, params[w], g.indice, o["indice"], g.df, o["df"]))
+    else:
+        relmax64 = max(relmax64, abs(abs(g.xval) - abs(o["xval"])) / abs(o["xval"]))
+print(json.dumps({"windows": nwin, "n": N, "mismatches": mism, "max_rel_peak_error": relmax, "f64_mismatches": mism64, "f64_max_rel_peak_error": relmax64, "noise_only_windows": sum(1 for p in params if p[0] == 0),
                   "oracle_seconds": round(time.time() - t0, 1)}))
