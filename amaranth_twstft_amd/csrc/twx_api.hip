@@ -575,6 +575,15 @@ template <typename T> struct Ctx : CtxBase {
     std::atomic<int> h2d_failed{0};             // set by a reader thread whose copy to the device was refused
     int ncu = 256;
     int ntiles = 0, ntiles_inv = 0;          // column tiles per row: forward passes / last pass
+    // captured one-batch launches (process()): key = everything of the call that the kernels' arguments hold
+    struct GraphEntry { const void* in; long long nwin; int nch, ch, rm; long long lo, hi; const void* out; hipGraphExec_t exec; unsigned long long used; };
+    std::vector<GraphEntry> graphs;
+    unsigned long long graph_clock = 0;
+    int graph_state = -1;                    // -1: ask the environment; 0: direct launches; 1: graphs
+    bool graphs_enabled() {
+        if (graph_state < 0) { const char* e = getenv("TWX_GRAPH"); graph_state = (e && atoi(e) != 0) ? 1 : 0; }
+        return graph_state == 1;
+    }
 
     template <typename U> int upload(U** dst, const std::vector<U>& src) {
         int rc = dalloc(dst, src.size());
@@ -757,6 +766,7 @@ template <typename T> struct Ctx : CtxBase {
     }
 
     ~Ctx() override {
+        for (auto& e : graphs) (void)hipGraphExecDestroy(e.exec);
         for (int k = 0; k < 4; ++k) { if (stage[k].host) (void)hipHostFree(stage[k].host); if (stage[k].dev) (void)hipFree(stage[k].dev); }
         for (int k = 1; k < nslots; ++k) if (slots[k].stream) (void)hipStreamDestroy(slots[k].stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -1127,6 +1137,45 @@ template <typename T> struct Ctx : CtxBase {
         const int c_lo = all ? 0 : ch, c_hi = all ? nch : ch + 1, ostride = all ? nch : 1;
         std::vector<double> dfc;
         int k = 0;
+        // One-batch calls with the carrier search on the device (the per-second callers: MEX form A, the receiver's loop) enqueue
+        // nothing but kernels on slot 0's stream: the sequence is captured once per (buffers, band) and replayed as a hipGraph —
+        // one submission instead of nine launches.  Anything the kernels' arguments hold is in the key or fixed for the context's
+        // life (slot buffers, tables; twx_set_code_spectrum* rewrites the spectrum in place).
+        if (graphs_enabled() && !profile && dbg_only < 0 && !stamps_dev && band && !df && !all && nwin <= B) {
+            if (band->k_lo < 0 || band->k_hi >= N || band->k_lo > band->k_hi) return fail(TWX_E_ARG, "band outside 0..N-1");
+            GraphEntry* g = nullptr;
+            for (auto& e : graphs)
+                if (e.in == iq_dev && e.nwin == nwin && e.nch == nch && e.ch == ch && e.rm == remove_mean && e.lo == band->k_lo && e.hi == band->k_hi &&
+                    e.out == (const void*)out_dev) g = &e;
+            if (!g) {
+                use_slot(0);
+                if (hipStreamBeginCapture(slots[0].stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    const short2* base = reinterpret_cast<const short2*>(iq_dev) + ch;
+                    const int rc = run_batch(base, (int)nwin, nch, band, nullptr, out_dev, nullptr, false, 1);
+                    hipGraph_t gr = nullptr; hipGraphExec_t ex = nullptr;
+                    const hipError_t e1 = hipStreamEndCapture(slots[0].stream, &gr);
+                    if (rc == TWX_OK && e1 == hipSuccess && gr && hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) == hipSuccess) {
+                        if (graphs.size() >= 8) {                                    // least recently used goes
+                            size_t v = 0;
+                            for (size_t i = 1; i < graphs.size(); ++i) if (graphs[i].used < graphs[v].used) v = i;
+                            (void)hipGraphExecDestroy(graphs[v].exec); graphs.erase(graphs.begin() + (long)v);
+                        }
+                        graphs.push_back(GraphEntry{iq_dev, nwin, nch, ch, remove_mean, band->k_lo, band->k_hi, (const void*)out_dev, ex, 0});
+                        g = &graphs.back();
+                    } else {
+                        (void)hipGetLastError();
+                        graph_state = 0;                                             // this context launches directly from now on
+                    }
+                    if (gr) (void)hipGraphDestroy(gr);
+                    if (rc != TWX_OK) return rc;
+                } else { (void)hipGetLastError(); graph_state = 0; }
+            }
+            if (g) {
+                g->used = ++graph_clock;
+                HIPCHK(hipGraphLaunch(g->exec, slots[0].stream));
+                return TWX_OK;
+            }
+        }
         // Everything is ordered against slot 0's stream (= twx_stream()): the other slots start after what the caller
         // enqueued there before this call (the producer of iq_dev), and slot 0 ends up waiting for all of them, so a
         // consumer of out_dev enqueued on twx_stream() after the call sees every record.

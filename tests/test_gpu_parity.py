@@ -1374,6 +1374,39 @@ def test_records_do_not_depend_on_the_batch_size(precision):
         assert got == ref, mb
 
 
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_one_batch_calls_replayed_as_graphs(precision, monkeypatch):
+    """TWX_GRAPH=1: a device-resident call of one batch with the carrier search on the device is captured once per (input, band, output)
+    and replayed as a hipGraph.  Calls that alternate between two inputs, three bands, two channel selections and two batch sizes —
+    each repeated, so every graph is both captured and replayed — return byte for byte what the directly launched chain returns;
+    calls the graph path does not take (supplied df, all channels, more than one batch) are unaffected."""
+    import torch
+    chips, raw = _capture(13, 27, 5000, 8, seed=91)
+    n = 2 * len(chips)
+    dev_a = torch.from_numpy(raw.reshape(-1)).cuda()
+    dev_b = torch.from_numpy(np.ascontiguousarray(raw.reshape(8, n, 4)[::-1]).reshape(-1)).cuda()       # the windows in reverse order
+    bands = [band_numpy(FS, n), band_numpy(FS, n, 500.0, 3000.0), band_godual(FS, n)]
+    key = lambda r: (r.indice, r.xval, r.correction, r.df, r.SNRr, r.SNRi, r.puissance, r.puissancecode, r.puissancenoise)
+    plan = [(d, nw, ch, b) for d in (dev_a, dev_b) for nw in (1, 8) for ch in (0, 1) for b in range(3)]
+
+    def run(graph):
+        monkeypatch.setenv("TWX_GRAPH", graph)
+        out = []
+        with Correlator(chips, fs=FS, Nint=1, precision=precision, max_batch=8) as cor:
+            for rep in range(3):
+                for d, nw, ch, b in plan:
+                    out.append([key(r) for r in cor.process_dev(d.data_ptr(), nw, 2, ch, band=bands[b])])
+            out.append([key(r) for r in cor.process_dev(dev_a.data_ptr(), 8, 2, 0, df=np.linspace(-700.0, 700.0, 8))])
+            out.append({c: [key(r) for r in v] for c, v in cor.process_dev(dev_a.data_ptr(), 8, 2, -1, band=bands[0]).items()})
+        with Correlator(chips, fs=FS, Nint=1, precision=precision, max_batch=3) as cor:                 # 8 windows = three batches: direct
+            out.append([key(r) for r in cor.process_dev(dev_b.data_ptr(), 8, 2, 1, band=bands[0])])
+        return out
+
+    direct, graphs = run("0"), run("1")
+    assert graphs == direct
+    assert direct[0] != direct[1]                     # the plan's calls do differ from each other
+
+
 def test_fine_frequency_step_with_other_options():
     """TWX_FLAG_FINE_FREQ (the phase-drift fine carrier step of experiments/221219_twoway/processing/godual_ranging.py:26-30; it needs
     fs/3 samples, so N = 2e6) combined with the other options — interpolation factor, variance convention, precision, one- / two-channel
