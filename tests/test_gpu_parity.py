@@ -1376,8 +1376,8 @@ def test_records_do_not_depend_on_the_batch_size(precision):
 
 @pytest.mark.parametrize("precision", ["f32", "f64"])
 def test_one_batch_calls_replayed_as_graphs(precision, monkeypatch):
-    """TWX_GRAPH=1: a device-resident call of one batch with the carrier search on the device is captured once per (input, band, output)
-    and replayed as a hipGraph.  Calls that alternate between two inputs, three bands, two channel selections and two batch sizes —
+    """TWX_GRAPH=1 (an experiment that stays off: profiles/r05_one_window_graph.txt): a device-resident call of one batch with the
+    carrier search on the device is captured once per (input, band, output) and replayed as a hipGraph.  Calls that alternate between two inputs, three bands, two channel selections and two batch sizes —
     each repeated, so every graph is both captured and replayed — return byte for byte what the directly launched chain returns;
     calls the graph path does not take (supplied df, all channels, more than one batch) are unaffected."""
     import torch
@@ -1404,7 +1404,7 @@ def test_one_batch_calls_replayed_as_graphs(precision, monkeypatch):
 
     direct, graphs = run("0"), run("1")
     assert graphs == direct
-    assert direct[0] != direct[1]                     # the plan's calls do differ from each other
+    assert direct[0] != direct[3] and direct[0] != direct[12]      # the plan's calls do differ (other channel, other input)
 
 
 def test_fine_frequency_step_with_other_options():
