@@ -332,6 +332,76 @@ def test_config4_session_steps_enqueued_behind_each_other():
         assert sess.step == 5
 
 
+@pytest.mark.parametrize("depth", [1, 3])
+def test_wideband_session_short_codes_any_depth(depth):
+    """The session with 5 000-chip codes (N = 10 000, plan plug-in 25 x 400), three windows per step, a 57-tap front end, buffer depths 1
+    (every step waits for the one before) and 3: seven steps with a different capture each, every record equal to the one-call-at-a-time
+    reference; fetch() of the newest `depth` steps only."""
+    import torch
+    from amaranth_twstft_amd.wideband import WidebandSession, godual_plan
+    dev = torch.device("cuda", 0)
+    nchips, n, W, dec, sps_in = 5000, 10000, 3, 14, 28
+    fs_in = FS * dec
+    taps = frontend.lowpass_taps(fs_in, 2.1e6, 3.0e6)
+    assert taps.size == 57
+    codes = {"A": chips_for(13, 27, nchips), "B": chips_for(14, 43, nchips)}
+    cdev = {k: torch.from_numpy(v).to(dev) for k, v in codes.items()}
+    n_in = (W * n - 1) * dec + taps.size
+    plan = godual_plan(("A", "B"), FS, n)
+
+    def capture(st, other, seed):
+        a = torch.empty((n_in, 2), dtype=torch.int16, device=dev)
+        b = torch.empty((n_in, 2), dtype=torch.int16, device=dev)
+        _synth_dev(a, n_in, cdev[st], nchips, sps_in, [synth.SynthParams(delay_q8=(1000 + 977 * seed) * 256, fstep=synth.fstep_for_df(3.25, fs_in), phi0=9, amp=2500,
+                                                                       noise_gain=synth.noise_gain_for_sigma(1500.0), seed=500 + seed, stream=0)])
+        _synth_dev(b, n_in, cdev[other], nchips, sps_in, [synth.SynthParams(delay_q8=(70000 + 1201 * seed) * 256, fstep=synth.fstep_for_df(50_000.0 if st == "A" else -50_000.0, fs_in),
+                                                                          phi0=7, amp=1500, noise_gain=0, seed=600 + seed, stream=1)])
+        torch.cuda.synchronize()
+        out = (a.to(torch.int32) + b.to(torch.int32)).clamp_(-32768, 32767).to(torch.int16).contiguous()
+        torch.cuda.synchronize()
+        return out
+
+    steps = [{"A": capture("A", "B", 2 * i), "B": capture("B", "A", 2 * i + 1)} for i in range(7)]
+    key = lambda r: (int(r.indice0), r.xval[0], r.xval[1], r.df, r.correction, r.SNRr, r.SNRi)
+    ref = []
+    nar = torch.empty((W * n, 2), dtype=torch.int16, device=dev)
+    with Correlator(codes["A"], fs=FS, Nint=1) as ca, Correlator(codes["B"], fs=FS, Nint=1) as cb:
+        by_code = {"A": ca, "B": cb}
+        for cs in steps:
+            out = {}
+            for name, (st, code_st, band) in plan.items():
+                c = by_code[code_st]
+                assert c.fir_decimate_dev(cs[st].data_ptr(), n_in, taps, dec, out_i16_dev=nar.data_ptr()) == W * n
+                c.synchronize()
+                out[name] = [key(r) for r in _records_dev(c, nar, W, band)]
+            ref.append(out)
+    assert all(ref[i] != ref[i + 1] for i in range(6))
+    with WidebandSession(codes, taps, dec, fs=FS, windows=W, depth=depth) as sess:
+        assert sess.plan == plan and sess.n_in == n_in
+        for i, cs in enumerate(steps):
+            assert sess.submit({st: t.data_ptr() for st, t in cs.items()}) == i
+            if depth == 1 or i >= 2:
+                j = i if depth == 1 else i - 2                       # depth 3: fetched two steps behind
+                got = sess.fetch(j)
+                assert {k_: [key(r) for r in v] for k_, v in got.items()} == ref[j], j
+        if depth == 3:
+            for j in (5, 6):
+                assert {k_: [key(r) for r in v] for k_, v in sess.fetch(j).items()} == ref[j], j
+            with pytest.raises(ValueError):
+                sess.fetch(3)
+        with pytest.raises(ValueError):
+            sess.fetch(7)
+
+
+def _records_dev(c, nar, W, band):
+    import torch
+    o = torch.zeros((W, C.sizeof(L.twx_result)), dtype=torch.uint8, device=nar.device)
+    b = L.twx_band(*band)
+    L.check(c._lib.twx_process_windows_dev(c._h, nar.data_ptr(), W, 1, 0, C.byref(b), None, o.data_ptr()), c._h)
+    c.synchronize()
+    return list((L.twx_result * W).from_buffer_copy(o.cpu().numpy().tobytes()))
+
+
 # --------------------------------------------------------------------------------------------------------------
 # multi-rank path with the real correlator (ranks share GPU 0, records exchanged with gloo)
 # --------------------------------------------------------------------------------------------------------------
