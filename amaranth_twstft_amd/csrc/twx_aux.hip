@@ -873,14 +873,324 @@ __global__ __launch_bounds__(FIR8_NT) void k_fir_poly8(const short2* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_fir_mfma (round 5): the decimating FIR on the fp16 matrix cores at fp32 accuracy.
+//
+// v_pk_fma_f32 ends at half the fp32 "peak" (two passes per instruction: k_fir_poly8 sits at 0.89 of what the vector unit can
+// issue), the fp32 MFMA forms run at that same rate, and a banded Toeplitz operand wastes a third of them.  The fp16 forms are 16 x
+// faster, and both operands of THIS product split into fp16 pieces without loss:
+//   * a sample is an int16: x = 256 xh + xl with xh in -128..127 and xl in 0..255 — both exact in fp16;
+//   * a tap (fp32) times 2^s (s: max |h| 2^s in [64, 128)) is h1 + h2 with two fp16 values to 2^-22 of the tap;
+//   * fp16 x fp16 products are exact in the fp32 the matrix cores accumulate in.
+// So  y[m] = 2^-s sum_j (h1 + h2)[j] (256 xh + xl)[m D + j]  is four fp16 products per tap, and a K = 32 step of
+// v_mfma_f32_16x16x32_f16 takes 16 samples as (xh, xl) pairs against the column (256 h, h): the recombination of the sample happens
+// inside the dot product.  Per phase p (x_p[q] = x[q D + p], h_p[a] = taps[a D + p]) the filter is the banded Toeplitz product
+//   D[i][n] = sum_k A[i][k] B[k][n],   A[i][k] = h_p[k - i],   B[k][n] = x_p[m0 + 16 n + k]      (outputs m0 + 16 n + i)
+// with KS = ceil((taps per phase + 15) / 16) steps of 16 samples.  Per lane (n = l & 15, g = l >> 4) a B fragment is ONE 16-byte LDS
+// read (samples 4g .. 4g+3 of the step as (xh, xl) pairs); the A fragments (taps, Toeplitz-shifted per lane, both pieces) are built
+// on the host and live in registers for the life of the workgroup.  Error against the fp64 direct sum: that of an fp32 accumulation
+// over 4 x ntaps terms (simulated and measured: about half of the 2e-6 gate at 421 taps).
+//
+// Workgroup = 8 waves, 512 outputs per trip (two tiles of 16 x 16), persistent over the trips: wave w takes the (phase, step) pairs
+// w, w + 8, ... for BOTH tiles (its A fragments serve 8 MFMAs each), the eight partial sums meet in LDS.  The staged span holds, per
+// phase and component, one 32-bit word (xh, xl) per sample, rows padded by 16 bytes per 64 samples (the 16 lanes of a fragment
+// read then hit 16 different bank quads).
+// ---------------------------------------------------------------------------------------------
+#ifndef TWX_FM_DEPHASE
+#define TWX_FM_DEPHASE 0
+#endif
+#ifndef TWX_FM_ABL
+#define TWX_FM_ABL 0     // timing-only ablations of k_fir_mfma: 1 no matrix-core loop, 2 staging on the first trip only, 3 no reduction / stores, 4 no fragment reads
+#endif
+constexpr int FM_NT = 512, FM_OUT = 512, FM_MAXNPW = 6, FM_SP = 68;      // (7 and 8 pairs per wave spill at 128 registers)
+typedef _Float16 fm_h8 __attribute__((ext_vector_type(8)));
+typedef float fm_f4 __attribute__((ext_vector_type(4)));
+__host__ __device__ inline int fm_phys(int q) { return q + 4 * (q >> 6); }
+struct FirMfmaGeom { int A, KS, NPW, NQ, PS; size_t lds; bool ok; };
+FirMfmaGeom fir_mfma_geom(int ntaps, int dec) {
+    FirMfmaGeom g;
+    g.A = (ntaps + dec - 1) / dec;
+    g.KS = (g.A + 15 + 15) / 16;                        // Toeplitz columns A + 15 in steps of 16
+    g.NPW = (dec * g.KS + 7) / 8;                       // (phase, step) pairs per wave
+    g.NQ = FM_OUT + 16 * g.KS;                          // samples staged per phase
+    int ps = fm_phys(g.NQ) + 4;
+    ps = (ps + 3) & ~3;
+    while ((ps & 7) != 4) ps += 4;                      // rows 16-byte aligned, PS / 4 odd: the staging writes of consecutive phases spread over the banks
+    g.PS = ps;
+    g.lds = std::max<size_t>((size_t)2 * dec * g.PS * 4, (size_t)2 * 8 * 8 * FM_SP * 4);     // the staged span; later the partial sums [tile][wave][8][FM_SP]
+    g.ok = g.NPW >= 1 && g.NPW <= FM_MAXNPW && g.lds <= 80 * 1024 && (long long)g.NQ * dec <= 16ll * FM_NT;      // (the span in 4 vectors per thread)
+    return g;
+}
+// table of A fragments [pair u][piece][lane] x 16 bytes, u = p * KS + ks padded to 8 * NPW pairs (zeros); returns 2^-s through inv_scale
+std::vector<float> fir_mfma_table(const float* taps, int ntaps, int dec, const FirMfmaGeom& g, float* inv_scale) {
+    double hmax = 0;
+    for (int j = 0; j < ntaps; ++j) hmax = std::max(hmax, (double)fabsf(taps[j]));
+    int s = 0;
+    if (hmax > 0) { s = (int)floor(log2(127.0 / hmax)); s = std::max(-100, std::min(100, s)); }
+    *inv_scale = (float)ldexp(1.0, -s);
+    std::vector<_Float16> h1((size_t)ntaps), h2((size_t)ntaps);
+    for (int j = 0; j < ntaps; ++j) {
+        const double hs = ldexp((double)taps[j], s);
+        h1[(size_t)j] = (_Float16)hs;
+        h2[(size_t)j] = (_Float16)(hs - (double)h1[(size_t)j]);
+    }
+    const int npairs = 8 * g.NPW;
+    std::vector<float> out((size_t)npairs * 2 * 64 * 4, 0.f);
+    unsigned short* o = reinterpret_cast<unsigned short*>(out.data());
+    for (int u = 0; u < dec * g.KS; ++u) {
+        const int p = u / g.KS, ks = u % g.KS;
+        for (int pc = 0; pc < 2; ++pc)
+            for (int l = 0; l < 64; ++l) {
+                const int i = l & 15, gq = l >> 4;
+                for (int e = 0; e < 8; ++e) {
+                    const int a = 16 * ks + 4 * gq + (e >> 1) - i;
+                    const long long j = (long long)a * dec + p;
+                    _Float16 v = (_Float16)0.0f;
+                    if (a >= 0 && j < ntaps) {
+                        const _Float16 h = pc ? h2[(size_t)j] : h1[(size_t)j];
+                        v = (e & 1) ? h : (_Float16)((float)h * 256.0f);              // (xh, xl) pairs meet (256 h, h): exact power-of-two scaling
+                    }
+                    unsigned short bits; memcpy(&bits, &v, 2);
+                    o[(((size_t)u * 2 + pc) * 64 + l) * 8 + e] = bits;
+                }
+            }
+    }
+    return out;
+}
+// one sample word (I | Q << 16, int16 each) -> the two staged words (xh, xl as fp16) of its components
+__device__ __forceinline__ void fm_split(unsigned w, unsigned& wi, unsigned& wq) {
+    // four SDWA converts: the high byte of a component, sign-extended, is xh; the low byte, unsigned, xl — each written as fp16 straight
+    // into its half of the staged word (the plain C form costs ten vector instructions per sample)
+    asm volatile("v_cvt_f16_i16_sdwa %0, sext(%1) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(wi) : "v"(w));
+    asm volatile("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(wi) : "v"(w));
+    asm volatile("v_cvt_f16_i16_sdwa %0, sext(%1) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(wq) : "v"(w));
+    asm volatile("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(wq) : "v"(w));
+}
+// the staged words of four consecutive samples (one 16-byte vector, first sample at phase p of group q) into their slots
+__device__ __forceinline__ void fm_put4(unsigned* __restrict__ XI, unsigned* __restrict__ XQ, int4 v, int p, int q, int D, int PS) {
+    const int w4[4] = {v.x, v.y, v.z, v.w};
+    int slot = p * PS + fm_phys(q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned wi, wq;
+        fm_split((unsigned)w4[i], wi, wq);
+        XI[slot] = wi; XQ[slot] = wq;
+        if (++p >= D) { p = 0; ++q; slot += 1 - (D - 1) * PS + ((q & 63) == 0 ? 4 : 0); }       // next group: one word on, a pad every 64
+        else slot += PS;
+    }
+}
+__device__ __forceinline__ void fm_stage(unsigned* __restrict__ XI, unsigned* __restrict__ XQ, const short2* __restrict__ x, int nch, long long nin,
+                                         long long e0, int span, int D, int PS, int tid) {
+    // the general path (a channel of a multi-channel capture, an unaligned base, the last trips): 4-byte loads, unconditional (clamped)
+    const int dq = FM_NT / D, dp = FM_NT - dq * D;
+    int q = tid / D, p = tid - q * D;
+    const unsigned* xs = reinterpret_cast<const unsigned*>(x);
+    for (int eb = 0; eb < span; eb += 8 * FM_NT) {
+        unsigned raw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long ge = e0 + eb + u * FM_NT + tid;
+            const unsigned v = xs[min(ge, nin - 1) * nch];
+            raw[u] = ge < nin ? v : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = eb + u * FM_NT + tid;
+            if (e < span) {
+                unsigned wi, wq;
+                fm_split(raw[u], wi, wq);
+                const int slot = p * PS + fm_phys(q);
+                XI[slot] = wi; XQ[slot] = wq;
+            }
+            q += dq; p += dp;
+            if (p >= D) { p -= D; ++q; }
+        }
+    }
+}
+// FAST: trips trip0 .. trip0 + ntrips - 1 of a one-channel capture on a 16-byte boundary whose spans lie inside the capture (16-byte
+// loads, the next trip's asked for ahead); otherwise the general staging (a launch of its own for the last trips / other captures)
+template <int NPW, bool FAST>
+__global__ __launch_bounds__(FM_NT, 4) void k_fir_mfma(const short2* __restrict__ x, int nch, long long nin, const uint4* __restrict__ atab, int D, int KS,
+                                                       int PS, float inv_scale, long long nout, int trip0, int ntrips, short2* __restrict__ y16,
+                                                       float2* __restrict__ yf) {
+    extern __shared__ uint4 XM4[];
+    unsigned* XI = reinterpret_cast<unsigned*>(XM4);
+    unsigned* XQ = XI + D * PS;
+    float* S = reinterpret_cast<float*>(XM4);
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
+    const int NQ = FM_OUT + 16 * KS;
+    // this wave's (phase, step) pairs: A fragments (both pieces) and the lane's word offset of the B fragment in tile 0
+    uint4 af[NPW][2];
+    int off[NPW];
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        const int u = w + 8 * j;
+        af[j][0] = atab[((size_t)u * 2 + 0) * 64 + l];
+        af[j][1] = atab[((size_t)u * 2 + 1) * 64 + l];
+        const bool live = u < D * KS;
+        const int p = live ? u / KS : 0, ks = live ? u - p * KS : 0;
+        off[j] = p * PS + fm_phys(16 * n + 16 * ks + 4 * g);
+    }
+    // One-channel captures on a 16-byte boundary: a trip's span is NV 16-byte vectors per thread, and the NEXT trip's are asked for as
+    // soon as this trip's span is staged — in flight under the matrix-core loop and the reduction (a workgroup that loads, waits and
+    // then computes spends most of its life waiting: 0.131 ms per second of 70 Msps; the walk is the row pass's, k_rowd<MID>)
+    constexpr int NV = 4;
+    const int span = NQ * D, nvec = span >> 2;                                   // (fir_mfma_geom: span <= NV * 4 * FM_NT)
+    int4 nx[FAST ? NV : 1];
+    auto ask = [&](int trip) {
+        const int4* xv = reinterpret_cast<const int4*>(x + (long long)trip * FM_OUT * D);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) nx[u] = xv[min(u * FM_NT + tid, nvec - 1)];
+    };
+    const int tend = trip0 + ntrips;
+    const int dq4 = (4 * FM_NT) / D, dp4 = 4 * FM_NT - dq4 * D;
+    const int q_first = (4 * tid) / D, p_first = 4 * tid - q_first * D;          // (group, phase) of the thread's first vector
+    if constexpr (FAST) { if (trip0 + (int)blockIdx.x < tend) ask(trip0 + (int)blockIdx.x); }
+#if TWX_FM_DEPHASE
+    // the two workgroups of a CU start half a trip apart (staging against the other's matrix-core loop)
+    if (blockIdx.x & 1) { for (int i = 0; i < TWX_FM_DEPHASE; ++i) __builtin_amdgcn_s_sleep(64); }
+#endif
+    for (int trip = trip0 + blockIdx.x; trip < tend; trip += gridDim.x) {
+        const long long m0 = (long long)trip * FM_OUT;
+        if (TWX_FM_ABL == 2 && trip != trip0 + (int)blockIdx.x) { asm volatile("" :: "v"(nx[0].x)); } else
+        if constexpr (FAST) {
+            int lt = tid, q = q_first, p = p_first;
+            asm volatile("" : "+v"(lt), "+v"(q), "+v"(p));  // the 32 slot addresses are computed per trip: hoisted out of the trip loop they hold 32 registers
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                if (u * FM_NT + lt < nvec) fm_put4(XI, XQ, nx[u], p, q, D, PS);
+                q += dq4; p += dp4;
+                if (p >= D) { p -= D; ++q; }
+                __builtin_amdgcn_sched_barrier(0);          // one vector's eight staged words at a time (interleaved, the four cost 46 registers)
+            }
+        } else fm_stage(XI, XQ, x, nch, nin, m0 * D, span, D, PS, tid);
+        __syncthreads();
+        if constexpr (FAST) {
+            const int nt = trip + (int)gridDim.x;
+            if (nt < tend) ask(nt);
+        }
+        fm_f4 aI0 = {0.f, 0.f, 0.f, 0.f}, aQ0 = aI0, aI1 = aI0, aQ1 = aI0;
+#pragma unroll
+        for (int j = 0; j < (TWX_FM_ABL == 1 ? 0 : NPW); ++j) {
+            // tile 1 = outputs 256..511: 256 samples = four padded groups further (fm_phys(q + 256) = fm_phys(q) + 272)
+            const fm_h8 bI0 = __builtin_bit_cast(fm_h8, *reinterpret_cast<const uint4*>(XI + off[j]));
+            const fm_h8 bQ0 = __builtin_bit_cast(fm_h8, *reinterpret_cast<const uint4*>(XQ + off[j]));
+            const fm_h8 bI1 = __builtin_bit_cast(fm_h8, *reinterpret_cast<const uint4*>(XI + off[j] + 272));
+            const fm_h8 bQ1 = __builtin_bit_cast(fm_h8, *reinterpret_cast<const uint4*>(XQ + off[j] + 272));
+            const fm_h8 a1 = __builtin_bit_cast(fm_h8, af[j][0]), a2 = __builtin_bit_cast(fm_h8, af[j][1]);
+            aI0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bI0, aI0, 0, 0, 0);
+            aQ0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bQ0, aQ0, 0, 0, 0);
+            aI1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bI1, aI1, 0, 0, 0);
+            aQ1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bQ1, aQ1, 0, 0, 0);
+            aI0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bI0, aI0, 0, 0, 0);
+            aQ0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bQ0, aQ0, 0, 0, 0);
+            aI1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bI1, aI1, 0, 0, 0);
+            aQ1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bQ1, aQ1, 0, 0, 0);
+            // one pair's fragments at a time: hoisting every pair's reads above the first MFMA costs 16 registers per pair, and the
+            // four waves of a SIMD cover each other's LDS latency
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                   // every fragment read is done: the span's memory takes the partial sums
+        if (TWX_FM_ABL == 3) { asm volatile("" :: "v"(aI0), "v"(aQ0), "v"(aI1), "v"(aQ1)); continue; }
+        {
+            // S[tile][wave][c * 4 + r][lane]: D[row 4 g + r][col n] of component c
+            // (planes of FM_SP = 68 floats: the finishing threads of a wave — four columns n, sixteen rows 4 g + r — read banks
+            // n + 16 g + 4 r, all different; with planes of 64 the four r met in one bank)
+            float* s0 = S + ((0 * 8 + w) * 8) * FM_SP + l;
+            float* s1 = S + ((1 * 8 + w) * 8) * FM_SP + l;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s0[r * FM_SP] = aI0[r]; s0[(4 + r) * FM_SP] = aQ0[r];
+                s1[r * FM_SP] = aI1[r]; s1[(4 + r) * FM_SP] = aQ1[r];
+            }
+        }
+        __syncthreads();
+        {
+            // thread tid finishes output m0 + tid: tile t, block n' = (tid >> 4) & 15, row i = tid & 15 = 4 g' + r
+            const int t = tid >> 8, nn = (tid >> 4) & 15, i = tid & 15, gg = i >> 2, r = i & 3, ll = nn + 16 * gg;
+            float sI = 0.f, sQ = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) {
+                sI += S[((t * 8 + ww) * 8 + r) * FM_SP + ll];
+                sQ += S[((t * 8 + ww) * 8 + 4 + r) * FM_SP + ll];
+            }
+            sI *= inv_scale; sQ *= inv_scale;
+            const long long m = m0 + tid;
+            if (m < nout) {
+                if (yf) yf[m] = make_float2(sI, sQ);
+                if (y16) {
+                    const float rI = fminf(fmaxf(rintf(sI), -32768.f), 32767.f), rQ = fminf(fmaxf(rintf(sQ), -32768.f), 32767.f);
+                    y16[m] = make_short2((short)rI, (short)rQ);
+                }
+            }
+        }
+        __syncthreads();                                   // the partial sums are read: the next trip stages over them
+    }
+}
+// which form runs: the matrix-core form where its geometry fits (NPW <= 8 pairs per wave: up to 64 (phase, step) pairs) and the call is
+// long enough to fill the chip; TWX_FIR_MFMA=0 / 1 forces the vector forms / the matrix-core form wherever its geometry fits (tests)
+bool fir_use_mfma(int ntaps, int dec, long long nout) {
+    static const int force = [] { const char* e = getenv("TWX_FIR_MFMA"); return e ? atoi(e) : -1; }();
+    if (force == 0) return false;
+    const FirMfmaGeom g = fir_mfma_geom(ntaps, dec);
+    if (!g.ok) return false;
+    if (force == 1) return true;
+    return ntaps >= 64 && nout >= 64 * 1024;
+}
+
 // phase-major tap table: hp[p][K-1 + a] = taps[a*D + p], zeros elsewhere
 std::vector<float> fir_phase_table(const float* taps, int ntaps, int dec, const FirGeom& g) {
     std::vector<float> hp((size_t)dec * g.HROW, 0.f);
     for (int j = 0; j < ntaps; ++j) hp[(size_t)(j % dec) * g.HROW + (g.K - 1) + j / dec] = taps[j];
     return hp;
 }
+// the table a call uploads: the matrix-core form's A fragments or the vector forms' phase-major taps (FirTable::mfma says which)
+struct FirTable { std::vector<float> words; bool mfma = false; float inv_scale = 1.f; };
+FirTable fir_table(const float* taps, int ntaps, int dec, long long nout) {
+    FirTable t;
+    t.mfma = fir_use_mfma(ntaps, dec, nout);
+    if (t.mfma) t.words = fir_mfma_table(taps, ntaps, dec, fir_mfma_geom(ntaps, dec), &t.inv_scale);
+    else t.words = fir_phase_table(taps, ntaps, dec, fir_geom(ntaps, dec));
+    return t;
+}
+int launch_fir_mfma(hipStream_t st, const short2* dx, int nch, long long nin, const float* tab_dev, int ntaps, int dec, float inv_scale, long long nout,
+                    short2* dy16, float2* dyf, int ch) {
+    const FirMfmaGeom g = fir_mfma_geom(ntaps, dec);
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    const unsigned long long dev_bit = 1ull << (cur_dev & 63);
+    static std::atomic<int> ncu_of[64];
+    int ncu = ncu_of[cur_dev & 63].load();
+    if (ncu <= 0) {
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cur_dev) != hipSuccess || ncu <= 0) ncu = 256;
+        ncu_of[cur_dev & 63].store(ncu);
+    }
+    const long long ntrips = (nout + FM_OUT - 1) / FM_OUT;
+    const uint4* atab = reinterpret_cast<const uint4*>(tab_dev);
+    // trips whose whole span lies inside a one-channel, 16-byte aligned capture go to the FAST form; the rest (the last one or two, or
+    // all of another kind of capture) to the general one
+    const long long span = (long long)g.NQ * dec;
+    long long nfast = 0;
+    if (nch == 1 && (reinterpret_cast<unsigned long long>(dx) & 15ull) == 0 && nin >= span) nfast = std::min<long long>(ntrips, (nin - span) / ((long long)FM_OUT * dec) + 1);
+    hipError_t attr = hipSuccess;
+#define FM_GO1(NPW_, FAST_, T0_, NT_) do { static std::atomic<unsigned long long> set{0}; auto* fn = &k_fir_mfma<NPW_, FAST_>; \
+        if (!(set.load() & dev_bit)) { attr = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr == hipSuccess) set.fetch_or(dev_bit); } \
+        if ((set.load() & dev_bit) && (NT_) > 0) hipLaunchKernelGGL(fn, dim3((unsigned)std::min<long long>((NT_), 2ll * ncu)), dim3(FM_NT), g.lds, st, dx, nch, nin, atab, dec, g.KS, g.PS, \
+                                                                   inv_scale, nout, (int)(T0_), (int)(NT_), dy16, dyf); } while (0)
+#define FM_GO(NPW_) do { FM_GO1(NPW_, true, 0, nfast); FM_GO1(NPW_, false, nfast, ntrips - nfast); } while (0)
+    switch (g.NPW) {
+        case 1: FM_GO(1); break; case 2: FM_GO(2); break; case 3: FM_GO(3); break; case 4: FM_GO(4); break;
+        case 5: FM_GO(5); break; case 6: FM_GO(6); break;
+        default: return TWX_E_STATE;
+    }
+#undef FM_GO1
+#undef FM_GO
+    if (attr != hipSuccess) return TWX_E_HIP;
+    return hipGetLastError() == hipSuccess ? TWX_OK : TWX_E_HIP;
+}
 int launch_fir(hipStream_t st, const short2* dx, int nch, long long nin, const float* hp_dev, int ntaps, int dec, long long nout,
-               short2* dy16, float2* dyf, int ch = 0) {            // dx: the channel's sample of frame 0; ch: its place in the frame
+               short2* dy16, float2* dyf, int ch = 0, bool mfma = false, float inv_scale = 1.f) {            // dx: the channel's sample of frame 0; ch: its place in the frame
+    if (mfma) return launch_fir_mfma(st, dx, nch, nin, hp_dev, ntaps, dec, inv_scale, nout, dy16, dyf, ch);
     const FirGeom g = fir_geom(ntaps, dec);
     // The dynamic-LDS limit is an attribute of the function ON A DEVICE: one bit per device (contexts on several devices and host
     // threads — twx_multi — may get here together; the attribute call is idempotent)
@@ -980,8 +1290,8 @@ static int twx_fir_decimate_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n
     if (int rc = twx::ctx_set_device(ctx)) return rc;
     const long long nout = (n_in - ntaps) / dec + 1;
     *n_out = nout;
-    const FirGeom g = fir_geom(ntaps, dec);
-    const std::vector<float> hp = fir_phase_table(taps, ntaps, dec, g);
+    const FirTable ft = fir_table(taps, ntaps, dec, nout);
+    const std::vector<float>& hp = ft.words;
     // the table lives in a context-owned buffer; the copy is ordered on the context's stream like the kernel
     float* hp_dev = static_cast<float*>(twx::ctx_scratch(ctx, 1, hp.size() * sizeof(float)));
     if (!hp_dev) return TWX_E_NOMEM;
@@ -995,7 +1305,7 @@ static int twx_fir_decimate_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n
         shadow.assign(reinterpret_cast<const unsigned char*>(hp.data()), reinterpret_cast<const unsigned char*>(hp.data()) + hp_bytes);
     }
     const int rc = launch_fir(st, reinterpret_cast<const short2*>(iq_dev) + channel, n_channels, n_in, hp_dev, ntaps, dec, nout,
-                              reinterpret_cast<short2*>(out_i16_dev), reinterpret_cast<float2*>(out_f32_dev), channel);
+                              reinterpret_cast<short2*>(out_i16_dev), reinterpret_cast<float2*>(out_f32_dev), channel, ft.mfma, ft.inv_scale);
     return rc ? twx::ctx_fail(ctx, rc, "twx_fir_decimate_dev: launch failed") : TWX_OK;
 }
 
@@ -1019,15 +1329,15 @@ static int twx_fir_decimate_impl(const int16_t* iq, int64_t n_in, int32_t n_chan
     if (!fir_args_ok(iq, taps, n_out, out_i16, out_f32, n_channels, channel, ntaps, dec, n_in)) return TWX_E_ARG;
     const long long nout = (n_in - ntaps) / dec + 1;
     *n_out = nout;
-    const FirGeom g = fir_geom(ntaps, dec);
-    const std::vector<float> hp = fir_phase_table(taps, ntaps, dec, g);
+    const FirTable ft = fir_table(taps, ntaps, dec, nout);
+    const std::vector<float>& hp = ft.words;
     DevBuf dx, dh, dy16, dyf;
     if (!dx.alloc((size_t)n_in * n_channels * 4) || !dh.alloc(hp.size() * 4) || (out_i16 && !dy16.alloc((size_t)nout * 4)) ||
         (out_f32 && !dyf.alloc((size_t)nout * 8))) return TWX_E_NOMEM;
     if (hipMemcpy(dx.p, iq, (size_t)n_in * n_channels * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(dh.p, hp.data(), hp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return TWX_E_HIP;
     if (int rc = launch_fir(nullptr, static_cast<const short2*>(dx.p) + channel, n_channels, n_in, static_cast<const float*>(dh.p), ntaps, dec, nout,
-                            static_cast<short2*>(dy16.p), static_cast<float2*>(dyf.p), channel)) return rc;
+                            static_cast<short2*>(dy16.p), static_cast<float2*>(dyf.p), channel, ft.mfma, ft.inv_scale)) return rc;
     if (out_i16 && hipMemcpy(out_i16, dy16.p, (size_t)nout * 4, hipMemcpyDeviceToHost) != hipSuccess) return TWX_E_HIP;
     if (out_f32 && hipMemcpy(out_f32, dyf.p, (size_t)nout * 8, hipMemcpyDeviceToHost) != hipSuccess) return TWX_E_HIP;
     return TWX_OK;
