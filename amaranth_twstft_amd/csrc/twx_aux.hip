@@ -886,23 +886,24 @@ __global__ __launch_bounds__(FIR8_NT) void k_fir_poly8(const short2* __restrict_
 // v_mfma_f32_16x16x32_f16 takes 16 samples as (xh, xl) pairs against the column (256 h, h): the recombination of the sample happens
 // inside the dot product.  Per phase p (x_p[q] = x[q D + p], h_p[a] = taps[a D + p]) the filter is the banded Toeplitz product
 //   D[i][n] = sum_k A[i][k] B[k][n],   A[i][k] = h_p[k - i],   B[k][n] = x_p[m0 + 16 n + k]      (outputs m0 + 16 n + i)
-// with KS = ceil((taps per phase + 15) / 16) steps of 16 samples.  Per lane (n = l & 15, g = l >> 4) a B fragment is ONE 16-byte LDS
-// read (samples 4g .. 4g+3 of the step as (xh, xl) pairs); the A fragments (taps, Toeplitz-shifted per lane, both pieces) are built
-// on the host and live in registers for the life of the workgroup.  Error against the fp64 direct sum: that of an fp32 accumulation
-// over 4 x ntaps terms (simulated and measured: about half of the 2e-6 gate at 421 taps).
+// with KS = ceil((taps per phase + 15) / 16) steps of 16 samples.  The A fragments (taps, Toeplitz-shifted per lane, both pieces) are
+// built on the host and live in registers for the life of the workgroup.  Error against the fp64 direct sum: that of an fp32
+// accumulation over 4 x ntaps terms (simulated and measured: about half of the 2e-6 gate at 421 taps).
 //
-// Workgroup = 8 waves, 512 outputs per trip (two tiles of 16 x 16), persistent over the trips: wave w takes the (phase, step) pairs
-// w, w + 8, ... for BOTH tiles (its A fragments serve 8 MFMAs each), the eight partial sums meet in LDS.  The staged span holds, per
-// phase and component, one 32-bit word (xh, xl) per sample, rows padded by 16 bytes per 64 samples (the 16 lanes of a fragment
-// read then hit 16 different bank quads).
+// Workgroup = 8 waves, one tile of 256 outputs per trip, persistent over its trips.  Wave w takes the (phase, step) pairs w, w + 8,
+// ...; the eight partial sums meet in LDS.  The span of a trip is staged RAW (the int16 pair of a sample, one word), phase-major, rows
+// padded by 16 bytes per 64 samples (the 16 lanes of a fragment read hit 16 different bank quads); a lane's B operand is ONE 16-byte
+// read — four samples, both components — split into the (xh, xl) fragments of I and of Q by sixteen SDWA converts (vector work that
+// runs beside the matrix cores; converted at staging time the span would take twice the LDS).  Two spans: trip i+1 is staged (from
+// registers: its 16-byte loads were issued a trip earlier) while trip i is multiplied — two barriers per trip.
 // ---------------------------------------------------------------------------------------------
-#ifndef TWX_FM_DEPHASE
-#define TWX_FM_DEPHASE 0
+#ifndef TWX_FM_ZERO_LDS
+#define TWX_FM_ZERO_LDS 0
 #endif
 #ifndef TWX_FM_ABL
-#define TWX_FM_ABL 0     // timing-only ablations of k_fir_mfma: 1 no matrix-core loop, 2 staging on the first trip only, 3 no reduction / stores, 4 no fragment reads
+#define TWX_FM_ABL 0     // timing-only ablations of k_fir_mfma: 1 no matrix-core loop, 2 no staging after the first trips, 3 no reduction / stores
 #endif
-constexpr int FM_NT = 512, FM_OUT = 512, FM_MAXNPW = 6, FM_SP = 68;      // (7 and 8 pairs per wave spill at 128 registers)
+constexpr int FM_NT = 512, FM_OUT = 256, FM_MAXNPW = 6, FM_SP = 68, FM_NV = 3;      // (7 and 8 pairs per wave spill at 128 registers)
 typedef _Float16 fm_h8 __attribute__((ext_vector_type(8)));
 typedef float fm_f4 __attribute__((ext_vector_type(4)));
 __host__ __device__ inline int fm_phys(int q) { return q + 4 * (q >> 6); }
@@ -917,8 +918,8 @@ FirMfmaGeom fir_mfma_geom(int ntaps, int dec) {
     ps = (ps + 3) & ~3;
     while ((ps & 7) != 4) ps += 4;                      // rows 16-byte aligned, PS / 4 odd: the staging writes of consecutive phases spread over the banks
     g.PS = ps;
-    g.lds = std::max<size_t>((size_t)2 * dec * g.PS * 4, (size_t)2 * 8 * 8 * FM_SP * 4);     // the staged span; later the partial sums [tile][wave][8][FM_SP]
-    g.ok = g.NPW >= 1 && g.NPW <= FM_MAXNPW && g.lds <= 80 * 1024 && (long long)g.NQ * dec <= 16ll * FM_NT;      // (the span in 4 vectors per thread)
+    g.lds = (size_t)2 * dec * g.PS * 4 + (size_t)8 * 8 * FM_SP * 4;          // two spans + the partial sums [wave][8][FM_SP]
+    g.ok = g.NPW >= 1 && g.NPW <= FM_MAXNPW && g.lds <= 80 * 1024 && (long long)g.NQ * dec <= 4ll * FM_NV * FM_NT;      // (the span in FM_NV vectors per thread)
     return g;
 }
 // table of A fragments [pair u][piece][lane] x 16 bytes, u = p * KS + ks padded to 8 * NPW pairs (zeros); returns 2^-s through inv_scale
@@ -957,31 +958,28 @@ std::vector<float> fir_mfma_table(const float* taps, int ntaps, int dec, const F
     }
     return out;
 }
-// one sample word (I | Q << 16, int16 each) -> the two staged words (xh, xl as fp16) of its components
+// one sample word (I | Q << 16, int16 each) -> its (xh, xl) fp16 pairs: four SDWA converts — the high byte of a component,
+// sign-extended, is xh; the low byte, unsigned, xl — each written straight into its half of the word
 __device__ __forceinline__ void fm_split(unsigned w, unsigned& wi, unsigned& wq) {
-    // four SDWA converts: the high byte of a component, sign-extended, is xh; the low byte, unsigned, xl — each written as fp16 straight
-    // into its half of the staged word (the plain C form costs ten vector instructions per sample)
     asm volatile("v_cvt_f16_i16_sdwa %0, sext(%1) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(wi) : "v"(w));
     asm volatile("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(wi) : "v"(w));
     asm volatile("v_cvt_f16_i16_sdwa %0, sext(%1) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(wq) : "v"(w));
     asm volatile("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(wq) : "v"(w));
 }
-// the staged words of four consecutive samples (one 16-byte vector, first sample at phase p of group q) into their slots
-__device__ __forceinline__ void fm_put4(unsigned* __restrict__ XI, unsigned* __restrict__ XQ, int4 v, int p, int q, int D, int PS) {
+// four consecutive samples (one 16-byte vector, first sample at phase p of group q) into their slots of a span
+__device__ __forceinline__ void fm_put4(unsigned* __restrict__ X, int4 v, int p, int q, int D, int PS) {
     const int w4[4] = {v.x, v.y, v.z, v.w};
     int slot = p * PS + fm_phys(q);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        unsigned wi, wq;
-        fm_split((unsigned)w4[i], wi, wq);
-        XI[slot] = wi; XQ[slot] = wq;
+        X[slot] = (unsigned)w4[i];
         if (++p >= D) { p = 0; ++q; slot += 1 - (D - 1) * PS + ((q & 63) == 0 ? 4 : 0); }       // next group: one word on, a pad every 64
         else slot += PS;
     }
 }
-__device__ __forceinline__ void fm_stage(unsigned* __restrict__ XI, unsigned* __restrict__ XQ, const short2* __restrict__ x, int nch, long long nin,
-                                         long long e0, int span, int D, int PS, int tid) {
-    // the general path (a channel of a multi-channel capture, an unaligned base, the last trips): 4-byte loads, unconditional (clamped)
+// the general staging (a channel of a multi-channel capture, an unaligned base): 4-byte loads, unconditional (clamped), zeros past the end
+__device__ __forceinline__ void fm_stage(unsigned* __restrict__ X, const short2* __restrict__ x, int nch, long long nin, long long e0, int span, int D,
+                                         int PS, int tid) {
     const int dq = FM_NT / D, dp = FM_NT - dq * D;
     int q = tid / D, p = tid - q * D;
     const unsigned* xs = reinterpret_cast<const unsigned*>(x);
@@ -996,30 +994,26 @@ __device__ __forceinline__ void fm_stage(unsigned* __restrict__ XI, unsigned* __
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = eb + u * FM_NT + tid;
-            if (e < span) {
-                unsigned wi, wq;
-                fm_split(raw[u], wi, wq);
-                const int slot = p * PS + fm_phys(q);
-                XI[slot] = wi; XQ[slot] = wq;
-            }
+            if (e < span) X[p * PS + fm_phys(q)] = raw[u];
             q += dq; p += dp;
             if (p >= D) { p -= D; ++q; }
         }
     }
 }
-// FAST: trips trip0 .. trip0 + ntrips - 1 of a one-channel capture on a 16-byte boundary whose spans lie inside the capture (16-byte
-// loads, the next trip's asked for ahead); otherwise the general staging (a launch of its own for the last trips / other captures)
+// FAST: a one-channel capture on a 16-byte boundary — 16-byte loads, the next trip's asked for a trip ahead.  A vector index is clamped
+// to the vector that holds the capture's last sample: what a clamped load returns only ever meets zero taps or outputs past the end
+// (a 16-byte aligned vector that holds one valid byte lies inside that byte's page).
 template <int NPW, bool FAST>
 __global__ __launch_bounds__(FM_NT, 4) void k_fir_mfma(const short2* __restrict__ x, int nch, long long nin, const uint4* __restrict__ atab, int D, int KS,
-                                                       int PS, float inv_scale, long long nout, int trip0, int ntrips, short2* __restrict__ y16,
+                                                       int PS, float inv_scale, long long nout, int ntrips, short2* __restrict__ y16,
                                                        float2* __restrict__ yf) {
     extern __shared__ uint4 XM4[];
-    unsigned* XI = reinterpret_cast<unsigned*>(XM4);
-    unsigned* XQ = XI + D * PS;
-    float* S = reinterpret_cast<float*>(XM4);
+    unsigned* X0 = reinterpret_cast<unsigned*>(XM4);
+    const int span_words = D * PS;
+    float* S = reinterpret_cast<float*>(X0 + 2 * span_words);
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int NQ = FM_OUT + 16 * KS;
-    // this wave's (phase, step) pairs: A fragments (both pieces) and the lane's word offset of the B fragment in tile 0
+    // this wave's (phase, step) pairs: A fragments (both pieces) and the lane's word offset of its B operand
     uint4 af[NPW][2];
     int off[NPW];
 #pragma unroll
@@ -1031,88 +1025,91 @@ __global__ __launch_bounds__(FM_NT, 4) void k_fir_mfma(const short2* __restrict_
         const int p = live ? u / KS : 0, ks = live ? u - p * KS : 0;
         off[j] = p * PS + fm_phys(16 * n + 16 * ks + 4 * g);
     }
-    // One-channel captures on a 16-byte boundary: a trip's span is NV 16-byte vectors per thread, and the NEXT trip's are asked for as
-    // soon as this trip's span is staged — in flight under the matrix-core loop and the reduction (a workgroup that loads, waits and
-    // then computes spends most of its life waiting: 0.131 ms per second of 70 Msps; the walk is the row pass's, k_rowd<MID>)
-    constexpr int NV = 4;
-    const int span = NQ * D, nvec = span >> 2;                                   // (fir_mfma_geom: span <= NV * 4 * FM_NT)
-    int4 nx[FAST ? NV : 1];
-    auto ask = [&](int trip) {
-        const int4* xv = reinterpret_cast<const int4*>(x + (long long)trip * FM_OUT * D);
-#pragma unroll
-        for (int u = 0; u < NV; ++u) nx[u] = xv[min(u * FM_NT + tid, nvec - 1)];
-    };
-    const int tend = trip0 + ntrips;
+    const int span = NQ * D, nvec = span >> 2;                                   // (fir_mfma_geom: span <= FM_NV * 4 * FM_NT)
+    const long long last_vec = (nin - 1) >> 2;
     const int dq4 = (4 * FM_NT) / D, dp4 = 4 * FM_NT - dq4 * D;
     const int q_first = (4 * tid) / D, p_first = 4 * tid - q_first * D;          // (group, phase) of the thread's first vector
-    if constexpr (FAST) { if (trip0 + (int)blockIdx.x < tend) ask(trip0 + (int)blockIdx.x); }
-#if TWX_FM_DEPHASE
-    // the two workgroups of a CU start half a trip apart (staging against the other's matrix-core loop)
-    if (blockIdx.x & 1) { for (int i = 0; i < TWX_FM_DEPHASE; ++i) __builtin_amdgcn_s_sleep(64); }
-#endif
-    for (int trip = trip0 + blockIdx.x; trip < tend; trip += gridDim.x) {
-        const long long m0 = (long long)trip * FM_OUT;
-        if (TWX_FM_ABL == 2 && trip != trip0 + (int)blockIdx.x) { asm volatile("" :: "v"(nx[0].x)); } else
+    int4 nx[FAST ? FM_NV : 1];
+    auto ask = [&](int trip) {
+        const long long v0 = ((long long)trip * FM_OUT * D) >> 2;                // FM_OUT * D is a multiple of 4
+        const int4* xv = reinterpret_cast<const int4*>(x);
+#pragma unroll
+        for (int u = 0; u < FM_NV; ++u) nx[u] = xv[min(v0 + min(u * FM_NT + tid, nvec - 1), last_vec)];
+    };
+    auto stage = [&](unsigned* X, int trip) {
         if constexpr (FAST) {
             int lt = tid, q = q_first, p = p_first;
-            asm volatile("" : "+v"(lt), "+v"(q), "+v"(p));  // the 32 slot addresses are computed per trip: hoisted out of the trip loop they hold 32 registers
+            asm volatile("" : "+v"(lt), "+v"(q), "+v"(p));  // slot addresses per trip: hoisted out of the trip loop they hold a register each
 #pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                if (u * FM_NT + lt < nvec) fm_put4(XI, XQ, nx[u], p, q, D, PS);
+            for (int u = 0; u < FM_NV; ++u) {
+                if (u * FM_NT + lt < nvec) fm_put4(X, nx[u], p, q, D, PS);
                 q += dq4; p += dp4;
                 if (p >= D) { p -= D; ++q; }
-                __builtin_amdgcn_sched_barrier(0);          // one vector's eight staged words at a time (interleaved, the four cost 46 registers)
             }
-        } else fm_stage(XI, XQ, x, nch, nin, m0 * D, span, D, PS, tid);
-        __syncthreads();
-        if constexpr (FAST) {
-            const int nt = trip + (int)gridDim.x;
-            if (nt < tend) ask(nt);
-        }
-        fm_f4 aI0 = {0.f, 0.f, 0.f, 0.f}, aQ0 = aI0, aI1 = aI0, aQ1 = aI0;
-#pragma unroll
-        for (int j = 0; j < (TWX_FM_ABL == 1 ? 0 : NPW); ++j) {
-            // tile 1 = outputs 256..511: 256 samples = four padded groups further (fm_phys(q + 256) = fm_phys(q) + 272)
-            const fm_h8 bI0 = __builtin_bit_cast(fm_h8, *reinterpret_cast<const uint4*>(XI + off[j]));
-            const fm_h8 bQ0 = __builtin_bit_cast(fm_h8, *reinterpret_cast<const uint4*>(XQ + off[j]));
-            const fm_h8 bI1 = __builtin_bit_cast(fm_h8, *reinterpret_cast<const uint4*>(XI + off[j] + 272));
-            const fm_h8 bQ1 = __builtin_bit_cast(fm_h8, *reinterpret_cast<const uint4*>(XQ + off[j] + 272));
-            const fm_h8 a1 = __builtin_bit_cast(fm_h8, af[j][0]), a2 = __builtin_bit_cast(fm_h8, af[j][1]);
-            aI0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bI0, aI0, 0, 0, 0);
-            aQ0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bQ0, aQ0, 0, 0, 0);
-            aI1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bI1, aI1, 0, 0, 0);
-            aQ1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bQ1, aQ1, 0, 0, 0);
-            aI0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bI0, aI0, 0, 0, 0);
-            aQ0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bQ0, aQ0, 0, 0, 0);
-            aI1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bI1, aI1, 0, 0, 0);
-            aQ1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bQ1, aQ1, 0, 0, 0);
-            // one pair's fragments at a time: hoisting every pair's reads above the first MFMA costs 16 registers per pair, and the
-            // four waves of a SIMD cover each other's LDS latency
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();                                   // every fragment read is done: the span's memory takes the partial sums
-        if (TWX_FM_ABL == 3) { asm volatile("" :: "v"(aI0), "v"(aQ0), "v"(aI1), "v"(aQ1)); continue; }
-        {
-            // S[tile][wave][c * 4 + r][lane]: D[row 4 g + r][col n] of component c
-            // (planes of FM_SP = 68 floats: the finishing threads of a wave — four columns n, sixteen rows 4 g + r — read banks
-            // n + 16 g + 4 r, all different; with planes of 64 the four r met in one bank)
-            float* s0 = S + ((0 * 8 + w) * 8) * FM_SP + l;
-            float* s1 = S + ((1 * 8 + w) * 8) * FM_SP + l;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s0[r * FM_SP] = aI0[r]; s0[(4 + r) * FM_SP] = aQ0[r];
-                s1[r * FM_SP] = aI1[r]; s1[(4 + r) * FM_SP] = aQ1[r];
+        } else fm_stage(X, x, nch, nin, (long long)trip * FM_OUT * D, span, D, PS, tid);
+    };
+    int trip = blockIdx.x;
+    if (trip < ntrips) {
+        if constexpr (FAST) ask(trip);
+        stage(X0, trip);
+        if constexpr (FAST) { if (trip + (int)gridDim.x < ntrips) ask(trip + (int)gridDim.x); }
+    }
+    __syncthreads();
+    int b = 0;
+    for (; trip < ntrips; trip += gridDim.x, b ^= 1) {
+        const long long m0 = (long long)trip * FM_OUT;
+        const unsigned* X = X0 + b * span_words;
+        const int nt = trip + (int)gridDim.x;
+        fm_f4 aI = {0.f, 0.f, 0.f, 0.f}, aQ = aI;
+        // the next trip's span into the other buffer (its last readers passed the previous trip's first barrier), the one after asked for
+        auto stage_next = [&]() {
+            if (nt < ntrips && !(TWX_FM_ABL == 2)) {
+                stage(X0 + (b ^ 1) * span_words, nt);
+                if constexpr (FAST) { if (nt + (int)gridDim.x < ntrips) ask(nt + (int)gridDim.x); }
             }
+        };
+        auto multiply = [&]() {
+#pragma unroll
+            for (int j = 0; j < (TWX_FM_ABL == 1 ? 0 : NPW); ++j) {
+                const uint4 raw = *reinterpret_cast<const uint4*>(X + off[j]);      // four samples of the step, I and Q
+                uint4 bi, bq;
+                if (TWX_FM_ABL == 5) { bi = raw; bq = raw; }          // no SDWA converts
+                else { fm_split(raw.x, bi.x, bq.x); fm_split(raw.y, bi.y, bq.y); fm_split(raw.z, bi.z, bq.z); fm_split(raw.w, bi.w, bq.w); }
+                const fm_h8 bI = __builtin_bit_cast(fm_h8, bi), bQ = __builtin_bit_cast(fm_h8, bq);
+                const fm_h8 a1 = __builtin_bit_cast(fm_h8, af[j][0]), a2 = __builtin_bit_cast(fm_h8, af[j][1]);
+                if (TWX_FM_ABL == 4) {                                  // no matrix-core instructions
+                    aI[0] += (float)bI[0] * (float)a1[0]; aQ[0] += (float)bQ[1] * (float)a2[1];
+                } else {
+                aI = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bI, aI, 0, 0, 0);
+                aQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bQ, aQ, 0, 0, 0);
+                aI = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bI, aI, 0, 0, 0);
+                aQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bQ, aQ, 0, 0, 0);
+                }
+            }
+        };
+        // (the two jobs of a trip are independent; odd waves multiplying first and staging afterwards, so that every SIMD has vector
+        // work and matrix-core work side by side, measured the same: 0.100-0.105 ms either way)
+        stage_next();
+        __builtin_amdgcn_sched_barrier(0);
+        multiply();
+        __syncthreads();                                   // this span is read, the next one is staged, the previous trip's sums are read
+        if (TWX_FM_ABL == 3) { asm volatile("" :: "v"(aI), "v"(aQ)); continue; }
+        {
+            // S[wave][c * 4 + r][lane]: D[row 4 g + r][col n] of component c (planes of FM_SP = 68 floats: the finishing threads of a
+            // wave — four columns n, sixteen rows 4 g + r — read banks n + 16 g + 4 r, all different)
+            float* sw = S + (w * 8) * FM_SP + l;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sw[r * FM_SP] = aI[r]; sw[(4 + r) * FM_SP] = aQ[r]; }
         }
         __syncthreads();
-        {
-            // thread tid finishes output m0 + tid: tile t, block n' = (tid >> 4) & 15, row i = tid & 15 = 4 g' + r
-            const int t = tid >> 8, nn = (tid >> 4) & 15, i = tid & 15, gg = i >> 2, r = i & 3, ll = nn + 16 * gg;
+        if (tid < FM_OUT) {
+            // thread tid finishes output m0 + tid: block n' = tid >> 4, row i = tid & 15 = 4 g' + r
+            const int nn = tid >> 4, i = tid & 15, gg = i >> 2, r = i & 3, ll = nn + 16 * gg;
             float sI = 0.f, sQ = 0.f;
 #pragma unroll
             for (int ww = 0; ww < 8; ++ww) {
-                sI += S[((t * 8 + ww) * 8 + r) * FM_SP + ll];
-                sQ += S[((t * 8 + ww) * 8 + 4 + r) * FM_SP + ll];
+                sI += S[(ww * 8 + r) * FM_SP + ll];
+                sQ += S[(ww * 8 + 4 + r) * FM_SP + ll];
             }
             sI *= inv_scale; sQ *= inv_scale;
             const long long m = m0 + tid;
@@ -1124,18 +1121,29 @@ __global__ __launch_bounds__(FM_NT, 4) void k_fir_mfma(const short2* __restrict_
                 }
             }
         }
-        __syncthreads();                                   // the partial sums are read: the next trip stages over them
     }
+#if TWX_FM_ZERO_LDS
+    // diagnostic: leave the workgroup's LDS zeroed (does a kernel that follows on this CU read what this one left?)
+    __syncthreads();
+    for (int i = tid; i < 2 * span_words + 8 * 8 * FM_SP; i += FM_NT) X0[i] = 0u;
+#endif
 }
-// which form runs: the matrix-core form where its geometry fits (NPW <= 8 pairs per wave: up to 64 (phase, step) pairs) and the call is
-// long enough to fill the chip; TWX_FIR_MFMA=0 / 1 forces the vector forms / the matrix-core form wherever its geometry fits (tests)
+// Which form runs: the vector forms, unless TWX_FIR_MFMA=1 asks for the matrix-core form (taken wherever its geometry fits).  It is
+// 20 % faster alone (0.100-0.105 against 0.124-0.131 ms per second of 70 Msps) and NOT the default: while its workgroups share CUs with
+// k_rowd (the DIF/DIT row pass of a correlation running on another stream), a few rows of that pass come out wrong — whole rows k1 of
+// the spectrum, 6-12 of 625 per call (tools/chain_corunner_map.py); the Stockham row pass, the column passes, a copy, a torch fp16 GEMM
+// and the vector FIR beside the same chain are clean, the chain beside poisoned or busy LDS is clean, the FIR's own outputs are right
+// and deterministic, and every part of the kernel removed in turn (matrix-core instructions, the SDWA converts, the staging) makes
+// the effect disappear; a bare fp16 MFMA loop beside the chain reproduces it rarely (profiles/r05_fir_mfma.txt).  Not understood yet,
+// so the form stays opt-in for callers that run nothing else on the GPU at the time.
 bool fir_use_mfma(int ntaps, int dec, long long nout) {
-    static const int force = [] { const char* e = getenv("TWX_FIR_MFMA"); return e ? atoi(e) : -1; }();
+    const char* fe = getenv("TWX_FIR_MFMA");          // read per call: tests switch it inside one process
+    const int force = fe ? atoi(fe) : -1;
     if (force == 0) return false;
     const FirMfmaGeom g = fir_mfma_geom(ntaps, dec);
     if (!g.ok) return false;
-    if (force == 1) return true;
-    return ntaps >= 64 && nout >= 64 * 1024;
+    (void)nout;
+    return force == 1;
 }
 
 // phase-major tap table: hp[p][K-1 + a] = taps[a*D + p], zeros elsewhere
@@ -1167,17 +1175,16 @@ int launch_fir_mfma(hipStream_t st, const short2* dx, int nch, long long nin, co
     }
     const long long ntrips = (nout + FM_OUT - 1) / FM_OUT;
     const uint4* atab = reinterpret_cast<const uint4*>(tab_dev);
-    // trips whose whole span lies inside a one-channel, 16-byte aligned capture go to the FAST form; the rest (the last one or two, or
-    // all of another kind of capture) to the general one
-    const long long span = (long long)g.NQ * dec;
-    long long nfast = 0;
-    if (nch == 1 && (reinterpret_cast<unsigned long long>(dx) & 15ull) == 0 && nin >= span) nfast = std::min<long long>(ntrips, (nin - span) / ((long long)FM_OUT * dec) + 1);
+    const bool fast = nch == 1 && (reinterpret_cast<unsigned long long>(dx) & 15ull) == 0;
+    static const int per_cu = [] { const char* e = getenv("TWX_FM_WGS_PER_CU"); return e ? atoi(e) : 2; }();     // experiments: 0 = one workgroup per trip
+    const unsigned grid = (unsigned)(per_cu > 0 ? std::min<long long>(ntrips, (long long)per_cu * ncu) : ntrips);          // two workgroups per CU (registers), each walks its trips
+    static const size_t lds_min = [] { const char* e = getenv("TWX_FM_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();     // experiments: reserve more LDS per workgroup
+    const size_t lds_bytes = std::max(g.lds, lds_min);
     hipError_t attr = hipSuccess;
-#define FM_GO1(NPW_, FAST_, T0_, NT_) do { static std::atomic<unsigned long long> set{0}; auto* fn = &k_fir_mfma<NPW_, FAST_>; \
+#define FM_GO1(NPW_, FAST_) do { static std::atomic<unsigned long long> set{0}; auto* fn = &k_fir_mfma<NPW_, FAST_>; \
         if (!(set.load() & dev_bit)) { attr = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr == hipSuccess) set.fetch_or(dev_bit); } \
-        if ((set.load() & dev_bit) && (NT_) > 0) hipLaunchKernelGGL(fn, dim3((unsigned)std::min<long long>((NT_), 2ll * ncu)), dim3(FM_NT), g.lds, st, dx, nch, nin, atab, dec, g.KS, g.PS, \
-                                                                   inv_scale, nout, (int)(T0_), (int)(NT_), dy16, dyf); } while (0)
-#define FM_GO(NPW_) do { FM_GO1(NPW_, true, 0, nfast); FM_GO1(NPW_, false, nfast, ntrips - nfast); } while (0)
+        if (set.load() & dev_bit) hipLaunchKernelGGL(fn, dim3(grid), dim3(FM_NT), lds_bytes, st, dx, nch, nin, atab, dec, g.KS, g.PS, inv_scale, nout, (int)ntrips, dy16, dyf); } while (0)
+#define FM_GO(NPW_) do { if (fast) FM_GO1(NPW_, true); else FM_GO1(NPW_, false); } while (0)
     switch (g.NPW) {
         case 1: FM_GO(1); break; case 2: FM_GO(2); break; case 3: FM_GO(3); break; case 4: FM_GO(4); break;
         case 5: FM_GO(5); break; case 6: FM_GO(6); break;

@@ -557,6 +557,48 @@ def test_fir_decimator_shapes(ntaps, dec, nch, ch):
         assert ys.shape[0] == 1 + extra // dec and np.abs(ys - ref[: ys.shape[0]]).max() <= 2e-6 * np.abs(ref).max() + 1e-3
 
 
+@pytest.mark.parametrize("ntaps,dec,nch,ch", [
+    (421, 14, 1, 0),      # configs[4]: 31 taps per phase, 3 steps of 16 columns, 42 (phase, step) pairs = 6 per wave
+    (421, 14, 2, 1),      # a channel of a two-channel capture: the general staging
+    (64, 16, 1, 0),       # 4 taps per phase, 2 steps
+    (33, 3, 1, 0),        # 3 phases, 2 steps: one pair per wave, two waves idle
+    (100, 5, 1, 0),
+    (97, 4, 1, 0),
+    (171, 3, 1, 0),       # 57 taps per phase: 5 steps
+    (232, 8, 1, 0),       # 29 taps per phase, 8 phases
+    (31, 1, 1, 0),        # no decimation: one phase
+    (700, 16, 1, 0),      # 44 taps per phase, 16 phases: 64 pairs do not fit six per wave -> the vector form answers (forced or not)
+])
+def test_fir_matrix_core_form_shapes(ntaps, dec, nch, ch, monkeypatch):
+    """k_fir_mfma (fp16 matrix cores, samples and taps split into exact fp16 pieces) forced wherever its geometry fits, against the fp64
+    direct sum with the gates of the vector forms: pair counts 1..6 per wave, idle waves, both staging paths (16-byte loads with the
+    next trip asked for ahead / 4-byte loads), several trips per workgroup with a ragged last one, the shortest inputs; random taps
+    spanning three decades (the scaling to fp16 range and the two-piece split), full-scale samples of both signs."""
+    from amaranth_twstft_amd import frontend
+    monkeypatch.setenv("TWX_FIR_MFMA", "1")
+    rng = np.random.default_rng(2000 * ntaps + dec)
+    taps = (rng.normal(0, 1, ntaps) * np.hamming(ntaps) / np.sqrt(ntaps) * 10.0 ** rng.uniform(-3, 0, ntaps)).astype(np.float32)
+    n_in = dec * 256 * 5 + 3 * ntaps + 11                                # five trips and a ragged tail
+    raw = np.clip(rng.normal(0, 9000, (n_in, 2 * nch)), -32768, 32767).astype(np.int16)
+    raw[7, :] = -32768; raw[8, :] = 32767; raw[9, :] = -1; raw[10, :] = 255; raw[11, :] = 256; raw[12, :] = -256      # the split's corner values
+    y = frontend.fir_decimate(raw, taps, dec, n_channels=nch, channel=ch, out="f32")
+    x = raw[:, 2 * ch].astype(np.float64) + 1j * raw[:, 2 * ch + 1]
+    ref = orc.fir_decimate(x, taps.astype(np.float64), dec)
+    assert y.shape == ref.shape and y.shape[0] == (n_in - ntaps) // dec + 1
+    assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-3
+    y16 = frontend.fir_decimate(raw, taps, dec, n_channels=nch, channel=ch, out="int16")
+    assert np.abs(y16[:, 0] - np.clip(np.rint(ref.real), -32768, 32767)).max() <= 1
+    assert np.abs(y16[:, 1] - np.clip(np.rint(ref.imag), -32768, 32767)).max() <= 1
+    for extra in (0, dec):
+        ys = frontend.fir_decimate(raw[: ntaps + extra], taps, dec, n_channels=nch, channel=ch, out="f32")
+        assert ys.shape[0] == 1 + extra // dec and np.abs(ys - ref[: ys.shape[0]]).max() <= 2e-6 * np.abs(ref).max() + 1e-3
+    # the two forms against each other on the same call: int16 outputs within one count, floats within the gate
+    monkeypatch.setenv("TWX_FIR_MFMA", "0")
+    yv = frontend.fir_decimate(raw, taps, dec, n_channels=nch, channel=ch, out="f32")
+    yv16 = frontend.fir_decimate(raw, taps, dec, n_channels=nch, channel=ch, out="int16")
+    assert np.abs(y - yv).max() <= 4e-6 * np.abs(ref).max() + 2e-3 and np.abs(y16.astype(np.int32) - yv16).max() <= 1
+
+
 def test_wideband_chain_70msps():
     """configs[4] in miniature: chips held 28 samples at 70 Msps → FIR ↓14 → standard chain at 5 Msps;
     the lag found equals the lag the oracle finds on the same decimated int16 samples, fp32 vs fp64
