@@ -44,5 +44,19 @@ with Correlator(chips, fs=FS, Nint=1) as c, Correlator(chips, fs=FS, Nint=1) as 
             k = kk % N                                                              # the N-point bin it came from (zero-padded spectrum)
             print("  spectrum of the difference: bins above 1e-3 of its max:", kb.size, " k1 = k % 625:", np.unique(k % 625)[:30], "count", np.unique(k % 625).size,
                   " k2 = k // 625 range", (k // 625).min(), (k // 625).max(), "count", np.unique(k // 625).size)
+            rm = ref.cpu().numpy().astype(np.float64); Rz = np.fft.fft(rm[:, 0] + 1j * rm[:, 1])
+            Mz = Rz + D
+            for k1 in np.unique(k % 625)[:4]:
+                kk2 = np.arange(0, 4000)                                           # positive-frequency half of the row: bins k1 + 625 k2 of the 3N-point spectrum
+                bins = k1 + 625 * kk2
+                r = Rz[bins]; m = Mz[bins]
+                ratio = m / np.where(np.abs(r) > 0, r, 1)
+                good = np.abs(r) > np.abs(r).max() * 1e-3
+                badk2 = kk2[np.abs(m - r) > 0.05 * np.abs(r).mean()]
+                print("   row k1 =", k1, "bins k2 off by > 5 % of the row's mean:", badk2.size, " q0 = k2 % 20:", np.unique(badk2 % 20), " q1 = (k2 // 20) % 20:", np.unique((badk2 // 20) % 20),
+                      " q2 = k2 // 400:", np.unique(badk2 // 400))
+                print("   row k1 =", k1, ": |wrong|/|right| median %.4f  min %.4f max %.4f;  phase(wrong/right) median %.4f rad, spread %.4f;  corr(wrong,right) = %.4f" % (
+                    np.median(np.abs(ratio[good])), np.abs(ratio[good]).min(), np.abs(ratio[good]).max(), np.median(np.angle(ratio[good])), np.std(np.angle(ratio[good])),
+                    np.abs(np.vdot(r[good], m[good])) / np.sqrt(np.vdot(r[good], r[good]).real * np.vdot(m[good], m[good]).real)))
             rel = ((maps[i] - ref).abs().max() / ref.abs().max()).item()
             print("  max |diff| / max |ref| =", rel)
