@@ -1083,8 +1083,10 @@ __global__ __launch_bounds__(FM_NT, 4) void k_fir_mfma(const short2* __restrict_
 // the spectrum, 6-12 of 625 per call (tools/chain_corunner_map.py); the Stockham row pass, the column passes, a copy, a torch fp16 GEMM
 // and the vector FIR beside the same chain are clean, the chain beside poisoned or busy LDS is clean, the FIR's own outputs are right
 // and deterministic, and every part of the kernel removed in turn (matrix-core instructions, the SDWA converts, the staging) makes
-// the effect disappear; a bare fp16 MFMA loop beside the chain reproduces it rarely (profiles/r05_fir_mfma.txt).  Not understood yet,
-// so the form stays opt-in for callers that run nothing else on the GPU at the time.
+// the effect disappear; a bare fp16 MFMA loop beside the chain reproduces it rarely (profiles/r05_fir_mfma.txt).  A diagnostic build of
+// k_rowd (-DTWX_ROWD_CHECK) that runs ONE non-inlined butterfly function twice on the same register values gets two different results in
+// such a wave, and only beside this kernel: not a race and not stale data, nothing either source shows.  So the form stays opt-in for
+// callers that run nothing else on the GPU at the time.
 bool fir_use_mfma(int ntaps, int dec, long long nout) {
     const char* fe = getenv("TWX_FIR_MFMA");          // read per call: tests switch it inside one process
     const int force = fe ? atoi(fe) : -1;

@@ -1079,6 +1079,14 @@ template <typename T> struct RowDArgs {
     unsigned total_rows;             // N1 * windows (the grid is smaller when k_rowd<MID> runs with resident workgroups)
 };
 
+#ifdef TWX_ROWD_CHECK
+template <typename T, int R> __device__ __attribute__((noinline)) void rowd_check_bfly(const cpx<T>* in, cpx<T>* out) {
+    cpx<T> t[R];
+    for (int r = 0; r < R; ++r) t[r] = in[r];
+    Bfly<T, R, false>::run(t);
+    for (int r = 0; r < R; ++r) out[r] = t[r];
+}
+#endif
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1257,6 +1265,24 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
         // (visible to every wave after the barrier at the top of the first phase)
         if (tid < R0 * R) tabs[D::tab_c + tid] = cmulc(fb, PERSIST ? s_tc[tid] : tabs[D::tab_c + tid]);
     }
+#ifdef TWX_ROWD_CHECK
+    // diagnostic (profiles/r05_fir_mfma.txt): ONE wave runs the SAME instructions (a function that is not inlined) twice on the same inputs:
+    // do the results agree?  And does it read the same LDS words twice with the same result?
+    if constexpr (MODE == ROW_MID && sizeof(T) == 4) {
+        C va[R], vb[R], oa[R], ob[R];
+        int m1 = 0, m2 = 0;
+        if (act) { TWX_UNROLL for (int r = 0; r < R; ++r) va[r] = lds[D::phys(q0, r, qi)]; }
+        wave_sync_lds();
+        if (act) {
+            TWX_UNROLL for (int r = 0; r < R; ++r) vb[r] = lds[D::phys(q0, r, qi)];
+            TWX_UNROLL for (int r = 0; r < R; ++r) m1 += (va[r].x != vb[r].x) | (va[r].y != vb[r].y);
+            rowd_check_bfly<T, R>(va, oa);
+            rowd_check_bfly<T, R>(va, ob);
+            TWX_UNROLL for (int r = 0; r < R; ++r) m2 += (__float_as_uint(oa[r].x) != __float_as_uint(ob[r].x)) | (__float_as_uint(oa[r].y) != __float_as_uint(ob[r].y));
+            if (m1 | m2) printf("k_rowd check: k1 %d q0 %d lane-row %d: %d words read differently twice, %d butterfly outputs differ between two calls of one function\n", k1, q0, qi, m1, m2);
+        }
+    }
+#endif
     if (act) D::f1(lds, tabs, q0, qi, v);
     TWX_STAMP(5);
     bool pruned = false;
