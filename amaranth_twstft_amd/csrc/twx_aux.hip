@@ -910,6 +910,19 @@ typedef float fm_f4 __attribute__((ext_vector_type(4)));
 // one sample word (I | Q << 16, int16 each) -> its (xh, xl) fp16 pairs: four SDWA converts — the high byte of a component,
 // sign-extended, is xh; the low byte, unsigned, xl — each written straight into its half of the word
 __device__ __forceinline__ void fm_split(unsigned w, unsigned& wi, unsigned& wq) {
+#if defined(TWX_FM_NOSDWA)
+    // diagnostic: the same values without SDWA instructions (bit-field extracts, int -> f32 -> f16, pack)
+    int ih, il, qh, ql; float fih, fil, fqh, fql; unsigned hih, hil, hqh, hql;
+    asm volatile("v_bfe_i32 %0, %1, 8, 8" : "=v"(ih) : "v"(w));   asm volatile("v_bfe_u32 %0, %1, 0, 8" : "=v"(il) : "v"(w));
+    asm volatile("v_ashrrev_i32 %0, 24, %1" : "=v"(qh) : "v"(w)); asm volatile("v_bfe_u32 %0, %1, 16, 8" : "=v"(ql) : "v"(w));
+    asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(fih) : "v"(ih)); asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(fil) : "v"(il));
+    asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(fqh) : "v"(qh)); asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(fql) : "v"(ql));
+    asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(hih) : "v"(fih)); asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(hil) : "v"(fil));
+    asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(hqh) : "v"(fqh)); asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(hql) : "v"(fql));
+    asm volatile("v_pack_b32_f16 %0, %1, %2" : "=v"(wi) : "v"(hih), "v"(hil));
+    asm volatile("v_pack_b32_f16 %0, %1, %2" : "=v"(wq) : "v"(hqh), "v"(hql));
+    return;
+#endif
     asm volatile("v_cvt_f16_i16_sdwa %0, sext(%1) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(wi) : "v"(w));
     asm volatile("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(wi) : "v"(w));
     asm volatile("v_cvt_f16_i16_sdwa %0, sext(%1) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(wq) : "v"(w));
