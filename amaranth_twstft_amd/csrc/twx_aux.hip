@@ -1047,6 +1047,10 @@ __global__ __launch_bounds__(FM_NT, 4) void k_fir_mfma(const short2* __restrict_
                 aI = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bI, aI, 0, 0, 0);
                 aQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bQ, aQ, 0, 0, 0);
                 }
+#if defined(TWX_FM_THROTTLE)
+                // diagnostic: idle issue slots after every group of four matrix-core instructions
+                for (int z = 0; z < TWX_FM_THROTTLE; ++z) __builtin_amdgcn_s_sleep(1);
+#endif
             }
         };
         // (the two jobs of a trip are independent; odd waves multiplying first and staging afterwards, so that every SIMD has vector

@@ -22,6 +22,7 @@ side = torch.cuda.Stream(device=dev)
 sink = torch.zeros(4, device=dev)
 poison = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bin', 'liblds_poison.so'))
 poison.lds_poison.argtypes = [C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int]
+poison.mfma_burn_live.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 poison.mfma_burn32.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]
 poison.mfma_burn.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_void_p]
 lib.twx_stream.restype = C.c_void_p
@@ -49,6 +50,8 @@ with Correlator(chips, fs=FS, Nint=1) as c, Correlator(chips, fs=FS, Nint=1) as 
                 # LDS-holding workgroups (52 KB each, 2 per CU) of another stream, spinning beside the chain's kernels
                 pat = 0x7FC00000 if mode.endswith("nan") else 0x7149F2CA
                 assert poison.lds_poison(C.c_void_p(int(lib.twx_stream(b1._h))), pat, 52, 512, 40) == 0
+            elif mode.startswith("burn live"):
+                assert poison.mfma_burn_live(C.c_void_p(int(lib.twx_stream(b1._h))), 2048, 3000, sink.data_ptr()) == 0
             elif mode.startswith("burn32"):
                 assert poison.mfma_burn32(C.c_void_p(int(lib.twx_stream(b1._h))), 0.0 if mode.endswith("zero") else 1.25, 0.0 if mode.endswith("zero") else 0.75, 2048, 3000, sink.data_ptr()) == 0
             elif mode.startswith("burn"):

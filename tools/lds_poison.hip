@@ -41,6 +41,26 @@ __global__ __launch_bounds__(256) void k_burn32(float av, float bv, int iters, f
     }
     if (c0[0] + c1[1] + c2[2] + c3[3] == 12345.f) sink[0] = 1.f;
 }
+// the same with operands that CHANGE every iteration (normal fp16 numbers in [1, 2) from a running counter): live data
+__global__ __launch_bounds__(256) void k_burn_live(int iters, float* sink) {
+    unsigned s0 = 0x9E3779B9u * (threadIdx.x + 1) + blockIdx.x, s1 = 0x85EBCA6Bu * (threadIdx.x + 7);
+    bf4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    for (int i = 0; i < iters; ++i) {
+        s0 = s0 * 1664525u + 1013904223u; s1 = s1 * 22695477u + 1u;
+        uint4 ua = {(s0 & 0x03FF03FFu) | 0x3C003C00u, ((s0 >> 3) & 0x03FF03FFu) | 0x3C003C00u, ((s0 >> 5) & 0x03FF03FFu) | 0xBC003C00u, ((s0 >> 7) & 0x03FF03FFu) | 0x3C00BC00u};
+        uint4 ub = {(s1 & 0x03FF03FFu) | 0x3C003C00u, ((s1 >> 3) & 0x03FF03FFu) | 0xBC003C00u, ((s1 >> 5) & 0x03FF03FFu) | 0x3C003C00u, ((s1 >> 7) & 0x03FF03FFu) | 0x3C00BC00u};
+        const bh8 a = __builtin_bit_cast(bh8, ua), b = __builtin_bit_cast(bh8, ub);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, a, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, b, c3, 0, 0, 0);
+    }
+    if (c0[0] + c1[1] + c2[2] + c3[3] == 12345.f) sink[0] = 1.f;
+}
+extern "C" int mfma_burn_live(void* stream, int blocks, int iters, float* sink) {
+    hipLaunchKernelGGL(k_burn_live, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, sink);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 extern "C" int mfma_burn32(void* stream, float a, float b, int blocks, int iters, float* sink) {
     hipLaunchKernelGGL(k_burn32, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, iters, sink);
     return hipGetLastError() == hipSuccess ? 0 : -2;
