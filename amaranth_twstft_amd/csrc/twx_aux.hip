@@ -1102,8 +1102,10 @@ __global__ __launch_bounds__(FM_NT, 4) void k_fir_mfma(const short2* __restrict_
 // and deterministic, and every part of the kernel removed in turn (matrix-core instructions, the SDWA converts, the staging) makes
 // the effect disappear; a bare fp16 MFMA loop beside the chain reproduces it rarely (profiles/r05_fir_mfma.txt).  A diagnostic build of
 // k_rowd (-DTWX_ROWD_CHECK) that runs ONE non-inlined butterfly function twice on the same register values gets two different results in
-// such a wave, and only beside this kernel: not a race and not stale data, nothing either source shows.  So the form stays opt-in for
-// callers that run nothing else on the GPU at the time.
+// such a wave, and only beside this kernel — also with arguments and results in registers only (sixteen v_pk_*_f32 instructions); a build
+// of the library without packed-fp32 instructions is immune.  Not a race, not stale data, nothing either source shows: v_pk_*_f32 results
+// of one wave go wrong while this kernel's waves are resident beside it.  So the form stays opt-in for callers that run nothing else on
+// the GPU at the time.
 bool fir_use_mfma(int ntaps, int dec, long long nout) {
     const char* fe = getenv("TWX_FIR_MFMA");          // read per call: tests switch it inside one process
     const int force = fe ? atoi(fe) : -1;

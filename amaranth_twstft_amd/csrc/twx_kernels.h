@@ -1086,6 +1086,15 @@ template <typename T, int R> __device__ __attribute__((noinline)) void rowd_chec
     Bfly<T, R, false>::run(t);
     for (int r = 0; r < R; ++r) out[r] = t[r];
 }
+// the same question with nothing but registers: arguments and results of a non-inlined function travel in VGPRs (no scratch memory)
+struct RowdCheck4 { cpx<float> a, b, c, d; };
+__device__ __attribute__((noinline)) RowdCheck4 rowd_check4(cpx<float> a, cpx<float> b, cpx<float> c, cpx<float> d, int tag) {
+    asm volatile("" :: "v"(tag) : "memory");          // not a pure function: two calls with the same values stay two calls
+    cpx<float> t[4] = {a, b, c, d};
+    Bfly<float, 4, false>::run(t);
+    t[1] = cmul(t[1], t[3]); t[2] = cmul(t[2], t[0]);
+    return RowdCheck4{t[0], t[1], t[2], t[3]};
+}
 #endif
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_wave_barrier();
@@ -1279,7 +1288,15 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
             rowd_check_bfly<T, R>(va, oa);
             rowd_check_bfly<T, R>(va, ob);
             TWX_UNROLL for (int r = 0; r < R; ++r) m2 += (__float_as_uint(oa[r].x) != __float_as_uint(ob[r].x)) | (__float_as_uint(oa[r].y) != __float_as_uint(ob[r].y));
-            if (m1 | m2) printf("k_rowd check: k1 %d q0 %d lane-row %d: %d words read differently twice, %d butterfly outputs differ between two calls of one function\n", k1, q0, qi, m1, m2);
+            int m3 = 0;
+            TWX_UNROLL for (int r = 0; r + 3 < R; r += 4) {
+                const RowdCheck4 x = rowd_check4(va[r], va[r + 1], va[r + 2], va[r + 3], r);
+                const RowdCheck4 y = rowd_check4(va[r], va[r + 1], va[r + 2], va[r + 3], r + 1);
+                m3 += (__float_as_uint(x.a.x) != __float_as_uint(y.a.x)) | (__float_as_uint(x.a.y) != __float_as_uint(y.a.y)) | (__float_as_uint(x.b.x) != __float_as_uint(y.b.x)) |
+                      (__float_as_uint(x.b.y) != __float_as_uint(y.b.y)) | (__float_as_uint(x.c.x) != __float_as_uint(y.c.x)) | (__float_as_uint(x.c.y) != __float_as_uint(y.c.y)) |
+                      (__float_as_uint(x.d.x) != __float_as_uint(y.d.x)) | (__float_as_uint(x.d.y) != __float_as_uint(y.d.y));
+            }
+            if (m1 | m2 | m3) printf("k_rowd check: k1 %d q0 %d lane-row %d: %d words read differently twice, %d butterfly outputs differ between two calls of one function, %d register-only calls differ\n", k1, q0, qi, m1, m2, m3);
         }
     }
 #endif
