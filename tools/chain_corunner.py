@@ -19,6 +19,10 @@ torch.cuda.synchronize()
 band = L.twx_band(*band_godual(FS, N))
 key = lambda r: (int(r.indice0), r.xval[0], r.xval[1], r.df)
 side = torch.cuda.Stream(device=dev)
+sn = 400_000 * 96 + 64
+sx = torch.randint(-3000, 3000, (sn, 2), dtype=torch.int16, device=dev)
+srep = (torch.randint(0, 2, (400_000,), device=dev).float() * 2 - 1).contiguous()
+sout = torch.empty((96, 57, 2), dtype=torch.float64, device=dev)
 sink = torch.zeros(4, device=dev)
 poison = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bin', 'liblds_poison.so'))
 poison.lds_poison.argtypes = [C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int]
@@ -50,6 +54,11 @@ with Correlator(chips, fs=FS, Nint=1) as c, Correlator(chips, fs=FS, Nint=1) as 
                 # LDS-holding workgroups (52 KB each, 2 per CU) of another stream, spinning beside the chain's kernels
                 pat = 0x7FC00000 if mode.endswith("nan") else 0x7149F2CA
                 assert poison.lds_poison(C.c_void_p(int(lib.twx_stream(b1._h))), pat, 52, 512, 40) == 0
+            elif mode.startswith("sliding"):
+                # the product's own fp32 matrix-core kernel (k_sliding_mfma: 96 codes, +-28 lags) or its packed-FMA form on another context's stream
+                os.environ["TWX_SLIDING_MFMA"] = "1" if mode.endswith("mfma") else "0"
+                for _ in range(3):
+                    b1.sliding_dot_dev(sx.data_ptr(), sn, srep.data_ptr(), 400_000, 96, 28, sout.data_ptr(), ff=1.234e-5, scale=1.0 / 32768)
             elif mode.startswith("burn live"):
                 assert poison.mfma_burn_live(C.c_void_p(int(lib.twx_stream(b1._h))), 2048, 3000, sink.data_ptr()) == 0
             elif mode.startswith("burn32"):
