@@ -408,6 +408,30 @@ def wideband_legs(local_rank: int, seconds: int = 4, steps: int = 5):
     fir_flops = n_out * ntaps * 4                                # complex int16 sample x real tap: 2 FMAs
     fir_bytes = n_in * 4 + n_out * 4
     sess.synchronize()
+    # the opt-in matrix-core form of the front end, ALONE on the GPU (nothing else in flight: profiles/r05_fir_mfma.txt), against the vector form's output
+    fir_mc = None
+    try:
+        vec_out = sess.nar["OP"][0].clone()
+        os.environ["TWX_FIR_MFMA"] = "1"
+        c32["OPlo"].fir_decimate_dev(wptr["OP"], n_in, taps, dec, out_i16_dev=sess.nar["OP"][0].data_ptr())
+        e0.record(es)
+        for _ in range(5):
+            c32["OPlo"].fir_decimate_dev(wptr["OP"], n_in, taps, dec, out_i16_dev=sess.nar["OP"][0].data_ptr())
+        e1.record(es)
+        e1.synchronize()
+        mc_ms = e0.elapsed_time(e1) / 5
+        same = int((sess.nar["OP"][0].to(torch.int32) - vec_out.to(torch.int32)).abs().max().item())
+        fir_mc = {"kernel": "k_fir_mfma (fp16 matrix cores, samples and taps split exactly; TWX_FIR_MFMA=1)", "avg_ms": round(mc_ms, 4),
+                  "input_Msamples_per_s": round(n_in / mc_ms / 1e3, 1), "GB/s": round(fir_bytes / (mc_ms * 1e-3) / 1e9, 1),
+                  "frac_hbm": round(fir_bytes / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                  "fp32_equivalent_TFLOP/s": round(fir_flops / (mc_ms * 1e-3) / 1e12, 2), "frac_of_fp32_vector_peak": round(fir_flops / (mc_ms * 1e-3) / 1e12 / 157.3, 4),
+                  "max_abs_difference_from_the_vector_form_int16": same,
+                  "note": "opt-in and measured alone: packed-fp32 results of waves resident beside this kernel go wrong (profiles/r05_fir_mfma.txt), so no timed "
+                          "step of this line uses it"}
+    finally:
+        os.environ.pop("TWX_FIR_MFMA", None)
+        c32["OPlo"].fir_decimate_dev(wptr["OP"], n_in, taps, dec, out_i16_dev=sess.nar["OP"][0].data_ptr())      # the vector form's output for what follows
+        sess.synchronize()
     nar = {st: sess.nar[st][0].clone() for st in sess.stations}   # the decimated captures for the fp64 leg
     torch.cuda.synchronize(dev)
     sess.close()
@@ -468,7 +492,7 @@ def wideband_legs(local_rank: int, seconds: int = 4, steps: int = 5):
                   "roofline": {"bound": "fp32 vector", "achieved": round(fir_flops / (fir_ms * 1e-3) / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
                                "frac": round(fir_flops / (fir_ms * 1e-3) / 1e12 / 157.3, 4), "flops_per_launch": int(fir_flops)},
                   "GB/s": round(fir_bytes / (fir_ms * 1e-3) / 1e9, 1), "frac_hbm": round(fir_bytes / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                  "timing": "HIP events on the context's stream around 5 launches"}}
+                  "timing": "HIP events on the context's stream around 5 launches", "matrix_core_form": fir_mc}}
     f64 = {"workload": f"the same four correlations in fp64 (twx_config.precision = f64) on the decimated captures, {W} windows each, in flight together",
            "dtype": "f64", "correlated_Msamples_per_s": round(corr_samples / t_corr64 / 1e6, 1), "ms_per_step": round(t_corr64 * 1e3, 3),
            "chain_GBs_algorithmic": round(180 * corr_samples / t_corr64 / 1e9, 1), "chain_frac_hbm": round(180 * corr_samples / t_corr64 / 1e9 / HBM_PEAK_GBS, 4),
