@@ -552,6 +552,9 @@ def test_bench_wideband_and_fp64_legs():
     w, f = j["wideband_workload"], j["f64_workload"]
     assert w["expected_lags_within_one_sample"] and w["input_Msamples_per_s"] > 1000 and w["correlated_Msamples_per_s"] > 1000
     assert w["fir"]["roofline"]["bound"] == "fp32 vector" and 0.05 < w["fir"]["roofline"]["frac"] < 1.0 and w["fir"]["avg_ms"] > 0
+    mc = w["fir"]["matrix_core_form"]                                  # the opt-in form, measured alone: the same outputs to one count
+    assert mc["kernel"].startswith("k_fir_mfma") and mc["avg_ms"] > 0 and mc["max_abs_difference_from_the_vector_form_int16"] <= 1
+    assert w["ms_per_step"] > 0 and w["ms_per_step_one_at_a_time"] > 0
     assert f["dtype"] == "f64" and f["integer_lags_equal_fp32"] and f["within_tolerance"] and f["fp32_vs_fp64_peak_rel"] <= 1e-6
     r = f["roofline"]
     assert r["bound"] == "hbm" and r["kernel"].startswith("k_row_mid") and 0.05 < r["frac"] < 1.0 and r["algorithmic_bytes_per_launch"] == 64 * 5_000_000 + 16 * 5_000_000
