@@ -26,6 +26,7 @@ sout = torch.empty((96, 57, 2), dtype=torch.float64, device=dev)
 sink = torch.zeros(4, device=dev)
 poison = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bin', 'liblds_poison.so'))
 poison.lds_poison.argtypes = [C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int]
+poison.mfma_burn_lds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
 poison.mfma_burn_live.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 poison.mfma_burn32.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]
 poison.mfma_burn.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_void_p]
@@ -59,6 +60,9 @@ with Correlator(chips, fs=FS, Nint=1) as c, Correlator(chips, fs=FS, Nint=1) as 
                 os.environ["TWX_SLIDING_MFMA"] = "1" if mode.endswith("mfma") else "0"
                 for _ in range(3):
                     b1.sliding_dot_dev(sx.data_ptr(), sn, srep.data_ptr(), 400_000, 96, 28, sout.data_ptr(), ff=1.234e-5, scale=1.0 / 32768)
+            elif mode.startswith("burn lds"):
+                src = cap.data_ptr() if mode.endswith("global") else None
+                assert poison.mfma_burn_lds(C.c_void_p(int(lib.twx_stream(b1._h))), 512, 1500, src, int(n_in // 4 - 8), sink.data_ptr()) == 0
             elif mode.startswith("burn live"):
                 assert poison.mfma_burn_live(C.c_void_p(int(lib.twx_stream(b1._h))), 2048, 3000, sink.data_ptr()) == 0
             elif mode.startswith("burn32"):

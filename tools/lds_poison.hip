@@ -57,6 +57,38 @@ __global__ __launch_bounds__(256) void k_burn_live(int iters, float* sink) {
     }
     if (c0[0] + c1[1] + c2[2] + c3[3] == 12345.f) sink[0] = 1.f;
 }
+// closer to k_fir_mfma: 512 threads, 52 KB of LDS; every iteration a wave writes words into LDS (ds_write_b32), reads 16-byte operands back
+// (ds_read_b128) and feeds them to the matrix cores; optionally 16-byte global loads feed the writes
+__global__ __launch_bounds__(512) void k_burn_lds(int iters, const uint4* src, int nsrc, float* sink) {
+    extern __shared__ unsigned L[];
+    const int tid = threadIdx.x, words = 13 * 1024;
+    unsigned s0 = 0x9E3779B9u * (tid + 1) + blockIdx.x;
+    bf4 c0 = {0, 0, 0, 0}, c1 = c0;
+    for (int i = tid; i < words; i += 512) L[i] = 0x3C003C00u;
+    __syncthreads();
+    for (int i = 0; i < iters; ++i) {
+        uint4 g = {0, 0, 0, 0};
+        if (src) g = src[(blockIdx.x * 512 + tid + i * 7919) % nsrc];
+        s0 = s0 * 1664525u + 1013904223u + g.x;
+        for (int k = 0; k < 4; ++k) L[(tid * 4 + k * 2053 + i) % words] = ((s0 >> k) & 0x03FF03FFu) | 0x3C003C00u;
+        __syncthreads();
+        const uint4 ua = *reinterpret_cast<const uint4*>(L + ((tid * 4 + i * 4) % (words - 4) & ~3));
+        const uint4 ub = *reinterpret_cast<const uint4*>(L + ((tid * 4 + 2048 + i * 8) % (words - 4) & ~3));
+        const bh8 a = __builtin_bit_cast(bh8, ua), b = __builtin_bit_cast(bh8, ub);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, a, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, b, c1, 0, 0, 0);
+        __syncthreads();
+    }
+    if (c0[0] + c1[1] == 12345.f) sink[0] = 1.f;
+}
+extern "C" int mfma_burn_lds(void* stream, int blocks, int iters, const void* src, int nsrc, float* sink) {
+    static bool set = false;
+    if (!set) { if (hipFuncSetAttribute((const void*)k_burn_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1; set = true; }
+    hipLaunchKernelGGL(k_burn_lds, dim3(blocks), dim3(512), (size_t)52 * 1024, (hipStream_t)stream, iters, (const uint4*)src, nsrc, sink);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 extern "C" int mfma_burn_live(void* stream, int blocks, int iters, float* sink) {
     hipLaunchKernelGGL(k_burn_live, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, sink);
     return hipGetLastError() == hipSuccess ? 0 : -2;
