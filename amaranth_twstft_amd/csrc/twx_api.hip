@@ -644,7 +644,9 @@ template <typename T> struct Ctx : CtxBase {
         if (int rc = upload(&eb, heb)) return rc;
         {   // DIF/DIT row pass tables (RowD, twx_fft.h)
             const char* e = getenv("TWX_ROWD");
-            use_rowd = (row->rowd != nullptr) && (!e || atoi(e) != 0);
+            // (TWX_ROWD=0, the Stockham row pass, is a diagnostic of fp32 contexts: in complex double its middle pass does not fit
+            // the registers, so that form is not built — twx_inst_row.hip)
+            use_rowd = (row->rowd != nullptr) && (!e || atoi(e) != 0 || sizeof(T) == 8);
         }
         if (use_rowd) {
             const int Rr = row->R[row->S - 1], R0 = row->S == 3 ? row->R[0] : 1, NU = R0 * Rr;

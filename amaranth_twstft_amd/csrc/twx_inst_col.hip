@@ -16,7 +16,8 @@ static_assert(P::max_tasks * W <= NT, "one task per thread per stage");
 template <typename T, int MODE, class In>
 int launch_fwd(In in, const ColFwdArgs<T>& a, unsigned nblk, hipStream_t s) {
     // measured on MI355X (N1 = 625, gpurun_out/ab3): MIX 0.1245 -> 0.119 ms per 8 windows, SQUARE 0.117 -> 0.129: only MIX uses it
-    if constexpr (P::S == 2 && std::is_same<T, float>::value && NT >= 384 && MODE == COL_MIX) {
+    // (int16 captures only: the complex-double loader of twx_process_complex needs two registers more than the 80 that six waves per SIMD leave)
+    if constexpr (P::S == 2 && std::is_same<T, float>::value && NT >= 384 && MODE == COL_MIX && !std::is_same<In, InCplxSplit>::value) {
         static const bool split = [] { const char* e = getenv("TWX_COLFWD3"); return !e || atoi(e) != 0; }();
         if (split) {                         // component-wise exchange: three or four workgroups per CU (twx_kernels.h)
             TWX_LAUNCH((k_col_fwd3<P, T, W, MODE, In, NT>), dim3(nblk), dim3(NT), s, in, a);

@@ -11,19 +11,25 @@ constexpr int NT = TWX_NT;
 constexpr int PADQ = TWX_PADQ;
 static_assert(P::max_tasks <= NT, "one task per thread per stage");
 
-template <typename T> int run(int mode, const void* args, unsigned nblk, hipStream_t s) {
-    const RowArgs<T>& a = *reinterpret_cast<const RowArgs<T>*>(args);
-    if (mode == ROW_STORE) TWX_LAUNCH((k_row<P, T, ROW_STORE, PADQ, NT>), dim3(nblk), dim3(NT), s, a);
-    else if (mode == ROW_BAND) TWX_LAUNCH((k_row<P, T, ROW_BAND, PADQ, NT>), dim3(nblk), dim3(NT), s, a);
-    else if (mode == ROW_MID) TWX_LAUNCH((k_row<P, T, ROW_MID, PADQ, NT>), dim3(nblk), dim3(NT), s, a);
-    else return -1;
-    return (int)hipGetLastError();
-}
-
 template <class PP> struct HasRowD {
     static constexpr bool value = (PP::S == 2 && PP::radix(0) == PP::radix(1) && 64 / PP::radix(1) >= 1) ||
                                   (PP::S == 3 && PP::radix(1) == PP::radix(2));
 };
+
+template <typename T> int run(int mode, const void* args, unsigned nblk, hipStream_t s) {
+    const RowArgs<T>& a = *reinterpret_cast<const RowArgs<T>*>(args);
+    if (mode == ROW_STORE) TWX_LAUNCH((k_row<P, T, ROW_STORE, PADQ, NT>), dim3(nblk), dim3(NT), s, a);
+    else if (mode == ROW_BAND) TWX_LAUNCH((k_row<P, T, ROW_BAND, PADQ, NT>), dim3(nblk), dim3(NT), s, a);
+    else if (mode == ROW_MID) {
+        // complex double through the Stockham form needs more registers than a lane has where the row is long (8000: 138 spilled, 556 B of
+        // scratch per lane in a pass that is bound by the same HBM): plans with the DIF/DIT form run that one, always (twx_api.hip ignores
+        // TWX_ROWD=0 for them), and the spilling instantiation does not exist
+        if constexpr (std::is_same<T, double>::value && HasRowD<P>::value) return -1;
+        else TWX_LAUNCH((k_row<P, T, ROW_MID, PADQ, NT>), dim3(nblk), dim3(NT), s, a);
+    } else return -1;
+    return (int)hipGetLastError();
+}
+
 
 template <typename T> int caf(const void* args, unsigned nblk, hipStream_t s) {
     const CafArgs<T>& a = *reinterpret_cast<const CafArgs<T>*>(args);
@@ -46,8 +52,10 @@ template <typename T> int rowd(int mode, const void* args, unsigned nblk, hipStr
         constexpr int NTD = RowD<P, T>::NT_MIN;
         RowDArgs<T> a = *reinterpret_cast<const RowDArgs<T>*>(args);
         a.total_rows = nblk;
-        if constexpr (RowD<P, T>::R0 == 1 && std::is_same<T, float>::value) {     // short rows: several rows per workgroup
-            constexpr int NTS = 448, G = (NTS / 64) * RowD<P, T>::BPW;
+        if constexpr (RowD<P, T>::R0 == 1) {     // short rows: several rows per workgroup
+            // complex double: four waves, one per SIMD, so that a lane may use 512 registers (v, pr, csr and the row loads in flight are
+            // 79 complex doubles: at 448 threads the 256-register cap spilled 24 of them)
+            constexpr int NTS = std::is_same<T, float>::value ? 448 : 256, G = (NTS / 64) * RowD<P, T>::BPW;
             const unsigned grid = (nblk + G - 1) / G;
             if (mode == ROW_BAND) TWX_LAUNCH((k_rowd_small<P, T, ROW_BAND, NTS>), dim3(grid), dim3(NTS), s, a, nblk);
             else if (mode == ROW_MID) TWX_LAUNCH((k_rowd_small<P, T, ROW_MID, NTS>), dim3(grid), dim3(NTS), s, a, nblk);

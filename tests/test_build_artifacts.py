@@ -1,0 +1,38 @@
+"""Build checks on the shipped gfx950 code objects (CPU only: llvm-readelf over the fat binaries)."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _rows():
+    import spill_check
+    if not os.path.exists(os.path.join(spill_check.LLVM, "llvm-readelf")) and not shutil.which("llvm-readelf"):
+        pytest.skip("llvm-readelf not available")
+    paths = [p for p in spill_check.default_paths() if os.path.exists(p)]
+    if not paths:
+        pytest.skip("library not built")
+    return spill_check.audit(paths), paths
+
+
+def test_no_kernel_of_the_library_or_a_plan_plugin_spills_registers():
+    """Every kernel of libtwstft_hip.so and of every plan plug-in: `.vgpr_spill_count` == 0 and no scratch memory.  The passes are bound by
+    HBM; a kernel that spills pays its scratch traffic out of the same bandwidth (round 5 shipped four such instantiations: the fp64
+    Stockham middle pass of the 4000 / 8000-point rows, the fp64 400-point row pass, one column pass of the complex-double entry)."""
+    rows, paths = _rows()
+    assert len(rows) > 300, "metadata of the code objects not found (%d kernels in %s)" % (len(rows), paths)
+    bad = [(r["file"], r["kernel"], r["vgpr_spill"], r["scratch"]) for r in rows if r["vgpr_spill"] or r["scratch"]]
+    assert not bad, "kernels with vector spills / scratch: %r" % (bad[:8],)
+
+
+def test_dominant_kernel_keeps_its_register_and_lds_budget():
+    """k_rowd<Plan<8000,20,20,20>, float, MID>: four workgroups of seven waves per CU need <= 128 VGPRs and <= 80 KB of LDS."""
+    rows, _ = _rows()
+    mid = [r for r in rows if r["kernel"].startswith("_ZN3twx6k_rowdINS_4PlanILi8000ELi20ELi20ELi20ELi1EEEfLi2E")]
+    assert mid, "the fp32 middle pass of the 8000-point row is not in the library"
+    for r in mid:
+        assert r["vgpr"] <= 128 and r["lds"] <= 81920 and r["vgpr_spill"] == 0, r
