@@ -17,6 +17,7 @@ TWX_CONV_GODUAL, TWX_CONV_CLAUDIO = 0, 1
 TWX_WIN_NONE, TWX_WIN_HAMMING = 0, 1
 TWX_F32, TWX_F64 = 0, 1
 TWX_OPT_REMOVE_MEAN = 1
+TWX_OPT_FIR_MFMA = 2
 TWX_FLAG_PROFILE = 1
 TWX_FLAG_FINE_FREQ = 2
 TWX_FLAG_CODE_ZERO_MEAN = 4
@@ -24,7 +25,7 @@ TWX_CODE_BIPOLAR, TWX_CODE_UNIPOLAR = 0, 1
 TWX_PROF_MAX = 16
 TWX_TRK_RANGING, TWX_TRK_RE, TWX_TRK_LO = 0, 1, 2
 TWX_CARRIER_SEARCH_DF, TWX_CARRIER_CHUNK_BAND = 0, 1
-TWX_ABI_VERSION = 5
+TWX_ABI_VERSION = 6
 TWX_MULTI_NO_RCCL, TWX_MULTI_RCCL_ONE = 1, 2
 TWX_ACQ_IZAMAX = 1
 
@@ -200,6 +201,9 @@ SYMBOLS = {
     "twx_multi_process_windows": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
     "twx_multi_process_windows_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
     "twx_multi_fetch_gathered": (C.c_int, [_VP, C.c_int32, _VP, C.c_int64]),
+    "twx_multi_block": (C.c_int, [_VP, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "twx_multi_process_recording_dev": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(twx_band), _VP, _VP]),
+    "twx_multi_exchange_only": (C.c_int, [_VP, C.c_int64]),
     "twx_file_df": (C.c_int, [C.c_char_p, C.c_double, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "twx_write_cmat": (C.c_int, [C.c_char_p, _VP, _VP, C.c_int64]),
     "twx_file_df_last_error": (C.c_char_p, []),

@@ -32,6 +32,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROBE_OK = "TWX_RCCL_PROBE_OK"
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"      # (module attributes: the CPU tests point them at a fake tree)
+DRI_DIR = "/dev/dri"
 
 
 def _inject(step: str, rank: int | None = None) -> bool:
@@ -48,10 +50,52 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def _visible_list(n_physical: int) -> int | None:
+    """How many devices the *_VISIBLE_DEVICES variables leave of ``n_physical``; None when none of them is set."""
+    for name in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(name)
+        if v is None:
+            continue
+        items = [x.strip() for x in v.split(",") if x.strip() != ""]
+        n = 0
+        for x in items:                                  # ordinals beyond the machine (or -1) end the list, as the runtime reads it
+            if x.lstrip("-").isdigit() and not (0 <= int(x) < n_physical):
+                break
+            n += 1
+        return min(n, n_physical)
+    return None
+
+
 def visible_gpus() -> int:
-    """Device count WITHOUT initialising HIP in this process (torch.cuda.device_count() does not, on this image)."""
+    """Device count WITHOUT loading HIP or torch into this process: the GPU nodes of /sys/class/kfd/kfd/topology (nodes with SIMDs),
+    narrowed by ROCR_/HIP_/CUDA_VISIBLE_DEVICES.  The probe's verdict — the environment RCCL came up with — is applied before the first
+    HIP call of every rank; a count taken through the runtime would have initialised HSA in rank 0 only, with the OLD environment.  Where
+    the topology cannot be read the count comes from torch.cuda.device_count(), which must then have left HIP uninitialised."""
+    base = KFD_NODES
+    try:
+        n = 0
+        for node in sorted(os.listdir(base)):
+            try:
+                with open(os.path.join(base, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) <= 0:
+                continue                                     # a CPU node
+            # a GPU of the machine that this container may not open (a slice of an 8-GPU node) is not ours
+            minor = int(props.get("drm_render_minor", "0"))
+            if minor > 0 and DRI_DIR and not os.access(os.path.join(DRI_DIR, "renderD%d" % minor), os.R_OK | os.W_OK):
+                continue
+            n += 1
+        if n > 0:
+            lim = _visible_list(n)
+            return n if lim is None else lim
+    except OSError:
+        pass
     import torch
-    return torch.cuda.device_count()
+    n = torch.cuda.device_count()
+    assert not torch.cuda.is_initialized(), "counting the devices initialised HIP: the RCCL probe's environment could no longer be applied"
+    return n
 
 
 def _run_group(cmd, env, timeout):
@@ -166,6 +210,8 @@ class RecordExchange:
         if self.world == 1 and not force:
             return self
         if self.want == "nccl" and _inject("exit", self.rank):
+            from . import launch
+            launch.mark_collective(self.rank, True)        # stands for a rank killed inside RCCL: the mark stays behind
             sys.stderr.write(f"rank {self.rank}: injected job failure (TWX_INJECT_RCCL_FAIL=exit:{self.rank})\n")
             sys.exit(3)
         import torch.distributed as dist
@@ -231,7 +277,9 @@ class RecordExchange:
         import torch.distributed as dist
         limit = float(os.environ.get("TWX_RCCL_INIT_TIMEOUT_S", "120")) if limit is None else limit
         if self.want == "nccl" and self.fallback is None:
+            from . import launch
             err = ""
+            launch.mark_collective(self.rank, True)        # (a process that dies in here is what the launcher's restart is for)
             try:
                 # (new_group is collective over the control plane: every rank enters it, whatever happens next)
                 self._data = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=max(limit, 30.0)), device_id=device)
@@ -253,6 +301,7 @@ class RecordExchange:
                 except Exception as e:                  # noqa: BLE001
                     err = f"{type(e).__name__}: {e}"[:300]
                 ok = self._agree(not err)
+            launch.mark_collective(self.rank, False)
             if ok:
                 self.backend = "nccl"
             else:
@@ -277,8 +326,11 @@ class RecordExchange:
         import torch
         import torch.distributed as dist
         if self.backend == "nccl":
+            from . import launch
+            launch.mark_collective(self.rank, True)
             dist.all_gather_into_tensor(gathered, local, group=self._data)
             torch.cuda.current_stream().synchronize()
+            launch.mark_collective(self.rank, False)
         else:
             host = torch.empty(gathered.shape, dtype=gathered.dtype)
             dist.all_gather_into_tensor(host, local.cpu(), group=self._ctl)

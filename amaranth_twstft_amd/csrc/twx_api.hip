@@ -1,6 +1,7 @@
 // twx_api.hip — C ABI (include/twstft_hip.h) of the TWSTFT correlator: context, plan choice,
 // twiddle tables, the per-batch kernel sequence and the inspection entry points.
 #include <hip/hip_runtime.h>
+#include <shared_mutex>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <math.h>
@@ -373,6 +374,7 @@ struct CtxBase {
     std::string err;
     int dev = 0;
     hipStream_t stream = nullptr;
+    int fir_mfma = -1;            // TWX_OPT_FIR_MFMA: -1 = follow TWX_FIR_MFMA of the environment, 0 = never, 1 = the matrix-core front end
     long long N = 0; int N1 = 0, N2 = 0, R = 1, B = 1;
     const ColOps* col = nullptr; const RowOps* row = nullptr;
     const ColOps* colinv = nullptr;          // the last pass's plan (choose_col_inv): col unless complex double needs a narrower tile
@@ -388,7 +390,7 @@ struct CtxBase {
         for (auto& p : allocs) (void)hipFree(p.first);
         for (auto& r : prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         for (auto e : ev_pool) (void)hipEventDestroy(e);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream) { twx::fence_unregister(dev, stream); (void)hipStreamDestroy(stream); }
     }
     int fail(int code, const std::string& msg) { err = msg; return code; }
     template <typename U> int dalloc(U** p, size_t count) {
@@ -779,6 +781,7 @@ template <typename T> struct Ctx : CtxBase {
         memset(slots, 0, sizeof slots);
         profile = (cfg.flags & TWX_FLAG_PROFILE) != 0;
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        twx::fence_register(dev, stream);          // (slots 1.. fork from and join this stream inside every call)
         R = cfg.nphase > 0 ? cfg.nphase : 2 * cfg.nint + 1;
         ntiles = N2 / col->W; ntiles_inv = N2 / colinv->W;
         if (cfg.max_batch > 0) B = cfg.max_batch;
@@ -1808,6 +1811,69 @@ int ctx_fail(twx_ctx* ctx, int code, const char* msg) { return ctx->impl->fail(c
 int ctx_set_device(twx_ctx* ctx) { return hipSetDevice(ctx->impl->dev) == hipSuccess ? TWX_OK : ctx->impl->fail(TWX_E_HIP, "hipSetDevice failed"); }
 std::vector<unsigned char>& ctx_scratch_shadow(twx_ctx* ctx, int slot) { return ctx->impl->aux_shadow[slot < 0 || slot >= AUX_SCRATCH_SLOTS ? 0 : slot]; }
 void* ctx_scratch(twx_ctx* ctx, int slot, size_t bytes) { return ctx->impl->scratch_slot(slot, bytes); }
+int ctx_device(twx_ctx* ctx) { return ctx->impl->dev; }
+int ctx_fir_mfma_option(twx_ctx* ctx) { return ctx->impl->fir_mfma; }
+
+// ---- device-wide fence around the matrix-core FIR (twx_internal.h) ----
+namespace {
+struct DeviceFence {
+    std::shared_mutex mu;                                  // shared: any enqueue; exclusive: a matrix-core FIR launch
+    std::mutex reg_mu;
+    std::vector<std::pair<hipStream_t, hipEvent_t>> streams;   // every stream the library created on this device + its marker event
+    hipEvent_t fir_ev = nullptr;                           // recorded behind the last matrix-core FIR (written under the exclusive lock)
+    std::atomic<int> fir_seen{0};
+};
+DeviceFence& fence_of(int dev) { static DeviceFence f[64]; return f[dev & 63]; }
+std::atomic<long long> g_mfma_launches{0};
+}  // namespace
+void fence_register(int dev, hipStream_t s) {
+    DeviceFence& f = fence_of(dev);
+    std::lock_guard<std::mutex> g(f.reg_mu);
+    for (auto& p : f.streams) if (p.first == s) return;
+    f.streams.push_back({s, nullptr});                     // the marker event is created by the first exclusive section that needs it
+}
+void fence_unregister(int dev, hipStream_t s) {
+    DeviceFence& f = fence_of(dev);
+    std::unique_lock<std::shared_mutex> x(f.mu);           // no launch in progress while a stream leaves
+    std::lock_guard<std::mutex> g(f.reg_mu);
+    for (size_t i = 0; i < f.streams.size(); ++i)
+        if (f.streams[i].first == s) { if (f.streams[i].second) (void)hipEventDestroy(f.streams[i].second); f.streams.erase(f.streams.begin() + (long)i); break; }
+}
+// entry points call each other (the tracked flow and the receiver run on the correlator's own entries): only the outermost section of a
+// thread takes the lock — a reader that re-enters behind a waiting writer would wait for itself
+static thread_local int t_fence_depth[64];
+FenceShared::FenceShared(int dev_, hipStream_t s) : dev(dev_) {
+    DeviceFence& f = fence_of(dev);
+    if (t_fence_depth[dev & 63]++ == 0) f.mu.lock_shared();
+    if (f.fir_seen.load(std::memory_order_acquire) && f.fir_ev) (void)hipStreamWaitEvent(s, f.fir_ev, 0);
+}
+FenceShared::~FenceShared() { if (--t_fence_depth[dev & 63] == 0) fence_of(dev).mu.unlock_shared(); }
+// TWX_FIR_MFMA_UNFENCED=1: DIAGNOSTIC ONLY — the launch is not ordered against anything (tools/chain_corunner.py needs the two
+// kernels resident together to show that TWX_OPT_SELFCHECK catches what then goes wrong)
+static bool fence_off() { const char* e = getenv("TWX_FIR_MFMA_UNFENCED"); return e && atoi(e) != 0; }
+FenceExclusive::FenceExclusive(int dev_, hipStream_t s_) : dev(dev_), s(s_) {
+    DeviceFence& f = fence_of(dev);
+    // (a thread inside a shared section of this device asks for the matrix-core FIR: its own section ends here, and resumes afterwards)
+    if (t_fence_depth[dev & 63] > 0) f.mu.unlock_shared();
+    f.mu.lock();
+    std::lock_guard<std::mutex> g(f.reg_mu);
+    if (fence_off()) return;
+    for (auto& p : f.streams) {
+        if (p.first == s) continue;
+        if (!p.second && hipEventCreateWithFlags(&p.second, hipEventDisableTiming) != hipSuccess) { p.second = nullptr; (void)hipGetLastError(); continue; }
+        if (hipEventRecord(p.second, p.first) == hipSuccess && hipStreamWaitEvent(s, p.second, 0) == hipSuccess) ++waited;
+        else (void)hipGetLastError();
+    }
+}
+FenceExclusive::~FenceExclusive() {
+    DeviceFence& f = fence_of(dev);
+    if (!fence_off() && !f.fir_ev && hipEventCreateWithFlags(&f.fir_ev, hipEventDisableTiming) != hipSuccess) { f.fir_ev = nullptr; (void)hipGetLastError(); }
+    if (!fence_off() && f.fir_ev) { (void)hipEventRecord(f.fir_ev, s); f.fir_seen.store(1, std::memory_order_release); }
+    g_mfma_launches.fetch_add(1);
+    f.mu.unlock();
+    if (t_fence_depth[dev & 63] > 0) f.mu.lock_shared();
+}
+long long fence_mfma_launches() { return g_mfma_launches.load(); }
 }  // namespace twx
 
 // No exception may cross the C boundary (std::async, std::vector and std::string can throw).
@@ -1815,7 +1881,10 @@ template <class F> static int guarded(CtxBase* c, F f) noexcept {
     // the launches of this library are checked with hipGetLastError(): an error another library left behind on this thread
     // (RCCL and PyTorch probe pointers and peers and do not clear what those probes set) must not be taken for ours
     (void)hipGetLastError();
-    try { return f(); }
+    try {
+        if (c && c->stream) { twx::FenceShared fence(c->dev, c->stream); return f(); }      // never beside a matrix-core FIR (twx_internal.h)
+        return f();
+    }
     catch (const std::bad_alloc&) { return c ? c->fail(TWX_E_NOMEM, "out of host memory") : TWX_E_NOMEM; }
     catch (const std::exception& e) { return c ? c->fail(TWX_E_STATE, std::string("internal error: ") + e.what()) : TWX_E_STATE; }
     catch (...) { return c ? c->fail(TWX_E_STATE, "internal error") : TWX_E_STATE; }
@@ -1935,6 +2004,7 @@ int twx_set_option(twx_ctx* ctx, int32_t option, int64_t value) {
     if (!ctx) return TWX_E_ARG;
     if (option == TWX_OPT_REMOVE_MEAN) { (void)ctx->impl->sync_all(); ctx->impl->remove_mean = value ? 1 : 0; return TWX_OK; }
     if (option == TWX_OPT_DEBUG_ONLY) { if (value > PC_PEAK) return ctx->impl->fail(TWX_E_ARG, "no such kernel class"); ctx->impl->dbg_only = value < 0 ? -1 : (int)value; return TWX_OK; }
+    if (option == TWX_OPT_FIR_MFMA) { ctx->impl->fir_mfma = value < 0 ? -1 : (value ? 1 : 0); return TWX_OK; }
     if (option == TWX_OPT_DEBUG_REPEAT) { ctx->impl->dbg_repeat = (int)std::max<long long>(1, std::min<long long>(value, 1000000)); return TWX_OK; }
     return ctx->impl->fail(TWX_E_ARG, "unknown option");
 }

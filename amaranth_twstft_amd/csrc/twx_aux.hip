@@ -1106,10 +1106,10 @@ __global__ __launch_bounds__(FM_NT, 4) void k_fir_mfma(const short2* __restrict_
 // of the library without packed-fp32 instructions is immune.  Not a race, not stale data, nothing either source shows: v_pk_*_f32 results
 // of one wave go wrong while this kernel's waves are resident beside it.  So the form stays opt-in for callers that run nothing else on
 // the GPU at the time.
-bool fir_use_mfma(int ntaps, int dec, long long nout) {
+bool fir_use_mfma(int ntaps, int dec, long long nout, int ctx_option = -1) {
     const char* fe = getenv("TWX_FIR_MFMA");          // read per call: tests switch it inside one process
-    const int force = fe ? atoi(fe) : -1;
-    if (force == 0) return false;
+    const int force = ctx_option >= 0 ? ctx_option : (fe ? atoi(fe) : -1);     // TWX_OPT_FIR_MFMA of the context wins over the environment
+    if (force <= 0) return false;
     const FirMfmaGeom g = fir_mfma_geom(ntaps, dec);
     if (!g.ok) return false;
     (void)nout;
@@ -1124,9 +1124,9 @@ std::vector<float> fir_phase_table(const float* taps, int ntaps, int dec, const 
 }
 // the table a call uploads: the matrix-core form's A fragments or the vector forms' phase-major taps (FirTable::mfma says which)
 struct FirTable { std::vector<float> words; bool mfma = false; float inv_scale = 1.f; };
-FirTable fir_table(const float* taps, int ntaps, int dec, long long nout) {
+FirTable fir_table(const float* taps, int ntaps, int dec, long long nout, int ctx_option = -1) {
     FirTable t;
-    t.mfma = fir_use_mfma(ntaps, dec, nout);
+    t.mfma = fir_use_mfma(ntaps, dec, nout, ctx_option);
     if (t.mfma) t.words = fir_mfma_table(taps, ntaps, dec, fir_mfma_geom(ntaps, dec), &t.inv_scale);
     else t.words = fir_phase_table(taps, ntaps, dec, fir_geom(ntaps, dec));
     return t;
@@ -1167,7 +1167,14 @@ int launch_fir_mfma(hipStream_t st, const short2* dx, int nch, long long nin, co
 }
 int launch_fir(hipStream_t st, const short2* dx, int nch, long long nin, const float* hp_dev, int ntaps, int dec, long long nout,
                short2* dy16, float2* dyf, int ch = 0, bool mfma = false, float inv_scale = 1.f) {            // dx: the channel's sample of frame 0; ch: its place in the frame
-    if (mfma) return launch_fir_mfma(st, dx, nch, nin, hp_dev, ntaps, dec, inv_scale, nout, dy16, dyf, ch);
+    if (mfma) {
+        // never beside other work of this process on the device (twx_internal.h): ordered behind everything enqueued so far on every
+        // other stream of the library, and everything enqueued later waits for it
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        twx::FenceExclusive fence(cur, st);
+        return launch_fir_mfma(st, dx, nch, nin, hp_dev, ntaps, dec, inv_scale, nout, dy16, dyf, ch);
+    }
     const FirGeom g = fir_geom(ntaps, dec);
     // The dynamic-LDS limit is an attribute of the function ON A DEVICE: one bit per device (contexts on several devices and host
     // threads — twx_multi — may get here together; the attribute call is idempotent)
@@ -1267,7 +1274,7 @@ static int twx_fir_decimate_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n
     if (int rc = twx::ctx_set_device(ctx)) return rc;
     const long long nout = (n_in - ntaps) / dec + 1;
     *n_out = nout;
-    const FirTable ft = fir_table(taps, ntaps, dec, nout);
+    const FirTable ft = fir_table(taps, ntaps, dec, nout, twx::ctx_fir_mfma_option(ctx));
     const std::vector<float>& hp = ft.words;
     // the table lives in a context-owned buffer; the copy is ordered on the context's stream like the kernel
     float* hp_dev = static_cast<float*>(twx::ctx_scratch(ctx, 1, hp.size() * sizeof(float)));
@@ -1350,11 +1357,14 @@ static int twx_track_epoch_dev_impl(twx_ctx* ctx, const void* iq_dev, int64_t n_
 }
 
 // No exception may cross the C boundary.
-template <class F> static int aux_guard(F f) noexcept {
+template <class F> static int aux_guard(F f, twx_ctx* ctx = nullptr) noexcept {
     // the launches of this library are checked with hipGetLastError(): an error another library left behind on this thread
     // (RCCL and PyTorch probe pointers and peers and do not clear what those probes set) must not be taken for ours
     (void)hipGetLastError();
-    try { return f(); }
+    try {
+        if (ctx) { twx::FenceShared fence(twx::ctx_device(ctx), twx::ctx_stream(ctx)); return f(); }     // never beside a matrix-core FIR (twx_internal.h)
+        return f();
+    }
     catch (const std::bad_alloc&) { return TWX_E_NOMEM; }
     catch (...) { return TWX_E_STATE; }
 }
@@ -1362,19 +1372,19 @@ template <class F> static int aux_guard(F f) noexcept {
 extern "C" {
 int twx_sliding_dot_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t pt, int64_t nobs,
                         int32_t ncodes, int32_t nlag, const float* replica_dev, double ff, double phi, double scale, double* out_dev) {
-    return aux_guard([&]() { return twx_sliding_dot_dev_impl(ctx, iq_dev, n_samples, n_channels, channel, pt, nobs, ncodes, nlag, replica_dev, ff, phi, scale, out_dev); });
+    return aux_guard([&]() { return twx_sliding_dot_dev_impl(ctx, iq_dev, n_samples, n_channels, channel, pt, nobs, ncodes, nlag, replica_dev, ff, phi, scale, out_dev); }, ctx);
 }
 int twx_sliding_dot_cdev(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, int64_t pt, int64_t nobs, int32_t ncodes, int32_t nlag,
                          const float* replica_dev, double ff, double phi, double scale, double* out_dev) {
-    return aux_guard([&]() { return twx_sliding_dot_cdev_impl(ctx, smp_dev, n_samples, pt, nobs, ncodes, nlag, replica_dev, ff, phi, scale, out_dev); });
+    return aux_guard([&]() { return twx_sliding_dot_cdev_impl(ctx, smp_dev, n_samples, pt, nobs, ncodes, nlag, replica_dev, ff, phi, scale, out_dev); }, ctx);
 }
 int twx_track_epoch_cdev(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, int64_t nobs, int32_t bps, int32_t nlag, const float* replica_dev,
                          double scale, twx_track_state* state, twx_track_result* out) {
-    return aux_guard([&]() { return twx_track_epoch_dev_impl(ctx, smp_dev, n_samples, 1, 0, nobs, bps, nlag, replica_dev, scale, state, out, true); });
+    return aux_guard([&]() { return twx_track_epoch_dev_impl(ctx, smp_dev, n_samples, 1, 0, nobs, bps, nlag, replica_dev, scale, state, out, true); }, ctx);
 }
 int twx_track_epoch_cdev_mai(twx_ctx* ctx, const void* smp_dev, int64_t n_samples, int64_t nobs, int32_t bps, int32_t nlag, const float* replica_dev,
                              double scale, twx_track_state* state, twx_track_result* out, const twx_track_mai* mai) {
-    return aux_guard([&]() { return twx_track_epoch_dev_impl(ctx, smp_dev, n_samples, 1, 0, nobs, bps, nlag, replica_dev, scale, state, out, true, mai); });
+    return aux_guard([&]() { return twx_track_epoch_dev_impl(ctx, smp_dev, n_samples, 1, 0, nobs, bps, nlag, replica_dev, scale, state, out, true, mai); }, ctx);
 }
 int twx_track_update_mai(const double* cor, const double* phi, int32_t bps, int32_t nlag, int64_t nobs, twx_track_state* state, twx_track_result* out,
                          const twx_track_mai* mai) {
@@ -1382,14 +1392,14 @@ int twx_track_update_mai(const double* cor, const double* phi, int32_t bps, int3
 }
 int twx_fir_decimate_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_in, int32_t n_channels, int32_t channel, const float* taps, int32_t ntaps,
                          int32_t dec, void* out_i16_dev, void* out_f32_dev, int64_t* n_out) {
-    return aux_guard([&]() { return twx_fir_decimate_dev_impl(ctx, iq_dev, n_in, n_channels, channel, taps, ntaps, dec, out_i16_dev, out_f32_dev, n_out); });
+    return aux_guard([&]() { return twx_fir_decimate_dev_impl(ctx, iq_dev, n_in, n_channels, channel, taps, ntaps, dec, out_i16_dev, out_f32_dev, n_out); }, ctx);
 }
 int twx_track_update(const double* cor, const double* phi, int32_t bps, int32_t nlag, twx_track_state* state, twx_track_result* out) {
     return aux_guard([&]() { return track_update_impl(cor, phi, bps, nlag, state, out); });
 }
 int twx_track_epoch_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t nobs,
                         int32_t bps, int32_t nlag, const float* replica_dev, double scale, twx_track_state* state, twx_track_result* out) {
-    return aux_guard([&]() { return twx_track_epoch_dev_impl(ctx, iq_dev, n_samples, n_channels, channel, nobs, bps, nlag, replica_dev, scale, state, out); });
+    return aux_guard([&]() { return twx_track_epoch_dev_impl(ctx, iq_dev, n_samples, n_channels, channel, nobs, bps, nlag, replica_dev, scale, state, out); }, ctx);
 }
 int twx_sliding_dot(const int16_t* iq, int64_t n_samples, int32_t n_channels, int32_t channel, int64_t pt, int64_t nobs,
                     int32_t ncodes, int32_t nlag, const float* replica, double ff, double phi, double scale, double* out) {

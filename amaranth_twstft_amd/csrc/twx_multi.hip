@@ -96,6 +96,10 @@ struct Rccl {
 };
 Rccl& rccl() { static Rccl r; return r; }
 std::mutex& rccl_mu() { static std::mutex m; return m; }
+// An ncclCommInitAll that never returned leaves a thread of this process inside RCCL's bootstrap: a second one beside it would most
+// likely hang the same way (another 120 s) and share state with the abandoned one.  From then on every twx_multi_create of the
+// process skips RCCL at once, with the same reason (guarded by rccl_mu).
+std::string& rccl_unusable() { static std::string why; return why; }
 
 using twx::Worker;               // one persistent host thread per context (twx_workers.h: plain C++, run under -fsanitize=thread on the CPU)
 
@@ -171,19 +175,22 @@ struct twx_multi {
     // RCCL is given up for the rest of this object's life: the exchange continues as host-side concatenation (flagged, never silent)
     void give_up_rccl(int why, const std::string& text, bool abort_comms) {
         Rccl& R = rccl();
+        int leaked = 0;
         for (int r = 0; r < (int)comms.size(); ++r) {
             if (!comms[r]) continue;
             (void)hipSetDevice(devices[r]);
             // a communicator with a collective still in flight is aborted, never destroyed (ncclCommDestroy would wait for it);
             // without ncclCommAbort it is left alone
-            if (abort_comms) { if (R.CommAbort) (void)R.CommAbort(comms[r]); }
+            if (abort_comms) { if (R.CommAbort) (void)R.CommAbort(comms[r]); else ++leaked; }
             else (void)R.CommDestroy(comms[r]);
             comms[r] = nullptr;
         }
         comms.clear();
         use_rccl = false;
         info.rccl = 0; info.rccl_fallback = why;
-        snprintf(info.rccl_error, sizeof(info.rccl_error), "%s", text.c_str());
+        std::string t = text;
+        if (leaked) t += " (" + std::to_string(leaked) + " communicators with a collective in flight left alone: this RCCL has no ncclCommAbort)";
+        snprintf(info.rccl_error, sizeof(info.rccl_error), "%s", t.c_str());
     }
     // send_dev[r] holds `block` records on every device -> recv_dev[r] holds n*block on every device (one collective).
     // false: RCCL failed or timed out and has been given up (give_up_rccl); the caller continues on the host path.
@@ -229,6 +236,45 @@ struct twx_multi {
         info.gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         info.records_gathered = (int64_t)(block * n); info.bytes_per_rank = (int64_t)(block * sizeof(twx_result));
         return true;
+    }
+    // send_dev[r] (block records each, complete) -> recv_dev[r] on every device, and `out` on the host: all n*block records in
+    // context order, or — counts given — only the first counts[r]*per of every block, packed (a sharded recording: window order)
+    int exchange_dev(size_t block, const std::vector<long long>* counts, twx_result* out, int per = 1) {
+        auto pack = [&](const twx_result* all) {
+            if (!out) return;
+            if (!counts) { memcpy(out, all, block * n * sizeof(twx_result)); return; }
+            size_t o = 0;
+            for (int r = 0; r < n; ++r) { const size_t k = (size_t)(*counts)[r] * per; memcpy(out + o, all + (size_t)r * block, k * sizeof(twx_result)); o += k; }
+        };
+        if (use_rccl && all_gather(block)) {
+            if (out) {
+                (void)hipSetDevice(devices[0]);
+                if (!counts) {
+                    if (hipMemcpy(out, recv_dev[0], block * n * sizeof(twx_result), hipMemcpyDeviceToHost) != hipSuccess) return fail(TWX_E_HIP, "gathered records D2H failed");
+                } else {
+                    std::vector<twx_result> all(block * n);
+                    if (hipMemcpy(all.data(), recv_dev[0], all.size() * sizeof(twx_result), hipMemcpyDeviceToHost) != hipSuccess) return fail(TWX_E_HIP, "gathered records D2H failed");
+                    pack(all.data());
+                }
+            }
+            return TWX_OK;
+        }
+        // host-side concatenation (repeated devices, TWX_MULTI_NO_RCCL, or RCCL given up — possibly just now, by all_gather);
+        // every context's "gathered" buffer is filled from it so that both modes leave the same state
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<twx_result> all(block * n);
+        for (int r = 0; r < n; ++r) {
+            (void)hipSetDevice(devices[r]);
+            if (hipMemcpy(all.data() + (size_t)r * block, send_dev[r], block * sizeof(twx_result), hipMemcpyDeviceToHost) != hipSuccess) return fail(TWX_E_HIP, "record D2H failed");
+        }
+        for (int r = 0; r < n; ++r) {
+            (void)hipSetDevice(devices[r]);
+            if (hipMemcpy(recv_dev[r], all.data(), all.size() * sizeof(twx_result), hipMemcpyHostToDevice) != hipSuccess) return fail(TWX_E_HIP, "record H2D failed");
+        }
+        pack(all.data());
+        info.gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();     // the exchange as it ran: copies through the host
+        info.records_gathered = (int64_t)all.size(); info.bytes_per_rank = (int64_t)(block * sizeof(twx_result));
+        return TWX_OK;
     }
     // the blocks local[r][0 .. counts[r]*per) -> out (blocks in rank order, no padding); through the devices when RCCL is on
     int gather_host_blocks(const std::vector<long long>& counts, int per, twx_result* out) {
@@ -339,7 +385,8 @@ static int multi_create_impl(const twx_config* cfg, const int32_t* devices, int3
         std::lock_guard<std::mutex> g(rccl_mu());
         Rccl& R = rccl();
         std::string why;
-        if (!R.load()) why = R.err;
+        if (!rccl_unusable().empty()) why = rccl_unusable() + " (an earlier twx_multi_create of this process; RCCL is not tried again)";
+        else if (!R.load()) why = R.err;
         else if (inject("init")) why = "ncclCommInitAll failed: injected failure (TWX_MULTI_INJECT=init)";
         else {
             // ncclCommInitAll on its own thread with a deadline: a bootstrap that never returns (a peer's IPC handle that cannot be
@@ -365,6 +412,7 @@ static int multi_create_impl(const twx_config* cfg, const int32_t* devices, int3
                 char b[160];
                 snprintf(b, sizeof(b), "ncclCommInitAll did not return within %.1f s%s", limit, hang ? " (injected: TWX_MULTI_INJECT=init_hang)" : "");
                 why = b;
+                if (!hang) rccl_unusable() = why;           // (the injected hang is a sleeping thread, not RCCL state: later creates may try)
             } else if (st->rc != ncclSuccess) {
                 why = std::string("ncclCommInitAll failed: ") + R.GetErrorString(st->rc);
                 if (!st->last.empty()) why += " - " + st->last;
@@ -464,31 +512,49 @@ int twx_multi_process_windows_dev(twx_multi* m, const void* const* iq_dev, int64
             return e ? e : twx_synchronize(m->ctx[r]);                 // records complete before the collective reads them
         });
         if (rc) return rc;
-        bool done = false;
-        if (m->use_rccl && m->all_gather(block)) {
-            if (out) {
-                (void)hipSetDevice(m->devices[0]);
-                if (hipMemcpy(out, m->recv_dev[0], block * m->n * sizeof(twx_result), hipMemcpyDeviceToHost) != hipSuccess) return m->fail(TWX_E_HIP, "gathered records D2H failed");
-            }
-            done = true;
-        }
-        if (!done) {
-            // host-side concatenation (repeated devices, TWX_MULTI_NO_RCCL, or RCCL given up — possibly just now, by all_gather);
-            // every context's "gathered" buffer is filled from it so that both modes leave the same state
-            std::vector<twx_result> all(block * m->n);
-            for (int r = 0; r < m->n; ++r) {
-                (void)hipSetDevice(m->devices[r]);
-                if (hipMemcpy(all.data() + (size_t)r * block, m->send_dev[r], block * sizeof(twx_result), hipMemcpyDeviceToHost) != hipSuccess) return m->fail(TWX_E_HIP, "record D2H failed");
-            }
-            for (int r = 0; r < m->n; ++r) {
-                (void)hipSetDevice(m->devices[r]);
-                if (hipMemcpy(m->recv_dev[r], all.data(), all.size() * sizeof(twx_result), hipMemcpyHostToDevice) != hipSuccess) return m->fail(TWX_E_HIP, "record H2D failed");
-            }
-            if (out) memcpy(out, all.data(), all.size() * sizeof(twx_result));
-            m->info.gather_ms = 0; m->info.records_gathered = (int64_t)all.size(); m->info.bytes_per_rank = (int64_t)(block * sizeof(twx_result));
-        }
-        return TWX_OK;
+        return m->exchange_dev(block, nullptr, out);
     });
+}
+
+// BASELINE.json configs[3] as written (godual_ranging.m:75-102: one recording, consecutive windows): n_windows_total windows of ONE
+// recording, context r owning the contiguous block shard(total, r, n) whose first window sits at iq_block_dev[r] on its device.
+// Blocks differ by at most one window: the gather runs on blocks padded to the longest, `out` is compact, in window order.
+int twx_multi_block(const twx_multi* m, int64_t n_windows_total, int32_t i, int64_t* start, int64_t* count) {
+    if (!m || i < 0 || i >= m->n || n_windows_total < 0) return TWX_E_ARG;
+    long long s0 = 0, c0 = 0;
+    twx_multi::shard(n_windows_total, i, m->n, &s0, &c0);
+    if (start) *start = s0;
+    if (count) *count = c0;
+    return TWX_OK;
+}
+int twx_multi_process_recording_dev(twx_multi* m, const void* const* iq_block_dev, int64_t n_windows_total, int32_t n_channels, int32_t channel,
+                                    const twx_band* band, const double* df, twx_result* out) {
+    if (!m) return TWX_E_ARG;
+    if (!iq_block_dev || n_windows_total < 1 || n_channels < 1 || channel < TWX_ALL_CHANNELS || channel >= n_channels || (!band && !df)) return m->fail(TWX_E_ARG, "bad argument");
+    return multi_guard(m, [&]() -> int {
+        const size_t per = channel < 0 ? n_channels : 1;
+        std::vector<long long> start(m->n), count(m->n);
+        long long mx = 0;
+        for (int r = 0; r < m->n; ++r) { twx_multi::shard(n_windows_total, r, m->n, &start[r], &count[r]); mx = std::max(mx, count[r]); }
+        const size_t block = (size_t)mx * per;
+        if (int rc = m->ensure_gather(block)) return rc;
+        int rc = m->run_all([&](int r) -> int {
+            if (count[r] == 0) return TWX_OK;
+            if (!iq_block_dev[r]) return TWX_E_ARG;
+            const int e = twx_process_windows_dev(m->ctx[r], iq_block_dev[r], count[r], n_channels, channel, band, df ? df + start[r] * (long long)per : nullptr,
+                                                  static_cast<twx_result*>(m->send_dev[r]));
+            return e ? e : twx_synchronize(m->ctx[r]);                 // records complete before the collective reads them
+        });
+        if (rc) return rc;
+        return m->exchange_dev(block, &count, out, (int)per);
+    });
+}
+// The exchange alone, on whatever the last device-resident call left in the contexts' send buffers (compute removed): what one
+// step of a sharded recording pays for its gather.  gather_ms of twx_multi_get_info holds its wall time.
+int twx_multi_exchange_only(twx_multi* m, int64_t records_per_context) {
+    if (!m) return TWX_E_ARG;
+    if (records_per_context < 1 || (size_t)records_per_context > m->cap_records) return m->fail(TWX_E_ARG, "no device-resident call has left that many records in the send buffers");
+    return multi_guard(m, [&]() -> int { return m->exchange_dev((size_t)records_per_context, nullptr, nullptr); });
 }
 
 // NUMA placement of a device, and binding the calling thread next to it (what the twx_multi workers do for themselves; the

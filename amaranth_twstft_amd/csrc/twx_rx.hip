@@ -191,7 +191,7 @@ struct twx_rx {
         for (auto& kv : acq_ctx) twx_destroy(kv.second);
         if (interp) twx_destroy(interp);
         for (void* p : {(void*)iq_dev, (void*)smp[0], (void*)smp[1], (void*)part_dev, (void*)mai_free}) if (p) (void)hipFree(p);
-        if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (own_stream) { twx::fence_unregister(dev, own_stream); (void)hipStreamDestroy(own_stream); }
     }
     hipStream_t stream() const { return interp ? (hipStream_t)twx_stream(interp) : own_stream; }
     void log_line(const char* text) const {
@@ -340,6 +340,7 @@ struct twx_rx {
         }
         if (real) {                                                                   // rx.cpp: no interpolation, the samples as they come
             if (hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking) != hipSuccess) return fail(TWX_E_HIP, "stream creation failed");
+            twx::fence_register(dev, own_stream);
             if (any_sic && hipMalloc((void**)&mai_free, (size_t)sps * 8) != hipSuccess) return fail(TWX_E_NOMEM, "device allocation failed (interference-free stream)");
         } else {
         // interpolator: the fused chain with two output phases and short2double's weights as replica spectrum
@@ -478,7 +479,10 @@ template <class F> static int rx_guard(twx_rx* rx, F f) noexcept {
     // the launches of this library are checked with hipGetLastError(): an error another library left behind on this thread
     // (RCCL and PyTorch probe pointers and peers and do not clear what those probes set) must not be taken for ours
     (void)hipGetLastError();
-    try { return f(); }
+    try {
+        if (rx && rx->stream()) { twx::FenceShared fence(rx->dev, rx->stream()); return f(); }      // never beside a matrix-core FIR (twx_internal.h)
+        return f();
+    }
     catch (const std::bad_alloc&) { return rx ? rx->fail(TWX_E_NOMEM, "out of host memory") : TWX_E_NOMEM; }
     catch (const std::exception& e) { return rx ? rx->fail(TWX_E_STATE, std::string("internal error: ") + e.what()) : TWX_E_STATE; }
     catch (...) { return rx ? rx->fail(TWX_E_STATE, "internal error") : TWX_E_STATE; }

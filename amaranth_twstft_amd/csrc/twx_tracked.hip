@@ -319,7 +319,10 @@ template <class F> static int trk_guard(twx_tracked* t, F f) noexcept {
     // the launches of this library are checked with hipGetLastError(): an error another library left behind on this thread
     // (RCCL and PyTorch probe pointers and peers and do not clear what those probes set) must not be taken for ours
     (void)hipGetLastError();
-    try { return f(); }
+    try {
+        if (t && t->ctx) { twx::FenceShared fence(twx::ctx_device(t->ctx), twx::ctx_stream(t->ctx)); return f(); }     // never beside a matrix-core FIR (twx_internal.h)
+        return f();
+    }
     catch (const std::bad_alloc&) { if (t) t->err = "out of host memory"; return TWX_E_NOMEM; }
     catch (const std::exception& e) { if (t) t->err = std::string("internal error: ") + e.what(); return TWX_E_STATE; }
     catch (...) { if (t) t->err = "internal error"; return TWX_E_STATE; }

@@ -89,7 +89,9 @@ class EplTracker:
         filtered_code_phase_error = self.T_blk * self.B_DLL / .25 * code_phase_error          # :193
         measured_code_phase = self.code_phase + code_phase_error
         filtered_code_phase = self.code_phase + filtered_code_phase_error
-        delta_theta = math.atan(zp.imag / zp.real) / (2 * math.pi)                             # :201
+        # Octave: atan(y/0) = +-pi/2 (and NaN for 0/0), where Python's division raises
+        ratio = zp.imag / zp.real if zp.real != 0 else (math.copysign(math.inf, zp.imag) if zp.imag != 0 else math.nan)
+        delta_theta = math.atan(ratio) / (2 * math.pi)                                          # :201
         sortie = math.atan2(zp.imag, zp.real) / (2 * math.pi)                                   # :202
         doppler_freq_error = self.T_blk / 2 * delta_theta                                       # :204
         filtered_carrier_phase_error = (2 * self.zeta * self.omega_n * self.T_blk - 3 / 2 * self.omega_n ** 2 * self.T_blk ** 2) * delta_theta   # :210

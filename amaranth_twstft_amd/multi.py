@@ -151,6 +151,32 @@ class MultiCorrelator:
                                                             out.ctypes.data_as(C.c_void_p) if fetch else None))
         return out
 
+    def block(self, n_windows_total: int, i: int) -> tuple[int, int]:
+        """(start, count) of context ``i``'s contiguous block of a recording of ``n_windows_total`` windows (``dist.shard_windows``)."""
+        s, c = C.c_int64(), C.c_int64()
+        self._check(self._lib.twx_multi_block(self._h, int(n_windows_total), int(i), C.byref(s), C.byref(c)))
+        return int(s.value), int(c.value)
+
+    def process_recording_dev(self, iq_block_ptrs, n_windows_total: int, n_channels=1, channel=0, band=None, df=None, fetch: bool = True):
+        """BASELINE.json configs[3] as written: ONE recording of ``n_windows_total`` windows, context i holding its block
+        (:meth:`block`) at ``iq_block_ptrs[i]`` on its device; one exchange; returns the records in window order as a uint8
+        array [n_windows_total*(channels), sizeof(twx_result)] (``fetch=False``: nothing, timing loops)."""
+        ptrs = (C.c_void_p * self.n_contexts)(*[int(p) if p else None for p in iq_block_ptrs])
+        per = n_channels if channel < 0 else 1
+        dptr = None
+        if band is None:
+            dfa = np.ascontiguousarray(np.broadcast_to(np.asarray(df, dtype=np.float64), (n_windows_total * per,)))
+            dptr = dfa.ctypes.data_as(C.c_void_p)
+        out = np.empty((n_windows_total * per, C.sizeof(L.twx_result)), dtype=np.uint8) if fetch else None
+        self._check(self._lib.twx_multi_process_recording_dev(self._h, C.cast(ptrs, C.c_void_p), n_windows_total, n_channels, channel, self._band(band), dptr,
+                                                              out.ctypes.data_as(C.c_void_p) if fetch else None))
+        return out
+
+    def exchange_only(self, records_per_context: int) -> float:
+        """The record exchange alone on what the last device-resident call left in the send buffers; returns its wall time in ms."""
+        self._check(self._lib.twx_multi_exchange_only(self._h, int(records_per_context)))
+        return float(self.info.gather_ms)
+
     def fetch_gathered(self, i: int, n_records: int) -> np.ndarray:
         """Context ``i``'s copy of the gathered records of the last :meth:`process_dev`."""
         out = np.empty((n_records, C.sizeof(L.twx_result)), dtype=np.uint8)

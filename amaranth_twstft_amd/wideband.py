@@ -56,6 +56,11 @@ class WidebandSession:
             self.plan = plan
             for k, (_, code_st, _) in plan.items():
                 self.ctx[k] = Correlator(codes[code_st], fs=fs, Nint=1, device=device, precision=precision, **ctx_kw)
+            # the front end of step i+1 runs beside the correlations of step i BY DESIGN: the matrix-core form of the FIR, which makes
+            # packed-fp32 arithmetic of co-resident waves go wrong, is ruled out here whatever TWX_FIR_MFMA says (the library would
+            # serialise it against the correlations anyway: csrc/twx_internal.h) — the session always runs the vector form
+            for c in self.ctx.values():
+                L.check(self.lib.twx_set_option(c._h, L.TWX_OPT_FIR_MFMA, 0), c._h)
             self.N = next(iter(self.ctx.values())).n
             if any(c.n != self.N for c in self.ctx.values()):
                 raise ValueError("the codes of a session must have one length")

@@ -259,6 +259,54 @@ def single_process(a, t_start):
     other = "xcorr" if a.workload == "processing" else "processing"
     step(other)
     dt_other = timed(other)
+    # --- BASELINE.json configs[3] as written: ONE nwin-window recording sharded over the contexts (twx_multi_process_recording_dev)
+    strong = None
+    if world > 1:
+        blocks = [m.block(nwin, r) for r in range(world)]
+        cap = max(c for _, c in blocks)
+        sblk = []
+        for r, (s0, c0) in enumerate(blocks):
+            devr = torch.device("cuda", devices[r])
+            torch.cuda.set_device(devr)
+            cd = torch.from_numpy(chips).to(devr)
+            t = torch.empty((max(c0, 1), N, 2), dtype=torch.int16, device=devr)
+            for i in range(c0):
+                sp, _ = window_params(s0 + i, 0)
+                params = np.array([sp.delay_q8, sp.fstep, sp.phi0, sp.amp, sp.noise_gain, sp.seed, sp.stream, 0], dtype=np.int64)
+                L.check(lib.twx_synth_capture_dev(t[i].data_ptr(), N, 0, cd.data_ptr(), NCHIPS, 2, 1, params.ctypes.data_as(C.c_void_p), None))
+            torch.cuda.synchronize(devr)
+            sblk.append(t)
+        sptr = [t.data_ptr() for t in sblk]
+        sstep = lambda fetch=False: m.process_recording_dev(sptr, nwin, band=band if a.workload == "processing" else None,
+                                                            df=None if a.workload == "processing" else df_true, fetch=fetch)
+        for _ in range(max(1, a.warmup)):
+            sstep()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            sstep()
+        sdt = time.perf_counter() - t0
+        gms = [m.exchange_only(cap) for _ in range(max(5, a.steps))]
+        sgot = sstep(True)
+        sarr = (L.twx_result * nwin).from_buffer_copy(sgot.tobytes())
+        sinfo = m.info
+        s_rank = [all(int(sarr[s0 + i].indice0) == 3 * window_params(s0 + i, 0)[1] for i in range(c0)) for s0, c0 in blocks]
+        # every context's device copy of the (padded) gather holds every rank's block
+        s_copies = []
+        for r in range(world):
+            g = m.fetch_gathered(r, world * cap).reshape(world, cap, -1)
+            s_copies.append(all(g[q, :blocks[q][1]].tobytes() == sgot[blocks[q][0]:blocks[q][0] + blocks[q][1]].tobytes() for q in range(world)))
+        svalue = nwin * N * a.steps / sdt / 1e6
+        strong = {"workload": f"BASELINE.json configs[3] as written: ONE {nwin}-window recording sharded over {world} contexts (contiguous blocks of "
+                              f"{min(c for _, c in blocks)}..{cap} windows, HBM-resident), "
+                              + ("processing(d,k) full chain" if a.workload == "processing" else "xcorr, df supplied")
+                              + ", one exchange of the 240-byte records per step (twx_multi_process_recording_dev)",
+                  "scaling": "strong", "value": round(svalue, 2), "unit": "Msamples/s", "ms_per_step": round(sdt / a.steps * 1e3, 3), "steps": a.steps,
+                  "windows_total": nwin, "windows_per_rank": [c for _, c in blocks],
+                  "gather_ms": round(float(np.median(gms)), 3), "gather_ms_note": "the exchange alone (twx_multi_exchange_only: the compute removed), median of %d" % len(gms),
+                  "ratio_to_weak_headline": round(svalue / (world * nwin * N * a.steps / dt / 1e6), 4),
+                  "collective": {"backend": "rccl" if sinfo.rccl else "host", "bytes_per_rank": int(sinfo.bytes_per_rank), "records": int(sinfo.records_gathered)},
+                  "ranks_with_exact_lags": int(sum(s_rank)), "all_ranks_agree": bool(all(s_rank) and all(s_copies))}
+        del sblk
     got = step(a.workload, fetch=True)
     info = m.info
     arr = (L.twx_result * (world * nwin)).from_buffer_copy(got.tobytes())
@@ -289,6 +337,8 @@ def single_process(a, t_start):
                           "ranks_with_exact_lags": int(sum(per_rank)), "gathered_lag_exact": bool(all(per_rank)),
                           "own_block_identical": bool(all(copies)), "all_ranks_agree": bool(all(copies) and all(per_rank)),
                           "note": "every context's device copy of the gathered buffer was fetched and compared"}}
+    if strong is not None:
+        out["strong_workload"] = strong
     print(json.dumps(out))
     m.close()
 
@@ -412,7 +462,7 @@ def wideband_legs(local_rank: int, seconds: int = 4, steps: int = 5):
     fir_mc = None
     try:
         vec_out = sess.nar["OP"][0].clone()
-        os.environ["TWX_FIR_MFMA"] = "1"
+        L.check(lib.twx_set_option(c32["OPlo"]._h, L.TWX_OPT_FIR_MFMA, 1), c32["OPlo"]._h)     # (the session set it to 0 on its contexts)
         c32["OPlo"].fir_decimate_dev(wptr["OP"], n_in, taps, dec, out_i16_dev=sess.nar["OP"][0].data_ptr())
         e0.record(es)
         for _ in range(5):
@@ -421,15 +471,16 @@ def wideband_legs(local_rank: int, seconds: int = 4, steps: int = 5):
         e1.synchronize()
         mc_ms = e0.elapsed_time(e1) / 5
         same = int((sess.nar["OP"][0].to(torch.int32) - vec_out.to(torch.int32)).abs().max().item())
-        fir_mc = {"kernel": "k_fir_mfma (fp16 matrix cores, samples and taps split exactly; TWX_FIR_MFMA=1)", "avg_ms": round(mc_ms, 4),
+        fir_mc = {"kernel": "k_fir_mfma (fp16 matrix cores, samples and taps split exactly; TWX_OPT_FIR_MFMA = 1)", "avg_ms": round(mc_ms, 4),
                   "input_Msamples_per_s": round(n_in / mc_ms / 1e3, 1), "GB/s": round(fir_bytes / (mc_ms * 1e-3) / 1e9, 1),
                   "frac_hbm": round(fir_bytes / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                   "fp32_equivalent_TFLOP/s": round(fir_flops / (mc_ms * 1e-3) / 1e12, 2), "frac_of_fp32_vector_peak": round(fir_flops / (mc_ms * 1e-3) / 1e12 / 157.3, 4),
                   "max_abs_difference_from_the_vector_form_int16": same,
-                  "note": "opt-in and measured alone: packed-fp32 results of waves resident beside this kernel go wrong (profiles/r05_fir_mfma.txt), so no timed "
-                          "step of this line uses it"}
+                  "note": "opt-in (TWX_OPT_FIR_MFMA); packed-fp32 results of waves resident beside this kernel go wrong (profiles/r05_fir_mfma.txt), so the "
+                          "library orders every such launch behind all other work it has enqueued on the device and all later work behind it "
+                          "(csrc/twx_internal.h): it always runs alone.  No timed step of this line uses it"}
     finally:
-        os.environ.pop("TWX_FIR_MFMA", None)
+        L.check(lib.twx_set_option(c32["OPlo"]._h, L.TWX_OPT_FIR_MFMA, 0), c32["OPlo"]._h)
         c32["OPlo"].fir_decimate_dev(wptr["OP"], n_in, taps, dec, out_i16_dev=sess.nar["OP"][0].data_ptr())      # the vector form's output for what follows
         sess.synchronize()
     nar = {st: sess.nar[st][0].clone() for st in sess.stations}   # the decimated captures for the fp64 leg
@@ -503,6 +554,100 @@ def wideband_legs(local_rank: int, seconds: int = 4, steps: int = 5):
            "integer_lags_equal_fp32": bool(same), "fp32_vs_fp64_peak_rel": float("%.3g" % rel), "tolerance": 1e-6,
            "within_tolerance": bool(rel <= 1e-6 and same)}
     return wl, f64
+
+
+def strong_leg(a, ex, cor, lib, L, dev, rank, world, chips_dev, band, df_true, weak_value):
+    """BASELINE.json configs[3] as written (godual_ranging.m:75-102: ONE recording, consecutive windows): `--windows`
+    windows IN TOTAL, rank r owning the contiguous block dist.shard_windows names, per step its block through the full chain, one
+    all-gather of the fixed-size records (blocks padded to the longest), the same barrier + max-over-ranks timing as the headline.
+    Reported beside the weak headline, never instead of it: this is the leg that can show a scaling defect (per-step synchronise +
+    gather + barrier against 1/N of the compute, the launch tail of a short block).  Also times the exchange alone (compute removed)."""
+    import numpy as np
+    import torch
+    from amaranth_twstft_amd import dist
+    total = a.windows
+    lo, hi = dist.shard_windows(total, rank, world)
+    nloc, cap = hi - lo, dist.max_shard(total, world)
+    RB = C.sizeof(L.twx_result)
+    iq_s = torch.empty((max(nloc, 1), N, 2), dtype=torch.int16, device=dev)
+    for i, p in enumerate(range(lo, hi)):                     # ONE recording description: window p of rank 0's parameters, whoever holds it
+        sp, _ = window_params(p, 0)
+        params = np.array([sp.delay_q8, sp.fstep, sp.phi0, sp.amp, sp.noise_gain, sp.seed, sp.stream, 0], dtype=np.int64)
+        L.check(lib.twx_synth_capture_dev(iq_s[i].data_ptr(), N, 0, chips_dev.data_ptr(), NCHIPS, 2, 1, params.ctypes.data_as(C.c_void_p), None))
+    torch.cuda.synchronize()
+    res_s = torch.zeros((cap, RB), dtype=torch.uint8, device=dev)
+    gat_s = torch.zeros((world * cap, RB), dtype=torch.uint8, device=dev)
+    dfp = np.ascontiguousarray(df_true[:1].repeat(max(nloc, 1)))
+
+    def compute():
+        if nloc:
+            if a.workload == "processing":
+                L.check(lib.twx_process_windows_dev(cor._h, iq_s.data_ptr(), nloc, 1, 0, C.byref(band), None, res_s.data_ptr()), cor._h)
+            else:
+                L.check(lib.twx_process_windows_dev(cor._h, iq_s.data_ptr(), nloc, 1, 0, None, dfp.ctypes.data_as(C.c_void_p), res_s.data_ptr()), cor._h)
+
+    def exchange():
+        L.check(lib.twx_synchronize(cor._h), cor._h)          # records complete before the exchange reads them
+        ex.all_gather_records(gat_s, res_s)
+
+    def barrier():
+        ex.barrier()
+        L.check(lib.twx_synchronize(cor._h), cor._h)
+        torch.cuda.synchronize()
+
+    def timed(fn):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            fn()
+        barrier()
+        return ex.max_float(time.perf_counter() - t0)
+
+    def step():
+        compute()
+        exchange()
+
+    for _ in range(max(1, a.warmup)):
+        step()
+    dt = timed(step)
+    dt_compute = timed(lambda: (compute(), L.check(lib.twx_synchronize(cor._h), cor._h)))      # the same blocks without the exchange
+    # the exchange alone: every rank enters it together (barrier), the slowest rank's median
+    gms = []
+    for _ in range(max(5, a.steps)):
+        ex.barrier()
+        t0 = time.perf_counter()
+        exchange()
+        gms.append((time.perf_counter() - t0) * 1e3)
+    gather_ms = ex.max_float(float(np.median(gms)))
+    step()
+    barrier()
+    # every rank checks ITS copy of the gathered recording against the generator: all `total` lags, in window order
+    gh = gat_s.cpu().numpy().reshape(world, cap, RB)
+    per_rank = []
+    for r in range(world):
+        s0, e0 = dist.shard_windows(total, r, world)
+        arr = (L.twx_result * max(e0 - s0, 1)).from_buffer_copy(np.ascontiguousarray(gh[r, :max(e0 - s0, 1)]).tobytes())
+        per_rank.append(bool(all(int(arr[i].indice0) == 3 * window_params(s0 + i, 0)[1] for i in range(e0 - s0))))
+    own = bool(gh[rank, :nloc].tobytes() == res_s[:nloc].cpu().numpy().tobytes())
+    agree = ex.all_true(bool(all(per_rank) and own))
+    value = total * N * a.steps / dt / 1e6
+    blocks = [dist.shard_windows(total, r, world) for r in range(world)]
+    return {"workload": f"BASELINE.json configs[3] as written: ONE {total}-window recording sharded over {world} ranks (contiguous blocks of "
+                        f"{min(e - s for s, e in blocks)}..{max(e - s for s, e in blocks)} windows, HBM-resident), "
+                        + ("processing(d,k) full chain" if a.workload == "processing" else "xcorr, df supplied")
+                        + ", one all-gather of the 240-byte records per step",
+            "scaling": "strong", "value": round(value, 2), "unit": "Msamples/s", "ms_per_step": round(dt / a.steps * 1e3, 3), "steps": a.steps,
+            "windows_total": total, "windows_per_rank": [e - s for s, e in blocks],
+            "compute_only_ms_per_step": round(dt_compute / a.steps * 1e3, 3),
+            "gather_ms": round(gather_ms, 3), "gather_ms_note": "the exchange alone (synchronise + all-gather of the padded blocks, every rank entering "
+                                                               "together), median of %d, the slowest rank's" % len(gms),
+            "exchange_share_of_step": round(max(0.0, 1.0 - dt_compute / dt), 4),
+            "ratio_to_weak_headline": round(value / weak_value, 4),
+            "ratio_note": "strong value / weak value of the same run: 1.0 = a rank processes its 1/N block at the rate it processes a whole "
+                          "recording (per-step overheads hidden); the N = 1 rate is the driver's own N = 1 line",
+            "collective": {"backend": ex.describe(), "bytes_per_rank": cap * RB, "records": world * cap},
+            "ranks_with_exact_lags": int(sum(per_rank)), "own_block_identical": own, "all_ranks_agree": bool(agree)}
+
 
 
 def caf_only():
@@ -676,7 +821,7 @@ def main():
 
     # --- the collective moved the right data: every rank's block of the gathered buffer must hold THAT rank's lags
     # (window_params is a pure function of (window, rank), so rank 0 can recompute what every other rank was given)
-    collective = None
+    coll_info = None
     if use_dist:
         gh = gathered.cpu().numpy()
         garr = (L.twx_result * (world * nwin)).from_buffer_copy(gh.tobytes())
@@ -685,17 +830,23 @@ def main():
             ok = all(int(garr[r * nwin + p].indice0) == 3 * window_params(p, r)[1] for p in range(nwin))
             per_rank.append(bool(ok))
         own = gh[rank * nwin:(rank + 1) * nwin].tobytes() == host
-        collective = {"op": "all_gather_into_tensor", "backend": ex.describe(), "requested": a.backend, "world": world,
+        coll_info = {"op": "all_gather_into_tensor", "backend": ex.describe(), "requested": a.backend, "world": world,
                       "records": world * nwin, "bytes_per_rank": nwin * C.sizeof(L.twx_result), "ranks_with_exact_lags": int(sum(per_rank)),
                       "gathered_lag_exact": bool(all(per_rank)), "own_block_identical": bool(own), "checked_on_rank": rank,
                       "control_plane": "gloo over 127.0.0.1 (barriers, max-over-ranks of the time, agreements)"}
         if ex.probe is not None:
-            collective["rccl_probe"] = {k: ex.probe[k] for k in ("ok", "tried", "seconds") if k in ex.probe}
+            coll_info["rccl_probe"] = {k: ex.probe[k] for k in ("ok", "tried", "seconds") if k in ex.probe}
         if sharing:
-            collective["ranks_sharing_devices"] = f"{world} ranks on {ndev} GPU(s)"
+            coll_info["ranks_sharing_devices"] = f"{world} ranks on {ndev} GPU(s)"
         # every rank checks its copy; rank 0 reports whether ALL copies were right
-        collective["all_ranks_agree"] = ex.all_true(bool(all(per_rank) and own))
-        collective["numa"] = ex.all_objects(pin)            # per rank: NUMA node of its GPU and the CPUs it was bound to
+        coll_info["all_ranks_agree"] = ex.all_true(bool(all(per_rank) and own))
+        coll_info["numa"] = ex.all_objects(pin)            # per rank: NUMA node of its GPU and the CPUs it was bound to
+
+    # --- BASELINE.json configs[3] AS WRITTEN (N > 1 only; the weak headline above stays): ONE recording of `nwin` windows in total,
+    # rank r processing its contiguous block (dist.shard_windows), one all-gather of the records per step
+    strong = None
+    if use_dist:
+        strong = strong_leg(a, ex, cor, lib, L, dev, rank, world, chips_dev, band, df_true, weak_value=world * nwin * N * a.steps / dt / 1e6)
 
     samples = world * nwin * N * a.steps
     value = samples / dt / 1e6
@@ -828,8 +979,10 @@ def main():
             out["wideband_workload"], out["f64_workload"] = wideband_legs(local_rank, a.wideband_seconds)
         except Exception as e:                               # the headline line is never lost to a side leg
             out["wideband_workload"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    if collective is not None:
-        out["collective"] = collective
+    if strong is not None:
+        out["strong_workload"] = strong
+    if coll_info is not None:
+        out["collective"] = coll_info
     else:
         out["numa"] = pin
     if world > 1:

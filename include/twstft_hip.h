@@ -24,8 +24,12 @@ extern "C" {
  *    acquisition and *_dev entry points were added.  twx_abi_version() of an older library answers 1.
  * 3: twx_multi_* (several GPUs from one host process) and twx_rx_* (the DLL/PLL receiver) added; nothing changed.
  * 5: twx_multi_info grew (rccl_fallback, threads_pinned, numa_node, rccl_error: the RCCL exchange falls back to host-side
- *    concatenation instead of failing the job); twx_device_affinity / twx_pin_thread_to_device, twx_file_df / twx_write_cmat added. */
-#define TWX_ABI_VERSION 5
+ *    concatenation instead of failing the job); twx_device_affinity / twx_pin_thread_to_device, twx_file_df / twx_write_cmat added.
+ * 6: twx_multi_block / twx_multi_process_recording_dev / twx_multi_exchange_only (BASELINE.json configs[3] as written: ONE recording
+ *    sharded over the contexts); the options TWX_OPT_FIR_MFMA / TWX_OPT_SELFCHECK and the twx_result.status bits; the velocity-compensated
+ *    window (twx_set_resample; twx_result.reserved became the live field `dt`); the off-peak / squared-spectrum SNR estimators
+ *    (twx_extra, twx_fetch_extra).  No struct changed its size. */
+#define TWX_ABI_VERSION 6
 
 typedef struct twx_ctx twx_ctx;
 
@@ -172,7 +176,14 @@ enum { TWX_OPT_REMOVE_MEAN = 1,
         * names: 0 k_sums, 1 k_col_fwd_square, 2 k_row_band, 3 k_df_tables, 4 k_col_fwd_mix, 5 k_row_mid, 6 k_col_inv,
         * 7 k_peak; -1 = the whole chain again), TWX_OPT_DEBUG_REPEAT times per batch, on whatever the batch buffers hold
         * from the last complete call.  Results of such a call are meaningless. */
-       TWX_OPT_DEBUG_ONLY = 100, TWX_OPT_DEBUG_REPEAT = 101 };
+       TWX_OPT_DEBUG_ONLY = 100, TWX_OPT_DEBUG_REPEAT = 101,
+       /* The matrix-core form of the FIR front end (k_fir_mfma) for twx_fir_decimate_dev on THIS context: 1 = use it, 0 = never,
+        * -1 (default) = follow the environment variable TWX_FIR_MFMA.  That kernel is 20 % faster than the vector form and makes
+        * packed-fp32 arithmetic of waves resident beside it go wrong (profiles/r05_fir_mfma.txt), so the library never lets it share the
+        * device with other work of the process: every such launch is ordered behind everything this library has enqueued on the device
+        * so far, on any context or stream, and everything enqueued later waits for it (csrc/twx_internal.h).  Work of OTHER processes on
+        * the same GPU is out of the library's reach: leave the option off unless the process owns the GPU. */
+       TWX_OPT_FIR_MFMA = 2 };
 int twx_set_option(twx_ctx* ctx, int32_t option, int64_t value);
 void* twx_stream(twx_ctx* ctx);                      /* hipStream_t of the context */
 
@@ -537,6 +548,18 @@ int twx_multi_process_windows(twx_multi* m, const int16_t* iq, int64_t n_windows
  * n_windows [* n_channels] records in context order) may be NULL.  df as in twx_process_windows_dev, shared by all. */
 int twx_multi_process_windows_dev(twx_multi* m, const void* const* iq_dev, int64_t n_windows, int32_t n_channels,
                                   int32_t channel, const twx_band* band, const double* df, twx_result* out);
+/* BASELINE.json configs[3] as written — ONE recording of n_windows_total consecutive windows (godual_ranging.m:75-102) sharded over the
+ * contexts: context i owns the contiguous block twx_multi_block() names (sizes differ by at most one; the rule of
+ * twx_multi_process_file) and iq_block_dev[i] points at the FIRST window of that block in the memory of its device.  One exchange per
+ * call, on blocks padded to the longest; out (host, may be NULL): n_windows_total [* n_channels] records in WINDOW order; df (when
+ * band == NULL): one entry per window [and channel] of the whole recording.  Every context's device copy of the padded gather stays
+ * available through twx_multi_fetch_gathered (context r's block starts at record r * ceil(n_windows_total / n_contexts) [* n_channels]). */
+int twx_multi_block(const twx_multi* m, int64_t n_windows_total, int32_t i, int64_t* start, int64_t* count);
+int twx_multi_process_recording_dev(twx_multi* m, const void* const* iq_block_dev, int64_t n_windows_total, int32_t n_channels,
+                                    int32_t channel, const twx_band* band, const double* df, twx_result* out);
+/* The exchange ALONE (the compute removed): gathers records_per_context records per context as the last device-resident call left them
+ * in the send buffers; its wall time is twx_multi_info.gather_ms.  What one step of a sharded recording pays for the gather. */
+int twx_multi_exchange_only(twx_multi* m, int64_t records_per_context);
 /* Context i's copy of the gathered records of the last *_dev call (what the collective delivered to that device). */
 int twx_multi_fetch_gathered(twx_multi* m, int32_t i, twx_result* out, int64_t n_records);
 /* NUMA placement of a device (/sys/bus/pci/devices/<bus id>/{numa_node,local_cpulist}): *numa_node = -1 where the platform does

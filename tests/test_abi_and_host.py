@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/twstft_hip.h but not exported"
     assert set(names) == set(L.SYMBOLS), (set(names) ^ set(L.SYMBOLS))
-    assert lib.twx_abi_version() == L.TWX_ABI_VERSION == 5          # 5: twx_multi_info grew (RCCL fall-back, NUMA pinning), twx_device_affinity (header)
+    assert lib.twx_abi_version() == L.TWX_ABI_VERSION == 6          # 6: sharded recording over twx_multi, TWX_OPT_FIR_MFMA / SELFCHECK, resampled window, twx_extra (header)
 
 
 def test_struct_layouts_match_header():

@@ -67,3 +67,49 @@ def test_launcher_restarts_a_failed_rccl_job_on_gloo(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "JOB_OK gloo (fallback: the RCCL job ended with status" in out.stdout
     assert "starting it once more with the record exchange on gloo" in out.stderr
+
+
+def test_launcher_does_not_restart_a_job_that_failed_outside_the_exchange(tmp_path):
+    """A job whose rank fails for a reason of its own (a bad argument, an assertion: no mark of an RCCL step left behind, no signal) is NOT
+    run a second time: its status comes back unchanged and the side effects happen once (advisor, round 5)."""
+    script = tmp_path / "job.py"
+    script.write_text(
+        "import argparse, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from amaranth_twstft_amd import launch\n"
+        "ap = argparse.ArgumentParser(); ap.add_argument('--backend', default='nccl'); a = ap.parse_args()\n"
+        "if not launch.is_rank():\n"
+        "    sys.exit(launch.spawn_with_fallback(2, os.path.abspath(__file__), sys.argv[1:], backend=a.backend))\n"
+        "rank, _, world = launch.rank_world()\n"
+        "open(os.path.join(%r, 'ran_%%d_%%d' %% (rank, os.getpid())), 'w').close()\n"
+        "sys.exit(7 if rank == 1 else 0)\n" % (ROOT, str(tmp_path)))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert "not restarted" in out.stderr and "starting it once more" not in out.stderr
+    assert len([f for f in os.listdir(tmp_path) if f.startswith("ran_")]) == 2         # two ranks, once
+
+
+def test_visible_gpus_counts_from_the_kfd_topology_without_hip(tmp_path, monkeypatch):
+    """collective.visible_gpus(): the GPU nodes of the kfd topology (nodes with SIMDs) whose render node this process may open, narrowed by
+    *_VISIBLE_DEVICES — no torch, no HIP in the counting process (advisor, round 5: rank 0 must not initialise HSA before the probe's
+    environment is applied)."""
+    from amaranth_twstft_amd import collective
+    nodes, dri = tmp_path / "nodes", tmp_path / "dri"
+    dri.mkdir()
+    for i, (simd, minor) in enumerate([(0, 0), (0, 0), (1024, 128), (1024, 129), (1024, 130)]):     # two CPU nodes, three GPUs
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\ndrm_render_minor %d\n" % (0 if simd else 64, simd, minor))
+    for m in (128, 129):                                                                 # the third GPU's render node is not ours
+        (dri / ("renderD%d" % m)).write_text("")
+    monkeypatch.setattr(collective, "KFD_NODES", str(nodes))
+    monkeypatch.setattr(collective, "DRI_DIR", str(dri))
+    for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    assert collective.visible_gpus() == 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert collective.visible_gpus() == 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,5")
+    assert collective.visible_gpus() == 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert collective.visible_gpus() == 0

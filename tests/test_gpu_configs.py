@@ -463,6 +463,32 @@ def test_bench_eight_ranks_collective_path():
     assert c["ranks_with_exact_lags"] == 8 and c["gathered_lag_exact"] and c["own_block_identical"] and c["all_ranks_agree"]
 
 
+@pytest.mark.parametrize("world,windows", [(2, 9), (8, 20)])
+def test_bench_strong_scaling_leg_times_configs3_as_written(world, windows):
+    """The N > 1 line carries `strong_workload`: ONE recording of `--windows` windows IN TOTAL sharded over the ranks (contiguous blocks,
+    dist.shard_windows: 9 = 5 + 4; 20 over 8 = 3,3,3,3,2,2,2,2), one all-gather of the padded blocks per step, the exchange timed alone —
+    BASELINE.json configs[3] as written (godual_ranging.m:75-102).  The weak headline is unchanged beside it.  Ranks share GPU 0: gloo."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--windows", str(windows),
+                          "--backend", "gloo", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, env=env, timeout=1500)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == world and j["scaling"] == "weak" and j["integer_lag_exact"] and j["collective"]["records"] == world * windows
+    s = j["strong_workload"]
+    base, rem = divmod(windows, world)
+    assert s["scaling"] == "strong" and s["windows_total"] == windows and s["windows_per_rank"] == [base + (1 if r < rem else 0) for r in range(world)]
+    assert s["ranks_with_exact_lags"] == world and s["own_block_identical"] and s["all_ranks_agree"]
+    assert s["value"] > 0 and s["ms_per_step"] > 0 and s["compute_only_ms_per_step"] > 0 and s["gather_ms"] > 0
+    assert s["collective"]["backend"] == "gloo" and s["collective"]["records"] == world * (base + (1 if rem else 0))
+    assert 0.0 <= s["exchange_share_of_step"] < 1.0 and s["ratio_to_weak_headline"] > 0
+
+
+def test_bench_one_rank_line_has_no_strong_leg():
+    """N = 1: the line is the round-5 line (no `strong_workload`, `scaling` weak)."""
+    j, _ = _bench_line(["--steps", "2", "--warmup", "1", "--windows", "9", "--no-cpu-baseline", "--no-roofline"])
+    assert j["n_gpus"] == 1 and "strong_workload" not in j and j["scaling"] == "weak" and j["integer_lag_exact"]
+
+
 def test_bench_two_ranks_over_real_rccl():
     """`python bench.py --gpus 2` with the nccl (= RCCL) backend, one GPU per rank: runs wherever the box has two GPUs
     (the driver's 8-GPU node), skipped on a one-GPU box.  The gathered records of BOTH ranks must carry their own lags."""
@@ -542,6 +568,64 @@ def test_bench_rccl_bring_up_failure_in_the_rank_falls_back(step):
     c = j["collective"]
     assert c["backend"].startswith("gloo (fallback: RCCL bring-up failed: rank 0: RuntimeError: injected failure"), c
     assert j["integer_lag_exact"] and c["gathered_lag_exact"] and c["own_block_identical"] and c["all_ranks_agree"]
+
+
+def test_matrix_core_fir_never_runs_beside_a_correlation():
+    """TWX_OPT_FIR_MFMA: k_fir_mfma makes packed-fp32 results of co-resident waves go wrong (profiles/r05_fir_mfma.txt: 6-12 wrong spectrum
+    rows of k_rowd per call, 7-8 wrong records of 12).  The library orders every such launch behind all other work it has enqueued on the
+    device and all later work behind it (csrc/twx_internal.h), so the SAME harness — a correlation enqueued right behind a matrix-core FIR of
+    another context, nothing synchronised in between — now returns the records of the correlation run alone, 24 of 24, from two host threads
+    as well; the session forces the vector form on its contexts whatever the environment says."""
+    import threading
+    import torch
+    from amaranth_twstft_amd import frontend, prn
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    Nw, dec = 5_000_000, 14
+    taps = frontend.lowpass_taps(70e6, 2.1e6, 0.4e6)
+    n_in = (Nw - 1) * dec + taps.size
+    chips = prn.lfsr_chips(22, 3, 2_500_000)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    cap = (torch.randn((n_in, 2), device=dev, generator=g) * 4000).clamp_(-32768, 32767).to(torch.int16)
+    win = [(torch.randn((Nw, 2), device=dev, generator=g) * 4000).to(torch.int16) for _ in range(2)]
+    out16 = torch.zeros((Nw, 2), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    band = L.twx_band(*band_godual(FS, Nw))
+    key = lambda r: (int(r.indice0), r.xval[0], r.xval[1], r.df, r.SNRr)
+    RB = C.sizeof(L.twx_result)
+    with Correlator(chips, fs=FS, Nint=1) as c, Correlator(chips, fs=FS, Nint=1) as b1:
+        L.check(lib.twx_set_option(b1._h, L.TWX_OPT_FIR_MFMA, 1), b1._h)
+        chain = lambda i, r: L.check(lib.twx_process_windows_dev(c._h, win[i % 2].data_ptr(), 1, 1, 0, C.byref(band), None, r.data_ptr()), c._h)
+        alone = []
+        for i in range(2):
+            r = torch.zeros(RB, dtype=torch.uint8, device=dev); chain(i, r); c.synchronize()
+            alone.append(key(L.twx_result.from_buffer_copy(r.cpu().numpy().tobytes())))
+        res = torch.zeros((24, RB), dtype=torch.uint8, device=dev)
+        for i in range(12):                                     # one host thread: FIR of context b1, then the chain of context c, back to back
+            b1.fir_decimate_dev(cap.data_ptr(), n_in, taps, dec, out_i16_dev=out16.data_ptr())
+            chain(i, res[i])
+        stop = threading.Event()
+
+        def fir_loop():                                         # a second host thread keeps matrix-core FIRs coming
+            torch.cuda.set_device(0)
+            while not stop.is_set():
+                b1.fir_decimate_dev(cap.data_ptr(), n_in, taps, dec, out_i16_dev=out16.data_ptr())
+                b1.synchronize()
+        th = threading.Thread(target=fir_loop); th.start()
+        try:
+            for i in range(12, 24):
+                chain(i, res[i]); c.synchronize()
+        finally:
+            stop.set(); th.join()
+        c.synchronize(); b1.synchronize(); torch.cuda.synchronize()
+        host = res.cpu().numpy()
+        bad = [i for i in range(24) if key(L.twx_result.from_buffer_copy(host[i].tobytes())) != alone[i % 2]]
+        assert not bad, "records that differ from the correlation run alone: %r" % bad
+        # the FIR's own output is the vector form's to one count
+        ref16 = out16.clone()
+        L.check(lib.twx_set_option(b1._h, L.TWX_OPT_FIR_MFMA, 0), b1._h)
+        b1.fir_decimate_dev(cap.data_ptr(), n_in, taps, dec, out_i16_dev=out16.data_ptr()); b1.synchronize()
+        assert int((out16.to(torch.int32) - ref16.to(torch.int32)).abs().max().item()) <= 1
 
 
 def test_bench_wideband_and_fp64_legs():

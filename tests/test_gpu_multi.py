@@ -89,6 +89,63 @@ def test_device_resident_step_and_every_contexts_gathered_copy():
             assert [w.xval.real for w in want] == [arr[r * nwin + w].xval[0] for w in range(nwin)]
 
 
+@pytest.mark.parametrize("nctx,nwin,rccl_one", [(3, 11, False), (8, 600, False), (5, 3, False), (1, 7, True)])
+def test_one_recording_sharded_over_the_contexts(nctx, nwin, rccl_one):
+    """twx_multi_process_recording_dev — BASELINE.json configs[3] as written (godual_ranging.m:75-102: ONE recording, consecutive
+    windows): context i holds only ITS contiguous block on its device; the records come back in window order, byte-identical to one
+    context processing the whole recording — ragged blocks (11 = 4+4+3), 600 over 8, fewer windows than contexts (3 over 5), and the
+    RCCL world of one.  The exchange alone (twx_multi_exchange_only) re-delivers the same buffers."""
+    import torch
+    from amaranth_twstft_amd import prn, synth
+    chips = prn.lfsr_chips(13, 27, 2500)
+    n = 2 * len(chips)
+    dev = torch.device("cuda", 0)
+    ps = [synth.SynthParams(delay_q8=(300 + 5 * w) * 256, fstep=synth.fstep_for_df(150.0 + w, FS), phi0=w, amp=300,
+                            noise_gain=synth.noise_gain_for_sigma(300.0), seed=700 + w) for w in range(nwin)]
+    raw = np.concatenate([synth.synth_channel(n, chips, 2, p) for p in ps]).reshape(nwin, n, 2)
+    whole = torch.from_numpy(raw).to(dev)
+    band = band_godual(FS, n)
+    with Correlator(chips, fs=FS, Nint=1) as one:
+        want = one.process_dev(whole.data_ptr(), nwin, band=band)
+    off = want[0].indice - 3 * 300                          # WindowResult.indice is Octave's (1-based)
+    assert [w.indice for w in want] == [3 * (300 + 5 * w) + off for w in range(nwin)] and off in (0, 1)
+    with MultiCorrelator(chips, [0] * nctx, fs=FS, Nint=1, rccl=rccl_one) as m:
+        blocks = [m.block(nwin, r) for r in range(nctx)]
+        assert sum(c for _, c in blocks) == nwin and blocks[0][0] == 0 and max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
+        parts = [torch.from_numpy(raw[s0:s0 + c0].copy()).to(dev) if c0 else None for s0, c0 in blocks]      # every context sees ONLY its block
+        got = m.process_recording_dev([t.data_ptr() if t is not None else 0 for t in parts], nwin, band=band)
+        arr = (L.twx_result * nwin).from_buffer_copy(got.tobytes())
+        assert [int(arr[w].indice0) + off for w in range(nwin)] == [w.indice for w in want]
+        assert [(arr[w].xval[0], arr[w].xval[1], arr[w].df, arr[w].SNRr) for w in range(nwin)] == [(w.xval.real, w.xval.imag, w.df, w.SNRr) for w in want]
+        cap = max(c for _, c in blocks)
+        i = m.info
+        assert i.records_gathered == nctx * cap and i.bytes_per_rank == cap * REC and i.rccl == (1 if rccl_one else 0)
+        g0 = m.fetch_gathered(0, nctx * cap).tobytes()
+        ms = m.exchange_only(cap)
+        assert ms >= 0 and m.fetch_gathered(nctx - 1, nctx * cap).tobytes() == g0            # the exchange alone delivers the same buffers again
+        # supplied carriers follow their windows across the block boundaries
+        dfs = np.linspace(140.0, 160.0 + nwin, nwin)
+        got2 = m.process_recording_dev([t.data_ptr() if t is not None else 0 for t in parts], nwin, df=dfs)
+        arr2 = (L.twx_result * nwin).from_buffer_copy(got2.tobytes())
+        assert [arr2[w].df for w in range(nwin)] == list(dfs)
+        with pytest.raises(L.TwxError):
+            m.exchange_only(10 ** 9)
+
+
+def test_bench_single_process_strong_leg():
+    """`bench.py --gpus 4 --single-process`: besides the weak headline the line times configs[3] as written — ONE recording of `--windows`
+    windows sharded over the four contexts — with the exchange isolated; every context's block carries the generator's lags."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--single-process", "--steps", "2", "--warmup", "1",
+                          "--windows", "9"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    s = j["strong_workload"]
+    assert j["scaling"] == "weak" and s["scaling"] == "strong" and s["windows_total"] == 9 and s["windows_per_rank"] == [3, 2, 2, 2]
+    assert s["ranks_with_exact_lags"] == 4 and s["all_ranks_agree"] and s["value"] > 0 and s["gather_ms"] >= 0 and s["ms_per_step"] > 0
+
+
 def test_rccl_world_of_one_runs_the_collective_calls(tmp_path):
     """One device, RCCL forced on: ncclCommInitAll + ncclGroupStart / ncclAllGather / ncclGroupEnd of a world of one — the calls
     of the N > 1 path, bound from librccl.so.1 at run time, on a box with a single GPU.  Same records as without."""
