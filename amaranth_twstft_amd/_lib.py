@@ -18,6 +18,9 @@ TWX_WIN_NONE, TWX_WIN_HAMMING = 0, 1
 TWX_F32, TWX_F64 = 0, 1
 TWX_OPT_REMOVE_MEAN = 1
 TWX_OPT_FIR_MFMA = 2
+TWX_OPT_SELFCHECK = 3
+TWX_OPT_DEBUG_FAULT = 102
+TWX_STATUS_SELFCHECK = 1
 TWX_FLAG_PROFILE = 1
 TWX_FLAG_FINE_FREQ = 2
 TWX_FLAG_CODE_ZERO_MEAN = 4
@@ -162,6 +165,7 @@ SYMBOLS = {
     "twx_synchronize": (C.c_int, [_VP]),
     "twx_set_option": (C.c_int, [_VP, C.c_int32, C.c_int64]),
     "twx_stream": (_VP, [_VP]),
+    "twx_selfcheck_stats": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
     "twx_fft_forward": (C.c_int, [_VP, _VP, _VP]),
     "twx_get_code_spectrum": (C.c_int, [_VP, _VP]),
     "twx_xcorr_map": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, _VP]),

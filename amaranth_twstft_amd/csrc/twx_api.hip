@@ -457,9 +457,14 @@ struct CtxBase {
         return p;
     }
     int remove_mean = 1;          // TWX_OPT_REMOVE_MEAN
+    int dbg_fault = 0;            // TWX_OPT_DEBUG_FAULT
     int dbg_only = -1, dbg_repeat = 1;   // TWX_OPT_DEBUG_ONLY / _REPEAT: launch one kernel class of the chain, n times (power / clock probes)
     int reps(int cls) const { return dbg_only < 0 ? 1 : (dbg_only == cls ? dbg_repeat : 0); }
     int snr_valid = 1;            // 0 for replicas that are not a +-1 code
+    // TWX_OPT_SELFCHECK: Parseval's identity per row of the middle pass (k_rowd<MID, CHK> + k_chk_verdict)
+    float selfcheck_tol = 0.f;    // 0 = off
+    unsigned* chk_stat = nullptr; // [0] largest relative deviation seen (float bits), [1] rows flagged — since the last reset
+    virtual int set_selfcheck(long long value) = 0;
     virtual int init() = 0;
     virtual int sync_all() = 0;
     virtual int pipeline_depth() const = 0;
@@ -543,6 +548,7 @@ template <typename T> struct Ctx : CtxBase {
         short2* planar; WinSums* sums2;      // two-channel captures in all-channel mode: planar copies + both channels' sums (lazy)
         SumPart* sum_parts;                  // k_sums: [2][B][TWX_SUMS_MAXCHUNKS] per-workgroup partials
         double tables_df; int tables_nb;     // the NCO tables e1/e2 of windows [0, tables_nb) hold this carrier (tables_nb = 0: unknown)
+        float* chk_rows; int* chk_flag;      // TWX_OPT_SELFCHECK (allocated when the option is first set): [B][N1][TWX_CHK_SLOTS] sums, [B] status words
     };
     Slot slots[4] = {}; int nslots = 1;
     bool sums_ready = false;                 // run_batch_in: `sums` already holds this batch's statistics (k_sums_deint2)
@@ -563,6 +569,22 @@ template <typename T> struct Ctx : CtxBase {
         static const int per_cu = [] { const char* e = getenv("TWX_SUMS_WGS"); return e ? std::max(1, atoi(e)) : 8; }();
         const long long want = ((long long)per_cu * ncu + nb - 1) / nb, cap = std::max<long long>(1, N / 4096);
         return (int)std::max<long long>(1, std::min<long long>(std::min(want, cap), TWX_SUMS_MAXCHUNKS));
+    }
+    // value: 0 off, 1 on at the default tolerance (1e-5 relative), > 1 the tolerance in units of 1e-9
+    int set_selfcheck(long long value) override {
+        if (value <= 0) { (void)sync_all(); selfcheck_tol = 0.f; return TWX_OK; }
+        const int R0 = (use_rowd && row->S == 3) ? row->R[0] : 1;
+        if (!use_rowd || R0 == 1) return fail(TWX_E_ARG, "TWX_OPT_SELFCHECK needs the three-stage DIF/DIT row pass (rows of 4000 / 8000 points and plug-ins of that shape)");
+        if (int rc = sync_all()) return rc;
+        HIPCHK(hipSetDevice(dev));
+        for (int k = 0; k < nslots; ++k) {
+            Slot& q = slots[k];
+            if (!q.chk_rows) { if (int rc = dalloc(&q.chk_rows, (size_t)B * N1 * TWX_CHK_SLOTS)) return rc; }
+            if (!q.chk_flag) { if (int rc = dalloc(&q.chk_flag, (size_t)B)) return rc; HIPCHK(hipMemset(q.chk_flag, 0, sizeof(int) * B)); }
+        }
+        if (!chk_stat) { if (int rc = dalloc(&chk_stat, (size_t)2)) return rc; HIPCHK(hipMemset(chk_stat, 0, 8)); }
+        selfcheck_tol = value == 1 ? 1e-5f : (float)((double)value * 1e-9);
+        return TWX_OK;
     }
     int pipeline_depth() const override { return nslots; }
     int sync_all() override {
@@ -1063,6 +1085,7 @@ template <typename T> struct Ctx : CtxBase {
         // second, both channels) skips the table kernel: 8 625 fp64 sincospi to write the same ones again
         Slot* cur_slot = nullptr;
         for (int k = 0; k < nslots; ++k) if (slots[k].e1 == e1) cur_slot = &slots[k];
+        Slot* chk_slot = (selfcheck_tol > 0.f && use_rowd && cur_slot && cur_slot->chk_rows && !map_only) ? cur_slot : nullptr;
         const bool same_tables = map_only && df_host && cur_slot && cur_slot->tables_nb >= nb && cur_slot->tables_df == df_host[0] && !(cfg.flags & TWX_FLAG_FINE_FREQ);
         if (!same_tables) {
             ProfScope ps(this, PC_DFT, nb);
@@ -1098,8 +1121,13 @@ template <typename T> struct Ctx : CtxBase {
             for (int it = 0, ne = reps(PC_ROW_MID); it < ne; ++it)
             if (use_rowd) {
                 RowDArgs<T> rd{}; rd.r = ra; rd.dtabs = dtabs; rd.cspec_perm = cspec_perm; rd.ea_d = ea_d; rd.eb_d = eb_d; rd.vc = vc_d; rd.vw = vw_d;
+                rd.chk_rows = chk_slot ? chk_slot->chk_rows : nullptr; rd.chk_fault = dbg_fault;
                 if (row->rowd(ROW_MID, &rd, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_rowd(mid) launch failed");
             } else if (row->run(ROW_MID, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(mid) launch failed");
+        }
+        if (chk_slot) {                                  // Parseval per row of the pass just enqueued -> the windows' status words
+            TWX_LAUNCH((k_chk_verdict<0>), dim3(nb), dim3(256), stream, (const float*)chk_slot->chk_rows, N1, N2, R, selfcheck_tol, chk_slot->chk_flag, chk_stat);
+            HIPCHK(hipGetLastError());
         }
         ColInvArgs<T> ia{};
         ia.n = N; ia.n2 = N2; ia.ntiles = ntiles_inv; ia.nphase = R; ia.nwin = nb; ia.Bz = Bz; ia.tw1 = tw1; ia.part = part_peak; ia.zout = zout; ia.norm1 = argmax_norm1; ia.zscale = (T)(map_only ? zscale : 1.0);
@@ -1112,6 +1140,7 @@ template <typename T> struct Ctx : CtxBase {
         pa.n = N; pa.n1 = N1; pa.n2 = N2; pa.nphase = R; pa.nparts = R * ntiles_inv; pa.part = part_peak; pa.Bz = Bz; pa.tw1d = tw1d;
         pa.sums = sums; pa.remove_mean = rm_mean; pa.dc = dc; pa.dfv = dfv; pa.dfidx = dfidx; pa.inv_scale = 1.0 / scale_pow2;
         pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.convention = cfg.convention; pa.snr_valid = snr_valid; pa.res = out_dev; pa.res_stride = res_stride;
+        pa.chk_flag = chk_slot ? chk_slot->chk_flag : nullptr;
         if (!map_only) {
             ProfScope ps(this, PC_PEAK, nb);
             for (int it = 0, ne = reps(PC_PEAK); it < ne; ++it)
@@ -1938,6 +1967,9 @@ static int create_impl(const twx_config* cfg, twx_ctx** out) {
     int rc = guarded(c, [&]() { return c->init(); });
     if (rc) { g_create_err = c->err; delete c; return rc; }
     c->cfg.chips = nullptr;
+    // TWX_SELFCHECK=<value of TWX_OPT_SELFCHECK>: the option's default for every context of the process whose row pass has the form
+    // (contexts of other shapes stay as they are; twx_set_option overrides either way)
+    if (const char* e = getenv("TWX_SELFCHECK")) { if (atoll(e) > 0) { (void)c->set_selfcheck(atoll(e)); c->err.clear(); } }
     twx_ctx* h = new (std::nothrow) twx_ctx{c};
     if (!h) { delete c; g_create_err = "out of host memory"; return TWX_E_NOMEM; }
     *out = h;
@@ -2004,11 +2036,27 @@ int twx_set_option(twx_ctx* ctx, int32_t option, int64_t value) {
     if (!ctx) return TWX_E_ARG;
     if (option == TWX_OPT_REMOVE_MEAN) { (void)ctx->impl->sync_all(); ctx->impl->remove_mean = value ? 1 : 0; return TWX_OK; }
     if (option == TWX_OPT_DEBUG_ONLY) { if (value > PC_PEAK) return ctx->impl->fail(TWX_E_ARG, "no such kernel class"); ctx->impl->dbg_only = value < 0 ? -1 : (int)value; return TWX_OK; }
+    if (option == TWX_OPT_SELFCHECK) return ctx->impl->set_selfcheck(value);
+    if (option == TWX_OPT_DEBUG_FAULT) { ctx->impl->dbg_fault = (int)value; return TWX_OK; }
     if (option == TWX_OPT_FIR_MFMA) { ctx->impl->fir_mfma = value < 0 ? -1 : (value ? 1 : 0); return TWX_OK; }
     if (option == TWX_OPT_DEBUG_REPEAT) { ctx->impl->dbg_repeat = (int)std::max<long long>(1, std::min<long long>(value, 1000000)); return TWX_OK; }
     return ctx->impl->fail(TWX_E_ARG, "unknown option");
 }
 void* twx_stream(twx_ctx* ctx) { return ctx ? (void*)ctx->impl->stream : nullptr; }
+int twx_selfcheck_stats(twx_ctx* ctx, double* max_rel_dev, int64_t* rows_flagged, int32_t reset) {
+    if (!ctx) return TWX_E_ARG;
+    CtxBase* c = ctx->impl;
+    if (!c->chk_stat) return c->fail(TWX_E_STATE, "TWX_OPT_SELFCHECK was never switched on in this context");
+    (void)hipSetDevice(c->dev);
+    if (int rc = c->sync_all()) return rc;
+    unsigned h[2] = {0, 0};
+    if (hipMemcpy(h, c->chk_stat, 8, hipMemcpyDeviceToHost) != hipSuccess) return c->fail(TWX_E_HIP, "D2H failed");
+    float f; memcpy(&f, &h[0], 4);
+    if (max_rel_dev) *max_rel_dev = (double)f;
+    if (rows_flagged) *rows_flagged = (int64_t)h[1];
+    if (reset && hipMemset(c->chk_stat, 0, 8) != hipSuccess) return c->fail(TWX_E_HIP, "memset failed");
+    return TWX_OK;
+}
 
 int twx_process_windows(twx_ctx* ctx, const int16_t* iq, int64_t n_windows, int32_t n_channels, int32_t channel,
                         const twx_band* band, const double* df, twx_result* out) {

@@ -65,7 +65,8 @@ template <typename T> int rowd(int mode, const void* args, unsigned nblk, hipStr
         else if (mode == ROW_MID) {
             unsigned grid = nblk;                          // resident workgroups walk the rows (a.total_rows = nblk)
             if (rowd_mid_resident<P, T>() && a.r.pf_stride > 0 && (unsigned)a.r.pf_stride < nblk) grid = (unsigned)a.r.pf_stride;
-            TWX_LAUNCH((k_rowd<P, T, ROW_MID, NTD>), dim3(grid), dim3(NTD), s, a);
+            if (a.chk_rows) TWX_LAUNCH((k_rowd<P, T, ROW_MID, NTD, true>), dim3(grid), dim3(NTD), s, a);      // TWX_OPT_SELFCHECK: Parseval per row
+            else TWX_LAUNCH((k_rowd<P, T, ROW_MID, NTD>), dim3(grid), dim3(NTD), s, a);
         } else return -1;
         }
         return (int)hipGetLastError();

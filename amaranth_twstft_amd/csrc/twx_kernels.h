@@ -1077,7 +1077,29 @@ template <typename T> struct RowDArgs {
     int nprune;                      // number of (q1, q2) pairs, 0 = full last stage
     unsigned long long pr_q1, pr_q2; // pair p in byte p
     unsigned total_rows;             // N1 * windows (the grid is smaller when k_rowd<MID> runs with resident workgroups)
+    // TWX_OPT_SELFCHECK (the CHK instantiation of k_rowd<MID>): per window a status word, context-wide statistics, the relative tolerance
+    float* chk_rows;                 // [b][k1][TWX_CHK_SLOTS]: the row's energy sums, compared by k_chk_verdict
+    int chk_fault;                   // TWX_OPT_DEBUG_FAULT (CHK instantiation only): 0 none; 2*(row + 1) + which damages one value of that row —
+                                     // which 0: between the forward stages, 1: between the inverse stages of the last phase
 };
+
+// TWX_OPT_SELFCHECK: energy sums of one row, reduced over the wave (DPP-free butterfly on shuffles) and added to the workgroup's LDS slot
+// (DPP inside the rows of 16 lanes — no LDS traffic, no address registers: the kernel has none to spare — then four v_readlane)
+#define TWX_DPP_ADD(v, ctrl) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true)))
+__device__ __forceinline__ void chk_add(float* slot, float v) {
+    v = TWX_DPP_ADD(v, 0xB1);       // quad_perm [1,0,3,2]
+    v = TWX_DPP_ADD(v, 0x4E);       // quad_perm [2,3,0,1]
+    v = TWX_DPP_ADD(v, 0x141);      // row_half_mirror
+    v = TWX_DPP_ADD(v, 0x140);      // row_mirror: every lane of a row of 16 holds the row's sum
+    const int iv = __builtin_bit_cast(int, v);
+    const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16)) +
+                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    if ((threadIdx.x & 63) == 0) atomicAdd(slot, t);
+}
+#ifndef TWX_CHK_PARTS
+#define TWX_CHK_PARTS 7      // diagnostic: bit 0 the |A|^2 sum, bit 1 spectrum + product, bit 2 the Bz sums
+#endif
+#define TWX_CHK_SLOTS (3 + TWX_MAX_PHASE)     // |A row|^2, |spectrum row|^2, |product row|^2, |Bz row|^2 of every phase
 
 #ifdef TWX_ROWD_CHECK
 template <typename T, int R> __device__ __attribute__((noinline)) void rowd_check_bfly(const cpx<T>* in, cpx<T>* out) {
@@ -1096,6 +1118,7 @@ __device__ __attribute__((noinline)) RowdCheck4 rowd_check4(cpx<float> a, cpx<fl
     return RowdCheck4{t[0], t[1], t[2], t[3]};
 }
 #endif
+template <class P> constexpr int N2_of_rowd() { return P::L; }
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1110,10 +1133,17 @@ template <class P2, typename T> constexpr bool rowd_mid_resident() {
     return TWX_MID_PERSIST && TWX_MID_FOLD && D::R0 > 1 && (sizeof(T) == 4 || (TWX_MID_PERSIST64 && fits64)) && D::M % 16 == 0;
 }
 
-template <class P2, typename T, int MODE, int NT>
+// CHK (TWX_OPT_SELFCHECK, MID only): every row is checked against Parseval's identity in both directions — sum |A row|^2 * N2 = sum |spectrum
+// row|^2 for the forward transform, sum |product row|^2 * N2 = sum |Bz row|^2 for every phase of the inverse (all twiddles, ramps and folded
+// factors have modulus one) — from values the passes hold in registers anyway: a wave reduction and one LDS atomic per sum and wave, compared
+// by one thread a barrier later.  A row outside the tolerance sets bit 0 of its window's status word (k_peak copies it into
+// twx_result.status).  This is the detector for the fault class of profiles/r05_fir_mfma.txt: whole rows of this pass going wrong while
+// some other kernel's waves are resident beside it, with nothing in either source to show for it.
+template <class P2, typename T, int MODE, int NT, bool CHK = false>
 __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) void k_rowd(RowDArgs<T> ad) {
     using C = cpx<T>;
     using D = RowD<P2, T>;
+    static_assert(!CHK || MODE == ROW_MID, "the self-check belongs to the middle pass");
     const RowArgs<T>& a = ad.r;
     constexpr int N2 = D::L, R = D::R, R0 = D::R0, M = D::M, NU = R0 * R;
     constexpr int RMAX = R > R0 ? R : R0;
@@ -1138,8 +1168,21 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     C* s_vc = s_eb + NEB;
     C* s_tc = s_vc + NVC;                   // PERSIST: the forward table tc as loaded (tabs[tab_c..] is folded per row and restored from here)
     void* red = (void*)(s_tc + NTC);
+    __shared__ float s_chk[CHK ? 2 * TWX_CHK_SLOTS : 1];     // [row parity][sum]: a row's sums are compared (and cleared) one barrier into the next row
     const unsigned total = PERSIST ? ad.total_rows : gridDim.x;
     const int tid0 = threadIdx.x;
+    if constexpr (CHK) { if (tid0 < 2 * TWX_CHK_SLOTS) s_chk[tid0] = 0.f; }
+    int chk_par = 0, chk_prev_row = -1;
+    // a row's sums leave for global memory one workgroup barrier into the next row (every wave reached that barrier behind its atomics);
+    // k_chk_verdict compares them — nothing of the comparison costs this kernel a register
+    auto chk_flush = [&](int par, int row) {
+        if constexpr (CHK) {
+            if (tid0 < TWX_CHK_SLOTS) {
+                ad.chk_rows[(long long)row * TWX_CHK_SLOTS + tid0] = s_chk[par * TWX_CHK_SLOTS + tid0];
+                s_chk[par * TWX_CHK_SLOTS + tid0] = 0.f;
+            }
+        }
+    };
     TWX_STAMP(30);
     C v[RMAX];
     C csr[MODE == ROW_MID ? R : 1];
@@ -1216,6 +1259,12 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
         TWX_UNROLL
         for (int r = 0; r < R0; ++r) v[r] = pr[r];
     }
+    if constexpr (CHK && (TWX_CHK_PARTS & 1)) {
+        float sa = 0.f;
+        TWX_UNROLL
+        for (int r = 0; r < R0; ++r) sa += (float)cnorm(v[r]);
+        chk_add(s_chk + chk_par * TWX_CHK_SLOTS + 0, tid < M ? sa : 0.f);      // (the idle lanes of the last wave hold a copy of element M-1)
+    }
     // the code spectrum of the row: needed after the forward transform.  One trip: issued with the row's start.  Resident
     // workgroups: after stage 0 has put its outputs into LDS, when v[] is free — at the row's start the butterfly's temporaries,
     // v[] and 40 landing registers do not fit into 128 (the L2 round trip is covered by the barrier and two stages either way)
@@ -1260,6 +1309,7 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     // first row: tables visible (the row loads are in flight meanwhile); later rows: the previous row's stage C has read every
     // block, and the restored table tc is visible
     __syncthreads();
+    if constexpr (CHK) { if (chk_prev_row >= 0) chk_flush(chk_par ^ 1, chk_prev_row); }
     TWX_STAMP(2);
     if (tid < M) {
         if constexpr (!PERSIST) Bfly<T, R0, false>::run(v);
@@ -1301,6 +1351,9 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     }
 #endif
     if (act) D::f1(lds, tabs, q0, qi, v);
+    if constexpr (CHK) {       // diagnostic fault: one element of the row between the forward stages, as a wrong butterfly output would leave it
+        if (ad.chk_fault == 2 * ((int)logical + 1) && tid == 0) { wave_sync_lds(); lds[D::phys(0, 1, 0)] = cscale(lds[D::phys(0, 1, 0)], T(1.5)); }
+    }
     TWX_STAMP(5);
     bool pruned = false;
     if constexpr (MODE == ROW_BAND) pruned = ad.nprune > 0;
@@ -1356,8 +1409,17 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
         if (act && k1 == 0 && u == 0) a.dc[b] = v[0];
         // in every lane (the idle ones of the last wave multiply leftovers): a conditional definition would keep the previous
         // contents of pr[] — the row loaded ahead — alive through the whole forward part
+        float chk_sx = 0.f, chk_sp = 0.f;
         TWX_UNROLL
-        for (int q2 = 0; q2 < R; ++q2) pr[q2] = cmul(v[q2], csr[q2]);      // ffty.*fcode (godual_ranging.m:26)
+        for (int q2 = 0; q2 < R; ++q2) {
+            if constexpr (CHK && (TWX_CHK_PARTS & 2)) chk_sx += (float)cnorm(v[q2]);
+            pr[q2] = cmul(v[q2], csr[q2]);      // ffty.*fcode (godual_ranging.m:26)
+            if constexpr (CHK && (TWX_CHK_PARTS & 2)) chk_sp += (float)cnorm(pr[q2]);
+        }
+        if constexpr (CHK && (TWX_CHK_PARTS & 2)) {
+            chk_add(s_chk + chk_par * TWX_CHK_SLOTS + 1, act ? chk_sx : 0.f);
+            chk_add(s_chk + chk_par * TWX_CHK_SLOTS + 2, act ? chk_sp : 0.f);
+        }
         // the thread's part of the folded output twiddle: asked for here, where csr[] has just left its registers, and met
         // after the first inverse butterfly (held from the row's start it was spilled)
         if constexpr (FOLD) fa = ad.vw[(long long)k1 * 2 * R + min(qi, R - 1)];
@@ -1396,6 +1458,9 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
             TWX_STAMP(8 + rho * 6);
             if constexpr (FOLD) { if (lact) D::iB_folded(lds, tabs, lq0, lqi, cmul(wa0, r1), v); }
             else if (lact) D::iB(lds, tabs, lq0, lqi, v);
+            if constexpr (CHK) {
+                if (ad.chk_fault == 2 * ((int)logical + 1) + 1 && rho == a.nphase - 1 && lt == 0) { wave_sync_lds(); lds[D::phys(0, 1, 0)] = cscale(lds[D::phys(0, 1, 0)], T(1.5)); }
+            }
             TWX_STAMP(9 + rho * 6);
             __syncthreads();
             TWX_STAMP(10 + rho * 6);
@@ -1409,9 +1474,17 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                 // later wait for a load issued before them (the next phase's ramp factor, the next row) becomes vmcnt(0): a store
                 // round trip per phase.  Unconditional, they are counted: vmcnt(20).
                 constexpr bool ST16 = TWX_MID_ST16 && FOLD && sizeof(T) == 4 && R0 % 2 == 0 && M % 2 == 0;
+                static_assert(!(CHK && ST16), "the self-check sums the plain store path");
                 // ST16: the idle lanes repeat the PAIR (M-2, M-1), so that every lane pair exchanges like a live one
                 const int ltc = ST16 ? (lt < M ? lt : M - 2 + (lt & 1)) : min(lt, M - 1);
                 D::iC(lds, ltc, v);
+                if constexpr (CHK && (TWX_CHK_PARTS & 4)) {
+                    // the phase's outputs before their last factor (modulus one): |Bz row|^2 without touching the store loop's registers
+                    float sb = 0.f;
+                    TWX_UNROLL
+                    for (int c = 0; c < R0; ++c) sb += (float)cnorm(v[c]);
+                    chk_add(s_chk + chk_par * TWX_CHK_SLOTS + 3 + rho, lt < M ? sb : 0.f);     // (idle lanes repeat lane M-1's work)
+                }
                 const C uu = cmul(ub, r1);
                 C* out = a.Bz + ((long long)b * a.nphase + rho) * a.n + (long long)k1 * N2;
                 const unsigned ltb = (unsigned)ltc * (unsigned)sizeof(C);
@@ -1438,7 +1511,7 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                         const unsigned rowoff = (unsigned)((c + (odd ? 1 : 0)) * M) * (unsigned)sizeof(C);
                         if (TWX_ABLR != 1) st_pin<f4, TWX_NT_BZ != 0>(ob, 0ull, ltb16 + rowoff, w);
                     }
-                } else
+                } else {
                 TWX_UNROLL
                 for (int c = 0; c < R0; ++c) {
                     C o;                                                                       // · W_N^{-k1 (t + c M)} · ramp1
@@ -1453,6 +1526,7 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
                     } else
 #endif
                     if (TWX_ABLR != 1) st_pin<C, TWX_NT_BZ != 0>(ob, (unsigned long long)c * M * sizeof(C), ltb, o);     // SGPR base + lane offset
+                }
                 }
             }
             TWX_STAMP(11 + rho * 6);
@@ -1473,8 +1547,50 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
             TWX_STAMP(12 + rho * 6);
         }
     }
+    if constexpr (CHK) { chk_prev_row = b * a.n1 + k1; chk_par ^= 1; }
     } while (PERSIST && (vb += gridDim.x) < total);        // rows of this workgroup
+    if constexpr (CHK) {
+        __syncthreads();                                   // the last row's sums are complete
+        if (chk_prev_row >= 0) chk_flush(chk_par ^ 1, chk_prev_row);
+    }
     TWX_STAMP(31);
+}
+
+// TWX_OPT_SELFCHECK, second half: Parseval's identity per row from the sums k_rowd<MID, CHK> left — |A row|^2 N2 = |spectrum row|^2, and
+// |product row|^2 N2 = |Bz row|^2 for every phase.  A row outside the tolerance (or not a number) sets bit 0 of its window's flag word;
+// stat[0] keeps the largest relative deviation the context has seen (float bits), stat[1] counts the rows flagged.   grid = windows
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_chk_verdict(const float* __restrict__ rows, int n1, int n2, int nphase, float tol, int* __restrict__ flag,
+                                                    unsigned* __restrict__ stat) {
+    const int b = blockIdx.x;
+    float worst = 0.f; int nbad = 0;
+    for (int k1 = threadIdx.x; k1 < n1; k1 += 256) {
+        const float* c = rows + ((long long)b * n1 + k1) * TWX_CHK_SLOTS;
+        const float fn = (float)n2;
+        float dev;
+        if (c[0] == 0.f && c[1] == 0.f && c[2] == 0.f) {           // an all-zero row stays zero
+            dev = 0.f;
+            for (int rho = 0; rho < nphase; ++rho) dev = fmaxf(dev, c[3 + rho]);
+        } else {
+            dev = fabsf(c[1] - fn * c[0]) / (fn * c[0]);
+            for (int rho = 0; rho < nphase; ++rho) { const float d = fabsf(c[3 + rho] - fn * c[2]) / (fn * c[2]); dev = (d > dev || !(d == d)) ? d : dev; }
+        }
+        if (!(dev <= tol)) ++nbad;
+        if (!(dev == dev)) dev = __uint_as_float(0x7f800000u);
+        worst = fmaxf(worst, dev);
+    }
+    __shared__ float s_w[256]; __shared__ int s_n[256];
+    s_w[threadIdx.x] = worst; s_n[threadIdx.x] = nbad;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) { s_w[threadIdx.x] = fmaxf(s_w[threadIdx.x], s_w[threadIdx.x + d]); s_n[threadIdx.x] += s_n[threadIdx.x + d]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        flag[b] = s_n[0] ? 1 : 0;
+        atomicMax(stat, __float_as_uint(s_w[0]));
+        if (s_n[0]) atomicAdd(stat + 1, (unsigned)s_n[0]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2161,6 +2277,7 @@ template <typename T> struct PeakArgs {
     int snr_valid;               // 0: replica is not a +-1 code, the wipe-off statistics are undefined
     twx_result* res;             // record of window b at res[b * res_stride]
     int res_stride;              // 1, or the channel count when all channels of a window are interleaved in the output
+    const int* chk_flag;         // TWX_OPT_SELFCHECK: the window's status word of k_chk_verdict (nullptr: off)
     int snr_only;                // 1: second call of a Hamming-window context — Bz now holds the correlation with the UNWINDOWED
                                  // replica; the peak is the one already in the record, only the wipe-off statistics are written
 };
@@ -2262,10 +2379,11 @@ __global__ __launch_bounds__(1024) void k_peak(PeakArgs<T> a) {
         r.SNRi = ok ? mi * mi / var : nan("");
         r.puissancecode = ok ? mr * mr + mi * mi : nan("");
         r.puissancenoise = ok ? var : nan("");
-        r.status = 0; r.reserved = 0;
+        r.status = (a.chk_flag && a.chk_flag[b]) ? TWX_STATUS_SELFCHECK : 0; r.reserved = 0;
         if (a.snr_only) {                                                  // everything but the wipe-off statistics stays as the first call left it
             twx_result o = a.res[(long long)b * a.res_stride];
             o.SNRr = r.SNRr; o.SNRi = r.SNRi; o.puissancecode = r.puissancecode; o.puissancenoise = r.puissancenoise;
+            o.status |= r.status;
             r = o;
         }
         a.res[(long long)b * a.res_stride] = r;

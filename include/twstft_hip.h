@@ -101,8 +101,12 @@ typedef struct twx_result {
     double df;               /* carrier offset used (Hz) */
     int64_t df_index;        /* 0-based fftshifted arg-max index of |fft(d.^2)|, -1 if df was supplied */
     double SNRr, SNRi, puissance, puissancecode, puissancenoise;   /* godual_ranging.m:44-48 */
-    int32_t status, reserved;
+    int32_t status;          /* 0, or TWX_STATUS_* bits */
+    int32_t reserved;
 } twx_result;
+/* twx_result.status bits.  TWX_STATUS_SELFCHECK: TWX_OPT_SELFCHECK was on and a row of this window's middle pass broke Parseval's
+ * identity — the record is not to be trusted (re-run the window). */
+enum { TWX_STATUS_SELFCHECK = 1 };
 
 typedef struct twx_info {
     int64_t n;               /* complex samples per channel-window = n_chips*sps */
@@ -177,13 +181,28 @@ enum { TWX_OPT_REMOVE_MEAN = 1,
         * 7 k_peak; -1 = the whole chain again), TWX_OPT_DEBUG_REPEAT times per batch, on whatever the batch buffers hold
         * from the last complete call.  Results of such a call are meaningless. */
        TWX_OPT_DEBUG_ONLY = 100, TWX_OPT_DEBUG_REPEAT = 101,
+       /* Diagnostic of TWX_OPT_SELFCHECK (ignored while that option is off): damage ONE value of one row of the middle pass of every batch —
+        * value = 2 * (row + 1) + which, row = k1 * batch_windows + window-in-batch; which 0: between the stages of the forward row
+        * transform, 1: between the stages of the last phase's inverse transform; 0 = none.  The window must come back flagged. */
+       TWX_OPT_DEBUG_FAULT = 102,
        /* The matrix-core form of the FIR front end (k_fir_mfma) for twx_fir_decimate_dev on THIS context: 1 = use it, 0 = never,
         * -1 (default) = follow the environment variable TWX_FIR_MFMA.  That kernel is 20 % faster than the vector form and makes
         * packed-fp32 arithmetic of waves resident beside it go wrong (profiles/r05_fir_mfma.txt), so the library never lets it share the
         * device with other work of the process: every such launch is ordered behind everything this library has enqueued on the device
         * so far, on any context or stream, and everything enqueued later waits for it (csrc/twx_internal.h).  Work of OTHER processes on
         * the same GPU is out of the library's reach: leave the option off unless the process owns the GPU. */
-       TWX_OPT_FIR_MFMA = 2 };
+       TWX_OPT_FIR_MFMA = 2,
+       /* Run-time self-check of the fused middle pass (FFT pass 2, x conj(FFT(code)), the R inverse row transforms = what
+        * godual_ranging.m:25-28 asks of that pass): per row, sum |input row|^2 * N2 against sum |spectrum row|^2 and sum |product row|^2 * N2
+        * against sum |output row|^2 of every phase (Parseval; every twiddle and ramp has modulus one), from values the pass holds in
+        * registers.  A row outside the tolerance sets TWX_STATUS_SELFCHECK in its window's record.  value: 0 = off (default), 1 = on at
+        * 1e-5 relative, > 1 = the tolerance in units of 1e-9.  The detector for silent faults of the fault class of
+        * profiles/r05_fir_mfma.txt (whole rows of this pass wrong while another kernel is resident beside it).  Rows of 4000 / 8000 points
+        * (three-stage plans); TWX_E_ARG elsewhere.  The environment variable TWX_SELFCHECK=<value> is the default of every context created
+        * afterwards whose pass has the form.  twx_selfcheck_stats: the largest relative deviation seen and the number of rows
+        * flagged since the last reset (synchronises the context). */
+       TWX_OPT_SELFCHECK = 3 };
+int twx_selfcheck_stats(twx_ctx* ctx, double* max_rel_dev, int64_t* rows_flagged, int32_t reset);
 int twx_set_option(twx_ctx* ctx, int32_t option, int64_t value);
 void* twx_stream(twx_ctx* ctx);                      /* hipStream_t of the context */
 

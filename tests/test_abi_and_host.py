@@ -296,7 +296,7 @@ def test_row_walking_kernel_fits_two_workgroups_per_cu(tmp_path):
     seen = 0
     for blk in txt.split("  - .agpr_count:")[1:]:
         name = re.search(r"\.name:\s+(\S+)", blk).group(1)
-        if "k_rowdINS_4PlanILi8000" in name and "EEEfLi2ELi448" in name:        # float, MODE = ROW_MID
+        if "k_rowdINS_4PlanILi8000" in name and "EEEfLi2ELi448ELb0E" in name:   # float, MODE = ROW_MID, CHK = false (the shipped default form)
             seen += 1
             vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
             spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))

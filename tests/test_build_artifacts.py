@@ -25,14 +25,19 @@ def test_no_kernel_of_the_library_or_a_plan_plugin_spills_registers():
     Stockham middle pass of the 4000 / 8000-point rows, the fp64 400-point row pass, one column pass of the complex-double entry)."""
     rows, paths = _rows()
     assert len(rows) > 300, "metadata of the code objects not found (%d kernels in %s)" % (len(rows), paths)
-    bad = [(r["file"], r["kernel"], r["vgpr_spill"], r["scratch"]) for r in rows if r["vgpr_spill"] or r["scratch"]]
+    # (the one exemption: the opt-in TWX_OPT_SELFCHECK instantiations of k_rowd<MID> — template argument CHK = true, mangled `Lb1E` — which
+    # add their sums to a kernel that sits exactly at its 128-register budget; bounded here, their cost is measured in profiles/r06_selfcheck.txt)
+    selfcheck = lambda r: r["kernel"].startswith("_ZN3twx6k_rowdI") and "Lb1EE" in r["kernel"]
+    bad = [(r["file"], r["kernel"], r["vgpr_spill"], r["scratch"]) for r in rows if (r["vgpr_spill"] or r["scratch"]) and not selfcheck(r)]
     assert not bad, "kernels with vector spills / scratch: %r" % (bad[:8],)
+    heavy = [(r["kernel"], r["scratch"]) for r in rows if selfcheck(r) and r["scratch"] > 64]
+    assert not heavy, "self-check instantiations with more than 64 bytes of scratch per lane: %r" % (heavy,)
 
 
 def test_dominant_kernel_keeps_its_register_and_lds_budget():
     """k_rowd<Plan<8000,20,20,20>, float, MID>: four workgroups of seven waves per CU need <= 128 VGPRs and <= 80 KB of LDS."""
     rows, _ = _rows()
-    mid = [r for r in rows if r["kernel"].startswith("_ZN3twx6k_rowdINS_4PlanILi8000ELi20ELi20ELi20ELi1EEEfLi2E")]
+    mid = [r for r in rows if r["kernel"].startswith("_ZN3twx6k_rowdINS_4PlanILi8000ELi20ELi20ELi20ELi1EEEfLi2E") and "Lb0EE" in r["kernel"]]
     assert mid, "the fp32 middle pass of the 8000-point row is not in the library"
     for r in mid:
         assert r["vgpr"] <= 128 and r["lds"] <= 81920 and r["vgpr_spill"] == 0, r

@@ -153,6 +153,13 @@ __global__ __launch_bounds__(448) void k_rowmid(const float2* __restrict__ A, fl
     }
 }
 
+__global__ __launch_bounds__(256) void k_fill_random(unsigned* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned long long z = (i + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+        z ^= z >> 29; z *= 0x94D049BB133111EBull; z ^= z >> 32;
+        p[i] = 0x3F000000u | ((unsigned)z & 0x007FFFFFu) | ((unsigned)(z >> 40) & 0x80000000u);     // floats of magnitude 0.5..1, random mantissa and sign
+    }
+}
 template <class F> static double time_ms(F f, int reps) {
     hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
     f(); CHK(hipDeviceSynchronize());
@@ -170,8 +177,12 @@ int main(int argc, char** argv) {
     void *a = nullptr, *b = nullptr; float* sink = nullptr;
     CHK(hipMalloc(&a, bytes)); CHK(hipMalloc(&b, bytes)); CHK(hipMalloc(&sink, 64));
     CHK(hipMemset(a, 1, bytes)); CHK(hipMemset(b, 2, bytes));
+    // argv[2] = "rand": the source buffer holds pseudo-random floats (what a kernel reads in production: every bit of the bus toggles)
+    // instead of one repeated byte — the difference is what constant test data flatter a memory system by
+    const bool randomised = argc > 2 && strcmp(argv[2], "rand") == 0;
+    if (randomised) { hipLaunchKernelGGL(k_fill_random, dim3(8192), dim3(256), 0, 0, (unsigned*)a, bytes / 4); CHK(hipDeviceSynchronize()); }
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
-    printf("device %s, %d CUs, buffers 2 x %.2f GiB\n", prop.name, prop.multiProcessorCount, gib);
+    printf("device %s, %d CUs, buffers 2 x %.2f GiB%s\n", prop.name, prop.multiProcessorCount, gib, randomised ? ", source: random floats" : ", source: one repeated byte");
     const int reps = 10;
     auto report = [&](const char* name, double ms, double moved) { printf("%-44s %8.3f ms  %8.1f GB/s\n", name, ms, moved / ms / 1e6); fflush(stdout); };
     const size_t n16 = bytes / 16, n8 = bytes / 8;
