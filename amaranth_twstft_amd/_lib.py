@@ -19,8 +19,10 @@ TWX_F32, TWX_F64 = 0, 1
 TWX_OPT_REMOVE_MEAN = 1
 TWX_OPT_FIR_MFMA = 2
 TWX_OPT_SELFCHECK = 3
+TWX_OPT_BRUIT_LEN, TWX_OPT_NOISE_SQUARE_LEN = 4, 5
 TWX_OPT_DEBUG_FAULT = 102
 TWX_STATUS_SELFCHECK = 1
+TWX_STATUS_RESAMPLE_NAN = 2
 TWX_FLAG_PROFILE = 1
 TWX_FLAG_FINE_FREQ = 2
 TWX_FLAG_CODE_ZERO_MEAN = 4
@@ -64,7 +66,11 @@ class twx_result(C.Structure):
                 ("df", C.c_double), ("df_index", C.c_int64),
                 ("SNRr", C.c_double), ("SNRi", C.c_double), ("puissance", C.c_double),
                 ("puissancecode", C.c_double), ("puissancenoise", C.c_double),
-                ("status", C.c_int32), ("reserved", C.c_int32)]
+                ("status", C.c_int32), ("dt", C.c_int32)]
+
+
+class twx_extra(C.Structure):
+    _fields_ = [("bruit", C.c_double), ("valmax_square", C.c_double), ("noise_square", C.c_double), ("reserved", C.c_double)]
 
 
 class twx_info(C.Structure):
@@ -165,6 +171,9 @@ SYMBOLS = {
     "twx_synchronize": (C.c_int, [_VP]),
     "twx_set_option": (C.c_int, [_VP, C.c_int32, C.c_int64]),
     "twx_stream": (_VP, [_VP]),
+    "twx_fetch_extra": (C.c_int, [_VP, C.POINTER(twx_extra), C.c_int64]),
+    "twx_set_resample": (C.c_int, [_VP, C.c_double, C.c_double, C.c_int64]),
+    "twx_get_resample": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "twx_selfcheck_stats": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
     "twx_fft_forward": (C.c_int, [_VP, _VP, _VP]),
     "twx_get_code_spectrum": (C.c_int, [_VP, _VP]),

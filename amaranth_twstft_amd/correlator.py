@@ -71,6 +71,8 @@ class WindowResult:
     puissance: float
     puissancecode: float
     puissancenoise: float
+    status: int = 0          # TWX_STATUS_* bits (self-check failed, resampled window all NaN)
+    dt: int = 0              # velocity-compensated window: the carried whole-sample offset the script adds to indice (godual_ranging_OP_vitesse.m:68)
 
     def correction_polyfit(self, half_width: int) -> float:
         """Parabola through 2·half_width+1 magnitude samples around the peak, ``[u,v]=polyfit([-h:+h]',abs(prnmap(indice-h:
@@ -92,7 +94,7 @@ def _to_result(r: L.twx_result) -> WindowResult:
     z = np.array([[p[0], p[1]] for p in r.zwin])
     return WindowResult(int(r.indice0), r.correction, complex(*r.xval), complex(*r.xvalm1), complex(*r.xvalp1),
                         z[:, 0] + 1j * z[:, 1], r.df, int(r.df_index), r.SNRr, r.SNRi, r.puissance,
-                        r.puissancecode, r.puissancenoise)
+                        r.puissancecode, r.puissancenoise, int(r.status), int(r.dt))
 
 
 ALL_CHANNELS = -1
@@ -345,6 +347,44 @@ class Correlator:
         if sp.size != self.n:
             raise ValueError("spectrum length must equal the window length")
         L.check(self._lib.twx_set_code_spectrum(self._h, sp.ctypes.data_as(C.c_void_p)), self._h)
+
+    def set_resample(self, vitesse: float, t0: float = 0.0, dt: int = 0):
+        """The velocity-compensated window of experiments/220706_TWSTFT/godual_ranging_OP_vitesse.m (:4 ``vitesse=-3.25e-9``): every
+        later window of this context is resampled after the NCO mix, ``yi=interp1([0:N-1],y,[0:N-1]*1/(1-vitesse)+t0)`` (:40), with
+        ``t0`` / ``dt`` carried from window to window as the script carries them (:41,:68-71; they start at 0).  ``vitesse = 0``: off.
+        Each ``WindowResult`` then holds its window's ``dt``: the script's ``indice1(p)`` is ``indice + 1 + dt``."""
+        L.check(self._lib.twx_set_resample(self._h, float(vitesse), float(t0), int(dt)), self._h)
+
+    def get_resample(self) -> tuple[float, float, int]:
+        """(vitesse, t0, dt) as they stand before the next window."""
+        v, t0, dt = C.c_double(), C.c_double(), C.c_int64()
+        L.check(self._lib.twx_get_resample(self._h, C.byref(v), C.byref(t0), C.byref(dt)), self._h)
+        return v.value, t0.value, int(dt.value)
+
+    def set_snr_estimators(self, bruit_len: int = 0, noise_square_len: int = 0):
+        """The other SNR estimators of experiments/220830_OP/process_OP.m beside the wipe-off SNR: ``bruit`` =
+        ``var(prnmap(indice+20:indice+20+bruit_len-1))`` (:119-121: 1001, :138: 10001) and ``valmax_square`` / ``noise_square`` =
+        the carrier peak of ``fftshift(abs(fft(d1.^2)))`` and the variance of the ``noise_square_len`` bins from 20 above it (:95-97:
+        10001).  0 = off.  :meth:`snr_estimators` returns them for the records of the last call."""
+        L.check(self._lib.twx_set_option(self._h, L.TWX_OPT_BRUIT_LEN, int(bruit_len)), self._h)
+        L.check(self._lib.twx_set_option(self._h, L.TWX_OPT_NOISE_SQUARE_LEN, int(noise_square_len)), self._h)
+
+    def snr_estimators(self, n_records: int) -> list[dict]:
+        """``[{bruit, valmax_square, noise_square}, ...]`` for the first ``n_records`` records of the last call (same order)."""
+        out = (L.twx_extra * max(n_records, 1))()
+        L.check(self._lib.twx_fetch_extra(self._h, out, n_records), self._h)
+        return [dict(bruit=out[i].bruit, valmax_square=out[i].valmax_square, noise_square=out[i].noise_square) for i in range(n_records)]
+
+    def set_selfcheck(self, value: int = 1):
+        """``TWX_OPT_SELFCHECK``: Parseval's identity per row of the fused middle pass; a window with a row outside the tolerance comes
+        back with ``status & TWX_STATUS_SELFCHECK``.  0 = off, 1 = 1e-5 relative, > 1 = the tolerance in units of 1e-9."""
+        L.check(self._lib.twx_set_option(self._h, L.TWX_OPT_SELFCHECK, int(value)), self._h)
+
+    def selfcheck_stats(self, reset: bool = True) -> tuple[float, int]:
+        """(largest relative Parseval deviation seen, rows flagged) since the last reset."""
+        d, n = C.c_double(), C.c_int64()
+        L.check(self._lib.twx_selfcheck_stats(self._h, C.byref(d), C.byref(n), 1 if reset else 0), self._h)
+        return d.value, int(n.value)
 
     def set_remove_mean(self, on: bool):
         """``d=d-mean(d)`` before the NCO (default on; the reference's callers do it, godual_ranging.m:80,94)."""

@@ -461,6 +461,14 @@ struct CtxBase {
     int dbg_only = -1, dbg_repeat = 1;   // TWX_OPT_DEBUG_ONLY / _REPEAT: launch one kernel class of the chain, n times (power / clock probes)
     int reps(int cls) const { return dbg_only < 0 ? 1 : (dbg_only == cls ? dbg_repeat : 0); }
     int snr_valid = 1;            // 0 for replicas that are not a +-1 code
+    // twx_set_resample: the velocity-compensated window (experiments/220706_TWSTFT/godual_ranging_OP_vitesse.m:4,40-43,68-71)
+    double rs_v = 0.0, rs_t0 = 0.0; long long rs_dt = 0;       // vitesse (0 = off), and the carried t0 / dt BEFORE the next window
+    virtual int set_resample(double vitesse, double t0, long long dt) = 0;
+    // TWX_OPT_BRUIT_LEN / TWX_OPT_NOISE_SQUARE_LEN: the off-peak and squared-spectrum SNR estimators of process_OP.m (k_offpeak, k_sq_noise)
+    int bruit_len = 0, sq_len = 0;
+    twx_extra* extra_dev = nullptr; size_t extra_cap = 0; long long extra_n = 0;   // the estimators of the LAST call, record for record
+    long long ex_off = -1;                   // record index of the batch being enqueued inside extra_dev (-1: this call has none)
+    virtual int set_extra(int which, long long value) = 0;
     // TWX_OPT_SELFCHECK: Parseval's identity per row of the middle pass (k_rowd<MID, CHK> + k_chk_verdict)
     float selfcheck_tol = 0.f;    // 0 = off
     unsigned* chk_stat = nullptr; // [0] largest relative deviation seen (float bits), [1] rows flagged — since the last reset
@@ -548,8 +556,14 @@ template <typename T> struct Ctx : CtxBase {
         short2* planar; WinSums* sums2;      // two-channel captures in all-channel mode: planar copies + both channels' sums (lazy)
         SumPart* sum_parts;                  // k_sums: [2][B][TWX_SUMS_MAXCHUNKS] per-workgroup partials
         double tables_df; int tables_nb;     // the NCO tables e1/e2 of windows [0, tables_nb) hold this carrier (tables_nb = 0: unknown)
+        double* ex_part_b; double* ex_part_s; double* ex_sqmax;   // the SNR estimators' partial sums (allocated when an option is first set)
         float* chk_rows; int* chk_flag;      // TWX_OPT_SELFCHECK (allocated when the option is first set): [B][N1][TWX_CHK_SLOTS] sums, [B] status words
     };
+    // twx_set_resample: per window of the CURRENT call the script's t0, edge word and dt (resample_begin), on the host and — uploaded
+    // before the first batch of the call is enqueued — on the device; rs_off = first window of the batch being enqueued (-1: none)
+    std::vector<double> rs_t0s, rs_t0_after; std::vector<int> rs_edges, rs_dts; std::vector<long long> rs_dt_after;
+    double* rs_dev_t0 = nullptr; int* rs_dev_edge = nullptr; int* rs_dev_dt = nullptr; size_t rs_dev_cap = 0;
+    long long rs_off = -1;
     Slot slots[4] = {}; int nslots = 1;
     bool sums_ready = false;                 // run_batch_in: `sums` already holds this batch's statistics (k_sums_deint2)
     hipEvent_t ev_fork = nullptr, ev_join[4] = {};   // ordering of slots 1.. against slot 0 = twx_stream() (process())
@@ -569,6 +583,90 @@ template <typename T> struct Ctx : CtxBase {
         static const int per_cu = [] { const char* e = getenv("TWX_SUMS_WGS"); return e ? std::max(1, atoi(e)) : 8; }();
         const long long want = ((long long)per_cu * ncu + nb - 1) / nb, cap = std::max<long long>(1, N / 4096);
         return (int)std::max<long long>(1, std::min<long long>(std::min(want, cap), TWX_SUMS_MAXCHUNKS));
+    }
+    int ex_blocks() const { return (std::max(bruit_len, 1) + 255) / 256; }
+    int set_extra(int which, long long value) override {
+        if (value < 0 || value == 1 || value > (1 << 20)) return fail(TWX_E_ARG, "estimator length: 0 (off) or 2 .. 1 048 576 samples");
+        if (which == 1 && value > 0 && N2 > 256 * TWX_SQN_EMAX) return fail(TWX_E_ARG, "TWX_OPT_NOISE_SQUARE_LEN: rows of more than 10 240 points are not supported");
+        if (int rc = sync_all()) return rc;
+        (which == 0 ? bruit_len : sq_len) = (int)value;
+        HIPCHK(hipSetDevice(dev));
+        for (int k = 0; k < nslots; ++k) {
+            Slot& q = slots[k];
+            if (q.ex_part_b) { dfree(q.ex_part_b); q.ex_part_b = nullptr; }
+            if (bruit_len > 0) { if (int rc = dalloc(&q.ex_part_b, (size_t)B * ex_blocks() * 3)) return rc; }
+            if (sq_len > 0 && !q.ex_part_s) { if (int rc = dalloc(&q.ex_part_s, (size_t)B * N1 * 2)) return rc; }
+            if (!q.ex_sqmax) { if (int rc = dalloc(&q.ex_sqmax, (size_t)B)) return rc; }
+        }
+        return TWX_OK;
+    }
+    bool extras_on() const { return bruit_len > 0 || sq_len > 0; }
+    // the records of a call start at index 0 of extra_dev: wait for the context's earlier work (it may still write there), grow if needed
+    int extra_begin(long long nrec) {
+        ex_off = -1; 
+        if (!extras_on() || nrec <= 0) { extra_n = 0; return TWX_OK; }
+        if (int rc = sync_all()) return rc;
+        if ((size_t)nrec > extra_cap) {
+            if (extra_dev) dfree(extra_dev);
+            extra_dev = nullptr; extra_cap = 0;
+            const size_t cap = (size_t)nrec + (size_t)nrec / 4 + 64;
+            if (int rc = dalloc(&extra_dev, cap)) return rc;
+            extra_cap = cap;
+        }
+        HIPCHK(hipMemset(extra_dev, 0xff, sizeof(twx_extra) * (size_t)nrec));        // (all-ones doubles are NaN: records a short call never reaches)
+        extra_n = nrec;
+        return TWX_OK;
+    }
+    int set_resample(double vitesse, double t0, long long dt) override {
+        if (!(vitesse == vitesse) || !(t0 == t0) || fabs(vitesse) >= 0.5 || fabs(t0) >= 2.0) return fail(TWX_E_ARG, "twx_set_resample: vitesse inside (-0.5, 0.5), t0 inside (-2, 2)");
+        if (vitesse != 0.0 && fabs((double)N * vitesse / (1.0 - vitesse)) >= 1.0)
+            return fail(TWX_E_ARG, "twx_set_resample: |N * vitesse| must stay under one sample per window (the script's t0 / dt bookkeeping assumes it: godual_ranging_OP_vitesse.m:70-71)");
+        if (int rc = sync_all()) return rc;
+        rs_v = vitesse; rs_t0 = t0; rs_dt = dt;
+        return TWX_OK;
+    }
+    // The script's loop bookkeeping for the next nwin windows (:40-43, :68-71), in fp64 with its own expressions, uploaded in one piece:
+    // a call with the option on first waits for the context's earlier work (the arrays of the previous call may still be read), which
+    // costs this variant the overlap between calls and nothing else.  resample_end(n) moves the carried state past n windows.
+    int resample_begin(long long nwin) {
+        if (rs_v == 0.0 || nwin <= 0) return TWX_OK;
+        if (int rc = sync_all()) return rc;
+        rs_t0s.resize((size_t)nwin); rs_edges.resize((size_t)nwin); rs_dts.resize((size_t)nwin); rs_t0_after.resize((size_t)nwin); rs_dt_after.resize((size_t)nwin);
+        const double n1 = (double)(N - 1), den = 1.0 - rs_v;
+        double t0c = rs_t0; long long dtc = rs_dt;
+        for (long long w = 0; w < nwin; ++w) {
+            const double t0 = t0c;
+            auto xq = [&](double n) { return (n * 1.0) / den + t0; };            // [0:N-1]*1/(1-vitesse)+t0
+            int edge = 0;
+            if (xq(0.0) < 0.0) edge |= 1;                                         // interp1 gives NaN outside [0, N-1]
+            if (xq(n1) > n1) edge |= 2;
+            if (xq(1.0) < 0.0 || xq(n1 - 1.0) > n1) edge |= 4;                    // more than the two edge samples: the whole map is NaN
+            rs_t0s[(size_t)w] = t0; rs_edges[(size_t)w] = edge; rs_dts[(size_t)w] = (int)dtc;
+            t0c = t0c + (double)N * rs_v;                                          // t0=t0+length(y)*vitesse
+            if (t0c >= 1.0) { t0c -= 1.0; dtc -= 1; }
+            if (t0c <= -1.0) { t0c += 1.0; dtc += 1; }
+            rs_t0_after[(size_t)w] = t0c; rs_dt_after[(size_t)w] = dtc;
+        }
+        if ((size_t)nwin > rs_dev_cap) {
+            if (rs_dev_t0) dfree(rs_dev_t0);
+            if (rs_dev_edge) dfree(rs_dev_edge);
+            if (rs_dev_dt) dfree(rs_dev_dt);
+            rs_dev_t0 = nullptr; rs_dev_edge = rs_dev_dt = nullptr; rs_dev_cap = 0;
+            const size_t cap = (size_t)nwin + (size_t)nwin / 4 + 64;
+            if (int rc = dalloc(&rs_dev_t0, cap)) return rc;
+            if (int rc = dalloc(&rs_dev_edge, cap)) return rc;
+            if (int rc = dalloc(&rs_dev_dt, cap)) return rc;
+            rs_dev_cap = cap;
+        }
+        HIPCHK(hipMemcpy(rs_dev_t0, rs_t0s.data(), sizeof(double) * nwin, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(rs_dev_edge, rs_edges.data(), sizeof(int) * nwin, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(rs_dev_dt, rs_dts.data(), sizeof(int) * nwin, hipMemcpyHostToDevice));
+        return TWX_OK;
+    }
+    void resample_end(long long ndone) {
+        rs_off = -1;
+        if (rs_v == 0.0 || ndone <= 0 || (size_t)ndone > rs_t0_after.size()) return;
+        rs_t0 = rs_t0_after[(size_t)ndone - 1]; rs_dt = rs_dt_after[(size_t)ndone - 1];
     }
     // value: 0 off, 1 on at the default tolerance (1e-5 relative), > 1 the tolerance in units of 1e-9
     int set_selfcheck(long long value) override {
@@ -1085,19 +1183,34 @@ template <typename T> struct Ctx : CtxBase {
         // second, both channels) skips the table kernel: 8 625 fp64 sincospi to write the same ones again
         Slot* cur_slot = nullptr;
         for (int k = 0; k < nslots; ++k) if (slots[k].e1 == e1) cur_slot = &slots[k];
+        const bool rs_on = rs_off >= 0 && intype == IN_I16 && rs_dev_t0 && !map_only && (size_t)(rs_off + nb) <= rs_t0s.size();
+        if (rs_off >= 0 && !rs_on) return fail(TWX_E_STATE, "the velocity-compensated window applies to int16 captures through twx_process_windows[_dev] / twx_process_file");
         Slot* chk_slot = (selfcheck_tol > 0.f && use_rowd && cur_slot && cur_slot->chk_rows && !map_only) ? cur_slot : nullptr;
         const bool same_tables = map_only && df_host && cur_slot && cur_slot->tables_nb >= nb && cur_slot->tables_df == df_host[0] && !(cfg.flags & TWX_FLAG_FINE_FREQ);
         if (!same_tables) {
             ProfScope ps(this, PC_DFT, nb);
             for (int it = 0, ne = reps(PC_DFT); it < ne; ++it)
             TWX_LAUNCH((k_df_tables<T>), dim3(nb, df_slices(nb)), dim3(256), stream, band ? 1 : 0, part_band, N1, dfv, dfidx, cfg.fs,
-                               (long long)N, N1, N2, e1, e2);
+                               (long long)N, N1, N2, e1, e2, (band && cur_slot) ? cur_slot->ex_sqmax : (double*)nullptr);
             HIPCHK(hipGetLastError());
             if (cur_slot) {
                 bool uniform = df_host && !band;
                 for (int i = 1; uniform && i < nb; ++i) uniform = df_host[i] == df_host[0];
                 cur_slot->tables_nb = uniform ? nb : 0;
                 cur_slot->tables_df = uniform ? df_host[0] : 0.0;
+            }
+        }
+        // the SNR estimators of process_OP.m (optional): the bins behind the carrier peak, while A still holds the squared signal's column pass
+        const bool ex_on = ex_off >= 0 && cur_slot && extra_dev && !map_only && (size_t)(ex_off + (long long)(nb - 1) * res_stride) < extra_cap;
+        if (ex_off >= 0 && !ex_on) return fail(TWX_E_STATE, "the SNR estimators are not available on this entry point");
+        ExtraArgs xa{};
+        if (ex_on) {
+            xa.n = N; xa.n1 = N1; xa.n2 = N2; xa.nphase = R; xa.bruit_len = bruit_len; xa.sq_len = sq_len;
+            xa.part_b = cur_slot->ex_part_b; xa.nblk_b = ex_blocks(); xa.part_s = cur_slot->ex_part_s; xa.sqmax = band ? cur_slot->ex_sqmax : nullptr;
+            xa.out = extra_dev + ex_off; xa.out_stride = res_stride;
+            if (band && sq_len > 0) {
+                TWX_LAUNCH((k_sq_noise<T>), dim3(N1, nb), dim3(256), stream, xa, (const C*)A, wshift_of(col->W), (const long long*)dfidx);
+                HIPCHK(hipGetLastError());
             }
         }
         if (cfg.flags & TWX_FLAG_FINE_FREQ) {
@@ -1108,13 +1221,19 @@ template <typename T> struct Ctx : CtxBase {
             TWX_LAUNCH((k_fine_fit<0>), dim3(nb), dim3(1024), stream, fine_u, fine_M, cfg.fs, dfv);
             HIPCHK(hipGetLastError());
             TWX_LAUNCH((k_df_tables<T>), dim3(nb, df_slices(nb)), dim3(256), stream, 2, part_band, N1, dfv, dfidx, cfg.fs,
-                               (long long)N, N1, N2, e1, e2);       // rebuild the NCO tables for df + dfleftover
+                               (long long)N, N1, N2, e1, e2, (double*)nullptr);       // rebuild the NCO tables for df + dfleftover
             HIPCHK(hipGetLastError());
         }
         {
             ProfScope ps(this, PC_COL_MIX, (long long)nb * N);
+            ResamplePtr rp{};
+            int mix_type = intype; const void* mix_in = colin;
+            if (rs_on) {
+                rp.iq = p0; rp.t0 = rs_dev_t0 + rs_off; rp.edge = rs_dev_edge + rs_off; rp.c = rs_v / (1.0 - rs_v);
+                mix_type = IN_I16RS; mix_in = &rp;
+            }
             for (int it = 0, ne = reps(PC_COL_MIX); it < ne; ++it)
-            if (col->fwd(COL_MIX, intype, colin, aux, &ca, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_fwd(mix) launch failed");
+            if (col->fwd(COL_MIX, mix_type, mix_in, aux, &ca, (unsigned)(ntiles * nb), stream)) return fail(TWX_E_HIP, "k_col_fwd(mix) launch failed");
         }
         {
             ProfScope ps(this, PC_ROW_MID, (long long)nb * N);
@@ -1141,10 +1260,20 @@ template <typename T> struct Ctx : CtxBase {
         pa.sums = sums; pa.remove_mean = rm_mean; pa.dc = dc; pa.dfv = dfv; pa.dfidx = dfidx; pa.inv_scale = 1.0 / scale_pow2;
         pa.var_ddof = cfg.var_ddof; pa.snr_rot = cfg.snr_rot; pa.convention = cfg.convention; pa.snr_valid = snr_valid; pa.res = out_dev; pa.res_stride = res_stride;
         pa.chk_flag = chk_slot ? chk_slot->chk_flag : nullptr;
+        pa.rs_dt = rs_on ? rs_dev_dt + rs_off : nullptr; pa.rs_edge = rs_on ? rs_dev_edge + rs_off : nullptr;
         if (!map_only) {
             ProfScope ps(this, PC_PEAK, nb);
             for (int it = 0, ne = reps(PC_PEAK); it < ne; ++it)
             TWX_LAUNCH((k_peak<T>), dim3(nb), dim3(1024), stream, pa);
+            HIPCHK(hipGetLastError());
+        }
+        if (ex_on) {
+            if (bruit_len > 0) {
+                TWX_LAUNCH((k_offpeak<T>), dim3(xa.nblk_b, nb), dim3(256), stream, xa, (const C*)Bz, (const cpx<double>*)tw1d, (const twx_result*)out_dev, res_stride,
+                           (int)cfg.convention, 1.0 / scale_pow2);
+                HIPCHK(hipGetLastError());
+            }
+            TWX_LAUNCH((k_extra_final<0>), dim3(nb), dim3(256), stream, xa, (const twx_result*)out_dev, res_stride, (const long long*)dfidx);
             HIPCHK(hipGetLastError());
         }
         if (!map_only && cspec_plain && snr_valid) {
@@ -1171,11 +1300,18 @@ template <typename T> struct Ctx : CtxBase {
         const int c_lo = all ? 0 : ch, c_hi = all ? nch : ch + 1, ostride = all ? nch : 1;
         std::vector<double> dfc;
         int k = 0;
+        struct RsScope { long long& off; ~RsScope() { off = -1; } } rs_scope{rs_off};
+        if (rs_v != 0.0) {
+            if (all) return fail(TWX_E_ARG, "the velocity-compensated window (twx_set_resample) takes one channel at a time");
+            if (int rc0 = resample_begin(nwin)) return rc0;
+        }
+        struct ExScope { long long& off; ~ExScope() { off = -1; } } ex_scope{ex_off};
+        if (int rc0 = extra_begin(nwin * ostride)) return rc0;
         // One-batch calls with the carrier search on the device (the per-second callers: MEX form A, the receiver's loop) enqueue
         // nothing but kernels on slot 0's stream: the sequence is captured once per (buffers, band) and replayed as a hipGraph —
         // one submission instead of nine launches.  Anything the kernels' arguments hold is in the key or fixed for the context's
         // life (slot buffers, tables; twx_set_code_spectrum* rewrites the spectrum in place).
-        if (graphs_enabled() && !profile && dbg_only < 0 && !stamps_dev && band && !df && !all && nwin <= B) {
+        if (graphs_enabled() && !profile && dbg_only < 0 && !stamps_dev && band && !df && !all && nwin <= B && rs_v == 0.0) {
             if (band->k_lo < 0 || band->k_hi >= N || band->k_lo > band->k_hi) return fail(TWX_E_ARG, "band outside 0..N-1");
             GraphEntry* g = nullptr;
             for (auto& e : graphs)
@@ -1220,7 +1356,7 @@ template <typename T> struct Ctx : CtxBase {
             for (int j = 1; j < nused; ++j) HIPCHK(hipStreamWaitEvent(slots[j].stream, ev_fork, 0));
         }
         int rc = TWX_OK;
-        const bool deint = all && nch == 2 && frames_ok_2ch(iq_dev);
+        const bool deint = all && nch == 2 && frames_ok_2ch(iq_dev) && !extras_on();
         std::vector<double> dfc1;
         for (long long w0 = 0; w0 < nwin && rc == TWX_OK; w0 += B) {
             const int nb = (int)std::min<long long>(B, nwin - w0);
@@ -1244,6 +1380,8 @@ template <typename T> struct Ctx : CtxBase {
                 }
                 use_slot(k);
                 const short2* base = reinterpret_cast<const short2*>(iq_dev) + c;
+                rs_off = rs_v != 0.0 ? w0 : -1;
+                ex_off = extras_on() ? w0 * ostride + (all ? c : 0) : -1;
                 rc = run_batch(base + w0 * N * nch, nb, nch, band, dfp, out_dev + w0 * ostride + (all ? c : 0), nullptr, false, ostride);
             }
         }
@@ -1252,6 +1390,7 @@ template <typename T> struct Ctx : CtxBase {
             if (hipEventRecord(ev_join[j], slots[j].stream) != hipSuccess || hipStreamWaitEvent(slots[0].stream, ev_join[j], 0) != hipSuccess)
                 if (rc == TWX_OK) rc = fail(TWX_E_HIP, "slot join failed");
         }
+        if (rc == TWX_OK) resample_end(nwin);
         return rc;
     }
 
@@ -1386,6 +1525,15 @@ template <typename T> struct Ctx : CtxBase {
         const bool all = ch < 0;
         if (all && nch > TWX_MAX_CHANNELS) return fail(TWX_E_ARG, "too many channels for the all-channel mode");
         const int c_lo = all ? 0 : ch, c_hi = all ? nch : ch + 1, ostride = all ? nch : 1;
+        struct RsScope { long long& off; ~RsScope() { off = -1; } } rs_scope{rs_off};
+        if (rs_v != 0.0) {
+            if (all) return fail(TWX_E_ARG, "the velocity-compensated window (twx_set_resample) takes one channel at a time");
+            if (max_windows > (1ll << 22)) return fail(TWX_E_ARG, "twx_set_resample: give max_windows (at most 4 194 304 windows per call)");
+            if (int rc0 = resample_begin(max_windows)) return rc0;
+        }
+        struct ExScope { long long& off; ~ExScope() { off = -1; } } ex_scope{ex_off};
+        if (extras_on() && max_windows > (1ll << 22)) return fail(TWX_E_ARG, "SNR estimators: give max_windows (at most 4 194 304 windows per call)");
+        if (int rc0 = extra_begin(max_windows * ostride)) return rc0;
         std::vector<double> dfs((size_t)B, df_const), dfc((size_t)B), dfc_b((size_t)B);
         for (int k = 0; k < nslots && rc == TWX_OK; ++k) {
             st[k].nb = 0;
@@ -1459,7 +1607,7 @@ template <typename T> struct Ctx : CtxBase {
                 use_slot(k);
                 // the chunk is already on its way: the readers enqueued its pieces on this slot's stream
                 (void)hipEventRecord(h2d_done[k], stream); h2d.used[k] = true;
-                if (all && nch == 2 && frames_ok_2ch(st[k].dev)) {         // one pass over the frames serves both channels
+                if (all && nch == 2 && frames_ok_2ch(st[k].dev) && !extras_on()) {         // one pass over the frames serves both channels
                     const double* d2[2] = {nullptr, nullptr};
                     if (!band) {
                         if (!df_arr) { d2[0] = d2[1] = dfs.data(); }
@@ -1478,6 +1626,8 @@ template <typename T> struct Ctx : CtxBase {
                         else if (!all) dfp = df_arr + w0;
                         else { for (int i = 0; i < nb; ++i) dfc[(size_t)i] = df_arr[(w0 + i) * nch + c]; dfp = dfc.data(); }
                     }
+                    rs_off = rs_v != 0.0 ? w0 : -1;
+                    ex_off = extras_on() ? w0 * ostride + (all ? c : 0) : -1;
                     rc = run_batch(st[k].dev + c, nb, nch, band, dfp, slots[k].res_dev + (all ? c : 0), nullptr, false, ostride);
                 }
                 st[k].w0 = w0; st[k].nb = nb;
@@ -1491,6 +1641,7 @@ template <typename T> struct Ctx : CtxBase {
         for (int k = 0; k < nslots; ++k) if (h2d.used[k]) (void)hipEventSynchronize(h2d_done[k]);
         for (int k = 0; k < nslots; ++k) { int r2 = drain(k); if (rc == TWX_OK) rc = r2; }
         use_slot(0);
+        if (rc == TWX_OK) resample_end(w0);                       // the carried t0 / dt move past the windows that were there
         return rc;
     }
 
@@ -2037,12 +2188,36 @@ int twx_set_option(twx_ctx* ctx, int32_t option, int64_t value) {
     if (option == TWX_OPT_REMOVE_MEAN) { (void)ctx->impl->sync_all(); ctx->impl->remove_mean = value ? 1 : 0; return TWX_OK; }
     if (option == TWX_OPT_DEBUG_ONLY) { if (value > PC_PEAK) return ctx->impl->fail(TWX_E_ARG, "no such kernel class"); ctx->impl->dbg_only = value < 0 ? -1 : (int)value; return TWX_OK; }
     if (option == TWX_OPT_SELFCHECK) return ctx->impl->set_selfcheck(value);
+    if (option == TWX_OPT_BRUIT_LEN) return ctx->impl->set_extra(0, value);
+    if (option == TWX_OPT_NOISE_SQUARE_LEN) return ctx->impl->set_extra(1, value);
     if (option == TWX_OPT_DEBUG_FAULT) { ctx->impl->dbg_fault = (int)value; return TWX_OK; }
     if (option == TWX_OPT_FIR_MFMA) { ctx->impl->fir_mfma = value < 0 ? -1 : (value ? 1 : 0); return TWX_OK; }
     if (option == TWX_OPT_DEBUG_REPEAT) { ctx->impl->dbg_repeat = (int)std::max<long long>(1, std::min<long long>(value, 1000000)); return TWX_OK; }
     return ctx->impl->fail(TWX_E_ARG, "unknown option");
 }
 void* twx_stream(twx_ctx* ctx) { return ctx ? (void*)ctx->impl->stream : nullptr; }
+int twx_fetch_extra(twx_ctx* ctx, twx_extra* out_host, int64_t n_records) {
+    if (!ctx) return TWX_E_ARG;
+    CtxBase* c = ctx->impl;
+    if (!out_host || n_records < 0) return c->fail(TWX_E_ARG, "bad argument");
+    if (n_records > c->extra_n) return c->fail(TWX_E_STATE, "the last call left fewer records (are TWX_OPT_BRUIT_LEN / TWX_OPT_NOISE_SQUARE_LEN on?)");
+    (void)hipSetDevice(c->dev);
+    if (int rc = c->sync_all()) return rc;
+    if (n_records && hipMemcpy(out_host, c->extra_dev, sizeof(twx_extra) * (size_t)n_records, hipMemcpyDeviceToHost) != hipSuccess) return c->fail(TWX_E_HIP, "D2H failed");
+    return TWX_OK;
+}
+int twx_set_resample(twx_ctx* ctx, double vitesse, double t0, int64_t dt) {
+    if (!ctx) return TWX_E_ARG;
+    CtxBase* c = ctx->impl;
+    return guarded(c, [&]() { return c->set_resample(vitesse, t0, dt); });
+}
+int twx_get_resample(twx_ctx* ctx, double* vitesse, double* t0, int64_t* dt) {
+    if (!ctx) return TWX_E_ARG;
+    if (vitesse) *vitesse = ctx->impl->rs_v;
+    if (t0) *t0 = ctx->impl->rs_t0;
+    if (dt) *dt = ctx->impl->rs_dt;
+    return TWX_OK;
+}
 int twx_selfcheck_stats(twx_ctx* ctx, double* max_rel_dev, int64_t* rows_flagged, int32_t reset) {
     if (!ctx) return TWX_E_ARG;
     CtxBase* c = ctx->impl;

@@ -17,7 +17,7 @@ template <typename T, int MODE, class In>
 int launch_fwd(In in, const ColFwdArgs<T>& a, unsigned nblk, hipStream_t s) {
     // measured on MI355X (N1 = 625, gpurun_out/ab3): MIX 0.1245 -> 0.119 ms per 8 windows, SQUARE 0.117 -> 0.129: only MIX uses it
     // (int16 captures only: the complex-double loader of twx_process_complex needs two registers more than the 80 that six waves per SIMD leave)
-    if constexpr (P::S == 2 && std::is_same<T, float>::value && NT >= 384 && MODE == COL_MIX && !std::is_same<In, InCplxSplit>::value) {
+    if constexpr (P::S == 2 && std::is_same<T, float>::value && NT >= 384 && MODE == COL_MIX && !std::is_same<In, InCplxSplit>::value && !InTraits<In>::resample) {
         static const bool split = [] { const char* e = getenv("TWX_COLFWD3"); return !e || atoi(e) != 0; }();
         if (split) {                         // component-wise exchange: three or four workgroups per CU (twx_kernels.h)
             TWX_LAUNCH((k_col_fwd3<P, T, W, MODE, In, NT>), dim3(nblk), dim3(NT), s, in, a);
@@ -43,6 +43,10 @@ template <typename T> int fwd(int mode, int intype, const void* inptr, int aux, 
         InCplxSplit in{sp->re, sp->im, aux};
         if (mode == COL_MIX) return launch_fwd<T, COL_MIX>(in, a, nblk, s);
         if (mode == COL_SQUARE) return launch_fwd<T, COL_SQUARE>(in, a, nblk, s);
+    } else if (intype == IN_I16RS && mode == COL_MIX) {
+        const ResamplePtr* rp = reinterpret_cast<const ResamplePtr*>(inptr);
+        InI16Resample in{reinterpret_cast<const short2*>(rp->iq), aux, rp->t0, rp->edge, rp->c};
+        return launch_fwd<T, COL_MIX>(in, a, nblk, s);
     } else if (intype == IN_C32) {
         InCplx<float> in{reinterpret_cast<const cpx<float>*>(inptr)};
         if (mode == COL_MIX) return launch_fwd<T, COL_MIX>(in, a, nblk, s);

@@ -219,6 +219,48 @@ struct InI16 {   // interleaved int16 IQ, nch channels per sample (godual_rangin
         return mk<T>((T)(short)(w & 0xffffu), (T)(short)(w >> 16));
     }
 };
+// The velocity-compensated window (experiments/220706_TWSTFT/godual_ranging_OP_vitesse.m:40-43): the MIXED window y = (d - mean) .* lo is
+// resampled linearly on the stretched axis x_q(n) = n / (1 - vitesse) + t0 before the transform.  x_q(n) - n = n c + t0 with
+// c = vitesse / (1 - vitesse) stays inside (-2, 2) (twx_set_resample checks it), so sample n needs d[n + m] and d[n + m + 1], m = floor(n c + t0)
+// — the neighbours' own loads — and lo[n + m] = lo[n] * rot^m with rot = exp(-2 pi i df / fs) = the NCO table entry of sample 1:
+//   yi[n] = lo[n] * rot^m * ((1 - f) (d[i0] - mean) + f (d[i0 + 1] - mean) rot),   i0 = n + m,  f = n c + t0 - m
+// (mix first, then interp1, as the script does).  The edge rule of :42-43 — yi(end) = yi(end-1) and yi(1) = yi(2) where the query left the
+// window — is the per-window word `edge` (bit 0 / bit 1), decided on the host with the script's own expression.
+struct InI16Resample {
+    const short2* p; int nch;
+    const double* t0; const int* edge; double c;
+    __device__ __forceinline__ void advance(long long e) { p += e; }
+    template <typename T> __device__ __forceinline__ cpx<T> load(long long n) const { short2 s = p[n * nch]; return mk<T>((T)s.x, (T)s.y); }
+    static constexpr bool has_raw = false;
+};
+template <class In> struct InTraits { static constexpr bool resample = false; };
+template <> struct InTraits<InI16Resample> { static constexpr bool resample = true; };
+// yi[n] / lo[n] of the resampled window (see InI16Resample): ((1 - f)(d[i0] - mean) + f (d[i0+1] - mean) rot) rot^m
+template <typename T> __device__ __forceinline__ cpx<T> rs_sample(const short2* p, int nch, long long n, long long N, double c, double t0, int edge, T mx, T my,
+                                                                  cpx<T> rot) {
+    long long ne = n;
+    if (n == 0 && (edge & 1)) ne = 1;                              // yi(1) = yi(2)        (godual_ranging_OP_vitesse.m:43)
+    if (n == N - 1 && (edge & 2)) ne = N - 2;                      // yi(end) = yi(end-1)  (:42)
+    const double dl = fma((double)ne, c, t0);
+    const double fl = floor(dl);
+    const T f = (T)(dl - fl);
+    const int m = (int)fl + (int)(ne - n);                         // i0 - n
+    long long i0 = n + m;
+    i0 = i0 < 0 ? 0 : (i0 > N - 1 ? N - 1 : i0);
+    const long long i1 = i0 + 1 > N - 1 ? N - 1 : i0 + 1;         // (x_q = N-1 exactly: f = 0, the second sample is not used)
+    const short2 s0 = p[i0 * nch], s1 = p[i1 * nch];
+    cpx<T> d0 = mk<T>((T)s0.x - mx, (T)s0.y - my), d1 = mk<T>((T)s1.x - mx, (T)s1.y - my);
+    const cpx<T> d1r = cmul(d1, rot);
+    const cpx<T> z = mk<T>(d0.x + (d1r.x - d0.x) * f, d0.y + (d1r.y - d0.y) * f);
+    cpx<T> pw = mk<T>(1, 0);
+    const cpx<T> st = m > 0 ? rot : cconj(rot);
+    for (int q = (m > 0 ? m : -m); q > 0; --q) pw = cmul(pw, st); // |m| <= 2
+    return cmul(z, pw);
+}
+template <typename T> __device__ __attribute__((noinline)) cpx<T> rs_sample_call(const short2* p, int nch, long long n, long long N, double c, double t0, int edge,
+                                                                                 T mx, T my, cpx<T> rot) {
+    return rs_sample<T>(p, nch, n, N, c, t0, edge, mx, my, rot);
+}
 struct InChips {  // code replica: chips {0,1} held sps samples, value 2c-1 (godual_ranging.m:63-65)
     const unsigned char* p; int sps;
     __device__ __forceinline__ void advance(long long e) { p += e; }
@@ -456,7 +498,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_df_tables(int estimate, const ArgPart<T>* __restrict__ part, int nparts,
                                                    double* __restrict__ dfv, long long* __restrict__ dfidx,
                                                    double fs, long long n, int n1, int n2,
-                                                   cpx<T>* __restrict__ e1, cpx<T>* __restrict__ e2) {
+                                                   cpx<T>* __restrict__ e1, cpx<T>* __restrict__ e2, double* __restrict__ sqmax = nullptr) {
     const int b = blockIdx.x;
     const bool lead = blockIdx.y == 0;
     __shared__ double s_df;
@@ -472,7 +514,7 @@ __global__ __launch_bounds__(256) void k_df_tables(int estimate, const ArgPart<T
             const double step = fs / (double)(n - 1);
             double f = (i == n - 1) ? fs / 2 : __dadd_rn(__dmul_rn((double)i, step), -fs / 2);
             s_df = f / 2;
-            if (lead) { dfv[b] = s_df; dfidx[b] = i; }
+            if (lead) { dfv[b] = s_df; dfidx[b] = i; if (sqmax) sqmax[b] = sqrt((double)best.val); }     // valmax_square (process_OP.m:95)
         }
     } else if (threadIdx.x == 0) {
         s_df = dfv[b];
@@ -610,11 +652,28 @@ __global__ __launch_bounds__(NT) void k_col_fwd(In in, ColFwdArgs<T> a) {
             // NCO factor exp(-j 2 pi df n/fs), n = (j + r*T)*N2 + n2:  E1[j]·E2[n2] per thread, E1[r*T] wave-uniform
             C ejc = mk<T>(1, 0);
             if (MODE == COL_MIX) ejc = cmul(a.e1[(long long)b * P1::L + j], a.e2[(long long)b * a.n2 + c0 + c]);
+            C rs_rot = mk<T>(1, 0);
+            double rs_t0 = 0; int rs_edge = 0;
+            if constexpr (InTraits<In>::resample) {
+                static_assert(!InTraits<In>::resample || MODE == COL_MIX, "the resampled window is the mixed one");
+                rs_rot = a.e2[(long long)b * a.n2 + 1];           // exp(-2 pi i df / fs): the NCO's step from one sample to the next
+                rs_t0 = in.t0[b]; rs_edge = in.edge[b];
+            }
             TWX_UNROLL
             for (int r = 0; r < R; ++r) {
                 C x;
+                if constexpr (InTraits<In>::resample) {
+                    const long long n = (long long)(j + r * (P1::L / R)) * a.n2 + (c0 + c);
+                    // (complex double: a real call per sample — inlined 25 times the body's address arithmetic and scalar loads were hoisted
+                    // to the top of the unrolled loop and spilled)
+                    if constexpr (sizeof(T) == 8) x = rs_sample_call<T>(win.p, win.nch, n, a.n, in.c, rs_t0, rs_edge, mx, my, rs_rot);
+                    else x = rs_sample<T>(win.p, win.nch, n, a.n, in.c, rs_t0, rs_edge, mx, my, rs_rot);
+                    C e = (r == 0) ? ejc : cmul(a.e1[(long long)b * P1::L + r * (P1::L / R)], ejc);
+                    v[r] = cmul(x, e);
+                    continue;
+                }
                 if constexpr (In::has_raw) x = (TWX_ABLF == 2 || TWX_ABLF == 4) ? mk<T>((T)(tid + r), (T)(r - tid)) : In::template unpack<T>(raw[r]);
-                else x = win.template load2<T>((long long)(r * (P1::L / R)) * a.n2, lane_in);
+                else if constexpr (!InTraits<In>::resample) x = win.template load2<T>((long long)(r * (P1::L / R)) * a.n2, lane_in);
                 x.x -= mx; x.y -= my;
                 if (MODE == COL_MIX) {
                     C e = (r == 0) ? ejc : cmul(a.e1[(long long)b * P1::L + r * (P1::L / R)], ejc);   // scalar load × per-thread constant
@@ -2256,6 +2315,167 @@ __global__ __launch_bounds__(NT, 6) void k_col_inv3(ColInvArgs<T> a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The other SNR estimators the reference compares (experiments/220830_OP/process_OP.m:94-97,119-121,138; 221127_SNR/simu_snr.m),
+// optional outputs (TWX_OPT_BRUIT_LEN / TWX_OPT_NOISE_SQUARE_LEN) next to the wipe-off SNR of k_peak:
+//   bruit         = var(prnmap(indice+20 : indice+20+L-1))   off-peak variance of the correlation map, from Bz (fp64 re-evaluation
+//                   lag by lag, as k_peak does for the twelve lags around the peak) — the map itself is never written
+//   valmax_square = max(d22(freqindex)), noise_square = var(d22(tmpdf+20 : tmpdf+20+L-1)), d22 = fftshift(abs(fft(d1.^2))): the bins
+//                   behind the carrier peak of the squared signal, from the column-pass output A of the SQUARE pass (still in its
+//                   buffer between k_df_tables and the MIX column pass): per row k1 the handful of bins k = k1 + N1 k2 of the range
+//                   as a pruned DFT over n2 (one twiddle per element, then a rotation per bin)
+// Partial sums per workgroup in fixed order (no atomics), k_extra_final combines them.
+// ------------------------------------------------------------------------------------------
+struct ExtraArgs {
+    long long n; int n1, n2, nphase;
+    int bruit_len, sq_len;
+    double* part_b;          // [b][nblk_b][3]: sum re, sum im, sum |z|^2 of the lags a workgroup evaluated
+    int nblk_b;
+    double* part_s;          // [b][n1][2]: sum |S|, sum |S|^2 of the bins row k1 holds
+    const double* sqmax;     // [b]: |fft(d.^2)| at the carrier arg-max (k_df_tables), or nullptr when the carrier was supplied
+    twx_extra* out; int out_stride;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_offpeak(ExtraArgs a, const cpx<T>* __restrict__ Bz, const cpx<double>* __restrict__ tw1d, const twx_result* __restrict__ res,
+                                                 int res_stride, int convention, double inv_scale) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const long long M = a.n * a.nphase;
+    const long long ind = res[(long long)b * res_stride].indice0;
+    const long long li = (long long)blockIdx.x * 256 + tid;            // lag number inside the range
+    double zr = 0, zi = 0, zz = 0;
+    if (li < a.bruit_len && ind + 20 + a.bruit_len < M) {              // the guard of process_OP.m:119 (1-based indice + 1020 < length)
+        long long m = ind + 20 + li;
+        if (convention == TWX_CONV_CLAUDIO) m = (M - m) % M;           // prnmap_c[m] = conj(prnmap_g[(M - m) mod M]): same modulus, same variance
+        const int rho = (int)(m % a.nphase);
+        const long long q = m / a.nphase;
+        const int q1 = (int)(q / a.n2), q2 = (int)(q % a.n2);
+        const cpx<T>* src = Bz + ((long long)b * a.nphase + rho) * a.n + q2;
+        double sx = 0, sy = 0;
+        int ti = 0;
+        for (int k1 = 0; k1 < a.n1; ++k1) {
+            const cpx<T> v = src[(long long)k1 * a.n2];
+            const cpx<double> w = tw1d[ti];                             // conj -> inverse
+            sx += (double)v.x * w.x + (double)v.y * w.y;
+            sy += (double)v.y * w.x - (double)v.x * w.y;
+            ti += q1; if (ti >= a.n1) ti -= a.n1;
+        }
+        zr = sx * inv_scale / (double)M; zi = sy * inv_scale / (double)M;
+        zz = zr * zr + zi * zi;
+    }
+    __shared__ double sh[3][256];
+    sh[0][tid] = zr; sh[1][tid] = zi; sh[2][tid] = zz;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (tid < d) { sh[0][tid] += sh[0][tid + d]; sh[1][tid] += sh[1][tid + d]; sh[2][tid] += sh[2][tid + d]; }
+        __syncthreads();
+    }
+    if (tid < 3) a.part_b[((long long)b * a.nblk_b + blockIdx.x) * 3 + tid] = sh[tid][0];
+}
+
+#define TWX_SQN_EMAX 40      // row elements per thread of k_sq_noise: rows up to 10 240 points
+#define TWX_SQN_GROUP 16     // bins of a row evaluated together
+template <typename T>
+__global__ __launch_bounds__(256) void k_sq_noise(ExtraArgs a, const cpx<T>* __restrict__ A, int wshift, const long long* __restrict__ dfidx) {
+    const int k1 = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const long long i0 = dfidx[b];
+    const long long lo = i0 + 20, hi = i0 + 20 + a.sq_len - 1;         // shifted indices tmpdf+20 .. tmpdf+20+L-1 (0-based)
+    double s1 = 0, s2 = 0;
+    __shared__ double sh[2][256];
+    if (i0 >= 0 && hi <= a.n - 1) {
+        // natural bin of shifted index i: k = (i + N - N/2) mod N; the bins of this row are k = k1 + N1 k2
+        const long long sh0 = a.n - a.n / 2;
+        const long long klo = (lo + sh0) % a.n;                          // first natural bin of the range (the range may wrap past N)
+        // k2 of the first bin of the row at or after klo, going round: members are k2 = k2a, k2a + 1, ... while inside the range
+        long long first = klo - k1; first = first <= 0 ? 0 : (first + a.n1 - 1) / a.n1;          // smallest k2 with k1 + N1 k2 >= klo
+        cpx<T> x[TWX_SQN_EMAX];
+        const cpx<T>* Ab = A + (long long)b * a.n;
+        TWX_UNROLL
+        for (int e = 0; e < TWX_SQN_EMAX; ++e) {
+            const int n2i = tid + 256 * e;
+            x[e] = n2i < a.n2 ? Ab[a_index((unsigned)n2i, (unsigned)k1, (unsigned)a.n1, wshift)] : mk<T>(0, 0);
+        }
+        // the row's bins of the range are k2 = first, first + 1, ... (going round past the end of the spectrum): sixteen at a time, per
+        // element ONE twiddle exp(-2 pi i n2 k2 / N2) for the group's first bin and the step exp(-2 pi i n2 / N2), then a rotation per bin
+        const long long cnt_max = (a.sq_len + a.n1 - 1) / a.n1 + 1;
+        for (long long j0 = 0; j0 < cnt_max; j0 += TWX_SQN_GROUP) {
+            double sr[TWX_SQN_GROUP], si[TWX_SQN_GROUP];
+            TWX_UNROLL
+            for (int g = 0; g < TWX_SQN_GROUP; ++g) { sr[g] = 0; si[g] = 0; }
+            const long long k2g = (first + j0) % a.n2;
+            TWX_UNROLL
+            for (int e = 0; e < TWX_SQN_EMAX; ++e) {
+                const int n2i = tid + 256 * e;
+                if (n2i < a.n2) {
+                    double ws, wc, ts, tc;
+                    sincospi(-2.0 * (double)n2i / (double)a.n2, &ws, &wc);
+                    sincospi(-2.0 * (double)(((long long)n2i * k2g) % a.n2) / (double)a.n2, &ts, &tc);
+                    const double xr = (double)x[e].x, xi = (double)x[e].y;
+                    double pr = xr * tc - xi * ts, pi = xr * ts + xi * tc;            // x * t
+                    TWX_UNROLL
+                    for (int g = 0; g < TWX_SQN_GROUP; ++g) {
+                        sr[g] += pr; si[g] += pi;
+                        const double nr = pr * wc - pi * ws; pi = pr * ws + pi * wc; pr = nr;
+                    }
+                }
+            }
+            TWX_UNROLL
+            for (int g = 0; g < TWX_SQN_GROUP; ++g) {
+                const long long j = j0 + g;
+                long long k2 = first + j;
+                long long k = (long long)k1 + (long long)a.n1 * k2;
+                if (k >= a.n) k -= a.n;                                            // past the end of the spectrum: the range continues at bin 0
+                long long i = k - sh0; if (i < 0) i += a.n;
+                const bool in = j < cnt_max && k2 < 2ll * a.n2 && i >= lo && i <= hi;      // (uniform over the workgroup)
+                sh[0][tid] = sr[g]; sh[1][tid] = si[g];
+                __syncthreads();
+                for (int d = 128; d >= 1; d >>= 1) {
+                    if (tid < d) { sh[0][tid] += sh[0][tid + d]; sh[1][tid] += sh[1][tid + d]; }
+                    __syncthreads();
+                }
+                const double mag = sqrt(sh[0][0] * sh[0][0] + sh[1][0] * sh[1][0]);
+                __syncthreads();
+                if (in) { s1 += mag; s2 += mag * mag; }
+            }
+        }
+    }
+    if (tid == 0) { a.part_s[((long long)b * a.n1 + k1) * 2] = s1; a.part_s[((long long)b * a.n1 + k1) * 2 + 1] = s2; }
+}
+
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void k_extra_final(ExtraArgs a, const twx_result* __restrict__ res, int res_stride, const long long* __restrict__ dfidx) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ double sh[5][256];
+    double v[5] = {0, 0, 0, 0, 0};
+    if (a.bruit_len > 0) for (int i = tid; i < a.nblk_b; i += 256) { const double* p = a.part_b + ((long long)b * a.nblk_b + i) * 3; v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; }
+    if (a.sq_len > 0 && a.sqmax) for (int i = tid; i < a.n1; i += 256) { const double* p = a.part_s + ((long long)b * a.n1 + i) * 2; v[3] += p[0]; v[4] += p[1]; }
+    for (int j = 0; j < 5; ++j) sh[j][tid] = v[j];
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (tid < d) for (int j = 0; j < 5; ++j) sh[j][tid] += sh[j][tid + d];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        twx_extra e;
+        const double qn = nan("");
+        e.bruit = e.valmax_square = e.noise_square = qn; e.reserved = 0;
+        const long long M = a.n * a.nphase;
+        if (a.bruit_len > 1 && res[(long long)b * res_stride].indice0 + 20 + a.bruit_len < M) {
+            const double L = (double)a.bruit_len;
+            e.bruit = (sh[2][0] - (sh[0][0] * sh[0][0] + sh[1][0] * sh[1][0]) / L) / (L - 1.0);       // Octave var of a complex vector: sum |z - mean|^2 / (L - 1)
+        }
+        if (a.sqmax) {
+            e.valmax_square = a.sqmax[b];
+            const long long i0 = dfidx[b];
+            if (a.sq_len > 1 && i0 >= 0 && i0 + 20 + a.sq_len - 1 <= a.n - 1) {
+                const double L = (double)a.sq_len;
+                e.noise_square = (sh[4][0] - sh[3][0] * sh[3][0] / L) / (L - 1.0);
+            }
+        }
+        a.out[(long long)b * a.out_stride] = e;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_peak: finish the arg-max, re-evaluate prnmap around the peak in fp64 from Bz, parabolic
 // correction (godual_ranging.m:29-33) and the wipe-off statistics (:38-48).  grid = windows
 // ------------------------------------------------------------------------------------------
@@ -2278,6 +2498,7 @@ template <typename T> struct PeakArgs {
     twx_result* res;             // record of window b at res[b * res_stride]
     int res_stride;              // 1, or the channel count when all channels of a window are interleaved in the output
     const int* chk_flag;         // TWX_OPT_SELFCHECK: the window's status word of k_chk_verdict (nullptr: off)
+    const int* rs_dt; const int* rs_edge;   // twx_set_resample: the window's carried dt (-> twx_result.dt) and edge word (bit 2: the whole map is NaN)
     int snr_only;                // 1: second call of a Hamming-window context — Bz now holds the correlation with the UNWINDOWED
                                  // replica; the peak is the one already in the record, only the wipe-off statistics are written
 };
@@ -2379,7 +2600,17 @@ __global__ __launch_bounds__(1024) void k_peak(PeakArgs<T> a) {
         r.SNRi = ok ? mi * mi / var : nan("");
         r.puissancecode = ok ? mr * mr + mi * mi : nan("");
         r.puissancenoise = ok ? var : nan("");
-        r.status = (a.chk_flag && a.chk_flag[b]) ? TWX_STATUS_SELFCHECK : 0; r.reserved = 0;
+        r.status = (a.chk_flag && a.chk_flag[b]) ? TWX_STATUS_SELFCHECK : 0; r.dt = a.rs_dt ? a.rs_dt[b] : 0;
+        if (a.rs_edge && (a.rs_edge[b] & 4)) {
+            // more than the two edge samples of the resampled window fell outside it: interp1 leaves NaN in yi, the whole map is NaN and
+            // Octave's max returns index 1 (godual_ranging_OP_vitesse.m:40-48)
+            const double qn = nan("");
+            r.indice0 = 0; r.correction = qn;
+            r.xval[0] = r.xval[1] = r.xvalm1[0] = r.xvalm1[1] = r.xvalp1[0] = r.xvalp1[1] = qn;
+            for (int i = 0; i < 7; ++i) r.zwin[i][0] = r.zwin[i][1] = qn;
+            r.SNRr = r.SNRi = r.puissancecode = r.puissancenoise = qn;
+            r.status |= TWX_STATUS_RESAMPLE_NAN;
+        }
         if (a.snr_only) {                                                  // everything but the wipe-off statistics stays as the first call left it
             twx_result o = a.res[(long long)b * a.res_stride];
             o.SNRr = r.SNRr; o.SNRi = r.SNRi; o.puissancecode = r.puissancecode; o.puissancenoise = r.puissancenoise;

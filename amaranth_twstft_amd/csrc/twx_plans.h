@@ -21,7 +21,9 @@ LaunchEvents& launch_events();          // thread-local, defined in twx_api.hip
         } else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                   \
     } while (0)
 
-enum { IN_I16 = 0, IN_CHIPS = 1, IN_C32 = 2, IN_C64 = 3, IN_C64S = 4 };
+enum { IN_I16 = 0, IN_CHIPS = 1, IN_C32 = 2, IN_C64 = 3, IN_C64S = 4, IN_I16RS = 5 };
+// IN_I16RS (COL_MIX only): inptr points to a ResamplePtr — the velocity-compensated window of twx_set_resample, aux = nch
+struct ResamplePtr { const void* iq; const double* t0; const int* edge; double c; };
 // IN_C64S: inptr points to a SplitPtr (real / imaginary double arrays), aux = element stride
 struct SplitPtr { const double* re; const double* im; };
 

@@ -102,11 +102,16 @@ typedef struct twx_result {
     int64_t df_index;        /* 0-based fftshifted arg-max index of |fft(d.^2)|, -1 if df was supplied */
     double SNRr, SNRi, puissance, puissancecode, puissancenoise;   /* godual_ranging.m:44-48 */
     int32_t status;          /* 0, or TWX_STATUS_* bits */
-    int32_t reserved;
+    int32_t dt;              /* velocity-compensated window (twx_set_resample): the carried whole-sample offset the script adds to this
+                                window's indice (`indice1(p)=indice1(p)+dt`, godual_ranging_OP_vitesse.m:68); 0 otherwise.  indice0 is
+                                the arg-max itself. */
 } twx_result;
 /* twx_result.status bits.  TWX_STATUS_SELFCHECK: TWX_OPT_SELFCHECK was on and a row of this window's middle pass broke Parseval's
  * identity — the record is not to be trusted (re-run the window). */
-enum { TWX_STATUS_SELFCHECK = 1 };
+enum { TWX_STATUS_SELFCHECK = 1,
+       /* twx_set_resample: more than the first / last sample of the resampled window fell outside the window — Octave's interp1 leaves NaN
+        * there, the map is NaN, max() answers index 1: the record holds indice0 = 0 and NaN values, as the script's workspace would. */
+       TWX_STATUS_RESAMPLE_NAN = 2 };
 
 typedef struct twx_info {
     int64_t n;               /* complex samples per channel-window = n_chips*sps */
@@ -171,6 +176,20 @@ int twx_process_windows_dev(twx_ctx* ctx, const void* iq_dev, int64_t n_windows,
                             int32_t channel, const twx_band* band, const double* df, twx_result* out_dev);
 int twx_synchronize(twx_ctx* ctx);
 
+/* The velocity-compensated window of experiments/220706_TWSTFT/godual_ranging_OP_vitesse.m (:4 `vitesse=-3.25e-9`): after the NCO mix the
+ * window is resampled linearly on a stretched time axis, `yi=interp1([0:N-1],y,[0:N-1]*1/(1-vitesse)+t0)` (:40), with the offset carried
+ * from window to window, `t0=t0+length(y)*vitesse` (:41), the edge rule `if isnan(yi(end)) yi(end)=yi(end-1)`, `if isnan(yi(1))
+ * yi(1)=yi(2)` (:42-43), and `t0` wrapped into (-1, 1) with the whole-sample count `dt` following it (:70-71).  twx_set_resample switches
+ * it on for every later twx_process_windows[_dev] / twx_process_file call of the context on ONE channel (vitesse = 0: off) and sets the
+ * carried state (the script starts at t0 = 0, dt = 0); windows are taken in call order, the state advances by one window each — also
+ * across calls — and twx_get_resample returns it as it stands BEFORE the next window.  Each record carries its window's `dt`
+ * (twx_result.dt); the script's `indice1(p)` is indice0 + 1 + dt.  The interpolation runs inside the column pass that loads the samples
+ * (two neighbouring int16 frames per output, gathered from the same cache lines): no extra pass over the window.  |N * vitesse| < 1.
+ * The script correlates with the zero-mean 0/1 replica, no interpolation: twx_config {nint = 0, code_levels = TWX_CODE_UNIPOLAR,
+ * flags = TWX_FLAG_CODE_ZERO_MEAN}; its band is (96 200, 106 200) Hz of the linspace axis (:32). */
+int twx_set_resample(twx_ctx* ctx, double vitesse, double t0, int64_t dt);
+int twx_get_resample(twx_ctx* ctx, double* vitesse, double* t0, int64_t* dt);
+
 /* Run-time options.  TWX_OPT_REMOVE_MEAN (default 1): subtract the window's complex mean before the
  * NCO (d=d-mean(d), godual_ranging.m:80,94, done by the caller of processing() in the reference);
  * 0 leaves the samples as they are (search_df mixes the raw chunk,
@@ -203,6 +222,22 @@ enum { TWX_OPT_REMOVE_MEAN = 1,
         * flagged since the last reset (synchronises the context). */
        TWX_OPT_SELFCHECK = 3 };
 int twx_selfcheck_stats(twx_ctx* ctx, double* max_rel_dev, int64_t* rows_flagged, int32_t reset);
+
+/* The other SNR estimators the reference compares (experiments/220830_OP/process_OP.m:94-97,119-121,138; the three-way comparison of
+ * experiments/221127_SNR/simu_snr.m and its README) as optional outputs beside the wipe-off SNR of twx_result:
+ *   bruit          var(prnmap(indice+20:indice+20+L-1)), the off-peak variance of the correlation map (Octave var: N-1, complex
+ *                  deviations by modulus), L = TWX_OPT_BRUIT_LEN (the script: 1001 for bruit1, 10001 for bruit2); NaN where the range
+ *                  leaves the map (the guard `(indice1(p)+1020)<length(prnmap01)` of :119)
+ *   valmax_square  max(d22(freqindex)), d22 = fftshift(abs(fft(d1.^2))): the carrier peak of the squared signal (:95)
+ *   noise_square   var(d22(tmpdf+20:tmpdf+20+L-1)), L = TWX_OPT_NOISE_SQUARE_LEN (the script: 10001, :97); NaN where the range leaves
+ *                  the spectrum.  Both NaN when the carrier was supplied (no squared spectrum is formed).
+ * Either option > 0 switches the outputs on for the context's later twx_process_windows[_dev] / twx_process_file
+ * calls (0, the default: off; the calls then cost nothing extra); twx_fetch_extra copies the estimators of the LAST call, record for
+ * record (extra[i] belongs to out[i]), to the host — it synchronises the context.  With the options on a call first waits for the
+ * context's earlier work.  Rows up to 10 240 points (TWX_E_ARG beyond). */
+typedef struct twx_extra { double bruit, valmax_square, noise_square, reserved; } twx_extra;
+enum { TWX_OPT_BRUIT_LEN = 4, TWX_OPT_NOISE_SQUARE_LEN = 5 };
+int twx_fetch_extra(twx_ctx* ctx, twx_extra* out_host, int64_t n_records);
 int twx_set_option(twx_ctx* ctx, int32_t option, int64_t value);
 void* twx_stream(twx_ctx* ctx);                      /* hipStream_t of the context */
 

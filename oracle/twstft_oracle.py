@@ -21,7 +21,8 @@ Parity pinning (see tests/golden/README.md, tools/make_golden.py):
     godual_ranging_OP.py:ranging`` (printed lag, correction and complex peak sample).
   * The reference holds NO test vectors of its own for the correlator, and the
     Octave-only variants (``processing_claudio``, ``search_df``, ``ranging_tracked``, ``go_1s_session``, the QPSK form of ``make_code_variant``,
-    ``peak_refine_polyfit``, ``epl_step`` / ``octave_xcorr``), the C++-only Hamming window
+    ``peak_refine_polyfit``, ``epl_step`` / ``octave_xcorr``, ``ranging_vitesse`` / ``interp1_linear``, the off-peak and
+    squared-spectrum SNR estimators ``snr_offpeak`` / ``snr_square``), the C++-only Hamming window
     and the 231001_DLL_PLL acquisition/tracking restatements (incl. the receiver programs ``rx_second`` — rxcomplex.cpp and, with
     ``real=True``, rx.cpp with its interference cancellation ``rx_mai_up`` / ``rx_mai_out``) have no runnable twin here:
     for those functions parity is UNPINNED (hand restatement, cross-checked by identities) — EXCEPT what the reference's own result
@@ -296,6 +297,96 @@ def ranging(raw, chips, fs=5e6, sps=2, Nint=1, n_channels=2, channels=(0, 1), ba
             d = d - np.mean(d)
             out[c].append(processing(d, k, freq, temps, fcode, code, Nint=Nint, fs=fs, **kw))
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# the other SNR estimators the reference compares (experiments/220830_OP/process_OP.m, 221127_SNR/simu_snr.m) — UNPINNED (Octave only)
+# --------------------------------------------------------------------------------------------
+
+def snr_offpeak(prnmap: np.ndarray, indice: int, length: int = 1001) -> float:
+    """``bruit1(p)=var(prnmap01(indice1(p)+20:indice1(p)+1020))`` behind the guard ``if ((indice1(p)+1020)<length(prnmap01))``
+    (experiments/220830_OP/process_OP.m:119-121; ``bruit2`` with 10020, i.e. ``length`` = 10001, :138): the variance (Octave ``var``:
+    N-1, complex deviations by modulus) of the correlation map off its peak — the "noise" of the cross-correlation SNR estimate that
+    experiments/221127_SNR/README.md shows saturating at high SNR.  ``indice`` 0-based; NaN where the guard fails (the script leaves
+    the entry unset)."""
+    if (indice + 1) + 20 + length - 1 < len(prnmap):
+        return float(np.var(prnmap[indice + 20: indice + 20 + length], ddof=1))
+    return float("nan")
+
+
+def snr_square(d: np.ndarray, k: np.ndarray, length: int = 10001):
+    """``[valmax_square(p),df(p)]=max(d22(freqindex)); tmpdf(p)=df(p)+freqindex(1)-1; noise_square(p)=var(d22(tmpdf(p)+20:tmpdf(p)+10020))``
+    with ``d22=fftshift(abs(fft(d1.^2)))`` (process_OP.m:94-97): peak of the squared signal's spectrum inside the search band and the
+    variance (N-1) of the magnitudes of the ``length`` bins from 20 bins above it.  Returns (valmax_square, noise_square, 0-based shifted
+    index); noise NaN where the range leaves the spectrum (Octave would stop with an index error)."""
+    d22 = np.fft.fftshift(np.abs(_fft(d * d)))
+    tmp = int(d22[k].argmax() + k[0])
+    noise = float(np.var(d22[tmp + 20: tmp + 20 + length], ddof=1)) if tmp + 20 + length - 1 <= len(d22) - 1 else float("nan")
+    return float(d22[tmp]), noise, tmp
+
+
+# --------------------------------------------------------------------------------------------
+# velocity-compensated window (experiments/220706_TWSTFT/godual_ranging_OP_vitesse.m) — UNPINNED (Octave only, no stored output)
+# --------------------------------------------------------------------------------------------
+
+def interp1_linear(y: np.ndarray, xq: np.ndarray) -> np.ndarray:
+    """Octave ``interp1([0:n-1], y, xq)`` (default method 'linear', no extrapolation): NaN outside [0, n-1]."""
+    n = len(y)
+    xq = np.asarray(xq, dtype=float)
+    inside = (xq >= 0) & (xq <= n - 1)
+    i0 = np.clip(np.floor(xq).astype(np.int64), 0, n - 2)
+    f = xq - i0
+    out = y[i0] + (y[i0 + 1] - y[i0]) * f
+    out = out.astype(complex if np.iscomplexobj(y) else float)
+    out[~inside] = np.nan
+    return out
+
+
+def ranging_vitesse(raw, chips, fs=5e6, sps=2, vitesse=-3.25e-9, n_channels=2, channel=0, band_hz=(96200.0, 106200.0), t0=0.0, dt=0):
+    """The window loop of experiments/220706_TWSTFT/godual_ranging_OP_vitesse.m:17-74 for its channel 1 (the returned signal):
+    replica = 0/1 chips held ``sps`` samples minus its mean (:7-10), ``d1-mean(d1)`` (:25), carrier from ``fft(d1.^2)`` inside
+    ``(freq<106200)&(freq>96200)`` (:31-33), mix (:34-37), THEN linear resampling on the stretched axis
+    ``interp1([0:N-1],y,[0:N-1]*1/(1-vitesse)+t0)`` (:40) with the carried offset ``t0=t0+length(y)*vitesse`` (:41) and the edge rule
+    ``if isnan(yi(end)) yi(end)=yi(end-1)``, ``if isnan(yi(1)) yi(1)=yi(2)`` (:42-43), ``ifft(fft(yi).*fcode)`` (:46, no interpolation),
+    arg-max, the three peak samples, the 3-point polyfit vertex (:56-57), ``indice1=indice1+dt`` (:68) and the wrap of ``t0`` into (-1, 1)
+    with ``dt`` following it (:70-71).  Returns one dict per window: 0-based ``indice`` (before ``dt``), ``dt`` as added to this window,
+    ``t0`` as used by it, ``solution = indice + 1 + dt + correction`` (the script's 1-based ``solution12``), and ``nan`` when more than the
+    two edge samples fell outside the window (the script's ``max`` then returns index 1 of an all-NaN map and its next line fails)."""
+    code = make_code_variant(chips, sps=sps, unipolar=True, zero_mean=True)
+    fcode = np.conj(_fft(code))
+    n = len(code)
+    freq = freq_axis(fs, n)
+    k = np.nonzero((freq < band_hz[1]) & (freq > band_hz[0]))[0]
+    temps = np.arange(n) / fs
+    raw = np.asarray(raw).reshape(-1, 2 * n_channels)
+    nwin = raw.shape[0] // n
+    out = []
+    for p in range(nwin):
+        d1 = deinterleave(raw[p * n:(p + 1) * n], n_channels, channel)
+        d1 = d1 - np.mean(d1)
+        tmp, df = coarse_df(d1, k, freq)
+        y = d1 * np.exp(-1j * 2 * np.pi * df * temps)
+        yi = interp1_linear(y, np.arange(n) * 1 / (1 - vitesse) + t0)
+        t0_used = t0
+        t0 = t0 + n * vitesse
+        if np.isnan(yi[-1]):
+            yi[-1] = yi[-2]
+        if np.isnan(yi[0]):
+            yi[0] = yi[1]
+        rec = dict(df=df, df_index=tmp, t0=t0_used, dt=dt)
+        if np.isnan(yi).any():
+            rec.update(nan=True, indice=0, correction=np.nan, xval=complex(np.nan, np.nan), xvalm1=complex(np.nan, np.nan), xvalp1=complex(np.nan, np.nan), solution=np.nan)
+        else:
+            prnmap = _ifft(_fft(yi) * fcode)
+            indice, _, xval, xvalm1, xvalp1 = peak_refine(prnmap)
+            correction = peak_refine_polyfit(prnmap, indice, 1)
+            rec.update(nan=False, indice=indice, correction=correction, xval=xval, xvalm1=xvalm1, xvalp1=xvalp1, solution=indice + 1 + dt + correction)
+        out.append(rec)
+        if t0 >= 1:
+            t0 -= 1; dt -= 1
+        if t0 <= -1:
+            t0 += 1; dt += 1
+    return out, t0, dt
 
 
 # --------------------------------------------------------------------------------------------
