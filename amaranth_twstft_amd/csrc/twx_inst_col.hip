@@ -5,6 +5,10 @@
 #include "twx_kernels.h"
 #include "twx_plans.h"
 
+#ifndef TWX_FWD3_SQUARE
+#define TWX_FWD3_SQUARE 1     // the component-wise column pass for the squared-signal pass as well: with its table values through LDS it beats k_col_fwd
+                              // there too (round 6: 0.126 -> 0.098 ms per 8 windows; without them it was slower, 0.129 against 0.117 in round 3)
+#endif
 namespace twx {
 namespace {
 using P = TWX_PLAN;
@@ -15,9 +19,9 @@ static_assert(P::max_tasks * W <= NT, "one task per thread per stage");
 
 template <typename T, int MODE, class In>
 int launch_fwd(In in, const ColFwdArgs<T>& a, unsigned nblk, hipStream_t s) {
-    // measured on MI355X (N1 = 625, gpurun_out/ab3): MIX 0.1245 -> 0.119 ms per 8 windows, SQUARE 0.117 -> 0.129: only MIX uses it
+    // measured on MI355X (N1 = 625): round 3 MIX 0.1245 -> 0.119 ms per 8 windows, SQUARE 0.117 -> 0.129; round 6, table values through LDS: both
     // (int16 captures only: the complex-double loader of twx_process_complex needs two registers more than the 80 that six waves per SIMD leave)
-    if constexpr (P::S == 2 && std::is_same<T, float>::value && NT >= 384 && MODE == COL_MIX && !std::is_same<In, InCplxSplit>::value && !InTraits<In>::resample) {
+    if constexpr (P::S == 2 && std::is_same<T, float>::value && NT >= 384 && (MODE == COL_MIX || (TWX_FWD3_SQUARE && MODE == COL_SQUARE && In::has_raw)) && !std::is_same<In, InCplxSplit>::value && !InTraits<In>::resample) {
         static const bool split = [] { const char* e = getenv("TWX_COLFWD3"); return !e || atoi(e) != 0; }();
         if (split) {                         // component-wise exchange: three or four workgroups per CU (twx_kernels.h)
             TWX_LAUNCH((k_col_fwd3<P, T, W, MODE, In, NT>), dim3(nblk), dim3(NT), s, in, a);

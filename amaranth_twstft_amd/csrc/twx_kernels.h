@@ -62,6 +62,16 @@
 #define TWX_MID_PERSIST64 1  // k_rowd<MID> for complex double in the row-walking form as well (round 5: one 128-KB row per CU, so the wait for the
                              // next row was fully exposed; 0.461 -> 0.392 ms per 4 windows, profiles/r05_f64_rowwalk.txt); 0 = one row per workgroup
 #endif
+#ifndef TWX_FWD3_LDS_SQ
+#define TWX_FWD3_LDS_SQ 3   // k_col_fwd3<SQUARE>: table values of the last stage through LDS, asked for ahead of the samples: bit 0 stage twiddles, bit 1 output twiddle
+                            // (round 6, profiles/r06_colinv.txt: 0.126 -> 0.098 ms per 8 windows with both; 0.108 with the output twiddle alone)
+#endif
+#ifndef TWX_FWD3_LDS_MIX
+#define TWX_FWD3_LDS_MIX 2  // the same for k_col_fwd3<MIX>: 0.124 -> 0.112 ms with the output twiddle; the stage twiddles through LDS cost it 12 % (0.139), both 0.170
+#endif
+#ifndef TWX_INV3_TWLDS
+#define TWX_INV3_TWLDS 1  // k_col_inv3: last-stage twiddles parked in LDS (round 6: 0.227 -> 0.182 ms per 8 windows, profiles/r06_colinv.txt)
+#endif
 #ifndef TWX_BZ16
 #define TWX_BZ16 0      // EXPERIMENT (round 5, profiles/r05_bz16.txt): fp32 contexts keep Bz as fp16 pairs (4 instead of 8 bytes per element) in
                         // k_rowd<MID> (store), k_col_inv3 (load) and k_peak (load) — the upper bound of what a compact Bz can buy; the
@@ -190,6 +200,15 @@ template <typename V> __device__ __forceinline__ V ld_su_nt(const void* ubase, u
 template <typename V> __device__ __forceinline__ void st_su_nt(void* ubase, unsigned lane_bytes, V val) {
     TWX_GLOBAL char* g = (TWX_GLOBAL char*)sgpr_u64(reinterpret_cast<unsigned long long>(ubase));
     __builtin_nontemporal_store(val, (TWX_GLOBAL V*)(g + lane_bytes));
+}
+
+// ndw dwords global -> LDS without a register in between (global_load_lds_dword: lane i of a wave writes its wave's base + 4 i); the
+// caller's next vmcnt(0) + workgroup barrier make them readable
+template <int NT> __device__ __forceinline__ void lds_fill_dwords(float* lds, const float* g, int ndw) {
+    float* wave_base = lds + (threadIdx.x & ~63u);
+    for (int u0 = 0; u0 < ndw; u0 += NT)
+        if (u0 + (int)threadIdx.x < ndw)
+            __builtin_amdgcn_global_load_lds((const TWX_GLOBAL void*)(g + u0 + threadIdx.x), (__attribute__((address_space(3))) void*)(wave_base + u0), 4, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -785,6 +804,16 @@ __global__ __launch_bounds__(NT, 6) void k_col_fwd3(In in, ColFwdArgs<T> a) {
     constexpr int L = P1::L, R0 = P1::radix(0), R1 = P1::radix(1);
     __shared__ T lf[L * W];
     __shared__ C s_wq[32];
+    // (per mode: bit 0 the stage twiddles, bit 1 the output twiddle)
+    // (the long column plans, 500 and 625 points, where it was measured; the 250-point plan's MIX form ran out of its 80 registers with it)
+    constexpr int LDSM = L < 500 ? 0 : (MODE == COL_SQUARE ? TWX_FWD3_LDS_SQ : (MODE == COL_MIX ? TWX_FWD3_LDS_MIX : 0));
+    // Every table value the last stage needs is asked for BEFORE the tile's samples and waits in LDS (round 6, after k_col_inv3): the stage
+    // twiddles W_L^{j r} straight into LDS (global_load_lds: no register in between), and the output twiddle W_N^{k1 n2}, k1 = j + q QS,
+    // n2 = c0 + c, as (W_N^{j c0} W_N^{j c}) — one value per thread, folded into the stage twiddles — times s_w2[q][c] = W_N^{q QS (c0 + c)},
+    // R1 x W values per workgroup.  No load is issued after the exchange: 25 + 24 + 2 late L2 round trips per lane leave the critical path.
+    __shared__ C s_tw[(LDSM & 1) ? L : 1];
+    __shared__ C s_w2[(LDSM & 2) ? R1 * W : 1];
+    if constexpr (LDSM & 1) lds_fill_dwords<NT>(reinterpret_cast<float*>(s_tw), reinterpret_cast<const float*>(a.tw1), 2 * L);
     static_assert(R1 <= 32, "output-twiddle table");
     const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
     const int b = logical / a.ntiles, tile = logical % a.ntiles;
@@ -799,6 +828,16 @@ __global__ __launch_bounds__(NT, 6) void k_col_fwd3(In in, ColFwdArgs<T> a) {
         WinSums s = a.sums[b];
         mx = (T)((double)s.sI / (double)a.n);
         my = (T)((double)s.sQ / (double)a.n);
+    }
+    C wjx = mk<T>(1, 0);
+    if constexpr (LDSM & 2) {
+        const int jj = min(j, L / R1 - 1);                       // (idle lanes of the last wave: a valid address)
+        const unsigned mj = (unsigned)jj * (unsigned)c0;
+        wjx = cmul3(a.ta[mj >> a.tshift], a.tb[mj & mask], a.tc[jj * W + c]);          // W_N^{j c0} W_N^{j c}
+        const int q = min(tid / W, R1 - 1), cc = tid % W;
+        const unsigned mq = (unsigned)(q * (L / R1)) * (unsigned)c0;
+        const C w2 = cmul3(a.ta[mq >> a.tshift], a.tb[mq & mask], a.tc[(q * (L / R1)) * W + cc]);      // W_N^{q QS c0} W_N^{q QS c}
+        if (tid < R1 * W) s_w2[tid] = w2;
     }
     C v[R0];
     if (p0) {
@@ -830,7 +869,7 @@ __global__ __launch_bounds__(NT, 6) void k_col_fwd3(In in, ColFwdArgs<T> a) {
         for (int q = 0; q < R0; ++q) lf[TL::template out_idx<0>(ob, j, q) * W + c] = v[q].x;
     }
     constexpr int QS = L / R1;                                   // row step between a thread's outputs
-    if (tid < R1) {                                              // wave-uniform parts W_N^{q QS c0} of the output twiddle
+    if (!(LDSM & 2) && tid < R1) {                               // wave-uniform parts W_N^{q QS c0} of the output twiddle
         const unsigned mq = (unsigned)(tid * QS) * (unsigned)c0;
         s_wq[tid] = cmul(a.ta[mq >> a.tshift], a.tb[mq & mask]);
     }
@@ -852,20 +891,31 @@ __global__ __launch_bounds__(NT, 6) void k_col_fwd3(In in, ColFwdArgs<T> a) {
         TWX_UNROLL
         for (int r = 0; r < R1; ++r) u[r].y = lf[TL::template in_idx<1>(ib, j, r) * W + c];
         // stage twiddles W_L^{j r} with the per-thread part W_N^{j c0} of the output twiddle folded in (the butterfly is linear)
-        const unsigned mj = (unsigned)j * (unsigned)c0;
-        const C wj0 = cmul(a.ta[mj >> a.tshift], a.tb[mj & mask]);
+        C wj0 = wjx;
+        if constexpr (!(LDSM & 2)) {
+            const unsigned mj = (unsigned)j * (unsigned)c0;
+            wj0 = cmul(a.ta[mj >> a.tshift], a.tb[mj & mask]);
+        }
         u[0] = cmul(u[0], wj0);
         TWX_UNROLL
-        for (int r = 1; r < R1; ++r) u[r] = cmul(u[r], cmul(tw_load(a.tw1, (unsigned)(j * r)), wj0));
+        for (int r = 1; r < R1; ++r) {
+            if constexpr (LDSM & 1) u[r] = cmul(u[r], cmul(s_tw[j * r], wj0));
+            else u[r] = cmul(u[r], cmul(tw_load(a.tw1, (unsigned)(j * r)), wj0));
+        }
         TL::template bfly<1>(u);
         // W_N^{k1 n2}, k1 = j + q*QS, n2 = c0 + c: remaining factors W_N^{q QS c0} (LDS) and W_N^{k1 c} (one coalesced 8-B load)
         char* out = reinterpret_cast<char*>(a.out + (long long)b * a.n + (long long)tile * (L * W));
         const unsigned lane_out = ((unsigned)TL::template out_pos<1>(j, 0) * W + c) * (unsigned)sizeof(C);
         const char* tcb = reinterpret_cast<const char*>(a.tc);
         constexpr unsigned ostride = QS * W * sizeof(C);
-        TWX_UNROLL
-        for (int q = 0; q < R1; ++q) u[q] = cmul3(u[q], s_wq[q], ld_su<C>(tcb + (q * QS * W * (int)sizeof(C)), lane_out));
-        __builtin_amdgcn_sched_barrier(0);                       // all table loads before the first store (shared vmcnt)
+        if constexpr (LDSM & 2) {
+            TWX_UNROLL
+            for (int q = 0; q < R1; ++q) u[q] = cmul(u[q], s_w2[q * W + c]);
+        } else {
+            TWX_UNROLL
+            for (int q = 0; q < R1; ++q) u[q] = cmul3(u[q], s_wq[q], ld_su<C>(tcb + (q * QS * W * (int)sizeof(C)), lane_out));
+            __builtin_amdgcn_sched_barrier(0);                   // all table loads before the first store (shared vmcnt)
+        }
         TWX_UNROLL
         for (int q = 0; q < R1; ++q) st_su<C>(out + q * ostride, lane_out, u[q]);
     }
@@ -2224,6 +2274,17 @@ __global__ __launch_bounds__(NT, 6) void k_col_inv3(ColInvArgs<T> a) {
     using C = cpx<T>;
     constexpr int L = P1R::L, R0 = P1R::radix(0), R1 = P1R::radix(1);
     __shared__ T lf[L * W];
+#if TWX_INV3_TWLDS
+    // The last stage's twiddles through LDS (round 6): asked for with the tile's own loads and parked in LDS instead of registers, so that
+    // the L2 round trip of the twiddle gather — 24 dependent-free but LATE loads per lane, issued after the exchange because 48 registers
+    // to hold them from the start do not exist — leaves the workgroup's critical path.  5 KB more LDS (three resident workgroups, not
+    // four) for 20 % less time: 4.24 -> 5.25 TB/s, profiles/r06_colinv.txt — what the cache counters had said (requests served faster
+    // than the probe's, fewer of them in flight: the kernel, not the memory system, was waiting).  The other reading of those counters —
+    // resident workgroups that walk the tiles with the next tile loaded ahead, 128 registers, two per CU — was built first and lost
+    // (0.238 - 0.263 against 0.226 ms): with two workgroups a CU has nothing to run while both wait at their barriers.
+    __shared__ C s_tw[L];
+    lds_fill_dwords<NT>(reinterpret_cast<float*>(s_tw), reinterpret_cast<const float*>(a.tw1), 2 * L);      // (global_load_lds: no register in between)
+#endif
     const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
     const int tile = logical % a.ntiles;
     const int rho = (logical / a.ntiles) % a.nphase;
@@ -2281,7 +2342,11 @@ __global__ __launch_bounds__(NT, 6) void k_col_inv3(ColInvArgs<T> a) {
         for (int r = 0; r < R1; ++r) u[r].y = lf[TL::template in_idx<1>(ib, j, r) * W + c];
         constexpr int step = L / (P1R::ns(1) * R1);             // == 1 for a two-stage plan; jm == j
         TWX_UNROLL
+#if TWX_INV3_TWLDS
+        for (int r = 1; r < R1; ++r) u[r] = cmulc(u[r], s_tw[j * r * step]);
+#else
         for (int r = 1; r < R1; ++r) u[r] = cmulc(u[r], tw_load(a.tw1, (unsigned)(j * r * step)));
+#endif
         TL::template bfly<1>(u);
         const unsigned int mbase = (unsigned int)(c0 + c) * (unsigned int)a.nphase + (unsigned int)rho;
         const unsigned int mstep = (unsigned int)a.n2 * (unsigned int)a.nphase;
