@@ -2,6 +2,7 @@
 // twiddle tables, the per-batch kernel sequence and the inspection entry points.
 #include <hip/hip_runtime.h>
 #include <shared_mutex>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <math.h>
@@ -19,6 +20,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -27,6 +29,9 @@
 #include "twx_internal.h"
 #include "twx_workers.h"
 
+#ifndef TWX_PIN_MODE_DEFAULT
+#define TWX_PIN_MODE_DEFAULT 0
+#endif
 namespace twx {
 
 // ------------------------------------------------------------------------------------------
@@ -393,6 +398,30 @@ struct CtxBase {
         if (stream) { twx::fence_unregister(dev, stream); (void)hipStreamDestroy(stream); }
     }
     int fail(int code, const std::string& msg) { err = msg; return code; }
+    // The pinned staging buffers of the ingest.  TWX_PIN_MODE: 0 hipHostMalloc default (coherent, fine-grained), 1 hipHostMallocNonCoherent
+    // (host-cacheable), 2 ordinary pages (2-MB aligned, MADV_HUGEPAGE) pinned with hipHostRegister.  The kernel's copy_to_user of a pread
+    // into the default kind runs at 1 - 2 GB/s per thread against 10 into ordinary memory (profiles/r06_io_rate.txt).
+    static int pin_mode() { static const int m = [] { const char* e = getenv("TWX_PIN_MODE"); return e ? atoi(e) : TWX_PIN_MODE_DEFAULT; }(); return m; }
+    std::vector<std::pair<void*, int>> pin_kinds;
+    void* pin_alloc(size_t bytes) {
+        void* p = nullptr;
+        const int mode = pin_mode();
+        if (mode == 2) {
+            const size_t len = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+            if (posix_memalign(&p, 2u << 20, len) != 0) return nullptr;
+            (void)madvise(p, len, MADV_HUGEPAGE);
+            memset(p, 0, len);                                   // touch: the pages exist before they are pinned
+            if (hipHostRegister(p, len, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); free(p); return nullptr; }
+        } else if (hipHostMalloc(&p, bytes, mode == 1 ? hipHostMallocNonCoherent : hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        pin_kinds.push_back({p, mode});
+        return p;
+    }
+    void pin_free(void* p) {
+        int mode = 0;
+        for (auto it = pin_kinds.begin(); it != pin_kinds.end(); ++it) if (it->first == p) { mode = it->second; pin_kinds.erase(it); break; }
+        if (mode == 2) { (void)hipHostUnregister(p); free(p); }
+        else (void)hipHostFree(p);
+    }
     template <typename U> int dalloc(U** p, size_t count) {
         void* q = nullptr;
         size_t bytes = std::max<size_t>(count * sizeof(U), 16);
@@ -694,6 +723,7 @@ template <typename T> struct Ctx : CtxBase {
     double* csum_part = nullptr;                // per-window partial sums of |d|^2 (complex-double input)
     int argmax_norm1 = 0;                       // cblas_izamax arg-max for the current call (twx_caf_freqs_cdev)
     int io_threads = 8;                         // TWX_IO_THREADS: concurrent preads per chunk in twx_process_file
+    size_t io_sub = (size_t)8 << 20;            // TWX_IO_SUB_MB: a reader hands its piece to the device in sub-pieces of this size (0: whole)
     std::atomic<int> h2d_failed{0};             // set by a reader thread whose copy to the device was refused
     int ncu = 256;
     int ntiles = 0, ntiles_inv = 0;          // column tiles per row: forward passes / last pass
@@ -891,7 +921,7 @@ template <typename T> struct Ctx : CtxBase {
 
     ~Ctx() override {
         for (auto& e : graphs) (void)hipGraphExecDestroy(e.exec);
-        for (int k = 0; k < 4; ++k) { if (stage[k].host) (void)hipHostFree(stage[k].host); if (stage[k].dev) (void)hipFree(stage[k].dev); }
+        for (int k = 0; k < 4; ++k) { if (stage[k].host) pin_free(stage[k].host); if (stage[k].dev) (void)hipFree(stage[k].dev); }
         for (int k = 1; k < nslots; ++k) if (slots[k].stream) (void)hipStreamDestroy(slots[k].stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (auto e : ev_join) if (e) (void)hipEventDestroy(e);
@@ -1005,7 +1035,15 @@ template <typename T> struct Ctx : CtxBase {
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
             const char* io = getenv("TWX_IO_THREADS");
-            if (io) io_threads = std::max(1, std::min(32, atoi(io)));
+            if (io) io_threads = std::max(1, std::min(128, atoi(io)));
+            else {
+                // one pread out of the page cache runs at 1 - 2 GB/s, the link behind it at 56: as many readers as a quarter of the CPUs
+                // this process may use, 8 ... 32 (profiles/r06_io_rate.txt)
+                cpu_set_t cs; CPU_ZERO(&cs);
+                const int ncpu = sched_getaffinity(0, sizeof cs, &cs) == 0 ? CPU_COUNT(&cs) : (int)std::thread::hardware_concurrency();
+                io_threads = std::max(8, std::min(32, ncpu / 4));
+            }
+            if (const char* sb = getenv("TWX_IO_SUB_MB")) io_sub = (size_t)std::max(0, atoi(sb)) << 20;
         }
 #ifdef TWX_STAMPS
         if (int rc = dalloc(&stamps_dev, (size_t)B * N1 * 8 * 32)) return rc;
@@ -1538,10 +1576,10 @@ template <typename T> struct Ctx : CtxBase {
         for (int k = 0; k < nslots && rc == TWX_OK; ++k) {
             st[k].nb = 0;
             if (st[k].bytes >= win_bytes * B) continue;
-            if (st[k].host) (void)hipHostFree(st[k].host);
+            if (st[k].host) pin_free(st[k].host);
             if (st[k].dev) (void)hipFree(st[k].dev);
             st[k].host = nullptr; st[k].dev = nullptr; st[k].bytes = 0;
-            if (hipHostMalloc(&st[k].host, win_bytes * B, hipHostMallocDefault) != hipSuccess) rc = fail(TWX_E_NOMEM, "pinned staging allocation failed");
+            if (!(st[k].host = pin_alloc(win_bytes * B))) rc = fail(TWX_E_NOMEM, "pinned staging allocation failed");
             else if (hipMalloc((void**)&st[k].dev, win_bytes * B) != hipSuccess) rc = fail(TWX_E_NOMEM, "device staging allocation failed");
             else st[k].bytes = win_bytes * B;
         }
@@ -1561,6 +1599,7 @@ template <typename T> struct Ctx : CtxBase {
             char* ddst = reinterpret_cast<char*>(st[k].dev);
             hipStream_t sk = slots[k].stream;
             const int nthr = io_threads, device = dev;
+            const size_t sub = io_sub;
             std::atomic<int>* bad = &h2d_failed;
             return std::async(std::launch::async, [=]() -> long long {
                 // every piece goes on to the device from the thread that read it (the link measured 56.6 GB/s for pinned copies, the
@@ -1570,7 +1609,7 @@ template <typename T> struct Ctx : CtxBase {
                     (void)hipSetDevice(device);
                     if (hipMemcpyAsync(ddst + lo, dst + lo, got, hipMemcpyHostToDevice, sk) != hipSuccess) bad->store(1);
                 };
-                const size_t total = read_in_pieces(read_at, dst, (size_t)first * win_bytes, win_bytes * (size_t)want, nthr, to_device);    // twx_workers.h
+                const size_t total = read_in_pieces(read_at, dst, (size_t)first * win_bytes, win_bytes * (size_t)want, nthr, to_device, sub);    // twx_workers.h
                 return (long long)(total / win_bytes);              // whole windows only
             });
         };
@@ -1655,7 +1694,10 @@ template <typename T> struct Ctx : CtxBase {
         const off_t base_off = (off_t)skip * nch * 4;
         // TWX_FILE_MMAP=1 (A/B, profiles/r05_io_rate.txt): the capture mapped, the reader threads memcpy from the mapping instead
         // of pread — no copy_to_user, a minor fault per 4-KB page of a mapping this process touches for the first time
-        static const bool use_mmap = [] { const char* e = getenv("TWX_FILE_MMAP"); return e && atoi(e) != 0; }();
+        // TWX_FILE_MMAP=2 (round 6): the same with MADV_POPULATE_READ on every piece before its memcpy — the page tables of the range filled in
+        // one call instead of one minor fault per page
+        static const int mmap_mode = [] { const char* e = getenv("TWX_FILE_MMAP"); return e ? atoi(e) : 0; }();
+        const bool use_mmap = mmap_mode != 0;
         if (use_mmap) {
             struct stat sb;
             if (fstat(fd, &sb) == 0 && sb.st_size > base_off) {
@@ -1665,9 +1707,17 @@ template <typename T> struct Ctx : CtxBase {
                     (void)madvise(mp.p, mp.len, MADV_SEQUENTIAL);
                     const char* src = static_cast<const char*>(mp.p) + base_off;
                     const size_t total = mp.len - (size_t)base_off;
-                    auto read_map = [src, total](char* dst, size_t off, size_t len) -> size_t {
+                    const int mode = mmap_mode;
+                    auto read_map = [src, total, mode](char* dst, size_t off, size_t len) -> size_t {
                         if (off >= total) return 0;
                         const size_t n = std::min(len, total - off);
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22
+#endif
+                        if (mode == 2) {
+                            const size_t a0 = ((size_t)(src + off)) & ~(size_t)4095, a1 = ((size_t)(src + off + n) + 4095) & ~(size_t)4095;
+                            (void)madvise((void*)a0, a1 - a0, MADV_POPULATE_READ);
+                        }
                         memcpy(dst, src + off, n);
                         return n;
                     };
@@ -1675,8 +1725,51 @@ template <typename T> struct Ctx : CtxBase {
                 }
             }
         }
+        // Round 6 (profiles/r06_io_rate.txt): a pread straight into a pinned slot — 160 MB of memory no cache holds — runs at 2 GB/s per thread
+        // (the kernel's copy_to_user with ordinary stores: every destination line is first read), the same pread into a buffer that stays in
+        // the reader's L2 at 10.  So a reader goes through a 1-MB bounce buffer of its own and moves each megabyte on with non-temporal
+        // stores (no read of the destination): TWX_IO_BOUNCE_KB, 0 = the direct pread of rounds 3-5.
+        static const size_t bounce_bytes = [] { const char* e = getenv("TWX_IO_BOUNCE_KB"); return (size_t)(e ? std::max(0, atoi(e)) : 1024) << 10; }();
         auto read_at = [fd, base_off](char* dst, size_t off, size_t len) -> size_t {
             size_t done = 0;
+            if (bounce_bytes && (((size_t)dst) & 15) == 0) {
+                // (the readers are short-lived threads: their buffers come from a process-wide free list, touched once)
+                struct Pool {
+                    std::mutex mu; std::vector<char*> free_list;
+                    char* get() {
+                        { std::lock_guard<std::mutex> g(mu); if (!free_list.empty()) { char* p = free_list.back(); free_list.pop_back(); return p; } }
+                        void* p = nullptr;
+                        if (posix_memalign(&p, 4096, bounce_bytes) != 0) return nullptr;
+                        memset(p, 0, bounce_bytes);
+                        return (char*)p;
+                    }
+                    void put(char* p) { std::lock_guard<std::mutex> g(mu); free_list.push_back(p); }
+                };
+                static Pool pool;
+                struct Lease { Pool& pl; char* p; ~Lease() { if (p) pl.put(p); } } lease{pool, pool.get()};
+                char* bb = lease.p;
+                if (bb) {
+                while (done < len) {
+                    const size_t want = std::min(bounce_bytes, len - done);
+                    size_t got = 0;
+                    while (got < want) {
+                        const ssize_t r = pread(fd, bb + got, want - got, base_off + (off_t)(off + done + got));
+                        if (r <= 0) break;
+                        got += (size_t)r;
+                    }
+                    typedef long long v2 __attribute__((vector_size(16), aligned(16)));
+                    const size_t body = got & ~(size_t)15;
+                    const v2* sp = reinterpret_cast<const v2*>(bb);
+                    v2* dp = reinterpret_cast<v2*>(dst + done);
+                    for (size_t i = 0; i < body / 16; ++i) __builtin_nontemporal_store(sp[i], dp + i);
+                    if (got > body) memcpy(dst + done + body, bb + body, got - body);
+                    done += got;
+                    if (got < want) break;
+                }
+                __builtin_ia32_sfence();                          // the streamed lines are globally visible before the DMA is asked for
+                return done;
+                }
+            }
             while (done < len) {
                 const ssize_t r = pread(fd, dst + done, len - done, base_off + (off_t)(off + done));
                 if (r <= 0) break;

@@ -67,17 +67,30 @@ struct Worker {
 // piece on to the device at once, so the PCIe copy of a chunk runs beside the reads of its later pieces.
 struct NoPieceHook { void operator()(size_t, size_t) const {} };
 template <class ReadAt, class OnPiece = NoPieceHook>
-size_t read_in_pieces(ReadAt read_at, char* dst, size_t off0, size_t need, int nthreads, OnPiece on_piece = OnPiece()) {
-    const int P = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, nthreads), need >> 22));
+size_t read_in_pieces(ReadAt read_at, char* dst, size_t off0, size_t need, int nthreads, OnPiece on_piece = OnPiece(), size_t sub = 0) {
+    const int P = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, nthreads), need >> 21));      // pieces of at least 2 MB
     const size_t piece = ((need + P - 1) / P + 4095) & ~(size_t)4095;
+    // a piece is fetched in sub-pieces of `sub` bytes (0: in one go), each handed on as soon as it is there: the copy to the device of a
+    // piece's first megabytes runs beside the read of its last ones instead of behind it
+    auto fetch = [=](size_t lo, size_t hi) -> size_t {
+        const size_t step = sub ? std::max<size_t>(sub, 1 << 20) & ~(size_t)4095 : hi - lo;
+        size_t got_all = 0;
+        for (size_t a = lo; a < hi; a += step) {
+            const size_t len = std::min(step, hi - a);
+            const size_t g = read_at(dst + a, off0 + a, len);
+            if (g) on_piece(a, g);
+            got_all += g;
+            if (g < len) break;                                 // the source ends here
+        }
+        return got_all;
+    };
     std::vector<std::future<size_t>> parts;
     for (int i = 1; i < P; ++i) {
         const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));
-        parts.push_back(std::async(std::launch::async, [=]() { const size_t g = read_at(dst + lo, off0 + lo, hi - lo); if (g) on_piece(lo, g); return g; }));
+        parts.push_back(std::async(std::launch::async, [=]() { return lo < hi ? fetch(lo, hi) : (size_t)0; }));
     }
     const size_t first_len = std::min(need, piece);
-    size_t total = read_at(dst, off0, first_len);
-    if (total) on_piece((size_t)0, total);
+    size_t total = fetch(0, first_len);
     bool contiguous = total == first_len;
     for (int i = 1; i < P; ++i) {
         const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));

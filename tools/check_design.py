@@ -15,6 +15,11 @@ The quoted value may carry a scale suffix the tool understands (``ms`` vs ``Aver
 x 1e-3, ``us`` vs ns → x 1e-3).  Exit status 1 when a quoted number differs from the profile by more than 5 % —
 ``tools/update_profiles.py`` ends with this check, so refreshing profiles/ without updating the text fails loudly.
 
+The driver's own record: a row that cites the builder's driver-style line ``profiles/rNN_bench_line.json:<key>`` is ALSO held against
+``BENCH_rNN.json`` (written by the round-end driver on its own box, ``parsed.<key>``) whenever that file exists: more than 5 % apart
+fails as well — a number quoted from a run the driver's measurement contradicts is not a current number (boxes differ by 1-3 %).  The
+record of the round being built does not exist yet while it is built; the check reports which rounds it could cross-check.
+
     python tools/check_design.py            # check
 """
 import csv
@@ -58,6 +63,22 @@ def lookup(source: str) -> float:
     return _json_path(json.loads(lines[-1]), sel)
 
 
+def driver_value(source: str):
+    """parsed.<key> of BENCH_rNN.json for a source ``profiles/rNN_bench_line.json:<key>``; None when there is no such record."""
+    m = re.match(r"profiles/r(\d\d)_bench_line\.json:(.+)$", source)
+    if not m or m.group(2).startswith("cpu_baseline"):         # (the host's CPUs, not the GPU: its spread between boxes is quoted in the row itself)
+        return None
+    path = os.path.join(ROOT, "BENCH_r%s.json" % m.group(1))
+    if not os.path.exists(path):
+        return None
+    try:
+        j = json.load(open(path))
+        return _json_path(j.get("parsed", j), m.group(2))
+    except (KeyError, ValueError, TypeError, IndexError):
+        return None
+
+
+CROSSCHECKED = set()
 SCALES = {("ms", "ns"): 1e-6, ("us", "ns"): 1e-3, ("Gsample/s", "M"): 1e-3, ("TB/s", "GB"): 1e-3}
 
 
@@ -97,6 +118,15 @@ def check_one(doc: str, verbose=True) -> int:
         if verbose or not ok:
             print(f"{'ok ' if ok else 'BAD'} {what[:60]:60s} {doc} {val:g} {unit:10s} profile {got:.6g}  ({source})")
         bad += not ok
+        drv = driver_value(source)
+        if drv is not None:
+            CROSSCHECKED.add(source.split("_")[0])
+            dgot = drv * scale
+            dok = abs(val - dgot) <= TOL * abs(dgot)
+            if verbose or not dok:
+                label, key = "  ... against the driver's own record", source.split(":", 1)[1]
+                print(f"{'ok ' if dok else 'BAD'} {label:60s} {doc} {val:g} {unit:10s} driver  {dgot:.6g}  (BENCH_r{source[10:12]}.json:parsed.{key})")
+            bad += not dok
     if n < 8:
         print(f"{doc}: only {n} checkable rows found")
         return 1
@@ -104,7 +134,10 @@ def check_one(doc: str, verbose=True) -> int:
 
 
 def check(verbose=True) -> int:
-    return max(check_one(d, verbose) for d in DOCS)
+    rc = max(check_one(d, verbose) for d in DOCS)
+    if verbose:
+        print("cross-checked against the driver's BENCH records of rounds:", sorted(CROSSCHECKED) or "none (no BENCH_rNN.json for the rounds the tables cite)")
+    return rc
 
 
 if __name__ == "__main__":
