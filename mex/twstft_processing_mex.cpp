@@ -30,9 +30,20 @@
 // thread inside the library, and the records come back through one RCCL all-gather (twx_multi_*, include/twstft_hip.h) —
 // the same outputs as with one GPU, record for record.
 //
+// (D) options of the cached context (one GPU), kept across calls and re-applied when the context is rebuilt:
+//     twstft_processing_mex('option', 'vitesse', [vitesse t0 dt])     % the velocity-compensated window of godual_ranging_OP_vitesse.m:4,40-43,68-71
+//                                                                      % (twx_set_resample; vitesse = 0: off); with one output: the carried [vitesse t0 dt]
+//     twstft_processing_mex('option', 'replica', 'unipolar_zero_mean') % code=code-mean(code) on the 0/1 bytes (godual_ranging_OP_vitesse.m:7-10,
+//                                                                      % 220616_Besancon/godual.m:5-7); 'bipolar' (default): 2*code-1
+//     twstft_processing_mex('option', 'snr_estimators', [Lb Ls])       % bruit / noise_square lengths of process_OP.m:97,119-121 (0 0: off)
+//     twstft_processing_mex('option', 'selfcheck', v)                  % TWX_OPT_SELFCHECK
+// (E) what the last call left besides its outputs, one value per record:
+//     [bruit, valmax_square, noise_square, status, dt] = twstft_processing_mex('extra')
+//
 // indice is 1-based like Octave's max(); variances use Octave's N-1 normalisation.
 #if __has_include("mex.h")
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #include "mex.h"
 #include "twstft_hip.h"
@@ -42,6 +53,16 @@ static twx_multi* g_multi = nullptr;      // ngpu > 1: one context + host thread
 static std::vector<uint8_t> g_chips;
 static double g_fs = 0;
 static int g_nint = -1, g_conv = -1, g_ngpu = 0;
+// call forms D / E
+static double g_vit[3] = {0, 0, 0};
+static int g_replica = 0, g_replica_built = -1, g_selfcheck = 0, g_est[2] = {0, 0};
+static std::vector<twx_result> g_last;
+static void apply_options(bool vitesse_too) {
+    if (!g_ctx) return;
+    if (twx_set_option(g_ctx, TWX_OPT_BRUIT_LEN, g_est[0]) || twx_set_option(g_ctx, TWX_OPT_NOISE_SQUARE_LEN, g_est[1])) mexErrMsgIdAndTxt("twstft:option", "%s", twx_last_error(g_ctx));
+    if (g_selfcheck >= 0 && twx_set_option(g_ctx, TWX_OPT_SELFCHECK, g_selfcheck) && g_selfcheck > 0) mexErrMsgIdAndTxt("twstft:option", "%s", twx_last_error(g_ctx));
+    if (vitesse_too && twx_set_resample(g_ctx, g_vit[0], g_vit[1], (int64_t)g_vit[2])) mexErrMsgIdAndTxt("twstft:option", "%s", twx_last_error(g_ctx));
+}
 
 static void cleanup(void) {
     if (g_ctx) { twx_destroy(g_ctx); g_ctx = nullptr; }
@@ -67,16 +88,19 @@ static void ensure_context(const mxArray* codeb, double fs, int nint, int conv, 
     const double* cd = mxIsDouble(codeb) ? mxGetPr(codeb) : nullptr;
     const uint8_t* cb = cd ? nullptr : (const uint8_t*)mxGetData(codeb);
     for (size_t i = 0; i < nchips; ++i) chips[i] = cd ? (uint8_t)cd[i] : cb[i];
-    if ((g_ctx || g_multi) && chips == g_chips && fs == g_fs && nint == g_nint && conv == g_conv && ngpu == g_ngpu) return;   // cached across calls
+    if ((g_ctx || g_multi) && chips == g_chips && fs == g_fs && nint == g_nint && conv == g_conv && ngpu == g_ngpu && g_replica == g_replica_built) return;   // cached across calls
+    if (ngpu > 1 && (g_vit[0] != 0 || g_est[0] || g_est[1] || g_selfcheck > 0)) mexErrMsgIdAndTxt("twstft:args", "the options of call form D apply to one GPU (ngpu = 1)");
     cleanup();
     twx_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.fs = fs; cfg.sps = 2; cfg.nint = nint; cfg.chips = chips.data(); cfg.n_chips = (int64_t)nchips;
     cfg.convention = conv; cfg.precision = TWX_F32; cfg.var_ddof = 1 /* Octave var */; cfg.snr_rot = -1; cfg.device = -1;
+    if (g_replica == 1) { cfg.code_levels = TWX_CODE_UNIPOLAR; cfg.flags |= TWX_FLAG_CODE_ZERO_MEAN; }
     if (ngpu > 1) {
         if (twx_multi_create(&cfg, nullptr, ngpu, 0, &g_multi)) mexErrMsgIdAndTxt("twstft:create", "%s", twx_multi_last_error(nullptr));
     } else if (twx_create(&cfg, &g_ctx)) mexErrMsgIdAndTxt("twstft:create", "%s", twx_last_error(nullptr));
-    g_chips = chips; g_fs = fs; g_nint = nint; g_conv = conv; g_ngpu = ngpu;
+    g_chips = chips; g_fs = fs; g_nint = nint; g_conv = conv; g_ngpu = ngpu; g_replica_built = g_replica;
+    apply_options(true);                       // (a rebuilt context starts the carried t0 / dt where the last 'vitesse' option put them)
     mexAtExit(cleanup);
     if (!mexIsLocked()) mexLock();             // once: `clear mex` can unload after the exit handler has run
 }
@@ -98,6 +122,7 @@ static void emit(int nlhs, mxArray* plhs[], const std::vector<twx_result>& res, 
     //   claudio: xval indice correction SNRr SNRi puissance puissancecode puissancenoise [df]
     const int nout = nlhs > 0 ? (nlhs > 9 ? 9 : nlhs) : 1;
     const int xpos = conv == TWX_CONV_CLAUDIO ? 0 : 8;
+    g_last.assign(res.begin(), res.begin() + (long)std::min(res.size(), rows * cols));
     double* o[9] = {0};
     double* oi = nullptr;
     for (int i = 0; i < nout; ++i) {
@@ -116,7 +141,62 @@ static void emit(int nlhs, mxArray* plhs[], const std::vector<twx_result>& res, 
     }
 }
 
+static bool forms_d_e(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    char what[16] = {0};
+    if (nrhs < 1 || !mxIsChar(prhs[0]) || mxGetString(prhs[0], what, sizeof what)) return false;
+    if (!strcmp(what, "extra")) {
+        const size_t n = g_last.size();
+        std::vector<twx_extra> ex(n ? n : 1);
+        const bool have = g_ctx && (g_est[0] || g_est[1]) && n && twx_fetch_extra(g_ctx, ex.data(), (int64_t)n) == 0;
+        const int nout = nlhs > 0 ? (nlhs > 5 ? 5 : nlhs) : 1;
+        for (int i = 0; i < nout; ++i) {
+            plhs[i] = mxCreateDoubleMatrix(1, (mwSize)n, mxREAL);
+            double* o = mxGetPr(plhs[i]);
+            for (size_t w = 0; w < n; ++w) {
+                const double nanv = mxGetNaN();
+                o[w] = i == 0 ? (have ? ex[w].bruit : nanv) : i == 1 ? (have ? ex[w].valmax_square : nanv) : i == 2 ? (have ? ex[w].noise_square : nanv)
+                     : i == 3 ? (double)g_last[w].status : (double)g_last[w].dt;
+            }
+        }
+        return true;
+    }
+    if (strcmp(what, "option")) return false;
+    char name[32] = {0};
+    if (nrhs < 2 || !mxIsChar(prhs[1]) || mxGetString(prhs[1], name, sizeof name)) mexErrMsgIdAndTxt("twstft:args", "usage: ('option', name [, value])");
+    if (!strcmp(name, "vitesse")) {
+        if (nrhs >= 3) {
+            const size_t ne = mxGetNumberOfElements(prhs[2]);
+            const double* v = mxGetPr(prhs[2]);
+            g_vit[0] = ne > 0 ? v[0] : 0; g_vit[1] = ne > 1 ? v[1] : 0; g_vit[2] = ne > 2 ? v[2] : 0;
+            if (g_ctx && twx_set_resample(g_ctx, g_vit[0], g_vit[1], (int64_t)g_vit[2])) mexErrMsgIdAndTxt("twstft:option", "%s", twx_last_error(g_ctx));
+        }
+        if (nlhs > 0 || nrhs < 3) {
+            double v = g_vit[0], t0 = g_vit[1]; int64_t dt = (int64_t)g_vit[2];
+            if (g_ctx) twx_get_resample(g_ctx, &v, &t0, &dt);
+            plhs[0] = mxCreateDoubleMatrix(1, 3, mxREAL);
+            double* o = mxGetPr(plhs[0]); o[0] = v; o[1] = t0; o[2] = (double)dt;
+            g_vit[1] = t0; g_vit[2] = (double)dt;          // a context rebuilt later carries on from here
+        }
+    } else if (!strcmp(name, "replica")) {
+        char r[32] = {0};
+        if (nrhs < 3 || !mxIsChar(prhs[2]) || mxGetString(prhs[2], r, sizeof r)) mexErrMsgIdAndTxt("twstft:args", "replica: 'bipolar' or 'unipolar_zero_mean'");
+        if (!strcmp(r, "bipolar")) g_replica = 0;
+        else if (!strcmp(r, "unipolar_zero_mean")) g_replica = 1;
+        else mexErrMsgIdAndTxt("twstft:args", "unknown replica '%s'", r);
+    } else if (!strcmp(name, "snr_estimators")) {
+        if (nrhs < 3 || mxGetNumberOfElements(prhs[2]) < 2) mexErrMsgIdAndTxt("twstft:args", "snr_estimators: [bruit_len noise_square_len]");
+        g_est[0] = (int)mxGetPr(prhs[2])[0]; g_est[1] = (int)mxGetPr(prhs[2])[1];
+        apply_options(false);
+    } else if (!strcmp(name, "selfcheck")) {
+        if (nrhs < 3) mexErrMsgIdAndTxt("twstft:args", "selfcheck: a value");
+        g_selfcheck = (int)mxGetScalar(prhs[2]);
+        apply_options(false);
+    } else mexErrMsgIdAndTxt("twstft:args", "unknown option '%s'", name);
+    return true;
+}
+
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    if (forms_d_e(nlhs, plhs, nrhs, prhs)) return;
     if (nrhs < 5) mexErrMsgIdAndTxt("twstft:args", "usage: (d, k_or_df, codeb, fs, Nint [, convention]) or (raw_int16, nchan, chan, k_or_df, codeb, fs, Nint [, convention] [, ngpu]) "
                                                    "or ('file', path, nchan, chan, k_or_df, codeb, fs, Nint [, convention] [, ngpu [, skip_samples [, max_windows]]])");
     const bool file_form = mxIsChar(prhs[0]);

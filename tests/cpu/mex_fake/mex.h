@@ -66,6 +66,7 @@ inline int mxGetString(const mxArray* a, char* buf, mwSize len) {
     return a->str.size() >= len;
 }
 inline void mxDestroyArray(mxArray* a) { delete a; }
+inline double mxGetNaN(void) { return __builtin_nan(""); }
 inline void mexErrMsgIdAndTxt(const char* id, const char* fmt, ...) {
     char b[1024]; va_list ap; va_start(ap, fmt); vsnprintf(b, sizeof b, fmt, ap); va_end(ap);
     throw MexError{id, b};

@@ -2,6 +2,8 @@
 //   mex_harness raw     capture.bin chips.bin out.bin nchan chan  klo khi|df  fs Nint [convention]
 //   mex_harness complex capture.bin chips.bin out.bin nchan chan  klo khi|df  fs Nint [convention]
 //   mex_harness file    capture.bin chips.bin out.bin nchan chan  klo khi|df  fs Nint [convention] [ngpu=N] [skip=S] [max=M]
+// Trailing opt=<name>:<v1>[,<v2>...] arguments are call form D ('option', name, value) issued BEFORE every main call (string values for
+// `replica`), extra=1 appends the five outputs of call form E ('extra') to out.bin, state=1 one more array: the carried [vitesse t0 dt].
 // `raw` also takes a trailing ngpu=N (several devices from the one process, twx_multi_*); `file` hands over the PATH (call form C).
 // `raw` hands the int16 capture over as fread(...,'int16=>int16') would; `complex` does what the reference scripts do
 // before calling processing(): de-interleave one channel into a complex double column and remove each window's mean
@@ -40,8 +42,12 @@ int main(int argc, char** argv) {
     mxArray* conv = nullptr;
     if (ai < argc && !strchr(argv[ai], '=')) { conv = new mxArray; conv->cls = mxCHAR_CLASS; conv->str = argv[ai]; ++ai; }
     double ngpu = 0, skip = -1, maxw = -1;
+    std::vector<std::string> opts; bool want_extra = false, want_state = false;
     for (; ai < argc; ++ai) {
-        if (!strncmp(argv[ai], "ngpu=", 5)) ngpu = atof(argv[ai] + 5);
+        if (!strncmp(argv[ai], "opt=", 4)) opts.push_back(argv[ai] + 4);
+        else if (!strcmp(argv[ai], "extra=1")) want_extra = true;
+        else if (!strcmp(argv[ai], "state=1")) want_state = true;
+        else if (!strncmp(argv[ai], "ngpu=", 5)) ngpu = atof(argv[ai] + 5);
         else if (!strncmp(argv[ai], "skip=", 5)) skip = atof(argv[ai] + 5);
         else if (!strncmp(argv[ai], "max=", 4)) maxw = atof(argv[ai] + 4);
         else { fprintf(stderr, "unknown argument %s\n", argv[ai]); return 2; }
@@ -79,11 +85,31 @@ int main(int argc, char** argv) {
         if (skip >= 0 || maxw >= 0) in.push_back(scalar(skip >= 0 ? skip : 0));
         if (maxw >= 0) in.push_back(scalar(maxw));
     }
-    mxArray* out[9] = {0};
+    mxArray* out[16] = {0};
     int nlhs = 9;
+    auto str = [](const std::string& t) { mxArray* a = new mxArray; a->cls = mxCHAR_CLASS; a->str = t; return a; };
+    auto set_options = [&]() {
+        for (const std::string& o : opts) {
+            const size_t c = o.find(':');
+            const std::string name = o.substr(0, c), val = c == std::string::npos ? "" : o.substr(c + 1);
+            mxArray* v;
+            if (name == "replica") v = str(val);
+            else {
+                std::vector<double> nums;
+                for (size_t p = 0; p < val.size();) { size_t q = val.find(',', p); if (q == std::string::npos) q = val.size(); nums.push_back(atof(val.substr(p, q - p).c_str())); p = q + 1; }
+                v = mxCreateDoubleMatrix(1, nums.size(), mxREAL); v->re = nums;
+            }
+            const mxArray* oin[3] = {str("option"), str(name), v};
+            mexFunction(0, nullptr, 3, oin);
+        }
+    };
     try {
+        set_options();
         mexFunction(nlhs, out, (int)in.size(), in.data());
+        set_options();                                                // (the carried state of 'vitesse' starts over: both calls do the same work)
         mexFunction(nlhs, out, (int)in.size(), in.data());            // second call: the cached context is reused, lock count stays 1
+        if (want_extra) { const mxArray* ein[1] = {str("extra")}; mexFunction(5, out + nlhs, 1, ein); nlhs += 5; }
+        if (want_state) { const mxArray* sin_[2] = {str("option"), str("vitesse")}; mexFunction(1, out + nlhs, 2, sin_); nlhs += 1; }
     } catch (const MexError& e) {
         fprintf(stderr, "MEX error %s: %s\n", e.id.c_str(), e.msg.c_str());
         return 3;

@@ -108,3 +108,64 @@ def test_velocity_window_device_and_file_entry_points(tmp_path):
             cor.process(np.zeros(4 * n, dtype=np.int16), n_channels=2, channel=-1, band=band)      # one channel at a time
         with pytest.raises(L.TwxError):
             cor.set_resample(1e-3)                                                                   # a sample or more per window
+
+
+def test_mex_gateway_option_forms_carry_the_velocity_window(tmp_path):
+    """Call forms D / E of mex/twstft_processing_mex.cpp executed on the functional fake mex.h — what mex/godual_ranging_OP_vitesse_hip.m
+    runs on: 'option' 'replica' / 'vitesse' / 'snr_estimators' before a raw-int16 call, then 'extra' (bruit, valmax_square, noise_square,
+    status, dt per record) and the carried state — against the same windows through ctypes."""
+    import os
+    import subprocess
+    from tests.test_abi_and_host import build_mex_harness
+    from tests.test_gpu_configs import _read_mex_outputs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = build_mex_harness(root, tmp_path)
+    chips = prn.lfsr_chips(13, 27, 2500)
+    n, nwin, v = 5000, 7, -7e-5
+    raw = _capture(chips, nwin)
+    raw.tofile(tmp_path / "cap.bin")
+    chips.tofile(tmp_path / "chips.bin")
+    band = _band(n)
+    r = subprocess.run([str(exe), "raw", str(tmp_path / "cap.bin"), str(tmp_path / "chips.bin"), str(tmp_path / "out.bin"), "1", "1",
+                        str(band[0] + 1), str(band[1] + 1), "5e6", "0", "opt=replica:unipolar_zero_mean", "opt=vitesse:%r,0,0" % v,
+                        "opt=snr_estimators:101,301", "extra=1", "state=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    o = _read_mex_outputs(tmp_path / "out.bin")
+    assert len(o) == 15
+    with Correlator(chips, fs=FS, Nint=0, code_levels="unipolar", code_zero_mean=True, var_ddof=1) as cor:
+        cor.set_resample(v)
+        cor.set_snr_estimators(101, 301)
+        want = cor.process(raw, n_channels=1, channel=0, band=band)
+        ex = cor.snr_estimators(nwin)
+        state = cor.get_resample()
+    for w, g in enumerate(want):
+        assert o[0][0, w] == g.indice + 1 and o[8][0, w] == g.xval and o[4][0, w] == g.df and o[1][0, w] == g.correction
+        assert o[12][0, w] == g.status and o[13][0, w] == g.dt
+        for i, key in enumerate(("bruit", "valmax_square", "noise_square")):
+            assert o[9 + i][0, w] == ex[w][key] or (np.isnan(o[9 + i][0, w]) and np.isnan(ex[w][key]))
+    assert tuple(o[14][0]) == (state[0], state[1], float(state[2])) and any(g.dt for g in want)
+
+
+def test_script_level_mirror_of_the_vitesse_loop(tmp_path):
+    """amaranth_twstft_amd/vitesse.py: the two-channel capture loop of the script (channel 1 resampled, channel 2 plain) against the oracle
+    on both channels: ``solution12 - solution22`` equal to 1e-5 sample."""
+    from amaranth_twstft_amd import vitesse
+    chips = prn.lfsr_chips(13, 27, 2500)
+    n, nwin, v = 5000, 6, -5e-5
+    ps1 = [synth.SynthParams(delay_q8=(900 + w) * 256, fstep=synth.fstep_for_df(50130.0, FS), phi0=w, amp=300, noise_gain=synth.noise_gain_for_sigma(250.0), seed=7 + w) for w in range(nwin)]
+    ps2 = [synth.SynthParams(delay_q8=200 * 256, fstep=0, phi0=w, amp=2000, noise_gain=synth.noise_gain_for_sigma(100.0), seed=70 + w, stream=1) for w in range(nwin)]
+    raw = np.concatenate([synth.synth_capture(n, chips, 2, [a, b]) for a, b in zip(ps1, ps2)]).reshape(-1)
+    path = tmp_path / "OP.bin"
+    raw.tofile(path)
+    got = vitesse.ranging_vitesse(str(path), chips, fs=FS, vitesse=v)
+    want1, _, _ = orc.ranging_vitesse(raw, chips, fs=FS, vitesse=v, n_channels=2, channel=0)
+    code = orc.make_code_variant(chips, unipolar=True, zero_mean=True)
+    fcode = np.conj(np.fft.fft(code))
+    for w in range(nwin):
+        d2 = orc.deinterleave(raw[w * n * 4:(w + 1) * n * 4], 2, 1)
+        d2 = d2 - d2.mean()
+        pm = np.fft.ifft(np.fft.fft(d2) * fcode)
+        i2, c2, x2, _, _ = orc.peak_refine(pm)
+        assert got["indice2"][w] == i2 + 1 and abs(got["correction22"][w] - c2) < 1e-5 and abs(got["xval2"][w] - x2) <= 1e-6 * abs(x2)
+        assert got["indice1"][w] == want1[w]["indice"] + 1 + want1[w]["dt"] and abs(got["solution12"][w] - want1[w]["solution"]) < 1e-5
+    assert got["delay"].shape == (nwin,) and np.all(got["status"] == 0)
