@@ -1268,6 +1268,8 @@ __global__ __launch_bounds__(NT, (MODE == ROW_MID && sizeof(T) == 4 ? 4 : 1)) vo
     // workgroup's life, tools/stamps_rowd.py) is gone.  What remains is the kernel's two balanced halves: its memory traffic
     // alone takes 0.26 ms, its loads + arithmetic without the stores 0.245 ms, together 0.326 ms (profiles/r03_rowd_resident.txt).
     constexpr bool PERSIST = MODE == ROW_MID && rowd_mid_resident<P2, T>();
+    // (The same walk for the BAND pass — resident workgroups, the next row asked for as soon as the current one has left its landing
+    // registers — was built in round 6 and lost: 0.1026 against 0.0911 ms per 8 windows, profiles/r06_colinv.txt.)
     constexpr int NTC = PERSIST ? R0 * R : 0;
     // data and tables are SEPARATE shared arrays: with one array the compiler must assume that a table read may
     // alias an earlier data write and serialises read -> wait -> multiply -> write for every element of a stage
