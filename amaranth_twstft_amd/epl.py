@@ -109,3 +109,90 @@ class EplTracker:
                    filtered_carrier_phase=filtered_carrier_phase, measured_doppler_freq=measured_doppler_freq, doppler_freq=filtered_doppler_freq)
         self.history.append(out)
         return out
+
+
+class CodeStepTracker:
+    """The SECOND DLL experiment, ``experiments/230503_100kchips_withcode/gotracking_test.m:121-187``: late / prompt / early correlations over
+    ``MAXLAG`` lags, the coherent early-minus-late discriminator ``d=(|ze|^2-|zl|^2)/(|ze|^2+|zl|^2)`` (:156) that STEPS the code by one
+    sample when it leaves (-0.5, 0.5) (:159-168: the prompt replica is rotated, late and early rebuilt from it), and the first-order loop
+    of the script's TEST block on the arctangent of the prompt peak (:66-72,:171-180).
+
+    After the first block the script correlates over +-20 lags only (``MAXLAG=20``, :158): that is the DIRECT sliding dot product of the
+    tracking stage (``twx_sliding_dot``: the NCO mix of :126-127 inside the kernel, ``ff = (freq0-freq)/fs`` cycles per sample, the phase of
+    the block's first sample as ``phi``) — a linear ``xcorr`` of two N-sample sequences is the circular sum over N + 20
+    zero-padded samples.  ``z[k] = xcorr(a,xx)[k] = conj(sum_i xx[i] a[i+k])``, i.e. the conjugate of the kernel's lag ``-k``.  The first
+    block (every lag) runs on the 2N-sample correlator contexts of :class:`EplTracker`.  Host arithmetic as in the script.  UNPINNED
+    (Octave only; oracle: ``oracle.codestep_step``)."""
+
+    NLAG = 20
+
+    def __init__(self, chips, fs: float = 5e6, sps: int = 2, freq0: float = 0.0, coef=(1.0, 0.0, 0.05 / 6, 0.0), time_end: float | None = None,
+                 precision: str = "f64", device: int = -1):
+        self.fs, self.freq0, self.coef = fs, freq0, tuple(coef)
+        self.al, self.ap, self.ae = replicas(chips, sps)
+        self.n = self.ap.size
+        self._chips, self._sps, self._precision, self._device = chips, sps, precision, device
+        self.l, self.maxlag = 1, self.n                           # MAXLAG=points_per_code (:87)
+        self.freq = self.freqm1 = self.freqm2 = self.ym1 = 0.0    # :80-84
+        self.time_end = (self.n - 1) / fs if time_end is None else time_end      # time=[0:points_per_code-1]'/fs (:44): the last sample of the alignment block
+        self.history: list[dict] = []
+
+    def _full_peaks(self, x):
+        """First block: every lag, through the 2N-sample contexts (replicas as they stand now)."""
+        t = EplTracker(self._chips, fs=self.fs, sps=self._sps, precision=self._precision, device=self._device)
+        try:
+            time = self.time_end + np.arange(1, x.size + 1) / self.fs
+            xx = x * np.exp(1j * (2 * np.pi * (-self.freq0 + self.freq) * time))
+            pad = np.zeros(2 * self.n, dtype=np.complex128)
+            pad[: self.n] = xx
+            return [t._peak(c, pad) for c in t._cor]             # (1-based index into the 2N+1 vector, value)
+        finally:
+            t.close()
+
+    def _narrow_peaks(self, raw_iq):
+        """Later blocks: +-20 lags by the direct sliding dot product, NCO inside the kernel."""
+        from . import tracking
+        n, nl = self.n, self.NLAG
+        m = n + nl
+        pad = np.zeros(2 * m, dtype=np.int16)
+        pad[: 2 * n] = raw_iq
+        ffc = (self.freq0 - self.freq) / self.fs                  # exp(-2 pi j (ff i + phi)) = exp(+2 pi j (-freq0+freq) t_i), t_i = time_end + (i+1)/fs
+        phi = ((self.freq0 - self.freq) * (self.time_end + 1.0 / self.fs)) % 1.0
+        out = []
+        for a in (self.al, self.ap, self.ae):
+            rep = np.zeros(m, dtype=np.float32)
+            rep[:n] = a
+            sd = tracking.sliding_dot(pad, rep, nobs=m, ncodes=1, nlag=nl, ff=ffc, phi=phi, scale=float(m))[0]
+            z = np.conj(sd[::-1])                                 # z[k + nl] = xcorr(a, xx, 20)[k]
+            i = int(np.abs(z).argmax())
+            out.append((i + 1, complex(z[i])))
+        return out
+
+    def step(self, raw_iq) -> dict:
+        """One code period: ``raw_iq`` = the block's N samples of the tracked channel as int16 ``[I Q I Q ...]`` (the script reads the capture
+        raw: no mean is removed, :122-124)."""
+        raw_iq = np.ascontiguousarray(raw_iq, dtype=np.int16).reshape(-1)
+        if raw_iq.size != 2 * self.n:
+            raise ValueError("a block is one code period")
+        x = raw_iq[0::2].astype(np.float64) + 1j * raw_iq[1::2].astype(np.float64)
+        (bbl, zl), (bbp, zp), (bbe, ze) = self._full_peaks(x) if self.maxlag >= self.n else self._narrow_peaks(raw_iq)
+        d = (abs(ze ** 2) - abs(zl) ** 2) / (abs(ze) ** 2 + abs(zl) ** 2)                      # :156
+        self.maxlag = self.NLAG                                                                 # :158
+        ap = self.ap
+        if d < -0.5:                                                                            # :159-163
+            ap = np.concatenate([ap[-1:], ap[:-1]])
+        if d > 0.5:                                                                             # :164-168
+            ap = np.concatenate([ap[1:], ap[:1]])
+        if d < -0.5 or d > 0.5:
+            self.ap, self.al, self.ae = ap, np.concatenate([ap[-1:], ap[:-1]]), np.concatenate([ap[1:], ap[:1]])
+        ratio = zp.imag / zp.real if zp.real != 0 else (math.copysign(math.inf, zp.imag) if zp.imag != 0 else math.nan)
+        yp = math.atan(ratio)                                                                   # :172
+        yyp = math.atan2(zp.imag, zp.real)                                                      # :173
+        freq = self.coef[0] * self.freqm1 + self.coef[1] * self.freqm2 + self.coef[2] * yp + self.coef[3] * self.ym1      # :174
+        out = dict(l=self.l, bbl=bbl, bbp=bbp, bbe=bbe, zl=zl, zp=zp, ze=ze, d=float(d), u=abs(zp), yp=yp, yyp=yyp, freq=freq,
+                   stepped=int(d > 0.5) - int(d < -0.5))
+        self.freqm2, self.freqm1, self.ym1, self.freq = self.freqm1, freq, yp, freq             # :175-178
+        self.time_end = self.time_end + self.n / self.fs
+        self.l += 1
+        self.history.append(out)
+        return out

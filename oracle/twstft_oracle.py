@@ -1310,3 +1310,42 @@ def epl_step(state: dict, x, al, ap, ae, fs=5e6, freq0=0.0, T_blk=80e-3, delay_s
     state["l"] = l + 1
     state["doppler_freq"].append(out["doppler_freq"])
     return out
+
+
+def codestep_step(state: dict, x, fs=5e6, freq0=0.0, coef=(1.0, 0.0, 0.05 / 6, 0.0)):
+    """One pass of the main loop of experiments/230503_100kchips_withcode/gotracking_test.m:121-187 — the SECOND DLL experiment: the block is
+    mixed by ``exp(1j*2*pi*(-freq0+freq)*time)`` (:126-127), correlated with the late / prompt / early replicas over ``MAXLAG`` lags
+    (``xcorr(al,xx,MAXLAG)``, :128-130: every lag in the first pass, 20 afterwards, :158), the COHERENT discriminator
+    ``d=(|ze|^2-|zl|^2)/(|ze|^2+|zl|^2)`` (:156) steps the code — the prompt replica is rotated by one sample and late / early rebuilt
+    from it (:159-168) — and the arctangent of the prompt peak drives the loop filter ``freq=coef_uk_1*freqm1+coef_uk_2*freqm2+
+    coef_ek*yp+coef_ek_1*ym1`` (:171-180; ``coef`` = the script's TEST values, :66-72).  ``state``: l, maxlag, ap, al, ae, freq, freqm1,
+    freqm2, ym1, time_end — updated in place.  UNPINNED (Octave only)."""
+    x = np.asarray(x, dtype=complex).reshape(-1)
+    n = x.size
+    time = state["time_end"] + np.arange(1, n + 1) / fs                                    # :125
+    xx = x * np.exp(1j * (2 * np.pi * (-freq0 + state["freq"]) * time))                   # :126-127
+    ml = min(state["maxlag"], n)
+    cut = lambda z: z[n - ml: n + ml + 1]                                                  # xcorr(a,xx,MAXLAG): lags -MAXLAG ... MAXLAG
+    zl, zp, ze = (cut(octave_xcorr(a, xx)) for a in (state["al"], state["ap"], state["ae"]))
+    bbl, bbp, bbe = (int(np.abs(z).argmax()) for z in (zl, zp, ze))                        # 0-based here; Octave's are +1
+    vl, vp, ve = zl[bbl], zp[bbp], ze[bbe]
+    d = (abs(ve ** 2) - abs(vl) ** 2) / (abs(ve) ** 2 + abs(vl) ** 2)                      # :156
+    state["maxlag"] = 20                                                                   # :158
+    ap = state["ap"]
+    if d < -0.5:                                                                           # :159-163
+        ap = np.concatenate([ap[-1:], ap[:-1]])
+    if d > 0.5:                                                                            # :164-168 (after the first test, on the possibly rotated ap, as the script does)
+        ap = np.concatenate([ap[1:], ap[:1]])
+    if d < -0.5 or d > 0.5:
+        state["ap"] = ap
+        state["al"] = np.concatenate([ap[-1:], ap[:-1]])
+        state["ae"] = np.concatenate([ap[1:], ap[:1]])
+    yp = float(np.arctan(np.divide(vp.imag, vp.real))) if vp.real != 0 else float(np.sign(vp.imag) * np.pi / 2 if vp.imag != 0 else np.nan)   # :172
+    yyp = float(np.arctan2(vp.imag, vp.real))                                              # :173
+    freq = coef[0] * state["freqm1"] + coef[1] * state["freqm2"] + coef[2] * yp + coef[3] * state["ym1"]      # :174
+    out = dict(l=state["l"], bbl=bbl + 1, bbp=bbp + 1, bbe=bbe + 1, zl=vl, zp=vp, ze=ve, d=float(d), u=float(abs(vp)), yp=yp, yyp=yyp, freq=float(freq),
+               stepped=int(d > 0.5) - int(d < -0.5))
+    state["freqm2"], state["freqm1"], state["ym1"], state["freq"] = state["freqm1"], freq, yp, freq      # :175-178
+    state["time_end"] = float(time[-1])
+    state["l"] += 1
+    return out

@@ -1436,3 +1436,45 @@ def test_early_prompt_late_tracking_loop(precision):
         assert len(trk.doppler_freq) == nblk + 1 and trk.l == nblk + 1
         # (with the script's constants — T_blk = 80 ms, B_PLL = 20 Hz, made for 40-ms codes — a 2-ms code period does not pull in; the
         # test holds the twin against the restatement, not the loop design)
+
+
+def test_code_stepping_tracking_loop_on_the_sliding_dot_product():
+    """experiments/230503_100kchips_withcode/gotracking_test.m:121-187 — the SECOND DLL experiment: after the first block (every lag) the three
+    correlations run over +-20 lags only, i.e. on the direct sliding dot product of the tracking stage (twx_sliding_dot, NCO inside the kernel);
+    the coherent discriminator d steps the code when it leaves (-0.5, 0.5).  A 5000-chip code whose delay DRIFTS by a sample every few
+    blocks, against oracle.codestep_step block by block: peak indices, the three peak values, d, the steps taken, the loop's frequency."""
+    from amaranth_twstft_amd import epl
+    chips = chips_for(13, 27, 5000)
+    fs, n = FS, 10000
+    _, ap, _ = epl.replicas(chips, 2)
+    rng = np.random.default_rng(18)
+    nblk, freq0, f_res = 30, 1000.0, 0.7
+    total = (nblk + 1) * n
+    t = np.arange(total) / fs
+    # The three correlations each find their OWN peak, so d stays near zero while all three peaks are inside the +-20 lags; it leaves
+    # (-0.5, 0.5) — and the code is stepped — when the received code has slid so far that the early (or late) replica's peak falls outside
+    # the window and only a sidelobe is left of it.  The received code slides one sample every 3 blocks, starting 17 samples off.
+    delay = 17 + (np.arange(total) // (3 * n))
+    idx = (np.arange(total) - delay) % n
+    sig = 900.0 * ap[idx] * np.exp(2j * np.pi * ((freq0 + f_res) * t + 0.07)) + rng.normal(0, 250.0, total) + 1j * rng.normal(0, 250.0, total)
+    raw = np.empty(2 * total, dtype=np.int16)
+    raw[0::2] = np.rint(sig.real); raw[1::2] = np.rint(sig.imag)
+    al0, ap0, ae0 = epl.replicas(chips, 2)
+    state = dict(l=1, maxlag=n, ap=ap0, al=al0, ae=ae0, freq=0.0, freqm1=0.0, freqm2=0.0, ym1=0.0, time_end=-1.0 / fs)
+    trk = epl.CodeStepTracker(chips, fs=fs, freq0=freq0, time_end=-1.0 / fs)
+    steps = 0
+    for b in range(nblk):
+        blk = raw[2 * b * n: 2 * (b + 1) * n]
+        x = blk[0::2].astype(float) + 1j * blk[1::2].astype(float)
+        got = trk.step(blk)
+        want = orc.codestep_step(state, x, fs=fs, freq0=freq0)
+        tol = 5e-9 if b == 0 else 3e-6                           # the first block on the fp64 contexts, the others on the fp32 sliding dot product
+        assert (got["bbl"], got["bbp"], got["bbe"]) == (want["bbl"], want["bbp"], want["bbe"]), (b, got["bbp"], want["bbp"])
+        for k in ("zl", "zp", "ze"):
+            assert abs(got[k] - want[k]) <= tol * abs(want[k]), (b, k, got[k], want[k])
+        assert abs(got["d"] - want["d"]) < 1e-4 and got["stepped"] == want["stepped"], (b, got["d"], want["d"])
+        assert abs(got["yp"] - want["yp"]) < 1e-4 and abs(got["freq"] - want["freq"]) < 1e-5, (b, got["freq"], want["freq"])
+        trk.freq, trk.freqm1, trk.freqm2, trk.ym1 = state["freq"], state["freqm1"], state["freqm2"], state["ym1"]      # keep the twins in step (the loop feeds back)
+        assert np.array_equal(trk.ap, state["ap"])
+        steps += abs(got["stepped"])
+    assert steps >= 3 and trk.maxlag == 20                      # the code was stepped as the peak reached the edge of the lag window
