@@ -9,6 +9,7 @@
 #include <condition_variable>
 #include <functional>
 #include <future>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -60,6 +61,49 @@ struct Worker {
     ~Worker() { stop(); }
 };
 
+// A process-wide pool of reader threads (round 6): the pieces of a chunk used to be std::async threads of their own — 32 thread starts per
+// 160-MB chunk, 768 for a 4-GB capture.  The pool grows to the largest reader count ever asked for and lives as long as the process (its
+// threads are detached: nothing of the library's shutdown waits for a thread that sits in a condition variable).
+class IoPool {
+    struct State {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<std::function<void()>> queue;
+        int threads = 0, idle = 0;
+    };
+    std::shared_ptr<State> st = std::make_shared<State>();      // owned by the workers as well: they may outlive the static object
+    static void worker(std::shared_ptr<State> s) {
+        std::unique_lock<std::mutex> lk(s->mu);
+        for (;;) {
+            ++s->idle;
+            s->cv.wait(lk, [&]() { return !s->queue.empty(); });
+            --s->idle;
+            std::function<void()> f = std::move(s->queue.back());
+            s->queue.pop_back();
+            lk.unlock();
+            f();
+            lk.lock();
+        }
+    }
+public:
+    static IoPool& instance() { static IoPool* p = new IoPool(); return *p; }      // never destroyed
+    // runs f on a pool thread; at most `want` threads exist because of this call (more may exist already)
+    template <class F> std::future<size_t> submit(F f, int want) {
+        auto task = std::make_shared<std::packaged_task<size_t()>>(std::move(f));
+        std::future<size_t> fut = task->get_future();
+        {
+            std::lock_guard<std::mutex> lk(st->mu);
+            st->queue.push_back([task]() { (*task)(); });
+            if (st->idle < (int)st->queue.size() && st->threads < std::max(1, want)) {
+                ++st->threads;
+                std::thread(worker, st).detach();
+            }
+        }
+        st->cv.notify_one();
+        return fut;
+    }
+};
+
 // [off0, off0 + need) of a source into dst as up to `nthreads` concurrent pieces (4096-byte aligned cuts, pieces of at least
 // 4 MB).  read_at(dst, offset, len) -> bytes delivered (short only at the end of the source).  Returns the bytes delivered
 // CONTIGUOUSLY from off0 (a short piece ends the count: what follows it is not part of the capture).
@@ -87,7 +131,7 @@ size_t read_in_pieces(ReadAt read_at, char* dst, size_t off0, size_t need, int n
     std::vector<std::future<size_t>> parts;
     for (int i = 1; i < P; ++i) {
         const size_t lo = std::min(need, piece * i), hi = std::min(need, piece * (i + 1));
-        parts.push_back(std::async(std::launch::async, [=]() { return lo < hi ? fetch(lo, hi) : (size_t)0; }));
+        parts.push_back(IoPool::instance().submit([=]() { return lo < hi ? fetch(lo, hi) : (size_t)0; }, 3 * nthreads));      // (three chunks are in flight at a time)
     }
     const size_t first_len = std::min(need, piece);
     size_t total = fetch(0, first_len);
