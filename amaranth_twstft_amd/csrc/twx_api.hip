@@ -643,6 +643,7 @@ template <typename T> struct Ctx : CtxBase {
             extra_cap = cap;
         }
         HIPCHK(hipMemset(extra_dev, 0xff, sizeof(twx_extra) * (size_t)nrec));        // (all-ones doubles are NaN: records a short call never reaches)
+        HIPCHK(hipStreamSynchronize(nullptr));    // the context's streams are non-blocking: nothing orders them behind the null stream but the host
         extra_n = nrec;
         return TWX_OK;
     }
@@ -2105,16 +2106,21 @@ void fence_register(int dev, hipStream_t s) {
     for (auto& p : f.streams) if (p.first == s) return;
     f.streams.push_back({s, nullptr});                     // the marker event is created by the first exclusive section that needs it
 }
+static thread_local int t_fence_depth[64];
 void fence_unregister(int dev, hipStream_t s) {
     DeviceFence& f = fence_of(dev);
-    std::unique_lock<std::shared_mutex> x(f.mu);           // no launch in progress while a stream leaves
+    // no launch in progress while a stream leaves; a thread that destroys a context from inside one of its own enqueue sections gives its
+    // share up for the moment (it would wait for itself otherwise)
+    const bool mine = t_fence_depth[dev & 63] > 0;
+    if (mine) f.mu.unlock_shared();
+    struct Back { DeviceFence& f; bool on; ~Back() { if (on) f.mu.lock_shared(); } } back{f, mine};
+    std::unique_lock<std::shared_mutex> x(f.mu);
     std::lock_guard<std::mutex> g(f.reg_mu);
     for (size_t i = 0; i < f.streams.size(); ++i)
         if (f.streams[i].first == s) { if (f.streams[i].second) (void)hipEventDestroy(f.streams[i].second); f.streams.erase(f.streams.begin() + (long)i); break; }
 }
 // entry points call each other (the tracked flow and the receiver run on the correlator's own entries): only the outermost section of a
-// thread takes the lock — a reader that re-enters behind a waiting writer would wait for itself
-static thread_local int t_fence_depth[64];
+// thread takes the lock — a reader that re-enters behind a waiting writer would wait for itself (t_fence_depth)
 FenceShared::FenceShared(int dev_, hipStream_t s) : dev(dev_) {
     DeviceFence& f = fence_of(dev);
     if (t_fence_depth[dev & 63]++ == 0) f.mu.lock_shared();
