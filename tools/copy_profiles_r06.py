@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Copy the summaries of a tools/prof_round6.sh run (gpurun_out/r06p) into profiles/ and check DESIGN.md's numbers against them.
-    python tools/copy_profiles_r05.py"""
+    python tools/copy_profiles_r06.py"""
 import json, os, shutil, subprocess, sys
 O, P, tag = "gpurun_out/r06p/", "profiles/", "r06"
 sys.path.insert(0, "tools")
