@@ -567,6 +567,7 @@ template <typename T> struct Ctx : CtxBase {
     C *cspec_perm = nullptr, *dtabs = nullptr, *ea_d = nullptr, *eb_d = nullptr;   // DIF/DIT row pass (k_rowd)
     C *cspec_plain = nullptr, *cspec_perm_plain = nullptr;   // Hamming-window contexts: the UNWINDOWED code spectrum, for the wipe-off statistics
     C* wr_d = nullptr;            // exp(-2 pi i j/R), j < R: pruned last stage of k_rowd<BAND>
+    C* wm_d = nullptr;            // exp(-2 pi i j/(R R)): k_rowd_bandsum (the pruned row pass without the row in LDS)
     C* vw_d = nullptr;            // [k1][2][R] exp(+2 pi i k1 a/N), exp(+2 pi i k1 R b/N): k_rowd<MID>'s folded output twiddle
     C* vc_d = nullptr;            // [k1][c] exp(+2 pi i k1 c M/N): stage C's per-row output twiddle of k_rowd<MID> (scalar loads)
     int use_rowd = 0;
@@ -817,6 +818,11 @@ template <typename T> struct Ctx : CtxBase {
             std::vector<C> wr((size_t)Rr);
             for (int j = 0; j < Rr; ++j) wr[(size_t)j] = Wf(j, Rr);
             if (int rc = upload(&wr_d, wr)) return rc;
+            {
+                std::vector<C> wm((size_t)Rr * Rr);
+                for (int j = 0; j < Rr * Rr; ++j) wm[(size_t)j] = Wf(j, (long long)Rr * Rr);
+                if (int rc = upload(&wm_d, wm)) return rc;
+            }
             {
                 const long long Mblk = (long long)N2 / R0;
                 std::vector<C> vc((size_t)N1 * R0);
@@ -1212,6 +1218,10 @@ template <typename T> struct Ctx : CtxBase {
                 if (use_rowd) {
                     RowDArgs<T> rd{}; rd.r = ra; rd.dtabs = dtabs; rd.cspec_perm = cspec_perm; rd.ea_d = ea_d; rd.eb_d = eb_d;
                     rd.wr = wr_d; band_pairs(band, &rd.nprune, &rd.pr_q1, &rd.pr_q2);
+                    // fp32, a band of at most 8 digit pairs: k_rowd_bandsum (the row never enters LDS).  TWX_BANDSUM=0: k_rowd<BAND> (A/B; read per
+                    // call so that one process can compare the two forms)
+                    const char* bs = getenv("TWX_BANDSUM");
+                    rd.wm = (!bs || atoi(bs) != 0) ? wm_d : nullptr;
                     if (row->rowd(ROW_BAND, &rd, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_rowd(band) launch failed");
                 } else if (row->run(ROW_BAND, &ra, (unsigned)(N1 * nb), stream)) return fail(TWX_E_HIP, "k_row(band) launch failed");
             }

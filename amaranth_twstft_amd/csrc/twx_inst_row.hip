@@ -61,8 +61,17 @@ template <typename T> int rowd(int mode, const void* args, unsigned nblk, hipStr
             else if (mode == ROW_MID) TWX_LAUNCH((k_rowd_small<P, T, ROW_MID, NTS>), dim3(grid), dim3(NTS), s, a, nblk);
             else return -1;
         } else {
-        if (mode == ROW_BAND) TWX_LAUNCH((k_rowd<P, T, ROW_BAND, NTD>), dim3(nblk), dim3(NTD), s, a);
-        else if (mode == ROW_MID) {
+        if (mode == ROW_BAND) {
+            // a narrow search band in fp32: the few bins a row can contribute are summed over the workgroup's threads, the row never enters LDS
+            if constexpr (std::is_same<T, float>::value && rowd_bandsum_ok<P>()) {
+                if (a.nprune > 0 && a.wm) {
+                    constexpr int NTB = BandsumDeal<RowD<P, T>::M / 16, TWX_BANDSUM_TPT>::threads;
+                    TWX_LAUNCH((k_rowd_bandsum<P, T, TWX_BANDSUM_TPT>), dim3(nblk), dim3(NTB), s, a);
+                    return (int)hipGetLastError();
+                }
+            }
+            TWX_LAUNCH((k_rowd<P, T, ROW_BAND, NTD>), dim3(nblk), dim3(NTD), s, a);
+        } else if (mode == ROW_MID) {
             unsigned grid = nblk;                          // resident workgroups walk the rows (a.total_rows = nblk)
             if (rowd_mid_resident<P, T>() && a.r.pf_stride > 0 && (unsigned)a.r.pf_stride < nblk) grid = (unsigned)a.r.pf_stride;
             if (a.chk_rows) TWX_LAUNCH((k_rowd<P, T, ROW_MID, NTD, true>), dim3(grid), dim3(NTD), s, a);      // TWX_OPT_SELFCHECK: Parseval per row

@@ -1183,6 +1183,7 @@ template <typename T> struct RowDArgs {
     const cpx<T>* vc;                // [k1][c]  exp(+2 pi i k1 c M/N), c < R0: the per-row output twiddle of stage C, read with scalar loads
     const cpx<T>* vw;                // [k1][2][R]  exp(+2 pi i k1 a/N), exp(+2 pi i k1 R b/N): the folded output twiddle of k_rowd<MID>
     const cpx<T>* wr;                // [R] exp(-2 pi i j / R)
+    const cpx<T>* wm;                // [R R] exp(-2 pi i j / (R R)): k_rowd_bandsum
     int nprune;                      // number of (q1, q2) pairs, 0 = full last stage
     unsigned long long pr_q1, pr_q2; // pair p in byte p
     unsigned total_rows;             // N1 * windows (the grid is smaller when k_rowd<MID> runs with resident workgroups)
@@ -1702,6 +1703,170 @@ __global__ __launch_bounds__(256) void k_chk_verdict(const float* __restrict__ r
         atomicMax(stat, __float_as_uint(s_w[0]));
         if (s_n[0]) atomicAdd(stat + 1, (unsigned)s_n[0]);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rowd_bandsum: the row pass of the carrier search (fft(d.^2) restricted to the search band, godual_ranging.m:13-16) where the band touches
+// only a few (q1, q2) digit pairs of the row bins k2 = q0 + R0 (q1 + R q2) — the pruned case of k_rowd<BAND>: +-20 kHz of a 5-Msps second is
+// |k2| <= 32 of 8000, four pairs — WITHOUT the row in LDS.  After the radix-R0 butterfly and its twiddle, thread t holds Y_t[q0], and
+//     X[q0 + R0 kappa] = sum_t Y_t[q0] W_M^{t kappa},   kappa = q1 + R q2,   M = R R,
+// is a sum over the workgroup's threads for each of the few kappa: R0 products per thread and kappa, summed over the wave by a
+// reduce-scatter on v_permlane32_swap / v_permlane16_swap (each halves the values a lane carries) and DPP inside the rows of 16 lanes,
+// over the waves through 9 KB of LDS.  k_rowd<BAND> holds the 64-KB row in LDS (two workgroups per CU, each waiting for its row, then
+// computing: 3.5 TB/s); this form keeps ~19 KB and 80 registers, so three workgroups per CU have their rows in flight.
+// fp32, even R0; everything else takes k_rowd<BAND>.
+// ------------------------------------------------------------------------------------------
+#define TWX_BANDSUM_MAXP 8
+#ifndef TWX_BANDSUM_ABL
+#define TWX_BANDSUM_ABL 0
+#endif
+__device__ __forceinline__ float twx_row16_sum(float v) {      // every lane of a row of 16 ends with the row's sum
+    v = TWX_DPP_ADD(v, 0xB1);       // quad_perm [1,0,3,2]
+    v = TWX_DPP_ADD(v, 0x4E);       // quad_perm [2,3,0,1]
+    v = TWX_DPP_ADD(v, 0x141);      // row_half_mirror
+    v = TWX_DPP_ADD(v, 0x140);      // row_mirror
+    return v;
+}
+// CH complex values per lane -> CH/2 floats per lane: rows 0 / 1 of 16 lanes hold the wave's sums of re[i] / re[i + CH/2], rows 2 / 3 of im[i] / im[i + CH/2]
+template <int CH> __device__ __forceinline__ void wave_sum_scatter(const cpx<float>* z, float* out) {
+    static_assert(CH % 2 == 0, "pairs of values");
+    float s[CH];
+    TWX_UNROLL
+    for (int i = 0; i < CH; ++i) {
+        // rows 2, 3 of the first operand <-> rows 0, 1 of the second: lanes < 32 then add re of lanes l and l + 32, lanes >= 32 the same for im
+        // (operands and results go through named scalars: this clang evaluates __builtin_bit_cast of a vector ELEMENT expression — z[i].y, r[1] —
+        // as a cast of element 0)
+        const float zx = z[i].x, zy = z[i].y;
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, zx), __builtin_bit_cast(unsigned, zy), false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        s[i] = __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+    }
+    TWX_UNROLL
+    for (int i = 0; i < CH / 2; ++i) {
+        // odd rows of the first operand <-> even rows of the second: row 0 = s[i] rows 0 + 1, row 1 = s[i + CH/2] rows 0 + 1, rows 2, 3 the same of rows 2 + 3
+        const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s[i]), __builtin_bit_cast(unsigned, s[i + CH / 2]), false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        out[i] = twx_row16_sum(__builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1));
+    }
+}
+template <int TILES, int TPT> struct BandsumDeal {
+    static constexpr int cnt(int j) { return TILES / TPT + (j < TILES % TPT ? 1 : 0); }
+    static constexpr int off(int j) { int o = 0; for (int i = 0; i < j; ++i) o += cnt(i); return o; }
+    static constexpr int threads = ((cnt(0) * 16 + 63) / 64) * 64;
+};
+#ifndef TWX_BANDSUM_TPT
+#define TWX_BANDSUM_TPT 2
+#endif
+template <class P2> constexpr bool rowd_bandsum_ok() {      // (asked of plans that have a RowD form)
+    using D = RowD<P2, float>;
+    return P2::S == 3 && D::R0 % 2 == 0 && D::M % 16 == 0 && D::M / 16 >= TWX_BANDSUM_TPT;
+}
+template <class P2, typename T, int TPT>
+__global__ __launch_bounds__((BandsumDeal<RowD<P2, T>::M / 16, TPT>::threads), (TPT == 1 ? 6 : TPT == 2 ? 4 : 2)) void k_rowd_bandsum(RowDArgs<T> ad) {
+    using C = cpx<T>;
+    using D = RowD<P2, T>;
+    static_assert(sizeof(T) == 4 && D::R0 % 2 == 0, "fp32, even first radix");
+    const RowArgs<T>& a = ad.r;
+    constexpr int R = D::R, R0 = D::R0, M = D::M;
+    using Deal = BandsumDeal<M / 16, TPT>;
+    constexpr int NT = Deal::threads, NW = NT / 64;
+    constexpr int CH = (R0 % 4 == 0) ? R0 / 2 : R0, NCH = R0 / CH;      // values per reduce-scatter round (20 registers at R0 = 20)
+    constexpr int NTW = 2 * R0 * R, NLT = (NTW + NT - 1) / NT, NLM = (M + NT - 1) / NT;
+    static_assert(M % 16 == 0, "whole tiles of 16 tasks");
+    __shared__ C s_tw[NTW];                                        // tb | tc: W_L^{q0 i2}, W_L^{q0 R i1}
+    __shared__ C s_wm[M];                                          // W_M^j
+    __shared__ float s_part[NW * TWX_BANDSUM_MAXP * R0 * 2];       // [wave][pair][q0][re, im]
+    __shared__ unsigned long long s_red[2 * NW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int k1 = logical / a.nwin, b = logical % a.nwin;
+    // tables first (loads return in order), then the row
+    C treg[NLT], mreg[NLM];
+    TWX_UNROLL
+    for (int k = 0; k < NLT; ++k) treg[k] = ad.dtabs[D::tab_b + min(tid + k * NT, NTW - 1)];
+    TWX_UNROLL
+    for (int k = 0; k < NLM; ++k) mreg[k] = ad.wm[min(tid + k * NT, M - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+    C v[TPT][R0];
+    int tj[TPT];
+    bool live[TPT];
+    {
+        const C* Ab = a.A + (long long)b * a.n;
+        const unsigned long long ab = sgpr_u64(reinterpret_cast<unsigned long long>(Ab));
+        const unsigned long long rstep = sgpr_u64((unsigned long long)M * (unsigned long long)a.n1 * sizeof(C));
+        TWX_UNROLL
+        for (int j = 0; j < TPT; ++j) {
+            live[j] = tid < 16 * Deal::cnt(j);
+            tj[j] = 16 * Deal::off(j) + min(tid, 16 * Deal::cnt(j) - 1);      // idle lanes copy the slot's last task (their factor is zero)
+            const unsigned lb = a_index((unsigned)tj[j], (unsigned)k1, (unsigned)a.n1, a.wshift) * (unsigned)sizeof(C);
+            TWX_UNROLL
+            for (int r = 0; r < R0; ++r) v[j][r] = ld_pin<C, TWX_NT_A != 0>(ab, r * rstep, lb);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    TWX_UNROLL
+    for (int k = 0; k < NLT; ++k) s_tw[min(tid + k * NT, NTW - 1)] = treg[k];      // (the clamped duplicates write the value that is there)
+    TWX_UNROLL
+    for (int k = 0; k < NLM; ++k) s_wm[min(tid + k * NT, M - 1)] = mreg[k];
+    __syncthreads();
+    TWX_UNROLL
+    for (int j = 0; j < TPT; ++j) {
+        Bfly<T, R0, false>::run(v[j]);
+        const int i1 = tj[j] / R, i2 = tj[j] % R;
+        TWX_UNROLL
+        for (int q0 = 1; q0 < R0; ++q0) v[j][q0] = cmul3(v[j][q0], s_tw[q0 * R + i2], s_tw[R0 * R + q0 * R + i1]);
+    }
+    const int np = TWX_BANDSUM_ABL == 2 ? 1 : ad.nprune;      // (diagnostic 2: one pair only)
+    for (int p = 0; p < np; ++p) {
+        const unsigned kap = (unsigned)((ad.pr_q1 >> (8 * p)) & 0xffu) + (unsigned)R * (unsigned)((ad.pr_q2 >> (8 * p)) & 0xffu);
+        C g[TPT];
+        TWX_UNROLL
+        for (int j = 0; j < TPT; ++j) {
+            g[j] = s_wm[((unsigned)tj[j] * kap) % (unsigned)M];
+            if (!live[j]) g[j] = mk<T>(0, 0);
+        }
+        TWX_UNROLL
+        for (int c = 0; c < NCH; ++c) {
+            C z[CH];
+            float o[CH / 2];
+            TWX_UNROLL
+            for (int i = 0; i < CH; ++i) {
+                z[i] = cmul(v[0][c * CH + i], g[0]);
+                TWX_UNROLL
+                for (int j = 1; j < TPT; ++j) z[i] = z[i] + cmul(v[j][c * CH + i], g[j]);
+            }
+#if TWX_BANDSUM_ABL == 1      // diagnostic: the products without the reduction over the wave
+            TWX_UNROLL
+            for (int i = 0; i < CH / 2; ++i) o[i] = z[i].x + z[i + CH / 2].y;
+#else
+            wave_sum_scatter<CH>(z, o);
+#endif
+            if ((lane & 15) == 0) {
+                const int row = lane >> 4;
+                float* dst = s_part + (((wv * TWX_BANDSUM_MAXP + p) * R0 + c * CH + (row & 1) * (CH / 2)) * 2 + (row >> 1));
+                TWX_UNROLL
+                for (int i = 0; i < CH / 2; ++i) dst[2 * i] = o[i];
+            }
+        }
+    }
+    __syncthreads();
+    Best<T> best; best.val = T(-1); best.idx = 0xffffffffu;
+    for (int e = tid; e < R0 * np; e += NT) {
+        const int q0 = e % R0, p = e / R0;
+        const int q1 = (int)((ad.pr_q1 >> (8 * p)) & 0xffu), q2 = (int)((ad.pr_q2 >> (8 * p)) & 0xffu);
+        C acc = mk<T>(0, 0);
+        TWX_UNROLL
+        for (int w = 0; w < NW; ++w) {
+            const float* src = s_part + ((w * TWX_BANDSUM_MAXP + p) * R0 + q0) * 2;
+            acc.x += src[0]; acc.y += src[1];
+        }
+        const long long half = a.n / 2;
+        const long long k = (long long)k1 + (long long)a.n1 * D::k_of(q0, q1, q2);
+        long long i = k - (a.n - half); if (i < 0) i += a.n;
+        if (i >= a.band_lo && i <= a.band_hi) best.take(cnorm(acc), (unsigned int)i);
+    }
+    best = block_best<T, NT>(best, (void*)s_red);
+    if (tid == 0) { ArgPart<T> pp; pp.val = best.val; pp.idx = best.idx; a.part[(long long)b * a.n1 + k1] = pp; }
 }
 
 // ------------------------------------------------------------------------------------------

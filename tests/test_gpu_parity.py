@@ -955,6 +955,50 @@ def test_stockham_row_pass_fallback(monkeypatch):
     assert np.array_equal(lag_d, lag_o) and np.abs(pk_d - pk_o).max() <= MAG_TOL * pk_o.max()
 
 
+@pytest.mark.parametrize("nchips,remote", [(100000, 0), (2_500_000, 0), (2_500_000, 1), (1_250_000, 0)])
+def test_band_row_pass_two_forms_agree(monkeypatch, nchips, remote):
+    """The carrier search's row pass in fp32 with a narrow band runs k_rowd_bandsum (sums over the workgroup's threads, no row in LDS;
+    rows of 4000 and 8000 points); TWX_BANDSUM=0 selects k_rowd<BAND> with its pruned last stage.  Same peak bin for every window — a tone
+    inside the near band (godual_ranging.m:83-84) and inside the remote band (:86-89, other digit pairs) — hence byte-identical records,
+    and the bin is the oracle's."""
+    import torch
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    chips = chips_for(22 if nchips > 1_000_000 else 17, 3 if nchips > 1_000_000 else 9, nchips)
+    n = 2 * nchips
+    nwin = 6
+    iq = torch.empty((nwin, n, 2), dtype=torch.int16, device=dev)
+    cd = torch.from_numpy(chips).to(dev)
+    dfs = [(50_000.0 - 1234.25 * w) if remote else (9000.5 - 3100.0 * w) for w in range(nwin)]      # 2 df inside the band in both cases
+    for w in range(nwin):
+        p = synth.SynthParams(delay_q8=(4321 + w) * 256, fstep=synth.fstep_for_df(dfs[w], FS), phi0=w, amp=300,
+                              noise_gain=synth.noise_gain_for_sigma(300.0), seed=50 + w)
+        params = np.array([p.delay_q8, p.fstep, p.phi0, p.amp, p.noise_gain, p.seed, p.stream, 0], dtype=np.int64)
+        L.check(lib.twx_synth_capture_dev(iq[w].data_ptr(), n, 0, cd.data_ptr(), nchips, 2, 1, params.ctypes.data_as(C.c_void_p), None))
+    torch.cuda.synchronize()
+    band = L.twx_band(*band_godual(FS, n, remote=remote))
+    RB = C.sizeof(L.twx_result)
+    out = {}
+    with Correlator(chips, fs=FS, Nint=1) as cor:
+        for form in ("1", "0"):
+            monkeypatch.setenv("TWX_BANDSUM", form)
+            res = torch.zeros((nwin, RB), dtype=torch.uint8, device=dev)
+            L.check(lib.twx_process_windows_dev(cor._h, iq.data_ptr(), nwin, 1, 0, C.byref(band), None, res.data_ptr()), cor._h)
+            cor.synchronize()
+            out[form] = res.cpu().numpy()
+    assert out["1"].tobytes() == out["0"].tobytes()
+    recs = (L.twx_result * nwin).from_buffer_copy(out["1"].tobytes())
+    for w in range(nwin):
+        assert abs(recs[w].df - dfs[w]) <= 0.51 * FS / n, (w, recs[w].df, dfs[w])      # df = half the d^2 peak's frequency: 1-bin grid of fs/n
+        assert int(recs[w].indice0) == 3 * (4321 + w)
+    if nchips <= 100000:                                             # the oracle's own search (fft(d.^2) over the band) on every window
+        freq = orc.freq_axis(FS, n)
+        k = orc.band_godual(freq, remote=remote)
+        for w in range(nwin):
+            d = orc.deinterleave(iq[w].cpu().numpy().reshape(-1), 1, 0)
+            assert abs(recs[w].df - orc.coarse_df(d - d.mean(), k, freq)[1]) < 1e-9
+
+
 def test_host_pipeline_many_chunks_per_window_df():
     """twx_process_windows through the pinned pipeline: more chunks than slots, a ragged tail, per-window df."""
     nchips, n, nwin = 10000, 20000, 64 * 3 + 64 + 5              # batch 64: 4 full chunks + a 5-window tail

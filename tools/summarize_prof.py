@@ -30,6 +30,8 @@ def short(name):
         mm = re.search(r">, (float|double), \d+, (\d),", targs)
         if mm:
             return "k_col_fwd" + {"0": "_mix", "1": "_square", "2": "_plain"}[mm.group(2)] + "(split)"
+    elif k == "k_rowd_bandsum":
+        return "k_row_band(sum)"
     elif k == "k_col_inv3":
         return "k_col_inv(split)"
     elif k == "k_col_fwd":
