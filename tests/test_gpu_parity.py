@@ -955,16 +955,16 @@ def test_stockham_row_pass_fallback(monkeypatch):
     assert np.array_equal(lag_d, lag_o) and np.abs(pk_d - pk_o).max() <= MAG_TOL * pk_o.max()
 
 
-@pytest.mark.parametrize("nchips,remote", [(100000, 0), (2_500_000, 0), (2_500_000, 1), (1_250_000, 0)])
-def test_band_row_pass_two_forms_agree(monkeypatch, nchips, remote):
+@pytest.mark.parametrize("bitlen,taps,nchips,remote", [(19, 39, 524288, 0), (22, 3, 2_500_000, 0), (22, 3, 2_500_000, 1), (22, 3, 1_250_000, 0)])
+def test_band_row_pass_two_forms_agree(monkeypatch, bitlen, taps, nchips, remote):
     """The carrier search's row pass in fp32 with a narrow band runs k_rowd_bandsum (sums over the workgroup's threads, no row in LDS;
-    rows of 4000 and 8000 points); TWX_BANDSUM=0 selects k_rowd<BAND> with its pruned last stage.  Same peak bin for every window — a tone
+    rows of 4096 (a plug-in plan, R0 = 16), 8000 and 4000 points); TWX_BANDSUM=0 selects k_rowd<BAND> with its pruned last stage.  Same peak bin for every window — a tone
     inside the near band (godual_ranging.m:83-84) and inside the remote band (:86-89, other digit pairs) — hence byte-identical records,
     and the bin is the oracle's."""
     import torch
     lib = L.load()
     dev = torch.device("cuda", 0)
-    chips = chips_for(22 if nchips > 1_000_000 else 17, 3 if nchips > 1_000_000 else 9, nchips)
+    chips = chips_for(bitlen, taps, nchips)
     n = 2 * nchips
     nwin = 6
     iq = torch.empty((nwin, n, 2), dtype=torch.int16, device=dev)
@@ -991,7 +991,7 @@ def test_band_row_pass_two_forms_agree(monkeypatch, nchips, remote):
     for w in range(nwin):
         assert abs(recs[w].df - dfs[w]) <= 0.51 * FS / n, (w, recs[w].df, dfs[w])      # df = half the d^2 peak's frequency: 1-bin grid of fs/n
         assert int(recs[w].indice0) == 3 * (4321 + w)
-    if nchips <= 100000:                                             # the oracle's own search (fft(d.^2) over the band) on every window
+    if nchips <= 524288:                                             # the oracle's own search (fft(d.^2) over the band) on every window
         freq = orc.freq_axis(FS, n)
         k = orc.band_godual(freq, remote=remote)
         for w in range(nwin):

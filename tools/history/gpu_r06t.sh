@@ -1,0 +1,4 @@
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r06t; rm -rf $O; mkdir -p $O
+timeout 900 python3 -m pytest tests/test_gpu_parity.py -x -q -k "two_forms" 2>&1 | tail -15 | tee $O/pytest.txt
