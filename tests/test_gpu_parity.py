@@ -999,6 +999,45 @@ def test_band_row_pass_two_forms_agree(monkeypatch, bitlen, taps, nchips, remote
             assert abs(recs[w].df - orc.coarse_df(d - d.mean(), k, freq)[1]) < 1e-9
 
 
+@pytest.mark.parametrize("bitlen,taps,nchips", [(22, 3, 2_500_000), (22, 3, 1_250_000)])
+def test_band_row_pass_two_forms_agree_on_random_bands(monkeypatch, bitlen, taps, nchips):
+    """Random search bands — one bin wide to 200 kHz wide, anywhere on the axis, around a tone or over noise only — through both forms of the
+    row pass: up to 8 digit pairs take k_rowd_bandsum, wider bands fall back to k_rowd<BAND> inside the library, and the records agree byte
+    for byte either way (noise-only windows included: the arg-max of a few hundred thousand noise bins)."""
+    import torch
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    chips = chips_for(bitlen, taps, nchips)
+    n = 2 * nchips
+    nwin = 4
+    rng = np.random.default_rng(int(os.environ.get("TWX_SWEEP_SEED", "0")) + nchips)
+    iq = torch.empty((nwin, n, 2), dtype=torch.int16, device=dev)
+    cd = torch.from_numpy(chips).to(dev)
+    tones = [float(rng.uniform(-9e4, 9e4)) for _ in range(nwin)]
+    for w in range(nwin):
+        p = synth.SynthParams(delay_q8=(777 + w) * 256, fstep=synth.fstep_for_df(tones[w], FS), phi0=w, amp=300 if w != 2 else 0,
+                              noise_gain=synth.noise_gain_for_sigma(300.0), seed=90 + w)
+        params = np.array([p.delay_q8, p.fstep, p.phi0, p.amp, p.noise_gain, p.seed, p.stream, 0], dtype=np.int64)
+        L.check(lib.twx_synth_capture_dev(iq[w].data_ptr(), n, 0, cd.data_ptr(), nchips, 2, 1, params.ctypes.data_as(C.c_void_p), None))
+    torch.cuda.synchronize()
+    RB = C.sizeof(L.twx_result)
+    ntrial = 24
+    with Correlator(chips, fs=FS, Nint=1) as cor:
+        for t in range(ntrial):
+            width = int(10 ** rng.uniform(0, np.log10(0.04 * n)))                      # bins of the fftshifted axis
+            centre = n // 2 + int(round(2 * tones[t % nwin] * n / FS)) if t % 3 else int(rng.integers(width, n - width))
+            lo = int(np.clip(centre - width // 2, 0, n - 1)); hi = int(np.clip(lo + width, lo, n - 1))
+            band = L.twx_band(lo, hi)
+            out = {}
+            for form in ("1", "0"):
+                monkeypatch.setenv("TWX_BANDSUM", form)
+                res = torch.zeros((nwin, RB), dtype=torch.uint8, device=dev)
+                L.check(lib.twx_process_windows_dev(cor._h, iq.data_ptr(), nwin, 1, 0, C.byref(band), None, res.data_ptr()), cor._h)
+                cor.synchronize()
+                out[form] = res.cpu().numpy()
+            assert out["1"].tobytes() == out["0"].tobytes(), (t, lo, hi)
+
+
 def test_host_pipeline_many_chunks_per_window_df():
     """twx_process_windows through the pinned pipeline: more chunks than slots, a ragged tail, per-window df."""
     nchips, n, nwin = 10000, 20000, 64 * 3 + 64 + 5              # batch 64: 4 full chunks + a 5-window tail
