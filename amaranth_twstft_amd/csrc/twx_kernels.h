@@ -1713,7 +1713,8 @@ __global__ __launch_bounds__(256) void k_chk_verdict(const float* __restrict__ r
 // is a sum over the workgroup's threads for each of the few kappa: R0 products per thread and kappa, summed over the wave by a
 // reduce-scatter on v_permlane32_swap / v_permlane16_swap (each halves the values a lane carries) and DPP inside the rows of 16 lanes,
 // over the waves through 9 KB of LDS.  k_rowd<BAND> holds the 64-KB row in LDS (two workgroups per CU, each waiting for its row, then
-// computing: 3.5 TB/s); this form keeps ~19 KB and 80 registers, so three workgroups per CU have their rows in flight.
+// computing: 3.5 TB/s); this form keeps 15 KB: with two tasks per thread (the default: 256 threads, 124 registers) four workgroups per CU have
+// their rows in flight (4.6 TB/s; one task per thread: 71 registers, three workgroups, slower — the reduction is the larger half of the arithmetic).
 // fp32, even R0; everything else takes k_rowd<BAND>.  (Complex double was built and dropped: a thread's 20 values are 80 registers before the
 // butterfly's temporaries — one task per thread spilled 136 registers at the 128 that two workgroups per CU allow, two tasks 149 at 256 — and
 // with ONE workgroup per CU, which is what k_rowd<BAND, double> has, the row's wait is not hidden either way; profiles/r06_colinv.txt item 7.)
