@@ -41,3 +41,14 @@ def test_dominant_kernel_keeps_its_register_and_lds_budget():
     assert mid, "the fp32 middle pass of the 8000-point row is not in the library"
     for r in mid:
         assert r["vgpr"] <= 128 and r["lds"] <= 81920 and r["vgpr_spill"] == 0, r
+
+
+def test_band_sum_row_pass_keeps_four_workgroups_per_cu():
+    """k_rowd_bandsum<Plan<8000,20,20,20>, float, 2> (the carrier search's row pass without the row in LDS): four workgroups of four waves per CU
+    need <= 128 VGPRs; its point is the small LDS footprint (<= 20 KB).  The 4000-point form exists as well."""
+    rows, _ = _rows()
+    bs = {n: [r for r in rows if r["kernel"].startswith("_ZN3twx14k_rowd_bandsumINS_4PlanILi%dE" % n)] for n in (8000, 4000)}
+    assert bs[8000] and bs[4000], "k_rowd_bandsum is not in the library"
+    for n in bs:
+        for r in bs[n]:
+            assert r["vgpr"] <= 128 and r["lds"] <= 20480 and r["vgpr_spill"] == 0 and r["scratch"] == 0, r
